@@ -1,0 +1,526 @@
+"""CPU oracle for the DDSP additive-synthesis hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy restatement, op for op, of the reference's
+`ddsp/core.py`, `ddsp/synths.py` and `ddsp/processors.py` for the one path this
+repository accelerates (synths.Harmonic + synths.FilteredNoise + processors.Add).
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it; the product package `ddsp_amd` never does (it fails loudly when
+the HIP library is missing).
+
+Pinning status
+--------------
+* The reference itself cannot run here (TensorFlow / gin are not installed), so
+  there is no output of real TensorFlow to compare with.
+* What IS pinned: `tests/golden/*.npz` are produced by executing the reference's
+  own `ddsp/core.py` / `ddsp/synths.py` source files, unmodified, on top of a
+  numpy stand-in for the dozen TensorFlow ops they call
+  (`tests/golden/make_golden.py`, `tests/golden/tf_numpy_shim.py`).  Those vectors
+  pin this restatement's index math, crops, windows, masks and op order against
+  the reference code; the TF op semantics themselves come from SURVEY.md
+  Appendix A (TF <= 2.11 behaviour) and are restated in the shim and here.
+* The reference's own known-answer tests for the path (fft_convolve vs scipy,
+  group-delay identity, IR sizes, Nyquist silence, resample sub-sampling,
+  ValueErrors) are re-expressed in `tests/test_oracle.py`.
+* Oscillator numerics vs real TensorFlow: PARITY UNPINNED (the reference's three
+  "is_accurate" oscillator tests compare empty slices).
+
+Two arithmetic modes share one code path (`dtype` argument):
+  np.float32  "faithful": same op order TF executes, sequential cumsum, no FMA.
+  np.float64  "truth":    same formulas in double precision.
+All tensors are row-major [batch, time, channel], as in the reference.
+"""
+
+import numpy as np
+
+TWO_PI = 2.0 * np.pi
+
+
+# ----------------------------------------------------------------------------
+# Utilities / scaling   (ddsp/core.py:31-36, 207-210, 386-404)
+# ----------------------------------------------------------------------------
+def as_float(x, dtype=np.float32):
+  """core.tf_float32 (core.py:31-36): convert anything to a float array."""
+  return np.asarray(x, dtype=dtype)
+
+
+def safe_divide(numerator, denominator, eps=1e-7):
+  """core.safe_divide (core.py:207-210): zero denominators become eps."""
+  dt = numerator.dtype
+  safe_denominator = np.where(denominator == 0.0, dt.type(eps), denominator)
+  return numerator / safe_denominator
+
+
+def sigmoid(x):
+  """tf.nn.sigmoid: 1/(1+exp(-x)), computed in x's dtype (stable both tails)."""
+  dt = x.dtype
+  e = np.exp(-np.abs(x))
+  return np.where(x >= 0, dt.type(1) / (dt.type(1) + e), e / (dt.type(1) + e))
+
+
+def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7, dtype=np.float32):
+  """core.exp_sigmoid (core.py:386-404): max_value*sigmoid(x)**log(exponent)+thr."""
+  x = as_float(x, dtype)
+  dt = x.dtype.type
+  return dt(max_value) * sigmoid(x)**dt(np.log(exponent)) + dt(threshold)
+
+
+# ----------------------------------------------------------------------------
+# Resampling   (ddsp/core.py:573-714)
+# ----------------------------------------------------------------------------
+def resize_bilinear_legacy(x, n_out, align_corners=False):
+  """tf.compat.v1.image.resize(BILINEAR) on the time axis of x[B, F, C].
+
+  Legacy kernel, no half-pixel centres: scale is computed
+  in fp32, pos = t*scale (fp32), lo=floor, hi=min(ceil, F-1), lerp=pos-lo,
+  out = top + (bottom - top) * lerp.  Index math is fp32 in both modes (that is
+  what TF does); only the value arithmetic follows x.dtype.
+  """
+  dt = x.dtype.type
+  n_in = x.shape[1]
+  if align_corners and n_out > 1:
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1)
+  else:
+    scale = np.float32(n_in) / np.float32(n_out)
+  pos = np.arange(n_out, dtype=np.float32) * scale            # fp32 product
+  lo = np.floor(pos)
+  hi = np.minimum(np.ceil(pos), np.float32(n_in - 1))
+  lerp = (pos - lo).astype(np.float32)
+  lo_i, hi_i = lo.astype(np.int64), hi.astype(np.int64)
+  top, bottom = x[:, lo_i, :], x[:, hi_i, :]
+  return top + (bottom - top) * lerp.astype(x.dtype)[None, :, None].astype(dt)
+
+
+def hann_window_periodic(n, dtype=np.float32):
+  """tf.signal.hann_window(n) (periodic=True): 0.5 - 0.5*cos(2*pi*i/n)."""
+  i = np.arange(n, dtype=np.float64)
+  return (0.5 - 0.5 * np.cos(TWO_PI * i / n)).astype(dtype)
+
+
+def overlap_and_add(frames, step):
+  """tf.signal.overlap_and_add(frames[..., F, L], step) -> [..., (F-1)*step+L]."""
+  n_frames, length = frames.shape[-2], frames.shape[-1]
+  out = np.zeros(frames.shape[:-2] + ((n_frames - 1) * step + length,), frames.dtype)
+  for f in range(n_frames):  # plain summation in frame order
+    out[..., f * step:f * step + length] += frames[..., f, :]
+  return out
+
+
+def upsample_with_windows(inputs, n_timesteps, add_endpoint=True, dtype=np.float32):
+  """core.upsample_with_windows (core.py:645-714), literal Hann overlap-add."""
+  inputs = as_float(inputs, dtype)
+  if inputs.ndim != 3:
+    raise ValueError('Upsample_with_windows() only supports 3 dimensions, '
+                     'not {}.'.format(inputs.shape))
+  if add_endpoint:
+    inputs = np.concatenate([inputs, inputs[:, -1:, :]], axis=1)
+  n_frames = int(inputs.shape[1])
+  n_intervals = n_frames - 1
+  if n_frames >= n_timesteps:
+    raise ValueError('Upsample with windows cannot be used for downsampling'
+                     'More input frames ({}) than output timesteps ({})'.format(
+                         n_frames, n_timesteps))
+  if n_timesteps % n_intervals != 0.0:
+    minus_one = '' if add_endpoint else ' - 1'
+    raise ValueError(
+        'For upsampling, the target the number of timesteps must be divisible '
+        'by the number of input frames{}. (timesteps:{}, frames:{}, '
+        'add_endpoint={}).'.format(minus_one, n_timesteps, n_frames, add_endpoint))
+  hop_size = n_timesteps // n_intervals
+  window = hann_window_periodic(2 * hop_size, dtype)
+  x = np.transpose(inputs, (0, 2, 1))                # [B, C, F]
+  x_windowed = x[:, :, :, None] * window[None, None, None, :]
+  x = overlap_and_add(x_windowed, hop_size)
+  x = np.transpose(x, (0, 2, 1))                     # [B, T, C]
+  return x[:, hop_size:-hop_size, :]
+
+
+def upsample_with_windows_closed_form(inputs, n_timesteps, dtype=np.float32):
+  """Raised-cosine interpolation identical to upsample_with_windows(add_endpoint=True).
+
+  out[t] = x[j]*w[hop+r] + x[j+1]*w[r], j=t//hop, r=t%hop, x[F]=x[F-1]
+  (SURVEY F7a).  This is the form the HIP kernel evaluates.
+  """
+  x = as_float(inputs, dtype)
+  n_frames = x.shape[1]
+  hop = n_timesteps // n_frames
+  w = hann_window_periodic(2 * hop, dtype)
+  xe = np.concatenate([x, x[:, -1:, :]], axis=1)
+  t = np.arange(n_timesteps)
+  j, r = t // hop, t % hop
+  return xe[:, j, :] * w[hop + r][None, :, None] + xe[:, j + 1, :] * w[r][None, :, None]
+
+
+def resample(inputs, n_timesteps, method='linear', add_endpoint=True, dtype=np.float32):
+  """core.resample (core.py:573-642) for 1-D..3-D inputs ('linear' and 'window')."""
+  inputs = as_float(inputs, dtype)
+  is_1d, is_2d = inputs.ndim == 1, inputs.ndim == 2
+  if is_1d:
+    inputs = inputs[None, :, None]
+  elif is_2d:
+    inputs = inputs[:, :, None]
+  if method == 'linear':
+    outputs = resize_bilinear_legacy(inputs, n_timesteps, align_corners=not add_endpoint)
+  elif method == 'window':
+    outputs = upsample_with_windows(inputs, n_timesteps, add_endpoint, dtype)
+  elif method in ('nearest', 'cubic'):
+    raise NotImplementedError("oracle restates only 'linear' and 'window'")
+  else:
+    raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+        method, "['nearest', 'linear', 'cubic', 'window']"))
+  if is_1d:
+    outputs = outputs[0, :, 0]
+  elif is_2d:
+    outputs = outputs[:, :, 0]
+  return outputs
+
+
+# ----------------------------------------------------------------------------
+# Oscillator bank   (ddsp/core.py:800-962, 1028-1111)
+# ----------------------------------------------------------------------------
+def angular_cumsum(angular_frequency, chunk_size=1000):
+  """core.angular_cumsum (core.py:800-866): chunked cumsum with mod-2pi stitching."""
+  x = angular_frequency
+  dt = x.dtype.type
+  n_batch, n_time = x.shape[0], x.shape[1]
+  ch_shape = x.shape[2:]
+  remainder = n_time % chunk_size
+  if remainder:
+    pad = [(0, 0), (0, chunk_size - remainder)] + [(0, 0)] * len(ch_shape)
+    x = np.pad(x, pad)
+  length = x.shape[1]
+  n_chunks = length // chunk_size
+  chunks = x.reshape((n_batch, n_chunks, chunk_size) + ch_shape)
+  phase = np.cumsum(chunks, axis=2, dtype=x.dtype)
+  two_pi = dt(TWO_PI)
+  offsets = np.mod(phase[:, :, -1:, ...], two_pi)
+  offsets = np.concatenate([np.zeros_like(offsets[:, :1]), offsets], axis=1)[:, :-1]
+  offsets = np.mod(np.cumsum(offsets, axis=1, dtype=x.dtype), two_pi)
+  phase = phase + offsets
+  phase = np.mod(phase, two_pi)
+  phase = phase.reshape((n_batch, length) + ch_shape)
+  if remainder:
+    phase = phase[:, :n_time]
+  return phase
+
+
+def remove_above_nyquist(frequency_envelopes, amplitude_envelopes, sample_rate=16000):
+  """core.remove_above_nyquist (core.py:869-891): amp=0 where f >= sr/2."""
+  dt = amplitude_envelopes.dtype.type
+  return np.where(frequency_envelopes >= dt(sample_rate / 2.0),
+                  np.zeros_like(amplitude_envelopes), amplitude_envelopes)
+
+
+def get_harmonic_frequencies(frequencies, n_harmonics):
+  """core.get_harmonic_frequencies (core.py:1028-1045): f0 * [1..K]."""
+  f_ratios = np.linspace(1.0, float(n_harmonics), int(n_harmonics)).astype(frequencies.dtype)
+  return frequencies * f_ratios[None, None, :]
+
+
+def normalize_harmonics(harmonic_distribution, f0_hz=None, sample_rate=None):
+  """core.normalize_harmonics (core.py:894-907)."""
+  if sample_rate is not None and f0_hz is not None:
+    n_harmonics = int(harmonic_distribution.shape[-1])
+    harmonic_frequencies = get_harmonic_frequencies(f0_hz, n_harmonics)
+    harmonic_distribution = remove_above_nyquist(
+        harmonic_frequencies, harmonic_distribution, sample_rate)
+  return safe_divide(harmonic_distribution,
+                     np.sum(harmonic_distribution, axis=-1, keepdims=True,
+                            dtype=harmonic_distribution.dtype))
+
+
+def oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=16000,
+                    sum_sinusoids=True, use_angular_cumsum=False):
+  """core.oscillator_bank (core.py:912-962). dtype follows the inputs."""
+  dt = frequency_envelopes.dtype.type
+  amplitude_envelopes = remove_above_nyquist(frequency_envelopes, amplitude_envelopes,
+                                             sample_rate)
+  omegas = frequency_envelopes * dt(TWO_PI)
+  omegas = omegas / dt(float(sample_rate))
+  if use_angular_cumsum:
+    phases = angular_cumsum(omegas)
+  else:
+    # numpy's cumsum along a non-contiguous axis is a strict sequential scan in
+    # the array dtype: the TF-CPU (Eigen scan) order assumed in SURVEY Appendix A.
+    phases = np.cumsum(omegas, axis=1, dtype=omegas.dtype)
+  wavs = np.sin(phases)
+  audio = amplitude_envelopes * wavs
+  if sum_sinusoids:
+    audio = np.sum(audio, axis=-1, dtype=audio.dtype)
+  return audio
+
+
+def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
+                       harmonic_distribution=None, n_samples=64000, sample_rate=16000,
+                       amp_resample_method='window', use_angular_cumsum=False,
+                       dtype=np.float32):
+  """core.harmonic_synthesis (core.py:1048-1111)."""
+  frequencies = as_float(frequencies, dtype)
+  amplitudes = as_float(amplitudes, dtype)
+  if harmonic_distribution is not None:
+    harmonic_distribution = as_float(harmonic_distribution, dtype)
+    n_harmonics = int(harmonic_distribution.shape[-1])
+  elif harmonic_shifts is not None:
+    harmonic_shifts = as_float(harmonic_shifts, dtype)
+    n_harmonics = int(harmonic_shifts.shape[-1])
+  else:
+    n_harmonics = 1
+  harmonic_frequencies = get_harmonic_frequencies(frequencies, n_harmonics)
+  if harmonic_shifts is not None:
+    harmonic_frequencies = harmonic_frequencies * (dtype(1.0) + harmonic_shifts)
+  if harmonic_distribution is not None:
+    harmonic_amplitudes = amplitudes * harmonic_distribution
+  else:
+    harmonic_amplitudes = amplitudes
+  frequency_envelopes = resample(harmonic_frequencies, n_samples, dtype=dtype)
+  amplitude_envelopes = resample(harmonic_amplitudes, n_samples,
+                                 method=amp_resample_method, dtype=dtype)
+  return oscillator_bank(frequency_envelopes, amplitude_envelopes,
+                         sample_rate=sample_rate, use_angular_cumsum=use_angular_cumsum)
+
+
+# ----------------------------------------------------------------------------
+# Time-varying FIR   (ddsp/core.py:1317-1565, 1628-1655)
+# ----------------------------------------------------------------------------
+def get_fft_size(frame_size, ir_size, power_of_2=True):
+  """core.get_fft_size (core.py:1317-1335), power-of-two branch only."""
+  convolved_frame_size = ir_size + frame_size - 1
+  if not power_of_2:
+    raise NotImplementedError('the hot path always uses power_of_2=True')
+  return int(2**np.ceil(np.log2(convolved_frame_size)))
+
+
+def crop_and_compensate_delay(audio, audio_size, ir_size, padding, delay_compensation):
+  """core.crop_and_compensate_delay (core.py:1338-1379)."""
+  if padding == 'valid':
+    crop_size = ir_size + audio_size - 1
+  elif padding == 'same':
+    crop_size = audio_size
+  else:
+    raise ValueError('Padding must be \'valid\' or \'same\', instead '
+                     'of {}.'.format(padding))
+  total_size = int(audio.shape[-1])
+  crop = total_size - crop_size
+  start = ((ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation)
+  end = crop - start
+  return audio[:, start:-end]
+
+
+def frame_pad_end(audio, frame_size, hop_size):
+  """tf.signal.frame(audio[B,N], frame, hop, pad_end=True) -> [B, ceil(N/hop), frame]."""
+  n = audio.shape[-1]
+  n_frames = -(-n // hop_size)
+  padded_len = (n_frames - 1) * hop_size + frame_size
+  padded = np.zeros(audio.shape[:-1] + (padded_len,), audio.dtype)
+  padded[..., :n] = audio
+  idx = np.arange(n_frames)[:, None] * hop_size + np.arange(frame_size)[None, :]
+  return padded[..., idx]
+
+
+def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1,
+                 dtype=np.float32):
+  """core.fft_convolve (core.py:1382-1473): framed FFT convolution + overlap-add."""
+  audio, impulse_response = as_float(audio, dtype), as_float(impulse_response, dtype)
+  batch_size, audio_size = audio.shape
+  ir_shape = impulse_response.shape
+  if len(ir_shape) == 2:
+    impulse_response = impulse_response[:, None, :]
+  if ir_shape[0] == 1 and batch_size > 1:
+    impulse_response = np.tile(impulse_response, [batch_size, 1, 1])
+  batch_size_ir, n_ir_frames, ir_size = impulse_response.shape
+  if batch_size != batch_size_ir:
+    raise ValueError('Batch size of audio ({}) and impulse response ({}) must '
+                     'be the same.'.format(batch_size, batch_size_ir))
+  frame_size = int(np.ceil(audio_size / n_ir_frames))
+  hop_size = frame_size
+  audio_frames = frame_pad_end(audio, frame_size, hop_size)
+  n_audio_frames = int(audio_frames.shape[1])
+  if n_audio_frames != n_ir_frames:
+    raise ValueError(
+        'Number of Audio frames ({}) and impulse response frames ({}) do not '
+        'match. For small hop size = ceil(audio_size / n_ir_frames), '
+        'number of impulse response frames must be a multiple of the audio '
+        'size.'.format(n_audio_frames, n_ir_frames))
+  fft_size = get_fft_size(frame_size, ir_size, power_of_2=True)
+  audio_fft = np.fft.rfft(audio_frames, fft_size)      # complex64 for fp32 input
+  ir_fft = np.fft.rfft(impulse_response, fft_size)
+  audio_ir_fft = audio_fft * ir_fft
+  audio_frames_out = np.fft.irfft(audio_ir_fft, fft_size).astype(dtype)
+  audio_out = overlap_and_add(audio_frames_out, hop_size)
+  return crop_and_compensate_delay(audio_out, audio_size, ir_size, padding,
+                                   delay_compensation)
+
+
+def time_varying_fir_direct(audio, impulse_response, delay_compensation=-1,
+                            dtype=np.float64):
+  """Direct-form equivalent of fft_convolve(padding='same').
+
+  z[m] = sum_k x[m-k] * h_{frame(m-k)}[k];  out[n] = z[n + start].
+  The tap set is chosen by the frame of the INPUT sample.  This is the form the
+  HIP kernel evaluates; used to cross-check fft_convolve on small cases.
+  """
+  audio, ir = as_float(audio, dtype), as_float(impulse_response, dtype)
+  if ir.ndim == 2:
+    ir = ir[:, None, :]
+  b, n = audio.shape
+  if ir.shape[0] == 1 and b > 1:
+    ir = np.tile(ir, [b, 1, 1])
+  n_frames, ir_size = ir.shape[1], ir.shape[2]
+  frame_size = int(np.ceil(n / n_frames))
+  z = np.zeros((b, n_frames * frame_size + ir_size - 1), dtype)
+  for i in range(n):
+    z[:, i:i + ir_size] += audio[:, i:i + 1] * ir[:, i // frame_size, :]
+  start = ((ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation)
+  return z[:, start:start + n]
+
+
+def apply_window_to_impulse_response(impulse_response, window_size=0, causal=False,
+                                     dtype=np.float32):
+  """core.apply_window_to_impulse_response (core.py:1477-1531)."""
+  impulse_response = as_float(impulse_response, dtype)
+  if causal:
+    impulse_response = np.fft.fftshift(impulse_response, axes=-1)
+  ir_size = int(impulse_response.shape[-1])
+  if (window_size <= 0) or (window_size > ir_size):
+    window_size = ir_size
+  window = hann_window_periodic(window_size, dtype)
+  padding = ir_size - window_size
+  if padding > 0:
+    half_idx = (window_size + 1) // 2
+    window = np.concatenate([window[half_idx:], np.zeros([padding], dtype),
+                             window[:half_idx]], axis=0)
+  else:
+    window = np.fft.fftshift(window, axes=-1)
+  impulse_response = window * impulse_response
+  if padding > 0:
+    first_half_start = (ir_size - (half_idx - 1)) + 1
+    second_half_end = half_idx + 1
+    impulse_response = np.concatenate([impulse_response[..., first_half_start:],
+                                       impulse_response[..., :second_half_end]], axis=-1)
+  else:
+    impulse_response = np.fft.fftshift(impulse_response, axes=-1)
+  return impulse_response
+
+
+def frequency_impulse_response(magnitudes, window_size=0, dtype=np.float32):
+  """core.frequency_impulse_response (core.py:1534-1565)."""
+  magnitudes = as_float(magnitudes, dtype)
+  ctype = np.complex64 if dtype == np.float32 else np.complex128
+  impulse_response = np.fft.irfft(magnitudes.astype(ctype)).astype(dtype)
+  return apply_window_to_impulse_response(impulse_response, window_size, dtype=dtype)
+
+
+def frequency_filter(audio, magnitudes, window_size=0, padding='same', dtype=np.float32):
+  """core.frequency_filter (core.py:1628-1655)."""
+  impulse_response = frequency_impulse_response(magnitudes, window_size, dtype)
+  return fft_convolve(audio, impulse_response, padding=padding, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------
+# Processors   (ddsp/synths.py:55-196, ddsp/processors.py:37-76, 162-176)
+# ----------------------------------------------------------------------------
+def harmonic_get_controls(amplitudes, harmonic_distribution, f0_hz, sample_rate=16000,
+                          scale_fn=exp_sigmoid, normalize_below_nyquist=True,
+                          dtype=np.float32):
+  """synths.Harmonic.get_controls (synths.py:94-121)."""
+  amplitudes = as_float(amplitudes, dtype)
+  harmonic_distribution = as_float(harmonic_distribution, dtype)
+  f0_hz = as_float(f0_hz, dtype)
+  if scale_fn is not None:
+    amplitudes = scale_fn(amplitudes, dtype=dtype)
+    harmonic_distribution = scale_fn(harmonic_distribution, dtype=dtype)
+  harmonic_distribution = normalize_harmonics(
+      harmonic_distribution, f0_hz, sample_rate if normalize_below_nyquist else None)
+  return {'amplitudes': amplitudes, 'harmonic_distribution': harmonic_distribution,
+          'f0_hz': f0_hz}
+
+
+def harmonic_get_signal(amplitudes, harmonic_distribution, f0_hz, n_samples=64000,
+                        sample_rate=16000, amp_resample_method='window',
+                        use_angular_cumsum=False, dtype=np.float32):
+  """synths.Harmonic.get_signal (synths.py:123-146)."""
+  return harmonic_synthesis(frequencies=f0_hz, amplitudes=amplitudes,
+                            harmonic_distribution=harmonic_distribution,
+                            n_samples=n_samples, sample_rate=sample_rate,
+                            amp_resample_method=amp_resample_method,
+                            use_angular_cumsum=use_angular_cumsum, dtype=dtype)
+
+
+def harmonic(amplitudes, harmonic_distribution, f0_hz, n_samples=64000, sample_rate=16000,
+             scale_fn=exp_sigmoid, normalize_below_nyquist=True,
+             amp_resample_method='window', use_angular_cumsum=False, dtype=np.float32):
+  """Processor.call for Harmonic (processors.py:53-68): get_signal(**get_controls())."""
+  c = harmonic_get_controls(amplitudes, harmonic_distribution, f0_hz, sample_rate,
+                            scale_fn, normalize_below_nyquist, dtype)
+  return harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'],
+                             n_samples, sample_rate, amp_resample_method,
+                             use_angular_cumsum, dtype)
+
+
+def filtered_noise_get_controls(magnitudes, scale_fn=exp_sigmoid, initial_bias=-5.0,
+                                dtype=np.float32):
+  """synths.FilteredNoise.get_controls (synths.py:165-179)."""
+  magnitudes = as_float(magnitudes, dtype)
+  if scale_fn is not None:
+    magnitudes = scale_fn(magnitudes + dtype(initial_bias), dtype=dtype)
+  return {'magnitudes': magnitudes}
+
+
+def filtered_noise_get_signal(magnitudes, noise, window_size=257, dtype=np.float32):
+  """synths.FilteredNoise.get_signal (synths.py:181-196) with the noise supplied.
+
+  The reference draws tf.random.uniform([B, n_samples], -1, 1) from TF's stateful
+  generator, which cannot be reproduced outside TF; parity is therefore defined
+  with the same noise array handed to both implementations.
+  """
+  return frequency_filter(as_float(noise, dtype), magnitudes, window_size=window_size,
+                          dtype=dtype)
+
+
+def filtered_noise(magnitudes, noise, window_size=257, scale_fn=exp_sigmoid,
+                   initial_bias=-5.0, dtype=np.float32):
+  c = filtered_noise_get_controls(magnitudes, scale_fn, initial_bias, dtype)
+  return filtered_noise_get_signal(c['magnitudes'], noise, window_size, dtype)
+
+
+def add(signal_one, signal_two):
+  """processors.Add.get_signal (processors.py:174-176)."""
+  return signal_one + signal_two
+
+
+# ----------------------------------------------------------------------------
+# Device noise generator restated (NOT part of the reference: the reference uses
+# TF's stateful RNG).  Philox4x32-10 (Salmon et al., SC'11), counter =
+# (sample_quad_index, batch_row, 0, 0), key = (seed_lo, seed_hi); word w of the
+# output block is sample 4*quad + w.  u = bits>>9 as a 23-bit mantissa in [1,2),
+# noise = (u - 1) * 2 - 1, i.e. the construction tf.random.uniform uses for fp32.
+# ----------------------------------------------------------------------------
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+  c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) for c in (c0, c1, c2, c3)]
+  k0, k1 = np.uint64(k0), np.uint64(k1)
+  mask = np.uint64(0xFFFFFFFF)
+  for _ in range(10):
+    p0 = c0 * np.uint64(PHILOX_M0)
+    p1 = c2 * np.uint64(PHILOX_M1)
+    hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+    hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+    c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & mask, lo1, (hi0 ^ c3 ^ k1) & mask, lo0
+    k0 = (k0 + np.uint64(PHILOX_W0)) & mask
+    k1 = (k1 + np.uint64(PHILOX_W1)) & mask
+  return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
+
+
+def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0):
+  """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL."""
+  n_quads = -(-n_samples // 4)
+  quad = np.arange(n_quads, dtype=np.uint64)[None, :].repeat(batch_size, 0)
+  row = (np.arange(batch_size, dtype=np.uint64) + np.uint64(batch_offset))[:, None]
+  row = np.broadcast_to(row, quad.shape)
+  words = philox4x32_10(quad, row, np.zeros_like(quad), np.zeros_like(quad),
+                        seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+  bits = np.stack(words, axis=-1).reshape(batch_size, n_quads * 4)[:, :n_samples]
+  u = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32)
+  return (u - np.float32(1.0)) * np.float32(2.0) - np.float32(1.0)

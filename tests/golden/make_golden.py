@@ -1,0 +1,120 @@
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN source files.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+`tf_numpy_shim.install()` makes `ddsp/core.py`, `ddsp/synths.py` and
+`ddsp/processors.py` importable, unmodified, on top of a numpy stand-in for the
+TensorFlow ops they call.  Every array stored below is therefore produced by the
+reference's code (index math, crops, windows, masks, op order) with TF-op semantics
+restated per SURVEY.md Appendix A; it is NOT an output of real TensorFlow.
+The fixtures are small (seconds of CPU) and committed; the GPU box never runs this.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import tf_numpy_shim  # noqa: E402
+
+tf_numpy_shim.install('/root/reference')
+from ddsp import core, processors, synths  # noqa: E402  (the reference's files)
+
+
+def a(x):
+  return np.ascontiguousarray(np.asarray(x))
+
+
+def harmonic_case(seed, batch, n_frames, n_harmonics, n_samples, sample_rate, f0_lo, f0_hi,
+                  amp_method, angular, scale=True, normalize=True):
+  rng = np.random.default_rng(seed)
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, n_harmonics)).astype(np.float32)
+  f0 = rng.uniform(f0_lo, f0_hi, (batch, n_frames, 1)).astype(np.float32)
+  if not scale:  # controls must then already be positive
+    amps, hd = np.abs(amps) + 0.1, np.abs(hd) + 0.01
+  synth = synths.Harmonic(n_samples=n_samples, sample_rate=sample_rate,
+                          scale_fn=core.exp_sigmoid if scale else None,
+                          normalize_below_nyquist=normalize,
+                          amp_resample_method=amp_method, use_angular_cumsum=angular)
+  out = synth(amps, hd, f0, return_outputs_dict=True)
+  return dict(
+      amplitudes=amps, harmonic_distribution=hd, f0_hz=f0,
+      n_samples=n_samples, sample_rate=sample_rate, amp_method=amp_method,
+      angular=int(angular), scale=int(scale), normalize=int(normalize),
+      ctl_amplitudes=a(out['controls']['amplitudes']),
+      ctl_harmonic_distribution=a(out['controls']['harmonic_distribution']),
+      signal=a(out['signal']))
+
+
+def noise_case(seed, batch, n_frames, n_bands, n_samples, window_size, scale=True):
+  rng = np.random.default_rng(seed)
+  mags = rng.standard_normal((batch, n_frames, n_bands)).astype(np.float32)
+  if not scale:
+    mags = np.abs(mags)
+  noise = rng.uniform(-1.0, 1.0, (batch, n_samples)).astype(np.float32)
+  synth = synths.FilteredNoise(n_samples=n_samples, window_size=window_size,
+                               scale_fn=core.exp_sigmoid if scale else None)
+  controls = synth.get_controls(mags)
+  # get_signal draws its own tf.random.uniform; inject the noise through the same
+  # core.frequency_filter call get_signal makes (synths.py:192-196).
+  ir = core.frequency_impulse_response(controls['magnitudes'], window_size=window_size)
+  signal = core.frequency_filter(noise, controls['magnitudes'], window_size=window_size)
+  return dict(magnitudes=mags, noise=noise, n_samples=n_samples, window_size=window_size,
+              scale=int(scale), ctl_magnitudes=a(controls['magnitudes']),
+              impulse_response=a(ir), signal=a(signal))
+
+
+def main():
+  cases = {}
+  # --- Harmonic: hop 64 (the canonical hop), some harmonics crossing Nyquist ---
+  cases['harmonic_window_cumsum'] = harmonic_case(
+      1, 2, 25, 12, 1600, 16000, 300.0, 900.0, 'window', False)
+  cases['harmonic_window_angular'] = harmonic_case(
+      2, 2, 25, 12, 1600, 16000, 300.0, 900.0, 'window', True)
+  cases['harmonic_linear_cumsum'] = harmonic_case(
+      3, 2, 25, 12, 1600, 16000, 100.0, 400.0, 'linear', False)
+  # all 100 harmonics live (the headline regime), short clip
+  cases['harmonic_k100_live'] = harmonic_case(
+      4, 1, 20, 100, 1280, 16000, 69.0, 71.0, 'window', False)
+  # hop 192 (48 kHz / 250 Hz): non power-of-two hop, K=40, angular (vst_48k.gin)
+  cases['harmonic_hop192_angular'] = harmonic_case(
+      5, 1, 10, 40, 1920, 48000, 200.0, 700.0, 'linear', True)
+  # scale_fn=None and normalize_below_nyquist=False (synths_test.py:26-30 style)
+  cases['harmonic_noscale_nonorm'] = harmonic_case(
+      6, 2, 16, 20, 1024, 16000, 350.0, 600.0, 'window', False, scale=False,
+      normalize=False)
+  # --- FilteredNoise ---
+  cases['noise_m65_w257'] = noise_case(11, 2, 25, 65, 1600, 257)      # ae.gin shape
+  cases['noise_m65_w0'] = noise_case(12, 2, 25, 65, 1600, 0)
+  cases['noise_m33_w17'] = noise_case(13, 2, 10, 33, 640, 17)         # cropped IR branch
+  cases['noise_m17_w16_even'] = noise_case(14, 1, 8, 17, 512, 16)     # even window -> 15 taps
+  cases['noise_ragged'] = noise_case(15, 2, 7, 9, 100, 0, scale=False)  # N % F != 0 (pad_end)
+
+  # --- resampling pieces on their own ---
+  rng = np.random.default_rng(21)
+  x = rng.standard_normal((2, 9, 3)).astype(np.float32)
+  cases['resample'] = dict(
+      x=x,
+      window_576=a(core.resample(x, 576, method='window')),
+      linear_576=a(core.resample(x, 576, method='linear')),
+      linear_1728=a(core.resample(x, 1728, method='linear')),   # hop 192
+      linear_900=a(core.resample(x, 900, method='linear')))     # hop 100
+  # --- Add ---
+  s1 = rng.standard_normal((2, 64)).astype(np.float32)
+  s2 = rng.standard_normal((2, 64)).astype(np.float32)
+  cases['add'] = dict(signal_one=s1, signal_two=s2, signal=a(processors.Add()(s1, s2)))
+
+  for name, d in cases.items():
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
+    print('wrote', os.path.relpath(path), {k: np.asarray(v).shape for k, v in d.items()
+                                            if np.asarray(v).ndim})
+
+
+if __name__ == '__main__':
+  main()

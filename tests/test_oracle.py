@@ -1,0 +1,184 @@
+"""CPU tests of the oracle: golden vectors made by the reference's own source files,
+the reference's known-answer tests re-expressed, and the closed
+forms the HIP kernels rely on."""
+import numpy as np
+import pytest
+import scipy.signal
+
+from oracle import ddsp_oracle as O
+from conftest import load_golden
+
+HARMONIC_CASES = ['harmonic_window_cumsum', 'harmonic_window_angular',
+                  'harmonic_linear_cumsum', 'harmonic_k100_live',
+                  'harmonic_hop192_angular', 'harmonic_noscale_nonorm']
+NOISE_CASES = ['noise_m65_w257', 'noise_m65_w0', 'noise_m33_w17', 'noise_m17_w16_even',
+               'noise_ragged']
+
+
+# ---- golden vectors (reference source on the numpy TF stand-in) -----------------
+@pytest.mark.parametrize('name', HARMONIC_CASES)
+def test_harmonic_matches_reference_source(name):
+  g = load_golden(name)
+  scale_fn = O.exp_sigmoid if int(g['scale']) else None
+  c = O.harmonic_get_controls(g['amplitudes'], g['harmonic_distribution'], g['f0_hz'],
+                              int(g['sample_rate']), scale_fn, bool(g['normalize']))
+  np.testing.assert_allclose(c['amplitudes'], g['ctl_amplitudes'], rtol=1e-6, atol=1e-9)
+  np.testing.assert_allclose(c['harmonic_distribution'], g['ctl_harmonic_distribution'],
+                             rtol=1e-6, atol=1e-9)
+  sig = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'],
+                              int(g['n_samples']), int(g['sample_rate']),
+                              str(g['amp_method']), bool(g['angular']))
+  assert sig.dtype == np.float32 and sig.shape == g['signal'].shape
+  np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', NOISE_CASES)
+def test_filtered_noise_matches_reference_source(name):
+  g = load_golden(name)
+  scale_fn = O.exp_sigmoid if int(g['scale']) else None
+  c = O.filtered_noise_get_controls(g['magnitudes'], scale_fn)
+  np.testing.assert_allclose(c['magnitudes'], g['ctl_magnitudes'], rtol=1e-6, atol=1e-9)
+  ir = O.frequency_impulse_response(c['magnitudes'], int(g['window_size']))
+  assert ir.shape == g['impulse_response'].shape
+  np.testing.assert_allclose(ir, g['impulse_response'], rtol=0, atol=1e-7)
+  sig = O.filtered_noise_get_signal(c['magnitudes'], g['noise'], int(g['window_size']))
+  np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=1e-6)
+
+
+def test_resample_matches_reference_source():
+  g = load_golden('resample')
+  np.testing.assert_array_equal(O.resample(g['x'], 576, 'window'), g['window_576'])
+  for n in (576, 1728, 900):
+    np.testing.assert_array_equal(O.resample(g['x'], n, 'linear'), g['linear_%d' % n])
+
+
+def test_add_matches_reference_source():
+  g = load_golden('add')
+  np.testing.assert_array_equal(O.add(g['signal_one'], g['signal_two']), g['signal'])
+
+
+# ---- closed forms the kernels evaluate -------------------------------
+def test_window_upsample_closed_form():
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((2, 11, 5))
+  lit = O.upsample_with_windows(x, 11 * 48, dtype=np.float64)
+  cf = O.upsample_with_windows_closed_form(x, 11 * 48, dtype=np.float64)
+  np.testing.assert_allclose(cf, lit, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize('n,f,m,ws', [(3200, 50, 65, 0), (640, 10, 33, 17), (100, 7, 9, 0)])
+def test_fft_convolve_equals_direct_time_varying_fir(n, f, m, ws):
+  rng = np.random.default_rng(1)
+  mags = np.abs(rng.standard_normal((2, f, m)))
+  noise = rng.uniform(-1, 1, (2, n))
+  ir = O.frequency_impulse_response(mags, ws, dtype=np.float64)
+  lit = O.fft_convolve(noise, ir, dtype=np.float64)
+  direct = O.time_varying_fir_direct(noise, ir)
+  np.testing.assert_allclose(direct, lit, rtol=0, atol=1e-12)
+
+
+def test_all_ones_magnitudes_is_a_two_sample_delay():
+  """M=65, window 0: L=128, peak 64, crop 62 -> the reference delays by 2 (F7c)."""
+  x = np.random.default_rng(2).uniform(-1, 1, (1, 640))
+  y = O.frequency_filter(x, np.ones((1, 10, 65)), window_size=0, dtype=np.float64)
+  np.testing.assert_allclose(y[:, 2:], x[:, :-2], atol=1e-12)
+  np.testing.assert_allclose(y[:, :2], 0.0, atol=1e-12)
+
+
+def test_constant_f0_single_harmonic_known_answer():
+  """cumsum is inclusive: sample t has phase 2*pi*f*(t+1)/sr."""
+  sr, n, f = 16000, 640, 440.0
+  sig = O.harmonic_get_signal(np.ones((1, 10, 1)), np.ones((1, 10, 1)),
+                              np.full((1, 10, 1), f), n, sr, dtype=np.float64)
+  t = np.arange(n)
+  np.testing.assert_allclose(sig[0], np.sin(2 * np.pi * f * (t + 1) / sr), atol=1e-9)
+
+
+# ---- the reference's own known-answer tests, re-expressed -------------------------
+@pytest.mark.parametrize('audio_size,ir_size', [(1000, 10), (10, 100)])
+def test_fft_convolve_is_accurate(audio_size, ir_size):            # core_test.py:730-757
+  audio, ir = np.ones([1, audio_size], np.float32), np.ones([1, 1, ir_size], np.float32)
+  out = O.fft_convolve(audio, ir, padding='valid', delay_compensation=0)[0]
+  target = scipy.signal.fftconvolve(audio[0], ir[0, 0], mode='full')
+  assert np.abs(target - out).mean() <= 1e-3
+
+
+@pytest.mark.parametrize('gain', [1.0, 0.1])
+def test_delay_compensation_corrects_group_delay(gain):             # core_test.py:759-785
+  n = 4 * 1024
+  audio = np.sin(np.linspace(0, 200.0, n))[None, :].astype(np.float32)
+  mags = gain * np.ones([1, 1025], np.float32)
+  out = O.frequency_filter(audio, mags, window_size=257)
+  assert np.abs(out - gain * audio).mean() <= 1e-3
+
+
+@pytest.mark.parametrize('fft_size,window_size', [(2048, 257), (2048, 256), (2048, 0),
+                                                  (1024, 1025 + 100)])
+def test_frequency_impulse_response_gives_correct_size(fft_size, window_size):  # :825-855
+  mags = np.ones([1, 5, fft_size // 2 + 1], np.float32)
+  ir = O.frequency_impulse_response(mags, window_size)
+  if window_size <= 0 or window_size > fft_size:
+    target = fft_size
+  else:
+    target = window_size if window_size % 2 else window_size - 1
+  assert ir.shape[-1] == target
+
+
+@pytest.mark.parametrize('sr', [4000, 16000, 44100])
+def test_silent_above_nyquist(sr):                                 # core_test.py:484-503
+  n = 1000
+  for ratio in (1.1, 1.5, 2.0):
+    f = np.full((2, n, 3), ratio * sr / 2.0, np.float32)
+    audio = O.oscillator_bank(f, np.ones_like(f), sample_rate=sr)
+    assert np.all(audio == 0.0)
+
+
+@pytest.mark.parametrize('method', ['linear', 'window'])
+def test_upsample_accuracy(method):                                # core_test.py:242-267
+  x = np.array([0.0, 1.0, 0.5, -0.3, 0.8], np.float32)[None, :, None]
+  n = 16000
+  y = O.resample(x, n, method=method)
+  idx = np.arange(5) * (n // 5)
+  np.testing.assert_allclose(y[0, idx, 0], x[0, :, 0], atol=1e-3)
+
+
+def test_value_errors():                                           # core_test.py:295-381, 787-886
+  with pytest.raises(ValueError):
+    O.upsample_with_windows(np.ones((2, 10)), 100)                  # not 3-D
+  with pytest.raises(ValueError):
+    O.upsample_with_windows(np.ones((1, 10, 1)), 5)                 # downsampling
+  with pytest.raises(ValueError):
+    O.upsample_with_windows(np.ones((1, 10, 1)), 105)               # not divisible
+  with pytest.raises(ValueError):
+    O.resample(np.ones((1, 10, 1)), 100, method='bogus')
+  with pytest.raises(ValueError):
+    O.fft_convolve(np.ones((2, 100)), np.ones((3, 10, 5)))          # batch mismatch
+  with pytest.raises(ValueError):
+    O.fft_convolve(np.ones((1, 100)), np.ones((1, 30, 5)))          # frame mismatch
+  with pytest.raises(ValueError):
+    O.fft_convolve(np.ones((1, 100)), np.ones((1, 10, 5)), padding='bogus')
+
+
+# ---- fp32 drift facts that define the parity contract ------------------
+def test_angular_cumsum_tracks_fp64_truth_and_plain_cumsum_drifts():
+  rng = np.random.default_rng(3)
+  n, f, k = 32000, 500, 30
+  amps = np.ones((1, f, 1)); hd = np.ones((1, f, k)) / k
+  f0 = (220 + 3 * rng.standard_normal((1, f, 1)))
+  truth = O.harmonic_get_signal(amps, hd, f0, n, dtype=np.float64)
+  ang = O.harmonic_get_signal(amps, hd, f0, n, use_angular_cumsum=True)
+  seq = O.harmonic_get_signal(amps, hd, f0, n, use_angular_cumsum=False)
+  assert np.abs(ang - truth).max() < 2e-2
+  assert np.abs(seq - truth).max() > 5 * np.abs(ang - truth).max()
+
+
+def test_device_noise_restatement_is_uniform():
+  x = O.device_uniform_noise(4, 4096, seed=7)
+  assert x.dtype == np.float32 and x.min() >= -1.0 and x.max() < 1.0
+  assert abs(x.mean()) < 0.03 and abs(x.var() - 1 / 3) < 0.02
+  # counter-based: rows and offsets are independent of batch tiling
+  y = O.device_uniform_noise(2, 4096, seed=7, batch_offset=2)
+  np.testing.assert_array_equal(x[2:], y)
+  # Philox4x32-10 known answer (Random123 kat_vectors: ctr=0,key=0)
+  w = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+  assert [int(v) for v in w] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
