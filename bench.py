@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py - Msamples/s of the Harmonic + FilteredNoise hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N)
+
+One "step" = one pass of the hot path over one batch of synthetic control tensors:
+`synths.Harmonic(amplitudes, harmonic_distribution, f0_hz)` + `synths.FilteredNoise(magnitudes)`
+(raw network outputs in, both get_controls prologues included, noise generated on chip),
+each output sample counted once.  Inputs are resident in HBM before the timed region.
+Workload (per GPU, weak scaling): BASELINE.json configs[1] - batch 32, 4 s @ 16 kHz,
+F=1000 frames, K=100 harmonics (all below Nyquist: f0 = 70 + N(0,1) Hz), M=65 noise bands.
+
+The JSON line also carries
+  roofline     : dominant kernel, algorithmic bytes per launch / its mean duration measured
+                 with HIP events on the launch stream during the timed region (ddsp_profile_*),
+                 against the 8 TB/s HBM peak (the path is in fact ALU-bound).
+  cpu_baseline : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
+                 here) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
+  ap.add_argument('--n-frames', type=int, default=1000)
+  ap.add_argument('--n-harmonics', type=int, default=100)
+  ap.add_argument('--n-bands', type=int, default=65)
+  ap.add_argument('--n-samples', type=int, default=64000)
+  ap.add_argument('--sample-rate', type=int, default=16000)
+  ap.add_argument('--f0', type=float, default=70.0, help='f0 centre in Hz (70: all harmonics live)')
+  ap.add_argument('--cpu-clips', type=int, default=12, help='clips timed by the CPU oracle leg')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--allgather', action='store_true',
+                  help='also time an RCCL all_gather of the audio (reported separately)')
+  return ap.parse_args()
+
+
+def make_inputs(batch, a, seed):
+  rng = np.random.default_rng(seed)
+  return dict(
+      amplitudes=rng.standard_normal((batch, a.n_frames, 1)).astype(np.float32),
+      harmonic_distribution=rng.standard_normal((batch, a.n_frames, a.n_harmonics)).astype(np.float32),
+      f0_hz=(a.f0 + rng.standard_normal((batch, a.n_frames, 1))).astype(np.float32),
+      magnitudes=rng.standard_normal((batch, a.n_frames, a.n_bands)).astype(np.float32))
+
+
+def algorithmic_bytes(a, batch):
+  """controls read once, each synth's audio written once, noise on chip."""
+  harm = 4 * batch * (a.n_frames * (a.n_harmonics + 2) + a.n_samples)
+  noise = 4 * batch * (a.n_frames * a.n_bands + a.n_samples)
+  return harm, noise
+
+
+def cpu_baseline(a):
+  """The oracle (numpy, fp32, op by op as TF executes it) on `cpu_clips` clips, one at a time."""
+  from oracle import ddsp_oracle as O
+  x = make_inputs(a.cpu_clips, a, seed=123)
+  rng = np.random.default_rng(5)
+  t0 = time.perf_counter()
+  for i in range(a.cpu_clips):
+    s = slice(i, i + 1)
+    O.harmonic(x['amplitudes'][s], x['harmonic_distribution'][s], x['f0_hz'][s], a.n_samples,
+               a.sample_rate)
+    noise = rng.uniform(-1, 1, (1, a.n_samples)).astype(np.float32)   # tf.random.uniform stand-in
+    O.filtered_noise(x['magnitudes'][s], noise, 0)
+  dt = time.perf_counter() - t0
+  return {
+      'value': a.cpu_clips * a.n_samples / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1,
+      'kind': 'port',
+      'sample': '%d clip(s) of the same workload (B=1 each, %d samples, K=%d, M=%d) through '
+                'oracle/ddsp_oracle.py (numpy fp32 restatement of the TF op chain; TF is not '
+                'installable here), %.1f s wall, host has %d logical CPUs' %
+                (a.cpu_clips, a.n_samples, a.n_harmonics, a.n_bands, dt, os.cpu_count())}
+
+
+def main():
+  a = parse_args()
+  import torch
+  import torch.distributed as dist
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != a.gpus and world > 1:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+  assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+  torch.cuda.set_device(local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+
+  from ddsp_amd import build
+  if rank == 0:
+    build.build()            # no-op when the shipped .so is current
+  if world > 1:
+    dist.barrier()
+  import ddsp_amd as ddsp
+  from ddsp_amd import _lib
+  _lib.load()
+
+  # ---- per-rank shard of the global batch: independent rows, no data-path collective ----
+  B = a.batch
+  x = make_inputs(B, a, seed=1000 + rank)
+  dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
+  harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
+  fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
+
+  def step():
+    h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
+    z = fnoise(dev['magnitudes'])
+    return h, z
+
+  def sync_all():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(a.warmup):
+    step()
+  torch.cuda.synchronize()
+
+  # diagnostic pass (untimed): every kernel bracketed, to find the dominant one
+  _lib.profile_begin(None, max_records=64)
+  for _ in range(2):
+    step()
+  breakdown = _lib.profile_end()
+  dominant = max(breakdown, key=lambda k: breakdown[k][0] / breakdown[k][1])
+
+  # ---- timed region: exactly K steps, barrier + synchronize on both sides ----------------
+  _lib.profile_begin([dominant], max_records=2 * a.steps + 8)
+  sync_all()
+  t0 = time.perf_counter()
+  for _ in range(a.steps):
+    out = step()
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  prof = _lib.profile_end()
+
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  gather_ms = None
+  if a.allgather and world > 1:
+    h = out[0]
+    full = torch.empty((world * B, a.n_samples), dtype=torch.float32, device='cuda')
+    for _ in range(3):
+      dist.all_gather_into_tensor(full, h)
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(10):
+      dist.all_gather_into_tensor(full, h)
+    sync_all()
+    gather_ms = (time.perf_counter() - t1) / 10 * 1e3
+
+  if rank == 0:
+    total_samples = world * B * a.n_samples * a.steps
+    value = total_samples / elapsed / 1e6
+    harm_bytes, noise_bytes = algorithmic_bytes(a, B)
+    dom_ms, dom_n = prof[dominant]
+    dom_avg_s = dom_ms / dom_n * 1e-3
+    # algorithmic bytes of the launch = those of the Processor the kernel belongs to
+    dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes
+    achieved = dom_bytes / dom_avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+      try:
+        rec = json.load(open(tpath))
+        if rec.get('batch') == B:
+          traffic = rec.get('kernels', {}).get(dominant)
+      except (ValueError, OSError):
+        traffic = None
+    step_bytes = harm_bytes + noise_bytes
+    result = {
+        'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
+        'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': 'BASELINE configs[1]: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
+                        '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
+                        'controls in (get_controls fused), noise generated on chip' %
+                        (B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
+            'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
+            'no collective' % world},
+        'roofline': {
+            'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': dom_avg_s * 1e6,
+            'launches': dom_n,
+            'whole_step': {'algorithmic_bytes': step_bytes,
+                           'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
+                           'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}},
+        'kernel_breakdown_us': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
+    }
+    if gather_ms is not None:
+      result['allgather_ms'] = gather_ms
+    if not a.no_cpu_baseline and world == 1:
+      result['cpu_baseline'] = cpu_baseline(a)
+    elif not a.no_cpu_baseline:
+      result['cpu_baseline'] = None     # rank 0 at N=1 only (bench contract)
+    print(json.dumps(result), flush=True)
+
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

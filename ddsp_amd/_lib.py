@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI in include/ddsp_amd.h.
+
+The product path has NO fallback: if `libddsp_amd.so` is missing or a symbol is absent
+this module raises, and every processor that needs a kernel fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libddsp_amd.so')
+
+c_f32p = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+c_int, c_uint, c_size_t = ctypes.c_int, ctypes.c_uint, ctypes.c_size_t
+c_u64, c_float, c_voidp = ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/ddsp_amd.h
+SIGNATURES = {
+    'ddsp_version': (ctypes.c_char_p, []),
+    'ddsp_harmonic_controls_f32': (c_int, [c_f32p] * 5 + [c_int] * 4 + [c_uint, c_voidp]),
+    'ddsp_harmonic_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ddsp_harmonic_signal_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                 [c_uint, c_voidp]),
+    'ddsp_harmonic_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 5 +
+                          [c_uint, c_voidp]),
+    'ddsp_filtered_noise_controls_f32': (c_int, [c_f32p] * 2 + [c_int] * 3 +
+                                         [c_float, c_uint, c_voidp]),
+    'ddsp_fir_size': (c_int, [c_int, c_int]),
+    'ddsp_frequency_impulse_response_f32': (c_int, [c_f32p] * 2 + [c_int] * 4 + [c_voidp]),
+    'ddsp_filtered_noise_workspace_bytes': (c_size_t, [c_int] * 5),
+    'ddsp_filtered_noise_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                [c_float, c_uint, c_u64, c_u64, c_voidp]),
+    'ddsp_fft_convolve_same_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
+    'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
+    'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
+    'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),
+    'ddsp_profile_kernel_count': (c_int, []),
+    'ddsp_profile_kernel_name': (ctypes.c_char_p, [c_int]),
+    'ddsp_profile_begin': (c_int, [c_uint, c_int]),
+    'ddsp_profile_end': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+}
+
+# flags (mirror include/ddsp_amd.h)
+HARM_SCALE_EXP_SIGMOID = 0x1
+HARM_NORMALIZE_NYQUIST = 0x2
+HARM_AMP_LINEAR = 0x4
+HARM_ANGULAR_CUMSUM = 0x8
+NOISE_SCALE_EXP_SIGMOID = 0x1
+
+ERRORS = {-1: 'DDSP_ERR_NULL_POINTER', -2: 'DDSP_ERR_BAD_SHAPE', -3: 'DDSP_ERR_UNSUPPORTED',
+          -4: 'DDSP_ERR_WORKSPACE', -5: 'DDSP_ERR_LAUNCH'}
+
+_lib = None
+
+
+class DdspLibraryError(RuntimeError):
+  pass
+
+
+def load():
+  """Load libddsp_amd.so (once) and type every entry point.  Raises if unavailable."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise DdspLibraryError(
+        'HIP library not built: %s is missing. Run `python -c "import __graft_entry__ as g; '
+        'g.build()"` (or `python -m ddsp_amd.build`). There is no CPU fallback.' % LIB_PATH)
+  # torch must be imported first so that libamdhip64.so.7 resolves to the HIP runtime torch
+  # already loaded: one runtime per process, device pointers are shared with torch.
+  import torch  # noqa: F401
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (restype, argtypes) in SIGNATURES.items():
+    fn = getattr(lib, name)       # AttributeError here == a declared symbol is not exported
+    fn.restype = restype
+    fn.argtypes = argtypes
+  _lib = lib
+  return lib
+
+
+def check(rc, what):
+  if rc != 0:
+    raise DdspLibraryError('%s failed: %s (%d)' % (what, ERRORS.get(rc, 'unknown'), rc))
+
+
+def profile_begin(kernel_names=None, max_records=4096):
+  """Start per-kernel HIP-event tracing; kernel_names=None traces every kernel."""
+  lib = load()
+  n = lib.ddsp_profile_kernel_count()
+  names = [lib.ddsp_profile_kernel_name(i).decode() for i in range(n)]
+  mask = 0
+  for i, nm in enumerate(names):
+    if kernel_names is None or nm in kernel_names:
+      mask |= 1 << i
+  check(lib.ddsp_profile_begin(mask, int(max_records)), 'ddsp_profile_begin')
+
+
+def profile_end():
+  """Stop tracing; returns {kernel_name: (total_ms, count)} for kernels that ran."""
+  lib = load()
+  n = lib.ddsp_profile_kernel_count()
+  ms = (ctypes.c_double * n)()
+  cnt = (c_int * n)()
+  check(lib.ddsp_profile_end(ms, cnt), 'ddsp_profile_end')
+  return {lib.ddsp_profile_kernel_name(i).decode(): (ms[i], cnt[i])
+          for i in range(n) if cnt[i] > 0}

@@ -1,0 +1,38 @@
+"""Build libddsp_amd.so for gfx950 with hipcc (in-tree, so it ships to the GPU box)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SOURCES = ['harmonic.hip', 'filtered_noise.hip', 'profile.hip']
+OUT = os.path.join(HERE, 'lib', 'libddsp_amd.so')
+
+
+def needs_rebuild():
+  if not os.path.exists(OUT):
+    return True
+  t = os.path.getmtime(OUT)
+  deps = [os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc'))]
+  deps.append(os.path.join(ROOT, 'include', 'ddsp_amd.h'))
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+  if not force and not needs_rebuild():
+    return OUT
+  hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  os.makedirs(os.path.dirname(OUT), exist_ok=True)
+  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+         '-I' + os.path.join(ROOT, 'include')]
+  cmd += [os.path.join(HERE, 'csrc', s) for s in SOURCES]
+  cmd += ['-o', OUT]
+  if verbose:
+    print('[ddsp_amd.build]', ' '.join(cmd), flush=True)
+  subprocess.run(cmd, check=True)
+  return OUT
+
+
+if __name__ == '__main__':
+  build(force='--force' in sys.argv)

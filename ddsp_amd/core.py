@@ -1,0 +1,234 @@
+"""Host-side mirror of the `ddsp.core` functions on the Harmonic / FilteredNoise path.
+
+Same names, argument meaning and ValueErrors as the reference (`ddsp/core.py`), but the
+arithmetic runs in the hand-written gfx950 kernels behind the C ABI of
+`include/ddsp_amd.h`.  Tensors are `torch.Tensor`s in HBM; torch is plumbing only
+(allocation, streams) - there is no torch / CPU compute fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from ddsp_amd import _lib
+
+
+# --------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------
+def _device():
+  if not torch.cuda.is_available():
+    raise _lib.DdspLibraryError(
+        'ddsp_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+        'there is no CPU fallback.')
+  return torch.device('cuda', torch.cuda.current_device())
+
+
+def tf_float32(x):
+  """core.tf_float32 (ddsp/core.py:31-36): anything -> contiguous fp32 tensor in HBM."""
+  if isinstance(x, torch.Tensor):
+    if not x.is_cuda:
+      x = x.to(_device())
+    return x.to(torch.float32).contiguous()
+  return torch.as_tensor(np.asarray(x, dtype=np.float32), device=_device()).contiguous()
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+  """Grow-only scratch buffer in HBM, reused across calls on one stream."""
+
+  def __init__(self):
+    self._buf = None
+
+  def get(self, nbytes, device):
+    nbytes = max(int(nbytes), 16)
+    if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+      self._buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return self._buf
+
+
+_default_ws = Workspace()
+
+
+# --------------------------------------------------------------------------------------
+# scaling  (ddsp/core.py:386-404)
+# --------------------------------------------------------------------------------------
+def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
+  """Exponentiated sigmoid: max_value * sigmoid(x)**log(exponent) + threshold."""
+  x = tf_float32(x)
+  out = torch.empty_like(x)
+  rc = _lib.load().ddsp_exp_sigmoid_f32(x.data_ptr(), out.data_ptr(), x.numel(),
+                                        float(exponent), float(max_value), float(threshold),
+                                        _stream())
+  _lib.check(rc, 'ddsp_exp_sigmoid_f32')
+  return out
+
+
+# --------------------------------------------------------------------------------------
+# harmonic synthesis  (ddsp/core.py:1048-1111)
+# --------------------------------------------------------------------------------------
+RESAMPLE_METHODS = ['nearest', 'linear', 'cubic', 'window']
+
+
+def _check_amp_method(method, n_frames, n_samples):
+  """The argument checks of core.resample / upsample_with_windows (core.py:633-634, 677-693)."""
+  if method not in RESAMPLE_METHODS:
+    raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+        method, "['nearest', 'linear', 'cubic', 'window']"))
+  if method in ('nearest', 'cubic'):
+    raise NotImplementedError(
+        "amp_resample_method='{}' is not implemented by the MI355X kernels "
+        "(no shipped gin config uses it); use 'window' or 'linear'.".format(method))
+  if method == 'window':
+    if n_frames + 1 >= n_samples:
+      raise ValueError('Upsample with windows cannot be used for downsampling'
+                       'More input frames ({}) than output timesteps ({})'.format(
+                           n_frames + 1, n_samples))
+    if n_samples % n_frames != 0:
+      raise ValueError(
+          'For upsampling, the target the number of timesteps must be divisible '
+          'by the number of input frames{}. (timesteps:{}, frames:{}, '
+          'add_endpoint={}).'.format('', n_samples, n_frames + 1, True))
+  elif n_samples % n_frames != 0:
+    raise NotImplementedError(
+        'n_samples ({}) must be a multiple of n_frames ({}) in the MI355X kernels.'.format(
+            n_samples, n_frames))
+
+
+def _harmonic_flags(scale, normalize, amp_resample_method, use_angular_cumsum):
+  flags = 0
+  if scale:
+    flags |= _lib.HARM_SCALE_EXP_SIGMOID
+  if normalize:
+    flags |= _lib.HARM_NORMALIZE_NYQUIST
+  if amp_resample_method == 'linear':
+    flags |= _lib.HARM_AMP_LINEAR
+  if use_angular_cumsum:
+    flags |= _lib.HARM_ANGULAR_CUMSUM
+  return flags
+
+
+def _check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz):
+  if harmonic_distribution.dim() != 3:
+    raise ValueError('harmonic_distribution must be [batch, n_frames, n_harmonics], got {}'
+                     .format(tuple(harmonic_distribution.shape)))
+  b, f, _ = harmonic_distribution.shape
+  for name, t in (('amplitudes', amplitudes), ('f0_hz', f0_hz)):
+    if tuple(t.shape) != (b, f, 1):
+      raise ValueError('{} must have shape [{}, {}, 1], got {}'.format(
+          name, b, f, tuple(t.shape)))
+  return b, f, harmonic_distribution.shape[2]
+
+
+def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
+                       harmonic_distribution=None, n_samples=64000, sample_rate=16000,
+                       amp_resample_method='window', use_angular_cumsum=False,
+                       workspace=None):
+  """core.harmonic_synthesis: frame-rate controls -> audio [batch, n_samples]."""
+  if harmonic_shifts is not None:
+    raise NotImplementedError('harmonic_shifts is not on the accelerated path '
+                              '(synths.Harmonic never passes it, ddsp/synths.py:138-145).')
+  frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
+  if harmonic_distribution is None:
+    harmonic_distribution = torch.ones_like(amplitudes)
+  harmonic_distribution = tf_float32(harmonic_distribution)
+  b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
+  _check_amp_method(amp_resample_method, f, int(n_samples))
+  lib = _lib.load()
+  audio = torch.empty((b, int(n_samples)), dtype=torch.float32, device=amplitudes.device)
+  nbytes = lib.ddsp_harmonic_workspace_bytes(b, f, k, int(n_samples))
+  ws = (workspace or _default_ws).get(nbytes, amplitudes.device)
+  rc = lib.ddsp_harmonic_signal_f32(
+      amplitudes.data_ptr(), harmonic_distribution.data_ptr(), frequencies.data_ptr(),
+      audio.data_ptr(), ws.data_ptr(), ws.numel(), b, f, k, int(n_samples), int(sample_rate),
+      _harmonic_flags(False, False, amp_resample_method, use_angular_cumsum), _stream())
+  _lib.check(rc, 'ddsp_harmonic_signal_f32')
+  return audio
+
+
+# --------------------------------------------------------------------------------------
+# time-varying FIR  (ddsp/core.py:1382-1565, 1628-1655)
+# --------------------------------------------------------------------------------------
+def frequency_impulse_response(magnitudes, window_size=0):
+  """core.frequency_impulse_response: [B,F,M] (or [B,M]) magnitudes -> causal windowed IR."""
+  magnitudes = tf_float32(magnitudes)
+  squeeze = magnitudes.dim() == 2
+  if squeeze:
+    magnitudes = magnitudes[:, None, :].contiguous()
+  b, f, m = magnitudes.shape
+  lib = _lib.load()
+  size = lib.ddsp_fir_size(m, int(window_size))
+  _lib.check(min(size, 0), 'ddsp_fir_size')
+  ir = torch.empty((b, f, size), dtype=torch.float32, device=magnitudes.device)
+  rc = lib.ddsp_frequency_impulse_response_f32(magnitudes.data_ptr(), ir.data_ptr(), b, f, m,
+                                               int(window_size), _stream())
+  _lib.check(rc, 'ddsp_frequency_impulse_response_f32')
+  return ir[:, 0, :] if squeeze else ir
+
+
+def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1):
+  """core.fft_convolve, evaluated as the equivalent direct time-varying FIR."""
+  audio, impulse_response = tf_float32(audio), tf_float32(impulse_response)
+  if audio.dim() != 2:
+    raise ValueError('audio must be [batch, audio_timesteps], got {}'.format(tuple(audio.shape)))
+  batch_size, audio_size = audio.shape
+  if impulse_response.dim() == 2:
+    impulse_response = impulse_response[:, None, :].contiguous()
+  batch_size_ir, n_ir_frames, ir_size = impulse_response.shape
+  if batch_size_ir == 1 and batch_size > 1:
+    batch_size_ir_eff = batch_size        # broadcast (core.py:1433-1434), done in-kernel
+  else:
+    batch_size_ir_eff = batch_size_ir
+  if batch_size != batch_size_ir_eff:
+    raise ValueError('Batch size of audio ({}) and impulse response ({}) must '
+                     'be the same.'.format(batch_size, batch_size_ir))
+  frame_size = int(np.ceil(audio_size / n_ir_frames))
+  n_audio_frames = int(math.ceil(audio_size / frame_size))
+  if n_audio_frames != n_ir_frames:
+    raise ValueError(
+        'Number of Audio frames ({}) and impulse response frames ({}) do not '
+        'match. For small hop size = ceil(audio_size / n_ir_frames), '
+        'number of impulse response frames must be a multiple of the audio '
+        'size.'.format(n_audio_frames, n_ir_frames))
+  if padding == 'valid':
+    raise NotImplementedError("padding='valid' is not implemented by the MI355X kernels "
+                              "(the synths only use 'same').")
+  if padding != 'same':
+    raise ValueError('Padding must be \'valid\' or \'same\', instead '
+                     'of {}.'.format(padding))
+  out = torch.empty_like(audio)
+  rc = _lib.load().ddsp_fft_convolve_same_f32(
+      audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
+      n_ir_frames, ir_size, audio_size, int(delay_compensation), _stream())
+  _lib.check(rc, 'ddsp_fft_convolve_same_f32')
+  return out
+
+
+def _check_frames(audio_size, n_ir_frames):
+  """The frame-count check of core.fft_convolve (ddsp/core.py:1446-1457)."""
+  frame_size = int(np.ceil(audio_size / n_ir_frames))
+  n_audio_frames = int(math.ceil(audio_size / frame_size))
+  if n_audio_frames != n_ir_frames:
+    raise ValueError(
+        'Number of Audio frames ({}) and impulse response frames ({}) do not '
+        'match. For small hop size = ceil(audio_size / n_ir_frames), '
+        'number of impulse response frames must be a multiple of the audio '
+        'size.'.format(n_audio_frames, n_ir_frames))
+
+
+def frequency_filter(audio, magnitudes, window_size=0, padding='same'):
+  """core.frequency_filter = fft_convolve(audio, frequency_impulse_response(magnitudes))."""
+  impulse_response = frequency_impulse_response(magnitudes, window_size=window_size)
+  return fft_convolve(audio, impulse_response, padding=padding)
+
+
+def uniform_noise(batch_size, n_samples, seed=0, batch_offset=0):
+  """The on-chip stand-in for tf.random.uniform([B, N], -1, 1) (ddsp/synths.py:192-193)."""
+  out = torch.empty((int(batch_size), int(n_samples)), dtype=torch.float32, device=_device())
+  rc = _lib.load().ddsp_uniform_noise_f32(out.data_ptr(), int(batch_size), int(n_samples),
+                                          int(seed), int(batch_offset), _stream())
+  _lib.check(rc, 'ddsp_uniform_noise_f32')
+  return out

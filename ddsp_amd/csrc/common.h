@@ -1,0 +1,67 @@
+// Shared device helpers for the gfx950 kernels (wave64 only; no other target).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddsp {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// core.exp_sigmoid (ddsp/core.py:386-404): max_value * sigmoid(x)**log(exponent) + threshold.
+// sigmoid(x)**p == exp(-p * softplus(-x)); evaluated with the hardware exp2/log2
+// (v_exp_f32 / v_log_f32), relative error ~1e-6, far below the parity tolerance.
+__device__ __forceinline__ float exp_sigmoid(float x, float log_exponent, float max_value,
+                                             float threshold) {
+  const float ax = fabsf(x);
+  const float sp_tail = __logf(1.0f + __expf(-ax));       // log(1 + e^-|x|)
+  const float softplus_neg = (x >= 0.0f) ? sp_tail : (ax + sp_tail);  // log(1 + e^-x)
+  return max_value * __expf(-log_exponent * softplus_neg) + threshold;
+}
+
+// sin(2*pi*x) for x in revolutions, |x| <= 256: one v_sin_f32.
+__device__ __forceinline__ float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }
+
+// ---- Philox4x32-10 (Salmon et al. SC'11); restated in oracle/ddsp_oracle.py ----------
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// 32 random bits -> uniform fp32 in [-1, 1): 23-bit mantissa in [1,2), as tf.random.uniform.
+__device__ __forceinline__ float bits_to_pm1(uint32_t bits) {
+  const float u = __uint_as_float((bits >> 9) | 0x3F800000u);
+  return (u - 1.0f) * 2.0f - 1.0f;
+}
+// noise sample n of global batch row `row`
+__device__ __forceinline__ float philox_noise(uint32_t n, uint64_t row, uint32_t k0,
+                                              uint32_t k1) {
+  const U4 r = philox4x32_10(U4{n >> 2, (uint32_t)row, 0u, 0u}, k0, k1);
+  const uint32_t w = n & 3u;
+  const uint32_t bits = (w == 0) ? r.x : (w == 1) ? r.y : (w == 2) ? r.z : r.w;
+  return bits_to_pm1(bits);
+}
+
+}  // namespace ddsp

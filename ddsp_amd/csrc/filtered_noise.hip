@@ -1,0 +1,352 @@
+// FilteredNoise kernels for gfx950 (MI355X).  Replaces ddsp/synths.py:165-196 ->
+// ddsp/core.py:1534-1565 (frequency_impulse_response), :1477-1531
+// (apply_window_to_impulse_response), :1382-1473 (fft_convolve) and :1338-1379
+// (crop_and_compensate_delay).  See DESIGN.md "FilteredNoise".
+//
+// fft_convolve's framed FFT / overlap-add is algebraically the direct time-varying FIR
+//     z[m] = sum_k x[m-k] * h_{frame(m-k)}[k],      out[n] = z[n + start],
+// (tap set chosen by the frame of the INPUT sample; oracle test
+// test_fft_convolve_equals_direct_time_varying_fir), which is what is evaluated here:
+// no FFT, no [B,F,fft_size] complex intermediates in HBM.
+#include "common.h"
+#include "profile.h"
+#include "../../include/ddsp_amd.h"
+
+namespace ddsp {
+
+// ------------------------------------------------------------------------------------
+// Geometry of core.apply_window_to_impulse_response (core.py:1477-1531).
+// ------------------------------------------------------------------------------------
+struct IrGeom {
+  int M, L0, ws, padding, half, L;
+};
+__host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
+  IrGeom g;
+  g.M = M;
+  g.L0 = 2 * (M - 1);                                     // irfft length (core.py:1559)
+  g.ws = (window_size <= 0 || window_size > g.L0) ? g.L0 : window_size;   // :1501-1503
+  g.padding = g.L0 - g.ws;
+  g.half = (g.ws + 1) / 2;                                // :1509
+  g.L = g.padding > 0 ? 2 * g.half - 1 : g.L0;            // :1520-1527
+  return g;
+}
+// causal tap index kappa -> zero-phase sample index n and Hann window index (or -1: zero)
+__device__ __forceinline__ void ir_tap_map(const IrGeom& g, int kappa, int* n, int* widx) {
+  if (g.padding > 0) {
+    // concat(ir[L0-half+2:], ir[:half+1])                         (core.py:1521-1526)
+    const int nn = (kappa < g.half - 2) ? (g.L0 - g.half + 2 + kappa) : (kappa - (g.half - 2));
+    // window_zp = concat(window[half:], zeros(padding), window[:half])   (:1510-1512)
+    int wi = -1;
+    if (nn < g.ws - g.half) wi = g.half + nn;
+    else if (nn >= g.L0 - g.half) wi = nn - (g.L0 - g.half);
+    *n = nn; *widx = wi;
+  } else {
+    // fftshift(window) * ir, then fftshift                          (:1514, 1529)
+    *n = (kappa + g.L0 / 2) % g.L0;
+    *widx = kappa;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel: controls.  ctl = exp_sigmoid(mag + bias) (synths.py:176-177) or copy.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_controls_kernel(const float* __restrict__ mag,
+                                                             float* __restrict__ ctl, size_t n,
+                                                             float bias, int scale) {
+  const float kLog10 = 2.302585092994046f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float x = mag[i];
+    ctl[i] = scale ? exp_sigmoid(x + bias, kLog10, 2.0f, 1e-7f) : x;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel: impulse-response design, general shapes.  One block per (batch*frame) row;
+// lanes = causal taps; the row's (scaled) magnitudes and the cosine table live in LDS.
+//   hz[n] = (1/L0) * ( mag[0] + mag[M-1]*cos(pi n) + 2*sum_{m=1}^{M-2} mag[m] cos(2 pi m n / L0) )
+//   h[kappa] = window_zp[n(kappa)] * hz[n(kappa)]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_ir_kernel(const float* __restrict__ mag,
+                                                       float* __restrict__ ctl_out,
+                                                       float* __restrict__ ir, long rows, int M,
+                                                       int window_size, float bias, int scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const IrGeom g = ir_geom(M, window_size);
+  float* s_cos = smem;            // [L0]
+  float* s_mag = smem + g.L0;     // [M]
+  const float kLog10 = 2.302585092994046f;
+  for (int i = threadIdx.x; i < g.L0; i += 256) s_cos[i] = cospif(2.0f * (float)i / (float)g.L0);
+  const float inv_L0 = 1.0f / (float)g.L0;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += 256) {
+      float x = mag[row * M + m];
+      if (scale) x = exp_sigmoid(x + bias, kLog10, 2.0f, 1e-7f);
+      if (ctl_out) ctl_out[row * M + m] = x;
+      // fold the irfft weights in: DC and Nyquist bins count once, the others twice
+      s_mag[m] = (m == 0 || m == M - 1) ? x : 2.0f * x;
+    }
+    __syncthreads();
+    for (int kappa = threadIdx.x; kappa < g.L; kappa += 256) {
+      int n, widx;
+      ir_tap_map(g, kappa, &n, &widx);
+      float acc = 0.0f;
+      int idx = 0;                               // (m*n) mod L0, incrementally
+      for (int m = 0; m < M; ++m) {
+        acc = fmaf(s_mag[m], s_cos[idx], acc);
+        idx += n;
+        if (idx >= g.L0) idx -= g.L0;
+      }
+      // periodic Hann (tf.signal.hann_window): 0.5 - 0.5 cos(2 pi i / ws)
+      const float w = (widx < 0) ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)g.ws);
+      ir[row * g.L + kappa] = w * (acc * inv_L0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel: uniform noise (the on-chip stand-in for tf.random.uniform, synths.py:192-193)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uniform_noise_kernel(float* __restrict__ out, int N,
+                                                            uint32_t k0, uint32_t k1,
+                                                            uint64_t batch_offset) {
+  const int b = blockIdx.y;
+  const int nq = (N + 3) / 4;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
+    const U4 r = philox4x32_10(U4{(uint32_t)q, (uint32_t)(batch_offset + b), 0u, 0u}, k0, k1);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * q + i < N) out[(size_t)b * N + 4 * q + i] = bits_to_pm1(w[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel: direct time-varying FIR, general shapes (v1).  One block per (tile of outputs,
+// batch row).  LDS: the input samples the tile touches (zero outside [0,N)) and the tap
+// sets of every frame those inputs belong to.  Each thread owns outputs tid + 256*r.
+// ------------------------------------------------------------------------------------
+struct FirArgs {
+  const float* x;      // [B,N] or null (generate)
+  const float* ir;     // [Bir,F,L]
+  float* out;          // [B,N]
+  int N, F, L, frame_size, start, tile;
+  size_t ir_batch_stride;   // F*L, or 0 when Bir == 1 (broadcast, core.py:1433-1434)
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+};
+
+template <bool GEN_NOISE>
+__global__ __launch_bounds__(256) void tv_fir_kernel(FirArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * p.tile;
+  const int n_out = min(p.tile, p.N - n0);
+  // inputs needed: i in [n0 + start - (L-1), n0 + n_out - 1 + start]
+  const int i_lo = n0 + p.start - (p.L - 1);
+  const int n_in = n_out + p.L - 1;
+  const int i_hi = i_lo + n_in - 1;
+  const int f_lo = max(i_lo, 0) / p.frame_size;
+  const int f_hi = min(min(i_hi, p.N - 1) / p.frame_size, p.F - 1);
+  const int nfr = max(f_hi - f_lo + 1, 0);
+  float* s_x = smem;                                   // [tile + L - 1]
+  float* s_h = smem + ((p.tile + p.L - 1 + 3) & ~3);   // [nfr][L]
+
+  for (int t = threadIdx.x; t < n_in; t += 256) {
+    const int i = i_lo + t;
+    float v = 0.0f;
+    if (i >= 0 && i < p.N)
+      v = GEN_NOISE ? philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1)
+                    : p.x[(size_t)b * p.N + i];
+    s_x[t] = v;
+  }
+  const float* irb = p.ir + (size_t)b * p.ir_batch_stride + (size_t)f_lo * p.L;
+  for (int t = threadIdx.x; t < nfr * p.L; t += 256) s_h[t] = irb[t];
+  __syncthreads();
+
+  for (int o = threadIdx.x; o < n_out; o += 256) {
+    const int m = n0 + o + p.start;              // index into the un-cropped convolution
+    float acc = 0.0f;
+    for (int f = f_lo; f <= f_hi; ++f) {         // uniform loop over the tile's frames
+      const int ia = max(f * p.frame_size, m - p.L + 1);
+      const int ib = min(min((f + 1) * p.frame_size - 1, m), p.N - 1);
+      const float* h = s_h + (f - f_lo) * p.L;
+      for (int i = ia; i <= ib; ++i) acc = fmaf(s_x[i - i_lo], h[m - i], acc);
+    }
+    p.out[(size_t)b * p.N + n0 + o] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
+                                                  const float* __restrict__ b,
+                                                  float* __restrict__ out, size_t n) {
+  const size_t n4 = n / 4;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 x = a4[i], y = b4[i];
+    o4[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    out[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void exp_sigmoid_kernel(const float* __restrict__ in,
+                                                          float* __restrict__ out, size_t n,
+                                                          float log_exponent, float max_value,
+                                                          float threshold) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = exp_sigmoid(in[i], log_exponent, max_value, threshold);
+}
+
+}  // namespace ddsp
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+using namespace ddsp;
+
+static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH; }
+static inline unsigned grid_for(size_t n, unsigned cap = 256 * 8) {
+  size_t g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+constexpr size_t kMaxDynLds = 64 * 1024;
+
+extern "C" const char* ddsp_version(void) { return "ddsp_amd 0.1.0 gfx950"; }
+
+extern "C" int ddsp_fir_size(int M, int window_size) {
+  if (M < 2) return DDSP_ERR_BAD_SHAPE;
+  return ir_geom(M, window_size).L;
+}
+
+extern "C" int ddsp_filtered_noise_controls_f32(const float* magnitudes, float* ctl, int B, int F,
+                                                int M, float initial_bias, unsigned flags,
+                                                void* stream) {
+  if (!magnitudes || !ctl) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || M <= 0) return DDSP_ERR_BAD_SHAPE;
+  const size_t n = (size_t)B * F * M;
+  ProfileScope prof(kNoiseControls, (hipStream_t)stream);
+  hipLaunchKernelGGL(noise_controls_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     magnitudes, ctl, n, initial_bias,
+                     (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0);
+  return check_launch();
+}
+
+static int launch_ir(const float* mag, float* ctl_out, float* ir, int B, int F, int M,
+                     int window_size, float bias, int scale, hipStream_t st) {
+  const IrGeom g = ir_geom(M, window_size);
+  const size_t lds = (size_t)(g.L0 + M) * sizeof(float);
+  if (lds > kMaxDynLds) return DDSP_ERR_UNSUPPORTED;
+  const long rows = (long)B * F;
+  const unsigned grid = (unsigned)(rows < 256 * 16 ? rows : 256 * 16);
+  ProfileScope prof(kNoiseIr, st);
+  hipLaunchKernelGGL(noise_ir_kernel, dim3(grid), dim3(256), lds, st, mag, ctl_out, ir, rows, M,
+                     window_size, bias, scale);
+  return check_launch();
+}
+
+extern "C" int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* ir, int B,
+                                                   int F, int M, int window_size, void* stream) {
+  if (!ctl_magnitudes || !ir) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || M < 2) return DDSP_ERR_BAD_SHAPE;
+  return launch_ir(ctl_magnitudes, nullptr, ir, B, F, M, window_size, 0.0f, 0, (hipStream_t)stream);
+}
+
+static int launch_fir(const float* x, const float* ir, float* out, int B, int Bir, int F, int L,
+                      int N, int delay_compensation, uint64_t seed, uint64_t batch_offset,
+                      hipStream_t st) {
+  if (B > 65535) return DDSP_ERR_UNSUPPORTED;
+  FirArgs p;
+  p.x = x; p.ir = ir; p.out = out;
+  p.N = N; p.F = F; p.L = L;
+  p.frame_size = (N + F - 1) / F;                               // core.py:1446
+  if ((N + p.frame_size - 1) / p.frame_size != F) return DDSP_ERR_BAD_SHAPE;   // :1451-1457
+  p.start = delay_compensation < 0 ? (L - 1) / 2 - 1 : delay_compensation;      // :1375-1376
+  if (p.start < 0) p.start = 0;   // L <= 2 with automatic compensation: python slice start -1
+  p.ir_batch_stride = (Bir == 1) ? 0 : (size_t)F * L;
+  p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
+  p.batch_offset = batch_offset;
+  // tile: as many outputs as keep x + taps under the LDS budget
+  int tile = 1024;
+  size_t lds = 0;
+  for (; tile >= 64; tile /= 2) {
+    const int nfr = (tile + L - 1) / p.frame_size + 2;
+    lds = ((size_t)((tile + L - 1 + 3) & ~3) + (size_t)nfr * L) * sizeof(float);
+    if (lds <= kMaxDynLds) break;
+  }
+  if (tile < 64) return DDSP_ERR_UNSUPPORTED;                 // very long IRs (Reverb): not v1
+  p.tile = tile;
+  const dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)B), block(256);
+  ProfileScope prof(kTvFir, st);
+  if (x) hipLaunchKernelGGL((tv_fir_kernel<false>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((tv_fir_kernel<true>), grid, block, lds, st, p);
+  return check_launch();
+}
+
+extern "C" int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response,
+                                          float* out, int B, int Bir, int F, int L, int N,
+                                          int delay_compensation, void* stream) {
+  if (!audio || !impulse_response || !out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || L <= 0 || N <= 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
+  return launch_fir(audio, impulse_response, out, B, Bir, F, L, N, delay_compensation, 0, 0,
+                    (hipStream_t)stream);
+}
+
+extern "C" size_t ddsp_filtered_noise_workspace_bytes(int B, int F, int M, int N, int window_size) {
+  (void)N;
+  if (B <= 0 || F <= 0 || M < 2) return 0;
+  return (size_t)B * F * (size_t)ir_geom(M, window_size).L * sizeof(float);
+}
+
+extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* audio,
+                                       float* ctl_magnitudes, void* workspace,
+                                       size_t workspace_bytes, int B, int F, int M, int N,
+                                       int window_size, float initial_bias, unsigned flags,
+                                       uint64_t seed, uint64_t batch_offset, void* stream) {
+  if (!magnitudes || !audio || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || M < 2 || N <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_filtered_noise_workspace_bytes(B, F, M, N, window_size) ||
+      ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
+  float* ir = (float*)workspace;
+  int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
+  if (rc != DDSP_OK) return rc;
+  return launch_fir(noise, ir, audio, B, B, F, ir_geom(M, window_size).L, N, -1, seed,
+                    batch_offset, st);
+}
+
+extern "C" int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed,
+                                      uint64_t batch_offset, void* stream) {
+  if (!out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  const dim3 grid(grid_for((size_t)(N + 3) / 4, 64), (unsigned)B);
+  ProfileScope prof(kUniformNoise, (hipStream_t)stream);
+  hipLaunchKernelGGL(uniform_noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, N,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), batch_offset);
+  return check_launch();
+}
+
+extern "C" int ddsp_add_f32(const float* a, const float* b, float* out, size_t n, void* stream) {
+  if (!a || !b || !out) return DDSP_ERR_NULL_POINTER;
+  if (n == 0) return DDSP_OK;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return DDSP_ERR_UNSUPPORTED;
+  ProfileScope prof(kAdd, (hipStream_t)stream);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     out, n);
+  return check_launch();
+}
+
+extern "C" int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
+                                    float max_value, float threshold, void* stream) {
+  if (!in || !out) return DDSP_ERR_NULL_POINTER;
+  if (n == 0) return DDSP_OK;
+  ProfileScope prof(kExpSigmoid, (hipStream_t)stream);
+  hipLaunchKernelGGL(exp_sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, n, logf(exponent), max_value, threshold);
+  return check_launch();
+}

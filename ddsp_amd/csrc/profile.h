@@ -1,0 +1,30 @@
+// Per-kernel HIP-event tracing (opt-in; off by default => zero overhead).
+// bench.py uses it to time the dominant kernel on the stream it is launched on; the same
+// numbers must agree with `rocprofv3 --kernel-trace --stats` (profiles/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ddsp {
+
+enum KernelId {
+  kHarmControls = 0,
+  kHarmSynth,
+  kNoiseControls,
+  kNoiseIr,
+  kTvFir,
+  kUniformNoise,
+  kAdd,
+  kExpSigmoid,
+  kNumKernels
+};
+
+// mask bit i set => kernel i is bracketed by events while tracing is on
+void profile_record(int kernel_id, hipStream_t st, bool start);
+
+struct ProfileScope {
+  int id; hipStream_t st;
+  ProfileScope(int kernel_id, hipStream_t s) : id(kernel_id), st(s) { profile_record(id, st, true); }
+  ~ProfileScope() { profile_record(id, st, false); }
+};
+
+}  // namespace ddsp

@@ -1,0 +1,60 @@
+"""Processor base class and Add (mirror of ddsp/processors.py:37-76, 162-176)."""
+import torch
+
+from ddsp_amd import _lib
+from ddsp_amd import core
+
+
+class Processor:
+  """Abstract base class for signal processors (ddsp/processors.py:37-76).
+
+  The reference derives from tf.keras.layers.Layer; the call protocol kept here is
+  `processor(*args, return_outputs_dict=False, **kwargs)` ==
+  `get_signal(**get_controls(*args, **kwargs))`, with keras' `training` / `mask` kwargs
+  dropped, so `ProcessorGroup`-style duck typing on get_controls/get_signal still works.
+  """
+
+  def __init__(self, name, trainable=False):
+    self.name = name
+    self.trainable = trainable
+
+  def __call__(self, *args, **kwargs):
+    return self.call(*args, **kwargs)
+
+  def call(self, *args, return_outputs_dict=False, **kwargs):
+    """Convert input tensors arguments into a signal tensor."""
+    for k in ['training', 'mask']:
+      if k in kwargs:
+        _ = kwargs.pop(k)
+    controls = self.get_controls(*args, **kwargs)
+    signal = self.get_signal(**controls)
+    if return_outputs_dict:
+      return dict(signal=signal, controls=controls)
+    return signal
+
+  def get_controls(self, *args, **kwargs):
+    raise NotImplementedError
+
+  def get_signal(self, *args, **kwargs):
+    raise NotImplementedError
+
+
+class Add(Processor):
+  """Sum two signals (ddsp/processors.py:162-176)."""
+
+  def __init__(self, name='add'):
+    super().__init__(name=name)
+
+  def get_controls(self, signal_one, signal_two):
+    return {'signal_one': signal_one, 'signal_two': signal_two}
+
+  def get_signal(self, signal_one, signal_two):
+    a, b = core.tf_float32(signal_one), core.tf_float32(signal_two)
+    if a.shape != b.shape:
+      a, b = torch.broadcast_tensors(a, b)
+      a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    rc = _lib.load().ddsp_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
+                                  core._stream())
+    _lib.check(rc, 'ddsp_add_f32')
+    return out

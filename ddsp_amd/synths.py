@@ -1,0 +1,196 @@
+"""Harmonic and FilteredNoise synthesisers (mirror of ddsp/synths.py:55-196).
+
+Constructor kwargs, defaults, `get_controls` / `get_signal` / `__call__` signatures and
+the controls-dict keys are the reference's.  Arithmetic: HIP kernels only.
+"""
+import torch
+
+from ddsp_amd import _lib
+from ddsp_amd import core
+from ddsp_amd import processors
+
+
+class Harmonic(processors.Processor):
+  """Synthesize audio with a bank of harmonic sinusoidal oscillators (synths.py:55-146)."""
+
+  def __init__(self,
+               n_samples=64000,
+               sample_rate=16000,
+               scale_fn=core.exp_sigmoid,
+               normalize_below_nyquist=True,
+               amp_resample_method='window',
+               use_angular_cumsum=False,
+               name='harmonic'):
+    super().__init__(name=name)
+    self.n_samples = n_samples
+    self.sample_rate = sample_rate
+    self.scale_fn = scale_fn
+    self.normalize_below_nyquist = normalize_below_nyquist
+    self.amp_resample_method = amp_resample_method
+    self.use_angular_cumsum = use_angular_cumsum
+    self._ws = core.Workspace()
+
+  # -- helpers -------------------------------------------------------------------------
+  def _prescale(self, amplitudes, harmonic_distribution):
+    """Returns (amplitudes, harmonic_distribution, fuse_exp_sigmoid)."""
+    amplitudes = core.tf_float32(amplitudes)
+    harmonic_distribution = core.tf_float32(harmonic_distribution)
+    if self.scale_fn is None:
+      return amplitudes, harmonic_distribution, False
+    if self.scale_fn is core.exp_sigmoid:
+      return amplitudes, harmonic_distribution, True          # fused into the kernel
+    # any other user callable runs as given, on device tensors
+    return (core.tf_float32(self.scale_fn(amplitudes)),
+            core.tf_float32(self.scale_fn(harmonic_distribution)), False)
+
+  def get_controls(self, amplitudes, harmonic_distribution, f0_hz):
+    """Network outputs -> {'amplitudes', 'harmonic_distribution', 'f0_hz'} (synths.py:94-121)."""
+    amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
+    f0_hz = core.tf_float32(f0_hz)
+    b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
+    ctl_amp = torch.empty_like(amplitudes)
+    ctl_hd = torch.empty_like(harmonic_distribution)
+    flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False)
+    # normalisation (safe_divide by the sum) always runs; only the Nyquist mask is optional
+    rc = _lib.load().ddsp_harmonic_controls_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(),
+        ctl_amp.data_ptr(), ctl_hd.data_ptr(), b, f, k, int(self.sample_rate), flags,
+        core._stream())
+    _lib.check(rc, 'ddsp_harmonic_controls_f32')
+    return {'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz}
+
+  def get_signal(self, amplitudes, harmonic_distribution, f0_hz):
+    """Controls -> audio [batch, n_samples] (synths.py:123-146)."""
+    return core.harmonic_synthesis(
+        frequencies=f0_hz, amplitudes=amplitudes, harmonic_distribution=harmonic_distribution,
+        n_samples=self.n_samples, sample_rate=self.sample_rate,
+        amp_resample_method=self.amp_resample_method,
+        use_angular_cumsum=self.use_angular_cumsum, workspace=self._ws)
+
+  def call(self, amplitudes, harmonic_distribution, f0_hz, return_outputs_dict=False, **kwargs):
+    """get_signal(**get_controls(...)) (processors.py:53-68) as ONE fused C-ABI call."""
+    for k in ['training', 'mask']:
+      kwargs.pop(k, None)
+    if kwargs:
+      raise TypeError('unexpected keyword arguments: {}'.format(sorted(kwargs)))
+    amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
+    f0_hz = core.tf_float32(f0_hz)
+    b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
+    n = int(self.n_samples)
+    core._check_amp_method(self.amp_resample_method, f, n)
+    lib = _lib.load()
+    dev = amplitudes.device
+    audio = torch.empty((b, n), dtype=torch.float32, device=dev)
+    ctl_amp = torch.empty_like(amplitudes) if return_outputs_dict else None
+    ctl_hd = torch.empty_like(harmonic_distribution) if return_outputs_dict else None
+    ws = self._ws.get(lib.ddsp_harmonic_workspace_bytes(b, f, k, n), dev)
+    flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
+                                 self.use_angular_cumsum)
+    rc = lib.ddsp_harmonic_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(),
+        audio.data_ptr(), ctl_amp.data_ptr() if return_outputs_dict else None,
+        ctl_hd.data_ptr() if return_outputs_dict else None, ws.data_ptr(), ws.numel(), b, f, k,
+        n, int(self.sample_rate), flags, core._stream())
+    _lib.check(rc, 'ddsp_harmonic_f32')
+    if return_outputs_dict:
+      controls = {'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz}
+      return dict(signal=audio, controls=controls)
+    return audio
+
+
+class FilteredNoise(processors.Processor):
+  """Synthesize audio by filtering white noise (synths.py:149-196).
+
+  `seed` is an extension: the reference draws from TensorFlow's stateful global generator;
+  here noise is Philox4x32-10 keyed by (seed, call counter), generated inside the FIR
+  kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
+  """
+
+  def __init__(self,
+               n_samples=64000,
+               window_size=257,
+               scale_fn=core.exp_sigmoid,
+               initial_bias=-5.0,
+               name='filtered_noise',
+               seed=0):
+    super().__init__(name=name)
+    self.n_samples = n_samples
+    self.window_size = window_size
+    self.scale_fn = scale_fn
+    self.initial_bias = initial_bias
+    self.seed = int(seed)
+    self._calls = 0
+    self._ws = core.Workspace()
+
+  def get_controls(self, magnitudes):
+    """Network outputs -> {'magnitudes'} (synths.py:165-179)."""
+    magnitudes = core.tf_float32(magnitudes)
+    if self.scale_fn is None:
+      return {'magnitudes': magnitudes}
+    if self.scale_fn is not core.exp_sigmoid:
+      return {'magnitudes': core.tf_float32(self.scale_fn(magnitudes + self.initial_bias))}
+    if magnitudes.dim() != 3:
+      raise ValueError('magnitudes must be [batch, n_frames, n_filter_banks], got {}'.format(
+          tuple(magnitudes.shape)))
+    b, f, m = magnitudes.shape
+    ctl = torch.empty_like(magnitudes)
+    rc = _lib.load().ddsp_filtered_noise_controls_f32(
+        magnitudes.data_ptr(), ctl.data_ptr(), b, f, m, float(self.initial_bias),
+        _lib.NOISE_SCALE_EXP_SIGMOID, core._stream())
+    _lib.check(rc, 'ddsp_filtered_noise_controls_f32')
+    return {'magnitudes': ctl}
+
+  def _next_seed(self):
+    s = (self.seed & 0xFFFFFFFF) | ((self._calls & 0xFFFFFFFF) << 32)
+    self._calls += 1
+    return s
+
+  def _run(self, magnitudes, noise, fuse_scale, want_controls):
+    magnitudes = core.tf_float32(magnitudes)
+    if magnitudes.dim() != 3:
+      raise ValueError('magnitudes must be [batch, n_frames, n_filter_banks], got {}'.format(
+          tuple(magnitudes.shape)))
+    b, f, m = magnitudes.shape
+    n = int(self.n_samples)
+    core._check_frames(n, f)
+    lib = _lib.load()
+    dev = magnitudes.device
+    if noise is not None:
+      noise = core.tf_float32(noise)
+      if tuple(noise.shape) != (b, n):
+        raise ValueError('noise must be [{}, {}], got {}'.format(b, n, tuple(noise.shape)))
+    audio = torch.empty((b, n), dtype=torch.float32, device=dev)
+    ctl = torch.empty_like(magnitudes) if want_controls else None
+    ws = self._ws.get(lib.ddsp_filtered_noise_workspace_bytes(b, f, m, n, int(self.window_size)),
+                      dev)
+    rc = lib.ddsp_filtered_noise_f32(
+        magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
+        audio.data_ptr(), ctl.data_ptr() if want_controls else None, ws.data_ptr(), ws.numel(),
+        b, f, m, n, int(self.window_size), float(self.initial_bias),
+        _lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0, self._next_seed(), 0,
+        core._stream())
+    _lib.check(rc, 'ddsp_filtered_noise_f32')
+    return audio, ctl
+
+  def get_signal(self, magnitudes, noise=None):
+    """Controls -> filtered noise [batch, n_samples] (synths.py:181-196)."""
+    audio, _ = self._run(magnitudes, noise, fuse_scale=False, want_controls=False)
+    return audio
+
+  def call(self, magnitudes, return_outputs_dict=False, noise=None, **kwargs):
+    """get_signal(**get_controls(magnitudes)) as one fused C-ABI call."""
+    for k in ['training', 'mask']:
+      kwargs.pop(k, None)
+    if kwargs:
+      raise TypeError('unexpected keyword arguments: {}'.format(sorted(kwargs)))
+    if self.scale_fn is None or self.scale_fn is core.exp_sigmoid:
+      audio, ctl = self._run(magnitudes, noise, fuse_scale=self.scale_fn is not None,
+                             want_controls=return_outputs_dict)
+      if return_outputs_dict and self.scale_fn is None:
+        ctl = core.tf_float32(magnitudes)
+    else:
+      ctl = self.get_controls(magnitudes)['magnitudes']
+      audio, _ = self._run(ctl, noise, fuse_scale=False, want_controls=False)
+    if return_outputs_dict:
+      return dict(signal=audio, controls={'magnitudes': ctl})
+    return audio

@@ -1,0 +1,173 @@
+/*
+ * ddsp_amd.h — C ABI of the MI355X (gfx950) additive-synthesis hot path.
+ *
+ * The reference (magenta/ddsp) has no native code and no FFI: its boundary for this
+ * path is the Python class API `ddsp.processors.Processor` (ddsp/processors.py:37-76)
+ * as implemented by `ddsp.synths.Harmonic` (ddsp/synths.py:55-146),
+ * `ddsp.synths.FilteredNoise` (ddsp/synths.py:149-196) and `ddsp.processors.Add`
+ * (ddsp/processors.py:162-176).  The entry points below are what a binding for that
+ * class API calls (see INTEGRATION.md for the ctypes stub a maintainer would add);
+ * each one names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller, fp32, contiguous,
+ *     row-major [batch, time, channel] exactly as the reference lays tensors out;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it and
+ *     never synchronise, allocate or free;
+ *   - return value: DDSP_OK or a negative DDSP_ERR_* (programmer errors only; the
+ *     reference's ValueErrors are raised by the host layer before the call);
+ *   - `workspace` is caller-provided scratch of at least *_workspace_bytes() bytes,
+ *     16-byte aligned, contents undefined on entry and exit.
+ */
+#ifndef DDSP_AMD_H_
+#define DDSP_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDSP_OK 0
+#define DDSP_ERR_NULL_POINTER (-1)
+#define DDSP_ERR_BAD_SHAPE (-2)
+#define DDSP_ERR_UNSUPPORTED (-3)   /* shape outside what the kernels implement */
+#define DDSP_ERR_WORKSPACE (-4)     /* workspace too small or misaligned */
+#define DDSP_ERR_LAUNCH (-5)        /* hipGetLastError() != hipSuccess after a launch */
+
+/* ---- flags for the Harmonic entry points (ddsp/synths.py:59-66 ctor kwargs) ------- */
+#define DDSP_HARM_SCALE_EXP_SIGMOID 0x1u  /* scale_fn=core.exp_sigmoid (else scale_fn=None) */
+#define DDSP_HARM_NORMALIZE_NYQUIST 0x2u  /* normalize_below_nyquist=True */
+#define DDSP_HARM_AMP_LINEAR 0x4u         /* amp_resample_method='linear' (else 'window') */
+#define DDSP_HARM_ANGULAR_CUMSUM 0x8u     /* use_angular_cumsum=True (phase) */
+
+/* ---- flags for the FilteredNoise entry points (ddsp/synths.py:153-163) ------------ */
+#define DDSP_NOISE_SCALE_EXP_SIGMOID 0x1u /* scale_fn=core.exp_sigmoid on (mag + initial_bias) */
+
+/* Library / build identification: "ddsp_amd <version> gfx950". */
+const char* ddsp_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Harmonic.get_controls  (ddsp/synths.py:94-121; core.exp_sigmoid core.py:386-404,
+ * core.normalize_harmonics core.py:894-907, remove_above_nyquist core.py:869-891,
+ * safe_divide core.py:207-210).
+ *   amplitudes            [B,F,1]  in
+ *   harmonic_distribution [B,F,K]  in
+ *   f0_hz                 [B,F,1]  in
+ *   ctl_amplitudes        [B,F,1]  out
+ *   ctl_harmonic_distribution [B,F,K] out
+ * flags: DDSP_HARM_SCALE_EXP_SIGMOID, DDSP_HARM_NORMALIZE_NYQUIST.
+ */
+int ddsp_harmonic_controls_f32(const float* amplitudes, const float* harmonic_distribution,
+                               const float* f0_hz, float* ctl_amplitudes,
+                               float* ctl_harmonic_distribution, int B, int F, int K,
+                               int sample_rate, unsigned flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Harmonic.get_signal  (ddsp/synths.py:123-146 -> core.harmonic_synthesis
+ * core.py:1048-1111: get_harmonic_frequencies :1028-1045, resample 'linear' :573-642,
+ * upsample_with_windows :645-714, oscillator_bank :912-962, angular_cumsum :800-866).
+ * Inputs are CONTROLS (already scaled / normalised).  audio [B,N] out.
+ * flags: DDSP_HARM_AMP_LINEAR, DDSP_HARM_ANGULAR_CUMSUM.
+ * Requires N % F == 0 (the reference requires it for 'window'; DDSP_ERR_UNSUPPORTED
+ * otherwise).
+ */
+size_t ddsp_harmonic_workspace_bytes(int B, int F, int K, int N);
+int ddsp_harmonic_signal_f32(const float* ctl_amplitudes,
+                             const float* ctl_harmonic_distribution, const float* f0_hz,
+                             float* audio, void* workspace, size_t workspace_bytes, int B,
+                             int F, int K, int N, int sample_rate, unsigned flags,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Harmonic.__call__  == get_signal(**get_controls(...))  (ddsp/processors.py:53-68),
+ * fused: raw network outputs in, audio out, the [B,F,K] controls never round-trip
+ * through fp32 HBM tensors unless the caller asks for them.
+ *   ctl_amplitudes / ctl_harmonic_distribution: NULL, or out buffers that receive the
+ *   controls dict (return_outputs_dict=True).
+ * flags: all DDSP_HARM_*.
+ */
+int ddsp_harmonic_f32(const float* amplitudes, const float* harmonic_distribution,
+                      const float* f0_hz, float* audio, float* ctl_amplitudes,
+                      float* ctl_harmonic_distribution, void* workspace,
+                      size_t workspace_bytes, int B, int F, int K, int N, int sample_rate,
+                      unsigned flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FilteredNoise.get_controls  (ddsp/synths.py:165-179):
+ *   ctl_magnitudes[B,F,M] = exp_sigmoid(magnitudes + initial_bias)   (or identity copy).
+ */
+int ddsp_filtered_noise_controls_f32(const float* magnitudes, float* ctl_magnitudes, int B,
+                                     int F, int M, float initial_bias, unsigned flags,
+                                     void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * core.frequency_impulse_response  (ddsp/core.py:1534-1565 +
+ * apply_window_to_impulse_response :1477-1531): ctl magnitudes [B,F,M] -> causal,
+ * windowed FIR taps [B,F,L].  ddsp_fir_size() gives L for (M, window_size).
+ */
+int ddsp_fir_size(int M, int window_size);
+int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* impulse_response,
+                                        int B, int F, int M, int window_size, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FilteredNoise.get_signal  (ddsp/synths.py:181-196 -> core.frequency_filter
+ * core.py:1628-1655 -> fft_convolve :1382-1473, crop_and_compensate_delay :1338-1379).
+ *   magnitudes [B,F,M]: raw (flags has DDSP_NOISE_SCALE_EXP_SIGMOID: get_controls is
+ *                       fused in) or controls (flag clear: pure get_signal).
+ *   noise      [B,N] or NULL.  NULL: uniform noise in [-1,1) is generated on chip
+ *              (Philox4x32-10, counter=(sample/4, batch_offset+row), key=seed), the
+ *              stand-in for the reference's tf.random.uniform (synths.py:192-193).
+ *              Non-NULL is the parity entry: the same maths as effects.FIRFilter
+ *              (ddsp/effects.py:311-324) / core.frequency_filter on supplied audio.
+ *   audio      [B,N] out.   ctl_magnitudes: NULL or [B,F,M] out (controls dict).
+ * Frames: frame_size = ceil(N/F) and ceil(N/frame_size) must equal F (the reference's
+ * ValueError, core.py:1451-1457) else DDSP_ERR_BAD_SHAPE.
+ */
+size_t ddsp_filtered_noise_workspace_bytes(int B, int F, int M, int N, int window_size);
+int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* audio,
+                            float* ctl_magnitudes, void* workspace, size_t workspace_bytes,
+                            int B, int F, int M, int N, int window_size, float initial_bias,
+                            unsigned flags, uint64_t seed, uint64_t batch_offset,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * core.fft_convolve(audio, impulse_response, padding='same', delay_compensation)
+ * (ddsp/core.py:1382-1473) evaluated as the equivalent direct time-varying FIR.
+ *   audio [B,N], impulse_response [Bir,F,L] with Bir == B or Bir == 1 (broadcast,
+ *   core.py:1433-1434), out [B,N].  delay_compensation < 0 selects (L-1)/2 - 1.
+ */
+int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response, float* out,
+                               int B, int Bir, int F, int L, int N, int delay_compensation,
+                               void* stream);
+
+/* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
+int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
+                           void* stream);
+
+/* processors.Add.get_signal (ddsp/processors.py:174-176): out = a + b, n elements. */
+int ddsp_add_f32(const float* signal_one, const float* signal_two, float* out, size_t n,
+                 void* stream);
+
+/* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
+int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
+                         float max_value, float threshold, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tracing (the reference has none beyond wall-clock logs): opt-in
+ * HIP-event brackets around individual kernels, recorded on the stream they are launched
+ * on.  ddsp_profile_begin(mask, max_records) turns it on for the kernels whose bit is set
+ * in `mask` (bit i = kernel id i, names via ddsp_profile_kernel_name); ddsp_profile_end
+ * synchronises the recorded events, fills total_ms[ddsp_profile_kernel_count()] and
+ * counts[...], and turns tracing off.  Not for use under stream capture.
+ */
+int ddsp_profile_kernel_count(void);
+const char* ddsp_profile_kernel_name(int kernel_id);
+int ddsp_profile_begin(unsigned kernel_mask, int max_records);
+int ddsp_profile_end(double* total_ms, int* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDSP_AMD_H_ */

@@ -1,0 +1,102 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every declared symbol,
+argument checks raise the reference's errors, and the product path fails loudly (no CPU
+fallback) when there is no GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from ddsp_amd import _lib, core, processors, synths
+from ddsp_amd import build as build_mod
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+  build_mod.build()
+  return _lib.load()
+
+
+def test_library_exports_every_symbol_declared_in_the_header(lib):
+  header = open(os.path.join(ROOT, 'include', 'ddsp_amd.h')).read()
+  header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+  declared = set(re.findall(r'\b(ddsp_[a-z0-9_]+)\s*\(', header))
+  assert declared, 'no declarations parsed'
+  assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+  for name in declared:
+    assert hasattr(lib, name), name
+  assert b'gfx950' in lib.ddsp_version()
+
+
+def test_fir_size_matches_reference_rule(lib):          # core_test.py:825-855
+  assert lib.ddsp_fir_size(1025, 257) == 257
+  assert lib.ddsp_fir_size(1025, 256) == 255
+  assert lib.ddsp_fir_size(1025, 0) == 2048
+  assert lib.ddsp_fir_size(513, 1025 + 100) == 1024
+  assert lib.ddsp_fir_size(65, 257) == 128               # ae.gin shape: window > ir size
+
+
+def test_workspace_queries(lib):
+  assert lib.ddsp_harmonic_workspace_bytes(128, 1000, 100, 64000) == 128 * 1001 * 112 * 4
+  assert lib.ddsp_filtered_noise_workspace_bytes(128, 1000, 65, 64000, 0) == 128 * 1000 * 128 * 4
+  assert lib.ddsp_harmonic_workspace_bytes(0, 10, 10, 10) == 0
+
+
+def test_null_pointers_and_bad_shapes_return_codes(lib):
+  assert lib.ddsp_add_f32(None, None, None, 16, None) == -1
+  assert lib.ddsp_harmonic_controls_f32(None, None, None, None, None, 1, 1, 1, 16000, 0, None) == -1
+  assert lib.ddsp_uniform_noise_f32(None, 1, 1, 0, 0, None) == -1
+  assert lib.ddsp_fir_size(1, 0) == -2
+
+
+def test_amp_method_errors_match_reference():           # core_test.py:295-381
+  with pytest.raises(ValueError, match='is invalid'):
+    core._check_amp_method('bogus', 10, 100)
+  with pytest.raises(ValueError, match='divisible'):
+    core._check_amp_method('window', 10, 105)
+  with pytest.raises(ValueError, match='downsampling'):
+    core._check_amp_method('window', 10, 5)
+  with pytest.raises(NotImplementedError):
+    core._check_amp_method('cubic', 10, 100)
+  core._check_amp_method('window', 10, 100)
+  core._check_amp_method('linear', 10, 100)
+
+
+def test_frame_count_error_matches_reference():         # core_test.py:868-886
+  with pytest.raises(ValueError, match='do not match'):
+    core._check_frames(100, 30)
+  core._check_frames(100, 7)                              # ragged but consistent (pad_end)
+  core._check_frames(64000, 1000)
+
+
+def test_constructor_defaults_match_reference():        # synths.py:59-66, 153-163
+  h = synths.Harmonic()
+  assert (h.n_samples, h.sample_rate, h.normalize_below_nyquist, h.amp_resample_method,
+          h.use_angular_cumsum, h.name) == (64000, 16000, True, 'window', False, 'harmonic')
+  assert h.scale_fn is core.exp_sigmoid
+  n = synths.FilteredNoise()
+  assert (n.n_samples, n.window_size, n.initial_bias, n.name) == (64000, 257, -5.0,
+                                                                  'filtered_noise')
+  assert processors.Add().name == 'add'
+  for cls in (synths.Harmonic, synths.FilteredNoise, processors.Add):
+    assert hasattr(cls, 'get_controls') and hasattr(cls, 'get_signal')   # dags.py:44 duck typing
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_no_gpu_fails_loudly_not_silently():
+  h = synths.Harmonic(n_samples=640)
+  with pytest.raises(_lib.DdspLibraryError, match='no CPU fallback'):
+    h(np.zeros((1, 10, 1)), np.zeros((1, 10, 4)), np.full((1, 10, 1), 100.0))
+
+
+def test_product_package_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'ddsp_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.h')):
+        text = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle|#include\s+[<"].*oracle', text, re.M), \
+            os.path.join(dirpath, f)

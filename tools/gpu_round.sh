@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU-box session: microbench, parity tests, smoke, bench, rocprof kernel trace.
+# Usage (from the build container): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
+if [ -x tools/microbench ]; then echo "== microbench"; timeout 120 tools/microbench 2>&1 | tee $OUT/microbench.txt; fi
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 | tee $OUT/pytest_gpu.txt
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
+echo "== bench (batch 32)"
+timeout 600 python bench.py --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_b32.json
+echo "== bench (batch 128)"
+timeout 600 python bench.py --steps 10 --warmup 3 --batch 128 --no-cpu-baseline 2>&1 | tail -3 | tee $OUT/bench_b128.json
+echo "== rocprofv3 kernel trace"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+ls -R $OUT/prof | head -20
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -2); do echo "--- $f"; head -15 $f; done
