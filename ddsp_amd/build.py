@@ -24,7 +24,7 @@ def build(force=False, verbose=True):
     return OUT
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
   os.makedirs(os.path.dirname(OUT), exist_ok=True)
-  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize',
          '-I' + os.path.join(ROOT, 'include')]
   cmd += [os.path.join(HERE, 'csrc', s) for s in SOURCES]
   cmd += ['-o', OUT]

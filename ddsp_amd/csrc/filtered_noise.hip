@@ -177,6 +177,254 @@ __global__ __launch_bounds__(256) void tv_fir_kernel(FirArgs p) {
   }
 }
 
+// ====================================================================================
+// Fast path for the canonical shape (ae.gin): M = 65 bands -> 128-point zero-phase IR,
+// full-length Hann window (window_size <= 0 or >= 128), frame_size = 64, L = 128.
+// ====================================================================================
+
+// ---- compile-time cosine tables -----------------------------------------------------
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double cos_taylor(double x) {        // |x| <= pi/4
+  double x2 = x * x, term = 1.0, sum = 1.0;
+  for (int i = 1; i <= 12; ++i) { term *= -x2 / ((2 * i - 1) * (2 * i)); sum += term; }
+  return sum;
+}
+constexpr double sin_taylor(double x) {        // |x| <= pi/4
+  double x2 = x * x, term = x, sum = x;
+  for (int i = 1; i <= 12; ++i) { term *= -x2 / ((2 * i) * (2 * i + 1)); sum += term; }
+  return sum;
+}
+constexpr double cos_q128(int q) {             // cos(2 pi q / 128), exact octant reduction
+  q = ((q % 128) + 128) % 128;
+  if (q > 64) q = 128 - q;                     // cos(2pi - x) = cos x        -> q in [0,64]
+  bool neg = false;
+  if (q > 32) { q = 64 - q; neg = true; }      // cos(pi - x) = -cos x        -> q in [0,32]
+  const double v = (q <= 16) ? cos_taylor(2.0 * kPi * q / 128.0)
+                             : sin_taylor(2.0 * kPi * (32 - q) / 128.0);   // cos x = sin(pi/2 - x)
+  return neg ? -v : v;
+}
+constexpr int kIrRowStride = 80;               // floats per table row (16-dword aligned halves)
+struct Ir65Table {
+  // row n (0..32): [0..32] = w_m * cos(2 pi (2i) n / 128) for even m = 2i,
+  //                [40..71] = w_m * cos(2 pi (2i+1) n / 128) for odd m = 2i+1,
+  // w_m = irfft weight: 1/128 for the DC and Nyquist bins, 2/128 otherwise.
+  float c[33 * kIrRowStride];
+  float win[64];                               // Hann(128)[64 + d] = 0.5 + 0.5 cos(2 pi d / 128)
+};
+constexpr Ir65Table make_ir65_table() {
+  Ir65Table t{};
+  for (int n = 0; n <= 32; ++n) {
+    for (int i = 0; i <= 32; ++i) {
+      const int m = 2 * i;
+      const double w = (m == 0 || m == 64) ? 1.0 / 128.0 : 2.0 / 128.0;
+      t.c[n * kIrRowStride + i] = (float)(w * cos_q128(m * n));
+    }
+    for (int i = 0; i < 32; ++i) {
+      const int m = 2 * i + 1;
+      t.c[n * kIrRowStride + 40 + i] = (float)((2.0 / 128.0) * cos_q128(m * n));
+    }
+  }
+  for (int d = 0; d < 64; ++d) t.win[d] = (float)(0.5 + 0.5 * cos_q128(d));
+  return t;
+}
+__constant__ Ir65Table kIr65 = make_ir65_table();
+
+// ---- IR design, lanes = frames --------------------------------------------------------
+// One block = 64 consecutive (batch*frame) rows, 4 wavefronts.  Every lane keeps ITS row's 65
+// magnitudes in registers; the cosine factor of (band m, tap n) is wave-uniform and comes from
+// the constant table through scalar loads, so the inner product is pure v_fmac with an SGPR
+// operand and no LDS traffic.  hz[-n] = hz[n] and cos(2 pi m (64-n)/128) = (-1)^m cos(2 pi m n/128)
+// give taps n and 64-n from one even-m and one odd-m partial sum.  h[64 +- d] = win[d]*hz[d],
+// h[0] = 0.  The four wavefronts split n = 0..32.
+__global__ __launch_bounds__(256) void noise_ir65_kernel(const float* __restrict__ mag,
+                                                         float* __restrict__ ctl_out,
+                                                         float* __restrict__ ir, long rows,
+                                                         float bias, int scale) {
+  __shared__ float s_m[64 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long r0 = (long)blockIdx.x * 64;
+  const int nrows = (int)min((long)64, rows - r0);
+  const float kLog10 = 2.302585092994046f;
+  const float* __restrict__ src = mag + r0 * 65;
+  for (int i = tid; i < nrows * 65; i += 256) {
+    float x = src[i];
+    if (scale) x = exp_sigmoid(x + bias, kLog10, 2.0f, 1e-7f);
+    if (ctl_out) ctl_out[r0 * 65 + i] = x;
+    s_m[i] = x;
+  }
+  for (int i = nrows * 65 + tid; i < 64 * 65; i += 256) s_m[i] = 0.0f;
+  __syncthreads();
+  float me[33], mo[32];
+#pragma unroll
+  for (int i = 0; i <= 32; ++i) me[i] = s_m[lane * 65 + 2 * i];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) mo[i] = s_m[lane * 65 + 2 * i + 1];
+  __syncthreads();                               // s_m is reused for the taps below
+  for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += 4) {
+    const float* __restrict__ ce = kIr65.c + n * kIrRowStride;
+    const float* __restrict__ co = ce + 40;
+    float e = 0.0f, o = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= 32; ++i) e = fmaf(me[i], ce[i], e);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o = fmaf(mo[i], co[i], o);
+    s_m[lane * 65 + n] = kIr65.win[n] * (e + o);                 // g[n],    n in [0,32]
+    if (n >= 1 && n < 32) s_m[lane * 65 + 64 - n] = kIr65.win[64 - n] * (e - o);   // g[64-n]
+  }
+  __syncthreads();
+  // coalesced write of the 128 causal taps per row: h[kappa] = g[|kappa - 64|], h[0] = 0
+  float4* __restrict__ dst = reinterpret_cast<float4*>(ir + r0 * 128);
+  for (int i = tid; i < nrows * 32; i += 256) {
+    const int row = i >> 5, k4 = (i & 31) * 4;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kappa = k4 + u;
+      const int d = kappa >= 64 ? kappa - 64 : 64 - kappa;
+      v[u] = (kappa == 0) ? 0.0f : s_m[row * 65 + d];
+    }
+    dst[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---- FIR, register tiled -------------------------------------------------------------------
+// z[m] = sum_k x[m-k] h_{frame(m-k)}[k].  A lane owns kFirR = 16 consecutive outputs; the
+// 128 taps are walked in 8 blocks of 16.  For tap block k0 the inputs are the 31 samples
+// x[i0-16 .. i0+15], i0 = m0 - k0: the upper half belongs to frame(i0) and the lower half to
+// frame(i0-16) (i0 is a multiple of 16 and frames are 64 long), so the 16x16 product splits
+// into the triangle r >= c fed by frame(i0)'s taps and r < c fed by frame(i0-16)'s taps:
+// 256 FMAs per 12 ds_read_b128, exactly 128 FMAs per output sample, no per-sample selects.
+// LDS: x tile in four 16-byte-chunk planes (lane stride 64 B would be a 4-way conflict), tap
+// rows padded to 132 dwords (the 16 frames a wavefront touches land on distinct bank quads).
+constexpr int kFirR = 16;
+constexpr int kFirWaves = 2;
+constexpr int kFirTile = 64 * kFirR * kFirWaves;        // 2048 z-samples per block
+constexpr int kFirFrames = kFirTile / 64 + 2;           // 34 tap rows
+constexpr int kTapStride = 132;
+constexpr int kFirXLen = kFirTile + 128;                // x[z0-128 .. z0+2047]
+constexpr int kFirPlane = kFirXLen / 4;                 // dwords per x plane
+
+__device__ __forceinline__ int fir_x_addr(int ip) {      // ip = i - (z0 - 128), dword address
+  const int c = ip >> 2;
+  return (c & 3) * kFirPlane + ((c >> 2) << 2) + (ip & 3);
+}
+
+__device__ __forceinline__ void fir_load16(const float* s_x, int ip, float (&v)[16]) {
+  const int chunk = ip >> 2;                               // ip is a multiple of 16
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const int c = chunk + c4;
+    const float4 t = *reinterpret_cast<const float4*>(&s_x[(c & 3) * kFirPlane + ((c >> 2) << 2)]);
+    v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
+  }
+}
+
+// one 16-tap block: hi = x[i0 .. i0+15] (already loaded), lo = x[i0-16 .. i0-1] (loaded here)
+__device__ __forceinline__ void fir_tap_block(const float* s_x, const float* s_h, int irel, int k0,
+                                              float (&acc)[16], const float (&hi)[16],
+                                              float (&lo)[16]) {
+  // frame(i0) and frame(i0-16) as tap-row indices (row 0 = frame J0-2); irel = i0 - z0 >= -112
+  const int rowA = (irel + 128) >> 6;
+  const int rowB = (irel + 112) >> 6;
+  fir_load16(s_x, irel + 128 - 16, lo);
+  float ta[16], tb[16];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const float4 va = *reinterpret_cast<const float4*>(&s_h[rowA * kTapStride + k0 + 4 * c4]);
+    const float4 vb = *reinterpret_cast<const float4*>(&s_h[rowB * kTapStride + k0 + 4 * c4]);
+    ta[4 * c4] = va.x; ta[4 * c4 + 1] = va.y; ta[4 * c4 + 2] = va.z; ta[4 * c4 + 3] = va.w;
+    tb[4 * c4] = vb.x; tb[4 * c4 + 1] = vb.y; tb[4 * c4 + 2] = vb.z; tb[4 * c4 + 3] = vb.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r >= c) acc[r] = fmaf(ta[c], hi[r - c], acc[r]);          // input i0 + (r-c)
+      else        acc[r] = fmaf(tb[c], lo[16 + r - c], acc[r]);     // input i0 - (c-r)
+    }
+  }
+}
+
+struct Fir128Args {
+  int N, F, start;
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+};
+
+template <bool GEN_NOISE>
+__global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
+    const float* __restrict__ x /*[B,N] or null*/, const float* __restrict__ ir /*[B,F,128]*/,
+    float* __restrict__ out /*[B,N]*/, Fir128Args p) {
+  __shared__ __attribute__((aligned(16))) float s_x[kFirXLen];
+  __shared__ __attribute__((aligned(16))) float s_h[kFirFrames * kTapStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int z0 = blockIdx.x * kFirTile;
+  const int J0 = z0 / 64;
+
+  // ---- stage x: quads, zero outside [0,N) ---------------------------------------------------
+  for (int qd = tid; qd < kFirXLen / 4; qd += 64 * kFirWaves) {
+    const int i = z0 - 128 + 4 * qd;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < p.N) {
+      if (GEN_NOISE) {
+        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
+                                   p.k0, p.k1);
+        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+        if (i + 3 >= p.N) {
+          if (i + 1 >= p.N) v.y = 0.f;
+          if (i + 2 >= p.N) v.z = 0.f;
+          v.w = 0.f;
+        }
+      } else {
+        const float* src = x + (size_t)b * p.N + i;
+        if (i + 3 < p.N && ((p.N & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (i + 1 < p.N) v.y = src[1];
+          if (i + 2 < p.N) v.z = src[2];
+          if (i + 3 < p.N) v.w = src[3];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(&s_x[fir_x_addr(4 * qd)]) = v;
+  }
+  // ---- stage tap rows J0-2 .. J0+31 (zeros outside [0,F)) -----------------------------------
+  for (int t = tid; t < kFirFrames * 32; t += 64 * kFirWaves) {
+    const int row = t >> 5, k4 = (t & 31) * 4;
+    const int f = J0 - 2 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f >= 0 && f < p.F)
+      v = *reinterpret_cast<const float4*>(ir + ((size_t)b * p.F + f) * 128 + k4);
+    *reinterpret_cast<float4*>(&s_h[row * kTapStride + k4]) = v;
+  }
+  __syncthreads();
+
+  // ---- 16 outputs per lane ---------------------------------------------------------------------
+  const int mrel = wave * (64 * kFirR) + lane * kFirR;    // m0 - z0
+  float acc[kFirR];
+#pragma unroll
+  for (int r = 0; r < kFirR; ++r) acc[r] = 0.0f;
+
+  float xa[16], xb[16];                   // x[i0 .. i0+15] and x[i0-16 .. i0-1], roles alternate
+  fir_load16(s_x, mrel + 128, xa);                         // i0 - (z0 - 128) at k0 = 0
+#pragma unroll 1
+  for (int kb = 0; kb < 8; kb += 2) {                      // two tap blocks per trip: ping-pong
+    fir_tap_block(s_x, s_h, mrel - 16 * kb, 16 * kb, acc, xa, xb);
+    fir_tap_block(s_x, s_h, mrel - 16 * (kb + 1), 16 * (kb + 1), acc, xb, xa);
+  }
+
+  // ---- out[n] = z[n + start] ---------------------------------------------------------------------
+  const long nbase = (long)z0 + mrel - p.start;
+  float* __restrict__ o = out + (size_t)b * p.N;
+#pragma unroll
+  for (int r = 0; r < kFirR; ++r) {
+    const long n = nbase + r;
+    if (n >= 0 && n < p.N) o[n] = acc[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
                                                   const float* __restrict__ b,
                                                   float* __restrict__ out, size_t n) {
@@ -238,6 +486,13 @@ extern "C" int ddsp_filtered_noise_controls_f32(const float* magnitudes, float* 
 static int launch_ir(const float* mag, float* ctl_out, float* ir, int B, int F, int M,
                      int window_size, float bias, int scale, hipStream_t st) {
   const IrGeom g = ir_geom(M, window_size);
+  if (M == 65 && g.padding == 0) {                 // canonical shape: lanes = frames
+    const long rows65 = (long)B * F;
+    ProfileScope prof(kNoiseIr, st);
+    hipLaunchKernelGGL(noise_ir65_kernel, dim3((unsigned)((rows65 + 63) / 64)), dim3(256), 0, st,
+                       mag, ctl_out, ir, rows65, bias, scale);
+    return check_launch();
+  }
   const size_t lds = (size_t)(g.L0 + M) * sizeof(float);
   if (lds > kMaxDynLds) return DDSP_ERR_UNSUPPORTED;
   const long rows = (long)B * F;
@@ -269,6 +524,16 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
   p.ir_batch_stride = (Bir == 1) ? 0 : (size_t)F * L;
   p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
   p.batch_offset = batch_offset;
+  if (L == 128 && p.frame_size == 64 && Bir == B && (((uintptr_t)ir) & 15) == 0 &&
+      (x == nullptr || (((uintptr_t)x) & 15) == 0)) {
+    Fir128Args q;
+    q.N = N; q.F = F; q.start = p.start; q.k0 = p.k0; q.k1 = p.k1; q.batch_offset = batch_offset;
+    const dim3 grid((unsigned)((N + p.start + kFirTile - 1) / kFirTile), (unsigned)B);
+    ProfileScope prof(kTvFir, st);
+    if (x) hipLaunchKernelGGL((tv_fir128_kernel<false>), grid, dim3(64 * kFirWaves), 0, st, x, ir, out, q);
+    else hipLaunchKernelGGL((tv_fir128_kernel<true>), grid, dim3(64 * kFirWaves), 0, st, x, ir, out, q);
+    return check_launch();
+  }
   // tile: as many outputs as keep x + taps under the LDS budget
   int tile = 1024;
   size_t lds = 0;

@@ -222,7 +222,7 @@ def test_harmonic_nyquist_crossing_between_frames(ddsp):
   assert np.abs(ours - faithful).max() <= HARM_FAITHFUL_ATOL
 
 
-@pytest.mark.parametrize('m,ws,n_frames,n', [(2, 0, 4, 64), (9, 0, 7, 100), (65, 0, 1, 300),
+@pytest.mark.parametrize('m,ws,n_frames,n', [(3, 0, 4, 64), (9, 0, 7, 100), (65, 0, 1000, 64000), (65, 0, 3, 192), (65, 0, 1, 300),
                                              (65, 257, 10, 640), (129, 65, 5, 1000),
                                              (1025, 257, 1, 4096), (33, 17, 16, 4096)])
 def test_filtered_noise_edge_shapes(ddsp, m, ws, n_frames, n):
