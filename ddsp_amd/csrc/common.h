@@ -23,6 +23,50 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// ---- DPP reductions: no LDS round trip (ds_bpermute costs ~100 cycles per dependent step) ---------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v) {    // lanes outside ROW_MASK read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 64 lanes, result in every lane (as a wave-uniform SGPR value)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov0<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov0<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov0<0x141, 0xF>(v);    // row_half_mirror
+  v += dpp_mov0<0x140, 0xF>(v);    // row_mirror: every lane holds its 16-lane row's sum
+  v += dpp_mov0<0x142, 0xA>(v);    // row_bcast:15 -> rows 1,3
+  v += dpp_mov0<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov0(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_mov0<0xB1, 0xF>(v);
+  v += dpp_mov0<0x4E, 0xF>(v);
+  v += dpp_mov0<0x141, 0xF>(v);
+  v += dpp_mov0<0x140, 0xF>(v);
+  v += dpp_mov0<0x142, 0xA>(v);
+  v += dpp_mov0<0x143, 0xC>(v);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// branch-free core.exp_sigmoid for the default constants' shape: the limits are right on both
+// tails (x -> -inf: exp2 overflows to +inf, log2(inf) = inf, exp2(-inf) = 0; x -> +inf: 1).
+__device__ __forceinline__ float exp_sigmoid_fast(float x, float log_exponent, float max_value,
+                                                  float threshold) {
+  const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);          // e^-x
+  const float l2 = __builtin_amdgcn_logf(1.0f + e);                          // log2(1 + e^-x)
+  return fmaf(max_value, __builtin_amdgcn_exp2f(-log_exponent * l2), threshold);
+}
+
 // core.exp_sigmoid (ddsp/core.py:386-404): max_value * sigmoid(x)**log(exponent) + threshold.
 // sigmoid(x)**p == exp(-p * softplus(-x)); evaluated with the hardware exp2/log2
 // (v_exp_f32 / v_log_f32), relative error ~1e-6, far below the parity tolerance.

@@ -425,6 +425,191 @@ __global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
   }
 }
 
+// ---- fused FilteredNoise for the canonical shape: IR design + noise + FIR in ONE launch -------
+// One block = kFnFrames = 62 output frames (3968 samples) of one batch row, 4 wavefronts.
+//   1. the 64 magnitude rows of frames J0-2 .. J0+61 (contiguous in HBM) -> exp_sigmoid -> LDS
+//   2. lanes = frames: every wavefront holds the 64 rows' magnitudes in registers and designs
+//      its share of the taps n = 0..32 (cosines from the constant table through scalar loads);
+//      the windowed taps go straight into the LDS tap table the FIR reads - they never touch HBM
+//   3. the noise tile x[z0-128 .. z0+3967] is generated by Philox into LDS (or copied from HBM)
+//   4. register-tiled FIR as tv_fir128_kernel (16 outputs per lane, 248 of 256 lanes busy)
+//   5. outputs are transposed through LDS and stored as coalesced 8-byte pieces.
+constexpr int kFnFrames = 62;
+constexpr int kFnTile = kFnFrames * 64;                 // 3968 z-samples per block
+constexpr int kFnXLen = kFnTile + 128;                  // 4096
+constexpr int kFnPlane = kFnXLen / 4;                   // 1024 dwords per plane
+constexpr int kFnUnion = 64 * 65;                       // floats: magnitude staging / x tile / out
+
+__device__ __forceinline__ void fn_load16(const float* s_x, int ip, float (&v)[16]) {
+  const int chunk = ip >> 2;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const int c = chunk + c4;
+    const float4 t = *reinterpret_cast<const float4*>(&s_x[(c & 3) * kFnPlane + ((c >> 2) << 2)]);
+    v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void fn_tap_block(const float* s_x, const float* s_h, int irel, int k0,
+                                             float (&acc)[16], const float (&hi)[16],
+                                             float (&lo)[16]) {
+  const int rowA = (irel + 128) >> 6;           // frame(i0)    - (J0-2)
+  const int rowB = (irel + 112) >> 6;           // frame(i0-16) - (J0-2)
+  fn_load16(s_x, irel + 128 - 16, lo);
+  float ta[16], tb[16];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const float4 va = *reinterpret_cast<const float4*>(&s_h[rowA * kTapStride + k0 + 4 * c4]);
+    const float4 vb = *reinterpret_cast<const float4*>(&s_h[rowB * kTapStride + k0 + 4 * c4]);
+    ta[4 * c4] = va.x; ta[4 * c4 + 1] = va.y; ta[4 * c4 + 2] = va.z; ta[4 * c4 + 3] = va.w;
+    tb[4 * c4] = vb.x; tb[4 * c4 + 1] = vb.y; tb[4 * c4 + 2] = vb.z; tb[4 * c4 + 3] = vb.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r >= c) acc[r] = fmaf(ta[c], hi[r - c], acc[r]);
+      else        acc[r] = fmaf(tb[c], lo[16 + r - c], acc[r]);
+    }
+  }
+}
+
+struct FusedNoiseArgs {
+  int N, F, start, scale;
+  float bias;
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+};
+
+template <bool GEN_NOISE>
+__global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
+    const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
+    float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/,
+    FusedNoiseArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_u[kFnUnion];
+  __shared__ __attribute__((aligned(16))) float s_h[64 * kTapStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int z0 = blockIdx.x * kFnTile;
+  const int J0 = blockIdx.x * kFnFrames;
+  const float kLog10 = 2.302585092994046f;
+
+  // ---- 1. magnitude rows of frames J0-2 .. J0+61 -------------------------------------------------
+  {
+    const int f_first = J0 - 2;
+    const float* __restrict__ src = mag + ((size_t)b * p.F) * 65;
+    float* __restrict__ ctl = ctl_out ? ctl_out + ((size_t)b * p.F) * 65 : nullptr;
+    for (int i = tid; i < 64 * 65; i += 256) {
+      const int row = i / 65;
+      const int f = f_first + row;
+      float v = 0.0f;
+      if (f >= 0 && f < p.F) {
+        const int g = f * 65 + (i - row * 65);
+        v = src[g];
+        if (p.scale) v = exp_sigmoid(v + p.bias, kLog10, 2.0f, 1e-7f);
+        if (ctl && row >= 2) ctl[g] = v;             // rows 0,1 belong to the previous block
+      }
+      s_u[i] = v;
+    }
+  }
+  __syncthreads();
+  // ---- 2. IR design, lanes = frames ------------------------------------------------------------------
+  {
+    float me[33], mo[32];
+#pragma unroll
+    for (int i = 0; i <= 32; ++i) me[i] = s_u[lane * 65 + 2 * i];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mo[i] = s_u[lane * 65 + 2 * i + 1];
+    float* __restrict__ hrow = s_h + lane * kTapStride;
+    if (wave == 0) hrow[0] = 0.0f;                     // h[0] = Hann(128)[0] * hz[-64] = 0
+    for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += 4) {
+      const float* __restrict__ ce = kIr65.c + n * kIrRowStride;
+      const float* __restrict__ co = ce + 40;
+      float e = 0.0f, o = 0.0f;
+#pragma unroll
+      for (int i = 0; i <= 32; ++i) e = fmaf(me[i], ce[i], e);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) o = fmaf(mo[i], co[i], o);
+      const float g0 = kIr65.win[n] * (e + o);         // g[n]:    taps 64+n and 64-n
+      hrow[64 + n] = g0;
+      if (n >= 1) hrow[64 - n] = g0;
+      if (n >= 1 && n < 32) {
+        const float g1 = kIr65.win[64 - n] * (e - o);  // g[64-n]: taps 128-n and n
+        hrow[128 - n] = g1;
+        hrow[n] = g1;
+      }
+    }
+  }
+  __syncthreads();                                      // magnitudes consumed: s_u is free
+  // ---- 3. noise tile x[z0-128 .. z0+3967] into s_u (four 16-byte-chunk planes) ----------------------
+  for (int qd = tid; qd < kFnXLen / 4; qd += 256) {
+    const int i = z0 - 128 + 4 * qd;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < p.N) {
+      if (GEN_NOISE) {
+        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
+                                   p.k0, p.k1);
+        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+        if (i + 1 >= p.N) v.y = 0.f;
+        if (i + 2 >= p.N) v.z = 0.f;
+        if (i + 3 >= p.N) v.w = 0.f;
+      } else {
+        const float* src = x + (size_t)b * p.N + i;
+        if (i + 3 < p.N && ((p.N & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (i + 1 < p.N) v.y = src[1];
+          if (i + 2 < p.N) v.z = src[2];
+          if (i + 3 < p.N) v.w = src[3];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
+  }
+  __syncthreads();
+  // ---- 4. FIR: 16 outputs per lane ---------------------------------------------------------------------
+  const int mrel = tid * kFirR;                          // m0 - z0; lanes 248..255 idle (>= 3968)
+  float acc[kFirR];
+#pragma unroll
+  for (int r = 0; r < kFirR; ++r) acc[r] = 0.0f;
+  if (mrel < kFnTile) {
+    float xa[16], xb[16];
+    fn_load16(s_u, mrel + 128, xa);
+#pragma unroll 1
+    for (int kb = 0; kb < 8; kb += 2) {
+      fn_tap_block(s_u, s_h, mrel - 16 * kb, 16 * kb, acc, xa, xb);
+      fn_tap_block(s_u, s_h, mrel - 16 * (kb + 1), 16 * (kb + 1), acc, xb, xa);
+    }
+  }
+  __syncthreads();                                      // everyone is done reading x
+  // ---- 5. transpose through LDS, coalesced stores: out[n] = z[n + start] ---------------------------
+  if (mrel < kFnTile) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+      *reinterpret_cast<float4*>(&s_u[mrel + 4 * c4]) =
+          make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+  }
+  __syncthreads();
+  float* __restrict__ o = out + (size_t)b * p.N;
+  const long nbase = (long)z0 - p.start;                // out index of tile element 0
+  if (((nbase & 1) == 0) && ((p.N & 1) == 0)) {         // 8-byte aligned pairs
+    for (int e = 2 * tid; e < kFnTile; e += 512) {
+      const long n = nbase + e;
+      if (n >= 0 && n + 1 < p.N) {
+        *reinterpret_cast<float2*>(o + n) = make_float2(s_u[e], s_u[e + 1]);
+      } else {
+        if (n >= 0 && n < p.N) o[n] = s_u[e];
+        if (n + 1 >= 0 && n + 1 < p.N) o[n + 1] = s_u[e + 1];
+      }
+    }
+  } else {
+    for (int e = tid; e < kFnTile; e += 256) {
+      const long n = nbase + e;
+      if (n >= 0 && n < p.N) o[n] = s_u[e];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
                                                   const float* __restrict__ b,
                                                   float* __restrict__ out, size_t n) {
@@ -578,6 +763,23 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
+  {
+    const IrGeom g = ir_geom(M, window_size);
+    const int frame_size = (N + F - 1) / F;
+    if (M == 65 && g.padding == 0 && frame_size == 64 && (N + 63) / 64 == F && B <= 65535 &&
+        (noise == nullptr || (((uintptr_t)noise) & 15) == 0)) {
+      FusedNoiseArgs q;
+      q.N = N; q.F = F; q.start = (g.L - 1) / 2 - 1; q.scale = scale; q.bias = initial_bias;
+      q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
+      const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
+      ProfileScope prof(kTvFir, st);
+      if (noise) hipLaunchKernelGGL((noise_fused65_kernel<false>), grid, dim3(256), 0, st, magnitudes,
+                                    noise, ctl_magnitudes, audio, q);
+      else hipLaunchKernelGGL((noise_fused65_kernel<true>), grid, dim3(256), 0, st, magnitudes,
+                              noise, ctl_magnitudes, audio, q);
+      return check_launch();
+    }
+  }
   float* ir = (float*)workspace;
   int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
   if (rc != DDSP_OK) return rc;

@@ -299,6 +299,321 @@ __global__ __launch_bounds__(kSynthThreads) void harm_synth_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// kernel 3 (the fast path, hop % 64 == 0): controls + phase prefix + synthesis in ONE launch.
+// Persistent blocks; a block takes "units" of kFramesPerBlock frames of one batch row.
+//   phase A  the unit's 17 amplitude rows (16 frames + the next frame, which the last frame
+//            interpolates towards) are computed as in kernel 1 and written to the BLOCK's
+//            private 7.6 KB workspace slot (re-used for every unit, so it lives in this XCD's
+//            L2 and never streams to HBM); an fp64 block reduction over the row's earlier
+//            frames gives the fundamental's phase at the start of each frame; one lane per
+//            frame precomputes everything that is per-frame (phase, slope, live-harmonic counts).
+//   phase B  after s_waitcnt vmcnt(0) + barrier the rows sit in L2; the scalar cache is
+//            invalidated and every wavefront pulls the two rows of its tile with
+//            s_load_dwordx16 (SGPR operands for the 2 FMAs per harmonic, no LDS traffic).
+//            The loads are inline asm: the compiler will not select scalar loads for memory
+//            written earlier in the same kernel.
+//            sin(2 pi h theta): super-blocks of 32 harmonics, four exact seeds, then the
+//            stride-2 recurrence s[h] = 2cos(4 pi theta) s[h-2] - s[h-4] - two independent
+//            chains (odd / even harmonics), which doubles the dependency distance of the FMA
+//            stream (a single chain issues at ~2.9 cycles/instruction, tools/microbench2).
+// ------------------------------------------------------------------------------------
+typedef float sgpr8 __attribute__((ext_vector_type(8)));
+
+// both loads and their wait in one statement (cdna_hip_programming.md 5.7, form (i))
+__device__ __forceinline__ void sload_rows(sgpr8& a0, sgpr8& a1, const float* p0, const float* p1) {
+  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1) : "memory");
+}
+
+// 8 harmonics k+1 .. k+8 in two groups of 4; only the first n4 groups are live (wave-uniform).
+// s[u] holds the latest sine of residue class u = (h-1) mod 4; acc = {a0 even, a1 even, a0 odd, a1 odd}.
+template <bool SEEDS>
+__device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k, int n4,
+                                         float theta, float c4, float (&s)[4], float (&acc)[4]) {
+  sgpr8 a0, a1;
+  sload_rows(a0, a1, p0 + k, p1 + k);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    if (g < n4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * g + u;
+        float sn;
+        if (SEEDS && g == 0) sn = sin_rev(frac_phase(theta, (float)(k + idx + 1)));
+        else sn = fmaf(c4, s[(u + 2) & 3], -s[u]);          // s[h-2], s[h-4]
+        s[u] = sn;
+        acc[2 * (u & 1)] = fmaf(a0[idx], sn, acc[2 * (u & 1)]);
+        acc[2 * (u & 1) + 1] = fmaf(a1[idx], sn, acc[2 * (u & 1) + 1]);
+      }
+    }
+  }
+}
+
+struct FusedArgs {
+  int B, F, K, Kp, N, hop, units_per_row, n_units;
+  float sample_rate, nyquist;
+  unsigned flags;
+  int inputs_are_controls, amp_linear;
+  float inv_K4;                  // 1 / (K/4)
+  double inv_sr, inv_2hop;       // 1/sample_rate, 1/(2*hop)   (host side: no fp64 divisions on chip)
+};
+
+constexpr int kUnitRows = kFramesPerBlock + 1;
+
+// LDS tables of one unit
+struct UnitTables {
+  double ssum;                                           // sum_{j<j0} f0_j
+  double theta[kFramesPerBlock], w[kFramesPerBlock], dw[kFramesPerBlock];
+  float f0[kUnitRows + 3];
+  float2 inv_amp[kUnitRows];                             // {1/sum(distribution), scaled amplitude}
+  int kA[kFramesPerBlock], kN[kFramesPerBlock];
+};
+
+// Phase A runs once per 16 frames but on every wavefront of the chip at the same time, so its
+// cost is its dynamic instruction count x 8 waves per SIMD: everything below is written to be
+// short (16-byte accesses, 32-bit indexing, no divisions, one-wave jobs on different waves).
+template <int NE>   // float4 groups per thread in phase A: NE * 256 >= 17 * K / 4
+__global__ __launch_bounds__(256, 8) void harm_fused_kernel(
+    const float* __restrict__ amplitudes, const float* __restrict__ hd,
+    const float* __restrict__ f0_all, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd,
+    float* ws /*[gridDim.x][17][Kp]*/, float* __restrict__ audio, FusedArgs p) {
+  __shared__ UnitTables t;
+  extern __shared__ __attribute__((aligned(16))) float s_x[];     // [17 * K] scaled distribution
+  // debug timeline (flag 0x02000000): ctl_amp is reinterpreted as long long [gridDim.x][16]
+  const bool dbg_time = (p.flags & 0x02000000u) != 0;
+  long long* dbg = dbg_time ? reinterpret_cast<long long*>(ctl_amp) + (size_t)blockIdx.x * 16 : nullptr;
+  int dbg_n = 0;
+#define DDSP_STAMP() do { if (dbg_time && threadIdx.x == 0 && dbg_n < 16) dbg[dbg_n++] = wall_clock64(); } while (0)
+  if (dbg_time) ctl_amp = nullptr;
+  DDSP_STAMP();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int F = p.F, K = p.K, Kp = p.Kp;
+  const int K4 = K >> 2;                               // K % 4 == 0 on this path
+  float* wsu = ws + (size_t)blockIdx.x * kUnitRows * Kp;
+  const bool scale = (p.flags & DDSP_HARM_SCALE_EXP_SIGMOID) && !p.inputs_are_controls;
+  const bool normalize = (p.flags & DDSP_HARM_NORMALIZE_NYQUIST) && !p.inputs_are_controls;
+  const float kLog10 = 2.302585092994046f;      // tf.math.log(exponent), ddsp/core.py:403
+  const int n_grp = kUnitRows * K4;                    // float4 groups of one unit
+
+  // (b, c) = (batch row, unit inside the row), advanced without divisions
+  int b = blockIdx.x / p.units_per_row;
+  int c = blockIdx.x - b * p.units_per_row;
+  const int db = gridDim.x / p.units_per_row, dc = gridDim.x - db * p.units_per_row;
+
+  for (int unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
+    const int j0 = c * kFramesPerBlock;
+    const int nfr = min(kFramesPerBlock, F - j0);
+    const int row0 = b * F + j0;                                          // first (batch*frame) row
+    const float* __restrict__ f0 = f0_all + (size_t)b * F;
+    // the unit's rows are contiguous in HBM: 16-byte accesses
+    const float4* __restrict__ hd_u = reinterpret_cast<const float4*>(hd) + (size_t)row0 * K4;
+    float4* __restrict__ ctl_hd_u = ctl_hd ? reinterpret_cast<float4*>(ctl_hd) + (size_t)row0 * K4 : nullptr;
+    const int halo_grp = (min(j0 + nfr, F - 1) - j0) * K4;              // halo row (clamped at F-1)
+
+    // ---------------- phase A.1: loads (scalars first: vmcnt retires in order) -------------------
+    float my_amp = 0.0f, my_f0 = 0.0f;
+    if (tid < kUnitRows) {                                               // thread q owns row q
+      const int j = min(j0 + min(tid, nfr), F - 1);
+      my_f0 = f0[j];
+      my_amp = amplitudes[(size_t)b * F + j];
+    }
+    // Phase prefix, fp64, on wave 3 only.  Frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop
+    // (legacy bilinear resize of f0), whose sum over the frame is hop*f_j + (f_{j+1}-f_j)(hop-1)/2;
+    // summed over j < J this telescopes to hop*sum_{j<J} f_j + (f_J - f_0)(hop-1)/2.
+    float pf[16];
+    if (wave == 3) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {                   // all loads in flight together (j0 <= 1024)
+        const int j = lane + 64 * u;
+        pf[u] = (j < j0) ? f0[j] : 0.0f;
+      }
+    }
+    float4 xv[NE];
+    int rowv[NE];
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const int g = tid + 256 * n;                                       // group = (row, 4 harmonics)
+      const int row = (int)(((float)g + 0.5f) * p.inv_K4);
+      rowv[n] = row;
+      const int src = (row < nfr) ? g : halo_grp + (g - row * K4);       // row nfr = halo
+      xv[n] = (g < n_grp && row <= nfr) ? hd_u[src] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < kUnitRows) t.f0[tid] = my_f0;
+    if (wave == 3) {
+      double part64 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) part64 += (double)pf[u];
+      for (int j = 1024 + lane; j < j0; j += 64) part64 += (double)f0[j];     // F > 1024: rare
+      part64 = wave_sum_dpp(part64);
+      if (lane == 0) t.ssum = part64;
+    }
+    __syncthreads();                                   // t.f0 visible
+    DDSP_STAMP();                                      // 1
+    // ---------------- phase A.2: scale, frame-rate Nyquist mask, stash in LDS ---------------------
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const int g = tid + 256 * n;
+      const int row = rowv[n];
+      const int k = (g - row * K4) * 4;
+      float x[4] = {xv[n].x, xv[n].y, xv[n].z, xv[n].w};
+      const float f0r = t.f0[min(row, kUnitRows - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (scale) x[u] = exp_sigmoid_fast(x[u], kLog10, 2.0f, 1e-7f);
+        // core.remove_above_nyquist on f0 * [1..K]  (core.py:899-903, 1028-1045)
+        if (normalize && (f0r * (float)(k + u + 1) >= p.nyquist)) x[u] = 0.0f;
+      }
+      xv[n] = make_float4(x[0], x[1], x[2], x[3]);
+      if (g < n_grp) *reinterpret_cast<float4*>(&s_x[4 * g]) = xv[n];
+    }
+    __syncthreads();
+    DDSP_STAMP();                                      // 2
+    // ---------------- phase A.3: row sums (a 16-lane DPP row per matrix row) and amplitudes ---------
+    // core.safe_divide(hd, reduce_sum(hd))  (core.py:905-907, 207-210)
+    for (int q = tid >> 4; q <= nfr; q += 16) {         // 16 groups of 16 lanes: rows 0..15, then 16
+      float inv = 1.0f;
+      if (!p.inputs_are_controls) {
+        float part = 0.0f;
+        for (int k4 = tid & 15; k4 < K4; k4 += 16) {
+          const float4 v4 = *reinterpret_cast<const float4*>(&s_x[q * K + 4 * k4]);
+          part += (v4.x + v4.y) + (v4.z + v4.w);
+        }
+        // all 64 lanes of a wave take the same number of trips (q differs by < 4 inside a wave and
+        // the loop bound is hit by whole waves: q = 16 only exists for tid < 16), so EXEC is full
+        // for the DPP steps of every wave that gets here
+        part += dpp_mov0<0xB1, 0xF>(part);     // quad_perm [1,0,3,2]
+        part += dpp_mov0<0x4E, 0xF>(part);     // quad_perm [2,3,0,1]
+        part += dpp_mov0<0x141, 0xF>(part);    // row_half_mirror
+        part += dpp_mov0<0x140, 0xF>(part);    // row_mirror: every lane holds its row's sum
+        inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
+      }
+      if ((tid & 15) == 0) t.inv_amp[q].x = inv;
+    }
+    if (tid < kUnitRows) {
+      float a = my_amp;
+      if (scale) a = exp_sigmoid_fast(a, kLog10, 2.0f, 1e-7f);
+      t.inv_amp[tid].y = a;
+      if (tid < nfr && ctl_amp) ctl_amp[row0 + tid] = a;
+    }
+    __syncthreads();
+    DDSP_STAMP();                                      // 3
+    // ---------------- phase A.4: normalised distribution -> controls out, amplitude rows -> slot --
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const int g = tid + 256 * n;
+      const int row = rowv[n];
+      if (g < n_grp && row <= nfr) {
+        const float2 ia = t.inv_amp[row];
+        const float4 h = make_float4(xv[n].x * ia.x, xv[n].y * ia.x, xv[n].z * ia.x, xv[n].w * ia.x);
+        if (ctl_hd_u && row < nfr) ctl_hd_u[g] = h;              // the halo row belongs to the next unit
+        // core.py:1097 amplitudes * distribution
+        *reinterpret_cast<float4*>(&wsu[row * Kp + (g - row * K4) * 4]) =
+            make_float4(ia.y * h.x, ia.y * h.y, ia.y * h.z, ia.y * h.w);
+      }
+    }
+    DDSP_STAMP();                                      // 4
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have reached L2
+    // ---------------- phase A.5: everything that is per frame, one lane per frame (wave 0) ---------
+    if (wave == 0) {
+      const double hop_d = (double)p.hop;
+      const float nyq_lo = p.nyquist * (1.0f - 4e-6f), nyq_hi = p.nyquist * (1.0f + 4e-6f);
+      const float fj = t.f0[min(lane, nfr)], fj1 = t.f0[min(lane + 1, nfr)];
+      const double fa = (double)fj, fb = (double)fj1;
+      const double mine = (lane < nfr) ? fa : 0.0;
+      double incl = mine;                                 // inclusive scan of f_j over the unit's frames
+      // (every lane executes the DPP moves: a source lane masked off by EXEC would read as 0;
+      //  sources shifted in from outside the 16-lane row read 0 by bound_ctrl=0 / old=0)
+      incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
+      incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
+      incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
+      incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
+      const double s_excl = t.ssum + (incl - mine);       // sum_{j < j0+lane} f_j
+      const double run = hop_d * s_excl + (fa - (double)f0[0]) * ((hop_d - 1.0) * 0.5);
+      const double cyc = run * p.inv_sr;
+      // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample.
+      // v_rcp_f32 (1 ulp) is well inside the 4e-6 guard band.
+      const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+      int kA = K, kN = K;
+      if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(nyq_lo * __builtin_amdgcn_rcpf(fmx)));
+      if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(nyq_hi * __builtin_amdgcn_rcpf(fmn)));
+      kA = max(min(kA, kN), 0);
+      if (lane < nfr) {
+        t.theta[lane] = cyc - floor(cyc);                  // revolutions at the start of the frame
+        t.w[lane] = fa * p.inv_sr;                         // revolutions per sample at r = 0
+        t.dw[lane] = (fb - fa) * p.inv_sr * p.inv_2hop;    // half the per-sample slope
+        t.kA[lane] = kA;
+        t.kN[lane] = kN;
+      }
+    }
+    __syncthreads();
+    if (!(p.flags & 0x08000000u)) __builtin_amdgcn_s_dcache_inv();   // drop stale scalar-cache lines of the slot
+    DDSP_STAMP();                                      // 5
+
+    DDSP_STAMP();                                      // 6: per-frame tables done
+    // ---------------- phase B: tiles of 64 samples ---------------------------------------------
+    const int hop = p.hop;
+    const float inv_hop = 1.0f / (float)hop;
+    const int tiles_per_frame = hop >> 6;
+    const int n_tiles = (p.flags & 0x20000000u) ? 0 : nfr * tiles_per_frame;   // experiment: phase A only
+    for (int tile = wave; tile < n_tiles; tile += 4) {
+      const int q = tile / tiles_per_frame;
+      const int r = (tile - q * tiles_per_frame) * 64 + lane;
+      const double rr = (double)r;
+      // inclusive cumsum of f[t]/sr inside the frame: (r+1)*w + r(r+1)*dw
+      const double cyc = t.theta[q] + (rr + 1.0) * (t.w[q] + t.dw[q] * rr);
+      const float theta = (float)(cyc - floor(cyc));
+      const int kA = __builtin_amdgcn_readfirstlane(t.kA[q]);
+      const int kN = __builtin_amdgcn_readfirstlane(t.kN[q]);
+
+      const float* a0p = wsu + q * Kp;
+      const float* a1p = a0p + Kp;
+      const float c4 = 2.0f * __builtin_amdgcn_cosf(theta + theta);   // 2 cos(4 pi theta)
+      float sn[4] = {0.f, 0.f, 0.f, 0.f};
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      // every harmonic live (the common case): the whole row (zero padded to a multiple of 4);
+      // otherwise only the groups of 4 that lie entirely below kA
+      const int kend = (kA == K) ? ((K + 3) & ~3) : (kA & ~3);
+      int k = 0;
+      for (; k < kend; k += 32) {           // super-block of 32 = 4 octets, seeds in the first
+        const int rem4 = (kend - k) >> 2;
+        harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, sn, acc);
+        if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, sn, acc);
+        if (rem4 > 4) harm_oct<false>(a0p, a1p, k + 16, min(rem4 - 4, 2), theta, c4, sn, acc);
+        if (rem4 > 6) harm_oct<false>(a0p, a1p, k + 24, min(rem4 - 6, 2), theta, c4, sn, acc);
+      }
+      float acc0 = acc[0] + acc[2], acc1 = acc[1] + acc[3];
+      k = min(kend, K);
+      const float lerp = (float)r * inv_hop;
+      if (k < kN) {                // remaining live harmonics, and those crossing Nyquist
+        const float fj = t.f0[q], fj1 = t.f0[q + 1];
+        for (; k < kN; ++k) {
+          const float kf = (float)(k + 1);
+          const float top = fj * kf, bot = fj1 * kf;
+          // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
+          const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+          const float sv = (fk >= p.nyquist) ? 0.0f : sin_rev(frac_phase(theta, kf));
+          const float x0 = __builtin_nontemporal_load(a0p + k), x1 = __builtin_nontemporal_load(a1p + k);
+          acc0 = fmaf(x0, sv, acc0);
+          acc1 = fmaf(x1, sv, acc1);
+        }
+      }
+      // frame-rate -> audio-rate amplitude envelope: weight of frame j+1 is lerp ('linear',
+      // core.resample) or the periodic Hann(2*hop)[r] ('window', core.py:696-698)
+      const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
+      const float w_cur = 1.0f - w_next;
+      audio[(size_t)(row0 + q) * hop + r] = w_cur * acc0 + w_next * acc1;      // N == F * hop
+    }
+    __syncthreads();              // the slot and the LDS tables are rewritten by the next unit
+    DDSP_STAMP();                                      // 7: tiles done
+    b += db; c += dc;
+    if (c >= p.units_per_row) { c -= p.units_per_row; ++b; }
+  }
+#undef DDSP_STAMP
+}
+
 }  // namespace ddsp
 
 // =====================================================================================
@@ -308,12 +623,52 @@ using namespace ddsp;
 
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH; }
 
-// workspace = [ theta0: B*F doubles ][ ws_a: B*(F+1)*Kp floats ]
+constexpr int kFusedMaxBlocks = 256 * 8;     // persistent grid: 8 blocks of 256 threads per CU
+// workspace = [ theta0: B*F doubles ][ ws_a: B*(F+1)*Kp floats ]  (two-kernel path), or one
+// 17-row slot per persistent block (fused path)
 static inline size_t theta_bytes(int B, int F) { return ((size_t)B * F * sizeof(double) + 63) & ~(size_t)63; }
 extern "C" size_t ddsp_harmonic_workspace_bytes(int B, int F, int K, int N) {
   (void)N;
   if (B <= 0 || F <= 0 || K <= 0) return 0;
-  return theta_bytes(B, F) + (size_t)B * (size_t)(F + 1) * (size_t)round_up(K, 16) * sizeof(float);
+  const size_t two_kernel = theta_bytes(B, F) + (size_t)B * (size_t)(F + 1) * (size_t)round_up(K, 16) * sizeof(float);
+  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float);
+  return two_kernel > fused ? two_kernel : fused;
+}
+
+static int launch_fused(const float* amps, const float* hd, const float* f0, float* audio,
+                        float* ctl_amp, float* ctl_hd, void* workspace, int B, int F, int K, int N,
+                        int sample_rate, unsigned flags, int inputs_are_controls, hipStream_t st) {
+  FusedArgs p;
+  p.B = B; p.F = F; p.K = K; p.Kp = round_up(K, 16); p.N = N; p.hop = N / F;
+  p.units_per_row = (F + kFramesPerBlock - 1) / kFramesPerBlock;
+  p.n_units = B * p.units_per_row;
+  p.sample_rate = (float)sample_rate;
+  p.nyquist = (float)(sample_rate / 2.0);
+  p.flags = flags;
+  p.inputs_are_controls = inputs_are_controls;
+  p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.inv_K4 = 1.0f / (float)(K / 4);
+  p.inv_sr = 1.0 / (double)sample_rate;
+  p.inv_2hop = 0.5 / (double)p.hop;
+  const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
+  const int ne = (kUnitRows * (K / 4) + 255) / 256;
+  const size_t lds = (size_t)kUnitRows * K * sizeof(float);
+  ProfileScope prof(kHarmSynth, st);
+#define DDSP_LAUNCH_FUSED(NE)                                                                \
+  hipLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, amps, hd, f0, ctl_amp, ctl_hd, \
+                     (float*)workspace, audio, p)
+  if (ne <= 1) DDSP_LAUNCH_FUSED(1);
+  else if (ne <= 2) DDSP_LAUNCH_FUSED(2);
+  else if (ne <= 3) DDSP_LAUNCH_FUSED(3);
+  else if (ne <= 5) DDSP_LAUNCH_FUSED(5);
+  else return DDSP_ERR_UNSUPPORTED;
+#undef DDSP_LAUNCH_FUSED
+  return check_launch();
+}
+// fused path: hop a multiple of 64, K a multiple of 4 (16-byte rows), caller buffers 16-byte aligned
+static inline bool fused_ok(int F, int K, int N, const void* hd, const void* ctl_hd) {
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K <= 256 && (K % 4) == 0 &&
+         (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0;
 }
 
 static int launch_controls(const float* amps, const float* hd, const float* f0, float* ctl_amp,
@@ -395,6 +750,9 @@ extern "C" int ddsp_harmonic_signal_f32(const float* ctl_amp, const float* ctl_h
   if (workspace_bytes < ddsp_harmonic_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (fused_ok(F, K, N, ctl_hd, nullptr))
+    return launch_fused(ctl_amp, ctl_hd, f0_hz, audio, nullptr, nullptr, workspace, B, F, K, N,
+                        sample_rate, flags, /*inputs_are_controls=*/1, st);
   rc = launch_controls(ctl_amp, ctl_hd, f0_hz, nullptr, nullptr, workspace, B, F, K, N,
                        sample_rate, flags, /*inputs_are_controls=*/1, st);
   if (rc != DDSP_OK) return rc;
@@ -411,6 +769,9 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
   if (workspace_bytes < ddsp_harmonic_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (fused_ok(F, K, N, hd, ctl_hd))
+    return launch_fused(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, workspace, B, F, K, N,
+                        sample_rate, flags, /*inputs_are_controls=*/0, st);
   rc = launch_controls(amplitudes, hd, f0_hz, ctl_amp, ctl_hd, workspace, B, F, K, N,
                        sample_rate, flags, /*inputs_are_controls=*/0, st);
   if (rc != DDSP_OK) return rc;

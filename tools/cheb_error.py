@@ -38,3 +38,20 @@ for block in (8, 16, 32):
   print('block %2d: max |err| per harmonic %.2e' % (block, np.abs(out - exact).max()))
 direct = np.sin(2 * np.pi * np.outer(theta, np.arange(1, K + 1, dtype=f32)).astype(f32).astype(np.float64))
 print('direct sin(fl32(k*theta)): max |err| %.2e' % np.abs(direct - exact).max())
+
+# ---- stride-2 variant used by harm_fused_kernel: s[h] = 2cos(4 pi theta) s[h-2] - s[h-4], four exact
+# seeds per super-block of SB harmonics (two independent chains: odd and even harmonics) ------------
+for sb in (16, 32, 64):
+  out = np.zeros((len(theta), K), f32)
+  c4 = (2 * np.cos(4 * np.pi * th64)).astype(f32)
+  for k0 in range(1, K + 1, sb):
+    ks = list(range(k0, min(k0 + sb, K + 1)))
+    hist = []
+    for i, k in enumerate(ks):
+      if i < 4:
+        v = seed(k)
+      else:
+        v = fma32(c4, hist[-2], -hist[-4])
+      out[:, k - 1] = v
+      hist.append(v)
+  print('stride-2, super-block %2d: max |err| per harmonic %.2e' % (sb, np.abs(out - exact).max()))
