@@ -492,26 +492,52 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   const int z0 = blockIdx.x * kFnTile;
   const int J0 = blockIdx.x * kFnFrames;
   const float kLog10 = 2.302585092994046f;
+  // debug timeline (p.scale bit 30): ctl_out is reinterpreted as long long [blocks][8]
+  const bool dbg_time = (p.scale & 0x40000000) != 0;
+  long long* dbg = dbg_time ? reinterpret_cast<long long*>(ctl_out) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  int dbg_n = 0;
+#define DDSP_STAMP() do { if (dbg_time && threadIdx.x == 0 && dbg_n < 8) dbg[dbg_n++] = wall_clock64(); } while (0)
+  if (dbg_time) ctl_out = nullptr;
+  const int do_scale = p.scale & 1;
+  DDSP_STAMP();
 
   // ---- 1. magnitude rows of frames J0-2 .. J0+61 -------------------------------------------------
+  // The 64 rows are one contiguous span of 4160 floats in HBM: 16-byte loads from the span's
+  // aligned-down start (vector-memory instruction issue, not bandwidth, is the cost here).
   {
-    const int f_first = J0 - 2;
-    const float* __restrict__ src = mag + ((size_t)b * p.F) * 65;
-    float* __restrict__ ctl = ctl_out ? ctl_out + ((size_t)b * p.F) * 65 : nullptr;
-    for (int i = tid; i < 64 * 65; i += 256) {
-      const int row = i / 65;
-      const int f = f_first + row;
-      float v = 0.0f;
-      if (f >= 0 && f < p.F) {
-        const int g = f * 65 + (i - row * 65);
-        v = src[g];
-        if (p.scale) v = exp_sigmoid(v + p.bias, kLog10, 2.0f, 1e-7f);
-        if (ctl && row >= 2) ctl[g] = v;             // rows 0,1 belong to the previous block
+    const long f_first = (long)b * p.F + (J0 - 2);                  // may be < b*F for the first tile
+    const long e0 = f_first * 65;                                   // first element wanted
+    const long lo = (long)b * p.F * 65, hi = ((long)b + 1) * p.F * 65;   // this batch row's elements
+    const long a0 = e0 & ~3L;                                       // aligned-down start (may be < 0)
+    const long total = ((long)p.F * 65) * (long)gridDim.y;          // elements in the whole tensor
+    for (int i4 = tid; i4 < (64 * 65 + 3) / 4 + 1; i4 += 256) {
+      const long ea = a0 + 4L * i4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ea >= 0 && ea + 3 < total) v = *reinterpret_cast<const float4*>(mag + ea);
+      else if (ea + 3 >= 0 && ea < total) {
+        if (ea >= 0 && ea < total) v.x = mag[ea];
+        if (ea + 1 >= 0 && ea + 1 < total) v.y = mag[ea + 1];
+        if (ea + 2 >= 0 && ea + 2 < total) v.z = mag[ea + 2];
+        if (ea + 3 >= 0 && ea + 3 < total) v.w = mag[ea + 3];
       }
-      s_u[i] = v;
+      const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long e = ea + u;
+        const int i = (int)(e - e0);                                // index into the 64x65 stage
+        if (i >= 0 && i < 64 * 65) {
+          float y = 0.0f;
+          if (e >= lo && e < hi) {                                  // frame inside [0,F) of this row
+            y = do_scale ? exp_sigmoid_fast(x[u] + p.bias, kLog10, 2.0f, 1e-7f) : x[u];
+            if (ctl_out && i >= 2 * 65) ctl_out[e] = y;             // rows 0,1 belong to the previous block
+          }
+          s_u[i] = y;
+        }
+      }
     }
   }
   __syncthreads();
+  DDSP_STAMP();    // 1: magnitudes staged
   // ---- 2. IR design, lanes = frames ------------------------------------------------------------------
   {
     float me[33], mo[32];
@@ -540,6 +566,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     }
   }
   __syncthreads();                                      // magnitudes consumed: s_u is free
+  DDSP_STAMP();    // 2: IR designed
   // ---- 3. noise tile x[z0-128 .. z0+3967] into s_u (four 16-byte-chunk planes) ----------------------
   for (int qd = tid; qd < kFnXLen / 4; qd += 256) {
     const int i = z0 - 128 + 4 * qd;
@@ -567,6 +594,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
   }
   __syncthreads();
+  DDSP_STAMP();    // 3: noise tile staged
   // ---- 4. FIR: 16 outputs per lane ---------------------------------------------------------------------
   const int mrel = tid * kFirR;                          // m0 - z0; lanes 248..255 idle (>= 3968)
   float acc[kFirR];
@@ -582,6 +610,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     }
   }
   __syncthreads();                                      // everyone is done reading x
+  DDSP_STAMP();    // 4: FIR done
   // ---- 5. transpose through LDS, coalesced stores: out[n] = z[n + start] ---------------------------
   if (mrel < kFnTile) {
 #pragma unroll
@@ -592,14 +621,17 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   __syncthreads();
   float* __restrict__ o = out + (size_t)b * p.N;
   const long nbase = (long)z0 - p.start;                // out index of tile element 0
-  if (((nbase & 1) == 0) && ((p.N & 1) == 0)) {         // 8-byte aligned pairs
-    for (int e = 2 * tid; e < kFnTile; e += 512) {
+  const int head = (int)((4 - (nbase & 3)) & 3);        // tile elements before the first 16-byte boundary
+  if ((p.N & 3) == 0) {
+    if (tid < head) { const long n = nbase + tid; if (n >= 0 && n < p.N) o[n] = s_u[tid]; }
+    for (int e = head + 4 * tid; e < kFnTile; e += 1024) {
       const long n = nbase + e;
-      if (n >= 0 && n + 1 < p.N) {
-        *reinterpret_cast<float2*>(o + n) = make_float2(s_u[e], s_u[e + 1]);
+      if (n >= 0 && n + 3 < p.N && e + 3 < kFnTile) {
+        *reinterpret_cast<float4*>(o + n) = make_float4(s_u[e], s_u[e + 1], s_u[e + 2], s_u[e + 3]);
       } else {
-        if (n >= 0 && n < p.N) o[n] = s_u[e];
-        if (n + 1 >= 0 && n + 1 < p.N) o[n + 1] = s_u[e + 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e + u < kFnTile && n + u >= 0 && n + u < p.N) o[n + u] = s_u[e + u];
       }
     }
   } else {
@@ -608,6 +640,8 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
       if (n >= 0 && n < p.N) o[n] = s_u[e];
     }
   }
+  DDSP_STAMP();    // 5: stored
+#undef DDSP_STAMP
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a,
@@ -769,7 +803,8 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
     if (M == 65 && g.padding == 0 && frame_size == 64 && (N + 63) / 64 == F && B <= 65535 &&
         (noise == nullptr || (((uintptr_t)noise) & 15) == 0)) {
       FusedNoiseArgs q;
-      q.N = N; q.F = F; q.start = (g.L - 1) / 2 - 1; q.scale = scale; q.bias = initial_bias;
+      q.N = N; q.F = F; q.start = (g.L - 1) / 2 - 1; q.bias = initial_bias;
+      q.scale = scale | ((flags & 0x40000000u) ? 0x40000000 : 0);      // bit 30: debug timeline
       q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
       ProfileScope prof(kTvFir, st);

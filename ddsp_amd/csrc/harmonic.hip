@@ -22,7 +22,7 @@
 
 namespace ddsp {
 
-constexpr int kFramesPerBlock = 16;   // frames handled by one synth block
+constexpr int kFramesPerBlock = 16;   // frames per synth block / unit of the fused kernel
 constexpr int kSynthThreads = 256;
 constexpr int kRowsPerWave = 4;       // controls kernel: rows per wavefront
 constexpr int kCheb = 16;             // harmonics per Chebyshev block (two exact seeds each)
@@ -351,20 +351,45 @@ __device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k
   }
 }
 
+typedef float sgpr16 __attribute__((ext_vector_type(16)));
+
+// 16 harmonics k+1 .. k+16, all live, rows at byte offset OFF from p0/p1 (immediate in the load:
+// no scalar address arithmetic, no guards - SALU instructions are not free, they take issue
+// slots of the wave and of the CU's scalar unit)
+template <bool SEEDS, int OFF>
+__device__ __forceinline__ void harm_hex_full(const float* p0, const float* p1, int k, float theta,
+                                              float c4, float (&s)[4], float (&acc)[4]) {
+  sgpr16 a0, a1;
+  asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
+#pragma unroll
+  for (int idx = 0; idx < 16; ++idx) {
+    const int u = idx & 3;
+    float sn;
+    if (SEEDS && idx < 4) sn = sin_rev(frac_phase(theta, (float)(k + idx + 1)));
+    else sn = fmaf(c4, s[(u + 2) & 3], -s[u]);          // s[h-2], s[h-4]
+    s[u] = sn;
+    acc[2 * (u & 1)] = fmaf(a0[idx], sn, acc[2 * (u & 1)]);
+    acc[2 * (u & 1) + 1] = fmaf(a1[idx], sn, acc[2 * (u & 1) + 1]);
+  }
+}
+
 struct FusedArgs {
   int B, F, K, Kp, N, hop, units_per_row, n_units;
   float sample_rate, nyquist;
   unsigned flags;
   int inputs_are_controls, amp_linear;
   float inv_K4;                  // 1 / (K/4)
-  double inv_sr, inv_2hop;       // 1/sample_rate, 1/(2*hop)   (host side: no fp64 divisions on chip)
+  float nyq_lo, nyq_hi;          // nyquist * (1 -+ 4e-6): guard band of the live-harmonic counts
+  // host-side constants (no fp64 divisions / hoisted-then-spilled invariants on chip)
+  double inv_sr, inv_2hop, hop_d, half_hm1;   // 1/sample_rate, 1/(2*hop), hop, (hop-1)/2
 };
 
 constexpr int kUnitRows = kFramesPerBlock + 1;
 
 // LDS tables of one unit
 struct UnitTables {
-  double ssum;                                           // sum_{j<j0} f0_j
+  double red[4];                                         // per-wave partials of sum_{j<j0} f0_j
   double theta[kFramesPerBlock], w[kFramesPerBlock], dw[kFramesPerBlock];
   float f0[kUnitRows + 3];
   float2 inv_amp[kUnitRows];                             // {1/sum(distribution), scaled amplitude}
@@ -420,15 +445,16 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       my_f0 = f0[j];
       my_amp = amplitudes[(size_t)b * F + j];
     }
-    // Phase prefix, fp64, on wave 3 only.  Frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop
-    // (legacy bilinear resize of f0), whose sum over the frame is hop*f_j + (f_{j+1}-f_j)(hop-1)/2;
-    // summed over j < J this telescopes to hop*sum_{j<J} f_j + (f_J - f_0)(hop-1)/2.
-    float pf[16];
-    if (wave == 3) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {                   // all loads in flight together (j0 <= 1024)
-        const int j = lane + 64 * u;
-        pf[u] = (j < j0) ? f0[j] : 0.0f;
+    // Phase prefix (fp64).  Frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop (legacy bilinear
+    // resize of f0), whose sum over the frame is hop*f_j + (f_{j+1}-f_j)(hop-1)/2; summed over
+    // j < J this telescopes to hop*sum_{j<J} f_j + (f_J - f_0)(hop-1)/2: only sum f_j is needed.
+    // One 16-byte load per thread covers 1024 frames.
+    float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const int j = 4 * tid;
+      if (j < j0) {
+        if ((F & 3) == 0) pf = *reinterpret_cast<const float4*>(f0 + j);
+        else { pf.x = f0[j]; if (j + 1 < F) pf.y = f0[j + 1]; if (j + 2 < F) pf.z = f0[j + 2]; if (j + 3 < F) pf.w = f0[j + 3]; }
       }
     }
     float4 xv[NE];
@@ -442,13 +468,13 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       xv[n] = (g < n_grp && row <= nfr) ? hd_u[src] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid < kUnitRows) t.f0[tid] = my_f0;
-    if (wave == 3) {
-      double part64 = 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) part64 += (double)pf[u];
-      for (int j = 1024 + lane; j < j0; j += 64) part64 += (double)f0[j];     // F > 1024: rare
+    {
+      const int j = 4 * tid;
+      double part64 = (j < j0 ? (double)pf.x : 0.0) + (j + 1 < j0 ? (double)pf.y : 0.0) +
+                      (j + 2 < j0 ? (double)pf.z : 0.0) + (j + 3 < j0 ? (double)pf.w : 0.0);
+      for (int jj = 1024 + tid; jj < j0; jj += 256) part64 += (double)f0[jj];     // F > 1024: rare
       part64 = wave_sum_dpp(part64);
-      if (lane == 0) t.ssum = part64;
+      if (lane == 0) t.red[wave] = part64;
     }
     __syncthreads();                                   // t.f0 visible
     DDSP_STAMP();                                      // 1
@@ -518,8 +544,6 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have reached L2
     // ---------------- phase A.5: everything that is per frame, one lane per frame (wave 0) ---------
     if (wave == 0) {
-      const double hop_d = (double)p.hop;
-      const float nyq_lo = p.nyquist * (1.0f - 4e-6f), nyq_hi = p.nyquist * (1.0f + 4e-6f);
       const float fj = t.f0[min(lane, nfr)], fj1 = t.f0[min(lane + 1, nfr)];
       const double fa = (double)fj, fb = (double)fj1;
       const double mine = (lane < nfr) ? fa : 0.0;
@@ -530,15 +554,15 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
       incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
       incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
-      const double s_excl = t.ssum + (incl - mine);       // sum_{j < j0+lane} f_j
-      const double run = hop_d * s_excl + (fa - (double)f0[0]) * ((hop_d - 1.0) * 0.5);
+      const double s_excl = ((t.red[0] + t.red[1]) + (t.red[2] + t.red[3])) + (incl - mine);   // sum_{j < j0+lane} f_j
+      const double run = p.hop_d * s_excl + (fa - (double)f0[0]) * p.half_hm1;
       const double cyc = run * p.inv_sr;
       // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample.
       // v_rcp_f32 (1 ulp) is well inside the 4e-6 guard band.
       const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
       int kA = K, kN = K;
-      if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(nyq_lo * __builtin_amdgcn_rcpf(fmx)));
-      if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(nyq_hi * __builtin_amdgcn_rcpf(fmn)));
+      if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
+      if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
       kA = max(min(kA, kN), 0);
       if (lane < nfr) {
         t.theta[lane] = cyc - floor(cyc);                  // revolutions at the start of the frame
@@ -577,7 +601,15 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       // otherwise only the groups of 4 that lie entirely below kA
       const int kend = (kA == K) ? ((K + 3) & ~3) : (kA & ~3);
       int k = 0;
-      for (; k < kend; k += 32) {           // super-block of 32 = 4 octets, seeds in the first
+      {
+        const float* q0 = a0p;
+        const float* q1 = a1p;
+        for (; k + 32 <= kend; k += 32, q0 += 32, q1 += 32) {      // full super-blocks of 32
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
+        }
+      }
+      for (; k < kend; k += 32) {           // the tail: octets with group guards, seeds in the first
         const int rem4 = (kend - k) >> 2;
         harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, sn, acc);
         if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, sn, acc);
@@ -650,6 +682,10 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   p.inv_K4 = 1.0f / (float)(K / 4);
   p.inv_sr = 1.0 / (double)sample_rate;
   p.inv_2hop = 0.5 / (double)p.hop;
+  p.hop_d = (double)p.hop;
+  p.half_hm1 = ((double)p.hop - 1.0) * 0.5;
+  p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
+  p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
   const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
   const int ne = (kUnitRows * (K / 4) + 255) / 256;
   const size_t lds = (size_t)kUnitRows * K * sizeof(float);
