@@ -179,7 +179,7 @@ def main():
     dom_ms, dom_n = prof[dominant]
     dom_avg_s = dom_ms / dom_n * 1e-3
     # algorithmic bytes of the launch = those of the Processor the kernel belongs to
-    dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes
+    dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes   # its Processor's bytes
     achieved = dom_bytes / dom_avg_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

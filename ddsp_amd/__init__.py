@@ -5,6 +5,7 @@
     audio = harmonic(amplitudes, harmonic_distribution, f0_hz)     # torch tensor in HBM
 """
 from ddsp_amd import core
+from ddsp_amd import dags
 from ddsp_amd import processors
 from ddsp_amd import synths
 

@@ -54,6 +54,53 @@ _default_ws = Workspace()
 
 
 # --------------------------------------------------------------------------------------
+# dict helpers used by the DAG plumbing  (ddsp/core.py:39-129)
+# --------------------------------------------------------------------------------------
+def make_iterable(x):
+  """Wrap in a list if not iterable, return empty list if None (ddsp/core.py:39-47)."""
+  if x is None:
+    return []
+  if isinstance(x, (np.ndarray, torch.Tensor, dict, str)):
+    return [x]
+  return x if hasattr(x, '__iter__') else [x]
+
+
+def to_dict(x, keys):
+  """Converts list to a dictionary with supplied keys (ddsp/core.py:50-61)."""
+  if isinstance(x, dict):
+    return x
+  x = make_iterable(x)
+  if len(keys) != len(x):
+    raise ValueError(f'Keys: {keys} must be the same length as {x}')
+  return dict(zip(keys, x))
+
+
+def nested_keys(nested_dict, delimiter='/', prefix=''):
+  """Returns a flattened list of nested key strings (ddsp/core.py:76-102)."""
+  keys = []
+  for k, v in nested_dict.items():
+    key = k if prefix == '' else f'{prefix}{delimiter}{k}'
+    if not isinstance(v, dict):
+      keys.append(key)
+    else:
+      keys += nested_keys(v, prefix=key)
+  return keys
+
+
+def nested_lookup(nested_key, nested_dict, delimiter='/'):
+  """Returns the value of a nested dict according to "key/key/key" (ddsp/core.py:105-129)."""
+  value = nested_dict
+  for key in nested_key.split(delimiter):
+    try:
+      value = value[key]
+    except KeyError:
+      raise KeyError(f'Key \'{key}\' as a part of nested key \'{nested_key}\' '
+                     'not found during nested dictionary lookup, out of '
+                     f'available keys: {nested_keys(nested_dict)}')
+  return value
+
+
+# --------------------------------------------------------------------------------------
 # scaling  (ddsp/core.py:386-404)
 # --------------------------------------------------------------------------------------
 def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):

@@ -807,7 +807,7 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       q.scale = scale | ((flags & 0x40000000u) ? 0x40000000 : 0);      // bit 30: debug timeline
       q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
-      ProfileScope prof(kTvFir, st);
+      ProfileScope prof(kNoiseFused, st);
       if (noise) hipLaunchKernelGGL((noise_fused65_kernel<false>), grid, dim3(256), 0, st, magnitudes,
                                     noise, ctl_magnitudes, audio, q);
       else hipLaunchKernelGGL((noise_fused65_kernel<true>), grid, dim3(256), 0, st, magnitudes,

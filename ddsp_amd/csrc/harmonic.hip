@@ -689,7 +689,7 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
   const int ne = (kUnitRows * (K / 4) + 255) / 256;
   const size_t lds = (size_t)kUnitRows * K * sizeof(float);
-  ProfileScope prof(kHarmSynth, st);
+  ProfileScope prof(kHarmFused, st);
 #define DDSP_LAUNCH_FUSED(NE)                                                                \
   hipLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, amps, hd, f0, ctl_amp, ctl_hd, \
                      (float*)workspace, audio, p)

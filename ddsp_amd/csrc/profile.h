@@ -15,6 +15,8 @@ enum KernelId {
   kUniformNoise,
   kAdd,
   kExpSigmoid,
+  kHarmFused,
+  kNoiseFused,
   kNumKernels
 };
 

@@ -319,3 +319,43 @@ def test_full_size_properties_batch32(ddsp):
   ir = npy(ddsp.core.frequency_impulse_response(c['magnitudes'], 0))[:, 500, :]
   np.testing.assert_allclose(yi[:, t0 - 62:t0 - 62 + 128], ir, rtol=0, atol=1e-7)
   assert np.all(yi[:, :t0 - 62] == 0) and np.all(yi[:, t0 - 62 + 128:] == 0)
+
+
+# ---- next rows of SURVEY 8(f): ProcessorGroup plumbing over the HIP processors ------------------
+def test_processor_group_harmonic_noise_add(ddsp):           # gin/models/ae.gin:49-56 DAG
+  n_frames, n = 100, 6400
+  x = canonical_inputs(2, seed=9, n_frames=n_frames)
+  features = {'amps': x['amplitudes'], 'harmonic_distribution': x['harmonic_distribution'],
+              'f0_hz': x['f0_hz'], 'magnitudes': x['magnitudes']}
+  harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+  noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, name='filtered_noise', seed=3)
+  add = ddsp.processors.Add(name='add')
+  dag = [(harmonic, ['amps', 'harmonic_distribution', 'f0_hz']),
+         (noise, ['magnitudes']),
+         (add, ['filtered_noise/signal', 'harmonic/signal'])]
+  group = ddsp.processors.ProcessorGroup(dag=dag, name='processor_group')
+  out = group(features, return_outputs_dict=True)
+  c = out['controls']
+  for key in ['inputs', 'harmonic', 'filtered_noise', 'add', 'out']:
+    assert key in c
+  h, z = npy(c['harmonic']['signal']), npy(c['filtered_noise']['signal'])
+  np.testing.assert_array_equal(npy(out['signal']), h + z)
+  truth = O.harmonic(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'], n, dtype=np.float64)
+  assert np.abs(h - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  zref = O.filtered_noise(x['magnitudes'], O.device_uniform_noise(2, n, 3, 0), 0, dtype=np.float64)
+  assert np.abs(z - zref).max() <= noise_tol(zref)
+  np.testing.assert_allclose(npy(c['harmonic']['controls']['harmonic_distribution']).sum(-1), 1.0,
+                             rtol=1e-5)
+
+
+def test_harmonic_48k_200_harmonics(ddsp):                   # BASELINE config 5 shape, one short clip
+  n_frames, hop, k, sr = 250, 192, 200, 48000
+  rng = np.random.default_rng(11)
+  amps = rng.standard_normal((2, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((2, n_frames, k)).astype(np.float32)
+  f0 = (100 + rng.standard_normal((2, n_frames, 1))).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n_frames * hop, sample_rate=sr, amp_resample_method='linear',
+                               use_angular_cumsum=True)
+  ours = npy(synth(amps, hd, f0))
+  truth = O.harmonic(amps, hd, f0, n_frames * hop, sr, amp_resample_method='linear', dtype=np.float64)
+  assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL * 2.0

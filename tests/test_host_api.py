@@ -101,3 +101,58 @@ def test_product_package_never_imports_the_oracle():
         text = open(os.path.join(dirpath, f)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle|#include\s+[<"].*oracle', text, re.M), \
             os.path.join(dirpath, f)
+
+
+# ---- ProcessorGroup / DAGLayer plumbing (ddsp/processors_test.py:28-101, ddsp/dags.py) ------------
+class _Const(processors.Processor):
+  """A processor that needs no GPU: returns a constant signal (host plumbing test double)."""
+
+  def __init__(self, value, name):
+    super().__init__(name=name)
+    self.value = value
+
+  def get_controls(self, x):
+    return {'x': x}
+
+  def get_signal(self, x):
+    return x + self.value
+
+
+class _Sum(processors.Processor):
+  def __init__(self, name='add'):
+    super().__init__(name=name)
+
+  def get_controls(self, signal_one, signal_two):
+    return {'signal_one': signal_one, 'signal_two': signal_two}
+
+  def get_signal(self, signal_one, signal_two):
+    return signal_one + signal_two
+
+
+def test_processor_group_dag_construction_and_routing():          # processors_test.py:80-91
+  a, b, add = _Const(1.0, 'harmonic'), _Const(10.0, 'filtered_noise'), _Sum()
+  dag = [(a, ['amps']), (b, ['magnitudes']), (add, ['filtered_noise/signal', 'harmonic/signal'])]
+  group = processors.ProcessorGroup(dag=dag)
+  x = {'amps': np.ones(3), 'magnitudes': np.zeros(3)}
+  out = group(x, return_outputs_dict=True)
+  assert set(out) == {'signal', 'controls'}
+  c = out['controls']
+  for key in ['inputs', 'amps', 'magnitudes', 'harmonic', 'filtered_noise', 'add', 'out']:
+    assert key in c
+  assert set(c['harmonic']) == {'signal', 'controls'} and 'x' in c['harmonic']['controls']
+  np.testing.assert_array_equal(out['signal'], np.ones(3) + 1.0 + 10.0)
+  np.testing.assert_array_equal(group(x), out['signal'])
+  assert group.processor_names == ['harmonic', 'filtered_noise', 'add']
+  assert group.processors[0] is a and group.harmonic is a
+  # string module names resolved from kwargs (gin style), output keys for non-dict returns
+  from ddsp_amd import dags
+  double = lambda v, **kw: 2 * v
+  double.name = 'double'
+  layer = dags.DAGLayer([['double', ['inputs/v'], ['twice']], [a, ['double/twice']]], double=double)
+  res = layer({'v': np.full(2, 3.0)})
+  np.testing.assert_array_equal(res['double']['twice'], np.full(2, 6.0))
+  np.testing.assert_array_equal(res['out']['signal'], np.full(2, 7.0))
+  with pytest.raises(KeyError, match='nested key'):
+    core.nested_lookup('harmonic/nope', res)
+  with pytest.raises(ValueError, match='same length'):
+    core.to_dict([1, 2], ['only_one'])

@@ -14,7 +14,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench (batch 32)"
 timeout 600 python bench.py --steps 20 --warmup 3 2>&1 | tail -3 | tee $OUT/bench_b32.json
 echo "== bench (batch 128)"
-timeout 600 python bench.py --steps 10 --warmup 3 --batch 128 --no-cpu-baseline 2>&1 | tail -3 | tee $OUT/bench_b128.json
+timeout 600 python bench.py --steps 30 --warmup 5 --batch 128 --no-cpu-baseline 2>&1 | tail -3 | tee $OUT/bench_b128.json
 echo "== rocprofv3 kernel trace"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 ls -R $OUT/prof | head -20

@@ -16,8 +16,7 @@ for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recur
         continue
       short = name.split('(')[0].replace('void ', '').replace('ddsp::', '').split('<')[0]
       vals[short][row['Counter_Name']].append(float(row['Counter_Value']))
-alias = {'harm_fused_kernel': 'harm_synth_kernel', 'noise_fused65_kernel': 'tv_fir_kernel',
-         'tv_fir128_kernel': 'tv_fir_kernel', 'noise_ir65_kernel': 'noise_ir_kernel'}
+alias = {'tv_fir128_kernel': 'tv_fir_kernel', 'noise_ir65_kernel': 'noise_ir_kernel'}
 out = {'batch': batch, 'note': 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 '
        '(gfx950 FETCH_SIZE correction x2; WRITE_SIZE uncalibrated)', 'kernels': {}, 'detail': {}}
 for k, d in vals.items():
