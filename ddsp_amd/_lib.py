@@ -33,6 +33,9 @@ SIGNATURES = {
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
     'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),
+    'ddsp_oscillator_bank_workspace_bytes': (c_size_t, [c_int] * 3),
+    'ddsp_oscillator_bank_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 + [c_voidp]),
+    'ddsp_resample_f32': (c_int, [c_f32p] * 2 + [c_int] * 5 + [c_voidp]),
     'ddsp_profile_kernel_count': (c_int, []),
     'ddsp_profile_kernel_name': (ctypes.c_char_p, [c_int]),
     'ddsp_profile_begin': (c_int, [c_uint, c_int]),

@@ -115,6 +115,134 @@ def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
 
 
 # --------------------------------------------------------------------------------------
+# resampling  (ddsp/core.py:573-714) - stand-alone; the synths evaluate it on the fly
+# --------------------------------------------------------------------------------------
+def resample(inputs, n_timesteps, method='linear', add_endpoint=True):
+  """core.resample: [n_frames] / [B, n_frames] / [B, n_frames, C] -> n_timesteps along time."""
+  inputs = tf_float32(inputs)
+  is_1d, is_2d = inputs.dim() == 1, inputs.dim() == 2
+  if is_1d:
+    inputs = inputs[None, :, None]
+  elif is_2d:
+    inputs = inputs[:, :, None]
+  if inputs.dim() != 3:
+    raise NotImplementedError('4-D inputs are not on the accelerated path')
+  if method not in RESAMPLE_METHODS:
+    raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+        method, "['nearest', 'linear', 'cubic', 'window']"))
+  if method in ('nearest', 'cubic') or not add_endpoint:
+    raise NotImplementedError("only method in ('linear', 'window') with add_endpoint=True is "
+                              'implemented by the MI355X kernels')
+  if method == 'window':
+    outputs = upsample_with_windows(inputs, n_timesteps, add_endpoint)
+  else:
+    outputs = _resample_call(inputs.contiguous(), int(n_timesteps), window=0)
+  if is_1d:
+    outputs = outputs[0, :, 0]
+  elif is_2d:
+    outputs = outputs[:, :, 0]
+  return outputs
+
+
+def upsample_with_windows(inputs, n_timesteps, add_endpoint=True):
+  """core.upsample_with_windows: overlapping Hann windows, [B, n_frames, C] -> [B, n_timesteps, C]."""
+  inputs = tf_float32(inputs)
+  if inputs.dim() != 3:
+    raise ValueError('Upsample_with_windows() only supports 3 dimensions, '
+                     'not {}.'.format(tuple(inputs.shape)))
+  if not add_endpoint:
+    raise NotImplementedError('add_endpoint=False is not implemented by the MI355X kernels')
+  n_frames = int(inputs.shape[1]) + 1           # the reference appends the endpoint frame
+  n_intervals = n_frames - 1
+  if n_frames >= n_timesteps:
+    raise ValueError('Upsample with windows cannot be used for downsampling'
+                     'More input frames ({}) than output timesteps ({})'.format(
+                         n_frames, n_timesteps))
+  if n_timesteps % n_intervals != 0.0:
+    raise ValueError(
+        'For upsampling, the target the number of timesteps must be divisible '
+        'by the number of input frames{}. (timesteps:{}, frames:{}, '
+        'add_endpoint={}).'.format('', n_timesteps, n_frames, add_endpoint))
+  return _resample_call(inputs.contiguous(), int(n_timesteps), window=1)
+
+
+def _resample_call(inputs, n_timesteps, window):
+  b, f, c = inputs.shape
+  out = torch.empty((b, n_timesteps, c), dtype=torch.float32, device=inputs.device)
+  rc = _lib.load().ddsp_resample_f32(inputs.data_ptr(), out.data_ptr(), b, f, n_timesteps, c, window,
+                                     _stream())
+  _lib.check(rc, 'ddsp_resample_f32')
+  return out
+
+
+def normalize_harmonics(harmonic_distribution, f0_hz=None, sample_rate=None):
+  """core.normalize_harmonics (ddsp/core.py:894-907): optional Nyquist removal, then sum-normalise."""
+  harmonic_distribution = tf_float32(harmonic_distribution)
+  b, f, k = harmonic_distribution.shape
+  bandlimit = sample_rate is not None and f0_hz is not None
+  f0 = tf_float32(f0_hz) if bandlimit else torch.zeros((b, f, 1), device=harmonic_distribution.device)
+  ones = torch.ones((b, f, 1), dtype=torch.float32, device=harmonic_distribution.device)
+  ctl_amp, ctl_hd = torch.empty_like(ones), torch.empty_like(harmonic_distribution)
+  rc = _lib.load().ddsp_harmonic_controls_f32(
+      ones.data_ptr(), harmonic_distribution.data_ptr(), f0.data_ptr(), ctl_amp.data_ptr(),
+      ctl_hd.data_ptr(), b, f, k, int(sample_rate) if bandlimit else 2,
+      _lib.HARM_NORMALIZE_NYQUIST if bandlimit else 0, _stream())
+  _lib.check(rc, 'ddsp_harmonic_controls_f32')
+  return ctl_hd
+
+
+def get_fft_size(frame_size, ir_size, power_of_2=True):
+  """core.get_fft_size (ddsp/core.py:1317-1335); host arithmetic, kept for API completeness."""
+  convolved_frame_size = ir_size + frame_size - 1
+  if power_of_2:
+    return int(2**np.ceil(np.log2(convolved_frame_size)))
+  from scipy import fftpack
+  return int(fftpack.next_fast_len(convolved_frame_size))
+
+
+def crop_and_compensate_delay(audio, audio_size, ir_size, padding, delay_compensation):
+  """core.crop_and_compensate_delay (ddsp/core.py:1338-1379): a slice, no arithmetic."""
+  if padding == 'valid':
+    crop_size = ir_size + audio_size - 1
+  elif padding == 'same':
+    crop_size = audio_size
+  else:
+    raise ValueError('Padding must be \'valid\' or \'same\', instead '
+                     'of {}.'.format(padding))
+  total_size = int(audio.shape[-1])
+  crop = total_size - crop_size
+  start = ((ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation)
+  end = crop - start
+  return audio[:, start:-end]
+
+
+def oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=16000,
+                    sum_sinusoids=True, use_angular_cumsum=False):
+  """core.oscillator_bank (ddsp/core.py:912-962) on [batch, n_samples, n_sinusoids] envelopes.
+
+  The phase scan runs in fp64 revolutions on chip, so both settings of `use_angular_cumsum`
+  give the same (more exact) result.
+  """
+  del use_angular_cumsum
+  frequency_envelopes = tf_float32(frequency_envelopes)
+  amplitude_envelopes = tf_float32(amplitude_envelopes)
+  if frequency_envelopes.dim() != 3 or frequency_envelopes.shape != amplitude_envelopes.shape:
+    raise ValueError('frequency and amplitude envelopes must both be [batch, n_samples, n_sinusoids]'
+                     ', got {} and {}'.format(tuple(frequency_envelopes.shape),
+                                              tuple(amplitude_envelopes.shape)))
+  b, n, k = frequency_envelopes.shape
+  lib = _lib.load()
+  out = torch.empty((b, n) if sum_sinusoids else (b, n, k), dtype=torch.float32,
+                    device=frequency_envelopes.device)
+  ws = _default_ws.get(lib.ddsp_oscillator_bank_workspace_bytes(b, n, k), frequency_envelopes.device)
+  rc = lib.ddsp_oscillator_bank_f32(frequency_envelopes.data_ptr(), amplitude_envelopes.data_ptr(),
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), b, n, k,
+                                    int(sample_rate), 1 if sum_sinusoids else 0, _stream())
+  _lib.check(rc, 'ddsp_oscillator_bank_f32')
+  return out
+
+
+# --------------------------------------------------------------------------------------
 # harmonic synthesis  (ddsp/core.py:1048-1111)
 # --------------------------------------------------------------------------------------
 RESAMPLE_METHODS = ['nearest', 'linear', 'cubic', 'window']

@@ -852,3 +852,52 @@ extern "C" int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float
                      out, n, logf(exponent), max_value, threshold);
   return check_launch();
 }
+
+// =====================================================================================
+// Stand-alone frame-rate -> audio-rate resampling (core.resample 'linear' / 'window',
+// ddsp/core.py:573-714) for callers that want the envelopes themselves.  The synth kernels
+// never materialise these [B,N,C] tensors; this is an HBM-write-bound elementwise kernel.
+// =====================================================================================
+namespace ddsp {
+// out[b,t,c] = x[b,lo,c]*(1-w) + x[b,hi,c]*w with
+//   'linear' (legacy bilinear, align_corners=False): pos = t*fl32(F/N), lo=floor, hi=min(ceil,F-1),
+//             w = pos-lo, evaluated as top + (bottom-top)*w exactly like TF;
+//   'window' (upsample_with_windows, add_endpoint=True): j=t/hop, r=t%hop, hi=min(j+1,F-1),
+//             w = Hann(2*hop)[r] = 0.5-0.5*cos(pi*r/hop), out = x[j]*(1-w) + x[hi]*w.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, int F, int N, int C,
+                                                       int window, float scale, int hop) {
+  const int b = blockIdx.y;
+  const size_t total = (size_t)N * C;
+  const float* __restrict__ xb = x + (size_t)b * F * C;
+  float* __restrict__ ob = out + (size_t)b * total;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / C), c = (int)(i - (size_t)t * C);
+    if (window) {
+      const int j = t / hop, r = t - j * hop;
+      const int hi = min(j + 1, F - 1);
+      const float w = 0.5f - 0.5f * cospif((float)r / (float)hop);
+      ob[i] = xb[(size_t)j * C + c] * (1.0f - w) + xb[(size_t)hi * C + c] * w;
+    } else {
+      const float pos = (float)t * scale;
+      const float lo = floorf(pos);
+      const int lo_i = (int)lo, hi_i = min((int)ceilf(pos), F - 1);
+      const float top = xb[(size_t)lo_i * C + c], bottom = xb[(size_t)hi_i * C + c];
+      ob[i] = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+    }
+  }
+}
+}  // namespace ddsp
+
+extern "C" int ddsp_resample_f32(const float* x, float* out, int B, int F, int N, int C, int window,
+                                 void* stream) {
+  if (!x || !out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || N <= 0 || C <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (window && (N % F != 0)) return DDSP_ERR_BAD_SHAPE;
+  const float scale = (float)F / (float)N;            // fp32, as TF computes it
+  const size_t total = (size_t)N * C;
+  const dim3 grid(grid_for(total, 2048), (unsigned)B);
+  hipLaunchKernelGGL(ddsp::resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, F, N, C,
+                     window, scale, window ? N / F : 1);
+  return check_launch();
+}

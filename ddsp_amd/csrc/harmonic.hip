@@ -380,6 +380,7 @@ struct FusedArgs {
   unsigned flags;
   int inputs_are_controls, amp_linear;
   float inv_K4;                  // 1 / (K/4)
+  float inv_upr;                 // 1 / units_per_row
   float nyq_lo, nyq_hi;          // nyquist * (1 -+ 4e-6): guard band of the live-harmonic counts
   // host-side constants (no fp64 divisions / hoisted-then-spilled invariants on chip)
   double inv_sr, inv_2hop, hop_d, half_hm1;   // 1/sample_rate, 1/(2*hop), hop, (hop-1)/2
@@ -389,6 +390,7 @@ constexpr int kUnitRows = kFramesPerBlock + 1;
 
 // LDS tables of one unit
 struct UnitTables {
+  int next_unit;
   double red[4];                                         // per-wave partials of sum_{j<j0} f0_j
   double theta[kFramesPerBlock], w[kFramesPerBlock], dw[kFramesPerBlock];
   float f0[kUnitRows + 3];
@@ -423,12 +425,15 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
   const float kLog10 = 2.302585092994046f;      // tf.math.log(exponent), ddsp/core.py:403
   const int n_grp = kUnitRows * K4;                    // float4 groups of one unit
 
-  // (b, c) = (batch row, unit inside the row), advanced without divisions
-  int b = blockIdx.x / p.units_per_row;
-  int c = blockIdx.x - b * p.units_per_row;
-  const int db = gridDim.x / p.units_per_row, dc = gridDim.x - db * p.units_per_row;
-
-  for (int unit = blockIdx.x; unit < p.n_units; unit += gridDim.x) {
+  // The first unit of a block is its blockIdx; further units are handed out dynamically (one atomic
+  // per unit on a counter zeroed by the launcher): resident blocks keep pulling work, so the kernel
+  // balances itself whatever share of the chip it gets - it is meant to run next to the
+  // FilteredNoise kernel on another stream.  (A burst of 2000 first pulls on one word would take
+  // ~25 us: one word serves ~88 atomics/us, MI355X_MICROARCH.md "dequeue".)
+  unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)gridDim.x * kUnitRows * Kp);
+  for (int unit = blockIdx.x; unit < p.n_units;) {
+    const int b = __builtin_amdgcn_readfirstlane((int)(((float)unit + 0.5f) * p.inv_upr));   // unit / units_per_row
+    const int c = unit - b * p.units_per_row;
     const int j0 = c * kFramesPerBlock;
     const int nfr = min(kFramesPerBlock, F - j0);
     const int row0 = b * F + j0;                                          // first (batch*frame) row
@@ -638,10 +643,11 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       const float w_cur = 1.0f - w_next;
       audio[(size_t)(row0 + q) * hop + r] = w_cur * acc0 + w_next * acc1;      // N == F * hop
     }
-    __syncthreads();              // the slot and the LDS tables are rewritten by the next unit
     DDSP_STAMP();                                      // 7: tiles done
-    b += db; c += dc;
-    if (c >= p.units_per_row) { c -= p.units_per_row; ++b; }
+    if (p.n_units <= (int)gridDim.x) break;            // one unit per block: nothing to pull
+    if (tid == 0) t.next_unit = (int)gridDim.x + (int)atomicAdd(counter, 1u);
+    __syncthreads();              // also: the slot and the LDS tables are rewritten by the next unit
+    unit = __builtin_amdgcn_readfirstlane(t.next_unit);
   }
 #undef DDSP_STAMP
 }
@@ -663,7 +669,7 @@ extern "C" size_t ddsp_harmonic_workspace_bytes(int B, int F, int K, int N) {
   (void)N;
   if (B <= 0 || F <= 0 || K <= 0) return 0;
   const size_t two_kernel = theta_bytes(B, F) + (size_t)B * (size_t)(F + 1) * (size_t)round_up(K, 16) * sizeof(float);
-  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float);
+  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float) + 64;
   return two_kernel > fused ? two_kernel : fused;
 }
 
@@ -680,6 +686,7 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   p.inputs_are_controls = inputs_are_controls;
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
   p.inv_K4 = 1.0f / (float)(K / 4);
+  p.inv_upr = 1.0f / (float)p.units_per_row;
   p.inv_sr = 1.0 / (double)sample_rate;
   p.inv_2hop = 0.5 / (double)p.hop;
   p.hop_d = (double)p.hop;
@@ -689,6 +696,9 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
   const int ne = (kUnitRows * (K / 4) + 255) / 256;
   const size_t lds = (size_t)kUnitRows * K * sizeof(float);
+  // the unit counter lives right after the slots
+  unsigned* counter = reinterpret_cast<unsigned*>((float*)workspace + (size_t)grid.x * kUnitRows * p.Kp);
+  if (hipMemsetAsync(counter, 0, sizeof(unsigned), st) != hipSuccess) return DDSP_ERR_LAUNCH;
   ProfileScope prof(kHarmFused, st);
 #define DDSP_LAUNCH_FUSED(NE)                                                                \
   hipLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, amps, hd, f0, ctl_amp, ctl_hd, \
@@ -812,4 +822,114 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
                        sample_rate, flags, /*inputs_are_controls=*/0, st);
   if (rc != DDSP_OK) return rc;
   return launch_synth(f0_hz, workspace, audio, B, F, K, N, sample_rate, flags, st);
+}
+
+// =====================================================================================
+// Stand-alone core.oscillator_bank (ddsp/core.py:912-962) on materialised audio-rate envelopes
+// [B,N,K] (what synths.Sinusoidal and direct callers use).  The Harmonic path never calls this:
+// it fuses the same maths with closed-form phases.  Here the phase really is a scan over time:
+//   pass 1  per (b, chunk of 256 samples): fp64 sum of f over the chunk, per sinusoid
+//   pass 2  per (b, k): exclusive prefix over chunks (in revolutions, wrapped to [0,1))
+//   pass 3  per (b, chunk): running phase from the chunk offset, Nyquist mask, sin, amplitude,
+//           sum over sinusoids (DPP wave reduction + LDS across wavefronts)
+// The fp64 wrapped phase is exact to ~1e-13 revolutions, i.e. closer to exact arithmetic than
+// either tf.cumsum in fp32 or angular_cumsum; `use_angular_cumsum` is therefore accepted and ignored.
+// =====================================================================================
+namespace ddsp {
+constexpr int kOscChunk = 256;
+
+__global__ __launch_bounds__(256) void osc_chunk_sums_kernel(const float* __restrict__ freq,
+                                                             double* __restrict__ sums, int N, int K,
+                                                             int n_chunks) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
+  const float* __restrict__ fb = freq + (size_t)b * N * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) s += (double)fb[(size_t)t * K + k];
+    sums[((size_t)b * n_chunks + c) * K + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void osc_chunk_prefix_kernel(double* __restrict__ sums, int K,
+                                                               int n_chunks, double inv_sr) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double run = 0.0;                                   // revolutions, wrapped
+  for (int c = 0; c < n_chunks; ++c) {
+    double* p = sums + ((size_t)b * n_chunks + c) * K + k;
+    const double s = *p * inv_sr;
+    *p = run;
+    run += s;
+    run -= floor(run);
+  }
+}
+
+__global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict__ freq,
+                                                        const float* __restrict__ amp,
+                                                        const double* __restrict__ offs,
+                                                        float* __restrict__ out, int N, int K,
+                                                        int n_chunks, double inv_sr, float nyquist,
+                                                        int sum_sinusoids) {
+  __shared__ float s_acc[kOscChunk];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float* __restrict__ fb = freq + (size_t)b * N * K;
+  const float* __restrict__ ab = amp + (size_t)b * N * K;
+  for (int i = tid; i < kOscChunk; i += 256) s_acc[i] = 0.0f;
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += 256) {               // every thread takes the trip: full waves for DPP
+    const int k = k0 + tid;
+    const bool live = k < K;
+    double ph = live ? offs[((size_t)b * n_chunks + c) * K + k] : 0.0;
+    for (int t = t0; t < t1; ++t) {
+      float v = 0.0f;
+      if (live) {
+        const float f = fb[(size_t)t * K + k];
+        ph += (double)f * inv_sr;                     // inclusive cumsum (core.py:955)
+        ph -= floor(ph);
+        const float a = (f >= nyquist) ? 0.0f : ab[(size_t)t * K + k];   // remove_above_nyquist
+        v = a * sin_rev((float)ph);
+        if (!sum_sinusoids) out[((size_t)b * N + t) * K + k] = v;
+      }
+      if (sum_sinusoids) {
+        const float s = wave_sum_dpp(v);
+        if (lane == 0) atomicAdd(&s_acc[t - t0], s);
+      }
+    }
+  }
+  if (sum_sinusoids) {
+    __syncthreads();
+    for (int i = tid; i < t1 - t0; i += 256) out[(size_t)b * N + t0 + i] = s_acc[i];
+  }
+}
+}  // namespace ddsp
+
+extern "C" size_t ddsp_oscillator_bank_workspace_bytes(int B, int N, int K) {
+  if (B <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)B * ((N + kOscChunk - 1) / kOscChunk) * K * sizeof(double);
+}
+
+extern "C" int ddsp_oscillator_bank_f32(const float* frequency_envelopes,
+                                        const float* amplitude_envelopes, float* out,
+                                        void* workspace, size_t workspace_bytes, int B, int N, int K,
+                                        int sample_rate, int sum_sinusoids, void* stream) {
+  if (!frequency_envelopes || !amplitude_envelopes || !out || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || K <= 0 || sample_rate <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_oscillator_bank_workspace_bytes(B, N, K) || ((uintptr_t)workspace & 7))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_chunks = (N + kOscChunk - 1) / kOscChunk;
+  const double inv_sr = 1.0 / (double)sample_rate;
+  double* sums = (double*)workspace;
+  hipLaunchKernelGGL(osc_chunk_sums_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes,
+                     sums, N, K, n_chunks);
+  hipLaunchKernelGGL(osc_chunk_prefix_kernel, dim3((K + 255) / 256, B), dim3(256), 0, st, sums, K,
+                     n_chunks, inv_sr);
+  hipLaunchKernelGGL(osc_apply_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes,
+                     amplitude_envelopes, sums, out, N, K, n_chunks, inv_sr,
+                     (float)(sample_rate / 2.0), sum_sinusoids);
+  return check_launch();
 }

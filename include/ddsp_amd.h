@@ -150,6 +150,22 @@ int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t bat
 int ddsp_add_f32(const float* signal_one, const float* signal_two, float* out, size_t n,
                  void* stream);
 
+/* core.oscillator_bank (ddsp/core.py:912-962) on materialised audio-rate envelopes [B,N,K]:
+ * Nyquist mask, phase = inclusive cumsum over time of 2*pi*f/sr, sum_k A_k sin(phase_k).
+ * out is [B,N] (sum_sinusoids != 0) or [B,N,K].  The phase scan runs in fp64 revolutions.
+ * (synths.Harmonic never materialises these tensors; this entry serves direct callers.) */
+size_t ddsp_oscillator_bank_workspace_bytes(int B, int N, int K);
+int ddsp_oscillator_bank_f32(const float* frequency_envelopes, const float* amplitude_envelopes,
+                             float* out, void* workspace, size_t workspace_bytes, int B, int N,
+                             int K, int sample_rate, int sum_sinusoids, void* stream);
+
+/* core.resample (ddsp/core.py:573-642) for [B,F,C] -> [B,N,C], add_endpoint=True:
+ *   window == 0: method='linear' (tf.compat.v1.image.resize BILINEAR, align_corners=False);
+ *   window == 1: method='window' (core.upsample_with_windows :645-714); needs N % F == 0.
+ * The synth kernels evaluate these envelopes on the fly; this entry is for direct callers. */
+int ddsp_resample_f32(const float* x, float* out, int B, int F, int N, int C, int window,
+                      void* stream);
+
 /* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
 int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
                          float max_value, float threshold, void* stream);

@@ -359,3 +359,48 @@ def test_harmonic_48k_200_harmonics(ddsp):                   # BASELINE config 5
   ours = npy(synth(amps, hd, f0))
   truth = O.harmonic(amps, hd, f0, n_frames * hop, sr, amp_resample_method='linear', dtype=np.float64)
   assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL * 2.0
+
+
+def test_standalone_resample_and_normalize(ddsp):            # core_test.py:153-267, golden 'resample'
+  g = load_golden('resample')
+  np.testing.assert_allclose(npy(ddsp.core.resample(g['x'], 576, method='window')), g['window_576'],
+                             rtol=0, atol=2e-6)
+  for n in (576, 1728, 900):
+    np.testing.assert_allclose(npy(ddsp.core.resample(g['x'], n, method='linear')), g['linear_%d' % n],
+                               rtol=0, atol=1e-6)
+  x1 = np.array([0.0, 1.0, 0.5, -0.3, 0.8], np.float32)
+  for method in ('linear', 'window'):                        # core_test.py:242-267 sub-sampling
+    y = npy(ddsp.core.resample(x1, 16000, method=method))
+    np.testing.assert_allclose(y[np.arange(5) * 3200], x1, atol=1e-3)
+  with pytest.raises(ValueError, match='is invalid'):
+    ddsp.core.resample(g['x'], 576, method='bogus')
+  with pytest.raises(ValueError, match='divisible'):
+    ddsp.core.upsample_with_windows(np.ones((1, 10, 1), np.float32), 105)
+  with pytest.raises(ValueError, match='3 dimensions'):
+    ddsp.core.upsample_with_windows(np.ones((2, 10), np.float32), 100)
+  rng = np.random.default_rng(12)
+  hd = np.abs(rng.standard_normal((2, 9, 20))).astype(np.float32)
+  f0 = rng.uniform(300, 900, (2, 9, 1)).astype(np.float32)
+  np.testing.assert_allclose(npy(ddsp.core.normalize_harmonics(hd, f0, 16000)),
+                             O.normalize_harmonics(hd, f0, 16000), rtol=2e-6, atol=1e-9)
+  np.testing.assert_allclose(npy(ddsp.core.normalize_harmonics(hd)), O.normalize_harmonics(hd),
+                             rtol=2e-6, atol=1e-9)
+  assert ddsp.core.get_fft_size(64, 128) == 256
+
+
+def test_standalone_oscillator_bank(ddsp):                    # core_test.py:460-503
+  rng = np.random.default_rng(13)
+  b, n, k, sr = 2, 3000, 70, 16000
+  freq = np.cumsum(rng.standard_normal((b, n, k)), axis=1).astype(np.float32) * 2 + \
+      rng.uniform(100, 9000, (b, 1, k)).astype(np.float32)
+  amp = rng.uniform(0, 1, (b, n, k)).astype(np.float32)
+  truth = O.oscillator_bank(freq.astype(np.float64), amp.astype(np.float64), sr)
+  ours = npy(ddsp.core.oscillator_bank(freq, amp, sr))
+  assert ours.shape == (b, n) and np.abs(ours - truth).max() <= 1e-4 * k
+  each = npy(ddsp.core.oscillator_bank(freq, amp, sr, sum_sinusoids=False))
+  truth_each = O.oscillator_bank(freq.astype(np.float64), amp.astype(np.float64), sr, sum_sinusoids=False)
+  assert each.shape == (b, n, k) and np.abs(each - truth_each).max() <= 1e-4
+  for srate in (4000, 16000, 44100):                         # silent at and above Nyquist
+    for ratio in (1.0, 1.1, 2.0):
+      f = np.full((2, 1000, 3), ratio * srate / 2.0, np.float32)
+      assert np.all(npy(ddsp.core.oscillator_bank(f, np.ones_like(f), srate)) == 0.0)
