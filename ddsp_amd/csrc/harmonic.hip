@@ -16,13 +16,14 @@
 //             amplitudes are wave-uniform -> scalar (SGPR) loads, zero LDS traffic in
 //             the k loop; the Hann / linear interpolation weights are applied once per
 //             sample after the loop.
+#include <atomic>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
 
-constexpr int kFramesPerBlock = 16;   // frames per synth block / unit of the fused kernel
+constexpr int kFramesPerBlock = 8;    // frames per synth block / unit of the fused kernel
 constexpr int kSynthThreads = 256;
 constexpr int kRowsPerWave = 4;       // controls kernel: rows per wavefront
 constexpr int kCheb = 16;             // harmonics per Chebyshev block (two exact seeds each)
@@ -351,6 +352,13 @@ __device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k
   }
 }
 
+// Work-distribution state of the fused kernel: kSchedSets independent sets (one per launch in
+// flight, handed out round-robin by the launcher), each with 8 (pull counter, done counter) pairs
+// on separate 128-byte lines.  Zero at module load; every launch leaves its set zeroed again (the
+// last block of each residue class resets its pair), so no memset is needed on the launch path.
+constexpr int kSchedSets = 32;
+__device__ unsigned g_sched[kSchedSets][8][64];
+
 typedef float sgpr16 __attribute__((ext_vector_type(16)));
 
 // 16 harmonics k+1 .. k+16, all live, rows at byte offset OFF from p0/p1 (immediate in the load:
@@ -381,6 +389,7 @@ struct FusedArgs {
   int inputs_are_controls, amp_linear;
   float inv_K4;                  // 1 / (K/4)
   float inv_upr;                 // 1 / units_per_row
+  int sched_set;                 // which g_sched set this launch uses
   float nyq_lo, nyq_hi;          // nyquist * (1 -+ 4e-6): guard band of the live-harmonic counts
   // host-side constants (no fp64 divisions / hoisted-then-spilled invariants on chip)
   double inv_sr, inv_2hop, hop_d, half_hm1;   // 1/sample_rate, 1/(2*hop), hop, (hop-1)/2
@@ -430,7 +439,12 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
   // balances itself whatever share of the chip it gets - it is meant to run next to the
   // FilteredNoise kernel on another stream.  (A burst of 2000 first pulls on one word would take
   // ~25 us: one word serves ~88 atomics/us, MI355X_MICROARCH.md "dequeue".)
-  unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)gridDim.x * kUnitRows * Kp);
+  // Eight counters (one per XCD-aligned residue class of the unit index, 128 B apart) keep the
+  // pulls off a single word: class x owns units x, x+8, x+16, ...
+  const int xcls = blockIdx.x & 7;
+  unsigned* counter = &g_sched[p.sched_set][xcls][0];
+  unsigned* done = &g_sched[p.sched_set][xcls][32];
+  const int first_pull = (((int)gridDim.x - xcls + 7) >> 3);   // blocks (= static units) of this class
   for (int unit = blockIdx.x; unit < p.n_units;) {
     const int b = __builtin_amdgcn_readfirstlane((int)(((float)unit + 0.5f) * p.inv_upr));   // unit / units_per_row
     const int c = unit - b * p.units_per_row;
@@ -609,6 +623,12 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       {
         const float* q0 = a0p;
         const float* q1 = a1p;
+        for (; k + 64 <= kend; k += 64, q0 += 64, q1 += 64) {      // full super-blocks of 64: 4 seeds
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
+          harm_hex_full<false, 128>(q0, q1, k + 32, theta, c4, sn, acc);
+          harm_hex_full<false, 192>(q0, q1, k + 48, theta, c4, sn, acc);
+        }
         for (; k + 32 <= kend; k += 32, q0 += 32, q1 += 32) {      // full super-blocks of 32
           harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
           harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
@@ -644,10 +664,17 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       audio[(size_t)(row0 + q) * hop + r] = w_cur * acc0 + w_next * acc1;      // N == F * hop
     }
     DDSP_STAMP();                                      // 7: tiles done
-    if (p.n_units <= (int)gridDim.x) break;            // one unit per block: nothing to pull
-    if (tid == 0) t.next_unit = (int)gridDim.x + (int)atomicAdd(counter, 1u);
+    if (p.n_units <= (int)gridDim.x) return;           // one unit per block: nothing to pull or reset
+    if (tid == 0) t.next_unit = xcls + 8 * (first_pull + (int)atomicAdd(counter, 1u));
     __syncthreads();              // also: the slot and the LDS tables are rewritten by the next unit
     unit = __builtin_amdgcn_readfirstlane(t.next_unit);
+  }
+  // the last block of this residue class to finish leaves the class's counters zeroed
+  if (p.n_units > (int)gridDim.x && tid == 0) {
+    if (atomicAdd(done, 1u) == (unsigned)first_pull - 1u) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #undef DDSP_STAMP
 }
@@ -669,7 +696,7 @@ extern "C" size_t ddsp_harmonic_workspace_bytes(int B, int F, int K, int N) {
   (void)N;
   if (B <= 0 || F <= 0 || K <= 0) return 0;
   const size_t two_kernel = theta_bytes(B, F) + (size_t)B * (size_t)(F + 1) * (size_t)round_up(K, 16) * sizeof(float);
-  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float) + 64;
+  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float);
   return two_kernel > fused ? two_kernel : fused;
 }
 
@@ -696,9 +723,8 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
   const int ne = (kUnitRows * (K / 4) + 255) / 256;
   const size_t lds = (size_t)kUnitRows * K * sizeof(float);
-  // the unit counter lives right after the slots
-  unsigned* counter = reinterpret_cast<unsigned*>((float*)workspace + (size_t)grid.x * kUnitRows * p.Kp);
-  if (hipMemsetAsync(counter, 0, sizeof(unsigned), st) != hipSuccess) return DDSP_ERR_LAUNCH;
+  static std::atomic<unsigned> ticket{0};
+  p.sched_set = (int)(ticket.fetch_add(1u) % (unsigned)kSchedSets);
   ProfileScope prof(kHarmFused, st);
 #define DDSP_LAUNCH_FUSED(NE)                                                                \
   hipLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, amps, hd, f0, ctl_amp, ctl_hd, \

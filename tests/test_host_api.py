@@ -41,7 +41,7 @@ def test_fir_size_matches_reference_rule(lib):          # core_test.py:825-855
 
 def test_workspace_queries(lib):
   assert lib.ddsp_harmonic_workspace_bytes(128, 1000, 100, 64000) == max(
-      128 * 1000 * 8 + 128 * 1001 * 112 * 4, 2048 * 17 * 112 * 4 + 64)
+      128 * 1000 * 8 + 128 * 1001 * 112 * 4, 2048 * 9 * 112 * 4)
   assert lib.ddsp_filtered_noise_workspace_bytes(128, 1000, 65, 64000, 0) == 128 * 1000 * 128 * 4
   assert lib.ddsp_harmonic_workspace_bytes(0, 10, 10, 10) == 0
 

@@ -19,3 +19,5 @@ echo "== rocprofv3 kernel trace"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 ls -R $OUT/prof | head -20
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -2); do echo "--- $f"; head -15 $f; done
+echo "== torchrun world=1 sanity (the N>1 code path of bench.py)"
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-300
