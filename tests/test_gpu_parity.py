@@ -404,3 +404,44 @@ def test_standalone_oscillator_bank(ddsp):                    # core_test.py:460
     for ratio in (1.0, 1.1, 2.0):
       f = np.full((2, 1000, 3), ratio * srate / 2.0, np.float32)
       assert np.all(npy(ddsp.core.oscillator_bank(f, np.ones_like(f), srate)) == 0.0)
+
+
+@pytest.mark.parametrize('n_frames,n', [(40, 2560 - 17), (62, 3968), (63, 4032), (125, 8000 - 63), (1, 64)])
+def test_filtered_noise_fused_tile_edges(ddsp, n_frames, n):
+  """Canonical M=65 / frame 64 shapes around the fused kernel's 62-frame tile boundary, ragged N."""
+  rng = np.random.default_rng(n)
+  mags = rng.standard_normal((3, n_frames, 65)).astype(np.float32)
+  noise = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=257)
+  out = synth(mags, noise=noise, return_outputs_dict=True)
+  ref = O.filtered_noise(mags, noise, 257, dtype=np.float64)
+  assert np.abs(npy(out['signal']) - ref).max() <= noise_tol(ref)
+  np.testing.assert_allclose(npy(out['controls']['magnitudes']),
+                             O.filtered_noise_get_controls(mags)['magnitudes'], rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('batch,n_frames', [(1, 8), (1, 9), (3, 17), (2, 130), (5, 1000)])
+def test_harmonic_fused_unit_edges(ddsp, batch, n_frames):
+  """Frame counts around the fused kernel's 8-frame units (partial last unit, halo at F-1)."""
+  rng = np.random.default_rng(n_frames)
+  k, hop = 100, 64
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
+  f0 = (70 + 30 * rng.standard_normal((batch, n_frames, 1))).astype(np.float32)
+  n = n_frames * hop
+  synth = ddsp.synths.Harmonic(n_samples=n)
+  out = synth(amps, hd, f0, return_outputs_dict=True)
+  if n_frames <= 130:
+    truth = O.harmonic(amps, hd, f0, n, dtype=np.float64)
+    c = O.harmonic_get_controls(amps, hd, f0)
+  else:                                      # keep the oracle cheap: check two rows
+    truth = O.harmonic(amps[:2], hd[:2], f0[:2], n, dtype=np.float64)
+    c = O.harmonic_get_controls(amps[:2], hd[:2], f0[:2])
+  nb = truth.shape[0]
+  assert np.abs(npy(out['signal'])[:nb] - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  np.testing.assert_allclose(npy(out['controls']['harmonic_distribution'])[:nb],
+                             c['harmonic_distribution'], rtol=2e-5, atol=1e-9)
+  np.testing.assert_allclose(npy(out['controls']['amplitudes'])[:nb], c['amplitudes'], rtol=2e-5)
+  # repeated launches reuse the self-resetting work counters
+  again = npy(synth(amps, hd, f0))
+  np.testing.assert_array_equal(again, npy(out['signal']))
