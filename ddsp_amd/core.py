@@ -301,8 +301,12 @@ def _check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz):
 def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
                        harmonic_distribution=None, n_samples=64000, sample_rate=16000,
                        amp_resample_method='window', use_angular_cumsum=False,
-                       workspace=None):
-  """core.harmonic_synthesis: frame-rate controls -> audio [batch, n_samples]."""
+                       workspace=None, tf_op_order=False):
+  """core.harmonic_synthesis: frame-rate controls -> audio [batch, n_samples].
+
+  tf_op_order=True (extension, validation only) runs the slow kernel that follows the reference's
+  fp32 op order exactly, sequential phase accumulation included.
+  """
   if harmonic_shifts is not None:
     raise NotImplementedError('harmonic_shifts is not on the accelerated path '
                               '(synths.Harmonic never passes it, ddsp/synths.py:138-145).')
@@ -314,6 +318,13 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
   _check_amp_method(amp_resample_method, f, int(n_samples))
   lib = _lib.load()
   audio = torch.empty((b, int(n_samples)), dtype=torch.float32, device=amplitudes.device)
+  if tf_op_order:
+    rc = lib.ddsp_harmonic_signal_tf_order_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), frequencies.data_ptr(),
+        audio.data_ptr(), b, f, k, int(n_samples), int(sample_rate),
+        _harmonic_flags(False, False, amp_resample_method, use_angular_cumsum), _stream())
+    _lib.check(rc, 'ddsp_harmonic_signal_tf_order_f32')
+    return audio
   nbytes = lib.ddsp_harmonic_workspace_bytes(b, f, k, int(n_samples))
   ws = (workspace or _default_ws).get(nbytes, amplitudes.device)
   rc = lib.ddsp_harmonic_signal_f32(

@@ -959,3 +959,95 @@ extern "C" int ddsp_oscillator_bank_f32(const float* frequency_envelopes,
                      (float)(sample_rate / 2.0), sum_sinusoids);
   return check_launch();
 }
+
+// =====================================================================================
+// Validation-only "TF order" Harmonic.get_signal: reproduces the reference's fp32 op chain
+// (core.harmonic_synthesis -> resample -> oscillator_bank, ddsp/core.py:1048-1111, 573-714,
+// 912-962, 800-866) operation by operation, INCLUDING the strictly sequential fp32 phase
+// accumulation of tf.cumsum (or angular_cumsum's chunked variant), so that full-length clips can be
+// compared with the fp32-faithful oracle directly.  One lane per (batch row, harmonic), a serial
+// loop over time: latency bound and slow by construction; it is never on the product path
+// (flag DDSP_HARM_TF_SEQUENTIAL, used by the parity tests only).
+// =====================================================================================
+namespace ddsp {
+__global__ __launch_bounds__(64) void harm_tf_order_kernel(
+    const float* __restrict__ ctl_amp, const float* __restrict__ ctl_hd,
+    const float* __restrict__ f0_all, float* __restrict__ audio /* pre-zeroed [B,N] */, int F, int K,
+    int N, int hop, float sample_rate, float nyquist, int amp_linear, int angular) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const bool live = k < K;
+  const int kk = live ? k : K - 1;
+  const float ratio = (float)(kk + 1);                    // tf.linspace(1, K, K)[k]
+  const float* __restrict__ f0 = f0_all + (size_t)b * F;
+  const float* __restrict__ amp = ctl_amp + (size_t)b * F;
+  const float* __restrict__ hd = ctl_hd + (size_t)b * F * K;
+  const float scale = (float)F / (float)N;                // legacy resize scale, fp32
+  const float two_pi = 6.283185307179586f;                // fl32(2*pi)
+  float phase = 0.0f, chunk_phase = 0.0f, offset = 0.0f, offset_sum = 0.0f;
+  for (int t = 0; t < N; ++t) {
+    // frequency envelope: resample(f0*ratio) 'linear' (core.py:1091,1102,613-621)
+    const float pos = (float)t * scale;
+    const float lo = floorf(pos);
+    const int lo_i = (int)lo, hi_i = min((int)ceilf(pos), F - 1);
+    const float top = __fmul_rn(f0[lo_i], ratio), bottom = __fmul_rn(f0[hi_i], ratio);
+    const float f = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+    // amplitude envelope: resample(amplitudes*distribution) 'window' or 'linear' (core.py:1097,1103)
+    float a;
+    if (amp_linear) {
+      const float atop = __fmul_rn(amp[lo_i], hd[(size_t)lo_i * K + kk]);
+      const float abot = __fmul_rn(amp[hi_i], hd[(size_t)hi_i * K + kk]);
+      a = __fadd_rn(atop, __fmul_rn(__fsub_rn(abot, atop), pos - lo));
+    } else {
+      const int j = t / hop, r = t - j * hop, j1 = min(j + 1, F - 1);
+      // periodic Hann(2*hop) in fp32: tf.signal.hann_window (core.py:698)
+      const float w_hi = 0.5f - 0.5f * cosf(two_pi * (float)(hop + r) / (float)(2 * hop));
+      const float w_lo = 0.5f - 0.5f * cosf(two_pi * (float)r / (float)(2 * hop));
+      const float x0 = __fmul_rn(amp[j], hd[(size_t)j * K + kk]);
+      const float x1 = __fmul_rn(amp[j1], hd[(size_t)j1 * K + kk]);
+      a = __fadd_rn(__fmul_rn(x0, w_hi), __fmul_rn(x1, w_lo));      // overlap_and_add of 2 frames
+    }
+    if (f >= nyquist) a = 0.0f;                                        // remove_above_nyquist
+    const float omega = __fdiv_rn(__fmul_rn(f, two_pi), sample_rate);   // core.py:947-948
+    float ph;
+    if (!angular) {
+      phase = __fadd_rn(phase, omega);                                 // tf.cumsum, sequential
+      ph = phase;
+    } else {                                                           // angular_cumsum, chunk 1000
+      if (t % 1000 == 0) {
+        if (t > 0) {
+          // offsets: previous chunks' final phases mod 2pi, cumulatively summed then mod 2pi
+          offset_sum = __fadd_rn(offset_sum, fmodf(chunk_phase, two_pi));
+          offset = fmodf(offset_sum, two_pi);
+        }
+        chunk_phase = 0.0f;
+      }
+      chunk_phase = __fadd_rn(chunk_phase, omega);
+      ph = fmodf(__fadd_rn(chunk_phase, offset), two_pi);
+    }
+    float v = live ? __fmul_rn(a, sinf(ph)) : 0.0f;
+    v = wave_sum_dpp(v);                                               // reduce_sum over harmonics
+    if (threadIdx.x == 0) {
+      if (gridDim.x == 1) audio[(size_t)b * N + t] = v;
+      else atomicAdd(&audio[(size_t)b * N + t], v);
+    }
+  }
+}
+}  // namespace ddsp
+
+extern "C" int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amp, const float* ctl_hd,
+                                                 const float* f0_hz, float* audio, int B, int F, int K,
+                                                 int N, int sample_rate, unsigned flags, void* stream) {
+  if (!ctl_amp || !ctl_hd || !f0_hz || !audio) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || K <= 0 || N <= 0 || sample_rate <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  const int amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  if (!amp_linear && (N % F != 0)) return DDSP_ERR_BAD_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int kblocks = (K + 63) / 64;
+  if (kblocks > 1 && hipMemsetAsync(audio, 0, (size_t)B * N * sizeof(float), st) != hipSuccess)
+    return DDSP_ERR_LAUNCH;
+  hipLaunchKernelGGL(harm_tf_order_kernel, dim3(kblocks, B), dim3(64), 0, st, ctl_amp, ctl_hd, f0_hz,
+                     audio, F, K, N, amp_linear ? 1 : N / F, (float)sample_rate,
+                     (float)(sample_rate / 2.0), amp_linear, (flags & DDSP_HARM_ANGULAR_CUMSUM) ? 1 : 0);
+  return check_launch();
+}

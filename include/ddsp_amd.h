@@ -80,6 +80,16 @@ int ddsp_harmonic_signal_f32(const float* ctl_amplitudes,
                              int F, int K, int N, int sample_rate, unsigned flags,
                              void* stream);
 
+/* Validation-only variant of ddsp_harmonic_signal_f32 that follows the reference's fp32 op order
+ * exactly, including the strictly sequential phase accumulation of tf.cumsum (ddsp/core.py:955)
+ * or angular_cumsum (:800-866, chunk 1000).  One lane per (row, harmonic), serial in time: slow by
+ * construction, used by the parity tests to compare full-length clips with the fp32-faithful
+ * oracle.  flags: DDSP_HARM_AMP_LINEAR, DDSP_HARM_ANGULAR_CUMSUM.  audio [B,N] out. */
+int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amplitudes,
+                                      const float* ctl_harmonic_distribution, const float* f0_hz,
+                                      float* audio, int B, int F, int K, int N, int sample_rate,
+                                      unsigned flags, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Harmonic.__call__  == get_signal(**get_controls(...))  (ddsp/processors.py:53-68),
  * fused: raw network outputs in, audio out, the [B,F,K] controls never round-trip

@@ -445,3 +445,28 @@ def test_harmonic_fused_unit_edges(ddsp, batch, n_frames):
   # repeated launches reuse the self-resetting work counters
   again = npy(synth(amps, hd, f0))
   np.testing.assert_array_equal(again, npy(out['signal']))
+
+
+@pytest.mark.parametrize('angular', [False, True])
+@pytest.mark.parametrize('method', ['window', 'linear'])
+def test_tf_op_order_kernel_matches_faithful_oracle_full_length(ddsp, angular, method):
+  """The validation kernel follows the reference's fp32 op order (sequential tf.cumsum /
+  angular_cumsum), so it tracks the fp32-faithful oracle over a whole 4 s clip, where the default
+  path has drifted by O(1) from exact arithmetic."""
+  x = canonical_inputs(1, seed=21, f0_center=200.0)
+  c = O.harmonic_get_controls(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'])
+  faithful = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'],
+                                   amp_resample_method=method, use_angular_cumsum=angular)
+  ours = npy(ddsp.core.harmonic_synthesis(c['f0_hz'], c['amplitudes'],
+                                          harmonic_distribution=c['harmonic_distribution'],
+                                          amp_resample_method=method, use_angular_cumsum=angular,
+                                          tf_op_order=True))
+  err = np.abs(ours - faithful)
+  print('tf-order kernel vs faithful fp32 oracle (angular=%s, %s): max %.2e' % (angular, method, err.max()))
+  # sin of fp32 phases up to 2e5 rad: 1 ulp of the phase is 1.6e-2 rad, so one differently rounded
+  # add anywhere in the chain shows up as ~1e-2 on a harmonic; typical error is far smaller
+  assert err.max() <= 5e-2 and np.sqrt((err**2).mean()) <= 2e-3
+  if not angular:
+    truth = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'],
+                                  amp_resample_method=method, dtype=np.float64)
+    assert np.abs(faithful - truth).max() > 10 * err.max()    # the drift this kernel reproduces
