@@ -8,6 +8,7 @@
 // (tap set chosen by the frame of the INPUT sample; oracle test
 // test_fft_convolve_equals_direct_time_varying_fir), which is what is evaluated here:
 // no FFT, no [B,F,fft_size] complex intermediates in HBM.
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
@@ -807,11 +808,12 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       q.scale = scale | ((flags & 0x40000000u) ? 0x40000000 : 0);      // bit 30: debug timeline
       q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
-      ProfileScope prof(kNoiseFused, st);
-      if (noise) hipLaunchKernelGGL((noise_fused65_kernel<false>), grid, dim3(256), 0, st, magnitudes,
-                                    noise, ctl_magnitudes, audio, q);
-      else hipLaunchKernelGGL((noise_fused65_kernel<true>), grid, dim3(256), 0, st, magnitudes,
-                              noise, ctl_magnitudes, audio, q);
+      hipEvent_t ev0, ev1;
+      profile_kernel_events(kNoiseFused, &ev0, &ev1);
+      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                       magnitudes, noise, ctl_magnitudes, audio, q);
+      else hipExtLaunchKernelGGL((noise_fused65_kernel<true>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                 magnitudes, noise, ctl_magnitudes, audio, q);
       return check_launch();
     }
   }

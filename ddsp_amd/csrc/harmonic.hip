@@ -17,6 +17,7 @@
 //             the k loop; the Hann / linear interpolation weights are applied once per
 //             sample after the loop.
 #include <atomic>
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
@@ -725,10 +726,11 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   const size_t lds = (size_t)kUnitRows * K * sizeof(float);
   static std::atomic<unsigned> ticket{0};
   p.sched_set = (int)(ticket.fetch_add(1u) % (unsigned)kSchedSets);
-  ProfileScope prof(kHarmFused, st);
+  hipEvent_t ev0, ev1;
+  profile_kernel_events(kHarmFused, &ev0, &ev1);
 #define DDSP_LAUNCH_FUSED(NE)                                                                \
-  hipLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, amps, hd, f0, ctl_amp, ctl_hd, \
-                     (float*)workspace, audio, p)
+  hipExtLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, ev0, ev1, 0, amps, hd, f0, \
+                        ctl_amp, ctl_hd, (float*)workspace, audio, p)
   if (ne <= 1) DDSP_LAUNCH_FUSED(1);
   else if (ne <= 2) DDSP_LAUNCH_FUSED(2);
   else if (ne <= 3) DDSP_LAUNCH_FUSED(3);

@@ -23,6 +23,12 @@ enum KernelId {
 // mask bit i set => kernel i is bracketed by events while tracing is on
 void profile_record(int kernel_id, hipStream_t st, bool start);
 
+// Events to attach to the kernel's own dispatch packet (hipExtLaunchKernelGGL start/stop events):
+// these carry the kernel's begin/end timestamps, which is what rocprofv3 reports, without the
+// command-processor gaps a pair of separate hipEventRecord packets would add.  Both are nullptr
+// when tracing is off for this kernel.
+void profile_kernel_events(int kernel_id, hipEvent_t* start, hipEvent_t* stop);
+
 struct ProfileScope {
   int id; hipStream_t st;
   ProfileScope(int kernel_id, hipStream_t s) : id(kernel_id), st(s) { profile_record(id, st, true); }

@@ -33,6 +33,16 @@ void profile_record(int kernel_id, hipStream_t st, bool start) {
     }
   }
 }
+void profile_kernel_events(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
+  *start = nullptr; *stop = nullptr;
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on || !((g_mask >> kernel_id) & 1u) || g_recs.size() >= g_cap) return;
+  Rec r; r.id = kernel_id;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  g_recs.push_back(r);
+  *start = r.e0; *stop = r.e1;
+}
 }  // namespace ddsp
 
 using namespace ddsp;
