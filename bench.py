@@ -47,9 +47,9 @@ def parse_args():
   ap.add_argument('--f0', type=float, default=70.0, help='f0 centre in Hz (70: all harmonics live)')
   ap.add_argument('--cpu-clips', type=int, default=12, help='clips timed by the CPU oracle leg')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--overlap', action='store_true',
-                  help='issue the two Processor calls on two HIP streams instead of back to back on '
-                       'one (measured slower on MI355X: 88 vs 73 us per step at batch 32)')
+  ap.add_argument('--no-overlap', action='store_true',
+                  help='issue the two Processor calls back to back on one stream instead of on two '
+                       'free-running HIP streams')
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
   return ap.parse_args()
@@ -126,21 +126,22 @@ def main():
   harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
   fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
 
-  # The two Processor calls of a step are independent; --overlap puts FilteredNoise on a second HIP
-  # stream (the persistent harmonic kernel hands its units out dynamically and uses whatever share
-  # of the CUs it gets).  Default: back to back on the current stream.
-  main_stream = torch.cuda.current_stream()
-  side_stream = torch.cuda.Stream()
-  overlap = a.overlap
+  # The two Processor calls of a step are independent (nothing on this path joins them; the
+  # reference's Add would): Harmonic and FilteredNoise are issued on two free-running HIP streams so
+  # FilteredNoise's latency-bound stages run under Harmonic's ALU-bound synthesis (the persistent
+  # harmonic kernel hands its units out dynamically and uses whatever share of the CUs it gets).
+  # Joining the streams every step costs more than it gains (88 vs 62 us at batch 32), so the join is
+  # the barrier + synchronize that closes the timed region.  --no-overlap: one stream, back to back.
+  stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
+  overlap = not a.no_overlap
 
-  def step():
-    if overlap:
-      side_stream.wait_stream(main_stream)
-      with torch.cuda.stream(side_stream):
+  def step(two_streams=None):
+    two_streams = overlap if two_streams is None else two_streams
+    if two_streams:
+      with torch.cuda.stream(stream_h):
+        h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
+      with torch.cuda.stream(stream_z):
         z = fnoise(dev['magnitudes'])
-      h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
-      main_stream.wait_stream(side_stream)
-      z.record_stream(main_stream)
     else:
       h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
       z = fnoise(dev['magnitudes'])
@@ -155,10 +156,12 @@ def main():
     step()
   torch.cuda.synchronize()
 
-  # diagnostic pass (untimed): every kernel bracketed, to find the dominant one
+  # diagnostic pass (untimed, one stream so every kernel runs alone): every kernel bracketed, to
+  # find the dominant one and give the isolated per-kernel times
   _lib.profile_begin(None, max_records=64)
-  for _ in range(2):
-    step()
+  for _ in range(3):
+    step(two_streams=False)
+  torch.cuda.synchronize()
   breakdown = _lib.profile_end()
   dominant = max(breakdown, key=lambda k: breakdown[k][0] / breakdown[k][1])
 
@@ -176,6 +179,18 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+  # the other issue mode, same K steps, reported next to the headline for transparency
+  sync_all()
+  t_alt = time.perf_counter()
+  for _ in range(a.steps):
+    step(two_streams=not overlap)
+  sync_all()
+  alt_elapsed = time.perf_counter() - t_alt
+  if world > 1:
+    t = torch.tensor([alt_elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    alt_elapsed = float(t.item())
 
   gather_ms = None
   if a.allgather and world > 1:
@@ -221,8 +236,8 @@ def main():
                         (B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
             'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
             'no collective' % world,
-            'streams': 'Harmonic and FilteredNoise on two HIP streams (concurrent)' if overlap
-                       else 'one stream (sequential)'},
+            'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
+                       else 'one stream, back to back'},
         'roofline': {
             'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -231,7 +246,11 @@ def main():
             'whole_step': {'algorithmic_bytes': step_bytes,
                            'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
                            'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}},
-        'kernel_breakdown_us': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
+        'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
+        'other_issue_mode': {
+            'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',
+            'ms_per_step': alt_elapsed / a.steps * 1e3,
+            'value': world * B * a.n_samples * a.steps / alt_elapsed / 1e6},
     }
     if gather_ms is not None:
       result['allgather_ms'] = gather_ms
