@@ -450,11 +450,13 @@ __device__ __forceinline__ void fn_load16(const float* s_x, int ip, float (&v)[1
     v[4 * c4] = t.x; v[4 * c4 + 1] = t.y; v[4 * c4 + 2] = t.z; v[4 * c4 + 3] = t.w;
   }
 }
+// irel = i0 - z0 (multiple of 16, >= -112); rel0 = (z0 - 128) - f_first*fs >= 0; rows are frames
+// relative to f_first.  (x + 0.5) * inv_fs floors exactly for the magnitudes involved (< 2^13).
 __device__ __forceinline__ void fn_tap_block(const float* s_x, const float* s_h, int irel, int k0,
                                              float (&acc)[16], const float (&hi)[16],
-                                             float (&lo)[16]) {
-  const int rowA = (irel + 128) >> 6;           // frame(i0)    - (J0-2)
-  const int rowB = (irel + 112) >> 6;           // frame(i0-16) - (J0-2)
+                                             float (&lo)[16], int rel0, float inv_fs) {
+  const int rowA = (int)(((float)(irel + 128 + rel0) + 0.5f) * inv_fs);   // frame(i0)    - f_first
+  const int rowB = (int)(((float)(irel + 112 + rel0) + 0.5f) * inv_fs);   // frame(i0-16) - f_first
   fn_load16(s_x, irel + 128 - 16, lo);
   float ta[16], tb[16];
 #pragma unroll
@@ -475,7 +477,8 @@ __device__ __forceinline__ void fn_tap_block(const float* s_x, const float* s_h,
 }
 
 struct FusedNoiseArgs {
-  int N, F, start, scale;
+  int N, F, start, scale, fs;      // fs = frame size: a multiple of 16, >= 64
+  float inv_fs;
   float bias;
   uint32_t k0, k1;
   uint64_t batch_offset;
@@ -491,7 +494,13 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int z0 = blockIdx.x * kFnTile;
-  const int J0 = blockIdx.x * kFnFrames;
+  // frames whose taps this tile needs: those of the inputs x[z0-128 .. z0+3967]; the 64 staged rows
+  // start at f_first = floor((z0-128)/fs) (negative for the first tile: zero rows)
+  const int f_first = (z0 - 128 >= 0) ? (z0 - 128) / p.fs : -((128 - z0 + p.fs - 1) / p.fs);
+  const int rel0 = (z0 - 128) - f_first * p.fs;
+  // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+  const int own_lo = (blockIdx.x == 0) ? 0 : f_first + 2;
+  const int own_hi = (z0 + kFnTile - 128) / p.fs + 2;          // f_first of the next tile + 2
   const float kLog10 = 2.302585092994046f;
   // debug timeline (p.scale bit 30): ctl_out is reinterpreted as long long [blocks][8]
   const bool dbg_time = (p.scale & 0x40000000) != 0;
@@ -506,8 +515,8 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   // The 64 rows are one contiguous span of 4160 floats in HBM: 16-byte loads from the span's
   // aligned-down start (vector-memory instruction issue, not bandwidth, is the cost here).
   {
-    const long f_first = (long)b * p.F + (J0 - 2);                  // may be < b*F for the first tile
-    const long e0 = f_first * 65;                                   // first element wanted
+    const long row_first = (long)b * p.F + f_first;                 // may be < b*F for the first tile
+    const long e0 = row_first * 65;                                 // first element wanted
     const long lo = (long)b * p.F * 65, hi = ((long)b + 1) * p.F * 65;   // this batch row's elements
     const long a0 = e0 & ~3L;                                       // aligned-down start (may be < 0)
     const long total = ((long)p.F * 65) * (long)gridDim.y;          // elements in the whole tensor
@@ -530,7 +539,10 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
           float y = 0.0f;
           if (e >= lo && e < hi) {                                  // frame inside [0,F) of this row
             y = do_scale ? exp_sigmoid_fast(x[u] + p.bias, kLog10, 2.0f, 1e-7f) : x[u];
-            if (ctl_out && i >= 2 * 65) ctl_out[e] = y;             // rows 0,1 belong to the previous block
+            if (ctl_out) {                                          // written by the owning tile only
+              const int fr = f_first + (int)(((float)i + 0.5f) * (1.0f / 65.0f));
+              if (fr >= own_lo && fr < own_hi) ctl_out[e] = y;
+            }
           }
           s_u[i] = y;
         }
@@ -606,8 +618,8 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     fn_load16(s_u, mrel + 128, xa);
 #pragma unroll 1
     for (int kb = 0; kb < 8; kb += 2) {
-      fn_tap_block(s_u, s_h, mrel - 16 * kb, 16 * kb, acc, xa, xb);
-      fn_tap_block(s_u, s_h, mrel - 16 * (kb + 1), 16 * (kb + 1), acc, xb, xa);
+      fn_tap_block(s_u, s_h, mrel - 16 * kb, 16 * kb, acc, xa, xb, rel0, p.inv_fs);
+      fn_tap_block(s_u, s_h, mrel - 16 * (kb + 1), 16 * (kb + 1), acc, xb, xa, rel0, p.inv_fs);
     }
   }
   __syncthreads();                                      // everyone is done reading x
@@ -801,10 +813,12 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   {
     const IrGeom g = ir_geom(M, window_size);
     const int frame_size = (N + F - 1) / F;
-    if (M == 65 && g.padding == 0 && frame_size == 64 && (N + 63) / 64 == F && B <= 65535 &&
+    if (M == 65 && g.padding == 0 && frame_size >= 64 && (frame_size % 16) == 0 && frame_size <= 4096 &&
+        (N + frame_size - 1) / frame_size == F && B <= 65535 &&
         (noise == nullptr || (((uintptr_t)noise) & 15) == 0)) {
       FusedNoiseArgs q;
       q.N = N; q.F = F; q.start = (g.L - 1) / 2 - 1; q.bias = initial_bias;
+      q.fs = frame_size; q.inv_fs = 1.0f / (float)frame_size;
       q.scale = scale | ((flags & 0x40000000u) ? 0x40000000 : 0);      // bit 30: debug timeline
       q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);

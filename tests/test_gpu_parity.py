@@ -470,3 +470,17 @@ def test_tf_op_order_kernel_matches_faithful_oracle_full_length(ddsp, angular, m
     truth = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'],
                                   amp_resample_method=method, dtype=np.float64)
     assert np.abs(faithful - truth).max() > 10 * err.max()    # the drift this kernel reproduces
+
+
+@pytest.mark.parametrize('fs,n_frames,ragged', [(128, 40, 0), (192, 50, 5), (320, 30, 0), (80, 70, 3), (960, 9, 0)])
+def test_filtered_noise_fused_other_frame_sizes(ddsp, fs, n_frames, ragged):
+  """M=65 with frame sizes other than 64 (48 kHz / VST configs: hop 192, 320, 960) on the fused kernel."""
+  n = fs * n_frames - ragged
+  rng = np.random.default_rng(fs)
+  mags = rng.standard_normal((2, n_frames, 65)).astype(np.float32)
+  noise = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+  out = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(mags, noise=noise, return_outputs_dict=True)
+  ref = O.filtered_noise(mags, noise, 0, dtype=np.float64)
+  assert np.abs(npy(out['signal']) - ref).max() <= noise_tol(ref)
+  np.testing.assert_allclose(npy(out['controls']['magnitudes']),
+                             O.filtered_noise_get_controls(mags)['magnitudes'], rtol=2e-5, atol=1e-9)
