@@ -383,6 +383,24 @@ __device__ __forceinline__ void harm_hex_full(const float* p0, const float* p1, 
   }
 }
 
+typedef float sgpr4 __attribute__((ext_vector_type(4)));
+
+// 4 more harmonics k+1 .. k+4 continuing the recurrence of the preceding super-block (no new seeds)
+template <int OFF>
+__device__ __forceinline__ void harm_quad_cont(const float* p0, const float* p1, float c4,
+                                               float (&s)[4], float (&acc)[4]) {
+  sgpr4 a0, a1;
+  asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float sn = fmaf(c4, s[(u + 2) & 3], -s[u]);
+    s[u] = sn;
+    acc[2 * (u & 1)] = fmaf(a0[u], sn, acc[2 * (u & 1)]);
+    acc[2 * (u & 1) + 1] = fmaf(a1[u], sn, acc[2 * (u & 1) + 1]);
+  }
+}
+
 struct FusedArgs {
   int B, F, K, Kp, N, hop, units_per_row, n_units;
   float sample_rate, nyquist;
@@ -603,8 +621,8 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const int tiles_per_frame = hop >> 6;
     const int n_tiles = (p.flags & 0x20000000u) ? 0 : nfr * tiles_per_frame;   // experiment: phase A only
     for (int tile = wave; tile < n_tiles; tile += 4) {
-      const int q = tile / tiles_per_frame;
-      const int r = (tile - q * tiles_per_frame) * 64 + lane;
+      const int q = (tiles_per_frame == 1) ? tile : tile / tiles_per_frame;
+      const int r = (tiles_per_frame == 1) ? lane : (tile - q * tiles_per_frame) * 64 + lane;
       const double rr = (double)r;
       // inclusive cumsum of f[t]/sr inside the frame: (r+1)*w + r(r+1)*dw
       const double cyc = t.theta[q] + (rr + 1.0) * (t.w[q] + t.dw[q] * rr);
@@ -634,6 +652,10 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
           harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
           harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
         }
+        // up to three trailing groups of 4 simply continue the last super-block's recurrence
+        // (K = 100: 64 + 32 + 4); only possible when at least one super-block came before
+        if (k > 0 && kend - k <= 12)
+          for (; k < kend; k += 4, q0 += 4, q1 += 4) harm_quad_cont<0>(q0, q1, c4, sn, acc);
       }
       for (; k < kend; k += 32) {           // the tail: octets with group guards, seeds in the first
         const int rem4 = (kend - k) >> 2;
