@@ -429,7 +429,7 @@ struct UnitTables {
 // Phase A runs once per 16 frames but on every wavefront of the chip at the same time, so its
 // cost is its dynamic instruction count x 8 waves per SIMD: everything below is written to be
 // short (16-byte accesses, 32-bit indexing, no divisions, one-wave jobs on different waves).
-template <int NE>   // float4 groups per thread in phase A: NE * 256 >= 17 * K / 4
+template <int NE, bool ONE_TILE>   // NE float4 groups per thread in phase A; ONE_TILE: hop == 64
 __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd,
     const float* __restrict__ f0_all, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd,
@@ -621,8 +621,10 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const int tiles_per_frame = hop >> 6;
     const int n_tiles = (p.flags & 0x20000000u) ? 0 : nfr * tiles_per_frame;   // experiment: phase A only
     for (int tile = wave; tile < n_tiles; tile += 4) {
-      const int q = (tiles_per_frame == 1) ? tile : tile / tiles_per_frame;
-      const int r = (tiles_per_frame == 1) ? lane : (tile - q * tiles_per_frame) * 64 + lane;
+      // ONE_TILE (hop == 64): r == lane for every tile, so everything that depends only on r (its
+      // fp64 image, the interpolation weights) is loop invariant and hoisted by the compiler
+      const int q = ONE_TILE ? tile : tile / tiles_per_frame;
+      const int r = ONE_TILE ? lane : (tile - q * tiles_per_frame) * 64 + lane;
       const double rr = (double)r;
       // inclusive cumsum of f[t]/sr inside the frame: (r+1)*w + r(r+1)*dw
       const double cyc = t.theta[q] + (rr + 1.0) * (t.w[q] + t.dw[q] * rr);
@@ -751,8 +753,14 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmFused, &ev0, &ev1);
 #define DDSP_LAUNCH_FUSED(NE)                                                                \
-  hipExtLaunchKernelGGL((harm_fused_kernel<NE>), grid, block, lds, st, ev0, ev1, 0, amps, hd, f0, \
-                        ctl_amp, ctl_hd, (float*)workspace, audio, p)
+  do {                                                                                       \
+    if (p.hop == 64)                                                                         \
+      hipExtLaunchKernelGGL((harm_fused_kernel<NE, true>), grid, block, lds, st, ev0, ev1, 0, amps, hd, \
+                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
+    else                                                                                     \
+      hipExtLaunchKernelGGL((harm_fused_kernel<NE, false>), grid, block, lds, st, ev0, ev1, 0, amps, hd, \
+                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
+  } while (0)
   if (ne <= 1) DDSP_LAUNCH_FUSED(1);
   else if (ne <= 2) DDSP_LAUNCH_FUSED(2);
   else if (ne <= 3) DDSP_LAUNCH_FUSED(3);
