@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
   ap.add_argument('--n-frames', type=int, default=1000)
@@ -47,9 +47,16 @@ def parse_args():
   ap.add_argument('--f0', type=float, default=70.0, help='f0 centre in Hz (70: all harmonics live)')
   ap.add_argument('--cpu-clips', type=int, default=12, help='clips timed by the CPU oracle leg')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--event-stride', type=int, default=8,
+                  help='bracket every n-th launch of the dominant kernel with HIP events inside the '
+                       'timed region (a bracketed launch costs ~5 us of queue time; 1 = all of them)')
   ap.add_argument('--no-overlap', action='store_true',
                   help='issue the two Processor calls back to back on one stream instead of on two '
                        'free-running HIP streams')
+  ap.add_argument('--also-other-mode', action='store_true',
+                  help='after the timed region, run K more steps in the other stream mode and report '
+                       'them as other_issue_mode (off by default so that a rocprofv3 trace of the '
+                       'default command sees one mode only)')
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
   return ap.parse_args()
@@ -133,15 +140,19 @@ def main():
   # Joining the streams every step costs more than it gains (88 vs 62 us at batch 32), so the join is
   # the barrier + synchronize that closes the timed region.  --no-overlap: one stream, back to back.
   stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
+  stream_0 = torch.cuda.current_stream()
   overlap = not a.no_overlap
 
   def step(two_streams=None):
     two_streams = overlap if two_streams is None else two_streams
     if two_streams:
-      with torch.cuda.stream(stream_h):
-        h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
-      with torch.cuda.stream(stream_z):
-        z = fnoise(dev['magnitudes'])
+      # set_stream, not the `with torch.cuda.stream()` context manager: the manager costs ~15 us of
+      # host time per use, which at batch 32 is as long as the kernels it is trying to overlap
+      torch.cuda.set_stream(stream_h)
+      h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
+      torch.cuda.set_stream(stream_z)
+      z = fnoise(dev['magnitudes'])
+      torch.cuda.set_stream(stream_0)
     else:
       h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
       z = fnoise(dev['magnitudes'])
@@ -166,7 +177,7 @@ def main():
   dominant = max(breakdown, key=lambda k: breakdown[k][0] / breakdown[k][1])
 
   # ---- timed region: exactly K steps, barrier + synchronize on both sides ----------------
-  _lib.profile_begin([dominant], max_records=2 * a.steps + 8)
+  _lib.profile_begin([dominant], max_records=2 * a.steps + 8, stride=a.event_stride)
   sync_all()
   t0 = time.perf_counter()
   for _ in range(a.steps):
@@ -180,17 +191,19 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  # the other issue mode, same K steps, reported next to the headline for transparency
-  sync_all()
-  t_alt = time.perf_counter()
-  for _ in range(a.steps):
-    step(two_streams=not overlap)
-  sync_all()
-  alt_elapsed = time.perf_counter() - t_alt
-  if world > 1:
-    t = torch.tensor([alt_elapsed], dtype=torch.float64, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    alt_elapsed = float(t.item())
+  # optionally the other issue mode, same K steps, reported next to the headline
+  alt_elapsed = None
+  if a.also_other_mode:
+    sync_all()
+    t_alt = time.perf_counter()
+    for _ in range(a.steps):
+      step(two_streams=not overlap)
+    sync_all()
+    alt_elapsed = time.perf_counter() - t_alt
+    if world > 1:
+      t = torch.tensor([alt_elapsed], dtype=torch.float64, device='cuda')
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      alt_elapsed = float(t.item())
 
   gather_ms = None
   if a.allgather and world > 1:
@@ -242,16 +255,19 @@ def main():
             'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': dom_avg_s * 1e6,
-            'launches': dom_n,
+            'launches': dom_n, 'event_stride': a.event_stride,
+            'timing': 'dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
+                      'every event_stride-th launch inside the timed region',
             'whole_step': {'algorithmic_bytes': step_bytes,
                            'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
                            'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}},
         'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
-        'other_issue_mode': {
-            'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',
-            'ms_per_step': alt_elapsed / a.steps * 1e3,
-            'value': world * B * a.n_samples * a.steps / alt_elapsed / 1e6},
     }
+    if alt_elapsed is not None:
+      result['other_issue_mode'] = {
+          'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',
+          'ms_per_step': alt_elapsed / a.steps * 1e3,
+          'value': world * B * a.n_samples * a.steps / alt_elapsed / 1e6}
     if gather_ms is not None:
       result['allgather_ms'] = gather_ms
     if not a.no_cpu_baseline and world == 1:

@@ -40,6 +40,7 @@ SIGNATURES = {
     'ddsp_profile_kernel_count': (c_int, []),
     'ddsp_profile_kernel_name': (ctypes.c_char_p, [c_int]),
     'ddsp_profile_begin': (c_int, [c_uint, c_int]),
+    'ddsp_profile_begin_sampled': (c_int, [c_uint, c_int, c_int]),
     'ddsp_profile_end': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
 }
 
@@ -86,8 +87,11 @@ def check(rc, what):
     raise DdspLibraryError('%s failed: %s (%d)' % (what, ERRORS.get(rc, 'unknown'), rc))
 
 
-def profile_begin(kernel_names=None, max_records=4096):
-  """Start per-kernel HIP-event tracing; kernel_names=None traces every kernel."""
+def profile_begin(kernel_names=None, max_records=4096, stride=1):
+  """Start per-kernel HIP-event tracing; kernel_names=None traces every kernel.
+
+  stride=n brackets only every n-th launch of each selected kernel (a bracketed launch costs
+  ~5 us of queue time, so a timed region samples instead of bracketing everything)."""
   lib = load()
   n = lib.ddsp_profile_kernel_count()
   names = [lib.ddsp_profile_kernel_name(i).decode() for i in range(n)]
@@ -95,7 +99,8 @@ def profile_begin(kernel_names=None, max_records=4096):
   for i, nm in enumerate(names):
     if kernel_names is None or nm in kernel_names:
       mask |= 1 << i
-  check(lib.ddsp_profile_begin(mask, int(max_records)), 'ddsp_profile_begin')
+  check(lib.ddsp_profile_begin_sampled(mask, int(max_records), int(stride)),
+        'ddsp_profile_begin_sampled')
 
 
 def profile_end():

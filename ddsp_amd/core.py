@@ -26,6 +26,8 @@ def _device():
 
 def tf_float32(x):
   """core.tf_float32 (ddsp/core.py:31-36): anything -> contiguous fp32 tensor in HBM."""
+  if type(x) is torch.Tensor and x.is_cuda and x.dtype is torch.float32 and x.is_contiguous():
+    return x                                  # the common case: nothing to do (host overhead matters)
   if isinstance(x, torch.Tensor):
     if not x.is_cuda:
       x = x.to(_device())
@@ -34,7 +36,22 @@ def tf_float32(x):
 
 
 def _stream():
-  return torch.cuda.current_stream().cuda_stream
+  """Raw hipStream_t of torch's current stream (the C call: torch.cuda.current_stream() alone
+  costs ~4 us of Python per launch, more than the launch itself)."""
+  return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+_ws_bytes_cache = {}
+
+
+def cached_workspace_bytes(fn_name, *shape):
+  """Workspace size queries are pure functions of the shape: one ctypes call per new shape."""
+  key = (fn_name,) + shape
+  n = _ws_bytes_cache.get(key)
+  if n is None:
+    n = getattr(_lib.load(), fn_name)(*shape)
+    _ws_bytes_cache[key] = n
+  return n
 
 
 class Workspace:

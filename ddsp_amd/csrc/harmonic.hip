@@ -17,6 +17,7 @@
 //             the k loop; the Hann / linear interpolation weights are applied once per
 //             sample after the loop.
 #include <atomic>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "profile.h"
@@ -406,7 +407,7 @@ struct FusedArgs {
   float sample_rate, nyquist;
   unsigned flags;
   int inputs_are_controls, amp_linear;
-  float inv_K4;                  // 1 / (K/4)
+  int f0_vec;                    // f0 rows are 16-byte aligned (F % 4 == 0, aligned base): float4 prefix loads
   float inv_upr;                 // 1 / units_per_row
   int sched_set;                 // which g_sched set this launch uses
   float nyq_lo, nyq_hi;          // nyquist * (1 -+ 4e-6): guard band of the live-harmonic counts
@@ -416,50 +417,69 @@ struct FusedArgs {
 
 constexpr int kUnitRows = kFramesPerBlock + 1;
 
-// LDS tables of one unit
+// LDS tables of one unit (written by the phase wave, read by every wavefront's tiles)
 struct UnitTables {
   int next_unit;
-  double red[4];                                         // per-wave partials of sum_{j<j0} f0_j
   double theta[kFramesPerBlock], w[kFramesPerBlock], dw[kFramesPerBlock];
-  float f0[kUnitRows + 3];
-  float2 inv_amp[kUnitRows];                             // {1/sum(distribution), scaled amplitude}
+  float f0[kUnitRows + 1];
   int kA[kFramesPerBlock], kN[kFramesPerBlock];
 };
 
-// Phase A runs once per 16 frames but on every wavefront of the chip at the same time, so its
-// cost is its dynamic instruction count x 8 waves per SIMD: everything below is written to be
-// short (16-byte accesses, 32-bit indexing, no divisions, one-wave jobs on different waves).
-template <int NE, bool ONE_TILE>   // NE float4 groups per thread in phase A; ONE_TILE: hop == 64
+// Sum over the LPR lanes that share a matrix row; every lane of the group gets the sum.  Full EXEC.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  if (LPR == 64) return wave_sum_dpp(v);
+  v += dpp_mov0<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov0<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov0<0x141, 0xF>(v);    // row_half_mirror
+  v += dpp_mov0<0x140, 0xF>(v);    // row_mirror: every lane holds its 16-lane row's sum
+  if (LPR == 32)                   // the neighbouring row of the pair: lane ^ 16 (swizzle, no address VGPR)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+  return v;
+}
+
+// Phase A is pure overhead relative to the synthesis loop (it touches 900 values per unit, the loop
+// 51200), but it is paid in issue slots on every wavefront: an earlier layout (flat float4 groups
+// staged through LDS, 5 barriers, run-time flags) cost ~370 VALU + ~240 SALU instructions per
+// wavefront per unit - a third of the kernel's instruction count (profiles/r01_pmc_sq_counters_b32).
+// This layout gives LPR lanes to one matrix row, so a row's sum is a DPP reduction in registers:
+// no LDS staging, no barrier inside phase A, and the common flag combination (STD) is compiled in.
+template <int LPR, bool ONE_TILE, bool STD>   // LPR lanes per row (K <= 4*LPR); ONE_TILE: hop == 64;
+                                              // STD: scale + Nyquist-normalise, no controls written
 __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd,
-    const float* __restrict__ f0_all, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd,
-    float* ws /*[gridDim.x][17][Kp]*/, float* __restrict__ audio, FusedArgs p) {
+    const float* __restrict__ f0_all, float* __restrict__ ctl_amp_arg, float* __restrict__ ctl_hd_arg,
+    float* ws /*[gridDim.x][kUnitRows][Kp]*/, float* __restrict__ audio, FusedArgs p) {
   __shared__ UnitTables t;
-  extern __shared__ __attribute__((aligned(16))) float s_x[];     // [17 * K] scaled distribution
-  // debug timeline (flag 0x02000000): ctl_amp is reinterpreted as long long [gridDim.x][16]
-  const bool dbg_time = (p.flags & 0x02000000u) != 0;
-  long long* dbg = dbg_time ? reinterpret_cast<long long*>(ctl_amp) + (size_t)blockIdx.x * 16 : nullptr;
+  float* __restrict__ ctl_amp = STD ? nullptr : ctl_amp_arg;
+  float* __restrict__ ctl_hd = STD ? nullptr : ctl_hd_arg;
+  // debug timeline (flag 0x02000000, generic variant only): ctl_amp is reinterpreted as long long [gridDim.x][16]
+  const bool dbg_time = !STD && (p.flags & 0x02000000u) != 0;
+  long long* dbg = dbg_time ? reinterpret_cast<long long*>(ctl_amp_arg) + (size_t)blockIdx.x * 16 : nullptr;
   int dbg_n = 0;
-#define DDSP_STAMP() do { if (dbg_time && threadIdx.x == 0 && dbg_n < 16) dbg[dbg_n++] = wall_clock64(); } while (0)
+#define DDSP_STAMP() do { if (!STD && dbg_time && threadIdx.x == 0 && dbg_n < 16) dbg[dbg_n++] = wall_clock64(); } while (0)
   if (dbg_time) ctl_amp = nullptr;
   DDSP_STAMP();
+  constexpr int RPW = 64 / LPR;                          // matrix rows per wavefront per pass
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int F = p.F, K = p.K, Kp = p.Kp;
-  const int K4 = K >> 2;                               // K % 4 == 0 on this path
+  const int K4 = K >> 2;                                 // K % 4 == 0 on this path
+  const int sub = lane / LPR, kq = lane % LPR;           // row within the wave's pass, float4 within the row
+  const bool live = kq < K4;
   float* wsu = ws + (size_t)blockIdx.x * kUnitRows * Kp;
-  const bool scale = (p.flags & DDSP_HARM_SCALE_EXP_SIGMOID) && !p.inputs_are_controls;
-  const bool normalize = (p.flags & DDSP_HARM_NORMALIZE_NYQUIST) && !p.inputs_are_controls;
+  const bool is_ctl = STD ? false : (p.inputs_are_controls != 0);
+  const bool scale = STD ? true : ((p.flags & DDSP_HARM_SCALE_EXP_SIGMOID) && !is_ctl);
+  const bool normalize = STD ? true : ((p.flags & DDSP_HARM_NORMALIZE_NYQUIST) && !is_ctl);
   const float kLog10 = 2.302585092994046f;      // tf.math.log(exponent), ddsp/core.py:403
-  const int n_grp = kUnitRows * K4;                    // float4 groups of one unit
+  const float4* __restrict__ hd4 = reinterpret_cast<const float4*>(hd);
+  float4* __restrict__ ctl_hd4 = reinterpret_cast<float4*>(ctl_hd);
 
   // The first unit of a block is its blockIdx; further units are handed out dynamically (one atomic
-  // per unit on a counter zeroed by the launcher): resident blocks keep pulling work, so the kernel
-  // balances itself whatever share of the chip it gets - it is meant to run next to the
-  // FilteredNoise kernel on another stream.  (A burst of 2000 first pulls on one word would take
-  // ~25 us: one word serves ~88 atomics/us, MI355X_MICROARCH.md "dequeue".)
-  // Eight counters (one per XCD-aligned residue class of the unit index, 128 B apart) keep the
-  // pulls off a single word: class x owns units x, x+8, x+16, ...
+  // per unit): resident blocks keep pulling work, so the kernel balances itself whatever share of
+  // the chip it gets - it is meant to run next to the FilteredNoise kernel on another stream.
+  // Eight counters (one per XCD-aligned residue class of the unit index, 128 B apart) keep the pulls
+  // off a single word (one word serves ~88 atomics/us): class x owns units x, x+8, x+16, ...
   const int xcls = blockIdx.x & 7;
   unsigned* counter = &g_sched[p.sched_set][xcls][0];
   unsigned* done = &g_sched[p.sched_set][xcls][32];
@@ -470,119 +490,63 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const int j0 = c * kFramesPerBlock;
     const int nfr = min(kFramesPerBlock, F - j0);
     const int row0 = b * F + j0;                                          // first (batch*frame) row
-    const float* __restrict__ f0 = f0_all + (size_t)b * F;
-    // the unit's rows are contiguous in HBM: 16-byte accesses
-    const float4* __restrict__ hd_u = reinterpret_cast<const float4*>(hd) + (size_t)row0 * K4;
-    float4* __restrict__ ctl_hd_u = ctl_hd ? reinterpret_cast<float4*>(ctl_hd) + (size_t)row0 * K4 : nullptr;
-    const int halo_grp = (min(j0 + nfr, F - 1) - j0) * K4;              // halo row (clamped at F-1)
 
-    // ---------------- phase A.1: loads (scalars first: vmcnt retires in order) -------------------
-    float my_amp = 0.0f, my_f0 = 0.0f;
-    if (tid < kUnitRows) {                                               // thread q owns row q
-      const int j = min(j0 + min(tid, nfr), F - 1);
-      my_f0 = f0[j];
-      my_amp = amplitudes[(size_t)b * F + j];
-    }
-    // Phase prefix (fp64).  Frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop (legacy bilinear
-    // resize of f0), whose sum over the frame is hop*f_j + (f_{j+1}-f_j)(hop-1)/2; summed over
-    // j < J this telescopes to hop*sum_{j<J} f_j + (f_J - f_0)(hop-1)/2: only sum f_j is needed.
-    // One 16-byte load per thread covers 1024 frames.
-    float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      const int j = 4 * tid;
-      if (j < j0) {
-        if ((F & 3) == 0) pf = *reinterpret_cast<const float4*>(f0 + j);
-        else { pf.x = f0[j]; if (j + 1 < F) pf.y = f0[j + 1]; if (j + 2 < F) pf.z = f0[j + 2]; if (j + 3 < F) pf.w = f0[j + 3]; }
-      }
-    }
-    float4 xv[NE];
-    int rowv[NE];
-#pragma unroll
-    for (int n = 0; n < NE; ++n) {
-      const int g = tid + 256 * n;                                       // group = (row, 4 harmonics)
-      const int row = (int)(((float)g + 0.5f) * p.inv_K4);
-      rowv[n] = row;
-      const int src = (row < nfr) ? g : halo_grp + (g - row * K4);       // row nfr = halo
-      xv[n] = (g < n_grp && row <= nfr) ? hd_u[src] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (tid < kUnitRows) t.f0[tid] = my_f0;
-    {
-      const int j = 4 * tid;
-      double part64 = (j < j0 ? (double)pf.x : 0.0) + (j + 1 < j0 ? (double)pf.y : 0.0) +
-                      (j + 2 < j0 ? (double)pf.z : 0.0) + (j + 3 < j0 ? (double)pf.w : 0.0);
-      for (int jj = 1024 + tid; jj < j0; jj += 256) part64 += (double)f0[jj];     // F > 1024: rare
-      part64 = wave_sum_dpp(part64);
-      if (lane == 0) t.red[wave] = part64;
-    }
-    __syncthreads();                                   // t.f0 visible
-    DDSP_STAMP();                                      // 1
-    // ---------------- phase A.2: scale, frame-rate Nyquist mask, stash in LDS ---------------------
-#pragma unroll
-    for (int n = 0; n < NE; ++n) {
-      const int g = tid + 256 * n;
-      const int row = rowv[n];
-      const int k = (g - row * K4) * 4;
-      float x[4] = {xv[n].x, xv[n].y, xv[n].z, xv[n].w};
-      const float f0r = t.f0[min(row, kUnitRows - 1)];
+    // ---------------- phase A, rows: LPR lanes per row, RPW rows per wavefront per pass -----------
+    // rows 0..nfr-1 are the unit's frames, row nfr is the halo (the next frame, clamped at F-1)
+    // that the last frame interpolates towards.  K = 100: 8 rows in pass 0, the halo in pass 1.
+    for (int r0 = wave * RPW; r0 <= nfr; r0 += 4 * RPW) {                  // wave-uniform trip count
+      const int r = r0 + sub;
+      const int rowi = b * F + min(j0 + min(r, nfr), F - 1);             // rows past the halo alias it (never stored)
+      const float4 xv = live ? hd4[(size_t)rowi * K4 + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float f0r = f0_all[rowi];
+      const float ampr = amplitudes[rowi];
+      float x[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (scale) x[u] = exp_sigmoid_fast(x[u], kLog10, 2.0f, 1e-7f);
         // core.remove_above_nyquist on f0 * [1..K]  (core.py:899-903, 1028-1045)
-        if (normalize && (f0r * (float)(k + u + 1) >= p.nyquist)) x[u] = 0.0f;
+        if (normalize && (f0r * (float)(4 * kq + u + 1) >= p.nyquist)) x[u] = 0.0f;
       }
-      xv[n] = make_float4(x[0], x[1], x[2], x[3]);
-      if (g < n_grp) *reinterpret_cast<float4*>(&s_x[4 * g]) = xv[n];
-    }
-    __syncthreads();
-    DDSP_STAMP();                                      // 2
-    // ---------------- phase A.3: row sums (a 16-lane DPP row per matrix row) and amplitudes ---------
-    // core.safe_divide(hd, reduce_sum(hd))  (core.py:905-907, 207-210)
-    for (int q = tid >> 4; q <= nfr; q += 16) {         // 16 groups of 16 lanes: rows 0..15, then 16
       float inv = 1.0f;
-      if (!p.inputs_are_controls) {
-        float part = 0.0f;
-        for (int k4 = tid & 15; k4 < K4; k4 += 16) {
-          const float4 v4 = *reinterpret_cast<const float4*>(&s_x[q * K + 4 * k4]);
-          part += (v4.x + v4.y) + (v4.z + v4.w);
-        }
-        // all 64 lanes of a wave take the same number of trips (q differs by < 4 inside a wave and
-        // the loop bound is hit by whole waves: q = 16 only exists for tid < 16), so EXEC is full
-        // for the DPP steps of every wave that gets here
-        part += dpp_mov0<0xB1, 0xF>(part);     // quad_perm [1,0,3,2]
-        part += dpp_mov0<0x4E, 0xF>(part);     // quad_perm [2,3,0,1]
-        part += dpp_mov0<0x141, 0xF>(part);    // row_half_mirror
-        part += dpp_mov0<0x140, 0xF>(part);    // row_mirror: every lane holds its row's sum
+      if (!is_ctl) {                                  // core.safe_divide(hd, reduce_sum(hd))  (core.py:905-907, 207-210)
+        const float part = group_sum<LPR>(live ? (x[0] + x[1]) + (x[2] + x[3]) : 0.0f);
         inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
       }
-      if ((tid & 15) == 0) t.inv_amp[q].x = inv;
-    }
-    if (tid < kUnitRows) {
-      float a = my_amp;
-      if (scale) a = exp_sigmoid_fast(a, kLog10, 2.0f, 1e-7f);
-      t.inv_amp[tid].y = a;
-      if (tid < nfr && ctl_amp) ctl_amp[row0 + tid] = a;
-    }
-    __syncthreads();
-    DDSP_STAMP();                                      // 3
-    // ---------------- phase A.4: normalised distribution -> controls out, amplitude rows -> slot --
-#pragma unroll
-    for (int n = 0; n < NE; ++n) {
-      const int g = tid + 256 * n;
-      const int row = rowv[n];
-      if (g < n_grp && row <= nfr) {
-        const float2 ia = t.inv_amp[row];
-        const float4 h = make_float4(xv[n].x * ia.x, xv[n].y * ia.x, xv[n].z * ia.x, xv[n].w * ia.x);
-        if (ctl_hd_u && row < nfr) ctl_hd_u[g] = h;              // the halo row belongs to the next unit
-        // core.py:1097 amplitudes * distribution
-        *reinterpret_cast<float4*>(&wsu[row * Kp + (g - row * K4) * 4]) =
-            make_float4(ia.y * h.x, ia.y * h.y, ia.y * h.z, ia.y * h.w);
+      const float a = scale ? exp_sigmoid_fast(ampr, kLog10, 2.0f, 1e-7f) : ampr;
+      const float4 h = make_float4(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv);
+      if (!STD) {                                     // the controls dict (the halo row belongs to the next unit)
+        if (ctl_hd && live && r < nfr) ctl_hd4[(size_t)rowi * K4 + kq] = h;
+        if (ctl_amp && kq == 0 && r < nfr) ctl_amp[rowi] = a;
       }
+      // core.py:1097 amplitudes * distribution -> the block's slot
+      if (live && r <= nfr)
+        *reinterpret_cast<float4*>(&wsu[r * Kp + 4 * kq]) = make_float4(a * h.x, a * h.y, a * h.z, a * h.w);
     }
-    DDSP_STAMP();                                      // 4
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have reached L2
-    // ---------------- phase A.5: everything that is per frame, one lane per frame (wave 0) ---------
-    if (wave == 0) {
-      const float fj = t.f0[min(lane, nfr)], fj1 = t.f0[min(lane + 1, nfr)];
+    DDSP_STAMP();                                      // 1: rows issued
+    // ---------------- phase A, phase wave: fp64 prefix and everything that is per frame ------------
+    // Frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop (legacy bilinear resize of f0), whose sum over
+    // the frame is hop*f_j + (f_{j+1}-f_j)(hop-1)/2; summed over j < J this telescopes to
+    // hop*sum_{j<J} f_j + (f_J - f_0)(hop-1)/2: only sum f_j is needed.
+    if (wave == 3) {
+      const float* __restrict__ f0 = f0_all + (size_t)b * F;
+      double part = 0.0;
+      if (p.f0_vec) {                                  // j0 % 4 == 0: whole float4s lie before j0
+        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f0);
+        const int n4 = j0 >> 2;
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (lane + 64 * i < n4) ? f4[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part += ((double)v[i].x + (double)v[i].y) + ((double)v[i].z + (double)v[i].w);
+        for (int m = lane + 256; m < n4; m += 64) {     // F > 1024: rare
+          const float4 q4 = f4[m];
+          part += ((double)q4.x + (double)q4.y) + ((double)q4.z + (double)q4.w);
+        }
+      } else {
+        for (int j = lane; j < j0; j += 64) part += (double)f0[j];
+      }
+      const double before = wave_sum_dpp(part);          // sum_{j < j0} f_j
+      const float fj = f0[min(j0 + min(lane, nfr), F - 1)], fj1 = f0[min(j0 + min(lane + 1, nfr), F - 1)];
       const double fa = (double)fj, fb = (double)fj1;
       const double mine = (lane < nfr) ? fa : 0.0;
       double incl = mine;                                 // inclusive scan of f_j over the unit's frames
@@ -592,7 +556,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
       incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
       incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
-      const double s_excl = ((t.red[0] + t.red[1]) + (t.red[2] + t.red[3])) + (incl - mine);   // sum_{j < j0+lane} f_j
+      const double s_excl = before + (incl - mine);       // sum_{j < j0+lane} f_j
       const double run = p.hop_d * s_excl + (fa - (double)f0[0]) * p.half_hm1;
       const double cyc = run * p.inv_sr;
       // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample.
@@ -602,6 +566,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
       if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
       kA = max(min(kA, kN), 0);
+      if (lane <= kFramesPerBlock) t.f0[lane] = fj;
       if (lane < nfr) {
         t.theta[lane] = cyc - floor(cyc);                  // revolutions at the start of the frame
         t.w[lane] = fa * p.inv_sr;                         // revolutions per sample at r = 0
@@ -610,16 +575,17 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
         t.kN[lane] = kN;
       }
     }
+    DDSP_STAMP();                                      // 2: tables issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have reached L2
     __syncthreads();
-    if (!(p.flags & 0x08000000u)) __builtin_amdgcn_s_dcache_inv();   // drop stale scalar-cache lines of the slot
-    DDSP_STAMP();                                      // 5
+    if (STD || !(p.flags & 0x08000000u)) __builtin_amdgcn_s_dcache_inv();   // drop stale scalar-cache lines of the slot
+    DDSP_STAMP();                                      // 3: slot + tables visible
 
-    DDSP_STAMP();                                      // 6: per-frame tables done
     // ---------------- phase B: tiles of 64 samples ---------------------------------------------
     const int hop = p.hop;
     const float inv_hop = 1.0f / (float)hop;
     const int tiles_per_frame = hop >> 6;
-    const int n_tiles = (p.flags & 0x20000000u) ? 0 : nfr * tiles_per_frame;   // experiment: phase A only
+    const int n_tiles = (!STD && (p.flags & 0x20000000u)) ? 0 : nfr * tiles_per_frame;   // experiment: phase A only
     for (int tile = wave; tile < n_tiles; tile += 4) {
       // ONE_TILE (hop == 64): r == lane for every tile, so everything that depends only on r (its
       // fp64 image, the interpolation weights) is loop invariant and hoisted by the compiler
@@ -688,7 +654,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       const float w_cur = 1.0f - w_next;
       audio[(size_t)(row0 + q) * hop + r] = w_cur * acc0 + w_next * acc1;      // N == F * hop
     }
-    DDSP_STAMP();                                      // 7: tiles done
+    DDSP_STAMP();                                      // 4: tiles done
     if (p.n_units <= (int)gridDim.x) return;           // one unit per block: nothing to pull or reset
     if (tid == 0) t.next_unit = xcls + 8 * (first_pull + (int)atomicAdd(counter, 1u));
     __syncthreads();              // also: the slot and the LDS tables are rewritten by the next unit
@@ -737,7 +703,7 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   p.flags = flags;
   p.inputs_are_controls = inputs_are_controls;
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
-  p.inv_K4 = 1.0f / (float)(K / 4);
+  p.f0_vec = ((F & 3) == 0 && ((uintptr_t)f0 & 15) == 0) ? 1 : 0;
   p.inv_upr = 1.0f / (float)p.units_per_row;
   p.inv_sr = 1.0 / (double)sample_rate;
   p.inv_2hop = 0.5 / (double)p.hop;
@@ -745,27 +711,31 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   p.half_hm1 = ((double)p.hop - 1.0) * 0.5;
   p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
   p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
-  const dim3 grid((unsigned)(p.n_units < kFusedMaxBlocks ? p.n_units : kFusedMaxBlocks)), block(256);
-  const int ne = (kUnitRows * (K / 4) + 255) / 256;
-  const size_t lds = (size_t)kUnitRows * K * sizeof(float);
+  static const int max_blocks = [] {
+    const char* e = getenv("DDSP_EXP_HARM_BLOCKS");
+    const int v = e ? atoi(e) : kFusedMaxBlocks;
+    return v > 0 && v <= kFusedMaxBlocks ? v : kFusedMaxBlocks;
+  }();
+  const dim3 grid((unsigned)(p.n_units < max_blocks ? p.n_units : max_blocks)), block(256);
   static std::atomic<unsigned> ticket{0};
   p.sched_set = (int)(ticket.fetch_add(1u) % (unsigned)kSchedSets);
+  // STD: the flag combination of Harmonic.__call__ with default arguments, compiled in
+  const bool std_flags = (flags & DDSP_HARM_SCALE_EXP_SIGMOID) && (flags & DDSP_HARM_NORMALIZE_NYQUIST) &&
+                         !inputs_are_controls && !ctl_amp && !ctl_hd && (flags >> 24) == 0;
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmFused, &ev0, &ev1);
-#define DDSP_LAUNCH_FUSED(NE)                                                                \
+#define DDSP_LAUNCH_FUSED(LPR, ONE, STD)                                                     \
+  hipExtLaunchKernelGGL((harm_fused_kernel<LPR, ONE, STD>), grid, block, 0, st, ev0, ev1, 0, amps, hd, \
+                        f0, ctl_amp, ctl_hd, (float*)workspace, audio, p)
+#define DDSP_LAUNCH_FUSED_LPR(LPR)                                                           \
   do {                                                                                       \
-    if (p.hop == 64)                                                                         \
-      hipExtLaunchKernelGGL((harm_fused_kernel<NE, true>), grid, block, lds, st, ev0, ev1, 0, amps, hd, \
-                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
-    else                                                                                     \
-      hipExtLaunchKernelGGL((harm_fused_kernel<NE, false>), grid, block, lds, st, ev0, ev1, 0, amps, hd, \
-                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
+    if (p.hop == 64) { if (std_flags) DDSP_LAUNCH_FUSED(LPR, true, true); else DDSP_LAUNCH_FUSED(LPR, true, false); } \
+    else { if (std_flags) DDSP_LAUNCH_FUSED(LPR, false, true); else DDSP_LAUNCH_FUSED(LPR, false, false); }           \
   } while (0)
-  if (ne <= 1) DDSP_LAUNCH_FUSED(1);
-  else if (ne <= 2) DDSP_LAUNCH_FUSED(2);
-  else if (ne <= 3) DDSP_LAUNCH_FUSED(3);
-  else if (ne <= 5) DDSP_LAUNCH_FUSED(5);
+  if (K <= 128) DDSP_LAUNCH_FUSED_LPR(32);
+  else if (K <= 256) DDSP_LAUNCH_FUSED_LPR(64);
   else return DDSP_ERR_UNSUPPORTED;
+#undef DDSP_LAUNCH_FUSED_LPR
 #undef DDSP_LAUNCH_FUSED
   return check_launch();
 }

@@ -10,6 +10,8 @@ std::mutex g_mu;
 bool g_on = false;
 unsigned g_mask = 0;
 size_t g_cap = 0;
+unsigned g_stride = 1;                 // bracket every g_stride-th launch of a selected kernel
+unsigned g_seen[kNumKernels] = {};
 std::vector<Rec> g_recs;
 const char* const kNames[kNumKernels] = {
     "harm_controls_kernel", "harm_synth_kernel", "noise_controls_kernel", "noise_ir_kernel",
@@ -23,11 +25,13 @@ void profile_record(int kernel_id, hipStream_t st, bool start) {
   if (!g_on || !((g_mask >> kernel_id) & 1u)) return;
   if (start) {
     if (g_recs.size() >= g_cap) return;
+    if (g_seen[kernel_id]++ % g_stride != 0) return;
     Rec r; r.id = kernel_id;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, st);
     g_recs.push_back(r);
   } else {
+    if ((g_seen[kernel_id] - 1) % g_stride != 0) return;          // its start was not recorded
     for (size_t i = g_recs.size(); i-- > 0;) {
       if (g_recs[i].id == kernel_id) { (void)hipEventRecord(g_recs[i].e1, st); break; }
     }
@@ -38,6 +42,7 @@ void profile_kernel_events(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_on || !((g_mask >> kernel_id) & 1u) || g_recs.size() >= g_cap) return;
+  if (g_seen[kernel_id]++ % g_stride != 0) return;
   Rec r; r.id = kernel_id;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
   g_recs.push_back(r);
@@ -53,8 +58,15 @@ extern "C" const char* ddsp_profile_kernel_name(int id) {
 }
 
 extern "C" int ddsp_profile_begin(unsigned kernel_mask, int max_records) {
+  return ddsp_profile_begin_sampled(kernel_mask, max_records, 1);
+}
+
+extern "C" int ddsp_profile_begin_sampled(unsigned kernel_mask, int max_records, int stride) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_on) return DDSP_ERR_UNSUPPORTED;
+  if (stride < 1) return DDSP_ERR_BAD_SHAPE;
+  g_stride = (unsigned)stride;
+  for (int i = 0; i < kNumKernels; ++i) g_seen[i] = 0;
   g_recs.clear();
   g_cap = max_records > 0 ? (size_t)max_records : 0;
   g_recs.reserve(g_cap);

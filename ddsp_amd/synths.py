@@ -83,7 +83,7 @@ class Harmonic(processors.Processor):
     audio = torch.empty((b, n), dtype=torch.float32, device=dev)
     ctl_amp = torch.empty_like(amplitudes) if return_outputs_dict else None
     ctl_hd = torch.empty_like(harmonic_distribution) if return_outputs_dict else None
-    ws = self._ws.get(lib.ddsp_harmonic_workspace_bytes(b, f, k, n), dev)
+    ws = self._ws.get(core.cached_workspace_bytes('ddsp_harmonic_workspace_bytes', b, f, k, n), dev)
     flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
                                  self.use_angular_cumsum)
     rc = lib.ddsp_harmonic_f32(
@@ -161,8 +161,8 @@ class FilteredNoise(processors.Processor):
         raise ValueError('noise must be [{}, {}], got {}'.format(b, n, tuple(noise.shape)))
     audio = torch.empty((b, n), dtype=torch.float32, device=dev)
     ctl = torch.empty_like(magnitudes) if want_controls else None
-    ws = self._ws.get(lib.ddsp_filtered_noise_workspace_bytes(b, f, m, n, int(self.window_size)),
-                      dev)
+    ws = self._ws.get(core.cached_workspace_bytes('ddsp_filtered_noise_workspace_bytes', b, f, m, n,
+                                                  int(self.window_size)), dev)
     rc = lib.ddsp_filtered_noise_f32(
         magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
         audio.data_ptr(), ctl.data_ptr() if want_controls else None, ws.data_ptr(), ws.numel(),

@@ -191,6 +191,11 @@ int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
 int ddsp_profile_kernel_count(void);
 const char* ddsp_profile_kernel_name(int kernel_id);
 int ddsp_profile_begin(unsigned kernel_mask, int max_records);
+/* As ddsp_profile_begin, but only every `stride`-th launch of each selected kernel is bracketed
+ * (the first one always is).  A bracketed launch carries a start marker and a stop event, which
+ * costs ~5 us of queue time each; sampling keeps a timed region honest while still measuring the
+ * kernel inside it.  stride < 1 -> DDSP_ERR_BAD_SHAPE. */
+int ddsp_profile_begin_sampled(unsigned kernel_mask, int max_records, int stride);
 int ddsp_profile_end(double* total_ms, int* counts);
 
 #ifdef __cplusplus

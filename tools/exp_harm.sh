@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd /tmp
-for B in 32 128; do for FL in 0x0; do
+for B in 32 128; do for FL in 0x0 0x20000000 0x28000000; do
   rm -rf /tmp/exp_prof
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/exp_prof -o t -- python $GRAFT_REPO_ROOT/tools/exp_harm.py $B $FL > /dev/null 2>&1
   python - <<PY

@@ -23,17 +23,18 @@ torch.cuda.synchronize()
 call(0x3 | 0x02000000, dbg.data_ptr())
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
-nb = min(2048, B * 63)
+nb = min(2048, B * ((F + 15) // 16))
 d = d[:nb]
 t0 = d[:, 0].min()
 d = np.where(d > 0, (d - t0) * 0.01, np.nan)     # 100 MHz -> us
-names = ['start', 'barrier 1 (loads issued, f0 in LDS)', 'values scaled in LDS', 'row sums', 'stores issued', 'tables + stores acked', 'tables (dup)', 'tiles done']
+names0 = ['start', 'barrier 1 (loads issued, f0 in LDS)', 'values scaled in LDS', 'row sums', 'stores issued', 'tables + stores acked', 'tables (dup)', 'tiles done']
+names = names0 + ['u2: ' + n for n in names0[1:]] + ['u3: ' + n for n in names0[1:]]
 print('B=%d  blocks=%d  (us since first block start; min / median / max over blocks)' % (B, nb))
 for i in range(16):
   col = d[:, i]
   if np.all(np.isnan(col)): break
   nm = names[i] if i < len(names) else '...'
-  print('  %-34s %7.2f %7.2f %7.2f' % (nm, np.nanmin(col), np.nanmedian(col), np.nanmax(col)))
+  print('  %-34s %7.2f %7.2f %7.2f   pct 10/25/75/90: %s  n=%d' % (nm, np.nanmin(col), np.nanmedian(col), np.nanmax(col), ' '.join('%.1f' % np.nanpercentile(col, q) for q in (10, 25, 75, 90)), np.sum(~np.isnan(col))))
 # ---- where are the stragglers? ----
 arr = d[:, 5]            # phase A done
 blk = np.arange(nb)
