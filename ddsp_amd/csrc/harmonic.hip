@@ -330,25 +330,45 @@ __device__ __forceinline__ void sload_rows(sgpr8& a0, sgpr8& a1, const float* p0
                : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1) : "memory");
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// The synthesis loop keeps PAIRS of adjacent harmonics {h, h+1} in 64-bit VGPR pairs: the two rows'
+// amplitudes of a pair are adjacent SGPRs, so the two accumulates of two harmonics (4 FMAs with an
+// SGPR operand, ~1.9 ns each) become two v_pk_fma_f32 with an SGPR-pair operand (~2.9 ns each):
+// tools/microbench4 measures 1.37 vs 1.66 ns per FMA-equivalent for the loop.  The stride-2
+// recurrence s[h] = 2cos(4 pi theta) s[h-2] - s[h-4] maps onto pairs directly:
+// P_m = c4 * P_{m-1} - P_{m-2}; accA = {row-0 odd h, row-0 even h}, accB likewise for row 1.
+struct PairState { f2 older, newer; };
+
+__device__ __forceinline__ f2 next_pair(PairState& st, float c4) {
+  f2 sn;
+  sn.x = fmaf(c4, st.newer.x, -st.older.x);
+  sn.y = fmaf(c4, st.newer.y, -st.older.y);
+  st.older = st.newer; st.newer = sn;
+  return sn;
+}
+__device__ __forceinline__ f2 seed_pair(PairState& st, float theta, int h /* first harmonic, 1-based */) {
+  f2 sn;
+  sn.x = sin_rev(frac_phase(theta, (float)h));
+  sn.y = sin_rev(frac_phase(theta, (float)(h + 1)));
+  st.older = st.newer; st.newer = sn;
+  return sn;
+}
+
 // 8 harmonics k+1 .. k+8 in two groups of 4; only the first n4 groups are live (wave-uniform).
-// s[u] holds the latest sine of residue class u = (h-1) mod 4; acc = {a0 even, a1 even, a0 odd, a1 odd}.
 template <bool SEEDS>
 __device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k, int n4,
-                                         float theta, float c4, float (&s)[4], float (&acc)[4]) {
+                                         float theta, float c4, PairState& st, f2& accA, f2& accB) {
   sgpr8 a0, a1;
   sload_rows(a0, a1, p0 + k, p1 + k);
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     if (g < n4) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = 4 * g + u;
-        float sn;
-        if (SEEDS && g == 0) sn = sin_rev(frac_phase(theta, (float)(k + idx + 1)));
-        else sn = fmaf(c4, s[(u + 2) & 3], -s[u]);          // s[h-2], s[h-4]
-        s[u] = sn;
-        acc[2 * (u & 1)] = fmaf(a0[idx], sn, acc[2 * (u & 1)]);
-        acc[2 * (u & 1) + 1] = fmaf(a1[idx], sn, acc[2 * (u & 1) + 1]);
+      for (int i = 4 * g; i < 4 * g + 4; i += 2) {
+        const f2 sn = (SEEDS && g == 0) ? seed_pair(st, theta, k + i + 1) : next_pair(st, c4);
+        accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
+        accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
       }
     }
   }
@@ -368,19 +388,15 @@ typedef float sgpr16 __attribute__((ext_vector_type(16)));
 // slots of the wave and of the CU's scalar unit)
 template <bool SEEDS, int OFF>
 __device__ __forceinline__ void harm_hex_full(const float* p0, const float* p1, int k, float theta,
-                                              float c4, float (&s)[4], float (&acc)[4]) {
+                                              float c4, PairState& st, f2& accA, f2& accB) {
   sgpr16 a0, a1;
   asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
 #pragma unroll
-  for (int idx = 0; idx < 16; ++idx) {
-    const int u = idx & 3;
-    float sn;
-    if (SEEDS && idx < 4) sn = sin_rev(frac_phase(theta, (float)(k + idx + 1)));
-    else sn = fmaf(c4, s[(u + 2) & 3], -s[u]);          // s[h-2], s[h-4]
-    s[u] = sn;
-    acc[2 * (u & 1)] = fmaf(a0[idx], sn, acc[2 * (u & 1)]);
-    acc[2 * (u & 1) + 1] = fmaf(a1[idx], sn, acc[2 * (u & 1) + 1]);
+  for (int i = 0; i < 16; i += 2) {
+    const f2 sn = (SEEDS && i < 4) ? seed_pair(st, theta, k + i + 1) : next_pair(st, c4);
+    accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
+    accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
   }
 }
 
@@ -389,16 +405,15 @@ typedef float sgpr4 __attribute__((ext_vector_type(4)));
 // 4 more harmonics k+1 .. k+4 continuing the recurrence of the preceding super-block (no new seeds)
 template <int OFF>
 __device__ __forceinline__ void harm_quad_cont(const float* p0, const float* p1, float c4,
-                                               float (&s)[4], float (&acc)[4]) {
+                                               PairState& st, f2& accA, f2& accB) {
   sgpr4 a0, a1;
   asm volatile("s_load_dwordx4 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const float sn = fmaf(c4, s[(u + 2) & 3], -s[u]);
-    s[u] = sn;
-    acc[2 * (u & 1)] = fmaf(a0[u], sn, acc[2 * (u & 1)]);
-    acc[2 * (u & 1) + 1] = fmaf(a1[u], sn, acc[2 * (u & 1) + 1]);
+  for (int i = 0; i < 4; i += 2) {
+    const f2 sn = next_pair(st, c4);
+    accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
+    accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
   }
 }
 
@@ -601,8 +616,8 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       const float* a0p = wsu + q * Kp;
       const float* a1p = a0p + Kp;
       const float c4 = 2.0f * __builtin_amdgcn_cosf(theta + theta);   // 2 cos(4 pi theta)
-      float sn[4] = {0.f, 0.f, 0.f, 0.f};
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      PairState st = {{0.f, 0.f}, {0.f, 0.f}};
+      f2 accA = {0.f, 0.f}, accB = {0.f, 0.f};
       // every harmonic live (the common case): the whole row (zero padded to a multiple of 4);
       // otherwise only the groups of 4 that lie entirely below kA
       const int kend = (kA == K) ? ((K + 3) & ~3) : (kA & ~3);
@@ -611,28 +626,28 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
         const float* q0 = a0p;
         const float* q1 = a1p;
         for (; k + 64 <= kend; k += 64, q0 += 64, q1 += 64) {      // full super-blocks of 64: 4 seeds
-          harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
-          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
-          harm_hex_full<false, 128>(q0, q1, k + 32, theta, c4, sn, acc);
-          harm_hex_full<false, 192>(q0, q1, k + 48, theta, c4, sn, acc);
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, st, accA, accB);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, st, accA, accB);
+          harm_hex_full<false, 128>(q0, q1, k + 32, theta, c4, st, accA, accB);
+          harm_hex_full<false, 192>(q0, q1, k + 48, theta, c4, st, accA, accB);
         }
         for (; k + 32 <= kend; k += 32, q0 += 32, q1 += 32) {      // full super-blocks of 32
-          harm_hex_full<true, 0>(q0, q1, k, theta, c4, sn, acc);
-          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, sn, acc);
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, st, accA, accB);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, st, accA, accB);
         }
         // up to three trailing groups of 4 simply continue the last super-block's recurrence
         // (K = 100: 64 + 32 + 4); only possible when at least one super-block came before
         if (k > 0 && kend - k <= 12)
-          for (; k < kend; k += 4, q0 += 4, q1 += 4) harm_quad_cont<0>(q0, q1, c4, sn, acc);
+          for (; k < kend; k += 4, q0 += 4, q1 += 4) harm_quad_cont<0>(q0, q1, c4, st, accA, accB);
       }
       for (; k < kend; k += 32) {           // the tail: octets with group guards, seeds in the first
         const int rem4 = (kend - k) >> 2;
-        harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, sn, acc);
-        if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, sn, acc);
-        if (rem4 > 4) harm_oct<false>(a0p, a1p, k + 16, min(rem4 - 4, 2), theta, c4, sn, acc);
-        if (rem4 > 6) harm_oct<false>(a0p, a1p, k + 24, min(rem4 - 6, 2), theta, c4, sn, acc);
+        harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, st, accA, accB);
+        if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, st, accA, accB);
+        if (rem4 > 4) harm_oct<false>(a0p, a1p, k + 16, min(rem4 - 4, 2), theta, c4, st, accA, accB);
+        if (rem4 > 6) harm_oct<false>(a0p, a1p, k + 24, min(rem4 - 6, 2), theta, c4, st, accA, accB);
       }
-      float acc0 = acc[0] + acc[2], acc1 = acc[1] + acc[3];
+      float acc0 = accA.x + accA.y, acc1 = accB.x + accB.y;
       k = min(kend, K);
       const float lerp = (float)r * inv_hop;
       if (k < kN) {                // remaining live harmonics, and those crossing Nyquist

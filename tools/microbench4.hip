@@ -60,6 +60,64 @@ __global__ __launch_bounds__(256, 8) void loop_kernel(const float* __restrict__ 
       }
       s0 = s[0]; s1 = s[1]; s2 = s[2]; s3 = s[3];
     }
+  } else if (MODE == 4) {
+    // rows interleaved {a0[k], a1[k]}: one v_pk_fma_f32 per harmonic does both accumulates
+    typedef float sgpr16 __attribute__((ext_vector_type(16)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 ev = {0.f, 0.f}, ov = {0.f, 0.f};
+    float s[4] = {s0, s1, s2, s3};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        sgpr16 a;
+        const float* p0 = amp;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(p0) : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int u = i & 3;
+          const float sn = fmaf(c4, s[(u + 2) & 3], -s[u]);
+          s[u] = sn;
+          const f2 a2 = {a[2 * i], a[2 * i + 1]};
+          const f2 s2 = {sn, sn};
+          if (u & 1) ov = __builtin_elementwise_fma(a2, s2, ov);
+          else ev = __builtin_elementwise_fma(a2, s2, ev);
+        }
+      }
+    }
+    e0 = ev.x; e1 = ev.y; o0 = ov.x; o1 = ov.y;
+    s0 = s[0]; s1 = s[1]; s2 = s[2]; s3 = s[3];
+  } else if (MODE == 3) {
+    // double-buffered s_load_dwordx8: wait for the current buffer (issued one block ago), issue the
+    // next, compute - the load latency sits under 24 VALU instructions of this wave
+    typedef float sgpr8 __attribute__((ext_vector_type(8)));
+    const float* p0 = amp; const float* p1 = amp + 16;
+    sgpr8 a0, a1, b0, b1;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0" : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1) : "memory");
+    float s[4] = {s0, s1, s2, s3};
+    for (int it = 0; it < iters; ++it) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %4, 0x20\n\ts_load_dwordx8 %1, %5, 0x20"
+                   : "=&s"(b0), "=&s"(b1), "+s"(a0), "+s"(a1) : "s"(p0), "s"(p1) : "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = i & 3;
+        const float sn = fmaf(c4, s[(u + 2) & 3], -s[u]);
+        s[u] = sn;
+        if (u & 1) { o0 = fmaf(a0[i], sn, o0); o1 = fmaf(a1[i], sn, o1); }
+        else { e0 = fmaf(a0[i], sn, e0); e1 = fmaf(a1[i], sn, e1); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0"
+                   : "=&s"(a0), "=&s"(a1), "+s"(b0), "+s"(b1) : "s"(p0), "s"(p1) : "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int u = i & 3;
+        const float sn = fmaf(c4, s[(u + 2) & 3], -s[u]);
+        s[u] = sn;
+        if (u & 1) { o0 = fmaf(b0[i], sn, o0); o1 = fmaf(b1[i], sn, o1); }
+        else { e0 = fmaf(b0[i], sn, e0); e1 = fmaf(b1[i], sn, e1); }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+    s0 = s[0] + a0[0]; s1 = s[1]; s2 = s[2]; s3 = s[3];
   } else {
     float a0 = amp[lane & 15], a1 = amp[16 + (lane & 15)];
     for (int it = 0; it < iters; ++it) {
@@ -106,7 +164,7 @@ template <int MODE> void run(const char* name, const float* amp, float* out) {
   hipLaunchKernelGGL((loop_kernel<MODE>), dim3(blocks), dim3(256), 0, 0, amp, out, iters);
   (void)hipEventRecord(b); (void)hipEventSynchronize(b);
   float ms; (void)hipEventElapsedTime(&ms, a, b);
-  // per SIMD: 8 waves x iters x 48 VALU
+  // per SIMD: 8 waves x iters x 48 VALU (a v_pk_fma counted as the two FMAs it replaces)
   printf("%-28s %.3f ms   %.3f ns per VALU instruction per SIMD\n", name, ms, ms * 1e6 / (8.0 * iters * 48));
 }
 
@@ -125,5 +183,7 @@ int main() {
   run<0>("SGPR operands (s_load x16)", amp, out);
   run<1>("DPP row_newbcast", amp, out);
   run<2>("plain VGPR operands", amp, out);
+  run<3>("SGPR, double-buffered x8", amp, out);
+  run<4>("SGPR pairs, v_pk_fma_f32", amp, out);
   return 0;
 }
