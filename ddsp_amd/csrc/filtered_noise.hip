@@ -9,6 +9,7 @@
 // test_fft_convolve_equals_direct_time_varying_fir), which is what is evaluated here:
 // no FFT, no [B,F,fft_size] complex intermediates in HBM.
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
@@ -484,8 +485,8 @@ struct FusedNoiseArgs {
   uint64_t batch_offset;
 };
 
-template <bool GEN_NOISE>
-__global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
+template <bool GEN_NOISE, int NW>   // NW wavefronts per block: 4, or 8 (the FIR's tap range split in two halves)
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/,
     FusedNoiseArgs p) {
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     const long lo = (long)b * p.F * 65, hi = ((long)b + 1) * p.F * 65;   // this batch row's elements
     const long a0 = e0 & ~3L;                                       // aligned-down start (may be < 0)
     const long total = ((long)p.F * 65) * (long)gridDim.y;          // elements in the whole tensor
-    for (int i4 = tid; i4 < (64 * 65 + 3) / 4 + 1; i4 += 256) {
+    for (int i4 = tid; i4 < (64 * 65 + 3) / 4 + 1; i4 += 64 * NW) {
       const long ea = a0 + 4L * i4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ea >= 0 && ea + 3 < total) v = *reinterpret_cast<const float4*>(mag + ea);
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
     for (int i = 0; i < 32; ++i) mo[i] = s_u[lane * 65 + 2 * i + 1];
     float* __restrict__ hrow = s_h + lane * kTapStride;
     if (wave == 0) hrow[0] = 0.0f;                     // h[0] = Hann(128)[0] * hz[-64] = 0
-    for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += 4) {
+    for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += NW) {
       const float* __restrict__ ce = kIr65.c + n * kIrRowStride;
       const float* __restrict__ co = ce + 40;
       float e = 0.0f, o = 0.0f;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   __syncthreads();                                      // magnitudes consumed: s_u is free
   DDSP_STAMP();    // 2: IR designed
   // ---- 3. noise tile x[z0-128 .. z0+3967] into s_u (four 16-byte-chunk planes) ----------------------
-  for (int qd = tid; qd < kFnXLen / 4; qd += 256) {
+  for (int qd = tid; qd < kFnXLen / 4; qd += 64 * NW) {
     const int i = z0 - 128 + 4 * qd;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
@@ -608,24 +609,43 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   }
   __syncthreads();
   DDSP_STAMP();    // 3: noise tile staged
-  // ---- 4. FIR: 16 outputs per lane ---------------------------------------------------------------------
-  const int mrel = tid * kFirR;                          // m0 - z0; lanes 248..255 idle (>= 3968)
+  // ---- 4. FIR: 16 outputs per lane; with 8 wavefronts, threads 256..511 take taps 64..127 of the
+  //         same outputs (half the dependent chain per lane, twice the wavefronts to hide latency) ----
+  const int half = (NW == 8) ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
+  const int mrel = (tid & 255) * kFirR;                  // m0 - z0; lanes 248..255 idle (>= 3968)
   float acc[kFirR];
 #pragma unroll
   for (int r = 0; r < kFirR; ++r) acc[r] = 0.0f;
   if (mrel < kFnTile) {
+    const int kb0 = (NW == 8) ? 4 * half : 0;
     float xa[16], xb[16];
-    fn_load16(s_u, mrel + 128, xa);
+    fn_load16(s_u, mrel + 128 - 16 * kb0, xa);
 #pragma unroll 1
-    for (int kb = 0; kb < 8; kb += 2) {
+    for (int kb = kb0; kb < kb0 + (NW == 8 ? 4 : 8); kb += 2) {
       fn_tap_block(s_u, s_h, mrel - 16 * kb, 16 * kb, acc, xa, xb, rel0, p.inv_fs);
       fn_tap_block(s_u, s_h, mrel - 16 * (kb + 1), 16 * (kb + 1), acc, xb, xa, rel0, p.inv_fs);
     }
   }
   __syncthreads();                                      // everyone is done reading x
   DDSP_STAMP();    // 4: FIR done
-  // ---- 5. transpose through LDS, coalesced stores: out[n] = z[n + start] ---------------------------
-  if (mrel < kFnTile) {
+  // ---- 5. (sum the two tap halves,) transpose through LDS, coalesced stores: out[n] = z[n + start] ----
+  if (NW == 8) {
+    if (half == 1 && mrel < kFnTile) {
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+        *reinterpret_cast<float4*>(&s_u[mrel + 4 * c4]) =
+            make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
+    }
+    __syncthreads();
+    if (half == 0 && mrel < kFnTile) {
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const float4 u = *reinterpret_cast<const float4*>(&s_u[mrel + 4 * c4]);
+        acc[4 * c4] += u.x; acc[4 * c4 + 1] += u.y; acc[4 * c4 + 2] += u.z; acc[4 * c4 + 3] += u.w;
+      }
+    }
+  }
+  if (half == 0 && mrel < kFnTile) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4)
       *reinterpret_cast<float4*>(&s_u[mrel + 4 * c4]) =
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
   const int head = (int)((4 - (nbase & 3)) & 3);        // tile elements before the first 16-byte boundary
   if ((p.N & 3) == 0) {
     if (tid < head) { const long n = nbase + tid; if (n >= 0 && n < p.N) o[n] = s_u[tid]; }
-    for (int e = head + 4 * tid; e < kFnTile; e += 1024) {
+    for (int e = head + 4 * tid; e < kFnTile; e += 4 * 64 * NW) {
       const long n = nbase + e;
       if (n >= 0 && n + 3 < p.N && e + 3 < kFnTile) {
         *reinterpret_cast<float4*>(o + n) = make_float4(s_u[e], s_u[e + 1], s_u[e + 2], s_u[e + 3]);
@@ -648,7 +668,7 @@ __global__ __launch_bounds__(256, 3) void noise_fused65_kernel(
       }
     }
   } else {
-    for (int e = tid; e < kFnTile; e += 256) {
+    for (int e = tid; e < kFnTile; e += 64 * NW) {
       const long n = nbase + e;
       if (n >= 0 && n < p.N) o[n] = s_u[e];
     }
@@ -824,10 +844,22 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
       hipEvent_t ev0, ev1;
       profile_kernel_events(kNoiseFused, &ev0, &ev1);
-      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false>), grid, dim3(256), 0, st, ev0, ev1, 0,
-                                       magnitudes, noise, ctl_magnitudes, audio, q);
-      else hipExtLaunchKernelGGL((noise_fused65_kernel<true>), grid, dim3(256), 0, st, ev0, ev1, 0,
-                                 magnitudes, noise, ctl_magnitudes, audio, q);
+      // 8-wavefront blocks (FIR tap range split in two) hide more latency once there is more than one
+      // round of blocks (3 resident per CU); a single partial round next to the harmonic kernel on the
+      // other stream does better with 4-wavefront blocks (measured: profiles/README.md)
+      static const int nw_env = [] { const char* e = getenv("DDSP_EXP_NOISE_WAVES"); return e ? atoi(e) : 0; }();
+      const int nw = nw_env ? nw_env : ((size_t)grid.x * grid.y > 768 ? 8 : 4);
+      if (nw == 8) {
+        if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8>), grid, dim3(512), 0, st, ev0, ev1, 0,
+                                         magnitudes, noise, ctl_magnitudes, audio, q);
+        else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 8>), grid, dim3(512), 0, st, ev0, ev1, 0,
+                                   magnitudes, noise, ctl_magnitudes, audio, q);
+      } else {
+        if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 4>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                         magnitudes, noise, ctl_magnitudes, audio, q);
+        else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 4>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                   magnitudes, noise, ctl_magnitudes, audio, q);
+      }
       return check_launch();
     }
   }
