@@ -12,9 +12,9 @@ timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 | tee $OUT/pytes
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
 echo "== bench (batch 32)"
-timeout 600 python bench.py --steps 50 --warmup 5 --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b32.json
+timeout 600 python bench.py --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b32.json
 echo "== bench (batch 128)"
-timeout 600 python bench.py --steps 30 --warmup 5 --batch 128 --no-cpu-baseline --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b128.json
+timeout 600 python bench.py --batch 128 --no-cpu-baseline --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b128.json
 echo "== rocprofv3 kernel trace"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 ls -R $OUT/prof | head -20
