@@ -50,6 +50,9 @@ def parse_args():
   ap.add_argument('--event-stride', type=int, default=8,
                   help='bracket every n-th launch of the dominant kernel with HIP events inside the '
                        'timed region (a bracketed launch costs ~5 us of queue time; 1 = all of them)')
+  ap.add_argument('--streams', choices=['auto', '1', '2'], default='auto',
+                  help='issue the two Processor calls on one stream or on two free-running streams; auto = two '
+                       'when the per-GPU batch is below 64 (the kernels leave CUs idle for each other), one above')
   ap.add_argument('--no-overlap', action='store_true',
                   help='issue the two Processor calls back to back on one stream instead of on two '
                        'free-running HIP streams')
@@ -141,7 +144,7 @@ def main():
   # the barrier + synchronize that closes the timed region.  --no-overlap: one stream, back to back.
   stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
   stream_0 = torch.cuda.current_stream()
-  overlap = not a.no_overlap
+  overlap = (a.streams == '2' or (a.streams == 'auto' and a.batch < 64)) and not a.no_overlap
 
   def step(two_streams=None):
     two_streams = overlap if two_streams is None else two_streams
