@@ -31,6 +31,9 @@ SIGNATURES = {
     'ddsp_filtered_noise_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
                                 [c_float, c_uint, c_u64, c_u64, c_voidp]),
     'ddsp_fft_convolve_same_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
+    'ddsp_fft_convolve_long_workspace_bytes': (c_size_t, [c_int] * 5),
+    'ddsp_fft_convolve_long_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                   [c_uint, c_voidp]),
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
     'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),
@@ -50,6 +53,8 @@ HARM_NORMALIZE_NYQUIST = 0x2
 HARM_AMP_LINEAR = 0x4
 HARM_ANGULAR_CUMSUM = 0x8
 NOISE_SCALE_EXP_SIGMOID = 0x1
+CONV_ADD_DRY = 0x1
+CONV_MASK_TAP0 = 0x2
 
 ERRORS = {-1: 'DDSP_ERR_NULL_POINTER', -2: 'DDSP_ERR_BAD_SHAPE', -3: 'DDSP_ERR_UNSUPPORTED',
           -4: 'DDSP_ERR_WORKSPACE', -5: 'DDSP_ERR_LAUNCH'}

@@ -402,11 +402,49 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
   if padding != 'same':
     raise ValueError('Padding must be \'valid\' or \'same\', instead '
                      'of {}.'.format(padding))
+  if n_ir_frames == 1 and ir_size > LONG_IR_TAPS:
+    # one long IR (a reverb): partitioned FFT convolution instead of the direct FIR
+    start = (ir_size - 1) // 2 - 1 if delay_compensation < 0 else int(delay_compensation)
+    return fft_convolve_long(audio, impulse_response[:, 0, :], delay=start)
   out = torch.empty_like(audio)
   rc = _lib.load().ddsp_fft_convolve_same_f32(
       audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
       n_ir_frames, ir_size, audio_size, int(delay_compensation), _stream())
   _lib.check(rc, 'ddsp_fft_convolve_same_f32')
+  return out
+
+
+LONG_IR_TAPS = 1024       # single-frame IRs longer than this take the FFT path
+
+
+def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0=False,
+                      workspace=None):
+  """out[b, n] = sum_k ir[b, k] audio[b, n + delay - k] (+ audio[b, n]) for one IR per row.
+
+  The single-frame case of core.fft_convolve (ddsp/core.py:1428-1430, padding='same',
+  crop start = delay) as effects.Reverb uses it (ddsp/effects.py:113-117), evaluated by
+  ddsp_fft_convolve_long_f32.  impulse_response [batch or 1, ir_size].
+  """
+  audio, impulse_response = tf_float32(audio), tf_float32(impulse_response)
+  if audio.dim() != 2 or impulse_response.dim() != 2:
+    raise ValueError('audio must be [batch, n_samples] and impulse_response [batch, ir_size], got '
+                     '{} and {}'.format(tuple(audio.shape), tuple(impulse_response.shape)))
+  b, n = audio.shape
+  b_ir, l = impulse_response.shape
+  if b_ir != b and b_ir != 1:
+    raise ValueError('Batch size of audio ({}) and impulse response ({}) must '
+                     'be the same.'.format(b, b_ir))
+  if delay < 0:
+    raise ValueError('delay must be >= 0, got {}'.format(delay))
+  lib = _lib.load()
+  nbytes = cached_workspace_bytes('ddsp_fft_convolve_long_workspace_bytes', b, b_ir, n, l, int(delay))
+  ws = (workspace if workspace is not None else Workspace()).get(nbytes, audio.device)
+  out = torch.empty_like(audio)
+  flags = (_lib.CONV_ADD_DRY if add_dry else 0) | (_lib.CONV_MASK_TAP0 if mask_tap0 else 0)
+  rc = lib.ddsp_fft_convolve_long_f32(audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), b, b_ir, n, l, int(delay), flags,
+                                      _stream())
+  _lib.check(rc, 'ddsp_fft_convolve_long_f32')
   return out
 
 

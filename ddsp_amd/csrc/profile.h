@@ -17,6 +17,9 @@ enum KernelId {
   kExpSigmoid,
   kHarmFused,
   kNoiseFused,
+  kReverbFft,
+  kReverbMac,
+  kReverbIfft,
   kNumKernels
 };
 

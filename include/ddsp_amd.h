@@ -152,6 +152,25 @@ int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response
                                int B, int Bir, int F, int L, int N, int delay_compensation,
                                void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Long single-frame convolution: effects.Reverb.get_signal (ddsp/effects.py:100-117) and
+ * core.fft_convolve (ddsp/core.py:1382-1473) with a 2-D impulse response (one frame,
+ * core.py:1428-1430), padding='same':
+ *     out[b][n] = sum_k ir[b][k] * audio[b][n + delay - k]   (+ audio[b][n] with ADD_DRY),
+ * i.e. crop_and_compensate_delay (core.py:1338-1379) with start = delay >= 0
+ * (Reverb passes delay_compensation=0).  ir [Bir,L], Bir == B or 1 (tiled over the batch,
+ * effects.py:62-69 / core.py:1433-1434).  DDSP_CONV_MASK_TAP0 zeroes tap 0 as
+ * Reverb._mask_dry_ir does (effects.py:50-60).  Evaluated as a partitioned overlap-save FFT
+ * convolution with LDS-resident 8192-point FFTs; L <= 65536 else DDSP_ERR_UNSUPPORTED.
+ * workspace: ddsp_fft_convolve_long_workspace_bytes(...) bytes, 16-byte aligned.
+ */
+#define DDSP_CONV_ADD_DRY 1u
+#define DDSP_CONV_MASK_TAP0 2u
+size_t ddsp_fft_convolve_long_workspace_bytes(int B, int Bir, int N, int L, int delay);
+int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response, float* out,
+                               void* workspace, size_t workspace_bytes, int B, int Bir, int N,
+                               int L, int delay, unsigned flags, void* stream);
+
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);

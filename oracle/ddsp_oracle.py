@@ -482,6 +482,40 @@ def filtered_noise(magnitudes, noise, window_size=257, scale_fn=exp_sigmoid,
   return filtered_noise_get_signal(c['magnitudes'], noise, window_size, dtype)
 
 
+def reverb_mask_dry_ir(ir, dtype=np.float32):
+  """effects.Reverb._mask_dry_ir (effects.py:50-60): 2-D IR with tap 0 zeroed."""
+  ir = as_float(ir, dtype)
+  if ir.ndim == 1:
+    ir = ir[None, :]
+  if ir.ndim == 3:
+    ir = ir[:, :, 0]
+  return np.concatenate([np.zeros((ir.shape[0], 1), dtype), ir[:, 1:]], axis=1)
+
+
+def reverb(audio, ir, add_dry=True, dtype=np.float32):
+  """effects.Reverb.get_signal (effects.py:100-117), ir given or a trainable Reverb's single IR.
+
+  wet = fft_convolve(audio, mask_dry(ir), padding='same', delay_compensation=0): one frame,
+  i.e. the first n_samples of the causal linear convolution; a 1-D / batch-1 IR is tiled over
+  the batch (effects.py:62-69, core.py:1433-1434).
+  """
+  audio = as_float(audio, dtype)
+  ir = reverb_mask_dry_ir(ir, dtype)
+  wet = fft_convolve(audio, ir, padding='same', delay_compensation=0, dtype=dtype)
+  return (wet + audio) if add_dry else wet
+
+
+def reverb_direct(audio, ir, add_dry=True):
+  """fp64 direct-form truth for reverb(): y[n] = sum_{k>=1} ir[k] x[n-k] (+ x[n])."""
+  audio = as_float(audio, np.float64)
+  ir = reverb_mask_dry_ir(ir, np.float64)
+  if ir.shape[0] == 1 and audio.shape[0] > 1:
+    ir = np.tile(ir, [audio.shape[0], 1])
+  n = audio.shape[1]
+  wet = np.stack([np.convolve(audio[b], ir[b])[:n] for b in range(audio.shape[0])])
+  return (wet + audio) if add_dry else wet
+
+
 def add(signal_one, signal_two):
   """processors.Add.get_signal (processors.py:174-176)."""
   return signal_one + signal_two

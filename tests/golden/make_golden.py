@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 import tf_numpy_shim  # noqa: E402
 
 tf_numpy_shim.install('/root/reference')
-from ddsp import core, processors, synths  # noqa: E402  (the reference's files)
+from ddsp import core, effects, processors, synths  # noqa: E402  (the reference's files)
 
 
 def a(x):
@@ -69,6 +69,23 @@ def noise_case(seed, batch, n_frames, n_bands, n_samples, window_size, scale=Tru
               impulse_response=a(ir), signal=a(signal))
 
 
+def reverb_case(seed, batch, n_samples, ir_size, ir_batch, add_dry, trainable=False, ir_rank=2):
+  rng = np.random.default_rng(seed)
+  audio = rng.standard_normal((batch, n_samples)).astype(np.float32)
+  decay = np.exp(-np.arange(ir_size) / (0.25 * ir_size))
+  ir = (rng.standard_normal((ir_batch, ir_size)) * decay).astype(np.float32)
+  rev = effects.Reverb(trainable=trainable, reverb_length=ir_size, add_dry=add_dry)
+  if trainable:                     # the variable tf would create in build() (effects.py:71-80)
+    rev._ir = ir[0]
+    rev.built = True
+    signal = rev(audio)
+    ir_in = ir[0]
+  else:
+    ir_in = ir[:, :, None] if ir_rank == 3 else ir
+    signal = rev(audio, ir_in)
+  return dict(audio=audio, ir=ir_in, add_dry=int(add_dry), trainable=int(trainable), signal=a(signal))
+
+
 def main():
   cases = {}
   # --- Harmonic: hop 64 (the canonical hop), some harmonics crossing Nyquist ---
@@ -94,6 +111,11 @@ def main():
   cases['noise_m33_w17'] = noise_case(13, 2, 10, 33, 640, 17)         # cropped IR branch
   cases['noise_m17_w16_even'] = noise_case(14, 1, 8, 17, 512, 16)     # even window -> 15 taps
   cases['noise_ragged'] = noise_case(15, 2, 7, 9, 100, 0, scale=False)  # N % F != 0 (pad_end)
+
+  # --- effects.Reverb: ir from the network [B, L(,1)], and a trainable Reverb's single IR ---
+  cases['reverb_b2_dry'] = reverb_case(31, 2, 1000, 300, 2, True)
+  cases['reverb_b2_wet_rank3'] = reverb_case(32, 2, 777, 1200, 2, False, ir_rank=3)   # IR longer than the audio
+  cases['reverb_trainable'] = reverb_case(33, 3, 640, 200, 1, True, trainable=True)
 
   # --- resampling pieces on their own ---
   rng = np.random.default_rng(21)

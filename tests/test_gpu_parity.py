@@ -484,3 +484,111 @@ def test_filtered_noise_fused_other_frame_sizes(ddsp, fs, n_frames, ragged):
   assert np.abs(npy(out['signal']) - ref).max() <= noise_tol(ref)
   np.testing.assert_allclose(npy(out['controls']['magnitudes']),
                              O.filtered_noise_get_controls(mags)['magnitudes'], rtol=2e-5, atol=1e-9)
+
+
+# ---- effects.Reverb / long single-frame fft_convolve -------------
+# REVERB  |ours - fp64 direct convolution| <= 1e-5 * max|ref| + 1e-6  (fp32 FFTs of 8192 points)
+REVERB_CASES = ['reverb_b2_dry', 'reverb_b2_wet_rank3', 'reverb_trainable']
+
+
+def reverb_tol(ref):
+  return 1e-6 + 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('name', REVERB_CASES)
+def test_reverb_golden(ddsp, name):
+  g = load_golden(name)
+  rev = ddsp.effects.Reverb(trainable=bool(g['trainable']), reverb_length=g['ir'].shape[-1] if g['ir'].ndim == 1 else 48000,
+                            add_dry=bool(g['add_dry']))
+  if int(g['trainable']):
+    rev._ir = ddsp.core.tf_float32(g['ir'])      # the variable's value the fixture was made with
+    rev.built = True
+    out = rev(g['audio'])
+  else:
+    out = rev(g['audio'], g['ir'])
+  assert tuple(out.shape) == g['signal'].shape
+  np.testing.assert_allclose(npy(out), g['signal'], rtol=0, atol=reverb_tol(g['signal']))
+
+
+@pytest.mark.parametrize('batch,n,l,ir_batch,add_dry', [
+    (2, 64000, 48000, 2, True),        # solo_instrument.gin: 4 s @ 16 kHz, 3 s reverb
+    (3, 64000, 48000, 1, False),       # a trainable Reverb's single IR
+    (1, 4096, 4096, 1, True),          # exactly one block / one partition
+    (2, 4097, 4097, 2, False),         # one sample past the block / partition edge
+    (2, 1000, 65536, 2, True),         # the longest supported IR, much longer than the audio
+    (1, 20001, 5, 1, False)])          # a tiny IR, ragged length (scalar load path)
+def test_reverb_vs_fp64_convolution(ddsp, batch, n, l, ir_batch, add_dry):
+  import scipy.signal
+  rng = np.random.default_rng(n + l)
+  audio = rng.standard_normal((batch, n)).astype(np.float32)
+  ir = (rng.standard_normal((ir_batch, l)) * np.exp(-np.arange(l) / (0.2 * l))).astype(np.float32)
+  out = npy(ddsp.effects.Reverb(add_dry=add_dry)(audio, ir))
+  h = ir.astype(np.float64).copy()
+  h[:, 0] = 0.0                                                     # _mask_dry_ir
+  ref = np.stack([scipy.signal.fftconvolve(audio[b].astype(np.float64), h[b % ir_batch])[:n]
+                  for b in range(batch)])
+  if add_dry:
+    ref = ref + audio
+  np.testing.assert_allclose(out, ref, rtol=0, atol=reverb_tol(ref))
+  # and the fp32 restatement of the reference's own algorithm (one big FFT)
+  np.testing.assert_allclose(out, O.reverb(audio, ir, add_dry=add_dry), rtol=0,
+                             atol=4 * reverb_tol(ref))
+
+
+def test_reverb_properties_full_size_batch32(ddsp):
+  rng = np.random.default_rng(77)
+  b, n, l = 32, 64000, 48000
+  x1 = ddsp.core.tf_float32(rng.standard_normal((b, n)))
+  x2 = ddsp.core.tf_float32(rng.standard_normal((b, n)))
+  ir = ddsp.core.tf_float32(rng.standard_normal((b, l)) * np.exp(-np.arange(l) / 9000.0))
+  wet = ddsp.effects.Reverb(add_dry=False)
+  # linearity
+  lhs = wet(0.5 * x1 - 2.0 * x2, ir)
+  rhs = 0.5 * wet(x1, ir) - 2.0 * wet(x2, ir)
+  scale = float(rhs.abs().max())
+  assert float((lhs - rhs).abs().max()) <= 2e-5 * scale
+  # a unit tap at k delays by k samples; tap 0 is masked; add_dry adds the input back
+  delta = torch.zeros((1, l), device='cuda')
+  delta[0, 0], delta[0, 4097] = 5.0, 1.0
+  y = wet(x1, delta)
+  assert float(y[:, :4097].abs().max()) <= 1e-5
+  assert float((y[:, 4097:] - x1[:, :n - 4097]).abs().max()) <= 2e-5 * float(x1.abs().max())
+  y_dry = ddsp.effects.Reverb(add_dry=True)(x1, delta)
+  assert float((y_dry - y - x1).abs().max()) <= 1e-6
+  # one IR tiled over the batch == the same IR given per row
+  one = wet(x1, ir[:1])
+  rows = wet(x1, ir[:1].repeat(b, 1))
+  assert float((one - rows).abs().max()) == 0.0
+
+
+def test_fft_convolve_single_long_frame_routes_to_fft_path(ddsp):    # core.py:1428-1430, 1338-1379
+  rng = np.random.default_rng(5)
+  audio = rng.standard_normal((2, 3000)).astype(np.float32)
+  ir = (rng.standard_normal((2, 2000)) * np.exp(-np.arange(2000) / 300.0)).astype(np.float32)
+  for delay in (-1, 0, 17):
+    out = npy(ddsp.core.fft_convolve(audio, ir, padding='same', delay_compensation=delay))
+    ref = O.fft_convolve(audio, ir, padding='same', delay_compensation=delay, dtype=np.float64)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=reverb_tol(ref))
+
+
+def test_reverb_in_processor_group(ddsp):                            # gin/models/solo_instrument.gin:26-40
+  rng = np.random.default_rng(9)
+  b, f, k, m, n, l = 2, 250, 60, 65, 16000, 12000
+  feats = {'amps': rng.standard_normal((b, f, 1)).astype(np.float32),
+           'harmonic_distribution': rng.standard_normal((b, f, k)).astype(np.float32),
+           'f0_hz': (200 + rng.standard_normal((b, f, 1))).astype(np.float32),
+           'magnitudes': rng.standard_normal((b, f, m)).astype(np.float32)}
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=3)
+  add = ddsp.processors.Add()
+  rev = ddsp.effects.Reverb(trainable=True, reverb_length=l)
+  rev.build(device=torch.device('cuda'))
+  rev._ir = ddsp.core.tf_float32(rng.standard_normal(l) * np.exp(-np.arange(l) / 2000.0) * 0.05)
+  dag = [(harm, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
+         (add, ['filtered_noise/signal', 'harmonic/signal']), (rev, ['add/signal'])]
+  group = ddsp.processors.ProcessorGroup(dag=dag)
+  outs = group.get_controls(feats)
+  dry = npy(outs['add']['signal'])
+  got = npy(group.get_signal(outs))
+  ref = O.reverb(dry, npy(rev._ir), add_dry=True, dtype=np.float64)
+  np.testing.assert_allclose(got, ref, rtol=0, atol=reverb_tol(ref))

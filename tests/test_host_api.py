@@ -156,3 +156,21 @@ def test_processor_group_dag_construction_and_routing():          # processors_t
     core.nested_lookup('harmonic/nope', res)
   with pytest.raises(ValueError, match='same length'):
     core.to_dict([1, 2], ['only_one'])
+
+
+def test_reverb_host_contract():                                   # effects.py:31-48, 82-98
+  import inspect
+  import ddsp_amd as ddsp
+  sig = inspect.signature(ddsp.effects.Reverb.__init__)
+  assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
+      ('trainable', False), ('reverb_length', 48000), ('add_dry', True), ('name', 'reverb')]
+  rev = ddsp.effects.Reverb()
+  assert rev.name == 'reverb' and rev.trainable is False
+  with pytest.raises(ValueError, match='Must provide "ir" tensor if Reverb trainable=False.'):
+    rev.get_controls(audio=None)
+  lib = _lib.load()
+  # 16 x-blocks + 12 IR partitions of 8192 complex bins each, per clip
+  assert lib.ddsp_fft_convolve_long_workspace_bytes(32, 32, 64000, 48000, 0) == 32 * (16 + 12) * 8192 * 8
+  assert lib.ddsp_fft_convolve_long_workspace_bytes(32, 1, 64000, 48000, 0) == (32 * 16 + 12) * 8192 * 8
+  # programmer errors come back as codes, before any launch
+  assert lib.ddsp_fft_convolve_long_f32(None, None, None, None, 0, 1, 1, 10, 10, 0, 0, None) == -1
