@@ -5,15 +5,21 @@
 // 131 072 points.  Here the same linear convolution is evaluated as a uniformly partitioned
 // overlap-save convolution whose FFTs (8192 points, 64 KB of float2) live entirely in LDS:
 //
-//   x blocks   X_j = FFT(x[(j-1)P .. (j+1)P)),  P = 4096, j = 0 .. nb-1      (rv_fft_kernel)
+//   x blocks   X_j = FFT(x[(j-1)P .. (j+1)P)),  P = 4096, j = 0 .. nb-1
 //   IR parts   H_p = FFT([h[pP .. (p+1)P), 0 ... 0]),   p = 0 .. np-1        (rv_fft_kernel)
-//   per bin    Y_j = sum_{p <= j} X_{j-p} H_p   - a sliding window over j in registers, every
-//              spectrum is read once and Y_j overwrites X_j in place         (rv_mac_kernel)
-//   y[jP + i] = IFFT(Y_j)[P + i],  out[n] = y[n + delay] (+ audio[n])        (rv_ifft_kernel)
+//   per bin    Y_j = sum_{p <= j} X_{j-p} H_p
+//   y[jP + i] = IFFT(Y_j)[P + i],  out[n] = y[n + delay] (+ audio[n])
 //
-// The forward transform is a radix-2 decimation-in-frequency FFT (natural order in, bit-reversed
-// out), the inverse a decimation-in-time FFT (bit-reversed in, natural out): the per-bin products do
-// not care about the order, so no bit-reversal pass exists anywhere.  Twiddles come from
+// x and h are real, so two x blocks ride in one complex FFT: Z_m = FFT(x_{m-1} + i x_m) = X_{m-1} + i X_m
+// (rv_fft_kernel).  The sum is linear in Z, so W_m = sum_p Z_{m-p} H_p = Y_{m-1} + i Y_m needs no
+// untangling: it is formed for odd m only - a sliding window over m in registers, every spectrum
+// read once, W_m overwriting Z_m in place (rv_mac_kernel) - and one inverse FFT returns output block
+// m-1 in its real part and block m in its imaginary part (rv_ifft_kernel): half the inverse FFTs and
+// half the multiply-adds of the plain scheme.
+//
+// The forward transform is an in-place radix-4 decimation-in-frequency FFT that leaves its bins in
+// digit-reversed order; the inverse undoes it stage by stage: the per-bin products do not care
+// about the order, so no reordering pass exists anywhere.  Twiddles come from
 // v_sin_f32 / v_cos_f32 on exact binary fractions of a revolution (abs. error 1.2e-7,
 // profiles/r01_microbench_alu.txt).
 #include <hip/hip_runtime.h>
@@ -28,47 +34,119 @@ namespace ddsp {
 constexpr int kRvP = 4096;             // output samples per block = taps per IR partition
 constexpr int kRvN = 2 * kRvP;         // FFT size
 constexpr int kRvMaxParts = 16;        // IR partitions held in registers by the MAC kernel
-constexpr int kRvThreads = 256;
+constexpr int kRvThreads = 1024;      // FFT blocks: 16 wavefronts on one 64 KB LDS array (2 radix-4 butterflies per lane per
+                                       // stage): with 4 wavefronts a stage took 1.3 us - one wavefront per SIMD cannot overlap
+                                       // its own LDS and VALU phases (tools/microbench5)
+constexpr int kRvMacThreads = 256;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 
-// natural order in, bit-reversed order out; kernel exp(-2 pi i nk/N)
-__device__ __forceinline__ void fft_dif_forward(float2* s, int tid) {
+// 8192 = 2 * 4^6: six radix-4 stages and one radix-2 stage, in place, 256 threads, one barrier per
+// stage.  Forward (decimation in frequency, kernel exp(-2 pi i nk/N)) leaves the bins in a
+// digit-reversed order; the inverse is the exact algebraic inverse of the forward pipeline - the
+// stages undone one by one in reverse order (conjugate twiddles, conjugate 4-point DFT, factor 1/N
+// left to the caller) - so it accepts that order and returns natural order, whatever the order is.
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {          // a * conj(b)
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+
+// All loads of a stage are issued before any arithmetic and all stores after it (the butterflies of
+// a stage touch disjoint elements, which the compiler cannot see through the LDS indices): 32 LDS
+// reads in flight per lane instead of 4 - a block of 4 wavefronts has nothing else to hide latency.
+constexpr int kRvBf = kRvN / 4 / kRvThreads;                   // radix-4 butterflies per thread per stage (8)
+
+__device__ __forceinline__ void fft_forward(float2* s, int tid) {
 #pragma unroll 1
-  for (int half = kRvN / 2; half >= 1; half >>= 1) {
-    const float inv_len = 0.5f / (float)half;                 // exact: powers of two
-#pragma unroll 4
-    for (int t = tid; t < kRvN / 2; t += kRvThreads) {
-      const int pos = t & (half - 1);
-      const int i0 = ((t - pos) << 1) + pos, i1 = i0 + half;
-      const float2 a = s[i0], b = s[i1];
-      const float rev = (float)pos * inv_len;                 // revolutions, exact
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      const float2 d = make_float2(a.x - b.x, a.y - b.y);
-      s[i0] = make_float2(a.x + b.x, a.y + b.y);
-      s[i1] = make_float2(fmaf(d.x, c, d.y * sn), fmaf(d.y, c, -d.x * sn));   // d * (c - i sn)
+  for (int q = kRvN / 4; q >= 2; q >>= 2) {                    // q = 2048, 512, 128, 32, 8, 2
+    const float inv_len = 0.25f / (float)q;                    // exact: powers of two
+    float2 v[kRvBf][4];
+    int idx[kRvBf];
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+      const int t = tid + kRvThreads * u, pos = t & (q - 1);
+      idx[u] = ((t - pos) << 2) + pos;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[u][m] = s[idx[u] + m * q];
+    }
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+      const int pos = (tid + kRvThreads * u) & (q - 1);
+      const float rev = (float)pos * inv_len;                  // revolutions, exact
+      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));   // conj of the twiddle
+      const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+      const float2 t0 = cadd(v[u][0], v[u][2]), t1 = csub(v[u][0], v[u][2]), t2 = cadd(v[u][1], v[u][3]),
+                   bd = csub(v[u][1], v[u][3]);
+      const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
+      v[u][0] = cadd(t0, t2);
+      v[u][1] = cmulc(cadd(t1, t3), w1);
+      v[u][2] = cmulc(csub(t0, t2), w2);
+      v[u][3] = cmulc(csub(t1, t3), w3);
+    }
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) s[idx[u] + m * q] = v[u][m];
     }
     __syncthreads();
   }
+  {                                                            // radix-2, neighbours, twiddle 1
+    float4 v[2 * kRvBf];
+#pragma unroll
+    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = reinterpret_cast<const float4*>(s)[tid + kRvThreads * u];
+#pragma unroll
+    for (int u = 0; u < 2 * kRvBf; ++u)
+      reinterpret_cast<float4*>(s)[tid + kRvThreads * u] =
+          make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
+  }
+  __syncthreads();
 }
 
-// bit-reversed order in, natural order out; kernel exp(+2 pi i nk/N), unscaled
-__device__ __forceinline__ void fft_dit_inverse(float2* s, int tid) {
+__device__ __forceinline__ void fft_inverse(float2* s, int tid) {
+  {
+    float4 v[2 * kRvBf];
+#pragma unroll
+    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = reinterpret_cast<const float4*>(s)[tid + kRvThreads * u];
+#pragma unroll
+    for (int u = 0; u < 2 * kRvBf; ++u)
+      reinterpret_cast<float4*>(s)[tid + kRvThreads * u] =
+          make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
+  }
+  __syncthreads();
 #pragma unroll 1
-  for (int half = 1; half <= kRvN / 2; half <<= 1) {
-    const float inv_len = 0.5f / (float)half;
-#pragma unroll 4
-    for (int t = tid; t < kRvN / 2; t += kRvThreads) {
-      const int pos = t & (half - 1);
-      const int i0 = ((t - pos) << 1) + pos, i1 = i0 + half;
-      const float2 a = s[i0], b = s[i1];
+  for (int q = 2; q <= kRvN / 4; q <<= 2) {
+    const float inv_len = 0.25f / (float)q;
+    float2 v[kRvBf][4];
+    int idx[kRvBf];
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+      const int t = tid + kRvThreads * u, pos = t & (q - 1);
+      idx[u] = ((t - pos) << 2) + pos;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[u][m] = s[idx[u] + m * q];
+    }
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+      const int pos = (tid + kRvThreads * u) & (q - 1);
       const float rev = (float)pos * inv_len;
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      const float2 w = make_float2(fmaf(b.x, c, -b.y * sn), fmaf(b.x, sn, b.y * c));   // b * (c + i sn)
-      s[i0] = make_float2(a.x + w.x, a.y + w.y);
-      s[i1] = make_float2(a.x - w.x, a.y - w.y);
+      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+      const float2 y0 = v[u][0], y1 = cmul(v[u][1], w1), y2 = cmul(v[u][2], w2), y3 = cmul(v[u][3], w3);
+      // undo y0 = t0+t2, y2 = t0-t2, y1 = t1+t3, y3 = t1-t3 (factor 2 each, part of the 1/N)
+      const float2 t0 = cadd(y0, y2), t2 = csub(y0, y2), t1 = cadd(y1, y3), t3 = csub(y1, y3);
+      const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i) = (b - d) * 2
+      v[u][0] = cadd(t0, t1);                                  // 4a
+      v[u][2] = csub(t0, t1);                                  // 4c
+      v[u][1] = cadd(t2, bd);                                  // 4b
+      v[u][3] = csub(t2, bd);                                  // 4d
+    }
+#pragma unroll
+    for (int u = 0; u < kRvBf; ++u) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) s[idx[u] + m * q] = v[u][m];
     }
     __syncthreads();
   }
@@ -88,14 +166,14 @@ __global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restr
   const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
   const int len = IS_IR ? p.L : p.N;
   const float* __restrict__ row = src + (size_t)b * len;
-  // x block: samples (j-1)P .. (j+1)P-1;  IR partition: taps pP .. (p+1)P-1 then P zeros
-  const int base = IS_IR ? j * kRvP : (j - 1) * kRvP;
+  // IR partition: taps jP .. (j+1)P-1 then P zeros (imaginary part 0);
+  // x spectrum m = j: real part samples (m-2)P .. mP-1 (block m-1), imaginary part (m-1)P .. (m+1)P-1 (block m)
+  const int base = IS_IR ? j * kRvP : (j - 2) * kRvP;
   const int live = IS_IR ? kRvP : kRvN;
   const bool vec = ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-  for (int i4 = tid; i4 < kRvN / 4; i4 += kRvThreads) {
-    const int i = 4 * i4, g = base + i;
+  auto load4 = [&](int g) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < live && g + 3 >= 0 && g < len) {
+    if (g + 3 >= 0 && g < len) {
       if (vec && g >= 0 && g + 3 < len) {
         v = *reinterpret_cast<const float4*>(row + g);
       } else {
@@ -104,23 +182,32 @@ __global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restr
         if (g + 2 >= 0 && g + 2 < len) v.z = row[g + 2];
         if (g + 3 >= 0 && g + 3 < len) v.w = row[g + 3];
       }
-      // effects.Reverb._mask_dry_ir (effects.py:50-60): tap 0 carries the dry signal -> 0
-      if (IS_IR && g == 0 && (p.flags & DDSP_CONV_MASK_TAP0)) v.x = 0.0f;
     }
-    reinterpret_cast<float4*>(s)[2 * i4] = make_float4(v.x, 0.f, v.y, 0.f);
-    reinterpret_cast<float4*>(s)[2 * i4 + 1] = make_float4(v.z, 0.f, v.w, 0.f);
+    return v;
+  };
+  for (int i4 = tid; i4 < kRvN / 4; i4 += kRvThreads) {
+    const int i = 4 * i4, g = base + i;
+    float4 re = make_float4(0.f, 0.f, 0.f, 0.f), im = re;
+    if (i < live) {
+      re = load4(g);
+      // effects.Reverb._mask_dry_ir (effects.py:50-60): tap 0 carries the dry signal -> 0
+      if (IS_IR && g == 0 && (p.flags & DDSP_CONV_MASK_TAP0)) re.x = 0.0f;
+      if (!IS_IR) im = load4(g + kRvP);
+    }
+    reinterpret_cast<float4*>(s)[2 * i4] = make_float4(re.x, im.x, re.y, im.y);
+    reinterpret_cast<float4*>(s)[2 * i4 + 1] = make_float4(re.z, im.z, re.w, im.w);
   }
   __syncthreads();
-  fft_dif_forward(s, tid);
+  fft_forward(s, tid);
   float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)b * gridDim.x + j) * kRvN);
   for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) dst[i2] = reinterpret_cast<const float4*>(s)[i2];
 }
 
 // One thread per pair of bins (16-byte accesses).  The IR spectra of all partitions sit in
-// registers, the x spectra slide through a register window, Y_j replaces X_j in memory.
-__global__ __launch_bounds__(kRvThreads) void rv_mac_kernel(float4* __restrict__ xspec,
+// registers, the Z spectra slide through a register window, W_m replaces Z_m (odd m) in memory.
+__global__ __launch_bounds__(kRvMacThreads) void rv_mac_kernel(float4* __restrict__ xspec,
                                                             const float4* __restrict__ hspec, RvArgs p) {
-  const int idx = blockIdx.x * kRvThreads + threadIdx.x;      // < kRvN / 2
+  const int idx = blockIdx.x * kRvMacThreads + threadIdx.x;      // < kRvN / 2
   const int b = blockIdx.y;
   const float4* __restrict__ hb = hspec + (size_t)(p.ir_batch == 1 ? 0 : b) * p.np * (kRvN / 2) + idx;
   float4* __restrict__ xb = xspec + (size_t)b * p.nb * (kRvN / 2) + idx;
@@ -134,6 +221,7 @@ __global__ __launch_bounds__(kRvThreads) void rv_mac_kernel(float4* __restrict__
 #pragma unroll
     for (int q = kRvMaxParts - 1; q > 0; --q) w[q] = w[q - 1];
     w[0] = xb[(size_t)j * (kRvN / 2)];
+    if ((j & 1) == 0) continue;                                // W_m only for odd m (blocks m-1 and m)
     float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < kRvMaxParts; ++q) {
@@ -152,26 +240,26 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
                                                              float* __restrict__ out, RvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float2 s[];
   const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
-  const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * gridDim.x + j) * kRvN);
+  // spectrum m = 2j+1 holds output blocks 2j (real part) and 2j+1 (imaginary part)
+  const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + 2 * j + 1) * kRvN);
   for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) reinterpret_cast<float4*>(s)[i2] = srcv[i2];
   __syncthreads();
-  fft_dit_inverse(s, tid);
+  fft_inverse(s, tid);
   // overlap-save: the last P samples of the block are y[jP .. (j+1)P); out[n] = y[n + delay]
   const float scale = 1.0f / (float)kRvN;
   const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;
   const float* __restrict__ arow = audio + (size_t)b * p.N;
   float* __restrict__ orow = out + (size_t)b * p.N;
   for (int i = tid; i < kRvP; i += kRvThreads) {
-    const int n = j * kRvP + i - p.delay;
-    if (n >= 0 && n < p.N) {
-      float v = s[kRvP + i].x * scale;
-      if (dry) v += arow[n];
-      orow[n] = v;
-    }
+    const float2 y = s[kRvP + i];
+    const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
+    if (n0 >= 0 && n0 < p.N) orow[n0] = fmaf(y.x, scale, dry ? arow[n0] : 0.0f);
+    if (n1 >= 0 && n1 < p.N) orow[n1] = fmaf(y.y, scale, dry ? arow[n1] : 0.0f);
   }
 }
 
-static inline int rv_blocks(int N, int delay) { return (N + delay + kRvP - 1) / kRvP; }
+// number of Z spectra: two output blocks each, so the block count rounded up to even
+static inline int rv_blocks(int N, int delay) { return (((N + delay + kRvP - 1) / kRvP) + 1) & ~1; }
 static inline int rv_parts(int L) { return (L + kRvP - 1) / kRvP; }
 
 }  // namespace ddsp
@@ -217,12 +305,12 @@ extern "C" int ddsp_fft_convolve_long_f32(const float* audio, const float* impul
   }
   {
     ProfileScope prof(kReverbMac, st);
-    hipLaunchKernelGGL(rv_mac_kernel, dim3(kRvN / 2 / kRvThreads, (unsigned)B), dim3(kRvThreads), 0, st,
+    hipLaunchKernelGGL(rv_mac_kernel, dim3(kRvN / 2 / kRvMacThreads, (unsigned)B), dim3(kRvMacThreads), 0, st,
                        (float4*)xspec, (const float4*)hspec, p);
   }
   {
     ProfileScope prof(kReverbIfft, st);
-    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)p.nb, (unsigned)B), dim3(kRvThreads), lds, st,
+    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)p.nb / 2, (unsigned)B), dim3(kRvThreads), lds, st,
                        (const float2*)xspec, audio, out, p);
   }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
