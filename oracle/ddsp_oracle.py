@@ -2,7 +2,8 @@
 
 This module is a numpy restatement, op for op, of the reference's
 `ddsp/core.py`, `ddsp/synths.py` and `ddsp/processors.py` for the one path this
-repository accelerates (synths.Harmonic + synths.FilteredNoise + processors.Add).
+repository accelerates (synths.Harmonic + synths.FilteredNoise + processors.Add),
+plus `ddsp/effects.py:27-117` (effects.Reverb).
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 import it; the product package `ddsp_amd` never does (it fails loudly when
 the HIP library is missing).
@@ -12,7 +13,7 @@ Pinning status
 * The reference itself cannot run here (TensorFlow / gin are not installed), so
   there is no output of real TensorFlow to compare with.
 * What IS pinned: `tests/golden/*.npz` are produced by executing the reference's
-  own `ddsp/core.py` / `ddsp/synths.py` source files, unmodified, on top of a
+  own `ddsp/core.py` / `ddsp/synths.py` / `ddsp/effects.py` source files, unmodified, on top of a
   numpy stand-in for the dozen TensorFlow ops they call
   (`tests/golden/make_golden.py`, `tests/golden/tf_numpy_shim.py`).  Those vectors
   pin this restatement's index math, crops, windows, masks and op order against
