@@ -7,6 +7,7 @@
 from ddsp_amd import core
 from ddsp_amd import dags
 from ddsp_amd import effects
+from ddsp_amd import losses
 from ddsp_amd import processors
 from ddsp_amd import synths
 

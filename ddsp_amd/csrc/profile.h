@@ -20,6 +20,7 @@ enum KernelId {
   kReverbFft,
   kReverbMac,
   kReverbIfft,
+  kStftL1,
   kNumKernels
 };
 

@@ -1,0 +1,196 @@
+// Forward pass of losses.SpectralLoss (ddsp/losses.py:131-243) for gfx950: for every FFT size S the
+// L1 distance between |STFT(target)| and |STFT(audio)| (and between their safe logs), averaged
+// over [batch, frames, S/2+1] - spectral_ops.compute_mag / stft (ddsp/spectral_ops.py:34-47, 67-70),
+// tf.signal.stft semantics: frames of S samples every S/4, zero pad_end, periodic Hann, rfft(S).
+//
+// One launch per FFT size.  A block holds G = 2048/S frames of the target and the same G frames of
+// the audio in LDS and runs one in-place radix-2 decimation-in-frequency FFT over all of them; bin
+// k sits at its bit-reversed position (one v_bfrev), magnitudes are compared on the fly and never
+// touch HBM.  The two signals are NOT packed into the real and imaginary parts of one transform:
+// rounding would leak ~1e-7 of one signal into the other, and core.safe_log treats exact zeros
+// (silent stretches of generated audio) differently from tiny values.  Per-block partial sums (fp64) go to the workspace; a one-block kernel adds them in a fixed
+// order, so the loss is deterministic.  HBM traffic: each sample is read 4 times per size (75 %
+// overlap), served by L2; nothing else is read or written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+#include "profile.h"
+#include "../../include/ddsp_amd.h"
+
+namespace ddsp {
+
+constexpr int kSlPoints = 4096;        // complex points per block (32 KB of LDS)
+constexpr int kSlThreads = 256;
+
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target,
+                                                             const float* __restrict__ audio,
+                                                             double* __restrict__ partial, int N,
+                                                             int n_frames, float safe_eps) {
+  constexpr int G = kSlPoints / 2 / S;  // frames per block (of each signal)
+  constexpr int LOG2S = __builtin_ctz(S);
+  constexpr int HOP = S / 4;
+  __shared__ __attribute__((aligned(16))) float2 s[kSlPoints];
+  __shared__ double red[2][kSlThreads / 64];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * G;
+  const float* __restrict__ trow = target + (size_t)b * N;
+  const float* __restrict__ arow = audio + (size_t)b * N;
+  // ---- frames -> LDS, windowed: w[i] = 0.5 - 0.5 cos(2 pi i / S) (tf.signal.hann_window, periodic)
+  for (int e = tid; e < kSlPoints; e += kSlThreads) {
+    const int g2 = e >> LOG2S, i = e & (S - 1);               // g2 < G: target frame, else audio frame
+    const int g = g2 >= G ? g2 - G : g2;
+    const int n = (f0 + g) * HOP + i;
+    float v = 0.0f;
+    if (f0 + g < n_frames && n < N) {
+      const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)S));
+      v = (g2 >= G ? arow[n] : trow[n]) * w;
+    }
+    s[e] = make_float2(v, 0.0f);
+  }
+  __syncthreads();
+  // ---- radix-2 DIF FFT of every frame, in place; bins end up bit-reversed ----------------------
+#pragma unroll 1
+  for (int half = S / 2; half >= 1; half >>= 1) {
+    const float inv_len = 0.5f / (float)half;
+    float2 va[kSlPoints / 2 / kSlThreads], vb[kSlPoints / 2 / kSlThreads];
+    int idx[kSlPoints / 2 / kSlThreads];
+#pragma unroll
+    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
+      const int t = tid + kSlThreads * u;                      // butterfly over the whole block
+      const int g = t >> (LOG2S - 1), r = t & (S / 2 - 1);   // g runs over the 2G frames of both signals
+      const int pos = r & (half - 1);
+      idx[u] = (g << LOG2S) + ((r - pos) << 1) + pos;
+      va[u] = s[idx[u]];
+      vb[u] = s[idx[u] + half];
+    }
+#pragma unroll
+    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
+      const int pos = (tid + kSlThreads * u) & (half - 1);
+      const float rev = (float)pos * inv_len;                  // revolutions, exact
+      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+      const float2 d = make_float2(va[u].x - vb[u].x, va[u].y - vb[u].y);
+      va[u] = make_float2(va[u].x + vb[u].x, va[u].y + vb[u].y);
+      vb[u] = make_float2(fmaf(d.x, c, d.y * sn), fmaf(d.y, c, -d.x * sn));      // d * exp(-2 pi i rev)
+    }
+#pragma unroll
+    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
+      s[idx[u]] = va[u];
+      s[idx[u] + half] = vb[u];
+    }
+    __syncthreads();
+  }
+  // ---- magnitudes of bins 0 .. S/2, L1 terms -------------------------------------------------------
+  float dm = 0.0f, dl = 0.0f;
+  for (int e = tid; e < G * (S / 2 + 1); e += kSlThreads) {
+    const int g = e / (S / 2 + 1), k = e - g * (S / 2 + 1);
+    if (f0 + g < n_frames) {
+      const int at = (g << LOG2S) + (int)(__brev((unsigned)k) >> (32 - LOG2S));
+      const float2 zt = s[at], za = s[at + (G << LOG2S)];
+      const float mt = sqrtf(fmaf(zt.x, zt.x, zt.y * zt.y)), ma = sqrtf(fmaf(za.x, za.x, za.y * za.y));
+      dm += fabsf(mt - ma);
+      // core.safe_log (core.py:213-216): non-positive -> eps
+      dl += fabsf(__logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma <= 0.0f ? safe_eps : ma));
+    }
+  }
+  const double sm = (double)wave_sum(dm), sl = (double)wave_sum(dl);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sl; }
+  __syncthreads();
+  if (tid == 0) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
+    double* out = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+    out[0] = a0; out[1] = a1;
+  }
+}
+
+struct SlFinishArgs {
+  int n_sizes;
+  int offset[16];          // first partial pair of each size
+  int count[16];           // partial pairs of each size
+  double inv_elems[16];    // 1 / (B * frames * bins)
+  double mag_weight, logmag_weight;
+};
+
+__global__ __launch_bounds__(256) void spectral_loss_finish_kernel(const double* __restrict__ partial,
+                                                                   float* __restrict__ loss, SlFinishArgs p) {
+  __shared__ double red[2][256];
+  double total = 0.0;
+  for (int z = 0; z < p.n_sizes; ++z) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < p.count[z]; i += 256) {
+      a0 += partial[2 * (size_t)(p.offset[z] + i)];
+      a1 += partial[2 * (size_t)(p.offset[z] + i) + 1];
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) {
+        red[0][threadIdx.x] += red[0][threadIdx.x + st];
+        red[1][threadIdx.x] += red[1][threadIdx.x + st];
+      }
+      __syncthreads();
+    }
+    // losses.mean_difference 'L1' (losses.py:102-128) per size, weighted sum over sizes (:199-236)
+    total += (p.mag_weight * red[0][0] + p.logmag_weight * red[1][0]) * p.inv_elems[z];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = (float)total;
+}
+
+static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }
+static inline int sl_blocks(int N, int S) { const int g = kSlPoints / 2 / S; return (sl_frames(N, S) + g - 1) / g; }
+static inline bool sl_size_ok(int S) { return S >= 16 && S <= kSlPoints / 2 && (S & (S - 1)) == 0; }
+
+}  // namespace ddsp
+
+using namespace ddsp;
+
+extern "C" size_t ddsp_spectral_loss_workspace_bytes(int B, int N, const int* fft_sizes, int n_sizes) {
+  if (B <= 0 || N <= 0 || !fft_sizes || n_sizes <= 0 || n_sizes > 16) return 0;
+  size_t pairs = 0;
+  for (int z = 0; z < n_sizes; ++z) {
+    if (!sl_size_ok(fft_sizes[z])) return 0;
+    pairs += (size_t)B * sl_blocks(N, fft_sizes[z]);
+  }
+  return pairs * 2 * sizeof(double);
+}
+
+extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* audio, float* loss,
+                                      void* workspace, size_t workspace_bytes, int B, int N,
+                                      const int* fft_sizes, int n_sizes, float mag_weight,
+                                      float logmag_weight, void* stream) {
+  if (!target_audio || !audio || !loss || !workspace || !fft_sizes) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
+  if (workspace_bytes < ddsp_spectral_loss_workspace_bytes(B, N, fft_sizes, n_sizes) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)workspace;
+  SlFinishArgs fin;
+  fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
+  int offset = 0;
+  {
+    ProfileScope prof(kStftL1, st);
+    for (int z = 0; z < n_sizes; ++z) {
+      const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+      fin.offset[z] = offset; fin.count[z] = B * blocks;
+      fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+      const dim3 grid((unsigned)blocks, (unsigned)B);
+      double* dst = partial + 2 * (size_t)offset;
+#define DDSP_SL_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
+                                                     target_audio, audio, dst, N, frames, 1e-5f); break
+      switch (S) {
+        DDSP_SL_CASE(16); DDSP_SL_CASE(32); DDSP_SL_CASE(64); DDSP_SL_CASE(128); DDSP_SL_CASE(256);
+        DDSP_SL_CASE(512); DDSP_SL_CASE(1024); DDSP_SL_CASE(2048);
+        default: return DDSP_ERR_UNSUPPORTED;
+      }
+#undef DDSP_SL_CASE
+      offset += B * blocks;
+    }
+  }
+  hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, loss, fin);
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}

@@ -171,6 +171,22 @@ int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response
                                void* workspace, size_t workspace_bytes, int B, int Bir, int N,
                                int L, int delay, unsigned flags, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * losses.SpectralLoss.call, forward pass (ddsp/losses.py:189-243), loss_type 'L1', magnitude and
+ * log-magnitude terms:
+ *     *loss = sum over fft_sizes of  mag_weight * mean|mag_t - mag_a| + logmag_weight * mean|safe_log mag_t - safe_log mag_a|
+ * with mag = |tf.signal.stft(frame_length=S, frame_step=S/4, pad_end=True)| (spectral_ops.py:34-47,
+ * 67-70), safe_log per core.py:213-216.  target_audio, audio [B,N] and loss (one float) are device
+ * pointers; fft_sizes is a HOST array of n_sizes (<= 16) powers of two in [16, 2048].
+ * workspace: ddsp_spectral_loss_workspace_bytes(...) bytes (per-block fp64 partial sums; the
+ * result does not depend on scheduling).
+ */
+size_t ddsp_spectral_loss_workspace_bytes(int B, int N, const int* fft_sizes, int n_sizes);
+int ddsp_spectral_loss_f32(const float* target_audio, const float* audio, float* loss,
+                           void* workspace, size_t workspace_bytes, int B, int N,
+                           const int* fft_sizes, int n_sizes, float mag_weight,
+                           float logmag_weight, void* stream);
+
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);

@@ -3,7 +3,8 @@
 This module is a numpy restatement, op for op, of the reference's
 `ddsp/core.py`, `ddsp/synths.py` and `ddsp/processors.py` for the one path this
 repository accelerates (synths.Harmonic + synths.FilteredNoise + processors.Add),
-plus `ddsp/effects.py:27-117` (effects.Reverb).
+plus `ddsp/effects.py:27-117` (effects.Reverb) and the forward pass of
+`ddsp/losses.py:131-243` (losses.SpectralLoss, rank 2).
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 import it; the product package `ddsp_amd` never does (it fails loudly when
 the HIP library is missing).
@@ -515,6 +516,62 @@ def reverb_direct(audio, ir, add_dry=True):
   n = audio.shape[1]
   wet = np.stack([np.convolve(audio[b], ir[b])[:n] for b in range(audio.shape[0])])
   return (wet + audio) if add_dry else wet
+
+
+# ----------------------------------------------------------------------------
+# losses.SpectralLoss  (ddsp/losses.py:100-243, ddsp/spectral_ops.py:34-70)
+# ----------------------------------------------------------------------------
+def stft(audio, frame_size=2048, overlap=0.75, pad_end=True, dtype=np.float32):
+  """spectral_ops.stft (spectral_ops.py:34-47) = tf.signal.stft: frames of `frame_size` every
+  frame_size*(1-overlap) samples (zero pad_end), periodic Hann, rfft of the enclosing power of 2."""
+  audio = as_float(audio, dtype)
+  if audio.ndim == 3:
+    audio = audio[..., 0]
+  frame_size = int(frame_size)
+  hop = int(frame_size * (1.0 - overlap))
+  fft_length = 1 << int(np.ceil(np.log2(frame_size)))
+  frames = frame_pad_end(audio, frame_size, hop) if pad_end else None
+  if frames is None:
+    n = 1 + (audio.shape[1] - frame_size) // hop
+    frames = np.stack([audio[:, i * hop:i * hop + frame_size] for i in range(n)], axis=1)
+  return np.fft.rfft(frames * hann_window_periodic(frame_size, dtype), fft_length)
+
+
+def compute_mag(audio, size=2048, overlap=0.75, pad_end=True, dtype=np.float32):
+  """spectral_ops.compute_mag (spectral_ops.py:67-70): |stft|."""
+  return np.abs(stft(audio, size, overlap, pad_end, dtype)).astype(dtype)
+
+
+def safe_log(x, eps=1e-5):
+  """core.safe_log (core.py:213-216): log of x with non-positive entries replaced by eps."""
+  return np.log(np.where(x <= 0.0, np.asarray(eps, x.dtype), x))
+
+
+def mean_difference(target, value, loss_type='L1', weights=None):
+  """losses.mean_difference (losses.py:102-128), 'L1' and 'L2'."""
+  difference = target - value
+  weights = 1.0 if weights is None else weights
+  loss_type = loss_type.upper()
+  if loss_type == 'L1':
+    return np.mean(np.abs(difference * weights), dtype=difference.dtype)
+  if loss_type == 'L2':
+    return np.mean(difference**2 * weights, dtype=difference.dtype)
+  raise ValueError('Loss type ({}), must be "L1", "L2", or "COSINE"'.format(loss_type))
+
+
+def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type='L1',
+                  mag_weight=1.0, logmag_weight=0.0, dtype=np.float32):
+  """losses.SpectralLoss.call (losses.py:189-243), magnitude and log-magnitude terms."""
+  loss = dtype(0.0)
+  for size in fft_sizes:
+    target_mag = compute_mag(target_audio, size, dtype=dtype)
+    value_mag = compute_mag(audio, size, dtype=dtype)
+    if mag_weight > 0:
+      loss += dtype(mag_weight) * mean_difference(target_mag, value_mag, loss_type)
+    if logmag_weight > 0:
+      loss += dtype(logmag_weight) * mean_difference(safe_log(target_mag), safe_log(value_mag),
+                                                     loss_type)
+  return loss
 
 
 def add(signal_one, signal_two):

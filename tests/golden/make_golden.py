@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 import tf_numpy_shim  # noqa: E402
 
 tf_numpy_shim.install('/root/reference')
-from ddsp import core, effects, processors, synths  # noqa: E402  (the reference's files)
+from ddsp import core, effects, losses, processors, spectral_ops, synths  # noqa: E402  (the reference's files)
 
 
 def a(x):
@@ -116,6 +116,18 @@ def main():
   cases['reverb_b2_dry'] = reverb_case(31, 2, 1000, 300, 2, True)
   cases['reverb_b2_wet_rank3'] = reverb_case(32, 2, 777, 1200, 2, False, ir_rank=3)   # IR longer than the audio
   cases['reverb_trainable'] = reverb_case(33, 3, 640, 200, 1, True, trainable=True)
+
+  # --- losses.SpectralLoss (mag + logmag terms, L1), and the magnitudes of one scale ---
+  rng = np.random.default_rng(41)
+  tgt = (rng.standard_normal((2, 3000)) * 0.3).astype(np.float32)
+  aud = (tgt + 0.05 * rng.standard_normal((2, 3000))).astype(np.float32)
+  aud[1, 1500:] = 0.0                                   # exact zeros: the safe_log branch
+  cases['spectral_loss'] = dict(
+      target_audio=tgt, audio=aud,
+      loss_default=a(losses.SpectralLoss()(tgt, aud)),
+      loss_ae_gin=a(losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)(tgt, aud)),      # ae.gin:36-41
+      loss_two_scales=a(losses.SpectralLoss(fft_sizes=(512, 64), logmag_weight=0.5)(tgt, aud)),
+      mag_256=a(spectral_ops.compute_mag(aud, size=256)))
 
   # --- resampling pieces on their own ---
   rng = np.random.default_rng(21)

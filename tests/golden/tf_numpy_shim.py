@@ -146,6 +146,16 @@ def irfft(x, fft_length=None):
   return _t(np.fft.irfft(x, n).astype(np.float32))
 
 
+def stft(signals, frame_length, frame_step, fft_length=None, window_fn=None, pad_end=False):
+  """tf.signal.stft: frame (zero pad_end), periodic Hann, rfft of the enclosing power of two."""
+  x = _np(signals)
+  if fft_length is None:
+    fft_length = 1 << int(np.ceil(np.log2(frame_length)))
+  frames = _np(frame(x, frame_length, frame_step, pad_end=pad_end))
+  win = _np(hann_window(frame_length, periodic=True)).astype(frames.dtype)
+  return _t(np.fft.rfft(frames * win, int(fft_length)).astype(np.complex64))
+
+
 def fftshift(x, axes=None):
   return _t(np.fft.fftshift(_np(x), axes=axes))
 
@@ -225,6 +235,7 @@ def build_tf_module():
   tf.cast = cast
   tf.cumsum = cumsum
   tf.reduce_sum = reduce_sum
+  tf.reduce_mean = lambda x, axis=None, keepdims=False: _t(np.mean(_np(x), axis=axis, keepdims=keepdims, dtype=np.float32))
   tf.where = where
   tf.pad = pad
   tf.linspace = linspace
@@ -253,13 +264,13 @@ def build_tf_module():
           np.random.default_rng(1234).uniform(minval, maxval, shape).astype(np.float32)))
 
   tf.math = types.SimpleNamespace(
-      log=_wrap(np.log), exp=_wrap(np.exp), real=_wrap(np.real),
+      log=_wrap(np.log), exp=_wrap(np.exp), real=_wrap(np.real), cumsum=cumsum,
       is_nan=_wrap(np.isnan))
   tf.nn = types.SimpleNamespace(sigmoid=sigmoid)
   tf.signal = types.SimpleNamespace(
       hann_window=hann_window, overlap_and_add=overlap_and_add, frame=frame,
-      rfft=rfft, irfft=irfft, fftshift=fftshift)
-  tf.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=Layer))
+      rfft=rfft, irfft=irfft, fftshift=fftshift, stft=stft)
+  tf.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=Layer), Model=Layer)
 
   v1 = types.SimpleNamespace(
       image=types.SimpleNamespace(resize=image_resize_v1, ResizeMethod=ResizeMethod))
@@ -289,6 +300,13 @@ def install(reference_root='/root/reference'):
   absl.logging = pylogging
   sys.modules['absl'] = absl
   sys.modules['absl.logging'] = pylogging
+
+  # losses.py / spectral_ops.py import these at module level and never touch them on the
+  # SpectralLoss(mag, logmag) path
+  for name in ('crepe', 'librosa', 'tensorflow_probability'):
+    stub = types.ModuleType(name)
+    stub.distributions = types.SimpleNamespace(HiddenMarkovModel=object)
+    sys.modules[name] = stub
 
   pkg = types.ModuleType('ddsp')
   pkg.__path__ = [reference_root + '/ddsp']      # namespace only: __init__.py not run

@@ -592,3 +592,50 @@ def test_reverb_in_processor_group(ddsp):                            # gin/model
   got = npy(group.get_signal(outs))
   ref = O.reverb(dry, npy(rev._ir), add_dry=True, dtype=np.float64)
   np.testing.assert_allclose(got, ref, rtol=0, atol=reverb_tol(ref))
+
+
+# ---- losses.SpectralLoss forward ------------------------------------
+# SPECTRAL  |ours - fp64 oracle| <= 2e-5 * |ref|   (sums of ~1e6 fp32 magnitudes, fp64 accumulation)
+def test_spectral_loss_golden(ddsp):
+  g = load_golden('spectral_loss')
+  t, a = g['target_audio'], g['audio']
+  for kwargs, key in [({}, 'loss_default'), (dict(mag_weight=1.0, logmag_weight=1.0), 'loss_ae_gin'),
+                      (dict(fft_sizes=(512, 64), logmag_weight=0.5), 'loss_two_scales')]:
+    out = ddsp.losses.SpectralLoss(**kwargs)(t, a)
+    assert out.dim() == 0
+    np.testing.assert_allclose(float(out), float(np.ravel(g[key])[0]), rtol=2e-5)
+
+
+@pytest.mark.parametrize('batch,n', [(2, 64000), (3, 12345), (1, 100)])
+def test_spectral_loss_vs_fp64_oracle(ddsp, batch, n):
+  rng = np.random.default_rng(n)
+  t = (0.3 * rng.standard_normal((batch, n))).astype(np.float32)
+  a = (t * rng.uniform(0.5, 1.5) + 0.02 * rng.standard_normal((batch, n))).astype(np.float32)
+  a[0, n // 2:] = 0.0                                            # a silent stretch: exact zeros -> safe_log eps
+  loss = ddsp.losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)
+  ref = float(O.spectral_loss(t, a, logmag_weight=1.0, dtype=np.float64))
+  np.testing.assert_allclose(float(loss(t, a)), ref, rtol=2e-5)
+  np.testing.assert_allclose(float(loss(t[..., None], a[..., None])), ref, rtol=2e-5)   # [B, N, 1] audio
+  assert float(loss(t, t)) == 0.0
+  d = loss.get_losses_dict(t, a)
+  assert list(d) == ['spectral_loss']
+  # run-to-run determinism (fixed-order fp64 reduction)
+  assert float(loss(t, a)) == float(loss(t, a))
+
+
+def test_spectral_loss_on_the_synth_output_batch32(ddsp):          # ae.gin:36-41 on config-3 shapes
+  rng = np.random.default_rng(3)
+  b, f, k, n = 32, 1000, 100, 64000
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  audio = harm(rng.standard_normal((b, f, 1)), rng.standard_normal((b, f, k)), 200 + rng.standard_normal((b, f, 1)))
+  target = harm(rng.standard_normal((b, f, 1)), rng.standard_normal((b, f, k)), 210 + rng.standard_normal((b, f, 1)))
+  loss = ddsp.losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)
+  got = float(loss(target, audio))
+  # the sum over sizes is additive: each scale on its own adds up to the total
+  parts = sum(float(ddsp.losses.SpectralLoss(fft_sizes=(s,), logmag_weight=1.0)(target, audio))
+              for s in (2048, 1024, 512, 256, 128, 64))
+  np.testing.assert_allclose(got, parts, rtol=1e-6)
+  # symmetric in its arguments (L1), and matches the oracle on the first two clips' worth of data
+  np.testing.assert_allclose(float(loss(audio, target)), got, rtol=1e-6)
+  ref2 = float(O.spectral_loss(npy(target[:2]), npy(audio[:2]), logmag_weight=1.0, dtype=np.float64))
+  np.testing.assert_allclose(float(loss(target[:2].contiguous(), audio[:2].contiguous())), ref2, rtol=2e-5)

@@ -209,3 +209,24 @@ def test_reverb_masks_the_dry_tap_and_is_causal():                 # effects.py:
   expect[0, 8] = 0.5
   np.testing.assert_allclose(wet, expect, atol=1e-6)
   np.testing.assert_allclose(O.reverb(x, ir, add_dry=True), expect + x, atol=1e-6)
+
+
+# ---- losses.SpectralLoss forward -------------------------------------
+def test_spectral_loss_matches_reference_source():
+  g = load_golden('spectral_loss')
+  t, a = g['target_audio'], g['audio']
+  np.testing.assert_allclose(O.compute_mag(a, 256), g['mag_256'], rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.spectral_loss(t, a), g['loss_default'], rtol=1e-5)
+  np.testing.assert_allclose(O.spectral_loss(t, a, logmag_weight=1.0), g['loss_ae_gin'], rtol=1e-5)
+  np.testing.assert_allclose(O.spectral_loss(t, a, fft_sizes=(512, 64), logmag_weight=0.5),
+                             g['loss_two_scales'], rtol=1e-5)
+  # fp64 truth is what the GPU path is held to
+  np.testing.assert_allclose(O.spectral_loss(t, a, logmag_weight=1.0, dtype=np.float64),
+                             g['loss_ae_gin'], rtol=2e-5)
+
+
+def test_spectral_loss_is_zero_for_identical_signals_and_counts_padded_frames():
+  x = np.random.default_rng(1).standard_normal((1, 1000)).astype(np.float32)
+  assert O.spectral_loss(x, x, logmag_weight=1.0) == 0.0
+  assert O.compute_mag(x, 64).shape == (1, 63, 33)                 # ceil(1000/16) frames, 33 bins
+  assert O.compute_mag(x, 2048).shape == (1, 2, 1025)              # frames longer than the clip
