@@ -1,4 +1,5 @@
 """Build libddsp_amd.so for gfx950 with hipcc (in-tree, so it ships to the GPU box)."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -10,13 +11,34 @@ SOURCES = ['harmonic.hip', 'filtered_noise.hip', 'reverb.hip', 'spectral_loss.hi
 OUT = os.path.join(HERE, 'lib', 'libddsp_amd.so')
 
 
+STAMP = OUT + '.stamp'
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
+
+
+def _deps():
+  deps = sorted(os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc')))
+  deps.append(os.path.join(ROOT, 'include', 'ddsp_amd.h'))
+  return deps
+
+
+def source_digest():
+  """sha256 over the sources, the header and the compiler flags: a snapshot copied to another
+  box need not preserve mtimes, and a needless rebuild there costs minutes of GPU-box time."""
+  h = hashlib.sha256(' '.join(FLAGS + SOURCES).encode())
+  for d in _deps():
+    with open(d, 'rb') as f:
+      h.update(os.path.basename(d).encode() + b'\0' + f.read())
+  return h.hexdigest()
+
+
 def needs_rebuild():
   if not os.path.exists(OUT):
     return True
+  if os.path.exists(STAMP):
+    with open(STAMP) as f:
+      return f.read().strip() != source_digest()
   t = os.path.getmtime(OUT)
-  deps = [os.path.join(HERE, 'csrc', f) for f in os.listdir(os.path.join(HERE, 'csrc'))]
-  deps.append(os.path.join(ROOT, 'include', 'ddsp_amd.h'))
-  return any(os.path.getmtime(d) > t for d in deps)
+  return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=True):
@@ -24,13 +46,14 @@ def build(force=False, verbose=True):
     return OUT
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
   os.makedirs(os.path.dirname(OUT), exist_ok=True)
-  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize',
-         '-I' + os.path.join(ROOT, 'include')]
+  cmd = [hipcc] + FLAGS + ['-I' + os.path.join(ROOT, 'include')]
   cmd += [os.path.join(HERE, 'csrc', s) for s in SOURCES]
   cmd += ['-o', OUT]
   if verbose:
     print('[ddsp_amd.build]', ' '.join(cmd), flush=True)
   subprocess.run(cmd, check=True)
+  with open(STAMP, 'w') as f:
+    f.write(source_digest() + '\n')
   return OUT
 
 
