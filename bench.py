@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=200)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=1000)
+  ap.add_argument('--warmup', type=int, default=500)   # ~20 ms of load: the GPU needs that long to reach its sustained clock (43 vs 37 us/step)
   ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
   ap.add_argument('--n-frames', type=int, default=1000)
   ap.add_argument('--n-harmonics', type=int, default=100)

@@ -25,7 +25,8 @@
 
 namespace ddsp {
 
-constexpr int kFramesPerBlock = 8;    // frames per synth block / unit of the fused kernel
+constexpr int kFramesPerBlock = 8;    // frames per block of the generic synthesis kernel
+constexpr int kMaxUnitFrames = 16;    // the fused kernel's units are 8 or 16 frames (template parameter FPB)
 constexpr int kSynthThreads = 256;
 constexpr int kRowsPerWave = 4;       // controls kernel: rows per wavefront
 constexpr int kCheb = 16;             // harmonics per Chebyshev block (two exact seeds each)
@@ -430,14 +431,15 @@ struct FusedArgs {
   double inv_sr, inv_2hop, hop_d, half_hm1;   // 1/sample_rate, 1/(2*hop), hop, (hop-1)/2
 };
 
-constexpr int kUnitRows = kFramesPerBlock + 1;
+constexpr int kMaxUnitRows = kMaxUnitFrames + 1;
 
 // LDS tables of one unit (written by the phase wave, read by every wavefront's tiles)
+template <int FPB>
 struct UnitTables {
   int next_unit;
-  double theta[kFramesPerBlock], w[kFramesPerBlock], dw[kFramesPerBlock];
-  float f0[kUnitRows + 1];
-  int kA[kFramesPerBlock], kN[kFramesPerBlock];
+  double theta[FPB], w[FPB], dw[FPB];
+  float f0[FPB + 2];
+  int kA[FPB], kN[FPB];
 };
 
 // Sum over the LPR lanes that share a matrix row; every lane of the group gets the sum.  Full EXEC.
@@ -459,13 +461,17 @@ __device__ __forceinline__ float group_sum(float v) {
 // wavefront per unit - a third of the kernel's instruction count (profiles/r01_pmc_sq_counters_b32).
 // This layout gives LPR lanes to one matrix row, so a row's sum is a DPP reduction in registers:
 // no LDS staging, no barrier inside phase A, and the common flag combination (STD) is compiled in.
-template <int LPR, bool ONE_TILE, bool STD>   // LPR lanes per row (K <= 4*LPR); ONE_TILE: hop == 64;
-                                              // STD: scale + Nyquist-normalise, no controls written
+template <int LPR, bool ONE_TILE, bool STD, int FPB>   // LPR lanes per row (K <= 4*LPR); ONE_TILE: hop == 64;
+                                              // STD: scale + Nyquist-normalise, no controls written;
+                                              // FPB: frames per unit - 16 when the whole job is one round of
+                                              // units (batch 32: 2016 units on 2048 blocks, phase A paid once
+                                              // per 16 frames), 8 otherwise (finer units balance better)
 __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd,
     const float* __restrict__ f0_all, float* __restrict__ ctl_amp_arg, float* __restrict__ ctl_hd_arg,
-    float* ws /*[gridDim.x][kUnitRows][Kp]*/, float* __restrict__ audio, FusedArgs p) {
-  __shared__ UnitTables t;
+    float* ws /*[gridDim.x][FPB + 1][Kp]*/, float* __restrict__ audio, FusedArgs p) {
+  constexpr int kUnitRows = FPB + 1;
+  __shared__ UnitTables<FPB> t;
   float* __restrict__ ctl_amp = STD ? nullptr : ctl_amp_arg;
   float* __restrict__ ctl_hd = STD ? nullptr : ctl_hd_arg;
   // debug timeline (flag 0x02000000, generic variant only): ctl_amp is reinterpreted as long long [gridDim.x][16]
@@ -502,8 +508,8 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
   for (int unit = blockIdx.x; unit < p.n_units;) {
     const int b = __builtin_amdgcn_readfirstlane((int)(((float)unit + 0.5f) * p.inv_upr));   // unit / units_per_row
     const int c = unit - b * p.units_per_row;
-    const int j0 = c * kFramesPerBlock;
-    const int nfr = min(kFramesPerBlock, F - j0);
+    const int j0 = c * FPB;
+    const int nfr = min(FPB, F - j0);
     const int row0 = b * F + j0;                                          // first (batch*frame) row
 
     // ---------------- phase A, rows: LPR lanes per row, RPW rows per wavefront per pass -----------
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
       if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
       kA = max(min(kA, kN), 0);
-      if (lane <= kFramesPerBlock) t.f0[lane] = fj;
+      if (lane <= FPB) t.f0[lane] = fj;
       if (lane < nfr) {
         t.theta[lane] = cyc - floor(cyc);                  // revolutions at the start of the frame
         t.w[lane] = fa * p.inv_sr;                         // revolutions per sample at r = 0
@@ -702,7 +708,7 @@ extern "C" size_t ddsp_harmonic_workspace_bytes(int B, int F, int K, int N) {
   (void)N;
   if (B <= 0 || F <= 0 || K <= 0) return 0;
   const size_t two_kernel = theta_bytes(B, F) + (size_t)B * (size_t)(F + 1) * (size_t)round_up(K, 16) * sizeof(float);
-  const size_t fused = (size_t)kFusedMaxBlocks * kUnitRows * (size_t)round_up(K, 16) * sizeof(float);
+  const size_t fused = (size_t)kFusedMaxBlocks * kMaxUnitRows * (size_t)round_up(K, 16) * sizeof(float);
   return two_kernel > fused ? two_kernel : fused;
 }
 
@@ -711,7 +717,9 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
                         int sample_rate, unsigned flags, int inputs_are_controls, hipStream_t st) {
   FusedArgs p;
   p.B = B; p.F = F; p.K = K; p.Kp = round_up(K, 16); p.N = N; p.hop = N / F;
-  p.units_per_row = (F + kFramesPerBlock - 1) / kFramesPerBlock;
+  // one round of 16-frame units if they all fit on the persistent grid, else 8-frame units
+  const int fpb = ((long)B * ((F + 15) / 16) <= (long)kFusedMaxBlocks) ? 16 : 8;
+  p.units_per_row = (F + fpb - 1) / fpb;
   p.n_units = B * p.units_per_row;
   p.sample_rate = (float)sample_rate;
   p.nyquist = (float)(sample_rate / 2.0);
@@ -740,8 +748,14 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmFused, &ev0, &ev1);
 #define DDSP_LAUNCH_FUSED(LPR, ONE, STD)                                                     \
-  hipExtLaunchKernelGGL((harm_fused_kernel<LPR, ONE, STD>), grid, block, 0, st, ev0, ev1, 0, amps, hd, \
-                        f0, ctl_amp, ctl_hd, (float*)workspace, audio, p)
+  do {                                                                                       \
+    if (fpb == 16)                                                                           \
+      hipExtLaunchKernelGGL((harm_fused_kernel<LPR, ONE, STD, 16>), grid, block, 0, st, ev0, ev1, 0, amps, hd, \
+                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
+    else                                                                                     \
+      hipExtLaunchKernelGGL((harm_fused_kernel<LPR, ONE, STD, 8>), grid, block, 0, st, ev0, ev1, 0, amps, hd,  \
+                            f0, ctl_amp, ctl_hd, (float*)workspace, audio, p);               \
+  } while (0)
 #define DDSP_LAUNCH_FUSED_LPR(LPR)                                                           \
   do {                                                                                       \
     if (p.hop == 64) { if (std_flags) DDSP_LAUNCH_FUSED(LPR, true, true); else DDSP_LAUNCH_FUSED(LPR, true, false); } \
