@@ -169,6 +169,14 @@ def main():
   for _ in range(a.warmup):
     step()
   torch.cuda.synchronize()
+  # Clock settle (untimed): an idle MI355X needs ~20 ms of load to reach its sustained clock - the
+  # same step measures 43 us right after a 5-step warm-up and 37 us from then on.  Whatever W is,
+  # keep the GPU busy for 50 ms before anything is measured.
+  t_settle = time.perf_counter()
+  while time.perf_counter() - t_settle < 0.05:
+    for _ in range(20):
+      step()
+    torch.cuda.synchronize()
 
   # diagnostic pass (untimed, one stream so every kernel runs alone): every kernel bracketed, to
   # find the dominant one and give the isolated per-kernel times
