@@ -31,6 +31,8 @@ SIGNATURES = {
     'ddsp_filtered_noise_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
                                 [c_float, c_uint, c_u64, c_u64, c_voidp]),
     'ddsp_fft_convolve_same_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
+    'ddsp_harmonic_streaming_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                    [c_uint, c_voidp]),
     'ddsp_fft_convolve_long_workspace_bytes': (c_size_t, [c_int] * 5),
     'ddsp_fft_convolve_long_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 +
                                    [c_uint, c_voidp]),
@@ -56,6 +58,7 @@ HARM_SCALE_EXP_SIGMOID = 0x1
 HARM_NORMALIZE_NYQUIST = 0x2
 HARM_AMP_LINEAR = 0x4
 HARM_ANGULAR_CUMSUM = 0x8
+HARM_INPUTS_ARE_AMPLITUDES = 0x20
 NOISE_SCALE_EXP_SIGMOID = 0x1
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2

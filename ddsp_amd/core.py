@@ -352,6 +352,48 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
   return audio
 
 
+def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=None,
+                                 initial_phase=None, n_samples=64000, sample_rate=16000,
+                                 amp_resample_method='linear', workspace=None):
+  """core.streaming_harmonic_synthesis (ddsp/core.py:1114-1164) -> (audio, final_phase).
+
+  One chunk of audio [batch, n_samples] from frame-wise controls, with the fundamental's phase
+  carried in (`initial_phase` [batch, 1, 1], radians) and out (`final_phase` [batch, 1, 1] =
+  (sum of omega mod 2 pi) + initial_phase, as harmonic_oscillator_bank returns it with its
+  default angular cumsum, core.py:1002-1012).  No audio-rate Nyquist mask, as in the reference.
+  """
+  frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
+  flags = _lib.HARM_AMP_LINEAR if amp_resample_method == 'linear' else 0
+  if harmonic_distribution is None:
+    harmonic_distribution = torch.ones_like(amplitudes)
+    flags |= _lib.HARM_INPUTS_ARE_AMPLITUDES
+  harmonic_distribution = tf_float32(harmonic_distribution)
+  b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
+  n = int(n_samples)
+  _check_amp_method(amp_resample_method, f, n)
+  if n % f:
+    raise ValueError('streaming_harmonic_synthesis needs n_samples ({}) to be a multiple of '
+                     'n_frames ({}) on the MI355X path.'.format(n, f))
+  dev = amplitudes.device
+  if initial_phase is not None:
+    initial_phase = tf_float32(initial_phase).reshape(-1)
+    if initial_phase.numel() != b:
+      raise ValueError('initial_phase must be [batch, 1, 1], got {} values for batch {}'.format(
+          initial_phase.numel(), b))
+    initial_phase = initial_phase.contiguous()
+  lib = _lib.load()
+  audio = torch.empty((b, n), dtype=torch.float32, device=dev)
+  final_phase = torch.empty((b, 1, 1), dtype=torch.float32, device=dev)
+  ws = (workspace or _default_ws).get(cached_workspace_bytes('ddsp_harmonic_workspace_bytes', b, f, k, n), dev)
+  rc = lib.ddsp_harmonic_streaming_f32(
+      amplitudes.data_ptr(), harmonic_distribution.data_ptr(), frequencies.data_ptr(),
+      initial_phase.data_ptr() if initial_phase is not None else None, audio.data_ptr(),
+      final_phase.data_ptr(), ws.data_ptr(), ws.numel(), b, f, k, n, int(sample_rate), flags,
+      _stream())
+  _lib.check(rc, 'ddsp_harmonic_streaming_f32')
+  return audio, final_phase
+
+
 # --------------------------------------------------------------------------------------
 # time-varying FIR  (ddsp/core.py:1382-1565, 1628-1655)
 # --------------------------------------------------------------------------------------

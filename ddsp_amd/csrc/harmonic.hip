@@ -52,6 +52,9 @@ struct ControlsArgs {
   float nyquist, sample_rate;
   unsigned flags;
   int inputs_are_controls;
+  // streaming synthesis (core.py:966-1025): phase carried in / out, radians, one value per row
+  const float* initial_phase;   // [B] or null
+  float* final_phase;           // [B] or null
 };
 
 template <int NCHUNK>   // ceil(K/64) <= NCHUNK
@@ -88,11 +91,19 @@ __global__ __launch_bounds__(256) void harm_controls_kernel(
     for (int w = 0; w < wave; ++w) base += s_wave[w];
     double run = base + incl - local;          // exclusive prefix at frame jb
     const double inv_sr = 1.0 / (double)p.sample_rate;
+    const double kTwoPi = 6.283185307179586;
+    const double init_rev = p.initial_phase ? (double)p.initial_phase[b] / kTwoPi : 0.0;
     for (int j = jb; j < je; ++j) {
-      const double cyc = run * inv_sr;
+      const double cyc = run * inv_sr + init_rev;
       theta0[(size_t)b * F + j] = cyc - floor(cyc);
       const double fa = (double)f0[j], fb = (double)f0[min(j + 1, F - 1)];
       run += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+    }
+    // harmonic_oscillator_bank's final_phase (core.py:1008-1012, angular cumsum):
+    // (sum of all omega mod 2 pi) + initial_phase - the fundamental's phase at the last sample
+    if (p.final_phase && jb < F && je == F) {
+      const double cyc = run * inv_sr;
+      p.final_phase[b] = (float)((cyc - floor(cyc)) * kTwoPi + (p.initial_phase ? (double)p.initial_phase[b] : 0.0));
     }
     return;
   }
@@ -176,6 +187,7 @@ struct SynthArgs {
   int F, K, Kp, N, hop;
   float sample_rate, nyquist;
   int amp_linear;
+  int no_audio_mask;       // harmonic_oscillator_bank has no audio-rate Nyquist mask (core.py:966-1025)
 };
 
 // exact fractional part of k*theta (theta in [0,1], k < 2^23): in [-0.5, 0.5]
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(kSynthThreads) void harm_synth_kernel(
     if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
     if (fmn > 0.0f) kN = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f + 2e-6f) / fmn));
     kA = max(min(kA, kN), 0);
+    if (p.no_audio_mask) kA = kN = p.K;
 
     const float* __restrict__ a0p = ws_a + ((size_t)b * (p.F + 1) + j) * p.Kp;
     const float* __restrict__ a1p = a0p + p.Kp;
@@ -777,7 +790,8 @@ static inline bool fused_ok(int F, int K, int N, const void* hd, const void* ctl
 static int launch_controls(const float* amps, const float* hd, const float* f0, float* ctl_amp,
                            float* ctl_hd, void* workspace, int B, int F, int K, int N,
                            int sample_rate, unsigned flags, int inputs_are_controls,
-                           hipStream_t st) {
+                           hipStream_t st, const float* initial_phase = nullptr,
+                           float* final_phase = nullptr) {
   ControlsArgs p;
   p.B = B; p.F = F; p.K = K; p.Kp = round_up(K, 16);
   p.hop = workspace ? N / F : 1;
@@ -787,6 +801,7 @@ static int launch_controls(const float* amps, const float* hd, const float* f0, 
   p.sample_rate = (float)sample_rate;
   p.flags = flags;
   p.inputs_are_controls = inputs_are_controls;
+  p.initial_phase = initial_phase; p.final_phase = final_phase;
   double* theta0 = (double*)workspace;
   float* ws_a = workspace ? (float*)((char*)workspace + theta_bytes(B, F)) : nullptr;
   const dim3 grid((unsigned)(p.n_ctl_blocks + (workspace ? B : 0))), block(256);
@@ -811,6 +826,7 @@ static int launch_synth(const float* f0, const void* workspace, float* audio, in
   p.sample_rate = (float)sample_rate;
   p.nyquist = (float)(sample_rate / 2.0);
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.no_audio_mask = (flags & DDSP_HARM_NO_AUDIO_RATE_MASK) ? 1 : 0;
   const double* theta0 = (const double*)workspace;
   const float* ws_a = (const float*)((const char*)workspace + theta_bytes(B, F));
   const dim3 grid((unsigned)((F + kFramesPerBlock - 1) / kFramesPerBlock), (unsigned)B);
@@ -879,6 +895,34 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
                        sample_rate, flags, /*inputs_are_controls=*/0, st);
   if (rc != DDSP_OK) return rc;
   return launch_synth(f0_hz, workspace, audio, B, F, K, N, sample_rate, flags, st);
+}
+
+// core.streaming_harmonic_synthesis (ddsp/core.py:1114-1164): frame-wise controls of a short chunk
+// (the VST model passes 2 frames: previous and current, ddsp/training/inference.py:446-472) ->
+// audio of the chunk + the fundamental's phase to carry into the next call.  Same closed forms as
+// ddsp_harmonic_signal_f32 with the phase offset added and, as harmonic_oscillator_bank
+// (core.py:966-1025) does, no audio-rate Nyquist mask; always the two-kernel path (the chunks
+// are a few hundred samples of one clip: latency, not throughput).
+extern "C" int ddsp_harmonic_streaming_f32(const float* amplitudes, const float* hd, const float* f0_hz,
+                                           const float* initial_phase, float* audio,
+                                           float* final_phase, void* workspace,
+                                           size_t workspace_bytes, int B, int F, int K, int N,
+                                           int sample_rate, unsigned flags, void* stream) {
+  if (!amplitudes || !hd || !f0_hz || !audio || !workspace) return DDSP_ERR_NULL_POINTER;
+  int rc = check_harmonic_shape(B, F, K, N, sample_rate);
+  if (rc != DDSP_OK) return rc;
+  if (workspace_bytes < ddsp_harmonic_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  // normalize_harmonics with the frame-rate Nyquist mask when a distribution is given
+  // (core.py:1141-1148); DDSP_HARM_INPUTS_ARE_AMPLITUDES: hd already holds amplitudes * distribution
+  const int as_is = (flags & DDSP_HARM_INPUTS_ARE_AMPLITUDES) ? 1 : 0;
+  const unsigned cflags = as_is ? 0u : DDSP_HARM_NORMALIZE_NYQUIST;
+  rc = launch_controls(amplitudes, hd, f0_hz, nullptr, nullptr, workspace, B, F, K, N, sample_rate,
+                       cflags, as_is, st, initial_phase, final_phase);
+  if (rc != DDSP_OK) return rc;
+  return launch_synth(f0_hz, workspace, audio, B, F, K, N, sample_rate,
+                      (flags & DDSP_HARM_AMP_LINEAR) | DDSP_HARM_NO_AUDIO_RATE_MASK, st);
 }
 
 // =====================================================================================

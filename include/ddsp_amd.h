@@ -41,6 +41,8 @@ extern "C" {
 #define DDSP_HARM_NORMALIZE_NYQUIST 0x2u  /* normalize_below_nyquist=True */
 #define DDSP_HARM_AMP_LINEAR 0x4u         /* amp_resample_method='linear' (else 'window') */
 #define DDSP_HARM_ANGULAR_CUMSUM 0x8u     /* use_angular_cumsum=True (phase) */
+#define DDSP_HARM_NO_AUDIO_RATE_MASK 0x10u      /* internal to the streaming entry: no per-sample Nyquist mask */
+#define DDSP_HARM_INPUTS_ARE_AMPLITUDES 0x20u   /* streaming entry: harmonic_distribution=None (core.py:1149-1150) */
 
 /* ---- flags for the FilteredNoise entry points (ddsp/synths.py:153-163) ------------ */
 #define DDSP_NOISE_SCALE_EXP_SIGMOID 0x1u /* scale_fn=core.exp_sigmoid on (mag + initial_bias) */
@@ -89,6 +91,27 @@ int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amplitudes,
                                       const float* ctl_harmonic_distribution, const float* f0_hz,
                                       float* audio, int B, int F, int K, int N, int sample_rate,
                                       unsigned flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * core.streaming_harmonic_synthesis (ddsp/core.py:1114-1164) with harmonic_oscillator_bank
+ * (core.py:966-1025, angular cumsum): one chunk of audio from frame-wise controls with the
+ * fundamental's phase carried in and out (the VST model, ddsp/training/inference.py:446-472,
+ * calls it with F = 2 frames per hop).
+ *   amplitudes [B,F,1], harmonic_distribution [B,F,K] (normalised with the frame-rate Nyquist
+ *   mask, core.py:1141-1148; with DDSP_HARM_INPUTS_ARE_AMPLITUDES the harmonic amplitudes are
+ *   amplitudes * harmonic_distribution as given - pass ones [B,F,1] for the reference's
+ *   harmonic_distribution=None), f0_hz [B,F,1],
+ *   initial_phase [B] radians or NULL (= 0), audio [B,N] out, final_phase [B] out or NULL:
+ *   (sum of omega mod 2 pi) + initial_phase, as the reference returns it.
+ * There is no audio-rate Nyquist mask on this path (as in the reference).  N % F == 0.
+ * flags: DDSP_HARM_AMP_LINEAR (amp_resample_method, default 'linear' in the reference),
+ * DDSP_HARM_INPUTS_ARE_AMPLITUDES.  workspace: ddsp_harmonic_workspace_bytes(B,F,K,N).
+ */
+int ddsp_harmonic_streaming_f32(const float* amplitudes, const float* harmonic_distribution,
+                                const float* f0_hz, const float* initial_phase, float* audio,
+                                float* final_phase, void* workspace, size_t workspace_bytes,
+                                int B, int F, int K, int N, int sample_rate, unsigned flags,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Harmonic.__call__  == get_signal(**get_controls(...))  (ddsp/processors.py:53-68),

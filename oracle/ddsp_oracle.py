@@ -283,6 +283,42 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
 # ----------------------------------------------------------------------------
 # Time-varying FIR   (ddsp/core.py:1317-1565, 1628-1655)
 # ----------------------------------------------------------------------------
+def harmonic_oscillator_bank(frequency, amplitude_envelopes, initial_phase=None,
+                             sample_rate=16000, use_angular_cumsum=True):
+  """core.harmonic_oscillator_bank (core.py:966-1025) -> (audio [B,N], final_phase [B,1,1])."""
+  dtype = amplitude_envelopes.dtype
+  omega = frequency * dtype.type(TWO_PI)
+  omega = omega / dtype.type(sample_rate)
+  phases = angular_cumsum(omega) if use_angular_cumsum else np.cumsum(omega, axis=1, dtype=dtype)
+  if initial_phase is None:
+    initial_phase = np.zeros([phases.shape[0], 1, 1], dtype)
+  phases = phases + as_float(initial_phase, dtype)
+  final_phase = phases[:, -1:, 0:1]
+  n_harmonics = int(amplitude_envelopes.shape[-1])
+  f_ratios = np.linspace(1.0, float(n_harmonics), n_harmonics).astype(dtype)[None, None, :]
+  phases = phases * f_ratios
+  audio = np.sum(amplitude_envelopes * np.sin(phases), axis=-1, dtype=dtype)
+  return audio, final_phase
+
+
+def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=None,
+                                 initial_phase=None, n_samples=64000, sample_rate=16000,
+                                 amp_resample_method='linear', dtype=np.float32):
+  """core.streaming_harmonic_synthesis (core.py:1114-1164)."""
+  frequencies, amplitudes = as_float(frequencies, dtype), as_float(amplitudes, dtype)
+  if harmonic_distribution is not None:
+    harmonic_distribution = normalize_harmonics(as_float(harmonic_distribution, dtype),
+                                                frequencies, sample_rate)
+    harmonic_amplitudes = amplitudes * harmonic_distribution
+  else:
+    harmonic_amplitudes = amplitudes
+  frequencies = resample(frequencies, n_samples, dtype=dtype)
+  amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method,
+                                 dtype=dtype)
+  return harmonic_oscillator_bank(frequencies, amplitude_envelopes, initial_phase,
+                                  sample_rate=sample_rate)
+
+
 def get_fft_size(frame_size, ir_size, power_of_2=True):
   """core.get_fft_size (core.py:1317-1335), power-of-two branch only."""
   convolved_frame_size = ir_size + frame_size - 1

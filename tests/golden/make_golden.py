@@ -129,6 +129,26 @@ def main():
       loss_two_scales=a(losses.SpectralLoss(fft_sizes=(512, 64), logmag_weight=0.5)(tgt, aud)),
       mag_256=a(spectral_ops.compute_mag(aud, size=256)))
 
+  # --- core.streaming_harmonic_synthesis: the VST model's call (2 frames -> one hop, carried phase) ---
+  rng = np.random.default_rng(51)
+  def streaming_case(batch, n_frames, n_harm, n_samples, sr, method, with_hd=True, f_lo=200.0, f_hi=900.0):
+    f0 = rng.uniform(f_lo, f_hi, (batch, n_frames, 1)).astype(np.float32)
+    amps = rng.uniform(0.1, 1.0, (batch, n_frames, 1)).astype(np.float32)
+    hd = rng.uniform(0.0, 1.0, (batch, n_frames, n_harm)).astype(np.float32) if with_hd else None
+    phase0 = rng.uniform(0.0, 6.0, (batch, 1, 1)).astype(np.float32)
+    audio, final_phase = core.streaming_harmonic_synthesis(
+        frequencies=f0, amplitudes=amps, harmonic_distribution=hd, initial_phase=phase0,
+        n_samples=n_samples, sample_rate=sr, amp_resample_method=method)
+    d = dict(f0_hz=f0, amplitudes=amps, initial_phase=phase0, n_samples=n_samples, sample_rate=sr,
+             amp_method=method, audio=a(audio), final_phase=a(final_phase))
+    if with_hd:
+      d['harmonic_distribution'] = hd
+    return d
+  cases['streaming_2frames_linear'] = streaming_case(1, 2, 60, 64, 16000, 'linear')
+  cases['streaming_2frames_window'] = streaming_case(2, 2, 100, 320, 16000, 'window', f_lo=60.0, f_hi=90.0)
+  cases['streaming_nyquist_crossing'] = streaming_case(2, 4, 30, 256, 16000, 'linear', f_lo=250.0, f_hi=600.0)
+  cases['streaming_no_distribution'] = streaming_case(3, 5, 1, 640, 48000, 'linear', with_hd=False)
+
   # --- resampling pieces on their own ---
   rng = np.random.default_rng(21)
   x = rng.standard_normal((2, 9, 3)).astype(np.float32)

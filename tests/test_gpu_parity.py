@@ -639,3 +639,49 @@ def test_spectral_loss_on_the_synth_output_batch32(ddsp):          # ae.gin:36-4
   np.testing.assert_allclose(float(loss(audio, target)), got, rtol=1e-6)
   ref2 = float(O.spectral_loss(npy(target[:2]), npy(audio[:2]), logmag_weight=1.0, dtype=np.float64))
   np.testing.assert_allclose(float(loss(target[:2].contiguous(), audio[:2].contiguous())), ref2, rtol=2e-5)
+
+
+# ---- core.streaming_harmonic_synthesis --------------------------------
+STREAMING_CASES = ['streaming_2frames_linear', 'streaming_2frames_window', 'streaming_nyquist_crossing',
+                   'streaming_no_distribution']
+
+
+@pytest.mark.parametrize('name', STREAMING_CASES)
+def test_streaming_synthesis_golden(ddsp, name):
+  g = load_golden(name)
+  hd = g.get('harmonic_distribution')
+  audio, final_phase = ddsp.core.streaming_harmonic_synthesis(
+      g['f0_hz'], g['amplitudes'], hd, g['initial_phase'], int(g['n_samples']), int(g['sample_rate']),
+      str(g['amp_method']))
+  assert tuple(audio.shape) == g['audio'].shape and tuple(final_phase.shape) == g['final_phase'].shape
+  a64, p64 = O.streaming_harmonic_synthesis(
+      g['f0_hz'], g['amplitudes'], hd, g['initial_phase'], int(g['n_samples']), int(g['sample_rate']),
+      str(g['amp_method']), dtype=np.float64)
+  amp_sum = float(np.abs(g['amplitudes']).max()) * (1.0 if hd is not None else 1.0)
+  np.testing.assert_allclose(npy(audio), a64, rtol=0, atol=HARM_TRUTH_ATOL * max(1.0, amp_sum))
+  np.testing.assert_allclose(npy(audio), g['audio'], rtol=0, atol=HARM_FAITHFUL_ATOL)
+  # the carried phase: equal modulo 2 pi to fp64 truth (the reference wraps before adding initial_phase)
+  d = (npy(final_phase) - p64 + np.pi) % (2 * np.pi) - np.pi
+  assert np.abs(d).max() < 2e-5
+
+
+def test_streaming_chunks_are_phase_continuous(ddsp):               # inference.py:446-472 call pattern
+  rng = np.random.default_rng(8)
+  hop, k, sr, n_hops = 64, 60, 16000, 40
+  f0 = (220.0 + 30.0 * np.sin(np.arange(n_hops + 1) / 5.0)).astype(np.float32)
+  amps = rng.uniform(0.5, 1.0, n_hops + 1).astype(np.float32)
+  hd = rng.uniform(0.0, 1.0, (n_hops + 1, k)).astype(np.float32)
+  phase = np.zeros((1, 1, 1), np.float32)
+  phase64 = np.zeros((1, 1, 1))
+  chunks, ref_chunks = [], []
+  for i in range(n_hops):
+    args = (f0[None, i:i + 2, None], amps[None, i:i + 2, None], hd[None, i:i + 2, :])
+    a, phase = ddsp.core.streaming_harmonic_synthesis(*args, initial_phase=phase, n_samples=hop,
+                                                      sample_rate=sr)
+    r, phase64 = O.streaming_harmonic_synthesis(*args, initial_phase=phase64, n_samples=hop,
+                                                sample_rate=sr, dtype=np.float64)
+    chunks.append(npy(a)[0]); ref_chunks.append(r[0])
+  got, ref = np.concatenate(chunks), np.concatenate(ref_chunks)
+  # 40 calls with the phase carried through fp32: the drift stays far below audibility
+  assert np.abs(got - ref).max() < 2e-3
+  assert np.abs(got).max() > 0.2

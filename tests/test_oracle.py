@@ -230,3 +230,25 @@ def test_spectral_loss_is_zero_for_identical_signals_and_counts_padded_frames():
   assert O.spectral_loss(x, x, logmag_weight=1.0) == 0.0
   assert O.compute_mag(x, 64).shape == (1, 63, 33)                 # ceil(1000/16) frames, 33 bins
   assert O.compute_mag(x, 2048).shape == (1, 2, 1025)              # frames longer than the clip
+
+
+# ---- core.streaming_harmonic_synthesis ---------------------------------
+STREAMING_CASES = ['streaming_2frames_linear', 'streaming_2frames_window', 'streaming_nyquist_crossing',
+                   'streaming_no_distribution']
+
+
+@pytest.mark.parametrize('name', STREAMING_CASES)
+def test_streaming_synthesis_matches_reference_source(name):
+  g = load_golden(name)
+  audio, final_phase = O.streaming_harmonic_synthesis(
+      g['f0_hz'], g['amplitudes'], g.get('harmonic_distribution'), g['initial_phase'],
+      int(g['n_samples']), int(g['sample_rate']), str(g['amp_method']))
+  assert audio.dtype == np.float32 and audio.shape == g['audio'].shape
+  np.testing.assert_allclose(audio, g['audio'], rtol=0, atol=2e-6)
+  np.testing.assert_allclose(final_phase, g['final_phase'], rtol=0, atol=1e-6)
+  # fp64 truth (what the HIP path is held to) stays close on these short chunks
+  a64, p64 = O.streaming_harmonic_synthesis(
+      g['f0_hz'], g['amplitudes'], g.get('harmonic_distribution'), g['initial_phase'],
+      int(g['n_samples']), int(g['sample_rate']), str(g['amp_method']), dtype=np.float64)
+  assert np.abs(a64 - g['audio']).max() < 2e-3
+  assert np.abs(p64 - g['final_phase']).max() < 5e-4      # the reference's own fp32 phase error
