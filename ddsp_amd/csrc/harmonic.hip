@@ -926,6 +926,229 @@ extern "C" int ddsp_harmonic_streaming_f32(const float* amplitudes, const float*
 }
 
 // =====================================================================================
+// Backward pass of Harmonic.__call__: dL/d(amplitudes), dL/d(harmonic_distribution) from
+// dL/d(audio) - what tf.GradientTape computes through ddsp/synths.py:94-146 in
+// ddsp/training/trainers.py:162-171.  f0 is a constant here (no gradient is formed for it).
+//
+//   audio[n] = w_cur(r) sum_k a[j,k] s_k(n) + w_next(r) sum_k a[j+1,k] s_k(n),   n = j hop + r,
+//   s_k(n) = sin(2 pi k theta(n)) where the harmonic is below Nyquist at sample n, a = amp * hd_norm.
+//
+//   harm_bwd_pq_kernel     lanes = harmonics, one block per (row, frame): every lane accumulates
+//                          P[j,k] = sum_r w_cur(r) g(n) s_k(n) and Q[j,k] = sum_r w_next(r) g(n) s_k(n)
+//                          over the frame's samples - the per-sample values (phase, weighted
+//                          gradient) are computed once with lanes = samples and broadcast from
+//                          LDS, so there is no cross-lane reduction anywhere.
+//   harm_bwd_chain_kernel  one wavefront per (row, frame): dL/da[j] = P[j] + Q[j-1] (+ Q[F-1] for
+//                          the held last frame), then the frame-rate chain rule through
+//                          amp * hd_norm, safe_divide, the Nyquist mask and exp_sigmoid.
+// =====================================================================================
+namespace ddsp {
+
+constexpr int kBwdMaxHop = 2048;
+
+struct BwdArgs {
+  int F, K, N, hop;
+  float sample_rate, nyquist;
+  int amp_linear;
+  unsigned flags;
+  int inputs_are_controls;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void harm_bwd_pq_kernel(const float* __restrict__ f0_all,
+                                                              const double* __restrict__ theta0,
+                                                              const float* __restrict__ grad_audio,
+                                                              float* __restrict__ pq /*[2][B*F][K]*/,
+                                                              size_t q_offset, BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float4 sm[kBwdMaxHop];      // {theta, w_cur g, w_next g, lerp}
+  const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
+  const float* __restrict__ f0 = f0_all + (size_t)b * p.F;
+  const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
+  {
+    const double inv_sr = 1.0 / (double)p.sample_rate, inv_2hop = 0.5 / (double)p.hop;
+    const double th0 = theta0[(size_t)b * p.F + j];
+    const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
+    const float inv_hop = 1.0f / (float)p.hop;
+    const float* __restrict__ g = grad_audio + (size_t)b * p.N + (size_t)j * p.hop;
+    for (int r = tid; r < p.hop; r += 64 * NW) {
+      const double rr = (double)r;
+      const double cyc = th0 + (rr + 1.0) * (wj + dw * rr);
+      const float lerp = (float)r * inv_hop;
+      const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
+      const float gv = g[r];
+      sm[r] = make_float4((float)(cyc - floor(cyc)), (1.0f - w_next) * gv, w_next * gv, lerp);
+    }
+  }
+  __syncthreads();
+  const int k = tid;                                     // harmonic index (0-based)
+  const float kf = (float)(k + 1);
+  // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample (as harm_synth_kernel)
+  const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+  int kA = p.K, kN = p.K;
+  if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
+  if (fmn > 0.0f) kN = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f + 2e-6f) / fmn));
+  kA = max(min(kA, kN), 0);
+  float P = 0.0f, Q = 0.0f;
+  if (kA == kN) {                                        // block-uniform: no harmonic crosses Nyquist in this frame
+#pragma unroll 4
+    for (int r = 0; r < p.hop; ++r) {
+      const float4 v = sm[r];                            // same address for every lane: LDS broadcast
+      const float s = sin_rev(frac_phase(v.x, kf));
+      P = fmaf(v.y, s, P);
+      Q = fmaf(v.z, s, Q);
+    }
+    if (k >= kA) { P = 0.0f; Q = 0.0f; }
+  } else {
+    const float top = fj * kf, bot = fj1 * kf;
+#pragma unroll 2
+    for (int r = 0; r < p.hop; ++r) {
+      const float4 v = sm[r];
+      // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
+      const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), v.w));
+      const float s = (fk >= p.nyquist || k >= kN) ? 0.0f : sin_rev(frac_phase(v.x, kf));
+      P = fmaf(v.y, s, P);
+      Q = fmaf(v.z, s, Q);
+    }
+  }
+  if (k < p.K) {
+    const size_t at = ((size_t)b * p.F + j) * p.K + k;
+    pq[at] = P;
+    pq[q_offset + at] = Q;
+  }
+}
+
+template <int NCHUNK>   // ceil(K/64) <= NCHUNK
+__global__ __launch_bounds__(256) void harm_bwd_chain_kernel(const float* __restrict__ amplitudes,
+                                                             const float* __restrict__ hd,
+                                                             const float* __restrict__ f0_hz,
+                                                             const float* __restrict__ pq, size_t q_offset,
+                                                             float* __restrict__ grad_amp,
+                                                             float* __restrict__ grad_hd, long rows,
+                                                             BwdArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int F = p.F, K = p.K;
+  const int j = (int)(row % F);
+  const bool is_ctl = p.inputs_are_controls != 0;
+  const bool scale = (p.flags & DDSP_HARM_SCALE_EXP_SIGMOID) && !is_ctl;
+  const bool normalize = (p.flags & DDSP_HARM_NORMALIZE_NYQUIST) && !is_ctl;
+  const float kLog10 = 2.302585092994046f;
+  const float f0r = f0_hz[row];
+  const float amp_raw = amplitudes[row];
+  const float amp_s = scale ? exp_sigmoid(amp_raw, kLog10, 2.0f, 1e-7f) : amp_raw;
+  float x[NCHUNK], raw[NCHUNK], ga[NCHUNK];
+  bool live[NCHUNK];
+  float part = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int k = c * 64 + lane;
+    raw[c] = 0.0f; x[c] = 0.0f; ga[c] = 0.0f; live[c] = false;
+    if (k < K) {
+      const size_t at = (size_t)row * K + k;
+      raw[c] = hd[at];
+      float v = scale ? exp_sigmoid(raw[c], kLog10, 2.0f, 1e-7f) : raw[c];
+      live[c] = !(normalize && (f0r * (float)(k + 1) >= p.nyquist));
+      if (!live[c]) v = 0.0f;
+      x[c] = v;
+      // dL/da[j] = P[j] + Q[j-1]; the last frame also receives Q[F-1] (row F repeats row F-1)
+      float g = pq[at];
+      if (j > 0) g += pq[q_offset + at - K];
+      if (j == F - 1) g += pq[q_offset + at];
+      ga[c] = g;
+    }
+    part += x[c];
+  }
+  float inv = 1.0f;
+  bool den_zero = false;
+  if (!is_ctl) {
+    float den = wave_sum(part);
+    den_zero = den == 0.0f;
+    if (den_zero) den = 1e-7f;
+    inv = 1.0f / den;
+  }
+  float dot = 0.0f;                                      // sum_k ga * hd_norm = dL/d(amp_scaled)
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) dot = fmaf(ga[c], x[c] * inv, dot);
+  dot = wave_sum(dot);
+  if (lane == 0)
+    grad_amp[row] = scale ? dot * kLog10 * (amp_s - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-amp_raw))) : dot;
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int k = c * 64 + lane;
+    if (k < K) {
+      float d;
+      if (is_ctl) {
+        d = ga[c] * amp_s;
+      } else {
+        // hd_norm = x / den: d x = (d hd_norm - sum_k d hd_norm hd_norm) / den, d hd_norm = ga * amp
+        d = (live[c] && !den_zero) ? amp_s * (ga[c] - dot) * inv : 0.0f;
+        if (scale) d *= kLog10 * (x[c] - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-raw[c])));
+      }
+      grad_hd[(size_t)row * K + k] = d;
+    }
+  }
+}
+
+static inline size_t bwd_pq_floats(int B, int F, int K) { return ((size_t)B * F * K + 15) & ~(size_t)15; }
+
+}  // namespace ddsp
+
+extern "C" size_t ddsp_harmonic_backward_workspace_bytes(int B, int F, int K, int N) {
+  const size_t fwd = ddsp_harmonic_workspace_bytes(B, F, K, N);
+  if (fwd == 0) return 0;
+  return ((fwd + 63) & ~(size_t)63) + 2 * bwd_pq_floats(B, F, K) * sizeof(float);
+}
+
+extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* hd, const float* f0_hz,
+                                          const float* grad_audio, float* grad_amplitudes,
+                                          float* grad_hd, void* workspace, size_t workspace_bytes,
+                                          int B, int F, int K, int N, int sample_rate,
+                                          unsigned flags, int inputs_are_controls, void* stream) {
+  if (!amplitudes || !hd || !f0_hz || !grad_audio || !grad_amplitudes || !grad_hd || !workspace)
+    return DDSP_ERR_NULL_POINTER;
+  int rc = check_harmonic_shape(B, F, K, N, sample_rate);
+  if (rc != DDSP_OK) return rc;
+  if (K > 256 || N / F > kBwdMaxHop) return DDSP_ERR_UNSUPPORTED;
+  if (workspace_bytes < ddsp_harmonic_backward_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  // the fp64 phase prefix theta0[B,F] (and, unused here, the amplitude rows) of the generic path
+  rc = launch_controls(amplitudes, hd, f0_hz, nullptr, nullptr, workspace, B, F, K, N, sample_rate,
+                       flags, inputs_are_controls, st);
+  if (rc != DDSP_OK) return rc;
+  const size_t fwd = (ddsp_harmonic_workspace_bytes(B, F, K, N) + 63) & ~(size_t)63;
+  float* pq = (float*)((char*)workspace + fwd);
+  const size_t q_offset = bwd_pq_floats(B, F, K);
+  BwdArgs p;
+  p.F = F; p.K = K; p.N = N; p.hop = N / F;
+  p.sample_rate = (float)sample_rate; p.nyquist = (float)(sample_rate / 2.0);
+  p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.flags = flags; p.inputs_are_controls = inputs_are_controls;
+  const double* theta0 = (const double*)workspace;
+  {
+    ProfileScope prof(kHarmBwdPq, st);
+    const dim3 grid((unsigned)F, (unsigned)B);
+    if (K <= 64) hipLaunchKernelGGL((harm_bwd_pq_kernel<1>), grid, dim3(64), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
+    else if (K <= 128) hipLaunchKernelGGL((harm_bwd_pq_kernel<2>), grid, dim3(128), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
+    else hipLaunchKernelGGL((harm_bwd_pq_kernel<4>), grid, dim3(256), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
+  }
+  {
+    ProfileScope prof(kHarmBwdChain, st);
+    const long rows = (long)B * F;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const int nchunk = (K + 63) / 64;
+#define DDSP_LAUNCH_BWD(NC) hipLaunchKernelGGL((harm_bwd_chain_kernel<NC>), grid, dim3(256), 0, st, amplitudes, hd, \
+                                               f0_hz, (const float*)pq, q_offset, grad_amplitudes, grad_hd, rows, p)
+    if (nchunk <= 1) DDSP_LAUNCH_BWD(1);
+    else if (nchunk <= 2) DDSP_LAUNCH_BWD(2);
+    else DDSP_LAUNCH_BWD(4);
+#undef DDSP_LAUNCH_BWD
+  }
+  return check_launch();
+}
+
+// =====================================================================================
 // Stand-alone core.oscillator_bank (ddsp/core.py:912-962) on materialised audio-rate envelopes
 // [B,N,K] (what synths.Sinusoidal and direct callers use).  The Harmonic path never calls this:
 // it fuses the same maths with closed-form phases.  Here the phase really is a scan over time:

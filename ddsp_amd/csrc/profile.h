@@ -21,6 +21,8 @@ enum KernelId {
   kReverbMac,
   kReverbIfft,
   kStftL1,
+  kHarmBwdPq,
+  kHarmBwdChain,
   kNumKernels
 };
 

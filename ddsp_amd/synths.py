@@ -29,6 +29,7 @@ class Harmonic(processors.Processor):
     self.amp_resample_method = amp_resample_method
     self.use_angular_cumsum = use_angular_cumsum
     self._ws = core.Workspace()
+    self._ws_bwd = core.Workspace()
 
   # -- helpers -------------------------------------------------------------------------
   def _prescale(self, amplitudes, harmonic_distribution):
@@ -68,7 +69,12 @@ class Harmonic(processors.Processor):
         use_angular_cumsum=self.use_angular_cumsum, workspace=self._ws)
 
   def call(self, amplitudes, harmonic_distribution, f0_hz, return_outputs_dict=False, **kwargs):
-    """get_signal(**get_controls(...)) (processors.py:53-68) as ONE fused C-ABI call."""
+    """get_signal(**get_controls(...)) (processors.py:53-68) as ONE fused C-ABI call.
+
+    When an input tensor requires grad the call is recorded for torch.autograd: backward()
+    produces dL/d amplitudes and dL/d harmonic_distribution (ddsp_harmonic_backward_f32);
+    f0_hz is treated as a constant.
+    """
     for k in ['training', 'mask']:
       kwargs.pop(k, None)
     if kwargs:
@@ -76,26 +82,76 @@ class Harmonic(processors.Processor):
     amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0_hz = core.tf_float32(f0_hz)
     b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
+    core._check_amp_method(self.amp_resample_method, f, int(self.n_samples))
+    needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or
+                                              harmonic_distribution.requires_grad)
+    if needs_grad:
+      audio = _HarmonicFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse)
+      if not return_outputs_dict:
+        return audio
+      with torch.no_grad():                               # the controls dict is not differentiable here
+        controls = self._forward(amplitudes.detach(), harmonic_distribution.detach(), f0_hz, fuse,
+                                 True)['controls']
+      return dict(signal=audio, controls=controls)
+    return self._forward(amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict)
+
+  def _flags(self, fuse):
+    return core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
+                                self.use_angular_cumsum)
+
+  def _forward(self, amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict=False):
+    b, f, k = harmonic_distribution.shape
     n = int(self.n_samples)
-    core._check_amp_method(self.amp_resample_method, f, n)
     lib = _lib.load()
     dev = amplitudes.device
     audio = torch.empty((b, n), dtype=torch.float32, device=dev)
     ctl_amp = torch.empty_like(amplitudes) if return_outputs_dict else None
     ctl_hd = torch.empty_like(harmonic_distribution) if return_outputs_dict else None
     ws = self._ws.get(core.cached_workspace_bytes('ddsp_harmonic_workspace_bytes', b, f, k, n), dev)
-    flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
-                                 self.use_angular_cumsum)
     rc = lib.ddsp_harmonic_f32(
         amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(),
         audio.data_ptr(), ctl_amp.data_ptr() if return_outputs_dict else None,
         ctl_hd.data_ptr() if return_outputs_dict else None, ws.data_ptr(), ws.numel(), b, f, k,
-        n, int(self.sample_rate), flags, core._stream())
+        n, int(self.sample_rate), self._flags(fuse), core._stream())
     _lib.check(rc, 'ddsp_harmonic_f32')
     if return_outputs_dict:
       controls = {'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz}
       return dict(signal=audio, controls=controls)
     return audio
+
+  def _backward(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
+    b, f, k = harmonic_distribution.shape
+    n = int(self.n_samples)
+    lib = _lib.load()
+    dev = amplitudes.device
+    grad_audio = core.tf_float32(grad_audio)
+    grad_amp = torch.empty_like(amplitudes)
+    grad_hd = torch.empty_like(harmonic_distribution)
+    ws = self._ws_bwd.get(core.cached_workspace_bytes('ddsp_harmonic_backward_workspace_bytes',
+                                                      b, f, k, n), dev)
+    rc = lib.ddsp_harmonic_backward_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(),
+        grad_audio.data_ptr(), grad_amp.data_ptr(), grad_hd.data_ptr(), ws.data_ptr(), ws.numel(),
+        b, f, k, n, int(self.sample_rate), self._flags(fuse), 0, core._stream())
+    _lib.check(rc, 'ddsp_harmonic_backward_f32')
+    return grad_amp, grad_hd
+
+
+class _HarmonicFunction(torch.autograd.Function):
+  """torch.autograd node of Harmonic.__call__ (plumbing: both directions are C-ABI calls)."""
+
+  @staticmethod
+  def forward(ctx, amplitudes, harmonic_distribution, f0_hz, synth, fuse):
+    ctx.save_for_backward(amplitudes, harmonic_distribution, f0_hz)
+    ctx.synth, ctx.fuse = synth, fuse
+    return synth._forward(amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach(), fuse)
+
+  @staticmethod
+  def backward(ctx, grad_audio):
+    amplitudes, harmonic_distribution, f0_hz = ctx.saved_tensors
+    grad_amp, grad_hd = ctx.synth._backward(amplitudes.detach(), harmonic_distribution.detach(),
+                                            f0_hz.detach(), ctx.fuse, grad_audio)
+    return grad_amp, grad_hd, None, None, None
 
 
 class FilteredNoise(processors.Processor):

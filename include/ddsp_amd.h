@@ -93,6 +93,22 @@ int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amplitudes,
                                       unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Backward pass of ddsp_harmonic_f32 (inputs_are_controls = 0) / ddsp_harmonic_signal_f32
+ * (inputs_are_controls = 1): the gradients tf.GradientTape forms through
+ * ddsp/synths.py:94-146 in ddsp/training/trainers.py:162-171.
+ *   grad_audio [B,N] in;  grad_amplitudes [B,F,1], grad_harmonic_distribution [B,F,K] out.
+ * f0_hz is a constant of the differentiation (no gradient is formed for it); the Nyquist masks
+ * have zero gradient, as tf.where gives them.  flags as ddsp_harmonic_f32.  K <= 256, N/F <= 2048.
+ * workspace: ddsp_harmonic_backward_workspace_bytes(B,F,K,N).
+ */
+size_t ddsp_harmonic_backward_workspace_bytes(int B, int F, int K, int N);
+int ddsp_harmonic_backward_f32(const float* amplitudes, const float* harmonic_distribution,
+                               const float* f0_hz, const float* grad_audio, float* grad_amplitudes,
+                               float* grad_harmonic_distribution, void* workspace,
+                               size_t workspace_bytes, int B, int F, int K, int N, int sample_rate,
+                               unsigned flags, int inputs_are_controls, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * core.streaming_harmonic_synthesis (ddsp/core.py:1114-1164) with harmonic_oscillator_bank
  * (core.py:966-1025, angular cumsum): one chunk of audio from frame-wise controls with the
  * fundamental's phase carried in and out (the VST model, ddsp/training/inference.py:446-472,

@@ -555,6 +555,60 @@ def reverb_direct(audio, ir, add_dry=True):
 
 
 # ----------------------------------------------------------------------------
+# Backward pass of synths.Harmonic.__call__ (what tf.GradientTape computes through
+# ddsp/synths.py:94-146, trainers.py:162-171).  fp64 only: it is the truth
+# the HIP gradients are compared with, itself checked against finite differences in tests/.
+# ----------------------------------------------------------------------------
+def exp_sigmoid_grad(x, exponent=10.0, max_value=2.0, threshold=1e-7):
+  """d/dx of core.exp_sigmoid: log(exponent) * (y - threshold) * (1 - sigmoid(x))."""
+  x = as_float(x, np.float64)
+  y = exp_sigmoid(x, exponent, max_value, threshold, dtype=np.float64)
+  return np.log(exponent) * (y - threshold) * (1.0 - sigmoid(x))
+
+
+def harmonic_backward(amplitudes, harmonic_distribution, f0_hz, grad_audio, n_samples=64000,
+                      sample_rate=16000, scale_fn=exp_sigmoid, normalize_below_nyquist=True,
+                      amp_resample_method='window'):
+  """(dL/d amplitudes [B,F,1], dL/d harmonic_distribution [B,F,K]) given dL/d audio [B,N].
+
+  f0_hz is treated as a constant (its gradient is not built).  The masks (>= Nyquist) have zero
+  gradient, as tf.where gives them.
+  """
+  amps_raw = as_float(amplitudes, np.float64)
+  hd_raw = as_float(harmonic_distribution, np.float64)
+  f0 = as_float(f0_hz, np.float64)
+  g = as_float(grad_audio, np.float64)
+  b, f, k = hd_raw.shape
+  # ---- forward pieces ----
+  amp_s = scale_fn(amps_raw, dtype=np.float64) if scale_fn is not None else amps_raw
+  x = scale_fn(hd_raw, dtype=np.float64) if scale_fn is not None else hd_raw
+  if normalize_below_nyquist:
+    live = get_harmonic_frequencies(f0, k) < sample_rate / 2.0
+    x = np.where(live, x, 0.0)
+  else:
+    live = np.ones_like(x, bool)
+  den = np.sum(x, axis=-1, keepdims=True)
+  den_safe = np.where(den == 0.0, 1e-7, den)
+  hdn = x / den_safe
+  # audio-rate pieces of harmonic_synthesis / oscillator_bank
+  freq_env = resample(get_harmonic_frequencies(f0, k), n_samples, dtype=np.float64)     # [B,N,K]
+  mask = freq_env < sample_rate / 2.0
+  phases = np.cumsum(freq_env * (TWO_PI / float(sample_rate)), axis=1)
+  gs = g[:, :, None] * np.where(mask, np.sin(phases), 0.0)                              # [B,N,K]
+  # the amplitude upsampling is linear in its input: U [N,F] from the identity
+  u = resample(np.eye(f)[None], n_samples, method=amp_resample_method, dtype=np.float64)[0]
+  grad_a = np.einsum('nf,bnk->bfk', u, gs)                                              # dL/d(amp*hdn)
+  # ---- frame-rate chain rule ----
+  d_amp_s = np.sum(grad_a * hdn, axis=-1, keepdims=True)
+  d_hdn = grad_a * amp_s
+  d_x = (d_hdn - np.sum(d_hdn * hdn, axis=-1, keepdims=True)) / den_safe
+  d_x = np.where(live & (den != 0.0), d_x, 0.0)
+  if scale_fn is not None:
+    return d_amp_s * exp_sigmoid_grad(amps_raw), d_x * exp_sigmoid_grad(hd_raw)
+  return d_amp_s, d_x
+
+
+# ----------------------------------------------------------------------------
 # losses.SpectralLoss  (ddsp/losses.py:100-243, ddsp/spectral_ops.py:34-70; SURVEY 8f rank 2)
 # ----------------------------------------------------------------------------
 def stft(audio, frame_size=2048, overlap=0.75, pad_end=True, dtype=np.float32):

@@ -685,3 +685,75 @@ def test_streaming_chunks_are_phase_continuous(ddsp):               # inference.
   # 40 calls with the phase carried through fp32: the drift stays far below audibility
   assert np.abs(got - ref).max() < 2e-3
   assert np.abs(got).max() > 0.2
+
+
+# ---- backward pass of Harmonic ----------------------------------------
+# GRAD  |ours - fp64 analytic gradient| <= 2e-4 * max|ref| + 1e-6   (fp32 sines, fp32 accumulation
+#       over one frame; the analytic oracle is itself checked against finite differences on CPU)
+def grad_tol(ref):
+  return 1e-6 + 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('batch,n_frames,k,hop,sr,f_lo,f_hi,method,scale,normalize', [
+    (2, 25, 12, 64, 16000, 300.0, 900.0, 'window', True, True),       # harmonics crossing Nyquist mid-frame
+    (2, 20, 100, 64, 16000, 69.0, 71.0, 'window', True, True),        # all 100 harmonics live
+    (1, 10, 40, 192, 48000, 200.0, 700.0, 'linear', True, True),      # hop 192, linear envelopes
+    (2, 16, 20, 64, 16000, 350.0, 600.0, 'window', False, False),     # scale_fn=None, no Nyquist normalisation
+    (1, 9, 200, 100, 16000, 30.0, 45.0, 'linear', True, True)])       # K=200 (4 wavefronts), hop 100
+def test_harmonic_backward_vs_analytic_oracle(ddsp, batch, n_frames, k, hop, sr, f_lo, f_hi, method, scale,
+                                              normalize):
+  rng = np.random.default_rng(batch * 1000 + k)
+  n = n_frames * hop
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
+  if not scale:
+    amps, hd = np.abs(amps) + 0.1, np.abs(hd) + 0.05
+  f0 = rng.uniform(f_lo, f_hi, (batch, n_frames, 1)).astype(np.float32)
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, scale_fn=ddsp.core.exp_sigmoid if scale else None,
+                               normalize_below_nyquist=normalize, amp_resample_method=method)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  audio = synth(ta, th, f0)
+  assert audio.requires_grad
+  (audio * ddsp.core.tf_float32(g)).sum().backward()
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid if scale else None, normalize, method)
+  np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=grad_tol(ga))
+  np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=grad_tol(gh))
+  # the forward value is the same with and without recording
+  np.testing.assert_array_equal(npy(audio), npy(synth(amps, hd, f0)))
+
+
+def test_harmonic_backward_full_size_properties(ddsp):
+  rng = np.random.default_rng(12)
+  b, f, k, n = 32, 1000, 100, 64000
+  amps = ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True)
+  hd = ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True)
+  f0 = ddsp.core.tf_float32(200 + rng.standard_normal((b, f, 1)))
+  synth = ddsp.synths.Harmonic(n_samples=n)
+  g1 = ddsp.core.tf_float32(rng.standard_normal((b, n)))
+  g2 = ddsp.core.tf_float32(rng.standard_normal((b, n)))
+  def grads(g):
+    amps.grad = hd.grad = None
+    (synth(amps, hd, f0) * g).sum().backward()
+    return amps.grad.clone(), hd.grad.clone()
+  a1, h1 = grads(g1)
+  a2, h2 = grads(g2)
+  a3, h3 = grads(0.5 * g1 - 2.0 * g2)                                # the backward map is linear in grad_audio
+  assert float((a3 - (0.5 * a1 - 2.0 * a2)).abs().max()) <= 1e-4 * float(a1.abs().max() + a2.abs().max())
+  assert float((h3 - (0.5 * h1 - 2.0 * h2)).abs().max()) <= 1e-4 * float(h1.abs().max() + h2.abs().max())
+  # harmonics at or above Nyquist (k * 200 Hz >= 8 kHz: k >= 40) get exactly zero gradient
+  assert float(h1[:, :, 45:].abs().max()) == 0.0
+  # directional derivative: <grad, d> ~ (L(x + eps d) - L(x - eps d)) / 2 eps, L = <audio, g1>
+  d = ddsp.core.tf_float32(rng.standard_normal((b, f, 1)))
+  with torch.no_grad():
+    eps = 1e-2
+    lp = float((synth(amps + eps * d, hd, f0) * g1).sum())
+    lm = float((synth(amps - eps * d, hd, f0) * g1).sum())
+  fd = (lp - lm) / (2 * eps)
+  an = float((a1 * d).sum())
+  assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0)
+  # first two clips against the fp64 analytic oracle
+  ga, gh = O.harmonic_backward(npy(amps[:2].detach()), npy(hd[:2].detach()), npy(f0[:2]), npy(g1[:2]), n, 16000)
+  np.testing.assert_allclose(npy(a1[:2]), ga, rtol=0, atol=grad_tol(ga))
+  np.testing.assert_allclose(npy(h1[:2]), gh, rtol=0, atol=grad_tol(gh))

@@ -252,3 +252,32 @@ def test_streaming_synthesis_matches_reference_source(name):
       int(g['n_samples']), int(g['sample_rate']), str(g['amp_method']), dtype=np.float64)
   assert np.abs(a64 - g['audio']).max() < 2e-3
   assert np.abs(p64 - g['final_phase']).max() < 5e-4      # the reference's own fp32 phase error
+
+
+# ---- backward pass of Harmonic: analytic fp64 vs finite differences ----
+@pytest.mark.parametrize('method,scale,normalize', [('window', True, True), ('linear', True, True),
+                                                     ('window', False, False)])
+def test_harmonic_backward_matches_finite_differences(method, scale, normalize):
+  rng = np.random.default_rng(3)
+  b, f, k, n, sr = 1, 5, 6, 40, 16000
+  amps = rng.standard_normal((b, f, 1))
+  hd = rng.standard_normal((b, f, k))
+  if not scale:
+    amps, hd = np.abs(amps) + 0.1, np.abs(hd) + 0.05
+  f0 = rng.uniform(900.0, 1500.0, (b, f, 1))                      # harmonics 6.. cross Nyquist: masks are exercised
+  g = rng.standard_normal((b, n))
+  scale_fn = O.exp_sigmoid if scale else None
+
+  def loss(a, h):
+    y = O.harmonic(a, h, f0, n, sr, scale_fn, normalize, method, dtype=np.float64)
+    return float(np.sum(y * g))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, scale_fn, normalize, method)
+  eps = 1e-6
+  for idx in [(0, 0, 0), (0, 2, 0), (0, 4, 0)]:
+    d = np.zeros_like(amps); d[idx] = eps
+    fd = (loss(amps + d, hd) - loss(amps - d, hd)) / (2 * eps)
+    np.testing.assert_allclose(ga[idx], fd, rtol=1e-5, atol=1e-8)
+  for idx in [(0, 0, 0), (0, 1, 3), (0, 3, 5), (0, 4, 2), (0, 2, 1)]:
+    d = np.zeros_like(hd); d[idx] = eps
+    fd = (loss(amps, hd + d) - loss(amps, hd - d)) / (2 * eps)
+    np.testing.assert_allclose(gh[idx], fd, rtol=1e-5, atol=1e-8)
