@@ -791,12 +791,12 @@ static int launch_controls(const float* amps, const float* hd, const float* f0, 
                            float* ctl_hd, void* workspace, int B, int F, int K, int N,
                            int sample_rate, unsigned flags, int inputs_are_controls,
                            hipStream_t st, const float* initial_phase = nullptr,
-                           float* final_phase = nullptr) {
+                           float* final_phase = nullptr, bool theta_only = false) {
   ControlsArgs p;
   p.B = B; p.F = F; p.K = K; p.Kp = round_up(K, 16);
   p.hop = workspace ? N / F : 1;
   const long rows = (long)B * F;
-  p.n_ctl_blocks = (int)((rows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave));
+  p.n_ctl_blocks = theta_only ? 0 : (int)((rows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave));   // theta_only: just the phase scan
   p.nyquist = (float)(sample_rate / 2.0);
   p.sample_rate = (float)sample_rate;
   p.flags = flags;
@@ -954,66 +954,89 @@ struct BwdArgs {
   int inputs_are_controls;
 };
 
+// A block takes `fb` consecutive frames of one row (fb * hop <= kBwdMaxHop samples staged at once):
+// 32000 two-wavefront blocks of one frame each were bound by the block launch rate.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void harm_bwd_pq_kernel(const float* __restrict__ f0_all,
                                                               const double* __restrict__ theta0,
                                                               const float* __restrict__ grad_audio,
                                                               float* __restrict__ pq /*[2][B*F][K]*/,
-                                                              size_t q_offset, BwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float4 sm[kBwdMaxHop];      // {theta, w_cur g, w_next g, lerp}
-  const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
+                                                              size_t q_offset, int fb, BwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float4 sm[];          // [fb * hop] {theta, w_cur g, w_next g, lerp}
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int j0 = blockIdx.x * fb, nfr = min(fb, p.F - j0);
   const float* __restrict__ f0 = f0_all + (size_t)b * p.F;
-  const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
   {
     const double inv_sr = 1.0 / (double)p.sample_rate, inv_2hop = 0.5 / (double)p.hop;
-    const double th0 = theta0[(size_t)b * p.F + j];
-    const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
     const float inv_hop = 1.0f / (float)p.hop;
-    const float* __restrict__ g = grad_audio + (size_t)b * p.N + (size_t)j * p.hop;
-    for (int r = tid; r < p.hop; r += 64 * NW) {
+    const float* __restrict__ g = grad_audio + (size_t)b * p.N + (size_t)j0 * p.hop;
+    for (int e = tid; e < nfr * p.hop; e += 64 * NW) {
+      const int q = e / p.hop, r = e - q * p.hop;
+      const int j = j0 + q;
+      const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
+      const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
       const double rr = (double)r;
-      const double cyc = th0 + (rr + 1.0) * (wj + dw * rr);
+      const double cyc = theta0[(size_t)b * p.F + j] + (rr + 1.0) * (wj + dw * rr);
       const float lerp = (float)r * inv_hop;
       const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
-      const float gv = g[r];
-      sm[r] = make_float4((float)(cyc - floor(cyc)), (1.0f - w_next) * gv, w_next * gv, lerp);
+      const float gv = g[e];
+      sm[e] = make_float4((float)(cyc - floor(cyc)), (1.0f - w_next) * gv, w_next * gv, lerp);
     }
   }
   __syncthreads();
-  const int k = tid;                                     // harmonic index (0-based)
-  const float kf = (float)(k + 1);
-  // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample (as harm_synth_kernel)
-  const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
-  int kA = p.K, kN = p.K;
-  if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
-  if (fmn > 0.0f) kN = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f + 2e-6f) / fmn));
-  kA = max(min(kA, kN), 0);
-  float P = 0.0f, Q = 0.0f;
-  if (kA == kN) {                                        // block-uniform: no harmonic crosses Nyquist in this frame
+  // every lane owns TWO harmonics, k0 = tid and k1 = tid + 64 NW: one broadcast read of the sample's
+  // values feeds both (with one harmonic per lane the LDS pipe, 8 clocks per 16-byte broadcast read,
+  // was the bound: 73 us at batch 32)
+  const int k0 = tid, k1 = tid + 64 * NW;
+  const float kf0 = (float)(k0 + 1), kf1 = (float)(k1 + 1);
+  for (int q = 0; q < nfr; ++q) {
+    const int j = j0 + q;
+    const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
+    // [0,kA): below Nyquist for every sample of the frame; [kA,kN): decided per sample (as harm_synth_kernel)
+    const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+    int kA = p.K, kN = p.K;
+    if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
+    if (fmn > 0.0f) kN = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f + 2e-6f) / fmn));
+    kA = max(min(kA, kN), 0);
+    const float4* __restrict__ sq = sm + q * p.hop;
+    float P0 = 0.0f, Q0 = 0.0f, P1 = 0.0f, Q1 = 0.0f;
+    const bool second = 64 * NW < kN;                    // block-uniform: any live harmonic in the upper half?
+    if (kA == kN) {                                      // block-uniform: no harmonic crosses Nyquist in this frame
+      if (second) {
 #pragma unroll 4
-    for (int r = 0; r < p.hop; ++r) {
-      const float4 v = sm[r];                            // same address for every lane: LDS broadcast
-      const float s = sin_rev(frac_phase(v.x, kf));
-      P = fmaf(v.y, s, P);
-      Q = fmaf(v.z, s, Q);
-    }
-    if (k >= kA) { P = 0.0f; Q = 0.0f; }
-  } else {
-    const float top = fj * kf, bot = fj1 * kf;
+        for (int r = 0; r < p.hop; ++r) {
+          const float4 v = sq[r];                        // same address for every lane: LDS broadcast
+          const float s0 = sin_rev(frac_phase(v.x, kf0)), s1 = sin_rev(frac_phase(v.x, kf1));
+          P0 = fmaf(v.y, s0, P0); Q0 = fmaf(v.z, s0, Q0);
+          P1 = fmaf(v.y, s1, P1); Q1 = fmaf(v.z, s1, Q1);
+        }
+      } else {
+#pragma unroll 4
+        for (int r = 0; r < p.hop; ++r) {
+          const float4 v = sq[r];
+          const float s0 = sin_rev(frac_phase(v.x, kf0));
+          P0 = fmaf(v.y, s0, P0); Q0 = fmaf(v.z, s0, Q0);
+        }
+      }
+      if (k0 >= kA) { P0 = 0.0f; Q0 = 0.0f; }
+      if (k1 >= kA) { P1 = 0.0f; Q1 = 0.0f; }
+    } else {
+      const float top0 = fj * kf0, bot0 = fj1 * kf0, top1 = fj * kf1, bot1 = fj1 * kf1;
 #pragma unroll 2
-    for (int r = 0; r < p.hop; ++r) {
-      const float4 v = sm[r];
-      // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
-      const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), v.w));
-      const float s = (fk >= p.nyquist || k >= kN) ? 0.0f : sin_rev(frac_phase(v.x, kf));
-      P = fmaf(v.y, s, P);
-      Q = fmaf(v.z, s, Q);
+      for (int r = 0; r < p.hop; ++r) {
+        const float4 v = sq[r];
+        // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
+        const float fk0 = __fadd_rn(top0, __fmul_rn(__fsub_rn(bot0, top0), v.w));
+        const float fk1 = __fadd_rn(top1, __fmul_rn(__fsub_rn(bot1, top1), v.w));
+        const float s0 = (fk0 >= p.nyquist || k0 >= kN) ? 0.0f : sin_rev(frac_phase(v.x, kf0));
+        const float s1 = (fk1 >= p.nyquist || k1 >= kN) ? 0.0f : sin_rev(frac_phase(v.x, kf1));
+        P0 = fmaf(v.y, s0, P0); Q0 = fmaf(v.z, s0, Q0);
+        P1 = fmaf(v.y, s1, P1); Q1 = fmaf(v.z, s1, Q1);
+      }
     }
-  }
-  if (k < p.K) {
-    const size_t at = ((size_t)b * p.F + j) * p.K + k;
-    pq[at] = P;
-    pq[q_offset + at] = Q;
+    const size_t at = ((size_t)b * p.F + j) * p.K;
+    if (k0 < p.K) { pq[at + k0] = P0; pq[q_offset + at + k0] = Q0; }
+    if (k1 < p.K) { pq[at + k1] = P1; pq[q_offset + at + k1] = Q1; }
   }
 }
 
@@ -1113,9 +1136,9 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   if (workspace_bytes < ddsp_harmonic_backward_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  // the fp64 phase prefix theta0[B,F] (and, unused here, the amplitude rows) of the generic path
+  // the fp64 phase prefix theta0[B,F] of the generic path (its scan blocks only)
   rc = launch_controls(amplitudes, hd, f0_hz, nullptr, nullptr, workspace, B, F, K, N, sample_rate,
-                       flags, inputs_are_controls, st);
+                       flags, inputs_are_controls, st, nullptr, nullptr, /*theta_only=*/true);
   if (rc != DDSP_OK) return rc;
   const size_t fwd = (ddsp_harmonic_workspace_bytes(B, F, K, N) + 63) & ~(size_t)63;
   float* pq = (float*)((char*)workspace + fwd);
@@ -1128,10 +1151,11 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   const double* theta0 = (const double*)workspace;
   {
     ProfileScope prof(kHarmBwdPq, st);
-    const dim3 grid((unsigned)F, (unsigned)B);
-    if (K <= 64) hipLaunchKernelGGL((harm_bwd_pq_kernel<1>), grid, dim3(64), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
-    else if (K <= 128) hipLaunchKernelGGL((harm_bwd_pq_kernel<2>), grid, dim3(128), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
-    else hipLaunchKernelGGL((harm_bwd_pq_kernel<4>), grid, dim3(256), 0, st, f0_hz, theta0, grad_audio, pq, q_offset, p);
+    const int fb = max(1, min(8, kBwdMaxHop / p.hop));           // frames per block
+    const dim3 grid((unsigned)((F + fb - 1) / fb), (unsigned)B);
+    const size_t lds = (size_t)fb * p.hop * sizeof(float4);      // 8 KB at hop 64: the occupancy is not LDS-limited
+    if (K <= 128) hipLaunchKernelGGL((harm_bwd_pq_kernel<1>), grid, dim3(64), lds, st, f0_hz, theta0, grad_audio, pq, q_offset, fb, p);
+    else hipLaunchKernelGGL((harm_bwd_pq_kernel<2>), grid, dim3(128), lds, st, f0_hz, theta0, grad_audio, pq, q_offset, fb, p);
   }
   {
     ProfileScope prof(kHarmBwdChain, st);
