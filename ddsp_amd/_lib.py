@@ -30,6 +30,9 @@ SIGNATURES = {
     'ddsp_filtered_noise_workspace_bytes': (c_size_t, [c_int] * 5),
     'ddsp_filtered_noise_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
                                 [c_float, c_uint, c_u64, c_u64, c_voidp]),
+    'ddsp_filtered_noise_backward_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ddsp_filtered_noise_backward_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                         [c_float, c_uint, c_u64, c_u64, c_voidp]),
     'ddsp_fft_convolve_same_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
     'ddsp_harmonic_backward_workspace_bytes': (c_size_t, [c_int] * 4),
     'ddsp_harmonic_backward_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 5 +

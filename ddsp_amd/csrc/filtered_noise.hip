@@ -870,6 +870,165 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
                     batch_offset, st);
 }
 
+// =====================================================================================
+// Backward pass of FilteredNoise.__call__ for the fused shape (M = 65, full window, L = 128):
+// dL/d(magnitudes) from dL/d(audio).  The output is linear in every frame's taps,
+//     dL/dh_f[t] = sum_{i in frame f} x[i] gz[i + t],   gz[m] = dL/d audio[m - start],
+// the taps are linear in the scaled magnitudes (the transpose of the cosine transform of the
+// forward IR design), and only exp_sigmoid is not linear.  The noise x is regenerated by the same
+// Philox counter/key as in the forward call (or read from the tensor the caller supplied).
+//   noise_bwd_taps_kernel  one wavefront per frame, lanes = taps t and t+64; the frame's samples are
+//                          held one per lane and broadcast with v_readlane, the gradient window
+//                          slides through an LDS tile.
+//   noise_bwd_mags_kernel  one wavefront per frame: folds the 128 tap gradients onto the 33 even /
+//                          32 odd partial sums, applies the transposed cosine table and exp_sigmoid'.
+// =====================================================================================
+namespace ddsp {
+
+struct NoiseBwdArgs {
+  int N, F, fs, start, tile_frames, scale;
+  float bias;
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+};
+
+__global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __restrict__ x /*[B,N] or null*/,
+                                                             const float* __restrict__ grad_audio,
+                                                             float* __restrict__ dh /*[B,F,128]*/,
+                                                             NoiseBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float s_g[];        // gz[f0*fs .. (f0+tile)*fs + 128)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * p.tile_frames;
+  const int nfr = min(p.tile_frames, p.F - f0);
+  const int span = nfr * p.fs + 128;
+  const float* __restrict__ g = grad_audio + (size_t)b * p.N;
+  for (int e = tid; e < span + 64; e += 256) {             // + 64 zeros: the last 64-sample chunk of a frame
+    const int n = f0 * p.fs + e - p.start;                 // whose size is not a multiple of 64 reads past the span
+    s_g[e] = (e < span && n >= 0 && n < p.N) ? g[n] : 0.0f;   // gz[m] = g[m - start]
+  }
+  __syncthreads();
+  for (int q = wave; q < nfr; q += 4) {
+    const int f = f0 + q;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int c = 0; c < p.fs; c += 64) {                   // 64 samples of the frame per chunk
+      const int i = f * p.fs + c + lane;                   // this lane's sample
+      float xv = 0.0f;
+      if (c + lane < p.fs && i < p.N)
+        xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1);
+      const float* __restrict__ win = s_g + q * p.fs + c + lane;      // + l: gz[i_l + t], t = lane
+#pragma unroll
+      for (int l = 0; l < 64; ++l) {
+        const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l));
+        acc0 = fmaf(xs, win[l], acc0);
+        acc1 = fmaf(xs, win[l + 64], acc1);
+      }
+    }
+    float* __restrict__ o = dh + ((size_t)b * p.F + f) * 128;
+    o[lane] = acc0;
+    o[lane + 64] = acc1;
+  }
+}
+
+constexpr int kBwdMagRows = 16;        // rows (frames) per block: the cosine table is staged in LDS once per block
+
+__global__ __launch_bounds__(256) void noise_bwd_mags_kernel(const float* __restrict__ mag /*[B,F,65]*/,
+                                                             const float* __restrict__ dh /*[B*F,128]*/,
+                                                             float* __restrict__ grad_mag, long rows,
+                                                             NoiseBwdArgs p) {
+  __shared__ float s_tab[33 * kIrRowStride];                 // kIr65.c: per-lane column reads are LDS reads, not 33 scattered loads
+  __shared__ float s_eo[4][80];                              // per wavefront: d_e[0..32] at 0, d_o[0..32] at 40
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 33 * kIrRowStride; e += 256) s_tab[e] = kIr65.c[e];
+  __syncthreads();
+  const long row_end = min(rows, ((long)blockIdx.x + 1) * kBwdMagRows);
+  for (long row = (long)blockIdx.x * kBwdMagRows + wave; row < row_end; row += 4) {
+    const float* __restrict__ d = dh + (size_t)row * 128;
+    if (lane <= 32) {
+      const int n = lane;
+      // forward: g0[n] = win[n] (e+o) -> taps 64+n and 64-n;  g1[n] = win[64-n] (e-o) -> taps 128-n and n
+      // (1 <= n < 32);  tap 0 is the constant 0
+      const float dg0 = d[64 + n] + (n >= 1 ? d[64 - n] : 0.0f);
+      const float dg1 = (n >= 1 && n < 32) ? d[128 - n] + d[n] : 0.0f;
+      const float w0 = kIr65.win[n] * dg0;
+      const float w1 = (n >= 1 && n < 32) ? kIr65.win[64 - n] * dg1 : 0.0f;
+      s_eo[wave][n] = w0 + w1;
+      s_eo[wave][40 + n] = w0 - w1;
+    }
+    __builtin_amdgcn_s_waitcnt(0);                           // this wavefront's LDS writes (in order per wave)
+    __builtin_amdgcn_wave_barrier();
+    for (int m = lane; m < 65; m += 64) {                    // magnitude bin (lane 0 also takes bin 64)
+      const int i = m >> 1, odd = m & 1;
+      const float* __restrict__ tab = s_tab + (odd ? 40 + i : i);
+      const float* __restrict__ src = &s_eo[wave][odd ? 40 : 0];
+      float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 32; n += 2) {
+        acc0 = fmaf(tab[n * kIrRowStride], src[n], acc0);
+        acc1 = fmaf(tab[(n + 1) * kIrRowStride], src[n + 1], acc1);
+      }
+      float acc = fmaf(tab[32 * kIrRowStride], src[32], acc0 + acc1);
+      const size_t at = (size_t)row * 65 + m;
+      if (p.scale) {
+        const float xr = mag[at] + p.bias;
+        const float y = exp_sigmoid_fast(xr, 2.302585092994046f, 2.0f, 1e-7f);
+        acc *= 2.302585092994046f * (y - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-xr)));
+      }
+      grad_mag[at] = acc;
+    }
+    __builtin_amdgcn_s_waitcnt(0);                           // s_eo is rewritten by the next row of this wavefront
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace ddsp
+
+extern "C" size_t ddsp_filtered_noise_backward_workspace_bytes(int B, int F, int M, int N) {
+  (void)N;
+  if (B <= 0 || F <= 0 || M != 65) return 0;
+  return (size_t)B * F * 128 * sizeof(float);
+}
+
+extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const float* noise,
+                                                const float* grad_audio, float* grad_magnitudes,
+                                                void* workspace, size_t workspace_bytes, int B,
+                                                int F, int M, int N, int window_size,
+                                                float initial_bias, unsigned flags, uint64_t seed,
+                                                uint64_t batch_offset, void* stream) {
+  if (!magnitudes || !grad_audio || !grad_magnitudes || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || M < 2 || N <= 0) return DDSP_ERR_BAD_SHAPE;
+  const IrGeom g = ir_geom(M, window_size);
+  const int fs = (N + F - 1) / F;
+  if (M != 65 || g.padding != 0 || g.L != 128 || fs < 64 || (fs % 16) != 0 || fs > 4096 ||
+      (N + fs - 1) / fs != F || B > 65535)
+    return DDSP_ERR_UNSUPPORTED;                            // the shapes the fused forward kernel takes
+  if (workspace_bytes < ddsp_filtered_noise_backward_workspace_bytes(B, F, M, N) ||
+      ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  NoiseBwdArgs p;
+  p.N = N; p.F = F; p.fs = fs; p.start = (g.L - 1) / 2 - 1;
+  p.tile_frames = fs <= 512 ? 8192 / fs : 1;                // <= 8192 + 128 gradient samples staged per block
+  if (p.tile_frames > 32) p.tile_frames = 32;
+  p.scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
+  p.bias = initial_bias;
+  p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.batch_offset = batch_offset;
+  float* dh = (float*)workspace;
+  {
+    ProfileScope prof(kNoiseBwdTaps, st);
+    const dim3 grid((unsigned)((F + p.tile_frames - 1) / p.tile_frames), (unsigned)B);
+    const size_t lds = ((size_t)p.tile_frames * fs + 128 + 64) * sizeof(float);
+    hipLaunchKernelGGL(noise_bwd_taps_kernel, grid, dim3(256), lds, st, noise, grad_audio, dh, p);
+  }
+  {
+    ProfileScope prof(kNoiseBwdMags, st);
+    const long rows = (long)B * F;
+    hipLaunchKernelGGL(noise_bwd_mags_kernel, dim3((unsigned)((rows + kBwdMagRows - 1) / kBwdMagRows)), dim3(256), 0, st,
+                       magnitudes, (const float*)dh, grad_magnitudes, rows, p);
+  }
+  return check_launch();
+}
+
 extern "C" int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed,
                                       uint64_t batch_offset, void* stream) {
   if (!out) return DDSP_ERR_NULL_POINTER;

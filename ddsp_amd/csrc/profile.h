@@ -23,6 +23,8 @@ enum KernelId {
   kStftL1,
   kHarmBwdPq,
   kHarmBwdChain,
+  kNoiseBwdTaps,
+  kNoiseBwdMags,
   kNumKernels
 };
 

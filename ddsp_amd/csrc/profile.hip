@@ -17,7 +17,8 @@ const char* const kNames[kNumKernels] = {
     "harm_controls_kernel", "harm_synth_kernel", "noise_controls_kernel", "noise_ir_kernel",
     "tv_fir_kernel", "uniform_noise_kernel", "add_kernel", "exp_sigmoid_kernel",
     "harm_fused_kernel", "noise_fused65_kernel", "rv_fft_kernel", "rv_mac_kernel",
-    "rv_ifft_kernel", "stft_l1_kernel", "harm_bwd_pq_kernel", "harm_bwd_chain_kernel"};
+    "rv_ifft_kernel", "stft_l1_kernel", "harm_bwd_pq_kernel", "harm_bwd_chain_kernel",
+    "noise_bwd_taps_kernel", "noise_bwd_mags_kernel"};
 }  // namespace
 
 void profile_record(int kernel_id, hipStream_t st, bool start) {

@@ -177,6 +177,7 @@ class FilteredNoise(processors.Processor):
     self.seed = int(seed)
     self._calls = 0
     self._ws = core.Workspace()
+    self._ws_bwd = core.Workspace()
 
   def get_controls(self, magnitudes):
     """Network outputs -> {'magnitudes'} (synths.py:165-179)."""
@@ -234,12 +235,24 @@ class FilteredNoise(processors.Processor):
     return audio
 
   def call(self, magnitudes, return_outputs_dict=False, noise=None, **kwargs):
-    """get_signal(**get_controls(magnitudes)) as one fused C-ABI call."""
+    """get_signal(**get_controls(magnitudes)) as one fused C-ABI call.
+
+    When `magnitudes` requires grad the call is recorded for torch.autograd (shapes of the fused
+    kernel only: 65 bands, window_size 0 or >= 128); backward() regenerates the same noise.
+    """
     for k in ['training', 'mask']:
       kwargs.pop(k, None)
     if kwargs:
       raise TypeError('unexpected keyword arguments: {}'.format(sorted(kwargs)))
     if self.scale_fn is None or self.scale_fn is core.exp_sigmoid:
+      mt = core.tf_float32(magnitudes)
+      if torch.is_grad_enabled() and mt.requires_grad:
+        audio = _FilteredNoiseFunction.apply(mt, self, noise)
+        if not return_outputs_dict:
+          return audio
+        with torch.no_grad():
+          ctl = self.get_controls(mt.detach())['magnitudes']
+        return dict(signal=audio, controls={'magnitudes': ctl})
       audio, ctl = self._run(magnitudes, noise, fuse_scale=self.scale_fn is not None,
                              want_controls=return_outputs_dict)
       if return_outputs_dict and self.scale_fn is None:
@@ -250,3 +263,44 @@ class FilteredNoise(processors.Processor):
     if return_outputs_dict:
       return dict(signal=audio, controls={'magnitudes': ctl})
     return audio
+
+  def _backward(self, magnitudes, noise, seed, grad_audio):
+    b, f, m = magnitudes.shape
+    n = int(self.n_samples)
+    lib = _lib.load()
+    nbytes = core.cached_workspace_bytes('ddsp_filtered_noise_backward_workspace_bytes', b, f, m, n)
+    if nbytes == 0:
+      raise NotImplementedError('FilteredNoise backward is built for 65 noise bands only, got {}'.format(m))
+    ws = self._ws_bwd.get(nbytes, magnitudes.device)
+    grad_audio = core.tf_float32(grad_audio)
+    grad_mag = torch.empty_like(magnitudes)
+    rc = lib.ddsp_filtered_noise_backward_f32(
+        magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
+        grad_audio.data_ptr(), grad_mag.data_ptr(), ws.data_ptr(), ws.numel(), b, f, m, n,
+        int(self.window_size), float(self.initial_bias),
+        _lib.NOISE_SCALE_EXP_SIGMOID if self.scale_fn is not None else 0, seed, 0, core._stream())
+    if rc == -3:
+      raise NotImplementedError('FilteredNoise backward is built for the shapes of the fused kernel '
+                                '(65 bands, full window, frame size a multiple of 16 >= 64)')
+    _lib.check(rc, 'ddsp_filtered_noise_backward_f32')
+    return grad_mag
+
+
+class _FilteredNoiseFunction(torch.autograd.Function):
+  """torch.autograd node of FilteredNoise.__call__ (plumbing: both directions are C-ABI calls)."""
+
+  @staticmethod
+  def forward(ctx, magnitudes, synth, noise):
+    if noise is not None:
+      noise = core.tf_float32(noise)
+    ctx.seed = (synth.seed & 0xFFFFFFFF) | ((synth._calls & 0xFFFFFFFF) << 32)   # what _run is about to use
+    audio, _ = synth._run(magnitudes.detach(), noise, fuse_scale=synth.scale_fn is not None,
+                          want_controls=False)
+    ctx.save_for_backward(magnitudes)
+    ctx.synth, ctx.noise = synth, noise
+    return audio
+
+  @staticmethod
+  def backward(ctx, grad_audio):
+    (magnitudes,) = ctx.saved_tensors
+    return ctx.synth._backward(magnitudes.detach(), ctx.noise, ctx.seed, grad_audio), None, None

@@ -182,6 +182,20 @@ int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* 
                             void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Backward pass of ddsp_filtered_noise_f32: dL/d magnitudes [B,F,M] from grad_audio [B,N]
+ * (the gradient tf.GradientTape forms through ddsp/synths.py:165-196).  `noise` as in the forward
+ * call: the tensor that was supplied, or NULL with the same seed / batch_offset so that the noise is
+ * regenerated.  Only the shapes of the fused forward kernel (M = 65, full window) are built:
+ * others return DDSP_ERR_UNSUPPORTED.  workspace: ddsp_filtered_noise_backward_workspace_bytes.
+ */
+size_t ddsp_filtered_noise_backward_workspace_bytes(int B, int F, int M, int N);
+int ddsp_filtered_noise_backward_f32(const float* magnitudes, const float* noise,
+                                     const float* grad_audio, float* grad_magnitudes,
+                                     void* workspace, size_t workspace_bytes, int B, int F, int M,
+                                     int N, int window_size, float initial_bias, unsigned flags,
+                                     uint64_t seed, uint64_t batch_offset, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * core.fft_convolve(audio, impulse_response, padding='same', delay_compensation)
  * (ddsp/core.py:1382-1473) evaluated as the equivalent direct time-varying FIR.
  *   audio [B,N], impulse_response [Bir,F,L] with Bir == B or Bir == 1 (broadcast,

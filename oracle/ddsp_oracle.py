@@ -608,6 +608,39 @@ def harmonic_backward(amplitudes, harmonic_distribution, f0_hz, grad_audio, n_sa
   return d_amp_s, d_x
 
 
+def filtered_noise_backward(magnitudes, noise, grad_audio, window_size=257, scale_fn=exp_sigmoid,
+                            initial_bias=-5.0):
+  """dL/d magnitudes [B,F,M] of filtered_noise() given dL/d audio [B,N] (fp64 truth).
+
+  out is linear in the impulse responses (fft_convolve = time-varying FIR) and the
+  impulse response of a frame is linear in its magnitudes; only exp_sigmoid is not.
+  """
+  mags_raw = as_float(magnitudes, np.float64)
+  x = as_float(noise, np.float64)
+  g = as_float(grad_audio, np.float64)
+  b, f, m = mags_raw.shape
+  n = x.shape[1]
+  ctl = scale_fn(mags_raw + initial_bias, dtype=np.float64) if scale_fn is not None else mags_raw
+  # A [L, M]: the (windowed, causal) impulse response of each unit magnitude
+  a = frequency_impulse_response(np.eye(m)[None], window_size=window_size, dtype=np.float64)[0].T
+  l = a.shape[0]
+  frame_size = int(np.ceil(n / f))
+  start = (l - 1) // 2 - 1
+  gz = np.zeros((b, f * frame_size + l + start))
+  gz[:, start:start + n] = g                              # out[n] = z[n + start]
+  xp = np.zeros((b, f * frame_size))
+  xp[:, :n] = x
+  d_ir = np.zeros((b, f, l))
+  for fr in range(f):
+    for i in range(frame_size):
+      p0 = fr * frame_size + i
+      d_ir[:, fr, :] += xp[:, p0:p0 + 1] * gz[:, p0:p0 + l]
+  d_ctl = d_ir @ a                                        # [B,F,L] x [L,M]
+  if scale_fn is not None:
+    return d_ctl * exp_sigmoid_grad(mags_raw + initial_bias)
+  return d_ctl
+
+
 # ----------------------------------------------------------------------------
 # losses.SpectralLoss  (ddsp/losses.py:100-243, ddsp/spectral_ops.py:34-70; SURVEY 8f rank 2)
 # ----------------------------------------------------------------------------

@@ -757,3 +757,55 @@ def test_harmonic_backward_full_size_properties(ddsp):
   ga, gh = O.harmonic_backward(npy(amps[:2].detach()), npy(hd[:2].detach()), npy(f0[:2]), npy(g1[:2]), n, 16000)
   np.testing.assert_allclose(npy(a1[:2]), ga, rtol=0, atol=grad_tol(ga))
   np.testing.assert_allclose(npy(h1[:2]), gh, rtol=0, atol=grad_tol(gh))
+
+
+@pytest.mark.parametrize('batch,n_frames,n,scale,given_noise', [
+    (2, 25, 1600, True, True),          # hop 64, noise supplied
+    (2, 40, 2560 - 17, True, False),    # ragged tail, noise regenerated on chip by the same Philox counters
+    (1, 50, 50 * 192 - 5, True, False), # frame size 192
+    (2, 30, 30 * 80, False, True),      # frame size 80 (not a multiple of 64), scale_fn=None
+    (3, 130, 130 * 64, True, False)])   # several blocks per row
+def test_filtered_noise_backward_vs_analytic_oracle(ddsp, batch, n_frames, n, scale, given_noise):
+  rng = np.random.default_rng(n_frames)
+  mags = (rng.standard_normal((batch, n_frames, 65)) + (4.0 if scale else 0.0)).astype(np.float32)
+  if not scale:
+    mags = np.abs(mags)
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, scale_fn=ddsp.core.exp_sigmoid if scale else None,
+                                    seed=11)
+  if given_noise:
+    noise = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+  else:
+    noise = O.device_uniform_noise(batch, n, seed=11)        # call counter 0: the first call of this synth
+  tm = ddsp.core.tf_float32(mags).requires_grad_(True)
+  audio = synth(tm, noise=noise if given_noise else None)
+  (audio * ddsp.core.tf_float32(g)).sum().backward()
+  ref = O.filtered_noise_backward(mags, noise, g, 0, O.exp_sigmoid if scale else None)
+  np.testing.assert_allclose(npy(tm.grad), ref, rtol=0, atol=1e-6 + 2e-5 * np.abs(ref).max())
+  np.testing.assert_allclose(npy(audio), O.filtered_noise(mags, noise, 0, O.exp_sigmoid if scale else None,
+                                                          dtype=np.float64), rtol=0, atol=2e-6 + 1e-5)
+
+
+def test_synth_backward_through_add_and_unsupported_shapes(ddsp):
+  rng = np.random.default_rng(4)
+  b, f, k, n = 2, 50, 60, 3200
+  amps = ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True)
+  hd = ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True)
+  mags = ddsp.core.tf_float32(rng.standard_normal((b, f, 65))).requires_grad_(True)
+  f0 = 200 + rng.standard_normal((b, f, 1))
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
+  y = harm(amps, hd, f0) + noise(mags)                       # torch's own add: plumbing
+  target = ddsp.core.tf_float32(rng.standard_normal((b, n)))
+  loss = ((y - target) ** 2).mean()
+  loss.backward()
+  for t in (amps, hd, mags):
+    assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+  # a gradient step along -grad lowers the loss
+  with torch.no_grad():
+    noise2 = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)     # same seed / call counter as `noise` had
+    y2 = harm(amps - 50.0 * amps.grad, hd - 50.0 * hd.grad, f0) + noise2(mags - 50.0 * mags.grad)
+    assert float(((y2 - target) ** 2).mean()) < float(loss)
+  with pytest.raises(NotImplementedError):
+    m33 = ddsp.core.tf_float32(rng.standard_normal((b, f, 33))).requires_grad_(True)
+    ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(m33).sum().backward()

@@ -281,3 +281,22 @@ def test_harmonic_backward_matches_finite_differences(method, scale, normalize):
     d = np.zeros_like(hd); d[idx] = eps
     fd = (loss(amps, hd + d) - loss(amps, hd - d)) / (2 * eps)
     np.testing.assert_allclose(gh[idx], fd, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('m,window_size,n_frames,n,scale', [(9, 0, 4, 64, True), (65, 0, 3, 192, True),
+                                                             (9, 5, 4, 50, False)])
+def test_filtered_noise_backward_matches_finite_differences(m, window_size, n_frames, n, scale):
+  rng = np.random.default_rng(5)
+  mags = rng.standard_normal((2, n_frames, m)) + (4.0 if scale else 0.0)
+  noise = rng.uniform(-1, 1, (2, n))
+  g = rng.standard_normal((2, n))
+  scale_fn = O.exp_sigmoid if scale else None
+
+  def loss(mm):
+    return float(np.sum(O.filtered_noise(mm, noise, window_size, scale_fn, dtype=np.float64) * g))
+  gm = O.filtered_noise_backward(mags, noise, g, window_size, scale_fn)
+  eps = 1e-6
+  for idx in [(0, 0, 0), (1, n_frames - 1, m - 1), (0, 1, m // 2), (1, 2, 1)]:
+    d = np.zeros_like(mags); d[idx] = eps
+    fd = (loss(mags + d) - loss(mags - d)) / (2 * eps)
+    np.testing.assert_allclose(gm[idx], fd, rtol=2e-5, atol=1e-9)
