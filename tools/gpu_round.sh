@@ -21,3 +21,9 @@ ls -R $OUT/prof | head -20
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -2); do echo "--- $f"; head -15 $f; done
 echo "== torchrun world=1 sanity (the N>1 code path of bench.py)"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-300
+echo "== next-row benches (Reverb, SpectralLoss, backward)"
+timeout 300 python tools/bench_reverb.py 32 2>&1 | tail -1 | tee $OUT/bench_reverb_b32.json
+timeout 300 python tools/bench_reverb.py 128 2>&1 | tail -1 | tee $OUT/bench_reverb_b128.json
+timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json
+timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json
+timeout 300 python tools/bench_backward.py 128 2>&1 | tail -1 | tee $OUT/bench_backward_b128.json
