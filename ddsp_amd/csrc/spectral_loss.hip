@@ -3,10 +3,11 @@
 // over [batch, frames, S/2+1] - spectral_ops.compute_mag / stft (ddsp/spectral_ops.py:34-47, 67-70),
 // tf.signal.stft semantics: frames of S samples every S/4, zero pad_end, periodic Hann, rfft(S).
 //
-// One launch per FFT size.  A block holds G = 2048/S frames of the target and the same G frames of
-// the audio in LDS and runs one in-place radix-2 decimation-in-frequency FFT over all of them; bin
-// k sits at its bit-reversed position (one v_bfrev), magnitudes are compared on the fly and never
-// touch HBM.  The two signals are NOT packed into the real and imaginary parts of one transform:
+// One launch per FFT size.  A block holds G = 4096/S frames of the target and the same G frames of
+// the audio in LDS, each as the S/2-point complex sequence of its even / odd samples, and runs one
+// in-place radix-2 decimation-in-frequency FFT over all of them; the real spectrum is untangled
+// from bins k and S/2-k (at their bit-reversed positions, one v_bfrev each), magnitudes are
+// compared on the fly and never touch HBM.  The two signals are NOT packed into the real and imaginary parts of one transform:
 // rounding would leak ~1e-7 of one signal into the other, and core.safe_log treats exact zeros
 // (silent stretches of generated audio) differently from tiny values.  Per-block partial sums (fp64) go to the workspace; a one-block kernel adds them in a fixed
 // order, so the loss is deterministic.  HBM traffic: each sample is read 4 times per size (75 %
@@ -20,15 +21,19 @@
 namespace ddsp {
 
 constexpr int kSlPoints = 4096;        // complex points per block (32 KB of LDS)
-constexpr int kSlThreads = 256;
+constexpr int kSlThreads = 1024;      // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
 
 template <int S>
 __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target,
                                                              const float* __restrict__ audio,
                                                              double* __restrict__ partial, int N,
                                                              int n_frames, float safe_eps) {
-  constexpr int G = kSlPoints / 2 / S;  // frames per block (of each signal)
-  constexpr int LOG2S = __builtin_ctz(S);
+  // A real frame x[0..S) is transformed as the complex sequence z[n] = x[2n] + i x[2n+1] of H = S/2
+  // points; X[k] = E[k] + exp(-2 pi i k / S) O[k] with E, O untangled from Z[k] and Z[H-k].  An
+  // all-zero frame still gives exact zeros (nothing of another frame or signal is mixed in).
+  constexpr int H = S / 2;
+  constexpr int G = kSlPoints / 2 / H;  // frames per block (of each signal)
+  constexpr int LOG2H = __builtin_ctz(H);
   constexpr int HOP = S / 4;
   __shared__ __attribute__((aligned(16))) float2 s[kSlPoints];
   __shared__ double red[2][kSlThreads / 64];
@@ -38,29 +43,32 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   const float* __restrict__ arow = audio + (size_t)b * N;
   // ---- frames -> LDS, windowed: w[i] = 0.5 - 0.5 cos(2 pi i / S) (tf.signal.hann_window, periodic)
   for (int e = tid; e < kSlPoints; e += kSlThreads) {
-    const int g2 = e >> LOG2S, i = e & (S - 1);               // g2 < G: target frame, else audio frame
+    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;       // g2 < G: target frame, else audio frame
     const int g = g2 >= G ? g2 - G : g2;
-    const int n = (f0 + g) * HOP + i;
-    float v = 0.0f;
+    const int n = (f0 + g) * HOP + n2;
+    float2 v = make_float2(0.f, 0.f);
     if (f0 + g < n_frames && n < N) {
-      const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)S));
-      v = (g2 >= G ? arow[n] : trow[n]) * w;
+      const float* __restrict__ row = g2 >= G ? arow : trow;
+      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+      v.x = row[n] * w0;
+      if (n + 1 < N) v.y = row[n + 1] * w1;
     }
-    s[e] = make_float2(v, 0.0f);
+    s[e] = v;
   }
   __syncthreads();
-  // ---- radix-2 DIF FFT of every frame, in place; bins end up bit-reversed ----------------------
+  // ---- radix-2 DIF FFT (H points) of every frame, in place; bins end up bit-reversed ---------------
 #pragma unroll 1
-  for (int half = S / 2; half >= 1; half >>= 1) {
+  for (int half = H / 2; half >= 1; half >>= 1) {
     const float inv_len = 0.5f / (float)half;
     float2 va[kSlPoints / 2 / kSlThreads], vb[kSlPoints / 2 / kSlThreads];
     int idx[kSlPoints / 2 / kSlThreads];
 #pragma unroll
     for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
       const int t = tid + kSlThreads * u;                      // butterfly over the whole block
-      const int g = t >> (LOG2S - 1), r = t & (S / 2 - 1);   // g runs over the 2G frames of both signals
+      const int g = t >> (LOG2H - 1), r = t & (H / 2 - 1);     // g runs over the 2G frames of both signals
       const int pos = r & (half - 1);
-      idx[u] = (g << LOG2S) + ((r - pos) << 1) + pos;
+      idx[u] = (g << LOG2H) + ((r - pos) << 1) + pos;
       va[u] = s[idx[u]];
       vb[u] = s[idx[u] + half];
     }
@@ -80,17 +88,28 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
     }
     __syncthreads();
   }
-  // ---- magnitudes of bins 0 .. S/2, L1 terms -------------------------------------------------------
+  // ---- untangle, magnitudes of bins 0 .. S/2, L1 terms ---------------------------------------------
   float dm = 0.0f, dl = 0.0f;
-  for (int e = tid; e < G * (S / 2 + 1); e += kSlThreads) {
-    const int g = e / (S / 2 + 1), k = e - g * (S / 2 + 1);
+  for (int e = tid; e < G * (H + 1); e += kSlThreads) {
+    const int g = e / (H + 1), k = e - g * (H + 1);
     if (f0 + g < n_frames) {
-      const int at = (g << LOG2S) + (int)(__brev((unsigned)k) >> (32 - LOG2S));
-      const float2 zt = s[at], za = s[at + (G << LOG2S)];
-      const float mt = sqrtf(fmaf(zt.x, zt.x, zt.y * zt.y)), ma = sqrtf(fmaf(za.x, za.x, za.y * za.y));
-      dm += fabsf(mt - ma);
+      const int ia = (int)(__brev((unsigned)(k & (H - 1))) >> (32 - LOG2H));
+      const int ib = (int)(__brev((unsigned)((H - k) & (H - 1))) >> (32 - LOG2H));
+      const float rev = (float)k * (1.0f / (float)S);
+      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+      float mag[2];
+#pragma unroll
+      for (int sig = 0; sig < 2; ++sig) {
+        const int base = (g + sig * G) << LOG2H;
+        const float2 za = s[base + ia], zb = s[base + ib];
+        const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
+        const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
+        const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
+        mag[sig] = sqrtf(fmaf(xr, xr, xi * xi));
+      }
+      dm += fabsf(mag[0] - mag[1]);
       // core.safe_log (core.py:213-216): non-positive -> eps
-      dl += fabsf(__logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma <= 0.0f ? safe_eps : ma));
+      dl += fabsf(__logf(mag[0] <= 0.0f ? safe_eps : mag[0]) - __logf(mag[1] <= 0.0f ? safe_eps : mag[1]));
     }
   }
   const double sm = (double)wave_sum(dm), sl = (double)wave_sum(dl);
@@ -139,8 +158,8 @@ __global__ __launch_bounds__(256) void spectral_loss_finish_kernel(const double*
 }
 
 static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }
-static inline int sl_blocks(int N, int S) { const int g = kSlPoints / 2 / S; return (sl_frames(N, S) + g - 1) / g; }
-static inline bool sl_size_ok(int S) { return S >= 16 && S <= kSlPoints / 2 && (S & (S - 1)) == 0; }
+static inline int sl_blocks(int N, int S) { const int g = kSlPoints / S; return (sl_frames(N, S) + g - 1) / g; }
+static inline bool sl_size_ok(int S) { return S >= 16 && S <= kSlPoints && (S & (S - 1)) == 0; }
 
 }  // namespace ddsp
 
@@ -184,7 +203,7 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
                                                      target_audio, audio, dst, N, frames, 1e-5f); break
       switch (S) {
         DDSP_SL_CASE(16); DDSP_SL_CASE(32); DDSP_SL_CASE(64); DDSP_SL_CASE(128); DDSP_SL_CASE(256);
-        DDSP_SL_CASE(512); DDSP_SL_CASE(1024); DDSP_SL_CASE(2048);
+        DDSP_SL_CASE(512); DDSP_SL_CASE(1024); DDSP_SL_CASE(2048); DDSP_SL_CASE(4096);
         default: return DDSP_ERR_UNSUPPORTED;
       }
 #undef DDSP_SL_CASE

@@ -75,7 +75,7 @@ class SpectralLoss(Loss):
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
-      raise ValueError('fft_sizes must be at most 16 powers of two in [16, 2048], got {}'.format(
+      raise ValueError('fft_sizes must be at most 16 powers of two in [16, 4096], got {}'.format(
           tuple(self.fft_sizes)))
     ws = self._ws.get(nbytes, audio.device)
     loss = torch.empty((), dtype=torch.float32, device=audio.device)

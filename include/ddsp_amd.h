@@ -230,7 +230,7 @@ int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response
  *     *loss = sum over fft_sizes of  mag_weight * mean|mag_t - mag_a| + logmag_weight * mean|safe_log mag_t - safe_log mag_a|
  * with mag = |tf.signal.stft(frame_length=S, frame_step=S/4, pad_end=True)| (spectral_ops.py:34-47,
  * 67-70), safe_log per core.py:213-216.  target_audio, audio [B,N] and loss (one float) are device
- * pointers; fft_sizes is a HOST array of n_sizes (<= 16) powers of two in [16, 2048].
+ * pointers; fft_sizes is a HOST array of n_sizes (<= 16) powers of two in [16, 4096].
  * workspace: ddsp_spectral_loss_workspace_bytes(...) bytes (per-block fp64 partial sums; the
  * result does not depend on scheduling).
  */

@@ -191,7 +191,7 @@ def test_spectral_loss_host_contract():                            # losses.py:1
   import ctypes
   lib = _lib.load()
   sizes = (ctypes.c_int * 2)(2048, 64)
-  # per-block fp64 pairs: ceil(frames / (2048/S)) blocks per clip
-  assert lib.ddsp_spectral_loss_workspace_bytes(4, 64000, sizes, 2) == 4 * (125 + 125) * 16
+  # per-block fp64 pairs: ceil(frames / (4096/S)) blocks per clip
+  assert lib.ddsp_spectral_loss_workspace_bytes(4, 64000, sizes, 2) == 4 * (63 + 63) * 16
   bad = (ctypes.c_int * 1)(1000)
   assert lib.ddsp_spectral_loss_workspace_bytes(4, 64000, bad, 1) == 0
