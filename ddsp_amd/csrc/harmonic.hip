@@ -355,9 +355,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct PairState { f2 older, newer; };
 
 __device__ __forceinline__ f2 next_pair(PairState& st, float c4) {
+  const f2 sn = __builtin_elementwise_fma((f2){c4, c4}, st.newer, -st.older);   // one v_pk_fma_f32
+  st.older = st.newer; st.newer = sn;
+  return sn;
+}
+// the second pair of seeds {h+2, h+3} from the exact pair {h, h+1} by two steps of the stride-1
+// recurrence s[h+1] = 2cos(2 pi theta) s[h] - s[h-1]: two FMAs instead of two more v_sin_f32
+__device__ __forceinline__ f2 seed_pair_next(PairState& st, float c2) {
   f2 sn;
-  sn.x = fmaf(c4, st.newer.x, -st.older.x);
-  sn.y = fmaf(c4, st.newer.y, -st.older.y);
+  sn.x = fmaf(c2, st.newer.y, -st.newer.x);
+  sn.y = fmaf(c2, sn.x, -st.newer.y);
   st.older = st.newer; st.newer = sn;
   return sn;
 }
@@ -372,7 +379,7 @@ __device__ __forceinline__ f2 seed_pair(PairState& st, float theta, int h /* fir
 // 8 harmonics k+1 .. k+8 in two groups of 4; only the first n4 groups are live (wave-uniform).
 template <bool SEEDS>
 __device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k, int n4,
-                                         float theta, float c4, PairState& st, f2& accA, f2& accB) {
+                                         float theta, float c4, float c2, PairState& st, f2& accA, f2& accB) {
   sgpr8 a0, a1;
   sload_rows(a0, a1, p0 + k, p1 + k);
 #pragma unroll
@@ -380,7 +387,8 @@ __device__ __forceinline__ void harm_oct(const float* p0, const float* p1, int k
     if (g < n4) {
 #pragma unroll
       for (int i = 4 * g; i < 4 * g + 4; i += 2) {
-        const f2 sn = (SEEDS && g == 0) ? seed_pair(st, theta, k + i + 1) : next_pair(st, c4);
+        const f2 sn = (SEEDS && i == 0) ? seed_pair(st, theta, k + 1)
+                    : (SEEDS && i == 2) ? seed_pair_next(st, c2) : next_pair(st, c4);
         accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
         accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
       }
@@ -402,13 +410,14 @@ typedef float sgpr16 __attribute__((ext_vector_type(16)));
 // slots of the wave and of the CU's scalar unit)
 template <bool SEEDS, int OFF>
 __device__ __forceinline__ void harm_hex_full(const float* p0, const float* p1, int k, float theta,
-                                              float c4, PairState& st, f2& accA, f2& accB) {
+                                              float c4, float c2, PairState& st, f2& accA, f2& accB) {
   sgpr16 a0, a1;
   asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {
-    const f2 sn = (SEEDS && i < 4) ? seed_pair(st, theta, k + i + 1) : next_pair(st, c4);
+    const f2 sn = (SEEDS && i == 0) ? seed_pair(st, theta, k + 1)
+                : (SEEDS && i == 2) ? seed_pair_next(st, c2) : next_pair(st, c4);
     accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
     accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
   }
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       const float* a0p = wsu + q * Kp;
       const float* a1p = a0p + Kp;
       const float c4 = 2.0f * __builtin_amdgcn_cosf(theta + theta);   // 2 cos(4 pi theta)
+      const float c2 = 2.0f * __builtin_amdgcn_cosf(theta);           // 2 cos(2 pi theta): seeds only
       PairState st = {{0.f, 0.f}, {0.f, 0.f}};
       f2 accA = {0.f, 0.f}, accB = {0.f, 0.f};
       // every harmonic live (the common case): the whole row (zero padded to a multiple of 4);
@@ -645,14 +655,14 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
         const float* q0 = a0p;
         const float* q1 = a1p;
         for (; k + 64 <= kend; k += 64, q0 += 64, q1 += 64) {      // full super-blocks of 64: 4 seeds
-          harm_hex_full<true, 0>(q0, q1, k, theta, c4, st, accA, accB);
-          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, st, accA, accB);
-          harm_hex_full<false, 128>(q0, q1, k + 32, theta, c4, st, accA, accB);
-          harm_hex_full<false, 192>(q0, q1, k + 48, theta, c4, st, accA, accB);
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, c2, st, accA, accB);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, c2, st, accA, accB);
+          harm_hex_full<false, 128>(q0, q1, k + 32, theta, c4, c2, st, accA, accB);
+          harm_hex_full<false, 192>(q0, q1, k + 48, theta, c4, c2, st, accA, accB);
         }
         for (; k + 32 <= kend; k += 32, q0 += 32, q1 += 32) {      // full super-blocks of 32
-          harm_hex_full<true, 0>(q0, q1, k, theta, c4, st, accA, accB);
-          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, st, accA, accB);
+          harm_hex_full<true, 0>(q0, q1, k, theta, c4, c2, st, accA, accB);
+          harm_hex_full<false, 64>(q0, q1, k + 16, theta, c4, c2, st, accA, accB);
         }
         // up to three trailing groups of 4 simply continue the last super-block's recurrence
         // (K = 100: 64 + 32 + 4); only possible when at least one super-block came before
@@ -661,10 +671,10 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
       }
       for (; k < kend; k += 32) {           // the tail: octets with group guards, seeds in the first
         const int rem4 = (kend - k) >> 2;
-        harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, st, accA, accB);
-        if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, st, accA, accB);
-        if (rem4 > 4) harm_oct<false>(a0p, a1p, k + 16, min(rem4 - 4, 2), theta, c4, st, accA, accB);
-        if (rem4 > 6) harm_oct<false>(a0p, a1p, k + 24, min(rem4 - 6, 2), theta, c4, st, accA, accB);
+        harm_oct<true>(a0p, a1p, k, min(rem4, 2), theta, c4, c2, st, accA, accB);
+        if (rem4 > 2) harm_oct<false>(a0p, a1p, k + 8, min(rem4 - 2, 2), theta, c4, c2, st, accA, accB);
+        if (rem4 > 4) harm_oct<false>(a0p, a1p, k + 16, min(rem4 - 4, 2), theta, c4, c2, st, accA, accB);
+        if (rem4 > 6) harm_oct<false>(a0p, a1p, k + 24, min(rem4 - 6, 2), theta, c4, c2, st, accA, accB);
       }
       float acc0 = accA.x + accA.y, acc1 = accB.x + accB.y;
       k = min(kend, K);
