@@ -414,12 +414,16 @@ __device__ __forceinline__ void harm_hex_full(const float* p0, const float* p1, 
   sgpr16 a0, a1;
   asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(a0), "=&s"(a1) : "s"(p0), "s"(p1), "i"(OFF) : "memory");
+  // the recurrence runs one pair ahead of the accumulates: the pair an accumulate reads was written
+  // three instructions earlier, not by the instruction before it
+  f2 sn = SEEDS ? seed_pair(st, theta, k + 1) : next_pair(st, c4);
 #pragma unroll
   for (int i = 0; i < 16; i += 2) {
-    const f2 sn = (SEEDS && i == 0) ? seed_pair(st, theta, k + 1)
-                : (SEEDS && i == 2) ? seed_pair_next(st, c2) : next_pair(st, c4);
+    f2 nx = sn;
+    if (i + 2 < 16) nx = (SEEDS && i == 0) ? seed_pair_next(st, c2) : next_pair(st, c4);
     accA = __builtin_elementwise_fma((f2){a0[i], a0[i + 1]}, sn, accA);
     accB = __builtin_elementwise_fma((f2){a1[i], a1[i + 1]}, sn, accB);
+    sn = nx;
   }
 }
 
