@@ -554,21 +554,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   DDSP_STAMP();    // 1: magnitudes staged
   // ---- 2. IR design, lanes = frames ------------------------------------------------------------------
   {
-    float me[33], mo[32];
+    // magnitudes in 64-bit VGPR pairs: the coefficients of a pair are adjacent SGPRs, so the inner
+    // products run as v_pk_fma_f32 with an SGPR-pair operand (2.9 ns per two FMAs against 2 x 1.9 ns,
+    // tools/microbench4) and as two independent partial sums each
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 me2[16], mo2[16];
 #pragma unroll
-    for (int i = 0; i <= 32; ++i) me[i] = s_u[lane * 65 + 2 * i];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) mo[i] = s_u[lane * 65 + 2 * i + 1];
+    for (int i = 0; i < 16; ++i) {
+      me2[i] = (f2){s_u[lane * 65 + 4 * i], s_u[lane * 65 + 4 * i + 2]};        // even bins 2(2i), 2(2i+1)
+      mo2[i] = (f2){s_u[lane * 65 + 4 * i + 1], s_u[lane * 65 + 4 * i + 3]};    // odd bins
+    }
+    const float me_last = s_u[lane * 65 + 64];
     float* __restrict__ hrow = s_h + lane * kTapStride;
     if (wave == 0) hrow[0] = 0.0f;                     // h[0] = Hann(128)[0] * hz[-64] = 0
     for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += NW) {
       const float* __restrict__ ce = kIr65.c + n * kIrRowStride;
       const float* __restrict__ co = ce + 40;
-      float e = 0.0f, o = 0.0f;
+      f2 ea = {0.0f, 0.0f}, oa = {0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i <= 32; ++i) e = fmaf(me[i], ce[i], e);
-#pragma unroll
-      for (int i = 0; i < 32; ++i) o = fmaf(mo[i], co[i], o);
+      for (int i = 0; i < 16; ++i) {
+        ea = __builtin_elementwise_fma((f2){ce[2 * i], ce[2 * i + 1]}, me2[i], ea);
+        oa = __builtin_elementwise_fma((f2){co[2 * i], co[2 * i + 1]}, mo2[i], oa);
+      }
+      const float e = fmaf(me_last, ce[32], ea.x + ea.y);
+      const float o = oa.x + oa.y;
       const float g0 = kIr65.win[n] * (e + o);         // g[n]:    taps 64+n and 64-n
       hrow[64 + n] = g0;
       if (n >= 1) hrow[64 - n] = g0;

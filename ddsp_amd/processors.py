@@ -89,6 +89,8 @@ class Add(Processor):
 
   def get_signal(self, signal_one, signal_two):
     a, b = core.tf_float32(signal_one), core.tf_float32(signal_two)
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+      return a + b          # recorded by torch.autograd (plumbing); the kernel below has no backward
     if a.shape != b.shape:
       a, b = torch.broadcast_tensors(a, b)
       a, b = a.contiguous(), b.contiguous()

@@ -809,3 +809,22 @@ def test_synth_backward_through_add_and_unsupported_shapes(ddsp):
   with pytest.raises(NotImplementedError):
     m33 = ddsp.core.tf_float32(rng.standard_normal((b, f, 33))).requires_grad_(True)
     ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(m33).sum().backward()
+
+
+def test_processor_group_is_trainable(ddsp):                         # ae.gin DAG + trainers.py:162-171
+  rng = np.random.default_rng(6)
+  b, f, k, n = 2, 50, 60, 3200
+  feats = {'amps': ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True),
+           'harmonic_distribution': ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True),
+           'f0_hz': ddsp.core.tf_float32(200 + rng.standard_normal((b, f, 1))),
+           'magnitudes': ddsp.core.tf_float32(rng.standard_normal((b, f, 65))).requires_grad_(True)}
+  dag = [(ddsp.synths.Harmonic(n_samples=n), ['amps', 'harmonic_distribution', 'f0_hz']),
+         (ddsp.synths.FilteredNoise(n_samples=n, window_size=0), ['magnitudes']),
+         (ddsp.processors.Add(), ['filtered_noise/signal', 'harmonic/signal'])]
+  audio = ddsp.processors.ProcessorGroup(dag=dag)(feats)
+  assert audio.requires_grad
+  audio.pow(2).mean().backward()
+  for key in ('amps', 'harmonic_distribution', 'magnitudes'):
+    g = feats[key].grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+  assert feats['f0_hz'].grad is None
