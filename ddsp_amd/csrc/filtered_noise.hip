@@ -459,20 +459,32 @@ __device__ __forceinline__ void fn_tap_block(const float* s_x, const float* s_h,
   const int rowA = (int)(((float)(irel + 128 + rel0) + 0.5f) * inv_fs);   // frame(i0)    - f_first
   const int rowB = (int)(((float)(irel + 112 + rel0) + 0.5f) * inv_fs);   // frame(i0-16) - f_first
   fn_load16(s_x, irel + 128 - 16, lo);
-  float ta[16], tb[16];
+  // two passes so that the taps of frame(i0) and of frame(i0-16) are never live together
+  // (the 8-wavefront variant has 80 VGPRs: acc + hi + lo + one set of 16 taps = 64)
+  {
+    float ta[16];
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) {
-    const float4 va = *reinterpret_cast<const float4*>(&s_h[rowA * kTapStride + k0 + 4 * c4]);
-    const float4 vb = *reinterpret_cast<const float4*>(&s_h[rowB * kTapStride + k0 + 4 * c4]);
-    ta[4 * c4] = va.x; ta[4 * c4 + 1] = va.y; ta[4 * c4 + 2] = va.z; ta[4 * c4 + 3] = va.w;
-    tb[4 * c4] = vb.x; tb[4 * c4 + 1] = vb.y; tb[4 * c4 + 2] = vb.z; tb[4 * c4 + 3] = vb.w;
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 va = *reinterpret_cast<const float4*>(&s_h[rowA * kTapStride + k0 + 4 * c4]);
+      ta[4 * c4] = va.x; ta[4 * c4 + 1] = va.y; ta[4 * c4 + 2] = va.z; ta[4 * c4 + 3] = va.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+#pragma unroll
+      for (int r = c; r < 16; ++r) acc[r] = fmaf(ta[c], hi[r - c], acc[r]);
+    }
   }
+  {
+    float tb[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 vb = *reinterpret_cast<const float4*>(&s_h[rowB * kTapStride + k0 + 4 * c4]);
+      tb[4 * c4] = vb.x; tb[4 * c4 + 1] = vb.y; tb[4 * c4 + 2] = vb.z; tb[4 * c4 + 3] = vb.w;
+    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r >= c) acc[r] = fmaf(ta[c], hi[r - c], acc[r]);
-      else        acc[r] = fmaf(tb[c], lo[16 + r - c], acc[r]);
+    for (int c = 1; c < 16; ++c) {
+#pragma unroll
+      for (int r = 0; r < c; ++r) acc[r] = fmaf(tb[c], lo[16 + r - c], acc[r]);
     }
   }
 }
