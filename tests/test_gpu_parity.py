@@ -699,7 +699,8 @@ def grad_tol(ref):
     (2, 20, 100, 64, 16000, 69.0, 71.0, 'window', True, True),        # all 100 harmonics live
     (1, 10, 40, 192, 48000, 200.0, 700.0, 'linear', True, True),      # hop 192, linear envelopes
     (2, 16, 20, 64, 16000, 350.0, 600.0, 'window', False, False),     # scale_fn=None, no Nyquist normalisation
-    (1, 9, 200, 100, 16000, 30.0, 45.0, 'linear', True, True)])       # K=200 (4 wavefronts), hop 100
+    (1, 9, 200, 100, 16000, 30.0, 45.0, 'linear', True, True),        # K=200 (two wavefronts), hop 100
+    (2, 12, 30, 50, 16000, 150.0, 400.0, 'window', True, True)])      # K not a multiple of 4, hop 50 (generic forward path)
 def test_harmonic_backward_vs_analytic_oracle(ddsp, batch, n_frames, k, hop, sr, f_lo, f_hi, method, scale,
                                               normalize):
   rng = np.random.default_rng(batch * 1000 + k)
