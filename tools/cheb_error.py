@@ -55,3 +55,22 @@ for sb in (16, 32, 64):
       out[:, k - 1] = v
       hist.append(v)
   print('stride-2, super-block %2d: max |err| per harmonic %.2e' % (sb, np.abs(out - exact).max()))
+
+# ---- what harm_fused_kernel does now: two exact seeds, the next two by two steps of the stride-1
+# recurrence, then stride 2; for K = 100 the runs are harmonics 1..64 and 65..100 -------------------
+out = np.zeros((len(theta), K), f32)
+c2 = (2 * np.cos(2 * np.pi * th64)).astype(f32)
+c4 = (2 * np.cos(4 * np.pi * th64)).astype(f32)
+for k0, k1 in ((1, 64), (65, 100)):
+  hist = []
+  for i, k in enumerate(range(k0, k1 + 1)):
+    if i < 2:
+      v = seed(k)
+    elif i < 4:
+      v = fma32(c2, hist[-1], -hist[-2])
+    else:
+      v = fma32(c4, hist[-2], -hist[-4])
+    out[:, k - 1] = v
+    hist.append(v)
+print('fused kernel (2 exact + 2 derived seeds, runs 1-64 / 65-100): max |err| per harmonic %.2e' %
+      np.abs(out - exact).max())
