@@ -439,8 +439,17 @@ __global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
 constexpr int kFnFrames = 62;
 constexpr int kFnTile = kFnFrames * 64;                 // 3968 z-samples per block
 constexpr int kFnXLen = kFnTile + 128;                  // 4096
-constexpr int kFnPlane = kFnXLen / 4;                   // 1024 dwords per plane
-constexpr int kFnUnion = 64 * 65;                       // floats: magnitude staging / x tile / out
+constexpr int kFnPlane = kFnXLen / 4 + 16;              // 1024 dwords per plane, + 16 so that the four planes start
+                                                        // 16 banks apart (the tile fill writes planes 0..3 from adjacent lanes)
+constexpr int kFnUnion = 64 * 65;                       // floats: magnitude staging / x tile (4 planes of 1040) / out
+static_assert(4 * kFnPlane <= kFnUnion, "x planes must fit the union buffer");
+
+// Where output sample e of the tile lives in LDS between the FIR and the store phase: lane t holds
+// outputs 16t..16t+15 and writes them as four float4; rotating the four slots by (t >> 2) & 3 spreads
+// the 16 lanes of a pass over all 64 banks (a plain 64-byte lane stride is a 4-way conflict).
+__device__ __forceinline__ int fn_out_addr(int e) {
+  return (e & ~15) + ((((e >> 2) ^ (e >> 6)) & 3) << 2) + (e & 3);
+}
 
 __device__ __forceinline__ void fn_load16(const float* s_x, int ip, float (&v)[16]) {
   const int chunk = ip >> 2;
@@ -654,14 +663,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
     if (half == 1 && mrel < kFnTile) {
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4)
-        *reinterpret_cast<float4*>(&s_u[mrel + 4 * c4]) =
+        *reinterpret_cast<float4*>(&s_u[fn_out_addr(mrel + 4 * c4)]) =
             make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
     }
     __syncthreads();
     if (half == 0 && mrel < kFnTile) {
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
-        const float4 u = *reinterpret_cast<const float4*>(&s_u[mrel + 4 * c4]);
+        const float4 u = *reinterpret_cast<const float4*>(&s_u[fn_out_addr(mrel + 4 * c4)]);
         acc[4 * c4] += u.x; acc[4 * c4 + 1] += u.y; acc[4 * c4 + 2] += u.z; acc[4 * c4 + 3] += u.w;
       }
     }
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   if (half == 0 && mrel < kFnTile) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4)
-      *reinterpret_cast<float4*>(&s_u[mrel + 4 * c4]) =
+      *reinterpret_cast<float4*>(&s_u[fn_out_addr(mrel + 4 * c4)]) =
           make_float4(acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]);
   }
   __syncthreads();
@@ -677,21 +686,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   const long nbase = (long)z0 - p.start;                // out index of tile element 0
   const int head = (int)((4 - (nbase & 3)) & 3);        // tile elements before the first 16-byte boundary
   if ((p.N & 3) == 0) {
-    if (tid < head) { const long n = nbase + tid; if (n >= 0 && n < p.N) o[n] = s_u[tid]; }
+    if (tid < head) { const long n = nbase + tid; if (n >= 0 && n < p.N) o[n] = s_u[fn_out_addr(tid)]; }
     for (int e = head + 4 * tid; e < kFnTile; e += 4 * 64 * NW) {
       const long n = nbase + e;
       if (n >= 0 && n + 3 < p.N && e + 3 < kFnTile) {
-        *reinterpret_cast<float4*>(o + n) = make_float4(s_u[e], s_u[e + 1], s_u[e + 2], s_u[e + 3]);
+        *reinterpret_cast<float4*>(o + n) = make_float4(s_u[fn_out_addr(e)], s_u[fn_out_addr(e + 1)],
+                                                        s_u[fn_out_addr(e + 2)], s_u[fn_out_addr(e + 3)]);
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (e + u < kFnTile && n + u >= 0 && n + u < p.N) o[n + u] = s_u[e + u];
+          if (e + u < kFnTile && n + u >= 0 && n + u < p.N) o[n + u] = s_u[fn_out_addr(e + u)];
       }
     }
   } else {
     for (int e = tid; e < kFnTile; e += 64 * NW) {
       const long n = nbase + e;
-      if (n >= 0 && n < p.N) o[n] = s_u[e];
+      if (n >= 0 && n < p.N) o[n] = s_u[fn_out_addr(e)];
     }
   }
   DDSP_STAMP();    // 5: stored
