@@ -40,6 +40,9 @@ SIGNATURES = {
     'ddsp_harmonic_streaming_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 5 +
                                     [c_uint, c_voidp]),
     'ddsp_fft_convolve_long_workspace_bytes': (c_size_t, [c_int] * 5),
+    'ddsp_fft_convolve_long_ex_workspace_bytes': (c_size_t, [c_int] * 6),
+    'ddsp_fft_convolve_long_ex_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 6 +
+                                      [c_uint, c_voidp]),
     'ddsp_fft_convolve_long_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 +
                                    [c_uint, c_voidp]),
     'ddsp_spectral_loss_workspace_bytes': (c_size_t, [c_int, c_int, ctypes.POINTER(c_int), c_int]),
@@ -68,6 +71,9 @@ HARM_INPUTS_ARE_AMPLITUDES = 0x20
 NOISE_SCALE_EXP_SIGMOID = 0x1
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2
+CONV_REVERSE_AUDIO = 0x4
+CONV_REVERSE_IR = 0x8
+CONV_REVERSE_OUT = 0x10
 
 ERRORS = {-1: 'DDSP_ERR_NULL_POINTER', -2: 'DDSP_ERR_BAD_SHAPE', -3: 'DDSP_ERR_UNSUPPORTED',
           -4: 'DDSP_ERR_WORKSPACE', -5: 'DDSP_ERR_LAUNCH'}

@@ -460,12 +460,15 @@ LONG_IR_TAPS = 1024       # single-frame IRs longer than this take the FFT path
 
 
 def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0=False,
-                      workspace=None):
+                      workspace=None, n_out=None, reverse_audio=False, reverse_ir=False,
+                      reverse_out=False):
   """out[b, n] = sum_k ir[b, k] audio[b, n + delay - k] (+ audio[b, n]) for one IR per row.
 
   The single-frame case of core.fft_convolve (ddsp/core.py:1428-1430, padding='same',
   crop start = delay) as effects.Reverb uses it (ddsp/effects.py:113-117), evaluated by
-  ddsp_fft_convolve_long_f32.  impulse_response [batch or 1, ir_size].
+  ddsp_fft_convolve_long_ex_f32.  impulse_response [batch or 1, ir_size].  n_out (default
+  n_samples) outputs per row; the reverse_* switches read an input / write the output with its
+  index reversed (the correlations of the Reverb backward pass).
   """
   audio, impulse_response = tf_float32(audio), tf_float32(impulse_response)
   if audio.dim() != 2 or impulse_response.dim() != 2:
@@ -478,15 +481,21 @@ def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0
                      'be the same.'.format(b, b_ir))
   if delay < 0:
     raise ValueError('delay must be >= 0, got {}'.format(delay))
+  n_out = n if n_out is None else int(n_out)
   lib = _lib.load()
-  nbytes = cached_workspace_bytes('ddsp_fft_convolve_long_workspace_bytes', b, b_ir, n, l, int(delay))
+  nbytes = cached_workspace_bytes('ddsp_fft_convolve_long_ex_workspace_bytes', b, b_ir, n, l, n_out,
+                                  int(delay))
   ws = (workspace if workspace is not None else Workspace()).get(nbytes, audio.device)
-  out = torch.empty_like(audio)
-  flags = (_lib.CONV_ADD_DRY if add_dry else 0) | (_lib.CONV_MASK_TAP0 if mask_tap0 else 0)
-  rc = lib.ddsp_fft_convolve_long_f32(audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), b, b_ir, n, l, int(delay), flags,
-                                      _stream())
-  _lib.check(rc, 'ddsp_fft_convolve_long_f32')
+  out = torch.empty((b, n_out), dtype=torch.float32, device=audio.device)
+  flags = ((_lib.CONV_ADD_DRY if add_dry else 0) | (_lib.CONV_MASK_TAP0 if mask_tap0 else 0) |
+           (_lib.CONV_REVERSE_AUDIO if reverse_audio else 0) | (_lib.CONV_REVERSE_IR if reverse_ir else 0) |
+           (_lib.CONV_REVERSE_OUT if reverse_out else 0))
+  rc = lib.ddsp_fft_convolve_long_ex_f32(audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), b, b_ir, n, l, n_out, int(delay),
+                                         flags, _stream())
+  if rc == -3:
+    raise NotImplementedError('the FFT convolution holds at most 65536 taps per row, got {}'.format(l))
+  _lib.check(rc, 'ddsp_fft_convolve_long_ex_f32')
   return out
 
 

@@ -153,7 +153,7 @@ __device__ __forceinline__ void fft_inverse(float2* s, int tid) {
 }
 
 struct RvArgs {
-  int N, L, nb, np, delay;
+  int N, L, n_out, nb, np, delay;      // n_out: samples written per row (out[n] = y[n + delay], n < n_out)
   unsigned flags;
   int ir_batch;                         // 1: one IR for every batch row
 };
@@ -170,11 +170,18 @@ __global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restr
   // x spectrum m = j: real part samples (m-2)P .. mP-1 (block m-1), imaginary part (m-1)P .. (m+1)P-1 (block m)
   const int base = IS_IR ? j * kRvP : (j - 2) * kRvP;
   const int live = IS_IR ? kRvP : kRvN;
-  const bool vec = ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  // DDSP_CONV_REVERSE_AUDIO / _IR: logical sample g is stored at len-1-g (correlations for the backward pass)
+  const bool rev = (p.flags & (IS_IR ? DDSP_CONV_REVERSE_IR : DDSP_CONV_REVERSE_AUDIO)) != 0;
+  const bool vec = !rev && ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
   auto load4 = [&](int g) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g + 3 >= 0 && g < len) {
-      if (vec && g >= 0 && g + 3 < len) {
+      if (rev) {
+        if (g >= 0 && g < len) v.x = row[len - 1 - g];
+        if (g + 1 >= 0 && g + 1 < len) v.y = row[len - 2 - g];
+        if (g + 2 >= 0 && g + 2 < len) v.z = row[len - 3 - g];
+        if (g + 3 >= 0 && g + 3 < len) v.w = row[len - 4 - g];
+      } else if (vec && g >= 0 && g + 3 < len) {
         v = *reinterpret_cast<const float4*>(row + g);
       } else {
         if (g >= 0 && g < len) v.x = row[g];
@@ -247,14 +254,17 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
   fft_inverse(s, tid);
   // overlap-save: the last P samples of the block are y[jP .. (j+1)P); out[n] = y[n + delay]
   const float scale = 1.0f / (float)kRvN;
-  const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;
+  const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;           // only with n_out == N (checked by the host)
+  const bool rev_a = (p.flags & DDSP_CONV_REVERSE_AUDIO) != 0, rev_o = (p.flags & DDSP_CONV_REVERSE_OUT) != 0;
   const float* __restrict__ arow = audio + (size_t)b * p.N;
-  float* __restrict__ orow = out + (size_t)b * p.N;
+  float* __restrict__ orow = out + (size_t)b * p.n_out;
   for (int i = tid; i < kRvP; i += kRvThreads) {
     const float2 y = s[kRvP + i];
     const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
-    if (n0 >= 0 && n0 < p.N) orow[n0] = fmaf(y.x, scale, dry ? arow[n0] : 0.0f);
-    if (n1 >= 0 && n1 < p.N) orow[n1] = fmaf(y.y, scale, dry ? arow[n1] : 0.0f);
+    if (n0 >= 0 && n0 < p.n_out)
+      orow[rev_o ? p.n_out - 1 - n0 : n0] = fmaf(y.x, scale, dry ? arow[rev_a ? p.N - 1 - n0 : n0] : 0.0f);
+    if (n1 >= 0 && n1 < p.n_out)
+      orow[rev_o ? p.n_out - 1 - n1 : n1] = fmaf(y.y, scale, dry ? arow[rev_a ? p.N - 1 - n1 : n1] : 0.0f);
   }
 }
 
@@ -266,25 +276,30 @@ static inline int rv_parts(int L) { return (L + kRvP - 1) / kRvP; }
 
 using namespace ddsp;
 
-extern "C" size_t ddsp_fft_convolve_long_workspace_bytes(int B, int Bir, int N, int L, int delay) {
-  if (B <= 0 || Bir <= 0 || N <= 0 || L <= 0 || delay < 0) return 0;
-  const size_t spectra = (size_t)B * rv_blocks(N, delay) + (size_t)Bir * rv_parts(L);
+extern "C" size_t ddsp_fft_convolve_long_ex_workspace_bytes(int B, int Bir, int N, int L, int n_out, int delay) {
+  if (B <= 0 || Bir <= 0 || N <= 0 || L <= 0 || n_out <= 0 || delay < 0) return 0;
+  const size_t spectra = (size_t)B * rv_blocks(n_out, delay) + (size_t)Bir * rv_parts(L);
   return spectra * kRvN * sizeof(float2);
 }
 
-extern "C" int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response,
-                                          float* out, void* workspace, size_t workspace_bytes,
-                                          int B, int Bir, int N, int L, int delay, unsigned flags,
-                                          void* stream) {
+extern "C" size_t ddsp_fft_convolve_long_workspace_bytes(int B, int Bir, int N, int L, int delay) {
+  return ddsp_fft_convolve_long_ex_workspace_bytes(B, Bir, N, L, N, delay);
+}
+
+extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* impulse_response,
+                                             float* out, void* workspace, size_t workspace_bytes,
+                                             int B, int Bir, int N, int L, int n_out, int delay,
+                                             unsigned flags, void* stream) {
   if (!audio || !impulse_response || !out || !workspace) return DDSP_ERR_NULL_POINTER;
-  if (B <= 0 || N <= 0 || L <= 0 || delay < 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
+  if (B <= 0 || N <= 0 || L <= 0 || n_out <= 0 || delay < 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
+  if ((flags & DDSP_CONV_ADD_DRY) && n_out != N) return DDSP_ERR_BAD_SHAPE;
   if (B > 65535 || rv_parts(L) > kRvMaxParts) return DDSP_ERR_UNSUPPORTED;
-  if (workspace_bytes < ddsp_fft_convolve_long_workspace_bytes(B, Bir, N, L, delay) ||
+  if (workspace_bytes < ddsp_fft_convolve_long_ex_workspace_bytes(B, Bir, N, L, n_out, delay) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   RvArgs p;
-  p.N = N; p.L = L; p.nb = rv_blocks(N, delay); p.np = rv_parts(L); p.delay = delay;
+  p.N = N; p.L = L; p.n_out = n_out; p.nb = rv_blocks(n_out, delay); p.np = rv_parts(L); p.delay = delay;
   p.flags = flags; p.ir_batch = Bir;
   float2* xspec = (float2*)workspace;
   float2* hspec = xspec + (size_t)B * p.nb * kRvN;
@@ -314,4 +329,12 @@ extern "C" int ddsp_fft_convolve_long_f32(const float* audio, const float* impul
                        (const float2*)xspec, audio, out, p);
   }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response,
+                                          float* out, void* workspace, size_t workspace_bytes,
+                                          int B, int Bir, int N, int L, int delay, unsigned flags,
+                                          void* stream) {
+  return ddsp_fft_convolve_long_ex_f32(audio, impulse_response, out, workspace, workspace_bytes, B,
+                                       Bir, N, L, N, delay, flags, stream);
 }

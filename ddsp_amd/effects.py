@@ -20,7 +20,8 @@ class Reverb(processors.Processor):
 
     Args:
       trainable: hold the impulse response as a single tensor for the entire dataset
-        (the reference's tf.Variable, effects.py:71-80; there is no autograd here yet).
+        (the reference's tf.Variable, effects.py:71-80); set `rev._ir.requires_grad_(True)` to
+        train it - get_signal is a torch.autograd node.
       reverb_length: length of the impulse response; only used if trainable=True.
       add_dry: add the dry signal to the reverberated signal on output.
       name: name of the processor module.
@@ -31,6 +32,7 @@ class Reverb(processors.Processor):
     self._ir = None
     self.built = False
     self._ws = core.Workspace()
+    self._ws_bwd = core.Workspace()
 
   def _ir_2d(self, ir):
     """[L] / [B, L] / [B, L, 1] -> contiguous [B or 1, L] (effects.py:50-57, 62-66)."""
@@ -68,8 +70,49 @@ class Reverb(processors.Processor):
   def get_signal(self, audio, ir):
     """Apply the impulse response -> [batch, n_samples] (effects.py:100-117)."""
     audio = tf_float32(audio)
-    ir = self._ir_2d(tf_float32(ir))
+    ir = tf_float32(ir)
+    if torch.is_grad_enabled() and (audio.requires_grad or ir.requires_grad):
+      return _ReverbFunction.apply(audio, ir, self)
+    return self._forward(audio, self._ir_2d(ir))
+
+  def _forward(self, audio, ir2d):
     # _mask_dry_ir (tap 0 -> 0), fft_convolve(padding='same', delay_compensation=0) and the
     # optional dry sum are one C-ABI call
-    return core.fft_convolve_long(audio, ir, delay=0, add_dry=self._add_dry, mask_tap0=True,
+    return core.fft_convolve_long(audio, ir2d, delay=0, add_dry=self._add_dry, mask_tap0=True,
                                   workspace=self._ws)
+
+  def _backward(self, audio, ir2d, grad_out, need_audio, need_ir):
+    """The two correlations of the backward pass, as FFT convolutions with reversed indices."""
+    g = tf_float32(grad_out)
+    n, l = audio.shape[1], ir2d.shape[1]
+    grad_audio = grad_ir = None
+    if need_audio:       # dL/d audio = reverse(conv(reverse(g), masked ir)[0:N]) (+ g)
+      grad_audio = core.fft_convolve_long(g, ir2d, delay=0, add_dry=self._add_dry, mask_tap0=True,
+                                          workspace=self._ws, reverse_audio=True, reverse_out=True)
+    if need_ir:          # dL/d ir[k] = conv(g, reverse(audio))[N-1+k]; the masked tap gets none
+      grad_ir = core.fft_convolve_long(g, audio, delay=n - 1, n_out=l, reverse_ir=True,
+                                       workspace=self._ws_bwd)
+      grad_ir[:, 0] = 0.0
+      if ir2d.shape[0] == 1 and audio.shape[0] > 1:
+        grad_ir = grad_ir.sum(dim=0, keepdim=True)       # one tiled IR collects the batch (plumbing)
+    return grad_audio, grad_ir
+
+
+class _ReverbFunction(torch.autograd.Function):
+  """torch.autograd node of Reverb.get_signal (plumbing: both directions are C-ABI calls)."""
+
+  @staticmethod
+  def forward(ctx, audio, ir, rev):
+    ir2d = rev._ir_2d(ir.detach())
+    ctx.save_for_backward(audio, ir2d)
+    ctx.rev, ctx.ir_shape = rev, ir.shape
+    return rev._forward(audio.detach(), ir2d)
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    audio, ir2d = ctx.saved_tensors
+    ga, gi = ctx.rev._backward(audio.detach(), ir2d, grad_out, ctx.needs_input_grad[0],
+                               ctx.needs_input_grad[1])
+    if gi is not None:
+      gi = gi.reshape(ctx.ir_shape)
+    return ga, gi, None

@@ -219,10 +219,24 @@ int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response
  */
 #define DDSP_CONV_ADD_DRY 1u
 #define DDSP_CONV_MASK_TAP0 2u
+#define DDSP_CONV_REVERSE_AUDIO 4u   /* _ex only: logical audio sample g is stored at N-1-g   */
+#define DDSP_CONV_REVERSE_IR 8u      /* _ex only: logical tap k is stored at L-1-k            */
+#define DDSP_CONV_REVERSE_OUT 16u    /* _ex only: logical output n is written to n_out-1-n    */
 size_t ddsp_fft_convolve_long_workspace_bytes(int B, int Bir, int N, int L, int delay);
 int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response, float* out,
                                void* workspace, size_t workspace_bytes, int B, int Bir, int N,
                                int L, int delay, unsigned flags, void* stream);
+/* The same convolution with n_out outputs per row (out [B,n_out], out[b][n] = y[n + delay] of the
+ * full linear convolution y) and optional index reversal of either input or of the output: the two
+ * correlations of the Reverb backward pass are
+ *   dL/d audio = reverse( conv(reverse(g), ir)[0:N] )           (REVERSE_AUDIO | REVERSE_OUT)
+ *   dL/d ir[k] = conv(g, reverse(audio))[N-1+k], k < L          (REVERSE_IR on the audio passed as "ir",
+ *                                                                 n_out = L, delay = N-1)
+ * The "impulse response" of a call may be up to 65536 samples long.  ADD_DRY needs n_out == N. */
+size_t ddsp_fft_convolve_long_ex_workspace_bytes(int B, int Bir, int N, int L, int n_out, int delay);
+int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* impulse_response, float* out,
+                                  void* workspace, size_t workspace_bytes, int B, int Bir, int N,
+                                  int L, int n_out, int delay, unsigned flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * losses.SpectralLoss.call, forward pass (ddsp/losses.py:189-243), loss_type 'L1', magnitude and

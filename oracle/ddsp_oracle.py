@@ -641,6 +641,34 @@ def filtered_noise_backward(magnitudes, noise, grad_audio, window_size=257, scal
   return d_ctl
 
 
+def reverb_backward(audio, ir, grad_out, add_dry=True):
+  """(dL/d audio [B,N], dL/d ir [Bir,L]) of reverb() given dL/d out [B,N] (fp64 truth).
+
+  out[n] = sum_{k>=1} ir[k] audio[n-k] (+ audio[n]):  dL/d audio[m] = sum_n g[n] ir[n-m] (+ g[m]),
+  dL/d ir[k] = sum_n g[n] audio[n-k] for k >= 1 and 0 for the masked tap; a single (tiled) IR
+  collects the sum over the batch.
+  """
+  x = as_float(audio, np.float64)
+  g = as_float(grad_out, np.float64)
+  h = reverb_mask_dry_ir(ir, np.float64)
+  b, n = x.shape
+  bir, l = h.shape
+  d_audio = np.zeros_like(x)
+  d_ir = np.zeros((b, l))
+  for r in range(b):
+    hr = h[r % bir]
+    # sum_n g[n] h[n-m] = correlate(g, h)[m]
+    d_audio[r] = np.correlate(np.concatenate([g[r], np.zeros(l - 1)]), hr, mode='valid')[:n]
+    full = np.convolve(g[r], x[r][::-1])                   # full[N-1+k] = sum_n g[n] x[n-k]
+    d_ir[r, :min(l, n)] = full[n - 1:n - 1 + min(l, n)]
+  d_ir[:, 0] = 0.0
+  if add_dry:
+    d_audio = d_audio + g
+  if bir == 1:
+    d_ir = d_ir.sum(axis=0, keepdims=True)
+  return d_audio, d_ir
+
+
 # ----------------------------------------------------------------------------
 # losses.SpectralLoss  (ddsp/losses.py:100-243, ddsp/spectral_ops.py:34-70; SURVEY 8f rank 2)
 # ----------------------------------------------------------------------------

@@ -829,3 +829,60 @@ def test_processor_group_is_trainable(ddsp):                         # ae.gin DA
     g = feats[key].grad
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
   assert feats['f0_hz'].grad is None
+
+
+@pytest.mark.parametrize('batch,n,l,ir_batch,add_dry,ir_rank', [
+    (2, 3000, 700, 2, True, 2), (3, 5000, 6000, 1, False, 1), (2, 64000, 48000, 2, True, 3)])
+def test_reverb_backward_vs_analytic_oracle(ddsp, batch, n, l, ir_batch, add_dry, ir_rank):
+  rng = np.random.default_rng(l)
+  x = rng.standard_normal((batch, n)).astype(np.float32)
+  h = (rng.standard_normal((ir_batch, l)) * np.exp(-np.arange(l) / (0.3 * l))).astype(np.float32)
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  h_in = h[0] if ir_rank == 1 else (h[:, :, None] if ir_rank == 3 else h)
+  tx = ddsp.core.tf_float32(x).requires_grad_(True)
+  th = ddsp.core.tf_float32(h_in).requires_grad_(True)
+  rev = ddsp.effects.Reverb(add_dry=add_dry)
+  out = rev(tx, th)
+  (out * ddsp.core.tf_float32(g)).sum().backward()
+  if n * l <= 4e7:
+    dx, dh = O.reverb_backward(x, h, g, add_dry)
+  else:                                                   # full size: fp64 FFT correlations (the direct form takes minutes)
+    import scipy.signal
+    hm = h.astype(np.float64).copy(); hm[:, 0] = 0.0
+    dx = np.stack([scipy.signal.fftconvolve(g[b].astype(np.float64)[::-1], hm[b % ir_batch])[:n][::-1]
+                   for b in range(batch)]) + (g if add_dry else 0.0)
+    dh = np.stack([scipy.signal.fftconvolve(g[b].astype(np.float64), x[b].astype(np.float64)[::-1])[n - 1:n - 1 + l]
+                   for b in range(batch)])
+    dh[:, 0] = 0.0
+    if ir_batch == 1:
+      dh = dh.sum(0, keepdims=True)
+  np.testing.assert_allclose(npy(tx.grad), dx, rtol=0, atol=reverb_tol(dx))
+  assert tuple(th.grad.shape) == tuple(th.shape)
+  np.testing.assert_allclose(npy(th.grad).reshape(dh.shape), dh, rtol=0, atol=reverb_tol(dh))
+  np.testing.assert_array_equal(npy(out), npy(rev(x, h_in)))        # same forward value without recording
+
+
+def test_synth_plus_trainable_reverb_trains(ddsp):                   # solo_instrument.gin:26-40 + trainers.py:162-171
+  rng = np.random.default_rng(10)
+  b, f, k, n, l = 2, 50, 60, 3200, 1500
+  amps = ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True)
+  hd = ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True)
+  f0 = 200 + rng.standard_normal((b, f, 1))
+  rev = ddsp.effects.Reverb(trainable=True, reverb_length=l)
+  rev.build(device=torch.device('cuda'))
+  rev._ir = ddsp.core.tf_float32(0.02 * rng.standard_normal(l)).requires_grad_(True)
+  dag = [(ddsp.synths.Harmonic(n_samples=n), ['amps', 'harmonic_distribution', 'f0_hz']),
+         (rev, ['harmonic/signal'])]
+  group = ddsp.processors.ProcessorGroup(dag=dag)
+  target = ddsp.core.tf_float32(rng.standard_normal((b, n)) * 0.1)
+  def loss_of():
+    return ((group({'amps': amps, 'harmonic_distribution': hd, 'f0_hz': f0}) - target) ** 2).mean()
+  loss = loss_of()
+  loss.backward()
+  for t in (amps, hd, rev._ir):
+    assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+  with torch.no_grad():
+    for t in (amps, hd, rev._ir):
+      t -= 20.0 * t.grad
+  with torch.no_grad():
+    assert float(loss_of()) < float(loss.detach())

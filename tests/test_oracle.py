@@ -300,3 +300,23 @@ def test_filtered_noise_backward_matches_finite_differences(m, window_size, n_fr
     d = np.zeros_like(mags); d[idx] = eps
     fd = (loss(mags + d) - loss(mags - d)) / (2 * eps)
     np.testing.assert_allclose(gm[idx], fd, rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('b,bir,n,l,add_dry', [(2, 2, 30, 12, True), (3, 1, 25, 40, False)])
+def test_reverb_backward_matches_finite_differences(b, bir, n, l, add_dry):
+  rng = np.random.default_rng(9)
+  x = rng.standard_normal((b, n))
+  h = rng.standard_normal((bir, l))
+  g = rng.standard_normal((b, n))
+
+  def loss(xx, hh):
+    return float(np.sum(O.reverb(xx, hh, add_dry, dtype=np.float64) * g))
+  dx, dh = O.reverb_backward(x, h, g, add_dry)
+  assert dx.shape == x.shape and dh.shape == h.shape
+  eps = 1e-6
+  for idx in [(0, 0), (b - 1, n - 1), (0, n // 2)]:
+    d = np.zeros_like(x); d[idx] = eps
+    np.testing.assert_allclose(dx[idx], (loss(x + d, h) - loss(x - d, h)) / (2 * eps), rtol=1e-6, atol=1e-8)
+  for idx in [(0, 0), (0, 1), (bir - 1, l - 1), (0, l // 2)]:
+    d = np.zeros_like(h); d[idx] = eps
+    np.testing.assert_allclose(dh[idx], (loss(x, h + d) - loss(x, h - d)) / (2 * eps), rtol=1e-6, atol=1e-8)
