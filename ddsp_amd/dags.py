@@ -1,46 +1,58 @@
-"""DAGLayer: string modules together as a list-of-nodes DAG (mirror of ddsp/dags.py:57-195).
+"""DAGLayer: a sequential list-of-nodes graph over named modules (behaviour of ddsp/dags.py:57-195).
 
-Host-side plumbing only (dict routing, no arithmetic); modules are any callables, Processors are
-recognised by duck typing on get_signal/get_controls exactly as the reference does (dags.py:44).
+Pure host plumbing - routing of dictionaries, no arithmetic.  The graph is compiled once, at
+construction, into `_Node` records (module name, pre-split input paths, output names); running it
+is one pass over those records.  What counts as a processor / loss is decided by the methods a
+module offers (ddsp/dags.py:40-44), so any object with the right methods can sit in the graph.
 """
+import collections
 import logging
 
 from ddsp_amd import core
 
-# duck typing (ddsp/dags.py:40-44)
-is_loss = lambda v: hasattr(v, 'get_losses_dict')
-is_processor = lambda v: hasattr(v, 'get_signal') and hasattr(v, 'get_controls')
-is_module = lambda v: callable(v) and hasattr(v, 'name') and not isinstance(v, str)
+_KERAS_ONLY = ('training', 'mask', 'name')
+
+_Node = collections.namedtuple('_Node', ['module_name', 'input_paths', 'output_names'])
+
+
+def is_loss(obj):
+  return hasattr(obj, 'get_losses_dict')
+
+
+def is_processor(obj):
+  return hasattr(obj, 'get_signal') and hasattr(obj, 'get_controls')
+
+
+def is_module(obj):
+  return callable(obj) and hasattr(obj, 'name') and not isinstance(obj, str)
 
 
 def split_keras_kwargs(kwargs):
-  """Strip keras specific kwargs (ddsp/dags.py:47-53)."""
-  keras_kwargs = {}
-  for key in ['training', 'mask', 'name']:
-    if kwargs.get(key) is not None:
-      keras_kwargs[key] = kwargs.pop(key)
-  return keras_kwargs, kwargs
+  """(keras-only kwargs that were set, the rest) - ddsp/dags.py:47-53."""
+  taken = {k: kwargs.pop(k) for k in _KERAS_ONLY if kwargs.get(k) is not None}
+  return taken, kwargs
 
 
 class DAGLayer:
-  """String modules together (ddsp/dags.py:57-195).
+  """Runs modules in list order, each fed from the outputs accumulated so far.
 
-  dag: list of nodes ['module', ['input_key', ...], ['output_key', ...]]; 'module' is an instance
-  or the name of a kwarg module; input keys are nested keys ("inputs/f0_hz", "harmonic/signal")
-  into the running outputs dict; the graph is read sequentially (topologically sorted).
+  A node is `(module, [input path, ...])` or `(module, [input path, ...], [output name, ...])`;
+  `module` is an instance (registered under its `.name`) or the name of a module passed as a
+  keyword argument.  Input paths are '/'-separated keys into the running outputs dictionary
+  ('f0_hz', 'inputs/f0_hz', 'harmonic/signal', 'harmonic/controls/amplitudes').
   """
 
   def __init__(self, dag, **kwarg_modules):
     keras_kwargs, kwarg_modules = split_keras_kwargs(kwarg_modules)
     self.name = keras_kwargs.get('name', type(self).__name__.lower())
     self.built = False
-    modules = {k: v for k, v in kwarg_modules.items() if is_module(v)}
-    dag, dag_modules = self.format_dag(dag)
-    self.dag = dag
-    modules.update(dag_modules)
-    self.module_names = list(modules.keys())
-    for module_name, module in modules.items():
+    registry = collections.OrderedDict((k, v) for k, v in kwarg_modules.items() if is_module(v))
+    self.dag, found = self.format_dag(dag)
+    registry.update(found)
+    self.module_names = list(registry)
+    for module_name, module in registry.items():
       setattr(self, module_name, module)
+    self._nodes = [_Node(n[0], tuple(n[1]), tuple(n[2]) if len(n) > 2 else None) for n in self.dag]
 
   @property
   def modules(self):
@@ -48,17 +60,15 @@ class DAGLayer:
 
   @staticmethod
   def format_dag(dag):
-    """Remove modules from dag, and replace with module names (ddsp/dags.py:112-127)."""
-    modules = {}
-    dag = list(dag)
-    for i, node in enumerate(dag):
-      node = list(node)
-      module = node[0]
-      if is_module(module):
-        modules[module.name] = module
-        node[0] = module.name
-      dag[i] = node
-    return dag, modules
+    """-> (dag with instances replaced by their names, {name: instance}) - ddsp/dags.py:112-127."""
+    named, instances = [], {}
+    for node in dag:
+      head, rest = node[0], list(node[1:])
+      if is_module(head):
+        instances[head.name] = head
+        head = head.name
+      named.append([head] + rest)
+    return named, instances
 
   def __call__(self, inputs, **kwargs):
     return self.call(inputs, **kwargs)
@@ -66,26 +76,27 @@ class DAGLayer:
   def call(self, inputs, **kwargs):
     return self.run_dag(inputs, **kwargs)
 
+  @staticmethod
+  def _invoke(module, args, kwargs):
+    if is_processor(module):
+      return module(*args, return_outputs_dict=True, **kwargs)
+    if is_loss(module):
+      return module.get_losses_dict(*args, **kwargs)
+    return module(*args, **kwargs)
+
   def run_dag(self, inputs, verbose=False, **kwargs):
-    """Connects and runs submodules of dag; returns the nested dict of all outputs (dags.py:134-195)."""
-    outputs = {'inputs': inputs}
-    outputs.update(inputs)          # reference keeps the inputs in the base namespace too
-    module_outputs = None
-    for node in self.dag:
-      module_key, input_keys = node[0], node[1]
-      module = getattr(self, module_key)
-      output_keys = node[2] if len(node) > 2 else None
-      node_inputs = [core.nested_lookup(key, outputs) for key in input_keys]
+    """Nested dict of every module's outputs; 'inputs' and 'out' are reserved keys (dags.py:134-195)."""
+    results = dict(inputs)               # the inputs are reachable without a prefix ...
+    results['inputs'] = inputs           # ... and under 'inputs/'
+    last = None
+    for node in self._nodes:
+      module = getattr(self, node.module_name)
+      args = [core.nested_lookup(path, results) for path in node.input_paths]
       if verbose:
-        logging.info('Input to Module: %s\nKeys: %s\n', module_key, input_keys)
-      if is_processor(module):
-        module_outputs = module(*node_inputs, return_outputs_dict=True, **kwargs)
-      elif is_loss(module):
-        module_outputs = module.get_losses_dict(*node_inputs, **kwargs)
-      else:
-        module_outputs = module(*node_inputs, **kwargs)
-      if not isinstance(module_outputs, dict):
-        module_outputs = core.to_dict(module_outputs, output_keys)
-      outputs[module_key] = module_outputs
-    outputs['out'] = module_outputs   # 'out' is a reserved key for the final dag output
-    return outputs
+        logging.info('module %s <- %s', node.module_name, list(node.input_paths))
+      last = self._invoke(module, args, kwargs)
+      if not isinstance(last, dict):
+        last = core.to_dict(last, list(node.output_names) if node.output_names else None)
+      results[node.module_name] = last
+    results['out'] = last
+    return results
