@@ -25,6 +25,7 @@ enum KernelId {
   kHarmBwdChain,
   kNoiseBwdTaps,
   kNoiseBwdMags,
+  kStftL1Bwd,
   kNumKernels
 };
 

@@ -123,6 +123,146 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   }
 }
 
+// ---- backward: dL/d audio ---------------------------------------------------------------------------
+// Same block structure as the forward kernel: frames -> LDS -> forward FFT of target and audio frames.
+// Then, per frame and per PAIR of bins (k, S/2-k) - the pair shares the packed bins Z[k], Z[H-k]:
+//   magnitudes as forward -> dL/d|X_a| = -(w_mag sign(d mag) + w_log sign(d log) / |X_a|) / count
+//   -> dL/dX_a = that * X_a / |X_a| -> the real-signal spectrum C of the frame's gradient
+//   (C_0, C_{S/2} real parts, C_k = G_k / 2) -> re-packed into the H-point spectrum Z' (in place);
+// an unscaled inverse FFT (the algebraic inverse of the forward stages) returns the frame's gradient
+// as even/odd samples, which are windowed and added into grad_audio (4 overlapping frames per
+// sample: fp32 atomics, so the last bit may differ from run to run).
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __restrict__ target,
+                                                                 const float* __restrict__ audio,
+                                                                 const float* __restrict__ grad_loss,
+                                                                 float* __restrict__ grad_audio, int N,
+                                                                 int n_frames, float safe_eps,
+                                                                 float mag_scale, float log_scale) {
+  constexpr int H = S / 2;
+  constexpr int G = kSlPoints / 2 / H;
+  constexpr int LOG2H = __builtin_ctz(H);
+  constexpr int HOP = S / 4;
+  __shared__ __attribute__((aligned(16))) float2 s[kSlPoints];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * G;
+  const float* __restrict__ trow = target + (size_t)b * N;
+  const float* __restrict__ arow = audio + (size_t)b * N;
+  for (int e = tid; e < kSlPoints; e += kSlThreads) {
+    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;
+    const int g = g2 >= G ? g2 - G : g2;
+    const int n = (f0 + g) * HOP + n2;
+    float2 v = make_float2(0.f, 0.f);
+    if (f0 + g < n_frames && n < N) {
+      const float* __restrict__ row = g2 >= G ? arow : trow;
+      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+      v.x = row[n] * w0;
+      if (n + 1 < N) v.y = row[n + 1] * w1;
+    }
+    s[e] = v;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int half = H / 2; half >= 1; half >>= 1) {              // forward DIF, as stft_l1_kernel
+    const float inv_len = 0.5f / (float)half;
+    for (int t = tid; t < kSlPoints / 2; t += kSlThreads) {
+      const int g = t >> (LOG2H - 1), r = t & (H / 2 - 1);
+      const int pos = r & (half - 1);
+      const int i0 = (g << LOG2H) + ((r - pos) << 1) + pos;
+      const float2 a = s[i0], bb = s[i0 + half];
+      const float rev = (float)pos * inv_len;
+      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+      const float2 d = make_float2(a.x - bb.x, a.y - bb.y);
+      s[i0] = make_float2(a.x + bb.x, a.y + bb.y);
+      s[i0 + half] = make_float2(fmaf(d.x, c, d.y * sn), fmaf(d.y, c, -d.x * sn));
+    }
+    __syncthreads();
+  }
+  // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
+  const float up = grad_loss[0];
+  const float ms = mag_scale * up, ls = log_scale * up;        // weight / count (per size), times dL/dloss
+  for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {
+    const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);     // pair (k, H-k), k = 0 .. H/2
+    if (f0 + g >= n_frames) continue;
+    const int ia = (int)(__brev((unsigned)k) >> (32 - LOG2H));
+    const int ib = (int)(__brev((unsigned)((H - k) & (H - 1))) >> (32 - LOG2H));
+    const float rev = (float)k * (1.0f / (float)S);
+    const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+    float2 x1[2], x2[2];                                        // X[k], X[H-k] of target (0) and audio (1)
+#pragma unroll
+    for (int sig = 0; sig < 2; ++sig) {
+      const int base = (g + sig * G) << LOG2H;
+      const float2 za = s[base + ia], zb = s[base + ib];
+      const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);
+      const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);
+      const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);     // W^k O
+      x1[sig] = make_float2(ex + wx, ey + wy);                  // X[k]   = E + W^k O
+      x2[sig] = make_float2(ex - wx, -(ey - wy));               // X[H-k] = conj(E - W^k O)
+    }
+    // dL/dX for one bin: coefficient * X_a / |X_a|
+    auto bin_grad = [&](float2 xt, float2 xa) {
+      const float mt = sqrtf(fmaf(xt.x, xt.x, xt.y * xt.y)), ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+      if (!(ma > 0.0f)) return make_float2(0.f, 0.f);
+      const float dmag = mt - ma;
+      const float dlog = __logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma);
+      const float sm = dmag > 0.0f ? 1.0f : (dmag < 0.0f ? -1.0f : 0.0f);
+      const float sl = dlog > 0.0f ? 1.0f : (dlog < 0.0f ? -1.0f : 0.0f);
+      const float inv = 1.0f / ma;
+      const float coef = -(ms * sm + ls * sl * inv) * inv;
+      return make_float2(coef * xa.x, coef * xa.y);
+    };
+    float2 c1 = bin_grad(x1[0], x1[1]);                         // G[k]
+    float2 c2 = bin_grad(x2[0], x2[1]);                         // G[H-k]
+    const int abase = (g + G) << LOG2H;
+    if (k == 0) {                                               // bins 0 and S/2: real, C = Re G
+      const float e0 = 0.5f * (c1.x + c2.x), o0 = 0.5f * (c1.x - c2.x);
+      s[abase + ia] = make_float2(e0, o0);                      // Z'[0] = E' + i O'
+    } else {
+      if (2 * k == H) c2 = c1;                                  // the self-paired bin S/4
+      c1 = make_float2(0.5f * c1.x, 0.5f * c1.y);               // C_k = G_k / 2 for inner bins
+      c2 = make_float2(0.5f * c2.x, 0.5f * c2.y);
+      // E' = (C[k] + conj C[H-k]) / 2,  O' = (C[k] - conj C[H-k]) / 2 * W^-k
+      const float ex = 0.5f * (c1.x + c2.x), ey = 0.5f * (c1.y - c2.y);
+      const float dx = 0.5f * (c1.x - c2.x), dy = 0.5f * (c1.y + c2.y);
+      const float ox = fmaf(dx, c, -dy * sn), oy = fmaf(dx, sn, dy * c);      // D * (c + i sn)
+      s[abase + ia] = make_float2(ex - oy, ey + ox);            // Z'[k]   = E' + i O'
+      if (2 * k != H) s[abase + ib] = make_float2(ex + oy, ox - ey);          // Z'[H-k] = conj E' + i conj O'
+    }
+  }
+  __syncthreads();
+  // ---- unscaled inverse of the DIF stages over the audio frames ---------------------------------------
+#pragma unroll 1
+  for (int half = 1; half <= H / 2; half <<= 1) {
+    const float inv_len = 0.5f / (float)half;
+    for (int t = tid; t < kSlPoints / 4; t += kSlThreads) {     // the audio half: G frames x H/2 butterflies
+      const int g = (t >> (LOG2H - 1)) + G, r = t & (H / 2 - 1);
+      const int pos = r & (half - 1);
+      const int i0 = (g << LOG2H) + ((r - pos) << 1) + pos;
+      const float2 pp = s[i0], q = s[i0 + half];
+      const float rev = (float)pos * inv_len;
+      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+      const float2 qw = make_float2(fmaf(q.x, c, -q.y * sn), fmaf(q.x, sn, q.y * c));   // q * conj(w)
+      s[i0] = make_float2(pp.x + qw.x, pp.y + qw.y);
+      s[i0 + half] = make_float2(pp.x - qw.x, pp.y - qw.y);
+    }
+    __syncthreads();
+  }
+  // ---- window, overlap-add into grad_audio: g_x[2n] = 2 Re U[n], g_x[2n+1] = 2 Im U[n] --------------
+  float* __restrict__ grow = grad_audio + (size_t)b * N;
+  for (int e = tid; e < G * H; e += kSlThreads) {
+    const int g = e >> LOG2H, n2 = (e & (H - 1)) * 2;
+    const int n = (f0 + g) * HOP + n2;
+    if (f0 + g < n_frames && n < N) {
+      const float2 u = s[((g + G) << LOG2H) + (e & (H - 1))];
+      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+      unsafeAtomicAdd(&grow[n], 2.0f * u.x * w0);
+      if (n + 1 < N) unsafeAtomicAdd(&grow[n + 1], 2.0f * u.y * w1);
+    }
+  }
+}
+
 struct SlFinishArgs {
   int n_sizes;
   int offset[16];          // first partial pair of each size
@@ -211,5 +351,33 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
     }
   }
   hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, loss, fin);
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_spectral_loss_backward_f32(const float* target_audio, const float* audio,
+                                               const float* grad_loss, float* grad_audio, int B,
+                                               int N, const int* fft_sizes, int n_sizes,
+                                               float mag_weight, float logmag_weight, void* stream) {
+  if (!target_audio || !audio || !grad_loss || !grad_audio || !fft_sizes) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_audio, 0, (size_t)B * N * sizeof(float), st) != hipSuccess) return DDSP_ERR_LAUNCH;
+  ProfileScope prof(kStftL1Bwd, st);
+  for (int z = 0; z < n_sizes; ++z) {
+    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+    const float inv_count = (float)(1.0 / ((double)B * (double)frames * (double)(S / 2 + 1)));
+    const dim3 grid((unsigned)blocks, (unsigned)B);
+#define DDSP_SLB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
+                                                      target_audio, audio, grad_loss, grad_audio, N, frames, 1e-5f, \
+                                                      mag_weight * inv_count, logmag_weight * inv_count); break
+    switch (S) {
+      DDSP_SLB_CASE(16); DDSP_SLB_CASE(32); DDSP_SLB_CASE(64); DDSP_SLB_CASE(128); DDSP_SLB_CASE(256);
+      DDSP_SLB_CASE(512); DDSP_SLB_CASE(1024); DDSP_SLB_CASE(2048); DDSP_SLB_CASE(4096);
+      default: return DDSP_ERR_UNSUPPORTED;
+    }
+#undef DDSP_SLB_CASE
+  }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

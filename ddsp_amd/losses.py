@@ -1,8 +1,8 @@
 """Losses: the multi-scale spectrogram loss, forward pass (mirror of ddsp/losses.py:41-48, 131-243).
 
 SURVEY.md section 8(f) rank 2.  Only what `gin/models/ae.gin:36-41` uses is built: loss_type 'L1'
-with the magnitude and log-magnitude terms.  There is no autograd in this package yet, so the
-value is for evaluation / monitoring; the other weights raise NotImplementedError.
+with the magnitude and log-magnitude terms; the other weights raise NotImplementedError.
+The call is a torch.autograd node: the gradient reaches `audio` (not `target_audio`).
 """
 import ctypes
 
@@ -70,8 +70,16 @@ class SpectralLoss(Loss):
     if target_audio.dim() != 2 or target_audio.shape != audio.shape:
       raise ValueError('target_audio and audio must both be [batch, n_samples], got {} and {}'.format(
           tuple(target_audio.shape), tuple(audio.shape)))
+    if torch.is_grad_enabled() and audio.requires_grad:
+      return _SpectralLossFunction.apply(target_audio.detach(), audio, self)
+    return self._forward(target_audio, audio)
+
+  def _sizes(self):
+    return (ctypes.c_int * len(self.fft_sizes))(*[int(v) for v in self.fft_sizes])
+
+  def _forward(self, target_audio, audio):
     b, n = audio.shape
-    sizes = (ctypes.c_int * len(self.fft_sizes))(*[int(v) for v in self.fft_sizes])
+    sizes = self._sizes()
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
@@ -84,3 +92,29 @@ class SpectralLoss(Loss):
                                     float(self.mag_weight), float(self.logmag_weight), core._stream())
     _lib.check(rc, 'ddsp_spectral_loss_f32')
     return loss
+
+  def _backward(self, target_audio, audio, grad_loss):
+    b, n = audio.shape
+    grad_loss = core.tf_float32(grad_loss).reshape(1).contiguous()
+    grad_audio = torch.empty_like(audio)
+    rc = _lib.load().ddsp_spectral_loss_backward_f32(
+        target_audio.data_ptr(), audio.data_ptr(), grad_loss.data_ptr(), grad_audio.data_ptr(), b, n,
+        self._sizes(), len(self.fft_sizes), float(self.mag_weight), float(self.logmag_weight),
+        core._stream())
+    _lib.check(rc, 'ddsp_spectral_loss_backward_f32')
+    return grad_audio
+
+
+class _SpectralLossFunction(torch.autograd.Function):
+  """torch.autograd node of SpectralLoss.call: the gradient flows to `audio` only."""
+
+  @staticmethod
+  def forward(ctx, target_audio, audio, loss_obj):
+    ctx.save_for_backward(target_audio, audio)
+    ctx.loss_obj = loss_obj
+    return loss_obj._forward(target_audio, audio.detach())
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    target_audio, audio = ctx.saved_tensors
+    return None, ctx.loss_obj._backward(target_audio, audio.detach(), grad_loss), None

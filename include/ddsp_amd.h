@@ -254,6 +254,15 @@ int ddsp_spectral_loss_f32(const float* target_audio, const float* audio, float*
                            const int* fft_sizes, int n_sizes, float mag_weight,
                            float logmag_weight, void* stream);
 
+/* Backward pass of ddsp_spectral_loss_f32 with respect to `audio`: grad_audio [B,N] (overwritten)
+ * = grad_loss[0] * dL/d audio, grad_loss a device pointer to one float.  |z| has gradient z/|z|
+ * (0 at 0), safe_log passes a gradient only where its argument is positive.  Overlapping frames
+ * add with fp32 atomics: the last bit may differ between runs. */
+int ddsp_spectral_loss_backward_f32(const float* target_audio, const float* audio,
+                                    const float* grad_loss, float* grad_audio, int B, int N,
+                                    const int* fft_sizes, int n_sizes, float mag_weight,
+                                    float logmag_weight, void* stream);
+
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);

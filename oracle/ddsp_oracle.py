@@ -725,6 +725,39 @@ def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64)
   return loss
 
 
+def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64),
+                           mag_weight=1.0, logmag_weight=0.0):
+  """dL/d audio [B,N] of spectral_loss(target_audio, audio, loss_type='L1') (fp64 truth).
+
+  |z| has gradient z/|z| (0 at z = 0, as tf.abs), safe_log passes a gradient only where its
+  argument is positive, sign(0) = 0; the zero-padded tail of the last frames gets no gradient.
+  """
+  t = as_float(target_audio, np.float64)
+  a = as_float(audio, np.float64)
+  b, n = a.shape
+  grad = np.zeros_like(a)
+  for size in fft_sizes:
+    hop = int(size * 0.25)
+    zt = stft(t, size, dtype=np.float64)
+    za = stft(a, size, dtype=np.float64)
+    mt, ma = np.abs(zt), np.abs(za)
+    count = float(mt.size)
+    coef = -mag_weight * np.sign(mt - ma)
+    if logmag_weight > 0:
+      coef = coef - logmag_weight * np.sign(safe_log(mt) - safe_log(ma)) * np.where(
+          ma > 0.0, 1.0 / np.where(ma > 0.0, ma, 1.0), 0.0)
+    g_bins = (coef / count) * np.where(ma > 0.0, za / np.where(ma > 0.0, ma, 1.0), 0.0)
+    full = np.zeros(za.shape[:-1] + (size,), complex)
+    full[..., :size // 2 + 1] = g_bins
+    g_frames = np.real(np.fft.ifft(full, axis=-1) * size) * hann_window_periodic(size, np.float64)
+    n_frames = g_frames.shape[1]
+    padded = np.zeros((b, (n_frames - 1) * hop + size))
+    for f in range(n_frames):
+      padded[:, f * hop:f * hop + size] += g_frames[:, f]
+    grad += padded[:, :n]
+  return grad
+
+
 def add(signal_one, signal_two):
   """processors.Add.get_signal (processors.py:174-176)."""
   return signal_one + signal_two

@@ -320,3 +320,16 @@ def test_reverb_backward_matches_finite_differences(b, bir, n, l, add_dry):
   for idx in [(0, 0), (0, 1), (bir - 1, l - 1), (0, l // 2)]:
     d = np.zeros_like(h); d[idx] = eps
     np.testing.assert_allclose(dh[idx], (loss(x, h + d) - loss(x, h - d)) / (2 * eps), rtol=1e-6, atol=1e-8)
+
+
+def test_spectral_loss_backward_matches_finite_differences():
+  rng = np.random.default_rng(2)
+  t = 0.3 * rng.standard_normal((2, 300))
+  a = t * 0.8 + 0.05 * rng.standard_normal((2, 300))
+  kw = dict(fft_sizes=(128, 64, 16), mag_weight=1.0, logmag_weight=0.7)
+  g = O.spectral_loss_backward(t, a, **kw)
+  eps = 1e-6
+  for idx in [(0, 0), (0, 150), (1, 299), (1, 37), (0, 291)]:
+    d = np.zeros_like(a); d[idx] = eps
+    fd = (O.spectral_loss(t, a + d, dtype=np.float64, **kw) - O.spectral_loss(t, a - d, dtype=np.float64, **kw)) / (2 * eps)
+    np.testing.assert_allclose(g[idx], fd, rtol=1e-4, atol=1e-9)

@@ -27,8 +27,15 @@ steps = 100
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): out = loss(t, a)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+ag = a.clone().requires_grad_(True)
+for _ in range(5):
+  ag.grad = None; loss(t, ag).backward()
+torch.cuda.synchronize(); t1 = time.perf_counter()
+for _ in range(50):
+  ag.grad = None; loss(t, ag).backward()
+torch.cuda.synchronize(); dt_fb = (time.perf_counter() - t1) / 50
 alg = 4.0 * 2 * B * N                  # both signals read once (the 6 scales x 4 overlaps re-read from L2)
 print(json.dumps({'workload': 'SpectralLoss(mag+logmag, 6 scales) batch=%d, %d samples' % (B, N),
-                  'ms_per_call': dt * 1e3, 'Msamples_per_s': B * N / dt / 1e6,
+                  'ms_per_call': dt * 1e3, 'ms_per_fwd_bwd': dt_fb * 1e3, 'Msamples_per_s': B * N / dt / 1e6,
                   'kernel_us': {k: v[0] / v[1] * 1e3 for k, v in bd.items()},
                   'algorithmic_bytes': alg, 'hbm_frac': alg / dt / 8e12}))
