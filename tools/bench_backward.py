@@ -18,14 +18,18 @@ mags = ddsp.core.tf_float32(rng.standard_normal((B, F, M))).requires_grad_(True)
 g = ddsp.core.tf_float32(rng.standard_normal((B, N)))
 harm = ddsp.synths.Harmonic(n_samples=N)
 noise = ddsp.synths.FilteredNoise(n_samples=N, window_size=0)
+spec = ddsp.losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)       # ae.gin:36-41
 def step(with_noise):
   amps.grad = hd.grad = mags.grad = None
   y = harm(amps, hd, f0)
   if with_noise:
     y = y + noise(mags)
-  (y * g).sum().backward()
+  if with_noise == 'loss':
+    spec(g, y).backward()           # the whole differentiable path of ae.gin, every kernel native
+  else:
+    (y * g).sum().backward()
 res = {}
-for name, wn in (('harmonic', False), ('harmonic+noise', True)):
+for name, wn in (('harmonic', False), ('harmonic+noise', True), ('harmonic+noise+spectral_loss', 'loss')):
   if wn and not hasattr(noise, '_backward'):
     continue
   t_settle = time.perf_counter()
