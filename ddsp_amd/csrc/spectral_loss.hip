@@ -21,7 +21,128 @@
 namespace ddsp {
 
 constexpr int kSlPoints = 4096;        // complex points per block (32 KB of LDS)
-constexpr int kSlThreads = 1024;      // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
+constexpr int kSlThreads = 512;       // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
+
+// ---- the H-point transforms of all frames of a block, in place in LDS -----------------------------
+// H = 2^L.  Forward = decimation in frequency: one radix-2 stage first when L is odd, then radix-4
+// stages (half the stages, barriers and twiddles of a radix-2 transform).  Bin k ends up at sl_pos(k).
+// The inverse is the algebraic inverse of those stages in reverse order, unscaled (H times the true
+// inverse).  When every stage is radix-4 and a frame's H/4 butterflies fit one wavefront (S = 128,
+// 512) the same wavefront reads and writes a frame in every stage: a wavefront-level wait replaces
+// the block barrier between stages.
+template <int H>
+struct SlPlan {
+  static constexpr int L = __builtin_ctz(H);
+  static constexpr bool kOdd = (L & 1) != 0;
+  static constexpr int M = kOdd ? H / 2 : H;              // the radix-4 part
+  static constexpr bool kWaveLocal = !kOdd && (H / 4 <= 64);
+};
+
+template <int H>
+__device__ __forceinline__ void sl_stage_sync() {
+  if (SlPlan<H>::kWaveLocal) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int H>
+__device__ __forceinline__ int sl_pos(int k) {             // where bin k sits after sl_forward
+  int p = 0, kk = k, m = H;
+  if (SlPlan<H>::kOdd) { p = (kk & 1) * (m / 2); kk >>= 1; m >>= 1; }
+#pragma unroll
+  for (int st = 0; st < SlPlan<H>::L / 2; ++st) { p += (kk & 3) * (m / 4); kk >>= 2; m >>= 2; }
+  return p;
+}
+
+__device__ __forceinline__ float2 sl_cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 sl_cmulc(float2 a, float2 b) {        // a * conj(b)
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+
+// frames g_lo .. g_lo + n_fr - 1 (H points each) of the array s
+template <int H>
+__device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
+  constexpr int LOG2H = SlPlan<H>::L;
+  if (SlPlan<H>::kOdd) {
+    constexpr int half = H / 2;
+    for (int t = tid; t < n_fr * half; t += kSlThreads) {
+      const int g = (t >> (LOG2H - 1)) + g_lo, pos = t & (half - 1);
+      const int i0 = (g << LOG2H) + pos;
+      const float2 a = s[i0], b = s[i0 + half];
+      const float rev = (float)pos * (1.0f / (float)H);
+      const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));   // conj of the twiddle
+      s[i0] = make_float2(a.x + b.x, a.y + b.y);
+      s[i0 + half] = sl_cmulc(make_float2(a.x - b.x, a.y - b.y), w);
+    }
+    sl_stage_sync<H>();
+  }
+#pragma unroll 1
+  for (int q = SlPlan<H>::M / 4; q >= 1; q >>= 2) {
+    const float inv_len = 0.25f / (float)q;
+    for (int t = tid; t < n_fr * (H / 4); t += kSlThreads) {
+      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+      const int pos = r & (q - 1);
+      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+      const float2 a = s[i0], b = s[i0 + q], c = s[i0 + 2 * q], d = s[i0 + 3 * q];
+      const float rev = (float)pos * inv_len;
+      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
+      const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
+      const float2 t2 = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
+      const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
+      s[i0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      s[i0 + q] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
+      s[i0 + 2 * q] = sl_cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
+      s[i0 + 3 * q] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+    }
+    sl_stage_sync<H>();
+  }
+}
+
+template <int H>
+__device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_lo) {
+  constexpr int LOG2H = SlPlan<H>::L;
+#pragma unroll 1
+  for (int q = 1; q <= SlPlan<H>::M / 4; q <<= 2) {
+    const float inv_len = 0.25f / (float)q;
+    for (int t = tid; t < n_fr * (H / 4); t += kSlThreads) {
+      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+      const int pos = r & (q - 1);
+      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+      const float rev = (float)pos * inv_len;
+      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
+      const float2 y0 = s[i0], y1 = sl_cmul(s[i0 + q], w1), y2 = sl_cmul(s[i0 + 2 * q], w2),
+                   y3 = sl_cmul(s[i0 + 3 * q], w3);
+      const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), t2 = make_float2(y0.x - y2.x, y0.y - y2.y);
+      const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
+      const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
+      s[i0] = make_float2(t0.x + t1.x, t0.y + t1.y);
+      s[i0 + 2 * q] = make_float2(t0.x - t1.x, t0.y - t1.y);
+      s[i0 + q] = make_float2(t2.x + bd.x, t2.y + bd.y);
+      s[i0 + 3 * q] = make_float2(t2.x - bd.x, t2.y - bd.y);
+    }
+    sl_stage_sync<H>();
+  }
+  if (SlPlan<H>::kOdd) {
+    constexpr int half = H / 2;
+    for (int t = tid; t < n_fr * half; t += kSlThreads) {
+      const int g = (t >> (LOG2H - 1)) + g_lo, pos = t & (half - 1);
+      const int i0 = (g << LOG2H) + pos;
+      const float rev = (float)pos * (1.0f / (float)H);
+      const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      const float2 pp = s[i0], qw = sl_cmul(s[i0 + half], w);  // undo (a+b, (a-b) conj(w))
+      s[i0] = make_float2(pp.x + qw.x, pp.y + qw.y);
+      s[i0 + half] = make_float2(pp.x - qw.x, pp.y - qw.y);
+    }
+    sl_stage_sync<H>();
+  }
+}
 
 template <int S>
 __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target,
@@ -57,44 +178,14 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
     s[e] = v;
   }
   __syncthreads();
-  // ---- radix-2 DIF FFT (H points) of every frame, in place; bins end up bit-reversed ---------------
-#pragma unroll 1
-  for (int half = H / 2; half >= 1; half >>= 1) {
-    const float inv_len = 0.5f / (float)half;
-    float2 va[kSlPoints / 2 / kSlThreads], vb[kSlPoints / 2 / kSlThreads];
-    int idx[kSlPoints / 2 / kSlThreads];
-#pragma unroll
-    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
-      const int t = tid + kSlThreads * u;                      // butterfly over the whole block
-      const int g = t >> (LOG2H - 1), r = t & (H / 2 - 1);     // g runs over the 2G frames of both signals
-      const int pos = r & (half - 1);
-      idx[u] = (g << LOG2H) + ((r - pos) << 1) + pos;
-      va[u] = s[idx[u]];
-      vb[u] = s[idx[u] + half];
-    }
-#pragma unroll
-    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
-      const int pos = (tid + kSlThreads * u) & (half - 1);
-      const float rev = (float)pos * inv_len;                  // revolutions, exact
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      const float2 d = make_float2(va[u].x - vb[u].x, va[u].y - vb[u].y);
-      va[u] = make_float2(va[u].x + vb[u].x, va[u].y + vb[u].y);
-      vb[u] = make_float2(fmaf(d.x, c, d.y * sn), fmaf(d.y, c, -d.x * sn));      // d * exp(-2 pi i rev)
-    }
-#pragma unroll
-    for (int u = 0; u < kSlPoints / 2 / kSlThreads; ++u) {
-      s[idx[u]] = va[u];
-      s[idx[u] + half] = vb[u];
-    }
-    __syncthreads();
-  }
+  sl_forward<H>(s, tid, 2 * G, 0);
+  if (SlPlan<H>::kWaveLocal) __syncthreads();                  // the bins of a frame are read by other wavefronts
   // ---- untangle, magnitudes of bins 0 .. S/2, L1 terms ---------------------------------------------
   float dm = 0.0f, dl = 0.0f;
   for (int e = tid; e < G * (H + 1); e += kSlThreads) {
     const int g = e / (H + 1), k = e - g * (H + 1);
     if (f0 + g < n_frames) {
-      const int ia = (int)(__brev((unsigned)(k & (H - 1))) >> (32 - LOG2H));
-      const int ib = (int)(__brev((unsigned)((H - k) & (H - 1))) >> (32 - LOG2H));
+      const int ia = sl_pos<H>(k & (H - 1)), ib = sl_pos<H>((H - k) & (H - 1));
       const float rev = (float)k * (1.0f / (float)S);
       const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
       float mag[2];
@@ -163,30 +254,15 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
     s[e] = v;
   }
   __syncthreads();
-#pragma unroll 1
-  for (int half = H / 2; half >= 1; half >>= 1) {              // forward DIF, as stft_l1_kernel
-    const float inv_len = 0.5f / (float)half;
-    for (int t = tid; t < kSlPoints / 2; t += kSlThreads) {
-      const int g = t >> (LOG2H - 1), r = t & (H / 2 - 1);
-      const int pos = r & (half - 1);
-      const int i0 = (g << LOG2H) + ((r - pos) << 1) + pos;
-      const float2 a = s[i0], bb = s[i0 + half];
-      const float rev = (float)pos * inv_len;
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      const float2 d = make_float2(a.x - bb.x, a.y - bb.y);
-      s[i0] = make_float2(a.x + bb.x, a.y + bb.y);
-      s[i0 + half] = make_float2(fmaf(d.x, c, d.y * sn), fmaf(d.y, c, -d.x * sn));
-    }
-    __syncthreads();
-  }
+  sl_forward<H>(s, tid, 2 * G, 0);
+  if (SlPlan<H>::kWaveLocal) __syncthreads();
   // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
   const float up = grad_loss[0];
   const float ms = mag_scale * up, ls = log_scale * up;        // weight / count (per size), times dL/dloss
   for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {
     const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);     // pair (k, H-k), k = 0 .. H/2
     if (f0 + g >= n_frames) continue;
-    const int ia = (int)(__brev((unsigned)k) >> (32 - LOG2H));
-    const int ib = (int)(__brev((unsigned)((H - k) & (H - 1))) >> (32 - LOG2H));
+    const int ia = sl_pos<H>(k), ib = sl_pos<H>((H - k) & (H - 1));
     const float rev = (float)k * (1.0f / (float)S);
     const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
     float2 x1[2], x2[2];                                        // X[k], X[H-k] of target (0) and audio (1)
@@ -231,23 +307,9 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
     }
   }
   __syncthreads();
-  // ---- unscaled inverse of the DIF stages over the audio frames ---------------------------------------
-#pragma unroll 1
-  for (int half = 1; half <= H / 2; half <<= 1) {
-    const float inv_len = 0.5f / (float)half;
-    for (int t = tid; t < kSlPoints / 4; t += kSlThreads) {     // the audio half: G frames x H/2 butterflies
-      const int g = (t >> (LOG2H - 1)) + G, r = t & (H / 2 - 1);
-      const int pos = r & (half - 1);
-      const int i0 = (g << LOG2H) + ((r - pos) << 1) + pos;
-      const float2 pp = s[i0], q = s[i0 + half];
-      const float rev = (float)pos * inv_len;
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      const float2 qw = make_float2(fmaf(q.x, c, -q.y * sn), fmaf(q.x, sn, q.y * c));   // q * conj(w)
-      s[i0] = make_float2(pp.x + qw.x, pp.y + qw.y);
-      s[i0 + half] = make_float2(pp.x - qw.x, pp.y - qw.y);
-    }
-    __syncthreads();
-  }
+  // ---- unscaled inverse transform of the audio frames ------------------------------------------------
+  sl_inverse<H>(s, tid, G, G);
+  if (SlPlan<H>::kWaveLocal) __syncthreads();
   // ---- window, overlap-add into grad_audio: g_x[2n] = 2 Re U[n], g_x[2n+1] = 2 Im U[n] --------------
   float* __restrict__ grow = grad_audio + (size_t)b * N;
   for (int e = tid; e < G * H; e += kSlThreads) {

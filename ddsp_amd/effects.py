@@ -2,7 +2,8 @@
 
 SURVEY.md section 8(f) rank 1.  The reference convolves with one 131 072-point FFT per clip; here
 `core.fft_convolve_long` runs a partitioned overlap-save convolution with LDS-resident FFTs
-(csrc/reverb.hip).  ExpDecayReverb / FilteredNoiseReverb / FIRFilter / ModDelay are not built.
+(csrc/reverb.hip).  FilteredNoiseReverb and FIRFilter are compositions of kernels that exist;
+ExpDecayReverb and ModDelay are not built.
 """
 import torch
 
@@ -116,3 +117,60 @@ class _ReverbFunction(torch.autograd.Function):
     if gi is not None:
       gi = gi.reshape(ctx.ir_shape)
     return ga, gi, None
+
+
+class FilteredNoiseReverb(Reverb):
+  """Impulse response = the output of a filtered-noise synth (ddsp/effects.py:200-278).
+
+  `seed` is this package's extension (FilteredNoise draws Philox noise keyed by it).
+  """
+
+  def __init__(self, trainable=False, reverb_length=48000, window_size=257, n_frames=1000,
+               n_filter_banks=16, scale_fn=core.exp_sigmoid, initial_bias=-3.0, add_dry=True,
+               name='filtered_noise_reverb', seed=0):
+    from ddsp_amd import synths          # effects <- synths, as in the reference
+    super().__init__(name=name, add_dry=add_dry, trainable=trainable)
+    self._n_frames = n_frames
+    self._n_filter_banks = n_filter_banks
+    self._magnitudes = None
+    self._synth = synths.FilteredNoise(n_samples=reverb_length, window_size=window_size,
+                                       scale_fn=scale_fn, initial_bias=initial_bias, seed=seed)
+
+  def build(self, unused_input_shape=None, device=None, seed=0):
+    """N(0, 1e-2) magnitudes [n_frames, n_filter_banks] when trainable (effects.py:238-247)."""
+    if self.trainable and self._magnitudes is None:
+      gen = torch.Generator(device='cpu').manual_seed(seed)
+      m = torch.randn(self._n_frames, self._n_filter_banks, generator=gen, dtype=torch.float32) * 1e-2
+      self._magnitudes = m.to(device if device is not None else core._device())
+    self.built = True
+
+  def get_controls(self, audio, magnitudes=None):
+    """Dry audio and the impulse response synthesised from `magnitudes` (effects.py:249-278)."""
+    if self.trainable:
+      if not self.built:
+        self.build(device=tf_float32(audio).device)
+      magnitudes = self._magnitudes[None, :]
+    elif magnitudes is None:
+      raise ValueError('Must provide "magnitudes" tensor if '
+                       'FilteredNoiseReverb trainable=False.')
+    ir = self._synth(magnitudes)          # [batch or 1, reverb_length]; a batch-1 IR is tiled in the kernel
+    return {'audio': audio, 'ir': ir}
+
+
+class FIRFilter(processors.Processor):
+  """Linear time-varying finite impulse response (LTV-FIR) filter (ddsp/effects.py:283-322)."""
+
+  def __init__(self, window_size=257, scale_fn=core.exp_sigmoid, name='fir_filter'):
+    super().__init__(name=name)
+    self.window_size = window_size
+    self.scale_fn = scale_fn
+
+  def get_controls(self, audio, magnitudes):
+    """Scaled magnitudes [batch, time, n_filter_banks] next to the dry audio."""
+    if self.scale_fn is not None:
+      magnitudes = self.scale_fn(magnitudes)
+    return {'audio': audio, 'magnitudes': magnitudes}
+
+  def get_signal(self, audio, magnitudes):
+    """Filter audio [batch, n_samples] with the time-varying FIR designed from `magnitudes`."""
+    return core.frequency_filter(audio, magnitudes, window_size=self.window_size)

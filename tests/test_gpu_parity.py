@@ -925,3 +925,24 @@ def test_training_loop_with_native_loss(ddsp):                       # ae.gin: s
     opt.step()
     history.append(float(loss.detach()))
   assert history[-1] < 0.7 * history[0], history
+
+
+def test_fir_filter_and_filtered_noise_reverb(ddsp):                 # effects.py:200-322
+  rng = np.random.default_rng(17)
+  b, n, f, m = 2, 3200, 50, 33
+  audio = rng.standard_normal((b, n)).astype(np.float32)
+  mags = rng.standard_normal((b, f, m)).astype(np.float32)
+  out = npy(ddsp.effects.FIRFilter(window_size=33)(audio, mags))
+  ref = O.frequency_filter(audio, O.exp_sigmoid(mags, dtype=np.float64), window_size=33, dtype=np.float64)
+  np.testing.assert_allclose(out, ref, rtol=0, atol=noise_tol(ref))
+  # FilteredNoiseReverb: IR = FilteredNoise(n_samples=reverb_length)(magnitudes), then Reverb
+  l, fr, nb = 2400, 50, 16
+  rmags = rng.standard_normal((b, fr, nb)).astype(np.float32)
+  rev = ddsp.effects.FilteredNoiseReverb(reverb_length=l, window_size=17, n_frames=fr, n_filter_banks=nb, seed=5)
+  got = npy(rev(audio, rmags))
+  noise = O.device_uniform_noise(b, l, seed=5)                       # call counter 0 of the inner synth
+  ir = O.filtered_noise(rmags, noise, 17, O.exp_sigmoid, initial_bias=-3.0, dtype=np.float64)
+  ref = O.reverb(audio, ir, add_dry=True, dtype=np.float64)
+  np.testing.assert_allclose(got, ref, rtol=0, atol=reverb_tol(ref))
+  with pytest.raises(ValueError, match='Must provide "magnitudes" tensor'):
+    ddsp.effects.FilteredNoiseReverb().get_controls(audio)
