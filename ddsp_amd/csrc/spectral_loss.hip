@@ -144,6 +144,39 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
   }
 }
 
+// frames -> LDS, windowed: w[i] = 0.5 - 0.5 cos(2 pi i / S) (tf.signal.hann_window, periodic); element e
+// of the array is the sample pair (2n, 2n+1) of frame e / H (first G frames: target, then audio).
+// For H <= 512 a thread meets the same pair index n in every pass: its two window values are computed once.
+template <int S>
+__device__ __forceinline__ void sl_load_frames(float2* s, const float* __restrict__ trow,
+                                               const float* __restrict__ arow, int tid, int f0,
+                                               int n_frames, int N) {
+  constexpr int H = S / 2, G = kSlPoints / 2 / H, LOG2H = __builtin_ctz(H), HOP = S / 4;
+  constexpr bool kFixed = (kSlThreads % H) == 0;
+  float w0 = 0.f, w1 = 0.f;
+  if (kFixed) {
+    const int n2 = (tid & (H - 1)) * 2;
+    w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+    w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+  }
+  for (int e = tid; e < kSlPoints; e += kSlThreads) {
+    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;       // g2 < G: target frame, else audio frame
+    const int g = g2 >= G ? g2 - G : g2;
+    const int n = (f0 + g) * HOP + n2;
+    float2 v = make_float2(0.f, 0.f);
+    if (f0 + g < n_frames && n < N) {
+      const float* __restrict__ row = g2 >= G ? arow : trow;
+      if (!kFixed) {
+        w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+        w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+      }
+      v.x = row[n] * w0;
+      if (n + 1 < N) v.y = row[n + 1] * w1;
+    }
+    s[e] = v;
+  }
+}
+
 template <int S>
 __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target,
                                                              const float* __restrict__ audio,
@@ -162,21 +195,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   const int f0 = blockIdx.x * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-  // ---- frames -> LDS, windowed: w[i] = 0.5 - 0.5 cos(2 pi i / S) (tf.signal.hann_window, periodic)
-  for (int e = tid; e < kSlPoints; e += kSlThreads) {
-    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;       // g2 < G: target frame, else audio frame
-    const int g = g2 >= G ? g2 - G : g2;
-    const int n = (f0 + g) * HOP + n2;
-    float2 v = make_float2(0.f, 0.f);
-    if (f0 + g < n_frames && n < N) {
-      const float* __restrict__ row = g2 >= G ? arow : trow;
-      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
-      v.x = row[n] * w0;
-      if (n + 1 < N) v.y = row[n + 1] * w1;
-    }
-    s[e] = v;
-  }
+  sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
   __syncthreads();
   sl_forward<H>(s, tid, 2 * G, 0);
   if (SlPlan<H>::kWaveLocal) __syncthreads();                  // the bins of a frame are read by other wavefronts
@@ -239,20 +258,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
   const int f0 = blockIdx.x * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-  for (int e = tid; e < kSlPoints; e += kSlThreads) {
-    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;
-    const int g = g2 >= G ? g2 - G : g2;
-    const int n = (f0 + g) * HOP + n2;
-    float2 v = make_float2(0.f, 0.f);
-    if (f0 + g < n_frames && n < N) {
-      const float* __restrict__ row = g2 >= G ? arow : trow;
-      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
-      v.x = row[n] * w0;
-      if (n + 1 < N) v.y = row[n + 1] * w1;
-    }
-    s[e] = v;
-  }
+  sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
   __syncthreads();
   sl_forward<H>(s, tid, 2 * G, 0);
   if (SlPlan<H>::kWaveLocal) __syncthreads();
