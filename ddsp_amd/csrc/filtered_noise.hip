@@ -918,6 +918,7 @@ namespace ddsp {
 
 struct NoiseBwdArgs {
   int N, F, fs, start, tile_frames, scale;
+  int L, Lpad, M, window_size;   // taps per frame, rounded up to 128; magnitudes per frame; Hann size argument
   float bias;
   uint32_t k0, k1;
   uint64_t batch_offset;
@@ -925,14 +926,14 @@ struct NoiseBwdArgs {
 
 __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __restrict__ x /*[B,N] or null*/,
                                                              const float* __restrict__ grad_audio,
-                                                             float* __restrict__ dh /*[B,F,128]*/,
+                                                             float* __restrict__ dh /*[B,F,L]*/,
                                                              NoiseBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float s_g[];        // gz[f0*fs .. (f0+tile)*fs + 128)
+  extern __shared__ __attribute__((aligned(16))) float s_g[];        // gz[f0*fs .. (f0+tile)*fs + Lpad)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * p.tile_frames;
   const int nfr = min(p.tile_frames, p.F - f0);
-  const int span = nfr * p.fs + 128;
+  const int span = nfr * p.fs + p.Lpad;
   const float* __restrict__ g = grad_audio + (size_t)b * p.N;
   for (int e = tid; e < span + 64; e += 256) {             // + 64 zeros: the last 64-sample chunk of a frame
     const int n = f0 * p.fs + e - p.start;                 // whose size is not a multiple of 64 reads past the span
@@ -941,23 +942,70 @@ __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __rest
   __syncthreads();
   for (int q = wave; q < nfr; q += 4) {
     const int f = f0 + q;
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (int c = 0; c < p.fs; c += 64) {                   // 64 samples of the frame per chunk
-      const int i = f * p.fs + c + lane;                   // this lane's sample
-      float xv = 0.0f;
-      if (c + lane < p.fs && i < p.N)
-        xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1);
-      const float* __restrict__ win = s_g + q * p.fs + c + lane;      // + l: gz[i_l + t], t = lane
+    for (int kc = 0; kc < p.L; kc += 128) {                // taps kc + lane and kc + 64 + lane (L = 128: one trip)
+      float acc0 = 0.0f, acc1 = 0.0f;
+      for (int c = 0; c < p.fs; c += 64) {                 // 64 samples of the frame per chunk
+        const int i = f * p.fs + c + lane;                 // this lane's sample
+        float xv = 0.0f;
+        if (c + lane < p.fs && i < p.N)
+          xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1);
+        const float* __restrict__ win = s_g + q * p.fs + c + kc + lane;    // + l: gz[i_l + t], t = kc + lane
 #pragma unroll
-      for (int l = 0; l < 64; ++l) {
-        const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l));
-        acc0 = fmaf(xs, win[l], acc0);
-        acc1 = fmaf(xs, win[l + 64], acc1);
+        for (int l = 0; l < 64; ++l) {
+          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l));
+          acc0 = fmaf(xs, win[l], acc0);
+          acc1 = fmaf(xs, win[l + 64], acc1);
+        }
       }
+      float* __restrict__ o = dh + ((size_t)b * p.F + f) * p.L + kc;
+      if (kc + lane < p.L) o[lane] = acc0;
+      if (kc + 64 + lane < p.L) o[lane + 64] = acc1;
     }
-    float* __restrict__ o = dh + ((size_t)b * p.F + f) * 128;
-    o[lane] = acc0;
-    o[lane + 64] = acc1;
+  }
+}
+
+// Any band count / window: dL/d mag[m] = (c_m / L0) sum_kappa dh[kappa] w(kappa) cos(2 pi m n(kappa) / L0),
+// the transpose of noise_ir_kernel (c_m = 1 for the DC and Nyquist bins, 2 otherwise), times exp_sigmoid'.
+__global__ __launch_bounds__(256) void noise_bwd_mags_generic_kernel(const float* __restrict__ mag,
+                                                                     const float* __restrict__ dh,
+                                                                     float* __restrict__ grad_mag,
+                                                                     long rows, NoiseBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const IrGeom g = ir_geom(p.M, p.window_size);
+  float* s_cos = smem;                 // [L0]
+  float* s_dw = smem + g.L0;           // [L]  dh * window
+  int* s_n = reinterpret_cast<int*>(smem + g.L0 + g.L);    // [L] zero-phase sample index of each tap
+  for (int i = threadIdx.x; i < g.L0; i += 256) s_cos[i] = cospif(2.0f * (float)i / (float)g.L0);
+  for (int kappa = threadIdx.x; kappa < g.L; kappa += 256) {
+    int n, widx;
+    ir_tap_map(g, kappa, &n, &widx);
+    s_n[kappa] = n;
+  }
+  const float inv_L0 = 1.0f / (float)g.L0;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    for (int kappa = threadIdx.x; kappa < g.L; kappa += 256) {
+      int n, widx;
+      ir_tap_map(g, kappa, &n, &widx);
+      const float w = (widx < 0) ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)g.ws);
+      s_dw[kappa] = w * dh[(size_t)row * g.L + kappa];
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < p.M; m += 256) {
+      float acc = 0.0f;
+      for (int kappa = 0; kappa < g.L; ++kappa) {
+        const int idx = (int)(((long)m * s_n[kappa]) % g.L0);
+        acc = fmaf(s_dw[kappa], s_cos[idx], acc);
+      }
+      acc *= ((m == 0 || m == p.M - 1) ? 1.0f : 2.0f) * inv_L0;
+      const size_t at = (size_t)row * p.M + m;
+      if (p.scale) {
+        const float xr = mag[at] + p.bias;
+        const float y = exp_sigmoid(xr, 2.302585092994046f, 2.0f, 1e-7f);
+        acc *= 2.302585092994046f * (y - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-xr)));
+      }
+      grad_mag[at] = acc;
+    }
   }
 }
 
@@ -1016,8 +1064,8 @@ __global__ __launch_bounds__(256) void noise_bwd_mags_kernel(const float* __rest
 
 extern "C" size_t ddsp_filtered_noise_backward_workspace_bytes(int B, int F, int M, int N) {
   (void)N;
-  if (B <= 0 || F <= 0 || M != 65) return 0;
-  return (size_t)B * F * 128 * sizeof(float);
+  if (B <= 0 || F <= 0 || M < 2) return 0;
+  return (size_t)B * F * (size_t)(2 * (M - 1)) * sizeof(float);     // tap gradients, L <= 2 (M - 1)
 }
 
 extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const float* noise,
@@ -1030,17 +1078,18 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
   if (B <= 0 || F <= 0 || M < 2 || N <= 0) return DDSP_ERR_BAD_SHAPE;
   const IrGeom g = ir_geom(M, window_size);
   const int fs = (N + F - 1) / F;
-  if (M != 65 || g.padding != 0 || g.L != 128 || fs < 64 || (fs % 16) != 0 || fs > 4096 ||
-      (N + fs - 1) / fs != F || B > 65535)
-    return DDSP_ERR_UNSUPPORTED;                            // the shapes the fused forward kernel takes
+  const int start = (g.L - 1) / 2 - 1;
+  if ((N + fs - 1) / fs != F || B > 65535 || start < 0 || fs > 8192 || g.L0 > 8192) return DDSP_ERR_UNSUPPORTED;
   if (workspace_bytes < ddsp_filtered_noise_backward_workspace_bytes(B, F, M, N) ||
       ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   NoiseBwdArgs p;
-  p.N = N; p.F = F; p.fs = fs; p.start = (g.L - 1) / 2 - 1;
-  p.tile_frames = fs <= 512 ? 8192 / fs : 1;                // <= 8192 + 128 gradient samples staged per block
+  p.N = N; p.F = F; p.fs = fs; p.start = start;
+  p.L = g.L; p.Lpad = (g.L + 127) & ~127; p.M = M; p.window_size = window_size;
+  p.tile_frames = 8192 / fs;                                // <= 8192 + Lpad gradient samples staged per block
   if (p.tile_frames > 32) p.tile_frames = 32;
+  if (p.tile_frames < 1) p.tile_frames = 1;
   p.scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
   p.bias = initial_bias;
   p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.batch_offset = batch_offset;
@@ -1048,14 +1097,26 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
   {
     ProfileScope prof(kNoiseBwdTaps, st);
     const dim3 grid((unsigned)((F + p.tile_frames - 1) / p.tile_frames), (unsigned)B);
-    const size_t lds = ((size_t)p.tile_frames * fs + 128 + 64) * sizeof(float);
+    const size_t lds = ((size_t)p.tile_frames * fs + p.Lpad + 64) * sizeof(float);
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute((const void*)noise_bwd_taps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      return true;
+    }();
+    (void)attr_set;
     hipLaunchKernelGGL(noise_bwd_taps_kernel, grid, dim3(256), lds, st, noise, grad_audio, dh, p);
   }
   {
     ProfileScope prof(kNoiseBwdMags, st);
     const long rows = (long)B * F;
-    hipLaunchKernelGGL(noise_bwd_mags_kernel, dim3((unsigned)((rows + kBwdMagRows - 1) / kBwdMagRows)), dim3(256), 0, st,
-                       magnitudes, (const float*)dh, grad_magnitudes, rows, p);
+    if (M == 65 && g.padding == 0) {                        // the fused forward kernel's shape: even / odd folding
+      hipLaunchKernelGGL(noise_bwd_mags_kernel, dim3((unsigned)((rows + kBwdMagRows - 1) / kBwdMagRows)), dim3(256), 0, st,
+                         magnitudes, (const float*)dh, grad_magnitudes, rows, p);
+    } else {
+      const size_t lds = ((size_t)g.L0 + 2 * (size_t)g.L) * sizeof(float);
+      const unsigned blocks = (unsigned)(rows < 8192 ? rows : 8192);
+      hipLaunchKernelGGL(noise_bwd_mags_generic_kernel, dim3(blocks), dim3(256), lds, st, magnitudes,
+                         (const float*)dh, grad_magnitudes, rows, p);
+    }
   }
   return check_launch();
 }

@@ -99,3 +99,31 @@ class Add(Processor):
                                   core._stream())
     _lib.check(rc, 'ddsp_add_f32')
     return out
+
+
+class Crop(Processor):
+  """Remove audio generated from padding frames (ddsp/processors.py:237-263; last node of vst.gin's DAG).
+
+  Host plumbing: a slice of the tensor, no kernel (and so transparent to torch.autograd).
+  """
+
+  def __init__(self, frame_size, crop_location='back', name='crop'):
+    super().__init__(name=name)
+    self.frame_size = frame_size
+    self.crop_location = crop_location
+
+  def get_controls(self, audio):
+    return {'audio': audio}
+
+  def get_signal(self, audio):
+    audio = core.tf_float32(audio)
+    half = int(self.frame_size // 2)                       # symmetric, even total
+    total = 2 * half
+    if self.crop_location == 'front':
+      return audio[:, total:]
+    if self.crop_location == 'center':
+      return audio[:, half:-half]
+    if self.crop_location == 'back':
+      return audio[:, :-total]
+    raise ValueError(f'Crop_location: ({self.crop_location}), must be '
+                     '"front", "center", or "back".')

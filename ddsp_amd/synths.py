@@ -237,8 +237,8 @@ class FilteredNoise(processors.Processor):
   def call(self, magnitudes, return_outputs_dict=False, noise=None, **kwargs):
     """get_signal(**get_controls(magnitudes)) as one fused C-ABI call.
 
-    When `magnitudes` requires grad the call is recorded for torch.autograd (shapes of the fused
-    kernel only: 65 bands, window_size 0 or >= 128); backward() regenerates the same noise.
+    When `magnitudes` requires grad the call is recorded for torch.autograd; backward()
+    regenerates the same noise.
     """
     for k in ['training', 'mask']:
       kwargs.pop(k, None)
@@ -269,8 +269,6 @@ class FilteredNoise(processors.Processor):
     n = int(self.n_samples)
     lib = _lib.load()
     nbytes = core.cached_workspace_bytes('ddsp_filtered_noise_backward_workspace_bytes', b, f, m, n)
-    if nbytes == 0:
-      raise NotImplementedError('FilteredNoise backward is built for 65 noise bands only, got {}'.format(m))
     ws = self._ws_bwd.get(nbytes, magnitudes.device)
     grad_audio = core.tf_float32(grad_audio)
     grad_mag = torch.empty_like(magnitudes)
@@ -280,8 +278,8 @@ class FilteredNoise(processors.Processor):
         int(self.window_size), float(self.initial_bias),
         _lib.NOISE_SCALE_EXP_SIGMOID if self.scale_fn is not None else 0, seed, 0, core._stream())
     if rc == -3:
-      raise NotImplementedError('FilteredNoise backward is built for the shapes of the fused kernel '
-                                '(65 bands, full window, frame size a multiple of 16 >= 64)')
+      raise NotImplementedError('FilteredNoise backward needs n_samples / n_frames <= 8192, at most 4097 '
+                                'bands and an impulse response of at least 3 taps')
     _lib.check(rc, 'ddsp_filtered_noise_backward_f32')
     return grad_mag
 

@@ -185,8 +185,8 @@ int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* 
  * Backward pass of ddsp_filtered_noise_f32: dL/d magnitudes [B,F,M] from grad_audio [B,N]
  * (the gradient tf.GradientTape forms through ddsp/synths.py:165-196).  `noise` as in the forward
  * call: the tensor that was supplied, or NULL with the same seed / batch_offset so that the noise is
- * regenerated.  Only the shapes of the fused forward kernel (M = 65, full window) are built:
- * others return DDSP_ERR_UNSUPPORTED.  workspace: ddsp_filtered_noise_backward_workspace_bytes.
+ * regenerated.  Any band count / window (M = 65 with the full window has its own fast kernel).
+ * workspace: ddsp_filtered_noise_backward_workspace_bytes.
  */
 size_t ddsp_filtered_noise_backward_workspace_bytes(int B, int F, int M, int N);
 int ddsp_filtered_noise_backward_f32(const float* magnitudes, const float* noise,

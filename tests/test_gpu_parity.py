@@ -787,7 +787,7 @@ def test_filtered_noise_backward_vs_analytic_oracle(ddsp, batch, n_frames, n, sc
                                                           dtype=np.float64), rtol=0, atol=2e-6 + 1e-5)
 
 
-def test_synth_backward_through_add_and_unsupported_shapes(ddsp):
+def test_synth_backward_through_add(ddsp):
   rng = np.random.default_rng(4)
   b, f, k, n = 2, 50, 60, 3200
   amps = ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True)
@@ -807,9 +807,6 @@ def test_synth_backward_through_add_and_unsupported_shapes(ddsp):
     noise2 = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)     # same seed / call counter as `noise` had
     y2 = harm(amps - 50.0 * amps.grad, hd - 50.0 * hd.grad, f0) + noise2(mags - 50.0 * mags.grad)
     assert float(((y2 - target) ** 2).mean()) < float(loss)
-  with pytest.raises(NotImplementedError):
-    m33 = ddsp.core.tf_float32(rng.standard_normal((b, f, 33))).requires_grad_(True)
-    ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(m33).sum().backward()
 
 
 def test_processor_group_is_trainable(ddsp):                         # ae.gin DAG + trainers.py:162-171
@@ -946,3 +943,50 @@ def test_fir_filter_and_filtered_noise_reverb(ddsp):                 # effects.p
   np.testing.assert_allclose(got, ref, rtol=0, atol=reverb_tol(ref))
   with pytest.raises(ValueError, match='Must provide "magnitudes" tensor'):
     ddsp.effects.FilteredNoiseReverb().get_controls(audio)
+
+
+@pytest.mark.parametrize('batch,n_frames,m,n,window_size,scale', [
+    (2, 25, 33, 1600, 17, True),        # cropped IR (window < 2(M-1)), 33 taps
+    (1, 500, 32, 24000, 257, True),     # vst.gin's FilteredNoiseReverb shape: frame size 48, 62 taps
+    (2, 7, 9, 100, 0, False),           # ragged tail, tiny IR, scale_fn=None
+    (2, 10, 129, 2560, 0, True)])       # 256 taps: two tap chunks per frame
+def test_filtered_noise_backward_generic_shapes(ddsp, batch, n_frames, m, n, window_size, scale):
+  rng = np.random.default_rng(m)
+  mags = (rng.standard_normal((batch, n_frames, m)) + (2.0 if scale else 0.0)).astype(np.float32)
+  if not scale:
+    mags = np.abs(mags)
+  noise = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=window_size,
+                                    scale_fn=ddsp.core.exp_sigmoid if scale else None, initial_bias=-3.0)
+  tm = ddsp.core.tf_float32(mags).requires_grad_(True)
+  (synth(tm, noise=noise) * ddsp.core.tf_float32(g)).sum().backward()
+  ref = O.filtered_noise_backward(mags, noise, g, window_size, O.exp_sigmoid if scale else None, initial_bias=-3.0)
+  np.testing.assert_allclose(npy(tm.grad), ref, rtol=0, atol=1e-6 + 5e-5 * np.abs(ref).max())
+
+
+def test_vst_dag_with_trainable_filtered_noise_reverb_trains(ddsp):   # gin/models/vst/vst.gin:66-87
+  rng = np.random.default_rng(30)
+  b, f, k, m, n = 2, 50, 60, 65, 3200
+  feats = {'amps': ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True),
+           'harmonic_distribution': ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True),
+           'f0_hz': ddsp.core.tf_float32(200 + rng.standard_normal((b, f, 1))),
+           'noise_magnitudes': ddsp.core.tf_float32(rng.standard_normal((b, f, m))).requires_grad_(True)}
+  rev = ddsp.effects.FilteredNoiseReverb(trainable=True, reverb_length=1200, n_frames=25, n_filter_banks=32,
+                                         name='reverb')
+  rev.build(device=torch.device('cuda'))
+  rev._magnitudes.requires_grad_(True)
+  crop = ddsp.processors.Crop(frame_size=64, crop_location='back')
+  dag = [(ddsp.synths.Harmonic(n_samples=n), ['amps', 'harmonic_distribution', 'f0_hz']),
+         (ddsp.synths.FilteredNoise(n_samples=n, window_size=0), ['noise_magnitudes']),
+         (ddsp.processors.Add(), ['filtered_noise/signal', 'harmonic/signal']),
+         (rev, ['add/signal']),
+         (crop, ['reverb/signal'])]
+  group = ddsp.processors.ProcessorGroup(dag=dag)
+  audio = group(feats)
+  assert tuple(audio.shape) == (b, n - 64) and audio.requires_grad
+  target = ddsp.core.tf_float32(0.1 * rng.standard_normal((b, n - 64)))
+  loss = ddsp.losses.SpectralLoss(fft_sizes=(256, 128, 64), logmag_weight=1.0)(target, audio.contiguous())
+  loss.backward()
+  for t in (feats['amps'], feats['harmonic_distribution'], feats['noise_magnitudes'], rev._magnitudes):
+    assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0

@@ -195,3 +195,20 @@ def test_spectral_loss_host_contract():                            # losses.py:1
   assert lib.ddsp_spectral_loss_workspace_bytes(4, 64000, sizes, 2) == 4 * (63 + 63) * 16
   bad = (ctypes.c_int * 1)(1000)
   assert lib.ddsp_spectral_loss_workspace_bytes(4, 64000, bad, 1) == 0
+
+
+def test_crop_processor():                                         # processors.py:237-263
+  x = torch.arange(20, dtype=torch.float32).reshape(2, 10)
+  class _Core:                                                     # Crop only needs tf_float32: keep the test off the GPU
+    tf_float32 = staticmethod(lambda t: t)
+  import ddsp_amd.processors as P
+  old = P.core
+  P.core = _Core
+  try:
+    assert P.Crop(frame_size=5)(x).tolist() == x[:, :-4].tolist()
+    assert P.Crop(frame_size=4, crop_location='front')(x).tolist() == x[:, 4:].tolist()
+    assert P.Crop(frame_size=4, crop_location='center')(x).tolist() == x[:, 2:-2].tolist()
+    with pytest.raises(ValueError, match='must be "front", "center", or "back"'):
+      P.Crop(frame_size=4, crop_location='middle')(x)
+  finally:
+    P.core = old
