@@ -51,6 +51,9 @@ SIGNATURES = {
                                                       c_voidp]),
     'ddsp_spectral_loss_backward_f32': (c_int, [c_f32p] * 4 + [c_int, c_int, ctypes.POINTER(c_int), c_int,
                                                            c_float, c_float, c_voidp]),
+    'ddsp_spectral_loss_value_and_grad_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t, c_int, c_int,
+                                                                 ctypes.POINTER(c_int), c_int, c_float,
+                                                                 c_float, c_voidp]),
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
     'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
                                                                  const float* __restrict__ grad_loss,
                                                                  float* __restrict__ grad_audio, int N,
                                                                  int n_frames, float safe_eps,
-                                                                 float mag_scale, float log_scale) {
+                                                                 float mag_scale, float log_scale,
+                                                                 double* __restrict__ partial) {
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;
   constexpr int LOG2H = __builtin_ctz(H);
@@ -263,8 +264,11 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
   sl_forward<H>(s, tid, 2 * G, 0);
   if (SlPlan<H>::kWaveLocal) __syncthreads();
   // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
-  const float up = grad_loss[0];
+  // grad_loss == nullptr: the fused loss + gradient call - dL/dloss = 1 and the block's L1 sums go to
+  // `partial` exactly as stft_l1_kernel writes them (the frame spectra are computed once for both)
+  const float up = grad_loss ? grad_loss[0] : 1.0f;
   const float ms = mag_scale * up, ls = log_scale * up;        // weight / count (per size), times dL/dloss
+  float dm_sum = 0.0f, dl_sum = 0.0f;
   for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {
     const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);     // pair (k, H-k), k = 0 .. H/2
     if (f0 + g >= n_frames) continue;
@@ -283,8 +287,12 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       x2[sig] = make_float2(ex - wx, -(ey - wy));               // X[H-k] = conj(E - W^k O)
     }
     // dL/dX for one bin: coefficient * X_a / |X_a|
-    auto bin_grad = [&](float2 xt, float2 xa) {
+    auto bin_grad = [&](float2 xt, float2 xa, bool count) {
       const float mt = sqrtf(fmaf(xt.x, xt.x, xt.y * xt.y)), ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+      if (count) {                                              // every bin 0 .. S/2 exactly once
+        dm_sum += fabsf(mt - ma);
+        dl_sum += fabsf(__logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma <= 0.0f ? safe_eps : ma));
+      }
       if (!(ma > 0.0f)) return make_float2(0.f, 0.f);
       const float dmag = mt - ma;
       const float dlog = __logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma);
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       const float coef = -(ms * sm + ls * sl * inv) * inv;
       return make_float2(coef * xa.x, coef * xa.y);
     };
-    float2 c1 = bin_grad(x1[0], x1[1]);                         // G[k]
-    float2 c2 = bin_grad(x2[0], x2[1]);                         // G[H-k]
+    float2 c1 = bin_grad(x1[0], x1[1], true);                   // G[k]
+    float2 c2 = bin_grad(x2[0], x2[1], 2 * k != H);             // G[H-k] (the self-paired bin S/4 counts once)
     const int abase = (g + G) << LOG2H;
     if (k == 0) {                                               // bins 0 and S/2: real, C = Re G
       const float e0 = 0.5f * (c1.x + c2.x), o0 = 0.5f * (c1.x - c2.x);
@@ -327,6 +335,18 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
       unsafeAtomicAdd(&grow[n], 2.0f * u.x * w0);
       if (n + 1 < N) unsafeAtomicAdd(&grow[n + 1], 2.0f * u.y * w1);
+    }
+  }
+  if (partial) {                                               // block-uniform
+    __shared__ double red[2][kSlThreads / 64];
+    const double sm = (double)wave_sum(dm_sum), sl = (double)wave_sum(dl_sum);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sl; }
+    __syncthreads();
+    if (tid == 0) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
+      double* out = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+      out[0] = a0; out[1] = a1;
     }
   }
 }
@@ -422,30 +442,68 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 
+static int sl_backward_impl(const float* target_audio, const float* audio, const float* grad_loss,
+                            float* grad_audio, float* loss, void* workspace, size_t workspace_bytes,
+                            int B, int N, const int* fft_sizes, int n_sizes, float mag_weight,
+                            float logmag_weight, hipStream_t st) {
+  if (!target_audio || !audio || !grad_audio || !fft_sizes) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
+  double* partial = nullptr;
+  if (loss) {
+    if (!workspace) return DDSP_ERR_NULL_POINTER;
+    if (workspace_bytes < ddsp_spectral_loss_workspace_bytes(B, N, fft_sizes, n_sizes) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15))
+      return DDSP_ERR_WORKSPACE;
+    partial = (double*)workspace;
+  }
+  if (hipMemsetAsync(grad_audio, 0, (size_t)B * N * sizeof(float), st) != hipSuccess) return DDSP_ERR_LAUNCH;
+  SlFinishArgs fin;
+  fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
+  int offset = 0;
+  {
+    ProfileScope prof(kStftL1Bwd, st);
+    for (int z = 0; z < n_sizes; ++z) {
+      const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+      const double inv_elems = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+      const float inv_count = (float)inv_elems;
+      fin.offset[z] = offset; fin.count[z] = B * blocks; fin.inv_elems[z] = inv_elems;
+      double* dst = partial ? partial + 2 * (size_t)offset : nullptr;
+      const dim3 grid((unsigned)blocks, (unsigned)B);
+#define DDSP_SLB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
+                                                      target_audio, audio, grad_loss, grad_audio, N, frames, 1e-5f, \
+                                                      mag_weight * inv_count, logmag_weight * inv_count, dst); break
+      switch (S) {
+        DDSP_SLB_CASE(16); DDSP_SLB_CASE(32); DDSP_SLB_CASE(64); DDSP_SLB_CASE(128); DDSP_SLB_CASE(256);
+        DDSP_SLB_CASE(512); DDSP_SLB_CASE(1024); DDSP_SLB_CASE(2048); DDSP_SLB_CASE(4096);
+        default: return DDSP_ERR_UNSUPPORTED;
+      }
+#undef DDSP_SLB_CASE
+      offset += B * blocks;
+    }
+  }
+  if (loss)
+    hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, loss, fin);
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
 extern "C" int ddsp_spectral_loss_backward_f32(const float* target_audio, const float* audio,
                                                const float* grad_loss, float* grad_audio, int B,
                                                int N, const int* fft_sizes, int n_sizes,
                                                float mag_weight, float logmag_weight, void* stream) {
-  if (!target_audio || !audio || !grad_loss || !grad_audio || !fft_sizes) return DDSP_ERR_NULL_POINTER;
-  if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
-  if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
-  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_audio, 0, (size_t)B * N * sizeof(float), st) != hipSuccess) return DDSP_ERR_LAUNCH;
-  ProfileScope prof(kStftL1Bwd, st);
-  for (int z = 0; z < n_sizes; ++z) {
-    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
-    const float inv_count = (float)(1.0 / ((double)B * (double)frames * (double)(S / 2 + 1)));
-    const dim3 grid((unsigned)blocks, (unsigned)B);
-#define DDSP_SLB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
-                                                      target_audio, audio, grad_loss, grad_audio, N, frames, 1e-5f, \
-                                                      mag_weight * inv_count, logmag_weight * inv_count); break
-    switch (S) {
-      DDSP_SLB_CASE(16); DDSP_SLB_CASE(32); DDSP_SLB_CASE(64); DDSP_SLB_CASE(128); DDSP_SLB_CASE(256);
-      DDSP_SLB_CASE(512); DDSP_SLB_CASE(1024); DDSP_SLB_CASE(2048); DDSP_SLB_CASE(4096);
-      default: return DDSP_ERR_UNSUPPORTED;
-    }
-#undef DDSP_SLB_CASE
-  }
-  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+  if (!grad_loss) return DDSP_ERR_NULL_POINTER;
+  return sl_backward_impl(target_audio, audio, grad_loss, grad_audio, nullptr, nullptr, 0, B, N, fft_sizes,
+                          n_sizes, mag_weight, logmag_weight, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_spectral_loss_value_and_grad_f32(const float* target_audio, const float* audio,
+                                                     float* loss, float* grad_audio, void* workspace,
+                                                     size_t workspace_bytes, int B, int N,
+                                                     const int* fft_sizes, int n_sizes,
+                                                     float mag_weight, float logmag_weight,
+                                                     void* stream) {
+  if (!loss) return DDSP_ERR_NULL_POINTER;
+  return sl_backward_impl(target_audio, audio, nullptr, grad_audio, loss, workspace, workspace_bytes, B, N,
+                          fft_sizes, n_sizes, mag_weight, logmag_weight, (hipStream_t)stream);
 }

@@ -93,6 +93,24 @@ class SpectralLoss(Loss):
     _lib.check(rc, 'ddsp_spectral_loss_f32')
     return loss
 
+  def _value_and_grad(self, target_audio, audio):
+    b, n = audio.shape
+    sizes = self._sizes()
+    lib = _lib.load()
+    nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
+    if nbytes == 0:
+      raise ValueError('fft_sizes must be at most 16 powers of two in [16, 4096], got {}'.format(
+          tuple(self.fft_sizes)))
+    ws = self._ws.get(nbytes, audio.device)
+    loss = torch.empty((), dtype=torch.float32, device=audio.device)
+    grad_audio = torch.empty_like(audio)
+    rc = lib.ddsp_spectral_loss_value_and_grad_f32(
+        target_audio.data_ptr(), audio.data_ptr(), loss.data_ptr(), grad_audio.data_ptr(), ws.data_ptr(),
+        ws.numel(), b, n, sizes, len(self.fft_sizes), float(self.mag_weight), float(self.logmag_weight),
+        core._stream())
+    _lib.check(rc, 'ddsp_spectral_loss_value_and_grad_f32')
+    return loss, grad_audio
+
   def _backward(self, target_audio, audio, grad_loss):
     b, n = audio.shape
     grad_loss = core.tf_float32(grad_loss).reshape(1).contiguous()
@@ -110,11 +128,12 @@ class _SpectralLossFunction(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, target_audio, audio, loss_obj):
-    ctx.save_for_backward(target_audio, audio)
-    ctx.loss_obj = loss_obj
-    return loss_obj._forward(target_audio, audio.detach())
+    # value and gradient in one pass (the frame spectra are computed once for both)
+    loss, grad_audio = loss_obj._value_and_grad(target_audio, audio.detach())
+    ctx.save_for_backward(grad_audio)
+    return loss
 
   @staticmethod
   def backward(ctx, grad_loss):
-    target_audio, audio = ctx.saved_tensors
-    return None, ctx.loss_obj._backward(target_audio, audio.detach(), grad_loss), None
+    (grad_audio,) = ctx.saved_tensors
+    return None, grad_audio * grad_loss, None       # scaling by the upstream scalar: plumbing

@@ -263,6 +263,15 @@ int ddsp_spectral_loss_backward_f32(const float* target_audio, const float* audi
                                     const int* fft_sizes, int n_sizes, float mag_weight,
                                     float logmag_weight, void* stream);
 
+/* Loss value and dL/d audio (for dL/dloss = 1) in one pass: the frame spectra are computed once
+ * for both, which is how a training step calls it (the caller scales grad_audio by the upstream
+ * gradient).  loss: one float; workspace as ddsp_spectral_loss_f32. */
+int ddsp_spectral_loss_value_and_grad_f32(const float* target_audio, const float* audio, float* loss,
+                                          float* grad_audio, void* workspace,
+                                          size_t workspace_bytes, int B, int N,
+                                          const int* fft_sizes, int n_sizes, float mag_weight,
+                                          float logmag_weight, void* stream);
+
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);

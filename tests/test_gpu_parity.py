@@ -990,3 +990,16 @@ def test_vst_dag_with_trainable_filtered_noise_reverb_trains(ddsp):   # gin/mode
   loss.backward()
   for t in (feats['amps'], feats['harmonic_distribution'], feats['noise_magnitudes'], rev._magnitudes):
     assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+
+
+def test_spectral_loss_fused_and_separate_gradient_entries_agree(ddsp):
+  rng = np.random.default_rng(44)
+  t = ddsp.core.tf_float32(0.3 * rng.standard_normal((2, 5000)))
+  a = ddsp.core.tf_float32(0.25 * rng.standard_normal((2, 5000)))
+  loss = ddsp.losses.SpectralLoss(fft_sizes=(1024, 256, 64), logmag_weight=1.0)
+  value, grad = loss._value_and_grad(t, a)                          # ddsp_spectral_loss_value_and_grad_f32
+  sep = loss._backward(t, a, torch.ones((), device='cuda'))         # ddsp_spectral_loss_backward_f32
+  fwd = loss._forward(t, a)                                         # ddsp_spectral_loss_f32
+  np.testing.assert_allclose(float(value), float(fwd), rtol=1e-6)
+  scale = float(grad.abs().max())
+  assert float((grad - sep).abs().max()) <= 1e-5 * scale            # same kernel, atomics order only
