@@ -152,28 +152,44 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
                                                const float* __restrict__ arow, int tid, int f0,
                                                int n_frames, int N) {
   constexpr int H = S / 2, G = kSlPoints / 2 / H, LOG2H = __builtin_ctz(H), HOP = S / 4;
+  constexpr int kPer = kSlPoints / kSlThreads;                // elements per thread
   constexpr bool kFixed = (kSlThreads % H) == 0;
+  // 8-byte loads when every sample pair is 8-byte aligned (pairs start at even sample indices)
+  const bool vec = ((N & 1) == 0) && (((reinterpret_cast<uintptr_t>(trow) | reinterpret_cast<uintptr_t>(arow)) & 7) == 0);
+  float2 v[kPer];
+  // all loads first: issued back to back, one wait (a load-use chain per element cost ~10 us per block)
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kSlThreads * u;
+    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;       // g2 < G: target frame, else audio frame
+    const int g = g2 >= G ? g2 - G : g2;
+    const int n = (f0 + g) * HOP + n2;
+    v[u] = make_float2(0.f, 0.f);
+    if (f0 + g < n_frames && n < N) {
+      const float* __restrict__ row = g2 >= G ? arow : trow;
+      if (vec) {
+        v[u] = *reinterpret_cast<const float2*>(row + n);    // n + 1 < N: N and n are even
+      } else {
+        v[u].x = row[n];
+        if (n + 1 < N) v[u].y = row[n + 1];
+      }
+    }
+  }
   float w0 = 0.f, w1 = 0.f;
   if (kFixed) {
     const int n2 = (tid & (H - 1)) * 2;
     w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
     w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
   }
-  for (int e = tid; e < kSlPoints; e += kSlThreads) {
-    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;       // g2 < G: target frame, else audio frame
-    const int g = g2 >= G ? g2 - G : g2;
-    const int n = (f0 + g) * HOP + n2;
-    float2 v = make_float2(0.f, 0.f);
-    if (f0 + g < n_frames && n < N) {
-      const float* __restrict__ row = g2 >= G ? arow : trow;
-      if (!kFixed) {
-        w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-        w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
-      }
-      v.x = row[n] * w0;
-      if (n + 1 < N) v.y = row[n + 1] * w1;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kSlThreads * u;
+    if (!kFixed) {
+      const int n2 = (e & (H - 1)) * 2;
+      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
+      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
     }
-    s[e] = v;
+    s[e] = make_float2(v[u].x * w0, v[u].y * w1);
   }
 }
 
@@ -361,28 +377,32 @@ struct SlFinishArgs {
 
 __global__ __launch_bounds__(256) void spectral_loss_finish_kernel(const double* __restrict__ partial,
                                                                    float* __restrict__ loss, SlFinishArgs p) {
-  __shared__ double red[2][256];
-  double total = 0.0;
+  // one pass, one barrier (a barrier tree per size made this single block take 20 us): every thread
+  // sums its strided share of each size's partials, a DPP reduction gives one value per wavefront
+  // and size, thread 0 adds the 4 x n_sizes values in a fixed order
+  __shared__ double red[16][2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int z = 0; z < p.n_sizes; ++z) {
     double a0 = 0.0, a1 = 0.0;
     for (int i = threadIdx.x; i < p.count[z]; i += 256) {
       a0 += partial[2 * (size_t)(p.offset[z] + i)];
       a1 += partial[2 * (size_t)(p.offset[z] + i) + 1];
     }
-    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st) {
-        red[0][threadIdx.x] += red[0][threadIdx.x + st];
-        red[1][threadIdx.x] += red[1][threadIdx.x + st];
-      }
-      __syncthreads();
-    }
-    // losses.mean_difference 'L1' (losses.py:102-128) per size, weighted sum over sizes (:199-236)
-    total += (p.mag_weight * red[0][0] + p.logmag_weight * red[1][0]) * p.inv_elems[z];
-    __syncthreads();
+    a0 = wave_sum_dpp(a0);
+    a1 = wave_sum_dpp(a1);
+    if (lane == 0) { red[z][0][wave] = a0; red[z][1][wave] = a1; }
   }
-  if (threadIdx.x == 0) *loss = (float)total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    for (int z = 0; z < p.n_sizes; ++z) {
+      const double m = (red[z][0][0] + red[z][0][1]) + (red[z][0][2] + red[z][0][3]);
+      const double l = (red[z][1][0] + red[z][1][1]) + (red[z][1][2] + red[z][1][3]);
+      // losses.mean_difference 'L1' (losses.py:102-128) per size, weighted sum over sizes (:199-236)
+      total += (p.mag_weight * m + p.logmag_weight * l) * p.inv_elems[z];
+    }
+    *loss = (float)total;
+  }
 }
 
 static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }

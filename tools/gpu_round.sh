@@ -27,3 +27,6 @@ timeout 300 python tools/bench_reverb.py 128 2>&1 | tail -1 | tee $OUT/bench_rev
 timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json
 timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json
 timeout 300 python tools/bench_backward.py 128 2>&1 | tail -1 | tee $OUT/bench_backward_b128.json
+echo "== rocprofv3 kernel trace of the training step (synths + loss, forward + backward)"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_train -o trace -- python $GRAFT_REPO_ROOT/tools/bench_backward.py 32 > $GRAFT_REPO_ROOT/$OUT/rocprof_train.log 2>&1 )
+for f in $(find $OUT/prof_train -name "*kernel_stats*.csv" | head -1); do echo "--- $f"; head -20 $f | cut -c1-200; done
