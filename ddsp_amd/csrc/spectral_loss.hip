@@ -21,7 +21,13 @@
 namespace ddsp {
 
 constexpr int kSlPoints = 4096;        // complex points per block (32 KB of LDS)
-constexpr int kSlThreads = 512;       // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
+constexpr int kSlThreads = 512;
+// LDS layout: 2 float2 of padding after every 16 (36 KB per block: four blocks still fit a CU) - a
+// 16-element chunk then starts 36 dwords after the previous one, so the small-stride stages of the transforms (4 lanes per chunk, chunks 128 B apart)
+// no longer land 8 or 16 lanes on the same banks; every index into the array goes through SP().
+constexpr int kSlStore = kSlPoints + kSlPoints / 8;
+__device__ __forceinline__ int SP(int i) { return i + ((i >> 4) << 1); }
+      // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
 
 // ---- the H-point transforms of all frames of a block, in place in LDS -----------------------------
 // H = 2^L.  Forward = decimation in frequency: one radix-2 stage first when L is odd, then radix-4
@@ -73,11 +79,11 @@ __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_l
     for (int t = tid; t < n_fr * half; t += kSlThreads) {
       const int g = (t >> (LOG2H - 1)) + g_lo, pos = t & (half - 1);
       const int i0 = (g << LOG2H) + pos;
-      const float2 a = s[i0], b = s[i0 + half];
+      const float2 a = s[SP(i0)], b = s[SP(i0 + half)];
       const float rev = (float)pos * (1.0f / (float)H);
       const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));   // conj of the twiddle
-      s[i0] = make_float2(a.x + b.x, a.y + b.y);
-      s[i0 + half] = sl_cmulc(make_float2(a.x - b.x, a.y - b.y), w);
+      s[SP(i0)] = make_float2(a.x + b.x, a.y + b.y);
+      s[SP(i0 + half)] = sl_cmulc(make_float2(a.x - b.x, a.y - b.y), w);
     }
     sl_stage_sync<H>();
   }
@@ -88,17 +94,17 @@ __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_l
       const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
       const int pos = r & (q - 1);
       const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
-      const float2 a = s[i0], b = s[i0 + q], c = s[i0 + 2 * q], d = s[i0 + 3 * q];
+      const float2 a = s[SP(i0)], b = s[SP(i0 + q)], c = s[SP(i0 + 2 * q)], d = s[SP(i0 + 3 * q)];
       const float rev = (float)pos * inv_len;
       const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
       const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
       const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
       const float2 t2 = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
       const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
-      s[i0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-      s[i0 + q] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
-      s[i0 + 2 * q] = sl_cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
-      s[i0 + 3 * q] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+      s[SP(i0)] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      s[SP(i0 + q)] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
+      s[SP(i0 + 2 * q)] = sl_cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
+      s[SP(i0 + 3 * q)] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
     }
     sl_stage_sync<H>();
   }
@@ -117,15 +123,15 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
       const float rev = (float)pos * inv_len;
       const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
       const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
-      const float2 y0 = s[i0], y1 = sl_cmul(s[i0 + q], w1), y2 = sl_cmul(s[i0 + 2 * q], w2),
-                   y3 = sl_cmul(s[i0 + 3 * q], w3);
+      const float2 y0 = s[SP(i0)], y1 = sl_cmul(s[SP(i0 + q)], w1), y2 = sl_cmul(s[SP(i0 + 2 * q)], w2),
+                   y3 = sl_cmul(s[SP(i0 + 3 * q)], w3);
       const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), t2 = make_float2(y0.x - y2.x, y0.y - y2.y);
       const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
       const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
-      s[i0] = make_float2(t0.x + t1.x, t0.y + t1.y);
-      s[i0 + 2 * q] = make_float2(t0.x - t1.x, t0.y - t1.y);
-      s[i0 + q] = make_float2(t2.x + bd.x, t2.y + bd.y);
-      s[i0 + 3 * q] = make_float2(t2.x - bd.x, t2.y - bd.y);
+      s[SP(i0)] = make_float2(t0.x + t1.x, t0.y + t1.y);
+      s[SP(i0 + 2 * q)] = make_float2(t0.x - t1.x, t0.y - t1.y);
+      s[SP(i0 + q)] = make_float2(t2.x + bd.x, t2.y + bd.y);
+      s[SP(i0 + 3 * q)] = make_float2(t2.x - bd.x, t2.y - bd.y);
     }
     sl_stage_sync<H>();
   }
@@ -136,9 +142,9 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
       const int i0 = (g << LOG2H) + pos;
       const float rev = (float)pos * (1.0f / (float)H);
       const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      const float2 pp = s[i0], qw = sl_cmul(s[i0 + half], w);  // undo (a+b, (a-b) conj(w))
-      s[i0] = make_float2(pp.x + qw.x, pp.y + qw.y);
-      s[i0 + half] = make_float2(pp.x - qw.x, pp.y - qw.y);
+      const float2 pp = s[SP(i0)], qw = sl_cmul(s[SP(i0 + half)], w);  // undo (a+b, (a-b) conj(w))
+      s[SP(i0)] = make_float2(pp.x + qw.x, pp.y + qw.y);
+      s[SP(i0 + half)] = make_float2(pp.x - qw.x, pp.y - qw.y);
     }
     sl_stage_sync<H>();
   }
@@ -189,7 +195,7 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
       w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
       w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
     }
-    s[e] = make_float2(v[u].x * w0, v[u].y * w1);
+    s[SP(e)] = make_float2(v[u].x * w0, v[u].y * w1);
   }
 }
 
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   constexpr int G = kSlPoints / 2 / H;  // frames per block (of each signal)
   constexpr int LOG2H = __builtin_ctz(H);
   constexpr int HOP = S / 4;
-  __shared__ __attribute__((aligned(16))) float2 s[kSlPoints];
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   __shared__ double red[2][kSlThreads / 64];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int f0 = blockIdx.x * G;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
 #pragma unroll
       for (int sig = 0; sig < 2; ++sig) {
         const int base = (g + sig * G) << LOG2H;
-        const float2 za = s[base + ia], zb = s[base + ib];
+        const float2 za = s[SP(base + ia)], zb = s[SP(base + ib)];
         const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
         const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
         const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
   constexpr int G = kSlPoints / 2 / H;
   constexpr int LOG2H = __builtin_ctz(H);
   constexpr int HOP = S / 4;
-  __shared__ __attribute__((aligned(16))) float2 s[kSlPoints];
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int f0 = blockIdx.x * G;
   const float* __restrict__ trow = target + (size_t)b * N;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
 #pragma unroll
     for (int sig = 0; sig < 2; ++sig) {
       const int base = (g + sig * G) << LOG2H;
-      const float2 za = s[base + ia], zb = s[base + ib];
+      const float2 za = s[SP(base + ia)], zb = s[SP(base + ib)];
       const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);
       const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);
       const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);     // W^k O
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
     const int abase = (g + G) << LOG2H;
     if (k == 0) {                                               // bins 0 and S/2: real, C = Re G
       const float e0 = 0.5f * (c1.x + c2.x), o0 = 0.5f * (c1.x - c2.x);
-      s[abase + ia] = make_float2(e0, o0);                      // Z'[0] = E' + i O'
+      s[SP(abase + ia)] = make_float2(e0, o0);                      // Z'[0] = E' + i O'
     } else {
       if (2 * k == H) c2 = c1;                                  // the self-paired bin S/4
       c1 = make_float2(0.5f * c1.x, 0.5f * c1.y);               // C_k = G_k / 2 for inner bins
@@ -332,26 +338,39 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       const float ex = 0.5f * (c1.x + c2.x), ey = 0.5f * (c1.y - c2.y);
       const float dx = 0.5f * (c1.x - c2.x), dy = 0.5f * (c1.y + c2.y);
       const float ox = fmaf(dx, c, -dy * sn), oy = fmaf(dx, sn, dy * c);      // D * (c + i sn)
-      s[abase + ia] = make_float2(ex - oy, ey + ox);            // Z'[k]   = E' + i O'
-      if (2 * k != H) s[abase + ib] = make_float2(ex + oy, ox - ey);          // Z'[H-k] = conj E' + i conj O'
+      s[SP(abase + ia)] = make_float2(ex - oy, ey + ox);            // Z'[k]   = E' + i O'
+      if (2 * k != H) s[SP(abase + ib)] = make_float2(ex + oy, ox - ey);          // Z'[H-k] = conj E' + i conj O'
     }
   }
   __syncthreads();
   // ---- unscaled inverse transform of the audio frames ------------------------------------------------
   sl_inverse<H>(s, tid, G, G);
   if (SlPlan<H>::kWaveLocal) __syncthreads();
-  // ---- window, overlap-add into grad_audio: g_x[2n] = 2 Re U[n], g_x[2n+1] = 2 Im U[n] --------------
+  // ---- window and overlap-add: g_x[2n] = 2 Re U[n], g_x[2n+1] = 2 Im U[n] ------------------------------
+  // Gathered per output sample: the (up to) four frames of this block that cover it are summed from
+  // LDS first.  A sample whose four frames all belong to this block is owned by the block - plain
+  // read-modify-write (the kernels of the other FFT sizes run before or after, never beside this
+  // one); only the three hops at either end of the block's range are shared with the neighbouring
+  // blocks and go through fp32 atomics.  (One atomic per frame and sample, 49 M per call at batch 32,
+  // was the bound of this kernel.)
   float* __restrict__ grow = grad_audio + (size_t)b * N;
-  for (int e = tid; e < G * H; e += kSlThreads) {
-    const int g = e >> LOG2H, n2 = (e & (H - 1)) * 2;
-    const int n = (f0 + g) * HOP + n2;
-    if (f0 + g < n_frames && n < N) {
-      const float2 u = s[((g + G) << LOG2H) + (e & (H - 1))];
-      const float w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-      const float w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
-      unsafeAtomicAdd(&grow[n], 2.0f * u.x * w0);
-      if (n + 1 < N) unsafeAtomicAdd(&grow[n + 1], 2.0f * u.y * w1);
+  constexpr int LOG2HOP = __builtin_ctz(HOP);
+  for (int pidx = tid; pidx < (G + 3) * HOP; pidx += kSlThreads) {
+    const int n = f0 * HOP + pidx;
+    if (n >= N) continue;
+    const int gp = pidx >> LOG2HOP, ir = pidx & (HOP - 1);
+    float acc = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int g = gp - jj, i = ir + jj * HOP;               // frame g covers the sample at its index i
+      if (g >= 0 && g < G && f0 + g < n_frames) {
+        const float2 u = s[SP(((g + G) << LOG2H) + (i >> 1))];
+        const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)S));
+        acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
+      }
     }
+    if (gp >= 3 && gp <= G - 1) grow[n] += acc;
+    else unsafeAtomicAdd(&grow[n], acc);
   }
   if (partial) {                                               // block-uniform
     __shared__ double red[2][kSlThreads / 64];
