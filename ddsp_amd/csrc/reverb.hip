@@ -38,6 +38,11 @@ constexpr int kRvThreads = 1024;      // FFT blocks: 16 wavefronts on one 64 KB 
                                        // stage): with 4 wavefronts a stage took 1.3 us - one wavefront per SIMD cannot overlap
                                        // its own LDS and VALU phases (tools/microbench5)
 constexpr int kRvMacThreads = 256;
+// LDS layout of the FFT array: 2 float2 of padding after every 16, so that the small-stride stages
+// (4 lanes per 16-element chunk, chunks 128 B apart) do not land 8-16 lanes on the same banks
+// (this took the SpectralLoss FFTs from 234 to 165 us).  Pairs (2i, 2i+1) stay adjacent and 16-byte aligned.
+constexpr int kRvStore = kRvN + kRvN / 8;
+__device__ __forceinline__ int RP(int i) { return i + ((i >> 4) << 1); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
@@ -70,7 +75,7 @@ __device__ __forceinline__ void fft_forward(float2* s, int tid) {
       const int t = tid + kRvThreads * u, pos = t & (q - 1);
       idx[u] = ((t - pos) << 2) + pos;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) v[u][m] = s[idx[u] + m * q];
+      for (int m = 0; m < 4; ++m) v[u][m] = s[RP(idx[u] + m * q)];
     }
 #pragma unroll
     for (int u = 0; u < kRvBf; ++u) {
@@ -89,17 +94,17 @@ __device__ __forceinline__ void fft_forward(float2* s, int tid) {
 #pragma unroll
     for (int u = 0; u < kRvBf; ++u) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) s[idx[u] + m * q] = v[u][m];
+      for (int m = 0; m < 4; ++m) s[RP(idx[u] + m * q)] = v[u][m];
     }
     __syncthreads();
   }
   {                                                            // radix-2, neighbours, twiddle 1
     float4 v[2 * kRvBf];
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = reinterpret_cast<const float4*>(s)[tid + kRvThreads * u];
+    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
 #pragma unroll
     for (int u = 0; u < 2 * kRvBf; ++u)
-      reinterpret_cast<float4*>(s)[tid + kRvThreads * u] =
+      *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
           make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
   }
   __syncthreads();
@@ -109,10 +114,10 @@ __device__ __forceinline__ void fft_inverse(float2* s, int tid) {
   {
     float4 v[2 * kRvBf];
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = reinterpret_cast<const float4*>(s)[tid + kRvThreads * u];
+    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
 #pragma unroll
     for (int u = 0; u < 2 * kRvBf; ++u)
-      reinterpret_cast<float4*>(s)[tid + kRvThreads * u] =
+      *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
           make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
   }
   __syncthreads();
@@ -126,7 +131,7 @@ __device__ __forceinline__ void fft_inverse(float2* s, int tid) {
       const int t = tid + kRvThreads * u, pos = t & (q - 1);
       idx[u] = ((t - pos) << 2) + pos;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) v[u][m] = s[idx[u] + m * q];
+      for (int m = 0; m < 4; ++m) v[u][m] = s[RP(idx[u] + m * q)];
     }
 #pragma unroll
     for (int u = 0; u < kRvBf; ++u) {
@@ -146,7 +151,7 @@ __device__ __forceinline__ void fft_inverse(float2* s, int tid) {
 #pragma unroll
     for (int u = 0; u < kRvBf; ++u) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) s[idx[u] + m * q] = v[u][m];
+      for (int m = 0; m < 4; ++m) s[RP(idx[u] + m * q)] = v[u][m];
     }
     __syncthreads();
   }
@@ -201,13 +206,13 @@ __global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restr
       if (IS_IR && g == 0 && (p.flags & DDSP_CONV_MASK_TAP0)) re.x = 0.0f;
       if (!IS_IR) im = load4(g + kRvP);
     }
-    reinterpret_cast<float4*>(s)[2 * i4] = make_float4(re.x, im.x, re.y, im.y);
-    reinterpret_cast<float4*>(s)[2 * i4 + 1] = make_float4(re.z, im.z, re.w, im.w);
+    *reinterpret_cast<float4*>(&s[RP(4 * i4)]) = make_float4(re.x, im.x, re.y, im.y);
+    *reinterpret_cast<float4*>(&s[RP(4 * i4 + 2)]) = make_float4(re.z, im.z, re.w, im.w);
   }
   __syncthreads();
   fft_forward(s, tid);
   float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)b * gridDim.x + j) * kRvN);
-  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) dst[i2] = reinterpret_cast<const float4*>(s)[i2];
+  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) dst[i2] = *reinterpret_cast<const float4*>(&s[RP(2 * i2)]);
 }
 
 // One thread per pair of bins (16-byte accesses).  The IR spectra of all partitions sit in
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
   const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
   // spectrum m = 2j+1 holds output blocks 2j (real part) and 2j+1 (imaginary part)
   const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + 2 * j + 1) * kRvN);
-  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) reinterpret_cast<float4*>(s)[i2] = srcv[i2];
+  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) *reinterpret_cast<float4*>(&s[RP(2 * i2)]) = srcv[i2];
   __syncthreads();
   fft_inverse(s, tid);
   // overlap-save: the last P samples of the block are y[jP .. (j+1)P); out[n] = y[n + delay]
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
   const float* __restrict__ arow = audio + (size_t)b * p.N;
   float* __restrict__ orow = out + (size_t)b * p.n_out;
   for (int i = tid; i < kRvP; i += kRvThreads) {
-    const float2 y = s[kRvP + i];
+    const float2 y = s[RP(kRvP + i)];
     const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
     if (n0 >= 0 && n0 < p.n_out)
       orow[rev_o ? p.n_out - 1 - n0 : n0] = fmaf(y.x, scale, dry ? arow[rev_a ? p.N - 1 - n0 : n0] : 0.0f);
@@ -303,11 +308,11 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   p.flags = flags; p.ir_batch = Bir;
   float2* xspec = (float2*)workspace;
   float2* hspec = xspec + (size_t)B * p.nb * kRvN;
-  const size_t lds = (size_t)kRvN * sizeof(float2);
+  const size_t lds = (size_t)kRvStore * sizeof(float2);
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvN * sizeof(float2)));
-    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvN * sizeof(float2)));
-    (void)hipFuncSetAttribute((const void*)rv_ifft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvN * sizeof(float2)));
+    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
+    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
+    (void)hipFuncSetAttribute((const void*)rv_ifft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
     return true;
   }();
   (void)attr_set;
