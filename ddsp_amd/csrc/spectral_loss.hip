@@ -394,18 +394,21 @@ struct SlFinishArgs {
   double mag_weight, logmag_weight;
 };
 
-__global__ __launch_bounds__(256) void spectral_loss_finish_kernel(const double* __restrict__ partial,
-                                                                   float* __restrict__ loss, SlFinishArgs p) {
-  // one pass, one barrier (a barrier tree per size made this single block take 20 us): every thread
-  // sums its strided share of each size's partials, a DPP reduction gives one value per wavefront
-  // and size, thread 0 adds the 4 x n_sizes values in a fixed order
-  __shared__ double red[16][2][4];
+constexpr int kSlFinishThreads = 1024;
+
+__global__ __launch_bounds__(kSlFinishThreads) void spectral_loss_finish_kernel(const double* __restrict__ partial,
+                                                                                float* __restrict__ loss, SlFinishArgs p) {
+  // one pass, one barrier, 1024 threads (a single block of 256 walking 12 000 partials with a barrier
+  // tree per size took 20 us): every thread sums its strided share of each size's partials, a DPP
+  // reduction gives one value per wavefront and size, thread 0 adds them in a fixed order
+  constexpr int kWaves = kSlFinishThreads / 64;
+  __shared__ double red[16][2][kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int z = 0; z < p.n_sizes; ++z) {
     double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < p.count[z]; i += 256) {
-      a0 += partial[2 * (size_t)(p.offset[z] + i)];
-      a1 += partial[2 * (size_t)(p.offset[z] + i) + 1];
+    for (int i = threadIdx.x; i < p.count[z]; i += kSlFinishThreads) {
+      const double2 v = *reinterpret_cast<const double2*>(partial + 2 * (size_t)(p.offset[z] + i));
+      a0 += v.x; a1 += v.y;
     }
     a0 = wave_sum_dpp(a0);
     a1 = wave_sum_dpp(a1);
@@ -415,8 +418,8 @@ __global__ __launch_bounds__(256) void spectral_loss_finish_kernel(const double*
   if (threadIdx.x == 0) {
     double total = 0.0;
     for (int z = 0; z < p.n_sizes; ++z) {
-      const double m = (red[z][0][0] + red[z][0][1]) + (red[z][0][2] + red[z][0][3]);
-      const double l = (red[z][1][0] + red[z][1][1]) + (red[z][1][2] + red[z][1][3]);
+      double m = 0.0, l = 0.0;
+      for (int w = 0; w < kWaves; ++w) { m += red[z][0][w]; l += red[z][1][w]; }
       // losses.mean_difference 'L1' (losses.py:102-128) per size, weighted sum over sizes (:199-236)
       total += (p.mag_weight * m + p.logmag_weight * l) * p.inv_elems[z];
     }
@@ -477,7 +480,7 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
       offset += B * blocks;
     }
   }
-  hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, loss, fin);
+  hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(kSlFinishThreads), 0, st, (const double*)partial, loss, fin);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 
@@ -523,7 +526,7 @@ static int sl_backward_impl(const float* target_audio, const float* audio, const
     }
   }
   if (loss)
-    hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, loss, fin);
+    hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(kSlFinishThreads), 0, st, (const double*)partial, loss, fin);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 
