@@ -210,7 +210,6 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;  // frames per block (of each signal)
   constexpr int LOG2H = __builtin_ctz(H);
-  constexpr int HOP = S / 4;
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   __shared__ double red[2][kSlThreads / 64];
   const int tid = threadIdx.x, b = blockIdx.y;
