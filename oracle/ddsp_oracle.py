@@ -568,11 +568,11 @@ def exp_sigmoid_grad(x, exponent=10.0, max_value=2.0, threshold=1e-7):
 
 def harmonic_backward(amplitudes, harmonic_distribution, f0_hz, grad_audio, n_samples=64000,
                       sample_rate=16000, scale_fn=exp_sigmoid, normalize_below_nyquist=True,
-                      amp_resample_method='window'):
-  """(dL/d amplitudes [B,F,1], dL/d harmonic_distribution [B,F,K]) given dL/d audio [B,N].
+                      amp_resample_method='window', with_f0=False):
+  """(dL/d amplitudes [B,F,1], dL/d harmonic_distribution [B,F,K][, dL/d f0_hz [B,F,1]]) given
+  dL/d audio [B,N].
 
-  f0_hz is treated as a constant (its gradient is not built).  The masks (>= Nyquist) have zero
-  gradient, as tf.where gives them.
+  The masks (>= Nyquist) have zero gradient, as tf.where gives them (also with respect to f0).
   """
   amps_raw = as_float(amplitudes, np.float64)
   hd_raw = as_float(harmonic_distribution, np.float64)
@@ -603,9 +603,19 @@ def harmonic_backward(amplitudes, harmonic_distribution, f0_hz, grad_audio, n_sa
   d_hdn = grad_a * amp_s
   d_x = (d_hdn - np.sum(d_hdn * hdn, axis=-1, keepdims=True)) / den_safe
   d_x = np.where(live & (den != 0.0), d_x, 0.0)
-  if scale_fn is not None:
-    return d_amp_s * exp_sigmoid_grad(amps_raw), d_x * exp_sigmoid_grad(hd_raw)
-  return d_amp_s, d_x
+  out = ((d_amp_s * exp_sigmoid_grad(amps_raw), d_x * exp_sigmoid_grad(hd_raw)) if scale_fn is not None
+         else (d_amp_s, d_x))
+  if not with_f0:
+    return out
+  # dL/d f0: phase[n] = (2 pi / sr) k cumsum(f_env)[n]  ->  dL/d f_env[t] = (2 pi / sr) sum_{n >= t} c[n],
+  # c[n] = g[n] sum_k k A_k[n] m_k[n] cos(phase_k[n]); f_env = U_f f0 (legacy bilinear resize, linear in f0)
+  amp_env = resample(amp_s * hdn, n_samples, method=amp_resample_method, dtype=np.float64)   # [B,N,K]
+  kk = np.arange(1, k + 1, dtype=np.float64)
+  c = g * np.sum(kk * amp_env * np.where(mask, np.cos(phases), 0.0), axis=-1)                # [B,N]
+  r_suffix = np.cumsum(c[:, ::-1], axis=1)[:, ::-1]
+  u_f = resample(np.eye(f)[None], n_samples, dtype=np.float64)[0]                             # [N,F]
+  d_f0 = (TWO_PI / float(sample_rate)) * np.einsum('nf,bn->bf', u_f, r_suffix)[:, :, None]
+  return out + (d_f0,)
 
 
 def filtered_noise_backward(magnitudes, noise, grad_audio, window_size=257, scale_fn=exp_sigmoid,

@@ -333,3 +333,22 @@ def test_spectral_loss_backward_matches_finite_differences():
     d = np.zeros_like(a); d[idx] = eps
     fd = (O.spectral_loss(t, a + d, dtype=np.float64, **kw) - O.spectral_loss(t, a - d, dtype=np.float64, **kw)) / (2 * eps)
     np.testing.assert_allclose(g[idx], fd, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('method', ['window', 'linear'])
+def test_harmonic_backward_f0_matches_finite_differences(method):
+  rng = np.random.default_rng(13)
+  b, f, k, n, sr = 1, 6, 5, 48, 16000
+  amps = rng.standard_normal((b, f, 1))
+  hd = rng.standard_normal((b, f, k))
+  f0 = rng.uniform(300.0, 700.0, (b, f, 1))                       # 5 * 700 < 8000: no mask flips under the perturbation
+  g = rng.standard_normal((b, n))
+
+  def loss(ff):
+    return float(np.sum(O.harmonic(amps, hd, ff, n, sr, O.exp_sigmoid, True, method, dtype=np.float64) * g))
+  _, _, gf = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, method, with_f0=True)
+  eps = 1e-4
+  for j in range(f):
+    d = np.zeros_like(f0); d[0, j, 0] = eps
+    fd = (loss(f0 + d) - loss(f0 - d)) / (2 * eps)
+    np.testing.assert_allclose(gf[0, j, 0], fd, rtol=1e-5, atol=1e-9)
