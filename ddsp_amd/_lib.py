@@ -73,6 +73,7 @@ HARM_NORMALIZE_NYQUIST = 0x2
 HARM_AMP_LINEAR = 0x4
 HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
+HARM_DIRECT_SUM = 0x40
 NOISE_SCALE_EXP_SIGMOID = 0x1
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2

@@ -21,6 +21,7 @@
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "profile.h"
+#include "harmonic_table.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
@@ -902,6 +903,9 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
   if (workspace_bytes < ddsp_harmonic_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (harm_table_ok(F, K, N, hd, ctl_amp, ctl_hd, flags, /*inputs_are_controls=*/0))
+    return launch_harm_table(amplitudes, hd, f0_hz, audio, B, F, K, N, sample_rate, flags, st);
+  flags &= ~DDSP_HARM_DIRECT_SUM;
   if (fused_ok(F, K, N, hd, ctl_hd))
     return launch_fused(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, workspace, B, F, K, N,
                         sample_rate, flags, /*inputs_are_controls=*/0, st);

@@ -1,0 +1,464 @@
+// Harmonic.__call__ (ddsp/synths.py:94-146) for gfx950 as wavetables built on the matrix cores.
+//
+// Within frame j every output sample is
+//     audio[t] = w_cur(r) S_j(theta_t) + w_next(r) S_{j+1}(theta_t),   S_j(theta) = sum_k a_j[k] sin(2 pi k theta)
+// (harmonic.hip derives this form from core.upsample_with_windows / core.oscillator_bank): a frame's
+// amplitude row enters only through the periodic, band-limited function S_j.  harm_fused_kernel evaluates
+// S_j and S_{j+1} harmonic by harmonic at every sample (3 FMAs per harmonic and sample, VALU bound).
+// Here each S_j is tabulated once on T = 512 uniform phases and every sample reads the two tables
+// through a W-tap Kaiser-Bessel window (the interpolation step of a type-2 nonuniform FFT, Dutt & Rokhlin
+// 1993; coefficients and the error analysis: tools/gen_wavetable_coeffs.py).  The tabulation
+//     S_j(phi_n) = sum_k sin(k phi_n) a_j[k] / psi_hat(k)
+// is a dense [T x K] . [K x frames] product with a constant left factor - the one place on this path that
+// is matrix-core work.  The symmetries of the sine cut it to an eighth: with the table grid offset by
+// half a step, phi_n = 2 pi (n + 1/2) / T, and O / E the sums over odd / even harmonics,
+//     S(n) = O(n) + E(n),  S(T/2-1-n) = O(n) - E(n),  S(T-1-n) = -S(n)      (n = 0 .. T/4-1)
+// so two [128 x K/2] products per row give the whole table.  v_mfma_f32_16x16x4_f32 (exact fp32, 64
+// flop/clk/SIMD) does them with the constant factor resident in registers for the life of the block.
+//
+// Per sample the VALU work drops from ~4 K flop-instructions to ~65 (phase, W polynomial weights,
+// 2 W taps), independent of K; error vs exact arithmetic <= 6.3e-6 * sum_k a_k (W = 6, K <= 100),
+// 6.5e-6 (W = 8, K <= 128), smaller than the sine recurrence's 3.1e-5.
+//
+// The audio-rate Nyquist mask of core.oscillator_bank (core.py:942-944) only differs from the frame-rate
+// mask of normalize_harmonics inside frames where a harmonic crosses sr/2; for those harmonics the masked
+// samples subtract their contribution again, evaluated directly.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
+#include "../../include/ddsp_amd.h"
+#include "common.h"
+#include "profile.h"
+#include "harmonic_table.h"
+#define DDSP_WT_TABLE __constant__
+#include "wavetable_coeffs.h"
+
+namespace ddsp {
+
+constexpr int kWtT = 512;            // table points per revolution
+constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, kWtHalf + kWtH); the other half is its mirror image
+constexpr int kWtNQ = kWtT / 4;      // positions produced by the matrix product
+constexpr int kWtH = 4;              // halo entries on either side (>= W/2)
+constexpr int kWtTS = 268;           // table row stride in floats: 4*odd, so 16 rows' b128 writes spread over the banks
+constexpr int kWtRows = 16;          // amplitude rows per chunk (MFMA N)
+constexpr int kWtFrames = 15;        // frames per chunk: row r+1 is the "next" row of frame r
+constexpr int kWtKS = 68;            // row stride of an amplitude plane (odd / even harmonics): 4*odd
+constexpr int kWtRS = 132;           // row stride of the raw staging buffer: 128 harmonics, f0, amplitude
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TableArgs {
+  int B, F, K, N, hop, chunks_per_row, n_chunks;
+  float nyquist, nyq_lo, nyq_hi;
+  int amp_linear, f0_vec;
+  double inv_sr, inv_2hop, hop_d, half_hm1;
+  long long* dbg;      // timeline of block 0 (tools/exp_table.py --timeline), or null
+};
+
+struct ChunkTables {
+  double theta[kWtRows], w[kWtRows], dw[kWtRows];
+  float f0[kWtRows + 2];
+  int kA[kWtRows], kN[kWtRows];
+};
+
+template <int W> struct WtPoly;
+template <> struct WtPoly<6> {
+  static constexpr int DE = kWtDegE6, DO = kWtDegO6;
+  static constexpr float e(int p, int d) { return kWtE6[p * (DE + 1) + d]; }
+  static constexpr float o(int p, int d) { return kWtO6[p * (DO + 1) + d]; }
+  __device__ static float invpsi(int k) { return kWtInvPsi6_T512[k]; }
+  __device__ static float psi(int k) { return kWtPsi6_T512[k]; }
+};
+template <> struct WtPoly<8> {
+  static constexpr int DE = kWtDegE8, DO = kWtDegO8;
+  static constexpr float e(int p, int d) { return kWtE8[p * (DE + 1) + d]; }
+  static constexpr float o(int p, int d) { return kWtO8[p * (DO + 1) + d]; }
+  __device__ static float invpsi(int k) { return kWtInvPsi8_T512[k]; }
+  __device__ static float psi(int k) { return kWtPsi8_T512[k]; }
+};
+
+template <int W, int P, int D> struct WtE { static constexpr float v = WtPoly<W>::e(P, D); };
+template <int W, int P, int D> struct WtO { static constexpr float v = WtPoly<W>::o(P, D); };
+
+// window weights of the tap pair at distance -+(P + 1/2) from the centre: E(z^2) +- z O(z^2)
+template <int W, int P>
+__device__ __forceinline__ void wt_pair(float z, float z2, float& w_lo, float& w_hi) {
+  float e, o;
+  if constexpr (WtPoly<W>::DE == 3)
+    e = fmaf(fmaf(fmaf(WtE<W, P, 3>::v, z2, WtE<W, P, 2>::v), z2, WtE<W, P, 1>::v), z2, WtE<W, P, 0>::v);
+  else
+    e = fmaf(fmaf(WtE<W, P, 2>::v, z2, WtE<W, P, 1>::v), z2, WtE<W, P, 0>::v);
+  if constexpr (WtPoly<W>::DO == 3)
+    o = fmaf(fmaf(fmaf(WtO<W, P, 3>::v, z2, WtO<W, P, 2>::v), z2, WtO<W, P, 1>::v), z2, WtO<W, P, 0>::v);
+  else
+    o = fmaf(fmaf(WtO<W, P, 2>::v, z2, WtO<W, P, 1>::v), z2, WtO<W, P, 0>::v);
+  w_lo = fmaf(z, o, e);
+  w_hi = fmaf(-z, o, e);
+}
+
+template <int W, int P>
+__device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, float z2, float& acc0, float& acc1) {
+  float w_lo, w_hi;
+  wt_pair<W, P>(z, z2, w_lo, w_hi);
+  acc0 = fmaf(w_lo, t0[-P], acc0);
+  acc0 = fmaf(w_hi, t0[1 + P], acc0);
+  acc1 = fmaf(w_lo, t0[kWtTS - P], acc1);
+  acc1 = fmaf(w_hi, t0[kWtTS + 1 + P], acc1);
+  if constexpr (P + 1 < W / 2) wt_taps<W, P + 1>(t0, z, z2, acc0, acc1);
+}
+
+// One block = 12 wavefronts in two roles, one block per CU.  T-wavefronts (0..3, one per SIMD) own the
+// matrix cores and the loads: each holds its share of the constant sine matrix in registers (two position
+// tiles x two parities) and turns the amplitude planes of a chunk into its table; around that it fetches
+// the raw rows of a later chunk from HBM into an LDS staging buffer (issued before the MFMAs, stored after
+// them, so the latency hides behind the matrix pipe).  S-wavefronts (4..11) own the vector ALUs and never
+// wait on HBM: the controls prologue of a chunk (phase A: exp_sigmoid, Nyquist mask, normalisation ->
+// amplitude planes; the fp64 phase tables) and the per-sample interpolation (phase B).  Chunks move through
+// a four-stage pipeline, one stage per tick and one barrier per tick:
+//     tick tau:   T: rows of chunk tau+3 -> staging;  MFMAs and table of chunk tau+1
+//                 S: phase B of chunk tau, then phase A of chunk tau+2
+// tables and staging double-buffered, planes / frame tables triple-buffered in LDS.
+// NS: k-steps of 4 per parity (ceil(K/2) <= 4 NS); ONE_TILE: hop == 64
+template <int W, int NS, bool ONE_TILE>
+__global__ __launch_bounds__(768, 3) void harm_table_kernel(
+    const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
+    float* __restrict__ audio, TableArgs p) {
+  __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
+  __shared__ __attribute__((aligned(16))) float planes_all[3][2 * kWtRows * kWtKS];   // [parity][row][k']: a_k / psi_hat(k)
+  __shared__ __attribute__((aligned(16))) float raw_all[2][kWtRows * kWtRS + 12];     // raw rows; then 4 doubles (parts of the sum of f0 before the chunk) and f0 of frame 0
+  __shared__ ChunkTables t_all[3];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_t = wave < 4;
+  const int rw = is_t ? wave : wave - 4;         // index within the role: 0..3 (T), 0..7 (S)
+  const int F = p.F, K = p.K;
+  const int K4 = K >> 2;
+  const float kLog10 = 2.302585092994046f;       // tf.math.log(exponent), ddsp/core.py:403
+  const int n_my = ((int)p.n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // chunks of this block
+  // 32 lanes per matrix row, lane kq owns harmonics 4 kq + 1 .. 4 kq + 4 (loads and phase A)
+  const int sub = lane >> 5, kq = lane & 31;
+  const bool live = kq < K4;
+  const float4* __restrict__ hd4 = reinterpret_cast<const float4*>(hd);
+  const int mi = lane & 15, mg = lane >> 4;      // MFMA fragment coordinates
+  // debug timeline: [wavefront 0 / 4 / 11][tick + 3][stamp], shader clocks
+  const int dbg_w = (wave == 0) ? 0 : (wave == 4) ? 1 : (wave == 11) ? 2 : -1;
+  const bool dbg_on = p.dbg != nullptr && blockIdx.x == 0 && lane == 0 && dbg_w >= 0;
+#define DDSP_WT_STAMP(i) do { if (dbg_on && tick + 3 < 64) p.dbg[(dbg_w * 64 + tick + 3) * 8 + (i)] = clock64(); } while (0)
+
+  if (is_t) {
+    // ---- this wavefront's share of the constant factor, in MFMA A-operand layout -----------------------
+    // A[i = lane & 15][kk = lane >> 4] of step s, parity par, position tile pt: sin(k phi_n) with
+    // n = 16 pt + i, k = 2 (4 s + kk) + 1 + par; the angle k (2n+1) / (2T) revolutions is exact in fp32.
+    float afrag[2][2][NS];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int n = 16 * (2 * rw + tt) + mi;
+          const int k = 2 * (4 * s + mg) + 1 + par;
+          const int num = (k * (2 * n + 1)) & (2 * kWtT - 1);
+          afrag[par][tt][s] = sin_rev((float)num * (1.0f / (2 * kWtT)));     // rows k > K meet zero amplitudes
+        }
+
+    for (int tick = -3; tick < n_my; ++tick) {
+      // ---------------- rows of chunk tick+3: issue the loads -----------------------------------------------
+      // Nothing below may depend on the loaded values until the MFMAs have been issued, so every load is
+      // unconditional (indices clamped to something valid, the result masked after the MFMAs): past the
+      // block's last chunk the last one is simply fetched again into a staging slot nobody reads.
+      DDSP_WT_STAMP(0);
+      const int lchunk = blockIdx.x + min(tick + 3, n_my - 1) * gridDim.x;
+      const int lb = lchunk / p.chunks_per_row;
+      const int lj0 = (lchunk - lb * p.chunks_per_row) * kWtFrames;
+      const int kqc = min(kq, K4 - 1);
+      const int lrow0 = lb * F + min(lj0 + rw * 4 + sub, F - 1), lrow1 = lb * F + min(lj0 + rw * 4 + 2 + sub, F - 1);
+      const float4 lx0 = hd4[(size_t)lrow0 * K4 + kqc], lx1 = hd4[(size_t)lrow1 * K4 + kqc];
+      const float lf00 = f0_all[lrow0], lf01 = f0_all[lrow1];
+      const float lamp0 = amplitudes[lrow0], lamp1 = amplitudes[lrow1];
+      // f0 of the frames before the chunk, for the fp64 phase prefix: float4 number lane + 64 rw of the row
+      // (rows of up to 1024 frames in one go), the <= 3 frames past the last whole float4 on wavefront 0
+      const float* __restrict__ f0row = f0_all + (size_t)lb * F;
+      const int n4 = p.f0_vec ? min(lj0 >> 2, 256) : 0;
+      const int m4 = lane + 64 * rw;
+      const float4 pf = reinterpret_cast<const float4*>(p.f0_vec ? f0row : hd)[min(m4, max(n4 - 1, 0))];
+      const int jt = (n4 << 2) + lane;
+      const float ptail = f0row[min(jt, F - 1)];
+      const float f0_first = f0row[0];
+      DDSP_WT_STAMP(1);
+      // ---------------- table of chunk tick+1: O and E on the quarter range -----------------------------------
+      if (tick + 1 >= 0 && tick + 1 < n_my) {
+        const float* bsrc = planes_all[(tick + 1) % 3] + mi * kWtKS + mg;   // B[kk = lane >> 4][j = lane & 15]: plane[par][row j][4 s + kk]
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) acc[par][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            const float bv = bsrc[par * kWtRows * kWtKS + 4 * s];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              acc[par][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[par][tt][s], bv, acc[par][tt], 0, 0, 0);
+          }
+        // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
+        float* trow = tab_all[(tick + 1) & 1] + mi * kWtTS + kWtH;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int n0 = 16 * (2 * rw + tt) + 4 * mg;
+          const f32x4 sp = acc[0][tt] + acc[1][tt];         // S(n)         = O + E
+          const f32x4 sm = acc[0][tt] - acc[1][tt];         // S(T/2-1-n)   = O - E
+          *reinterpret_cast<f32x4*>(trow + n0) = sp;
+          *reinterpret_cast<f32x4*>(trow + (kWtHalf - 4 - n0)) = (f32x4){sm.w, sm.z, sm.y, sm.x};
+          if (n0 == 0) {                                     // halos: S(-1-m) = -S(m), S(T/2+m) = -S(T/2-1-m)
+            *reinterpret_cast<f32x4*>(trow - kWtH) = (f32x4){-sp.w, -sp.z, -sp.y, -sp.x};
+            *reinterpret_cast<f32x4*>(trow + kWtHalf) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
+          }
+        }
+      }
+      DDSP_WT_STAMP(2);
+      // ---------------- rows of chunk tick+3: into the staging buffer --------------------------------------------
+      {
+        float* raw = raw_all[(tick + 3) & 1];
+        const int r0 = rw * 4 + sub;
+        *reinterpret_cast<float4*>(raw + r0 * kWtRS + 4 * kq) = lx0;
+        *reinterpret_cast<float4*>(raw + (r0 + 2) * kWtRS + 4 * kq) = lx1;
+        if (kq == 0) {
+          *reinterpret_cast<float2*>(raw + r0 * kWtRS + 128) = make_float2(lf00, lamp0);
+          *reinterpret_cast<float2*>(raw + (r0 + 2) * kWtRS + 128) = make_float2(lf01, lamp1);
+        }
+        double part = (m4 < n4) ? ((double)pf.x + (double)pf.y) + ((double)pf.z + (double)pf.w) : 0.0;
+        if (rw == 0 && jt < lj0 && (jt >> 2) == n4 && p.f0_vec) part += (double)ptail;
+        // what the one-shot loads do not cover (rows longer than 1024 frames, unaligned rows): serially
+        const int covered = p.f0_vec ? min(lj0, 1024) : 0;
+        for (int j = covered + tid; j < lj0; j += 256) part += (double)f0row[j];
+        const double psum = wave_sum_dpp(part);                // this wavefront's part of sum_{j < j0} f_j
+        if (lane == 0) {
+          reinterpret_cast<double*>(raw + kWtRows * kWtRS)[rw] = psum;
+          if (rw == 0) raw[kWtRows * kWtRS + 8] = f0_first;
+        }
+      }
+      DDSP_WT_STAMP(3);
+      __syncthreads();
+      DDSP_WT_STAMP(4);
+    }
+  } else {
+    float ipsi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
+    const int arow = rw * 2 + sub;                 // the chunk row this lane works on in phase A
+
+    for (int tick = -3; tick < n_my; ++tick) {
+      DDSP_WT_STAMP(0);
+      if (tick >= 0) {
+        // ---------------- phase B of chunk tick: tiles of 64 samples, lanes = samples ----------------------
+        const int chunk = blockIdx.x + tick * gridDim.x;
+        const int b = chunk / p.chunks_per_row;
+        const int j0 = (chunk - b * p.chunks_per_row) * kWtFrames;
+        const int nfr = min(kWtFrames, F - j0);
+        const int row0 = b * F + j0;
+        const float* tab = tab_all[tick & 1];
+        const float* planes = planes_all[tick % 3];
+        const ChunkTables& t = t_all[tick % 3];
+        const int hop = p.hop;
+        const float inv_hop = 1.0f / (float)hop;
+        const int tiles_per_frame = hop >> 6;
+        const int n_tiles = nfr * tiles_per_frame;
+        for (int tile = rw; tile < n_tiles; tile += 8) {
+          const int q = ONE_TILE ? tile : tile / tiles_per_frame;
+          const int r = ONE_TILE ? lane : (tile - q * tiles_per_frame) * 64 + lane;
+          const double rr = (double)r;
+          // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
+          const double cyc = t.theta[q] + (rr + 1.0) * (t.w[q] + t.dw[q] * rr);
+          const float theta = (float)(cyc - floor(cyc));                 // [0, 1]
+          const bool neg = theta >= 0.5f;                               // S(1 - theta) = -S(theta)
+          const float th = neg ? 1.0f - theta : theta;                  // [0, 0.5]
+          const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
+          const float fl = floorf(pos);
+          const float z = (pos - fl) - 0.5f;
+          const int i0 = (int)fl;                                       // [-1, 255]
+          const float* t0 = tab + q * kWtTS + kWtH + i0;
+          float acc0 = 0.0f, acc1 = 0.0f;
+          wt_taps<W, 0>(t0, z, z * z, acc0, acc1);
+          const float lerp = (float)r * inv_hop;
+          // frame-rate -> audio-rate amplitude envelope: weight of frame j+1 is lerp ('linear', core.resample)
+          // or the periodic Hann(2 hop)[r] ('window', core.py:696-698)
+          const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
+          const float w_cur = 1.0f - w_next;
+          float out = w_cur * acc0 + w_next * acc1;
+          out = neg ? -out : out;
+          const int kA = __builtin_amdgcn_readfirstlane(t.kA[q]);
+          const int kN = __builtin_amdgcn_readfirstlane(t.kN[q]);
+          if (kA < kN) {           // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
+            const float fj = t.f0[q], fj1 = t.f0[q + 1];
+            for (int k = kA; k < kN; ++k) {
+              const float kf = (float)(k + 1);
+              const float top = fj * kf, bot = fj1 * kf;
+              const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+              const float* pl = planes + (k & 1) * kWtRows * kWtKS + q * kWtKS + (k >> 1);
+              const float psi = WtPoly<W>::psi(k + 1);
+              const float ak = (w_cur * pl[0] + w_next * pl[kWtKS]) * psi;
+              const float sv = sin_rev(fmaf(theta, kf, -rintf(theta * kf)));     // exact fractional part of k theta
+              if (fk >= p.nyquist) out = fmaf(-ak, sv, out);
+            }
+          }
+          audio[(size_t)(row0 + q) * hop + r] = out;                    // N == F * hop
+        }
+      }
+      DDSP_WT_STAMP(1);
+      if (tick + 2 >= 0 && tick + 2 < n_my) {
+        // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+15 (clamped at F-1) -> planes ----
+        // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
+        // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
+        const int chunk = blockIdx.x + (tick + 2) * gridDim.x;
+        const int b = chunk / p.chunks_per_row;
+        const int j0 = (chunk - b * p.chunks_per_row) * kWtFrames;
+        const int nfr = min(kWtFrames, F - j0);
+        const float* raw = raw_all[(tick + 2) & 1];
+        float* planes = planes_all[(tick + 2) % 3];
+        ChunkTables& t = t_all[(tick + 2) % 3];
+        {
+          const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
+          const float2 fa2 = *reinterpret_cast<const float2*>(raw + arow * kWtRS + 128);
+          const float f0r = fa2.x;
+          float x[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            x[u] = exp_sigmoid_fast(x[u], kLog10, 2.0f, 1e-7f);
+            if (!live || f0r * (float)(4 * kq + u + 1) >= p.nyquist) x[u] = 0.0f;
+          }
+          float part = (x[0] + x[1]) + (x[2] + x[3]);
+          part += dpp_mov0<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]
+          part += dpp_mov0<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]
+          part += dpp_mov0<0x141, 0xF>(part);     // row_half_mirror
+          part += dpp_mov0<0x140, 0xF>(part);     // row_mirror
+          part += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, part), 0x401F));   // lane ^ 16
+          const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
+          const float a = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f) * inv;
+          float* dst = planes + arow * kWtKS + 2 * kq;
+          *reinterpret_cast<float2*>(dst) = make_float2(a * x[0] * ipsi[0], a * x[2] * ipsi[2]);                       // k odd
+          *reinterpret_cast<float2*>(dst + kWtRows * kWtKS) = make_float2(a * x[1] * ipsi[1], a * x[3] * ipsi[3]);    // k even
+        }
+        // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
+        // frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
+        // which telescopes over j < J to hop sum_{j<J} f_j + (f_J - f_0)(hop-1)/2
+        if (rw == 7) {
+          const double* psum = reinterpret_cast<const double*>(raw + kWtRows * kWtRS);
+          const double before = (psum[0] + psum[1]) + (psum[2] + psum[3]);                 // sum_{j < j0} f_j
+          const float f0_first = raw[kWtRows * kWtRS + 8];
+          const float fj = raw[min(lane, nfr) * kWtRS + 128], fj1 = raw[min(lane + 1, nfr) * kWtRS + 128];
+          const double fa = (double)fj, fb = (double)fj1;
+          const double mine = (lane < nfr) ? fa : 0.0;
+          double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..15)
+          incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
+          incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
+          incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
+          incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
+          const double s_excl = before + (incl - mine);
+          const double run = p.hop_d * s_excl + (fa - (double)f0_first) * p.half_hm1;
+          const double cyc = run * p.inv_sr;
+          // harmonics [0,kA) are below Nyquist at every sample of the frame, [kN,K) at none: both rows carry
+          // zeros there; [kA,kN) is decided per sample.  v_rcp_f32 (1 ulp) is well inside the 4e-6 guard band.
+          const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+          int kA = K, kN = K;
+          if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
+          if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
+          kA = max(min(kA, kN), 0);
+          if (lane <= kWtRows) t.f0[lane] = fj;
+          if (lane < kWtRows) {
+            t.theta[lane] = cyc - floor(cyc);
+            t.w[lane] = fa * p.inv_sr;
+            t.dw[lane] = (fb - fa) * p.inv_sr * p.inv_2hop;
+            t.kA[lane] = kA;
+            t.kN[lane] = kN;
+          }
+        }
+      }
+      DDSP_WT_STAMP(3);
+      __syncthreads();
+      DDSP_WT_STAMP(4);
+    }
+  }
+#undef DDSP_WT_STAMP
+}
+
+bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
+                   int inputs_are_controls) {
+  if (flags & DDSP_HARM_DIRECT_SUM) return false;
+  if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
+  if (inputs_are_controls || ctl_amp || ctl_hd || (flags >> 24) != 0) return false;
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 && ((uintptr_t)hd & 15) == 0;
+}
+
+int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, int B, int F,
+                      int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
+  TableArgs p;
+  p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
+  p.chunks_per_row = (F + kWtFrames - 1) / kWtFrames;
+  p.n_chunks = B * p.chunks_per_row;
+  p.nyquist = (float)(sample_rate / 2.0);
+  p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
+  p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
+  p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.f0_vec = ((F & 3) == 0 && ((uintptr_t)f0 & 15) == 0) ? 1 : 0;
+  p.inv_sr = 1.0 / (double)sample_rate;
+  p.inv_2hop = 0.5 / (double)p.hop;
+  p.hop_d = (double)p.hop;
+  p.half_hm1 = ((double)p.hop - 1.0) * 0.5;
+  // persistent grid: one block of 12 wavefronts per CU
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  const dim3 grid((unsigned)(p.n_chunks < n_cu ? p.n_chunks : n_cu)), block(768);
+  // DDSP_EXP_TABLE_TIMELINE=1: block 0 records shader-clock stamps per tick; printed after a synchronisation
+  static const bool timeline = getenv("DDSP_EXP_TABLE_TIMELINE") != nullptr;
+  static long long* dbg_buf = nullptr;
+  p.dbg = nullptr;
+  if (timeline) {
+    if (!dbg_buf && hipMalloc(&dbg_buf, 3 * 64 * 8 * sizeof(long long)) != hipSuccess) dbg_buf = nullptr;
+    if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 3 * 64 * 8 * sizeof(long long), st);
+    p.dbg = dbg_buf;
+  }
+  hipEvent_t ev0, ev1;
+  profile_kernel_events(kHarmTable, &ev0, &ev1);
+#define DDSP_LAUNCH_TABLE(W, NS)                                                                              \
+  do {                                                                                                        \
+    if (p.hop == 64)                                                                                          \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NS, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, p);                                                                        \
+    else                                                                                                      \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NS, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, p);                                                                        \
+  } while (0)
+  // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
+  if (K <= 64) DDSP_LAUNCH_TABLE(6, 8);
+  else if (K <= 100) DDSP_LAUNCH_TABLE(6, 13);
+  else DDSP_LAUNCH_TABLE(8, 16);
+#undef DDSP_LAUNCH_TABLE
+  if (p.dbg) {
+    static long long host[3 * 64 * 8];
+    if (hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(host, p.dbg, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess) {
+      const char* names[3] = {"T0", "S0", "S7"};
+      const long long t0 = host[0];
+      for (int w = 0; w < 3; ++w)
+        for (int i = 0; i < 64 && host[(w * 64 + i) * 8] != 0; ++i) {
+          const long long* r = host + (w * 64 + i) * 8;
+          fprintf(stderr, "[timeline] %s tick %3d  start %8lld  +%6lld +%6lld +%6lld  barrier +%6lld\n", names[w], i - 3,
+                  r[0] - t0, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]);
+        }
+    }
+  }
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+}  // namespace ddsp

@@ -26,6 +26,7 @@ enum KernelId {
   kNoiseBwdTaps,
   kNoiseBwdMags,
   kStftL1Bwd,
+  kHarmTable,
   kNumKernels
 };
 

@@ -11,7 +11,14 @@ from ddsp_amd import processors
 
 
 class Harmonic(processors.Processor):
-  """Synthesize audio with a bank of harmonic sinusoidal oscillators (synths.py:55-146)."""
+  """Synthesize audio with a bank of harmonic sinusoidal oscillators (synths.py:55-146).
+
+  `kernel` (an attribute, not a constructor argument - the constructor is the reference's) selects how
+  __call__ sums the harmonics where both kernels apply: 'auto' tabulates each frame's waveform on the
+  matrix cores and interpolates it per sample (harm_table_kernel), 'direct' evaluates every harmonic at
+  every sample (harm_fused_kernel).  Same result within the parity tolerance.
+  """
+  kernel = 'auto'
 
   def __init__(self,
                n_samples=64000,
@@ -96,8 +103,13 @@ class Harmonic(processors.Processor):
     return self._forward(amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict)
 
   def _flags(self, fuse):
-    return core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
-                                self.use_angular_cumsum)
+    flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
+                                 self.use_angular_cumsum)
+    if self.kernel == 'direct':
+      flags |= _lib.HARM_DIRECT_SUM
+    elif self.kernel != 'auto':
+      raise ValueError("Harmonic.kernel must be 'auto' or 'direct', got {!r}".format(self.kernel))
+    return flags
 
   def _forward(self, amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict=False):
     b, f, k = harmonic_distribution.shape
