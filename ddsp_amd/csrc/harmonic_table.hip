@@ -44,10 +44,13 @@ constexpr int kWtH = 4;              // halo entries on either side (>= W/2)
 constexpr int kWtTS = 268;           // table row stride in floats: 4*odd, so 16 rows' b128 writes spread over the banks
 constexpr int kWtRows = 16;          // amplitude rows per chunk (MFMA N)
 constexpr int kWtFrames = 15;        // frames per chunk: row r+1 is the "next" row of frame r
-constexpr int kWtKS = 68;            // row stride of an amplitude plane (odd / even harmonics): 4*odd
+constexpr int kWtPS = 72;            // row stride of an amplitude plane (fp16 elements; odd / even harmonics apart): 144 B
+constexpr float kWtLoScale = 2048.0f; // x = hi + lo / 2048 in two fp16 numbers
 constexpr int kWtRS = 132;           // row stride of the raw staging buffer: 128 harmonics, f0, amplitude
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct TableArgs {
   int B, F, K, N, hop, chunks_per_row, n_chunks;
@@ -120,13 +123,22 @@ __device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, f
 //     tick tau:   T: rows of chunk tau+3 -> staging;  MFMAs and table of chunk tau+1
 //                 S: phase B of chunk tau, then phase A of chunk tau+2
 // tables and staging double-buffered, planes / frame tables triple-buffered in LDS.
-// NS: k-steps of 4 per parity (ceil(K/2) <= 4 NS); ONE_TILE: hop == 64
-template <int W, int NS, bool ONE_TILE>
+//
+// Precision of the product.  The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the vector FMA rate and,
+// measured (tools/exp_table_timeline.py), *on* the vector ALUs' time: with it the S-wavefronts sharing the
+// SIMD crawled and the kernel was no faster than harm_fused_kernel.  The fp16 matrix cores are separate
+// hardware and 16x faster, so both factors are split into two fp16 numbers, x = hi + lo / 2048 with
+// hi = fp16(x), lo = fp16((x - hi) 2048) (the scaling keeps lo a normal number), and three products are
+// accumulated in fp32: hi.hi, and hi.lo + lo.hi in a second accumulator that is scaled back once.  The
+// dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
+// reproduces the split), below the fp32 round-off of the sum itself.
+// NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
+template <int W, int NK, bool ONE_TILE>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, TableArgs p) {
   __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
-  __shared__ __attribute__((aligned(16))) float planes_all[3][2 * kWtRows * kWtKS];   // [parity][row][k']: a_k / psi_hat(k)
+  __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
   __shared__ __attribute__((aligned(16))) float raw_all[2][kWtRows * kWtRS + 12];     // raw rows; then 4 doubles (parts of the sum of f0 before the chunk) and f0 of frame 0
   __shared__ ChunkTables t_all[3];
 
@@ -138,6 +150,10 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
   const int K4 = K >> 2;
   const float kLog10 = 2.302585092994046f;       // tf.math.log(exponent), ddsp/core.py:403
   const int n_my = ((int)p.n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // chunks of this block
+  // this block's chunks are blockIdx.x + i gridDim.x; (batch row, chunk within the row) advance by a fixed step
+  const int cpr = p.chunks_per_row;
+  const int step_b = (int)gridDim.x / cpr, step_c = (int)gridDim.x % cpr;
+  const int first_b = (int)blockIdx.x / cpr, first_c = (int)blockIdx.x % cpr;
   // 32 lanes per matrix row, lane kq owns harmonics 4 kq + 1 .. 4 kq + 4 (loads and phase A)
   const int sub = lane >> 5, kq = lane & 31;
   const bool live = kq < K4;
@@ -147,33 +163,39 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
   const int dbg_w = (wave == 0) ? 0 : (wave == 4) ? 1 : (wave == 11) ? 2 : -1;
   const bool dbg_on = p.dbg != nullptr && blockIdx.x == 0 && lane == 0 && dbg_w >= 0;
 #define DDSP_WT_STAMP(i) do { if (dbg_on && tick + 3 < 64) p.dbg[(dbg_w * 64 + tick + 3) * 8 + (i)] = clock64(); } while (0)
+#define DDSP_WT_ADVANCE(b_, c_) do { b_ += step_b; c_ += step_c; if (c_ >= cpr) { c_ -= cpr; b_ += 1; } } while (0)
 
   if (is_t) {
     // ---- this wavefront's share of the constant factor, in MFMA A-operand layout -----------------------
-    // A[i = lane & 15][kk = lane >> 4] of step s, parity par, position tile pt: sin(k phi_n) with
-    // n = 16 pt + i, k = 2 (4 s + kk) + 1 + par; the angle k (2n+1) / (2T) revolutions is exact in fp32.
-    float afrag[2][2][NS];
+    // element e of lane (i = lane & 15, g = lane >> 4) of k-step ks, parity par, position tile pt: sin(k phi_n),
+    // n = 16 pt + i, k' = 32 ks + 8 g + e, k = 2 k' + 1 + par (the B fragments use the same k'(g, e));
+    // the angle k (2n+1) / (2T) revolutions is exact in fp32.  Rows k > K meet zero amplitudes.
+    f16x8 ahi[2][2][NK], alo[2][2][NK];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const int n = 16 * (2 * rw + tt) + mi;
-          const int k = 2 * (4 * s + mg) + 1 + par;
-          const int num = (k * (2 * n + 1)) & (2 * kWtT - 1);
-          afrag[par][tt][s] = sin_rev((float)num * (1.0f / (2 * kWtT)));     // rows k > K meet zero amplitudes
-        }
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int n = 16 * (2 * rw + tt) + mi;
+            const int k = 2 * (32 * ks + 8 * mg + e) + 1 + par;
+            const int num = (k * (2 * n + 1)) & (2 * kWtT - 1);
+            const float v = sin_rev((float)num * (1.0f / (2 * kWtT)));
+            const _Float16 h = (_Float16)v;
+            ahi[par][tt][ks][e] = h;
+            alo[par][tt][ks][e] = (_Float16)((v - (float)h) * kWtLoScale);
+          }
+    int lb = first_b, lc = first_c;               // position of the chunk whose rows are fetched next
 
     for (int tick = -3; tick < n_my; ++tick) {
+      DDSP_WT_STAMP(0);
       // ---------------- rows of chunk tick+3: issue the loads -----------------------------------------------
       // Nothing below may depend on the loaded values until the MFMAs have been issued, so every load is
       // unconditional (indices clamped to something valid, the result masked after the MFMAs): past the
       // block's last chunk the last one is simply fetched again into a staging slot nobody reads.
-      DDSP_WT_STAMP(0);
-      const int lchunk = blockIdx.x + min(tick + 3, n_my - 1) * gridDim.x;
-      const int lb = lchunk / p.chunks_per_row;
-      const int lj0 = (lchunk - lb * p.chunks_per_row) * kWtFrames;
+      const int lj0 = lc * kWtFrames;
       const int kqc = min(kq, K4 - 1);
       const int lrow0 = lb * F + min(lj0 + rw * 4 + sub, F - 1), lrow1 = lb * F + min(lj0 + rw * 4 + 2 + sub, F - 1);
       const float4 lx0 = hd4[(size_t)lrow0 * K4 + kqc], lx1 = hd4[(size_t)lrow1 * K4 + kqc];
@@ -191,28 +213,41 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
       DDSP_WT_STAMP(1);
       // ---------------- table of chunk tick+1: O and E on the quarter range -----------------------------------
       if (tick + 1 >= 0 && tick + 1 < n_my) {
-        const float* bsrc = planes_all[(tick + 1) % 3] + mi * kWtKS + mg;   // B[kk = lane >> 4][j = lane & 15]: plane[par][row j][4 s + kk]
-        f32x4 acc[2][2];
+        // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row j][32 ks + 8 g + e]
+        const _Float16* bsrc = planes_all[(tick + 1) % 3] + mi * kWtPS + 8 * mg;
+        f32x4 acc[2][2], accx[2][2];
 #pragma unroll
         for (int par = 0; par < 2; ++par)
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) acc[par][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int tt = 0; tt < 2; ++tt) {
+            acc[par][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[par][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
           for (int par = 0; par < 2; ++par) {
-            const float bv = bsrc[par * kWtRows * kWtKS + 4 * s];
+            const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS + 32 * ks);
+            const f16x8 blo = *reinterpret_cast<const f16x8*>(bsrc + (1 * 2 + par) * kWtRows * kWtPS + 32 * ks);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
-              acc[par][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[par][tt][s], bv, acc[par][tt], 0, 0, 0);
+              acc[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][tt][ks], bhi, acc[par][tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              accx[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][tt][ks], blo, accx[par][tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              accx[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[par][tt], 0, 0, 0);
           }
         // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
         float* trow = tab_all[(tick + 1) & 1] + mi * kWtTS + kWtH;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int n0 = 16 * (2 * rw + tt) + 4 * mg;
-          const f32x4 sp = acc[0][tt] + acc[1][tt];         // S(n)         = O + E
-          const f32x4 sm = acc[0][tt] - acc[1][tt];         // S(T/2-1-n)   = O - E
+          const f32x4 so = acc[0][tt] + accx[0][tt] * (1.0f / kWtLoScale);     // odd harmonics
+          const f32x4 se = acc[1][tt] + accx[1][tt] * (1.0f / kWtLoScale);     // even harmonics
+          const f32x4 sp = so + se;                         // S(n)         = O + E
+          const f32x4 sm = so - se;                         // S(T/2-1-n)   = O - E
           *reinterpret_cast<f32x4*>(trow + n0) = sp;
           *reinterpret_cast<f32x4*>(trow + (kWtHalf - 4 - n0)) = (f32x4){sm.w, sm.z, sm.y, sm.x};
           if (n0 == 0) {                                     // halos: S(-1-m) = -S(m), S(T/2+m) = -S(T/2-1-m)
@@ -243,6 +278,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           if (rw == 0) raw[kWtRows * kWtRS + 8] = f0_first;
         }
       }
+      if (tick + 3 < n_my - 1) DDSP_WT_ADVANCE(lb, lc);
       DDSP_WT_STAMP(3);
       __syncthreads();
       DDSP_WT_STAMP(4);
@@ -252,18 +288,19 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
     const int arow = rw * 2 + sub;                 // the chunk row this lane works on in phase A
+    int bb = first_b, bc = first_c;                // position of the chunk of the next phase B
+    int ab = first_b, ac = first_c;                // position of the chunk of the next phase A
 
     for (int tick = -3; tick < n_my; ++tick) {
       DDSP_WT_STAMP(0);
       if (tick >= 0) {
         // ---------------- phase B of chunk tick: tiles of 64 samples, lanes = samples ----------------------
-        const int chunk = blockIdx.x + tick * gridDim.x;
-        const int b = chunk / p.chunks_per_row;
-        const int j0 = (chunk - b * p.chunks_per_row) * kWtFrames;
+        const int j0 = bc * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
-        const int row0 = b * F + j0;
+        const int row0 = bb * F + j0;
+        DDSP_WT_ADVANCE(bb, bc);
         const float* tab = tab_all[tick & 1];
-        const float* planes = planes_all[tick % 3];
+        const _Float16* planes = planes_all[tick % 3];
         const ChunkTables& t = t_all[tick % 3];
         const int hop = p.hop;
         const float inv_hop = 1.0f / (float)hop;
@@ -300,9 +337,10 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
               const float kf = (float)(k + 1);
               const float top = fj * kf, bot = fj1 * kf;
               const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
-              const float* pl = planes + (k & 1) * kWtRows * kWtKS + q * kWtKS + (k >> 1);
-              const float psi = WtPoly<W>::psi(k + 1);
-              const float ak = (w_cur * pl[0] + w_next * pl[kWtKS]) * psi;
+              const _Float16* pl = planes + ((k & 1) * kWtRows + q) * kWtPS + (k >> 1);
+              const float c0 = (float)pl[0] + (float)pl[2 * kWtRows * kWtPS] * (1.0f / kWtLoScale);
+              const float c1 = (float)pl[kWtPS] + (float)pl[2 * kWtRows * kWtPS + kWtPS] * (1.0f / kWtLoScale);
+              const float ak = (w_cur * c0 + w_next * c1) * WtPoly<W>::psi(k + 1);
               const float sv = sin_rev(fmaf(theta, kf, -rintf(theta * kf)));     // exact fractional part of k theta
               if (fk >= p.nyquist) out = fmaf(-ak, sv, out);
             }
@@ -315,12 +353,11 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+15 (clamped at F-1) -> planes ----
         // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
         // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
-        const int chunk = blockIdx.x + (tick + 2) * gridDim.x;
-        const int b = chunk / p.chunks_per_row;
-        const int j0 = (chunk - b * p.chunks_per_row) * kWtFrames;
+        const int j0 = ac * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
+        DDSP_WT_ADVANCE(ab, ac);
         const float* raw = raw_all[(tick + 2) & 1];
-        float* planes = planes_all[(tick + 2) % 3];
+        _Float16* planes = planes_all[(tick + 2) % 3];
         ChunkTables& t = t_all[(tick + 2) % 3];
         {
           const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
@@ -340,9 +377,21 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           part += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, part), 0x401F));   // lane ^ 16
           const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
           const float a = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f) * inv;
-          float* dst = planes + arow * kWtKS + 2 * kq;
-          *reinterpret_cast<float2*>(dst) = make_float2(a * x[0] * ipsi[0], a * x[2] * ipsi[2]);                       // k odd
-          *reinterpret_cast<float2*>(dst + kWtRows * kWtKS) = make_float2(a * x[1] * ipsi[1], a * x[3] * ipsi[3]);    // k even
+          // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
+          f16x2 hi[2], lo[2];                      // [parity][k' = 2 kq, 2 kq + 1]
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float c = a * x[u] * ipsi[u];
+            const _Float16 h = (_Float16)c;
+            hi[u & 1][u >> 1] = h;
+            lo[u & 1][u >> 1] = (_Float16)((c - (float)h) * kWtLoScale);
+          }
+          _Float16* dst = planes + arow * kWtPS + 2 * kq;
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            *reinterpret_cast<f16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi[par];
+            *reinterpret_cast<f16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo[par];
+          }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
         // frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
@@ -385,6 +434,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     }
   }
 #undef DDSP_WT_STAMP
+#undef DDSP_WT_ADVANCE
 }
 
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
@@ -430,19 +480,19 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-#define DDSP_LAUNCH_TABLE(W, NS)                                                                              \
+#define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
   do {                                                                                                        \
     if (p.hop == 64)                                                                                          \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NS, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, p);                                                                        \
     else                                                                                                      \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NS, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, p);                                                                        \
   } while (0)
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
-  if (K <= 64) DDSP_LAUNCH_TABLE(6, 8);
-  else if (K <= 100) DDSP_LAUNCH_TABLE(6, 13);
-  else DDSP_LAUNCH_TABLE(8, 16);
+  if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);
+  else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
+  else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
   if (p.dbg) {
     static long long host[3 * 64 * 8];

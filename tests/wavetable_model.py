@@ -53,8 +53,19 @@ def harmonic_table_model(amplitudes, hd, f0_hz, n_samples, sample_rate=16000, T=
   sinm = np.sin(2 * np.pi * ang).astype(F32)                            # [NQ,K]
   cdec = (rows * invpsi[1:K + 1]).astype(F32)
   odd, even = np.arange(0, K, 2), np.arange(1, K, 2)                    # k = 1,3,.. / 2,4,..
-  O = np.einsum('nk,bfk->bfn', sinm[:, odd], cdec[..., odd]).astype(F32)
-  E = np.einsum('nk,bfk->bfn', sinm[:, even], cdec[..., even]).astype(F32)
+  # both factors as two fp16 numbers, x = hi + lo / 2048; three products accumulated in fp32 (the kernel's MFMAs)
+  def split(v):
+    hi = v.astype(np.float16)
+    lo = ((v - hi.astype(F32)) * F32(2048)).astype(np.float16)
+    return hi.astype(F32), lo.astype(F32)
+  ah, al = split(sinm)
+  bh, bl = split(cdec)
+  def prod(sel):
+    main = np.einsum('nk,bfk->bfn', ah[:, sel], bh[..., sel]).astype(F32)
+    cross = (np.einsum('nk,bfk->bfn', ah[:, sel], bl[..., sel]) +
+             np.einsum('nk,bfk->bfn', al[:, sel], bh[..., sel])).astype(F32)
+    return (main + cross * F32(1.0 / 2048)).astype(F32)
+  O, E = prod(odd), prod(even)
   half = T // 2
   tab = np.zeros((B, Fr + 1, half + 2 * H), F32)                        # index p + H, p = -H .. half+H-1
   tab[..., H + n] = O + E
