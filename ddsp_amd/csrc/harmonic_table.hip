@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/ddsp_amd.h"
 #include "common.h"
 #include "profile.h"
@@ -50,7 +51,7 @@ constexpr int kWtRS = 132;           // row stride of the raw staging buffer: 12
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));      // what v_cvt_pkrtz_f16_f32 returns
 
 struct TableArgs {
   int B, F, K, N, hop, chunks_per_row, n_chunks;
@@ -110,6 +111,22 @@ __device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, f
   acc1 = fmaf(w_lo, t0[kWtTS - P], acc1);
   acc1 = fmaf(w_hi, t0[kWtTS + 1 + P], acc1);
   if constexpr (P + 1 < W / 2) wt_taps<W, P + 1>(t0, z, z2, acc0, acc1);
+}
+
+// the same for two tiles at once (two independent chains per instruction slot)
+template <int W, int P>
+__device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const float* __restrict__ tb, float za, float zb,
+                                         float za2, float zb2, float (&acc0)[2], float (&acc1)[2]) {
+  float la, ha, lb, hb;
+  wt_pair<W, P>(za, za2, la, ha);
+  wt_pair<W, P>(zb, zb2, lb, hb);
+  const float a0 = ta[-P], a1 = ta[1 + P], a2 = ta[kWtTS - P], a3 = ta[kWtTS + 1 + P];
+  const float b0 = tb[-P], b1 = tb[1 + P], b2 = tb[kWtTS - P], b3 = tb[kWtTS + 1 + P];
+  acc0[0] = fmaf(la, a0, acc0[0]);  acc0[1] = fmaf(lb, b0, acc0[1]);
+  acc1[0] = fmaf(la, a2, acc1[0]);  acc1[1] = fmaf(lb, b2, acc1[1]);
+  acc0[0] = fmaf(ha, a1, acc0[0]);  acc0[1] = fmaf(hb, b1, acc0[1]);
+  acc1[0] = fmaf(ha, a3, acc1[0]);  acc1[1] = fmaf(hb, b3, acc1[1]);
+  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
 }
 
 // One block = 12 wavefronts in two roles, one block per CU.  T-wavefronts (0..3, one per SIMD) own the
@@ -306,46 +323,73 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const float inv_hop = 1.0f / (float)hop;
         const int tiles_per_frame = hop >> 6;
         const int n_tiles = nfr * tiles_per_frame;
-        for (int tile = rw; tile < n_tiles; tile += 8) {
-          const int q = ONE_TILE ? tile : tile / tiles_per_frame;
-          const int r = ONE_TILE ? lane : (tile - q * tiles_per_frame) * 64 + lane;
-          const double rr = (double)r;
-          // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
-          const double cyc = t.theta[q] + (rr + 1.0) * (t.w[q] + t.dw[q] * rr);
-          const float theta = (float)(cyc - floor(cyc));                 // [0, 1]
-          const bool neg = theta >= 0.5f;                               // S(1 - theta) = -S(theta)
-          const float th = neg ? 1.0f - theta : theta;                  // [0, 0.5]
-          const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
-          const float fl = floorf(pos);
-          const float z = (pos - fl) - 0.5f;
-          const int i0 = (int)fl;                                       // [-1, 255]
-          const float* t0 = tab + q * kWtTS + kWtH + i0;
-          float acc0 = 0.0f, acc1 = 0.0f;
-          wt_taps<W, 0>(t0, z, z * z, acc0, acc1);
-          const float lerp = (float)r * inv_hop;
-          // frame-rate -> audio-rate amplitude envelope: weight of frame j+1 is lerp ('linear', core.resample)
-          // or the periodic Hann(2 hop)[r] ('window', core.py:696-698)
-          const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
-          const float w_cur = 1.0f - w_next;
-          float out = w_cur * acc0 + w_next * acc1;
-          out = neg ? -out : out;
-          const int kA = __builtin_amdgcn_readfirstlane(t.kA[q]);
-          const int kN = __builtin_amdgcn_readfirstlane(t.kN[q]);
-          if (kA < kN) {           // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
-            const float fj = t.f0[q], fj1 = t.f0[q + 1];
-            for (int k = kA; k < kN; ++k) {
-              const float kf = (float)(k + 1);
-              const float top = fj * kf, bot = fj1 * kf;
-              const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
-              const _Float16* pl = planes + ((k & 1) * kWtRows + q) * kWtPS + (k >> 1);
-              const float c0 = (float)pl[0] + (float)pl[2 * kWtRows * kWtPS] * (1.0f / kWtLoScale);
-              const float c1 = (float)pl[kWtPS] + (float)pl[2 * kWtRows * kWtPS + kWtPS] * (1.0f / kWtLoScale);
-              const float ak = (w_cur * c0 + w_next * c1) * WtPoly<W>::psi(k + 1);
-              const float sv = sin_rev(fmaf(theta, kf, -rintf(theta * kf)));     // exact fractional part of k theta
-              if (fk >= p.nyquist) out = fmaf(-ak, sv, out);
+        // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
+        // instructions, and a wavefront with a single chain leaves most issue slots empty
+        auto tiles = [&](int tile, auto nt_tag) {
+          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + 8 (NT == 2) or tile alone
+          int q[2], r[2];
+          double cyc[2];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            const int tl = tile + 8 * u;
+            q[u] = ONE_TILE ? tl : tl / tiles_per_frame;
+            r[u] = ONE_TILE ? lane : (tl - q[u] * tiles_per_frame) * 64 + lane;
+            const double rr = (double)r[u];
+            // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
+            cyc[u] = t.theta[q[u]] + (rr + 1.0) * (t.w[q[u]] + t.dw[q[u]] * rr);
+          }
+          float theta[2], z[2];
+          bool neg[2];
+          const float* t0[2];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            theta[u] = (float)(cyc[u] - floor(cyc[u]));                     // [0, 1]
+            neg[u] = theta[u] >= 0.5f;                                    // S(1 - theta) = -S(theta)
+            const float th = neg[u] ? 1.0f - theta[u] : theta[u];         // [0, 0.5]
+            const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
+            const float fl = floorf(pos);
+            z[u] = (pos - fl) - 0.5f;
+            t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
+          }
+          float acc0[2] = {0.0f, 0.0f}, acc1[2] = {0.0f, 0.0f};
+          if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z[0] * z[0], z[1] * z[1], acc0, acc1);
+          else wt_taps<W, 0>(t0[0], z[0], z[0] * z[0], acc0[0], acc1[0]);
+          float out[2], w_cur[2], w_next[2], lerp[2];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            lerp[u] = (float)r[u] * inv_hop;
+            // frame-rate -> audio-rate amplitude envelope: weight of frame j+1 is lerp ('linear', core.resample)
+            // or the periodic Hann(2 hop)[r] ('window', core.py:696-698)
+            w_next[u] = p.amp_linear ? lerp[u] : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp[u]);
+            w_cur[u] = 1.0f - w_next[u];
+            const float v = w_cur[u] * acc0[u] + w_next[u] * acc1[u];
+            out[u] = neg[u] ? -v : v;
+          }
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            const int kA = __builtin_amdgcn_readfirstlane(t.kA[q[u]]);
+            const int kN = __builtin_amdgcn_readfirstlane(t.kN[q[u]]);
+            if (kA < kN) {         // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
+              const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
+              for (int k = kA; k < kN; ++k) {
+                const float kf = (float)(k + 1);
+                const float top = fj * kf, bot = fj1 * kf;
+                const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp[u]));
+                const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
+                const float c0 = (float)pl[0] + (float)pl[2 * kWtRows * kWtPS] * (1.0f / kWtLoScale);
+                const float c1 = (float)pl[kWtPS] + (float)pl[2 * kWtRows * kWtPS + kWtPS] * (1.0f / kWtLoScale);
+                const float ak = (w_cur[u] * c0 + w_next[u] * c1) * WtPoly<W>::psi(k + 1);
+                const float sv = sin_rev(fmaf(theta[u], kf, -rintf(theta[u] * kf)));     // exact fractional part of k theta
+                if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
+              }
             }
           }
-          audio[(size_t)(row0 + q) * hop + r] = out;                    // N == F * hop
+          audio[(size_t)(row0 + q[0]) * hop + r[0]] = out[0];            // N == F * hop
+          if constexpr (NT == 2) audio[(size_t)(row0 + q[1]) * hop + r[1]] = out[1];
+        };
+        for (int tile = rw; tile < n_tiles; tile += 16) {
+          if (tile + 8 < n_tiles) tiles(tile, std::integral_constant<int, 2>{});
+          else tiles(tile, std::integral_constant<int, 1>{});
         }
       }
       DDSP_WT_STAMP(1);
@@ -373,24 +417,29 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           part += dpp_mov0<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]
           part += dpp_mov0<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]
           part += dpp_mov0<0x141, 0xF>(part);     // row_half_mirror
-          part += dpp_mov0<0x140, 0xF>(part);     // row_mirror
-          part += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, part), 0x401F));   // lane ^ 16
+          part += dpp_mov0<0x140, 0xF>(part);     // row_mirror: every lane holds its 16-lane row's sum
+          {                                        // + the other row of the pair, through SGPRs (no LDS round trip)
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
+            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
+            part = sub ? s2 + s3 : s0 + s1;
+          }
           const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
           const float a = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f) * inv;
           // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
-          f16x2 hi[2], lo[2];                      // [parity][k' = 2 kq, 2 kq + 1]
+          // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
+          float c[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float c = a * x[u] * ipsi[u];
-            const _Float16 h = (_Float16)c;
-            hi[u & 1][u >> 1] = h;
-            lo[u & 1][u >> 1] = (_Float16)((c - (float)h) * kWtLoScale);
-          }
+          for (int u = 0; u < 4; ++u) c[u] = a * x[u] * ipsi[u];
           _Float16* dst = planes + arow * kWtPS + 2 * kq;
 #pragma unroll
-          for (int par = 0; par < 2; ++par) {
-            *reinterpret_cast<f16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi[par];
-            *reinterpret_cast<f16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo[par];
+          for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
+            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
+            const h16x2 lo = __builtin_amdgcn_cvt_pkrtz((c[par] - (float)hi[0]) * kWtLoScale,
+                                                        (c[par + 2] - (float)hi[1]) * kWtLoScale);
+            *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
+            *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
           }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
