@@ -19,6 +19,12 @@ echo "== rocprofv3 kernel trace"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 ls -R $OUT/prof | head -20
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -2); do echo "--- $f"; head -15 $f; done
+echo "== rocprofv3 kernel trace, batch 128 (north-star shape: one stream, harm_table_kernel dominant)"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
+for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do echo "--- $f"; head -8 $f | cut -c1-220; done
+echo "== Harmonic: wavetable kernel vs direct sum, and the wavetable kernel's per-tick timeline"
+timeout 120 python tools/exp_table.py 32 128 2>&1 | tail -2 | tee $OUT/harm_table_vs_direct.json
+timeout 120 python tools/exp_table_timeline.py 32 2>&1 | grep -A40 "launch 2" | tee $OUT/timeline_harm_table_b32.txt | head -5
 echo "== torchrun world=1 sanity (the N>1 code path of bench.py)"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-300
 echo "== next-row benches (Reverb, SpectralLoss, backward)"
