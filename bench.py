@@ -239,14 +239,15 @@ def main():
     dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes   # its Processor's bytes
     achieved = dom_bytes / dom_avg_s / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):
-      try:
-        rec = json.load(open(tpath))
-        if rec.get('batch') == B:
-          traffic = rec.get('kernels', {}).get(dominant)
-      except (ValueError, OSError):
-        traffic = None
+    for tname in ('pmc_traffic_b%d.json' % B, 'pmc_traffic.json'):     # PMC passes are per batch size
+      tpath = os.path.join(ROOT, 'profiles', tname)
+      if traffic is None and os.path.exists(tpath):
+        try:
+          rec = json.load(open(tpath))
+          if rec.get('batch') == B:
+            traffic = rec.get('kernels', {}).get(dominant)
+        except (ValueError, OSError):
+          traffic = None
     step_bytes = harm_bytes + noise_bytes
     result = {
         'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
