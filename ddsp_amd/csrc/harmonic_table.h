@@ -6,12 +6,12 @@
 namespace ddsp {
 
 // True when ddsp_harmonic_f32 can run on harm_table_kernel: raw network outputs in (exp_sigmoid +
-// Nyquist-normalised distribution, the defaults of ddsp/synths.py:59-66), no controls dict requested,
-// N % F == 0 with a frame size that is a multiple of 64, K % 4 == 0 and K <= 128.
+// Nyquist-normalised distribution, the defaults of ddsp/synths.py:59-66), the controls dict requested in full
+// or not at all, N % F == 0 with a frame size that is a multiple of 64, K % 4 == 0 and K <= 128.
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
                    int inputs_are_controls);
 
-int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, int B, int F,
-                      int K, int N, int sample_rate, unsigned flags, hipStream_t st);
+int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
+                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st);
 
 }  // namespace ddsp

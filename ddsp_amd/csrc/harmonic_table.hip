@@ -153,7 +153,7 @@ __device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const flo
 template <int W, int NK, bool ONE_TILE>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
-    float* __restrict__ audio, TableArgs p) {
+    float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
   __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
   __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
   __shared__ __attribute__((aligned(16))) float raw_all[2][kWtRows * kWtRS + 12];     // raw rows; then 4 doubles (parts of the sum of f0 before the chunk) and f0 of frame 0
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
         const int j0 = ac * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
+        const int crow = ab * F + j0 + arow;           // this lane's (batch * frame) row, if arow < nfr
         DDSP_WT_ADVANCE(ab, ac);
         const float* raw = raw_all[(tick + 2) & 1];
         _Float16* planes = planes_all[(tick + 2) % 3];
@@ -426,7 +427,15 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             part = sub ? s2 + s3 : s0 + s1;
           }
           const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
-          const float a = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f) * inv;
+          const float a_ctl = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f);
+          const float a = a_ctl * inv;
+          // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
+          // belongs to the next chunk
+          if (ctl_hd != nullptr && arow < nfr) {
+            if (live)
+              reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv);
+            if (kq == 0) ctl_amp[crow] = a_ctl;
+          }
           // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
           // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
           float c[4];
@@ -490,12 +499,13 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
                    int inputs_are_controls) {
   if (flags & DDSP_HARM_DIRECT_SUM) return false;
   if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
-  if (inputs_are_controls || ctl_amp || ctl_hd || (flags >> 24) != 0) return false;
-  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 && ((uintptr_t)hd & 15) == 0;
+  if (inputs_are_controls || (ctl_amp == nullptr) != (ctl_hd == nullptr) || (flags >> 24) != 0) return false;
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 &&
+         (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0;
 }
 
-int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, int B, int F,
-                      int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
+int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
+                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
   TableArgs p;
   p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
   p.chunks_per_row = (F + kWtFrames - 1) / kWtFrames;
@@ -533,10 +543,10 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   do {                                                                                                        \
     if (p.hop == 64)                                                                                          \
       hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, p);                                                                        \
+                            audio, ctl_amp, ctl_hd, p);                                                                        \
     else                                                                                                      \
       hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, p);                                                                        \
+                            audio, ctl_amp, ctl_hd, p);                                                                        \
   } while (0)
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
   if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);

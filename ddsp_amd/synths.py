@@ -93,13 +93,12 @@ class Harmonic(processors.Processor):
     needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or
                                               harmonic_distribution.requires_grad)
     if needs_grad:
-      audio = _HarmonicFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse)
+      # one launch gives the audio and, if asked for, the controls dict (not differentiable here)
+      audio, ctl_amp, ctl_hd = _HarmonicFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse,
+                                                       bool(return_outputs_dict))
       if not return_outputs_dict:
         return audio
-      with torch.no_grad():                               # the controls dict is not differentiable here
-        controls = self._forward(amplitudes.detach(), harmonic_distribution.detach(), f0_hz, fuse,
-                                 True)['controls']
-      return dict(signal=audio, controls=controls)
+      return dict(signal=audio, controls={'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz})
     return self._forward(amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict)
 
   def _flags(self, fuse):
@@ -153,17 +152,24 @@ class _HarmonicFunction(torch.autograd.Function):
   """torch.autograd node of Harmonic.__call__ (plumbing: both directions are C-ABI calls)."""
 
   @staticmethod
-  def forward(ctx, amplitudes, harmonic_distribution, f0_hz, synth, fuse):
+  def forward(ctx, amplitudes, harmonic_distribution, f0_hz, synth, fuse, want_controls):
     ctx.save_for_backward(amplitudes, harmonic_distribution, f0_hz)
     ctx.synth, ctx.fuse = synth, fuse
-    return synth._forward(amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach(), fuse)
+    out = synth._forward(amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach(), fuse, want_controls)
+    if not want_controls:
+      empty = amplitudes.new_empty(0)
+      ctx.mark_non_differentiable(empty)
+      return out, empty, empty
+    ctl_amp, ctl_hd = out['controls']['amplitudes'], out['controls']['harmonic_distribution']
+    ctx.mark_non_differentiable(ctl_amp, ctl_hd)
+    return out['signal'], ctl_amp, ctl_hd
 
   @staticmethod
-  def backward(ctx, grad_audio):
+  def backward(ctx, grad_audio, _grad_ctl_amp, _grad_ctl_hd):
     amplitudes, harmonic_distribution, f0_hz = ctx.saved_tensors
     grad_amp, grad_hd = ctx.synth._backward(amplitudes.detach(), harmonic_distribution.detach(),
                                             f0_hz.detach(), ctx.fuse, grad_audio)
-    return grad_amp, grad_hd, None, None, None
+    return grad_amp, grad_hd, None, None, None, None
 
 
 class FilteredNoise(processors.Processor):
