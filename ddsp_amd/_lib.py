@@ -60,6 +60,12 @@ SIGNATURES = {
     'ddsp_oscillator_bank_workspace_bytes': (c_size_t, [c_int] * 3),
     'ddsp_oscillator_bank_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 + [c_voidp]),
     'ddsp_resample_f32': (c_int, [c_f32p] * 2 + [c_int] * 5 + [c_voidp]),
+    'ddsp_resample_ex_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
+    'ddsp_fft_convolve_f32': (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_voidp]),
+    'ddsp_harmonic_envelopes_f32': (c_int, [c_f32p] * 6 + [c_int] * 3 + [c_voidp]),
+    'ddsp_harmonic_f0_grad_workspace_bytes': (c_size_t, [c_int] * 4),
+    'ddsp_harmonic_f0_grad_f32': (c_int, [c_f32p] * 5 + [c_voidp, c_size_t] + [c_int] * 5 +
+                                  [c_uint, c_voidp]),
     'ddsp_profile_kernel_count': (c_int, []),
     'ddsp_profile_kernel_name': (ctypes.c_char_p, [c_int]),
     'ddsp_profile_begin': (c_int, [c_uint, c_int]),
@@ -75,6 +81,7 @@ HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
 NOISE_SCALE_EXP_SIGMOID = 0x1
+RESAMPLE_METHODS = {'nearest': 0, 'linear': 1, 'cubic': 2, 'window': 3}
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2
 CONV_REVERSE_AUDIO = 0x4

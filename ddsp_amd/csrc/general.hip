@@ -1,0 +1,371 @@
+// General-shape kernels for gfx950 that complete the argument space of the hot path's own functions
+// where the fast kernels are specialised (SURVEY.md section 8, rows a5-a7, a13 and the backward row):
+//
+//   ddsp_resample_ex_f32          core.resample, every method ('nearest', 'linear', 'cubic', 'window'),
+//                                 add_endpoint True / False, up- and down-sampling (ddsp/core.py:573-714)
+//   ddsp_fft_convolve_f32         core.fft_convolve for any crop: padding 'valid' or 'same', any
+//                                 delay_compensation (ddsp/core.py:1382-1473, 1338-1379)
+//   ddsp_harmonic_envelopes_f32   the frame-rate tensors core.harmonic_synthesis builds before it resamples:
+//                                 k f0 (1 + harmonic_shifts) and amplitudes * harmonic_distribution
+//                                 (ddsp/core.py:1080-1098, 1028-1045)
+//   ddsp_harmonic_f0_grad_f32     dL/d f0_hz of Harmonic (what tf.GradientTape forms through tf.cumsum and
+//                                 tf.sin, ddsp/core.py:950-960; trainers.py:162-171)
+//
+// These are generality paths: one thread per output value, HBM / L2 reads only, no LDS, no cross-lane
+// traffic, no inline assembly.  Their cost is irrelevant next to the fused kernels of harmonic*.hip and
+// filtered_noise.hip (no shipped gin config reaches them); what matters is that the reference's argument
+// space has no holes.  Because they are written in plain HIP, tests/hip_emu compiles this very file for the
+// host and the CPU test run checks every entry point against the oracle (tests/test_general_emulated.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ddsp_amd.h"
+
+namespace ddsp {
+namespace general {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ size_t global_thread() { return (size_t)blockIdx.x * kThreads + threadIdx.x; }
+__device__ __forceinline__ size_t grid_threads() { return (size_t)gridDim.x * kThreads; }
+
+// =====================================================================================
+// core.resample (ddsp/core.py:573-642): tf.compat.v1.image.resize on [B,F,1,C] -> [B,N,1,C] for
+// 'nearest' / 'linear' / 'cubic' (legacy kernels, half_pixel_centers=False, align_corners =
+// not add_endpoint; the width axis is 1 -> 1, a copy), core.upsample_with_windows for 'window'.
+// =====================================================================================
+struct ResampleArgs {
+  int F, N, C;
+  int method;          // DDSP_RESAMPLE_*
+  int align_corners;   // not add_endpoint
+  int hop;             // 'window': N / n_intervals
+  float scale;         // in fp32 as TF computes it: F/N, or (F-1)/(N-1) with align_corners and N > 1
+};
+
+// TF's bicubic coefficient table (A = -0.75, 1024 entries): the two polynomials in double on the
+// float abscissa, rounded to float once, exactly as the table is filled.
+__device__ __forceinline__ float cubic_near(int i) {      // |x| <= 1:  ((A+2)x - (A+3)) x^2 + 1
+  const double A = -0.75;
+  const double x = (double)((float)i * (1.0f / 1024.0f));
+  return (float)(((A + 2.0) * x - (A + 3.0)) * x * x + 1.0);
+}
+__device__ __forceinline__ float cubic_far(int i) {       // 1 <= x <= 2:  ((A x - 5A) x + 8A) x - 4A
+  const double A = -0.75;
+  const double x = (double)((float)i * (1.0f / 1024.0f) + 1.0f);
+  return (float)(((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A);
+}
+
+__global__ __launch_bounds__(kThreads) void resample_ex_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ out, ResampleArgs p) {
+  const int b = blockIdx.y;
+  const size_t total = (size_t)p.N * p.C;
+  const float* __restrict__ xb = x + (size_t)b * p.F * p.C;
+  float* __restrict__ ob = out + (size_t)b * total;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const int t = (int)(i / p.C), c = (int)(i - (size_t)t * p.C);
+    float v;
+    if (p.method == DDSP_RESAMPLE_WINDOW) {
+      // upsample_with_windows (core.py:645-714) in closed form: frame j = t / hop fades out with
+      // Hann(2 hop)[hop + r], frame j + 1 fades in with Hann(2 hop)[r]; with add_endpoint the
+      // appended frame repeats the last one
+      const int j = t / p.hop, r = t - j * p.hop;
+      const int hi = min(j + 1, p.F - 1);
+      const float w = 0.5f - 0.5f * cospif((float)r / (float)p.hop);
+      v = xb[(size_t)j * p.C + c] * (1.0f - w) + xb[(size_t)hi * p.C + c] * w;
+    } else {
+      const float pos = (float)t * p.scale;           // legacy scaler: out * scale
+      if (p.method == DDSP_RESAMPLE_NEAREST) {
+        const int src = min((int)(p.align_corners ? roundf(pos) : floorf(pos)), p.F - 1);
+        v = xb[(size_t)src * p.C + c];
+      } else if (p.method == DDSP_RESAMPLE_LINEAR) {
+        const float lo = floorf(pos);
+        const int lo_i = min(max((int)lo, 0), p.F - 1), hi_i = min((int)ceilf(pos), p.F - 1);
+        const float top = xb[(size_t)lo_i * p.C + c], bottom = xb[(size_t)hi_i * p.C + c];
+        v = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+      } else {                                          // DDSP_RESAMPLE_CUBIC
+        const float lo = floorf(pos);
+        const int src = (int)lo;
+        const int offset = (int)lrintf((pos - lo) * 1024.0f);
+        const float w0 = cubic_far(offset), w1 = cubic_near(offset);
+        const float w2 = cubic_near(1024 - offset), w3 = cubic_far(1024 - offset);
+        const int i0 = min(max(src - 1, 0), p.F - 1), i1 = min(max(src, 0), p.F - 1);
+        const int i2 = min(max(src + 1, 0), p.F - 1), i3 = min(max(src + 2, 0), p.F - 1);
+        // Interpolate1D: v0 w0 + v1 w1 + v2 w2 + v3 w3, fp32, left to right, no contraction
+        float acc = __fmul_rn(xb[(size_t)i0 * p.C + c], w0);
+        acc = __fadd_rn(acc, __fmul_rn(xb[(size_t)i1 * p.C + c], w1));
+        acc = __fadd_rn(acc, __fmul_rn(xb[(size_t)i2 * p.C + c], w2));
+        v = __fadd_rn(acc, __fmul_rn(xb[(size_t)i3 * p.C + c], w3));
+      }
+    }
+    ob[i] = v;
+  }
+}
+
+// =====================================================================================
+// core.fft_convolve (ddsp/core.py:1382-1473) as the direct time-varying FIR it equals:
+//   z[m] = sum_i x[i] h_{frame(i)}[m - i]   (framed FFT products, overlap-added)
+//   out[n] = z[n + start], n < n_out        (crop_and_compensate_delay, :1338-1379)
+// One thread per output sample; taps and samples come from L2.
+// =====================================================================================
+struct FirArgs {
+  int N, F, L, frame_size, start, n_out;
+  size_t ir_batch_stride;   // F*L, or 0 when the impulse response is broadcast over the batch
+};
+
+__global__ __launch_bounds__(kThreads) void tv_fir_any_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ ir,
+                                                              float* __restrict__ out, FirArgs p) {
+  const int b = blockIdx.y;
+  const float* __restrict__ xb = x + (size_t)b * p.N;
+  const float* __restrict__ hb = ir + (size_t)b * p.ir_batch_stride;
+  float* __restrict__ ob = out + (size_t)b * p.n_out;
+  for (size_t n = global_thread(); n < (size_t)p.n_out; n += grid_threads()) {
+    const long m = (long)n + p.start;                       // index into the un-cropped convolution
+    const long i_lo = max(m - (long)(p.L - 1), 0L), i_hi = min(m, (long)p.N - 1);
+    float acc = 0.0f;
+    if (i_lo <= i_hi) {
+      const int f_lo = (int)(i_lo / p.frame_size), f_hi = (int)(i_hi / p.frame_size);
+      for (int f = f_lo; f <= f_hi; ++f) {
+        const long ia = max((long)f * p.frame_size, i_lo);
+        const long ib = min((long)(f + 1) * p.frame_size - 1, i_hi);
+        const float* __restrict__ h = hb + (size_t)f * p.L;
+        for (long i = ia; i <= ib; ++i) acc = fmaf(xb[i], h[m - i], acc);
+      }
+    }
+    ob[n] = acc;
+  }
+}
+
+// =====================================================================================
+// The frame-rate tensors of core.harmonic_synthesis (ddsp/core.py:1080-1098):
+//   harmonic_frequencies = (frequencies * [1..K]) * (1 + harmonic_shifts)     fp32, in this order
+//   harmonic_amplitudes  = amplitudes * harmonic_distribution   (or amplitudes, broadcast over K)
+// =====================================================================================
+__global__ __launch_bounds__(kThreads) void harmonic_envelopes_kernel(
+    const float* __restrict__ amplitudes /*[R]*/, const float* __restrict__ hd /*[R,K] or null*/,
+    const float* __restrict__ f0 /*[R]*/, const float* __restrict__ shifts /*[R,K] or null*/,
+    float* __restrict__ freq_out /*[R,K]*/, float* __restrict__ amp_out /*[R,K]*/, size_t rows, int K) {
+  const size_t total = rows * (size_t)K;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const size_t row = i / K;
+    const int k = (int)(i - row * K);
+    float fk = __fmul_rn(f0[row], (float)(k + 1));
+    if (shifts != nullptr) fk = __fmul_rn(fk, __fadd_rn(1.0f, shifts[i]));
+    freq_out[i] = fk;
+    amp_out[i] = (hd != nullptr) ? __fmul_rn(amplitudes[row], hd[i]) : amplitudes[row];
+  }
+}
+
+// =====================================================================================
+// dL/d f0_hz of Harmonic.  With phase_k[n] = (2 pi / sr) k cumsum(f_env)[n] and f_env = U f0 (the legacy
+// bilinear resize, linear in f0; the Nyquist masks have zero gradient, as tf.where gives them):
+//   dL/d f_env[t] = (2 pi / sr) sum_{n >= t} c[n],   c[n] = g[n] sum_k k A_k[n] m_k[n] cos(phase_k[n])
+//   dL/d f0[j]    = sum_t U[t, j] dL/d f_env[t]
+// U[t, j] is 1 - r/hop on frame j's own samples and r/hop on frame j-1's (r = t % hop; the last frame
+// holds), so with per-frame sums T_j = sum c, P_j = sum c W1(r), Q_j = sum c W2(r), where
+// W1(r) = sum_{r' <= r} (1 - r'/hop), W2(r) = sum_{r' <= r} r'/hop, and S_j = sum_{j' >= j} T_j':
+//   dL/d f0[j] = (2 pi / sr) [ P_j + S_{j+1} (hop + 1)/2  +  (j >= 1: Q_{j-1} + S_j (hop - 1)/2)
+//                              +  (j == F-1: Q_{F-1}) ]
+// Four launches: the fp64 phase of the fundamental at every frame start (serial per row, as in
+// harmonic.hip), c[n] per sample, the three sums per frame, the suffix scan per row.
+// =====================================================================================
+struct F0GradArgs {
+  int B, F, K, N, hop;
+  float nyquist;
+  double inv_sr;
+  int amp_linear;
+};
+
+__global__ __launch_bounds__(kThreads) void f0grad_phase_kernel(const float* __restrict__ f0 /*[B,F]*/,
+                                                                double* __restrict__ theta0 /*[B,F]*/,
+                                                                F0GradArgs p) {
+  for (size_t b = global_thread(); b < (size_t)p.B; b += grid_threads()) {
+    const float* __restrict__ fr = f0 + b * p.F;
+    double* __restrict__ th = theta0 + b * p.F;
+    double acc = 0.0;                                   // revolutions, wrapped to [0,1)
+    for (int j = 0; j < p.F; ++j) {
+      th[j] = acc;
+      const double fj = (double)fr[j], fj1 = (double)fr[min(j + 1, p.F - 1)];
+      acc += ((double)p.hop * fj + (fj1 - fj) * (0.5 * (double)(p.hop - 1))) * p.inv_sr;
+      acc -= floor(acc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void f0grad_c_kernel(
+    const float* __restrict__ ctl_amp /*[B,F]*/, const float* __restrict__ ctl_hd /*[B,F,K]*/,
+    const float* __restrict__ f0 /*[B,F]*/, const double* __restrict__ theta0 /*[B,F]*/,
+    const float* __restrict__ grad_audio /*[B,N]*/, float* __restrict__ c_out /*[B,N]*/, F0GradArgs p) {
+  const size_t total = (size_t)p.B * p.N;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const size_t b = i / p.N;
+    const int n = (int)(i - b * p.N);
+    const int j = n / p.hop, r = n - j * p.hop, j1 = min(j + 1, p.F - 1);
+    const float fj = f0[b * p.F + j], fj1 = f0[b * p.F + j1];
+    // inclusive cumsum of the interpolated frequency, in revolutions (harm_synth_kernel's closed form)
+    const double rr = (double)r;
+    const double wj = (double)fj * p.inv_sr;
+    const double dw = ((double)fj1 - (double)fj) * p.inv_sr * (0.5 / (double)p.hop);
+    double cyc = theta0[b * p.F + j] + (rr + 1.0) * (wj + dw * rr);
+    cyc -= floor(cyc);
+    const float lerp = (float)r / (float)p.hop;
+    const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * cospif(lerp);
+    const float w_cur = 1.0f - w_next;
+    const float a_cur = ctl_amp[b * p.F + j] * w_cur, a_next = ctl_amp[b * p.F + j1] * w_next;
+    const float* __restrict__ h0 = ctl_hd + (b * p.F + j) * p.K;
+    const float* __restrict__ h1 = ctl_hd + (b * p.F + j1) * p.K;
+    float acc = 0.0f;
+    for (int k = 0; k < p.K; ++k) {
+      const float kf = (float)(k + 1);
+      // the audio-rate mask of oscillator_bank on the interpolated frequency, TF's fp32 op order
+      const float top = __fmul_rn(fj, kf), bot = __fmul_rn(fj1, kf);
+      const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+      if (fk >= p.nyquist) continue;
+      double ph = cyc * (double)(k + 1);
+      ph -= floor(ph);
+      const float amp = fmaf(a_cur, h0[k], a_next * h1[k]);
+      acc = fmaf(kf * amp, __builtin_amdgcn_cosf((float)ph), acc);
+    }
+    c_out[i] = grad_audio[i] * acc;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void f0grad_frame_kernel(const float* __restrict__ c /*[B,N]*/,
+                                                                double* __restrict__ sums /*[B,F,3]*/,
+                                                                F0GradArgs p) {
+  const size_t total = (size_t)p.B * p.F;
+  const double inv_2hop = 0.5 / (double)p.hop;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const size_t b = i / p.F;
+    const int j = (int)(i - b * p.F);
+    const float* __restrict__ cf = c + b * p.N + (size_t)j * p.hop;
+    double t = 0.0, pw = 0.0, qw = 0.0;
+    for (int r = 0; r < p.hop; ++r) {
+      const double v = (double)cf[r], rr = (double)r;
+      const double w2 = rr * (rr + 1.0) * inv_2hop;      // sum_{r' <= r} r'/hop
+      t += v;
+      pw += v * ((rr + 1.0) - w2);                        // sum_{r' <= r} (1 - r'/hop)
+      qw += v * w2;
+    }
+    sums[i * 3 + 0] = t; sums[i * 3 + 1] = pw; sums[i * 3 + 2] = qw;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void f0grad_scan_kernel(const double* __restrict__ sums /*[B,F,3]*/,
+                                                               float* __restrict__ grad_f0 /*[B,F]*/,
+                                                               F0GradArgs p) {
+  const double scale = 6.283185307179586476925 * p.inv_sr;
+  const double w_own = 0.5 * (double)(p.hop + 1), w_prev = 0.5 * (double)(p.hop - 1);
+  for (size_t b = global_thread(); b < (size_t)p.B; b += grid_threads()) {
+    const double* __restrict__ s = sums + b * p.F * 3;
+    float* __restrict__ g = grad_f0 + b * p.F;
+    double suffix_next = 0.0;                            // S_{j+1}
+    for (int j = p.F - 1; j >= 0; --j) {
+      const double suffix = suffix_next + s[j * 3 + 0];  // S_j
+      double d = s[j * 3 + 1] + suffix_next * w_own;
+      if (j >= 1) d += s[(j - 1) * 3 + 2] + suffix * w_prev;
+      if (j == p.F - 1) d += s[j * 3 + 2];
+      g[j] = (float)(scale * d);
+      suffix_next = suffix;
+    }
+  }
+}
+
+static inline unsigned grid_for(size_t n, unsigned cap = 256 * 32) {
+  size_t g = (n + kThreads - 1) / kThreads;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH; }
+static inline size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+}  // namespace general
+}  // namespace ddsp
+
+using namespace ddsp::general;
+
+extern "C" int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, int N, int C, int method,
+                                    int add_endpoint, void* stream) {
+  if (!x || !out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || N <= 0 || C <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (method < DDSP_RESAMPLE_NEAREST || method > DDSP_RESAMPLE_WINDOW) return DDSP_ERR_BAD_SHAPE;
+  ResampleArgs p;
+  p.F = F; p.N = N; p.C = C; p.method = method; p.align_corners = add_endpoint ? 0 : 1;
+  p.hop = 1;
+  if (method == DDSP_RESAMPLE_WINDOW) {
+    // core.py:677-693: upsampling only, N divisible by the number of intervals
+    const int n_intervals = add_endpoint ? F : F - 1;
+    if (n_intervals <= 0 || n_intervals + 1 >= N || N % n_intervals != 0) return DDSP_ERR_BAD_SHAPE;
+    p.hop = N / n_intervals;
+  }
+  p.scale = (p.align_corners && N > 1) ? (float)(F - 1) / (float)(N - 1) : (float)F / (float)N;
+  const dim3 grid(grid_for((size_t)N * C, 2048), (unsigned)B);
+  hipLaunchKernelGGL(resample_ex_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, out, p);
+  return check_launch();
+}
+
+extern "C" int ddsp_fft_convolve_f32(const float* audio, const float* impulse_response, float* out, int B,
+                                     int Bir, int F, int L, int N, int n_out, int start, void* stream) {
+  if (!audio || !impulse_response || !out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || L <= 0 || N <= 0 || n_out <= 0 || start < 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (Bir != B && Bir != 1) return DDSP_ERR_BAD_SHAPE;
+  FirArgs p;
+  p.N = N; p.F = F; p.L = L; p.start = start; p.n_out = n_out;
+  p.frame_size = (N + F - 1) / F;                                              // core.py:1446
+  if ((N + p.frame_size - 1) / p.frame_size != F) return DDSP_ERR_BAD_SHAPE;   // :1451-1457
+  p.ir_batch_stride = (Bir == 1) ? 0 : (size_t)F * L;
+  const dim3 grid(grid_for((size_t)n_out, 2048), (unsigned)B);
+  hipLaunchKernelGGL(tv_fir_any_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, audio, impulse_response,
+                     out, p);
+  return check_launch();
+}
+
+extern "C" int ddsp_harmonic_envelopes_f32(const float* amplitudes, const float* harmonic_distribution,
+                                           const float* f0_hz, const float* harmonic_shifts,
+                                           float* harmonic_frequencies, float* harmonic_amplitudes, int B,
+                                           int F, int K, void* stream) {
+  if (!amplitudes || !f0_hz || !harmonic_frequencies || !harmonic_amplitudes) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || K <= 0) return DDSP_ERR_BAD_SHAPE;
+  const size_t rows = (size_t)B * F;
+  hipLaunchKernelGGL(harmonic_envelopes_kernel, dim3(grid_for(rows * K)), dim3(kThreads), 0,
+                     (hipStream_t)stream, amplitudes, harmonic_distribution, f0_hz, harmonic_shifts,
+                     harmonic_frequencies, harmonic_amplitudes, rows, K);
+  return check_launch();
+}
+
+extern "C" size_t ddsp_harmonic_f0_grad_workspace_bytes(int B, int F, int K, int N) {
+  (void)K;
+  if (B <= 0 || F <= 0 || N <= 0) return 0;
+  return align_up((size_t)B * F * sizeof(double), 16) + align_up((size_t)B * F * 3 * sizeof(double), 16) +
+         align_up((size_t)B * N * sizeof(float), 16);
+}
+
+extern "C" int ddsp_harmonic_f0_grad_f32(const float* ctl_amplitudes, const float* ctl_harmonic_distribution,
+                                         const float* f0_hz, const float* grad_audio, float* grad_f0,
+                                         void* workspace, size_t workspace_bytes, int B, int F, int K, int N,
+                                         int sample_rate, unsigned flags, void* stream) {
+  if (!ctl_amplitudes || !ctl_harmonic_distribution || !f0_hz || !grad_audio || !grad_f0 || !workspace)
+    return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || K <= 0 || N <= 0 || sample_rate <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (N % F != 0) return DDSP_ERR_UNSUPPORTED;
+  if (workspace_bytes < ddsp_harmonic_f0_grad_workspace_bytes(B, F, K, N) || ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  F0GradArgs p;
+  p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
+  p.nyquist = (float)sample_rate / 2.0f;
+  p.inv_sr = 1.0 / (double)sample_rate;
+  p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  char* ws = (char*)workspace;
+  double* theta0 = (double*)ws;
+  ws += align_up((size_t)B * F * sizeof(double), 16);
+  double* sums = (double*)ws;
+  ws += align_up((size_t)B * F * 3 * sizeof(double), 16);
+  float* c = (float*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(f0grad_phase_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st, f0_hz, theta0, p);
+  hipLaunchKernelGGL(f0grad_c_kernel, dim3(grid_for((size_t)B * N)), dim3(kThreads), 0, st, ctl_amplitudes,
+                     ctl_harmonic_distribution, f0_hz, (const double*)theta0, grad_audio, c, p);
+  hipLaunchKernelGGL(f0grad_frame_kernel, dim3(grid_for((size_t)B * F)), dim3(kThreads), 0, st,
+                     (const float*)c, sums, p);
+  hipLaunchKernelGGL(f0grad_scan_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st,
+                     (const double*)sums, grad_f0, p);
+  return check_launch();
+}

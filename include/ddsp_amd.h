@@ -298,6 +298,53 @@ int ddsp_oscillator_bank_f32(const float* frequency_envelopes, const float* ampl
 int ddsp_resample_f32(const float* x, float* out, int B, int F, int N, int C, int window,
                       void* stream);
 
+/* core.resample (ddsp/core.py:573-642), the whole argument space: [B,F,C] -> [B,N,C] (a 4-D input
+ * [B,F,n_freq,C] is the same call with C = n_freq*C: the width axis is resized 1:1), up- or down-sampling.
+ *   method: DDSP_RESAMPLE_NEAREST / _LINEAR / _CUBIC = tf.compat.v1.image.resize NEAREST_NEIGHBOR / BILINEAR /
+ *           BICUBIC (legacy kernels: no half-pixel centres, align_corners = !add_endpoint; bicubic with the
+ *           1024-entry A = -0.75 table and clamped indices); DDSP_RESAMPLE_WINDOW = core.upsample_with_windows
+ *           (:645-714; upsampling only, N divisible by F, or by F-1 when add_endpoint == 0, else
+ *           DDSP_ERR_BAD_SHAPE - the reference's ValueErrors are raised by the host layer first).
+ * (ddsp/csrc/general.hip) */
+#define DDSP_RESAMPLE_NEAREST 0
+#define DDSP_RESAMPLE_LINEAR 1
+#define DDSP_RESAMPLE_CUBIC 2
+#define DDSP_RESAMPLE_WINDOW 3
+int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, int N, int C, int method,
+                         int add_endpoint, void* stream);
+
+/* core.fft_convolve (ddsp/core.py:1382-1473) with any crop (crop_and_compensate_delay :1338-1379):
+ *     out[b][n] = z[b][n + start],  n < n_out,   z[m] = sum_i audio[i] * ir[frame(i)][m - i]
+ * (z = the overlap-added framed FFT products = the direct time-varying FIR; zero beyond its support).
+ * padding='valid' is n_out = L + N - 1, 'same' is n_out = N; start = delay_compensation, or
+ * (L-1)/2 - 1 when that is negative.  audio [B,N], impulse_response [Bir,F,L] with Bir == B or 1,
+ * out [B,n_out].  frame_size = ceil(N/F) and ceil(N/frame_size) must equal F (DDSP_ERR_BAD_SHAPE).
+ * General shapes, one thread per output; ddsp_fft_convolve_same_f32 is the fast entry for 'same'. */
+int ddsp_fft_convolve_f32(const float* audio, const float* impulse_response, float* out, int B, int Bir,
+                          int F, int L, int N, int n_out, int start, void* stream);
+
+/* The frame-rate tensors core.harmonic_synthesis builds before resampling (ddsp/core.py:1080-1098,
+ * get_harmonic_frequencies :1028-1045), fp32 in the reference's op order:
+ *   harmonic_frequencies[B,F,K] = (f0_hz * (k+1)) * (1 + harmonic_shifts)      (shifts may be NULL)
+ *   harmonic_amplitudes [B,F,K] = amplitudes * harmonic_distribution           (distribution NULL: amplitudes)
+ * Used for the arguments the fused kernels do not take (harmonic_shifts, amp_resample_method 'nearest' /
+ * 'cubic'): the host layer then follows the reference's own chain resample -> oscillator_bank on these. */
+int ddsp_harmonic_envelopes_f32(const float* amplitudes, const float* harmonic_distribution,
+                                const float* f0_hz, const float* harmonic_shifts,
+                                float* harmonic_frequencies, float* harmonic_amplitudes, int B, int F,
+                                int K, void* stream);
+
+/* dL/d f0_hz [B,F,1] of Harmonic given grad_audio [B,N]: the gradient tf.GradientTape forms through
+ * tf.cumsum and tf.sin (ddsp/core.py:950-960) and the bilinear resize of the frequencies (:1101).  Inputs
+ * are the CONTROLS (ddsp_harmonic_controls_f32 / get_controls outputs) and f0_hz; the Nyquist masks have
+ * zero gradient.  flags: DDSP_HARM_AMP_LINEAR.  N % F == 0.  workspace:
+ * ddsp_harmonic_f0_grad_workspace_bytes(B,F,K,N). */
+size_t ddsp_harmonic_f0_grad_workspace_bytes(int B, int F, int K, int N);
+int ddsp_harmonic_f0_grad_f32(const float* ctl_amplitudes, const float* ctl_harmonic_distribution,
+                              const float* f0_hz, const float* grad_audio, float* grad_f0,
+                              void* workspace, size_t workspace_bytes, int B, int F, int K, int N,
+                              int sample_rate, unsigned flags, void* stream);
+
 /* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
 int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
                          float max_value, float threshold, void* stream);

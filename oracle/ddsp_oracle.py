@@ -92,6 +92,60 @@ def resize_bilinear_legacy(x, n_out, align_corners=False):
   return top + (bottom - top) * lerp.astype(x.dtype)[None, :, None].astype(dt)
 
 
+def _legacy_resize_positions(n_in, n_out, align_corners):
+  """Source coordinate of every output index, fp32: out * scale (LegacyScaler), scale as
+  CalculateResizeScale computes it (TF <= 2.11 image_resizer_state.h)."""
+  if align_corners and n_out > 1:
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1)
+  else:
+    scale = np.float32(n_in) / np.float32(n_out)
+  return np.arange(n_out, dtype=np.float32) * scale
+
+
+def resize_nearest_legacy(x, n_out, align_corners=False):
+  """tf.compat.v1.image.resize(NEAREST_NEIGHBOR) on the time axis of x[B, F, C] (legacy kernel):
+  source = min(floor(pos), F-1), or min(round(pos), F-1) with align_corners (roundf: half away from 0)."""
+  n_in = x.shape[1]
+  pos = _legacy_resize_positions(n_in, n_out, align_corners)
+  src = np.floor(pos + np.float32(0.5)) if align_corners else np.floor(pos)
+  return x[:, np.minimum(src.astype(np.int64), n_in - 1), :]
+
+
+_CUBIC_TABLE_SIZE = 1024
+
+
+def _cubic_coeffs_table():
+  """TF's bicubic coefficient table, A = -0.75 (resize_bicubic_op.cc InitCoeffsTable): entry 2i is the
+  |x| <= 1 polynomial at x = i/1024, entry 2i+1 the 1 <= |x| <= 2 polynomial at x + 1; evaluated in
+  double on the float abscissa and stored as float."""
+  a = -0.75
+  x = (np.arange(_CUBIC_TABLE_SIZE + 1, dtype=np.float64) / _CUBIC_TABLE_SIZE).astype(np.float32)
+  near = ((a + 2.0) * x.astype(np.float64) - (a + 3.0)) * x.astype(np.float64)**2 + 1.0
+  x1 = (x + np.float32(1.0)).astype(np.float64)
+  far = ((a * x1 - 5.0 * a) * x1 + 8.0 * a) * x1 - 4.0 * a
+  return near.astype(np.float32), far.astype(np.float32)
+
+
+def resize_bicubic_legacy(x, n_out, align_corners=False):
+  """tf.compat.v1.image.resize(BICUBIC) on the time axis of x[B, F, C] (legacy kernel, no half-pixel
+  centres): pos = t*scale, the fractional part quantised to 1/1024 (lrintf), weights from the
+  coefficient table, the four source indices clamped to [0, F-1], v0 w0 + v1 w1 + v2 w2 + v3 w3
+  summed left to right in x.dtype.  The width axis (1 -> 1) has weights (0, 1, 0, 0): a copy."""
+  n_in = x.shape[1]
+  near, far = _cubic_coeffs_table()
+  pos = _legacy_resize_positions(n_in, n_out, align_corners)
+  lo = np.floor(pos)
+  offset = np.rint((pos - lo).astype(np.float32) * np.float32(_CUBIC_TABLE_SIZE)).astype(np.int64)
+  src = lo.astype(np.int64)
+  w = [far[offset], near[offset], near[_CUBIC_TABLE_SIZE - offset], far[_CUBIC_TABLE_SIZE - offset]]
+  out = None
+  for tap in range(4):
+    idx = np.clip(src - 1 + tap, 0, n_in - 1)
+    term = x[:, idx, :] * w[tap].astype(x.dtype)[None, :, None]
+    out = term if out is None else out + term
+  return out
+
+
 def hann_window_periodic(n, dtype=np.float32):
   """tf.signal.hann_window(n) (periodic=True): 0.5 - 0.5*cos(2*pi*i/n)."""
   i = np.arange(n, dtype=np.float64)
@@ -153,19 +207,27 @@ def upsample_with_windows_closed_form(inputs, n_timesteps, dtype=np.float32):
 
 
 def resample(inputs, n_timesteps, method='linear', add_endpoint=True, dtype=np.float32):
-  """core.resample (core.py:573-642) for 1-D..3-D inputs ('linear' and 'window')."""
+  """core.resample (core.py:573-642) for 1-D..4-D inputs, every method."""
   inputs = as_float(inputs, dtype)
-  is_1d, is_2d = inputs.ndim == 1, inputs.ndim == 2
+  is_1d, is_2d, is_4d = inputs.ndim == 1, inputs.ndim == 2, inputs.ndim == 4
   if is_1d:
     inputs = inputs[None, :, None]
   elif is_2d:
     inputs = inputs[:, :, None]
+  elif is_4d:
+    if method == 'window':
+      raise ValueError('Upsample_with_windows() only supports 3 dimensions, '
+                       'not {}.'.format(inputs.shape))
+    shape_4d = inputs.shape                       # [B, F, n_freq, C]: the width axis is resized 1:1
+    inputs = inputs.reshape(shape_4d[0], shape_4d[1], -1)
   if method == 'linear':
     outputs = resize_bilinear_legacy(inputs, n_timesteps, align_corners=not add_endpoint)
   elif method == 'window':
     outputs = upsample_with_windows(inputs, n_timesteps, add_endpoint, dtype)
-  elif method in ('nearest', 'cubic'):
-    raise NotImplementedError("oracle restates only 'linear' and 'window'")
+  elif method == 'nearest':
+    outputs = resize_nearest_legacy(inputs, n_timesteps, align_corners=not add_endpoint)
+  elif method == 'cubic':
+    outputs = resize_bicubic_legacy(inputs, n_timesteps, align_corners=not add_endpoint)
   else:
     raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
         method, "['nearest', 'linear', 'cubic', 'window']"))
@@ -173,6 +235,8 @@ def resample(inputs, n_timesteps, method='linear', add_endpoint=True, dtype=np.f
     outputs = outputs[0, :, 0]
   elif is_2d:
     outputs = outputs[:, :, 0]
+  elif is_4d:
+    outputs = outputs.reshape(shape_4d[0], n_timesteps, shape_4d[2], shape_4d[3])
   return outputs
 
 
