@@ -135,25 +135,28 @@ def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
 # resampling  (ddsp/core.py:573-714) - stand-alone; the synths evaluate it on the fly
 # --------------------------------------------------------------------------------------
 def resample(inputs, n_timesteps, method='linear', add_endpoint=True):
-  """core.resample: [n_frames] / [B, n_frames] / [B, n_frames, C] -> n_timesteps along time."""
+  """core.resample (ddsp/core.py:573-642): [n_frames] / [B, n_frames] / [B, n_frames, C] /
+  [B, n_frames, n_freq, C] -> n_timesteps along time; methods 'nearest', 'linear', 'cubic', 'window'."""
   inputs = tf_float32(inputs)
-  is_1d, is_2d = inputs.dim() == 1, inputs.dim() == 2
+  is_1d, is_2d, is_4d = inputs.dim() == 1, inputs.dim() == 2, inputs.dim() == 4
   if is_1d:
     inputs = inputs[None, :, None]
   elif is_2d:
     inputs = inputs[:, :, None]
-  if inputs.dim() != 3:
-    raise NotImplementedError('4-D inputs are not on the accelerated path')
   if method not in RESAMPLE_METHODS:
     raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
         method, "['nearest', 'linear', 'cubic', 'window']"))
-  if method in ('nearest', 'cubic') or not add_endpoint:
-    raise NotImplementedError("only method in ('linear', 'window') with add_endpoint=True is "
-                              'implemented by the MI355X kernels')
   if method == 'window':
-    outputs = upsample_with_windows(inputs, n_timesteps, add_endpoint)
+    outputs = upsample_with_windows(inputs, n_timesteps, add_endpoint)     # ValueError unless 3-D
+  elif is_4d:
+    # tf.image.resize on [B, n_frames, n_freq, C] leaves the n_freq axis alone (core.py:613-621)
+    b, f, q, c = inputs.shape
+    outputs = _resample_call(inputs.reshape(b, f, q * c), int(n_timesteps), method, add_endpoint)
+    outputs = outputs.reshape(b, int(n_timesteps), q, c)
+  elif inputs.dim() == 3:
+    outputs = _resample_call(inputs, int(n_timesteps), method, add_endpoint)
   else:
-    outputs = _resample_call(inputs.contiguous(), int(n_timesteps), window=0)
+    raise ValueError('resample() takes 1-D to 4-D inputs, got shape {}'.format(tuple(inputs.shape)))
   if is_1d:
     outputs = outputs[0, :, 0]
   elif is_2d:
@@ -162,33 +165,43 @@ def resample(inputs, n_timesteps, method='linear', add_endpoint=True):
 
 
 def upsample_with_windows(inputs, n_timesteps, add_endpoint=True):
-  """core.upsample_with_windows: overlapping Hann windows, [B, n_frames, C] -> [B, n_timesteps, C]."""
+  """core.upsample_with_windows (ddsp/core.py:645-714): overlapping Hann windows,
+  [B, n_frames, C] -> [B, n_timesteps, C]."""
   inputs = tf_float32(inputs)
   if inputs.dim() != 3:
     raise ValueError('Upsample_with_windows() only supports 3 dimensions, '
                      'not {}.'.format(tuple(inputs.shape)))
-  if not add_endpoint:
-    raise NotImplementedError('add_endpoint=False is not implemented by the MI355X kernels')
-  n_frames = int(inputs.shape[1]) + 1           # the reference appends the endpoint frame
+  n_frames = int(inputs.shape[1]) + (1 if add_endpoint else 0)   # the reference appends the endpoint frame
   n_intervals = n_frames - 1
   if n_frames >= n_timesteps:
     raise ValueError('Upsample with windows cannot be used for downsampling'
                      'More input frames ({}) than output timesteps ({})'.format(
                          n_frames, n_timesteps))
-  if n_timesteps % n_intervals != 0.0:
+  if n_intervals <= 0 or n_timesteps % n_intervals != 0.0:
     raise ValueError(
         'For upsampling, the target the number of timesteps must be divisible '
         'by the number of input frames{}. (timesteps:{}, frames:{}, '
-        'add_endpoint={}).'.format('', n_timesteps, n_frames, add_endpoint))
-  return _resample_call(inputs.contiguous(), int(n_timesteps), window=1)
+        'add_endpoint={}).'.format('' if add_endpoint else ' - 1', n_timesteps, n_frames, add_endpoint))
+  return _resample_call(inputs, int(n_timesteps), 'window', add_endpoint)
 
 
-def _resample_call(inputs, n_timesteps, window):
+def _resample_call(inputs, n_timesteps, method, add_endpoint):
+  """[B,F,C] -> [B,N,C]: 'linear' / 'window' with the endpoint go to the stand-alone kernel of the hot
+  path's own forms (ddsp_resample_f32), every other combination to the general one (ddsp_resample_ex_f32)."""
+  inputs = inputs.contiguous()
   b, f, c = inputs.shape
   out = torch.empty((b, n_timesteps, c), dtype=torch.float32, device=inputs.device)
-  rc = _lib.load().ddsp_resample_f32(inputs.data_ptr(), out.data_ptr(), b, f, n_timesteps, c, window,
-                                     _stream())
-  _lib.check(rc, 'ddsp_resample_f32')
+  if b == 0 or c == 0:
+    return out
+  lib = _lib.load()
+  if add_endpoint and method in ('linear', 'window'):
+    rc = lib.ddsp_resample_f32(inputs.data_ptr(), out.data_ptr(), b, f, n_timesteps, c,
+                               1 if method == 'window' else 0, _stream())
+    _lib.check(rc, 'ddsp_resample_f32')
+  else:
+    rc = lib.ddsp_resample_ex_f32(inputs.data_ptr(), out.data_ptr(), b, f, n_timesteps, c,
+                                  _lib.RESAMPLE_METHODS[method], 1 if add_endpoint else 0, _stream())
+    _lib.check(rc, 'ddsp_resample_ex_f32')
   return out
 
 
@@ -270,10 +283,6 @@ def _check_amp_method(method, n_frames, n_samples):
   if method not in RESAMPLE_METHODS:
     raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
         method, "['nearest', 'linear', 'cubic', 'window']"))
-  if method in ('nearest', 'cubic'):
-    raise NotImplementedError(
-        "amp_resample_method='{}' is not implemented by the MI355X kernels "
-        "(no shipped gin config uses it); use 'window' or 'linear'.".format(method))
   if method == 'window':
     if n_frames + 1 >= n_samples:
       raise ValueError('Upsample with windows cannot be used for downsampling'
@@ -284,10 +293,13 @@ def _check_amp_method(method, n_frames, n_samples):
           'For upsampling, the target the number of timesteps must be divisible '
           'by the number of input frames{}. (timesteps:{}, frames:{}, '
           'add_endpoint={}).'.format('', n_samples, n_frames + 1, True))
-  elif n_samples % n_frames != 0:
-    raise NotImplementedError(
-        'n_samples ({}) must be a multiple of n_frames ({}) in the MI355X kernels.'.format(
-            n_samples, n_frames))
+
+
+def _on_closed_form_kernels(method, n_frames, n_samples):
+  """True where the synthesis kernels' closed forms apply ('window' / 'linear' envelopes, n_samples a
+  multiple of n_frames); other argument combinations follow the reference's own chain of materialised
+  envelopes (_harmonic_synthesis_materialised)."""
+  return method in ('window', 'linear') and n_samples % n_frames == 0
 
 
 def _harmonic_flags(scale, normalize, amp_resample_method, use_angular_cumsum):
@@ -319,20 +331,32 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
                        harmonic_distribution=None, n_samples=64000, sample_rate=16000,
                        amp_resample_method='window', use_angular_cumsum=False,
                        workspace=None, tf_op_order=False):
-  """core.harmonic_synthesis: frame-rate controls -> audio [batch, n_samples].
+  """core.harmonic_synthesis (ddsp/core.py:1048-1111): frame-rate controls -> audio [batch, n_samples].
 
+  'window' / 'linear' amplitude envelopes without harmonic_shifts (everything synths.Harmonic and the
+  shipped gin configs ask for) run the closed-form synthesis kernels; harmonic_shifts, 'nearest' / 'cubic'
+  envelopes and n_samples that is not a multiple of n_frames follow the reference's own chain
+  (frame-rate tensors -> resample -> oscillator_bank) on materialised [B, N, K] envelopes.
   tf_op_order=True (extension, validation only) runs the slow kernel that follows the reference's
   fp32 op order exactly, sequential phase accumulation included.
   """
-  if harmonic_shifts is not None:
-    raise NotImplementedError('harmonic_shifts is not on the accelerated path '
-                              '(synths.Harmonic never passes it, ddsp/synths.py:138-145).')
   frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
+  if harmonic_shifts is not None:
+    harmonic_shifts = tf_float32(harmonic_shifts)
   if harmonic_distribution is None:
+    if harmonic_shifts is not None:                          # n_harmonics from the shifts (core.py:1082-1084)
+      return _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, None, int(n_samples),
+                                              int(sample_rate), amp_resample_method, use_angular_cumsum)
     harmonic_distribution = torch.ones_like(amplitudes)
   harmonic_distribution = tf_float32(harmonic_distribution)
   b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
   _check_amp_method(amp_resample_method, f, int(n_samples))
+  if harmonic_shifts is not None or not _on_closed_form_kernels(amp_resample_method, f, int(n_samples)):
+    if tf_op_order:
+      raise NotImplementedError('tf_op_order covers the closed-form kernels\' argument space only')
+    return _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, harmonic_distribution,
+                                            int(n_samples), int(sample_rate), amp_resample_method,
+                                            use_angular_cumsum)
   lib = _lib.load()
   audio = torch.empty((b, int(n_samples)), dtype=torch.float32, device=amplitudes.device)
   if tf_op_order:
@@ -350,6 +374,39 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
       _harmonic_flags(False, False, amp_resample_method, use_angular_cumsum), _stream())
   _lib.check(rc, 'ddsp_harmonic_signal_f32')
   return audio
+
+
+def _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, harmonic_distribution,
+                                     n_samples, sample_rate, amp_resample_method, use_angular_cumsum):
+  """The reference's chain op for op (ddsp/core.py:1080-1111), each op a kernel of this library:
+  harmonic_frequencies = f0 [1..K] (1 + shifts), harmonic_amplitudes = amplitudes * distribution
+  (ddsp_harmonic_envelopes_f32), resample both to [B, N, K], oscillator_bank."""
+  if amplitudes.dim() != 3 or amplitudes.shape[2] != 1 or frequencies.shape != amplitudes.shape:
+    raise ValueError('frequencies and amplitudes must both be [batch, n_frames, 1], got {} and {}'.format(
+        tuple(frequencies.shape), tuple(amplitudes.shape)))
+  b, f, _ = amplitudes.shape
+  per_harmonic = harmonic_distribution if harmonic_distribution is not None else harmonic_shifts
+  if per_harmonic.dim() != 3 or tuple(per_harmonic.shape[:2]) != (b, f):
+    raise ValueError('per-harmonic controls must be [{}, {}, n_harmonics], got {}'.format(
+        b, f, tuple(per_harmonic.shape)))
+  k = int(per_harmonic.shape[2])
+  if harmonic_shifts is not None and tuple(harmonic_shifts.shape) != (b, f, k):
+    raise ValueError('harmonic_shifts must be [{}, {}, {}], got {}'.format(b, f, k, tuple(harmonic_shifts.shape)))
+  if amp_resample_method not in RESAMPLE_METHODS:
+    raise ValueError('Method ({}) is invalid. Must be one of {}.'.format(
+        amp_resample_method, "['nearest', 'linear', 'cubic', 'window']"))
+  dev = amplitudes.device
+  harmonic_frequencies = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+  harmonic_amplitudes = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+  rc = _lib.load().ddsp_harmonic_envelopes_f32(
+      amplitudes.data_ptr(), harmonic_distribution.data_ptr() if harmonic_distribution is not None else None,
+      frequencies.data_ptr(), harmonic_shifts.data_ptr() if harmonic_shifts is not None else None,
+      harmonic_frequencies.data_ptr(), harmonic_amplitudes.data_ptr(), b, f, k, _stream())
+  _lib.check(rc, 'ddsp_harmonic_envelopes_f32')
+  frequency_envelopes = resample(harmonic_frequencies, n_samples)
+  amplitude_envelopes = resample(harmonic_amplitudes, n_samples, method=amp_resample_method)
+  return oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=sample_rate,
+                         use_angular_cumsum=use_angular_cumsum)
 
 
 def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=None,
@@ -414,8 +471,30 @@ def frequency_impulse_response(magnitudes, window_size=0):
   return ir[:, 0, :] if squeeze else ir
 
 
+def _crop_range(audio_size, n_ir_frames, ir_size, padding, delay_compensation):
+  """(start as requested, first kept index, number of kept samples) of the slice
+  crop_and_compensate_delay (ddsp/core.py:1338-1379) takes from the overlap-added FFT frames of
+  fft_convolve - python slice semantics included: audio[:, start:-end] is empty when the FFT size leaves
+  nothing to crop at the end (end <= 0) or start is negative (ir_size <= 2 with automatic compensation)."""
+  if padding == 'valid':
+    crop_size = ir_size + audio_size - 1
+  elif padding == 'same':
+    crop_size = audio_size
+  else:
+    raise ValueError('Padding must be \'valid\' or \'same\', instead '
+                     'of {}.'.format(padding))
+  frame_size = int(np.ceil(audio_size / n_ir_frames))
+  total_size = (n_ir_frames - 1) * frame_size + get_fft_size(frame_size, ir_size, power_of_2=True)
+  start = (ir_size - 1) // 2 - 1 if delay_compensation < 0 else int(delay_compensation)
+  end = (total_size - crop_size) - start
+  kept = range(total_size)[start:-end]
+  return start, (kept[0] if len(kept) else 0), len(kept)
+
+
 def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1):
-  """core.fft_convolve, evaluated as the equivalent direct time-varying FIR."""
+  """core.fft_convolve (ddsp/core.py:1382-1473), evaluated as the equivalent direct time-varying FIR
+  (one long impulse response: as a partitioned FFT convolution), cropped as
+  crop_and_compensate_delay (:1338-1379) crops the overlap-added FFT frames."""
   audio, impulse_response = tf_float32(audio), tf_float32(impulse_response)
   if audio.dim() != 2:
     raise ValueError('audio must be [batch, audio_timesteps], got {}'.format(tuple(audio.shape)))
@@ -430,29 +509,25 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
   if batch_size != batch_size_ir_eff:
     raise ValueError('Batch size of audio ({}) and impulse response ({}) must '
                      'be the same.'.format(batch_size, batch_size_ir))
-  frame_size = int(np.ceil(audio_size / n_ir_frames))
-  n_audio_frames = int(math.ceil(audio_size / frame_size))
-  if n_audio_frames != n_ir_frames:
-    raise ValueError(
-        'Number of Audio frames ({}) and impulse response frames ({}) do not '
-        'match. For small hop size = ceil(audio_size / n_ir_frames), '
-        'number of impulse response frames must be a multiple of the audio '
-        'size.'.format(n_audio_frames, n_ir_frames))
-  if padding == 'valid':
-    raise NotImplementedError("padding='valid' is not implemented by the MI355X kernels "
-                              "(the synths only use 'same').")
-  if padding != 'same':
-    raise ValueError('Padding must be \'valid\' or \'same\', instead '
-                     'of {}.'.format(padding))
+  _check_frames(audio_size, n_ir_frames)
+  start_requested, start, n_out = _crop_range(audio_size, n_ir_frames, ir_size, padding, delay_compensation)
+  if n_out == 0:
+    return torch.empty((batch_size, 0), dtype=torch.float32, device=audio.device)
   if n_ir_frames == 1 and ir_size > LONG_IR_TAPS:
     # one long IR (a reverb): partitioned FFT convolution instead of the direct FIR
-    start = (ir_size - 1) // 2 - 1 if delay_compensation < 0 else int(delay_compensation)
-    return fft_convolve_long(audio, impulse_response[:, 0, :], delay=start)
-  out = torch.empty_like(audio)
-  rc = _lib.load().ddsp_fft_convolve_same_f32(
-      audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
-      n_ir_frames, ir_size, audio_size, int(delay_compensation), _stream())
-  _lib.check(rc, 'ddsp_fft_convolve_same_f32')
+    return fft_convolve_long(audio, impulse_response[:, 0, :], delay=start, n_out=n_out)
+  out = torch.empty((batch_size, n_out), dtype=torch.float32, device=audio.device)
+  lib = _lib.load()
+  if n_out == audio_size and start == start_requested:
+    rc = lib.ddsp_fft_convolve_same_f32(
+        audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
+        n_ir_frames, ir_size, audio_size, int(delay_compensation), _stream())
+    _lib.check(rc, 'ddsp_fft_convolve_same_f32')
+  else:
+    rc = lib.ddsp_fft_convolve_f32(
+        audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
+        n_ir_frames, ir_size, audio_size, n_out, start, _stream())
+    _lib.check(rc, 'ddsp_fft_convolve_f32')
   return out
 
 

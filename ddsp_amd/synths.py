@@ -79,19 +79,31 @@ class Harmonic(processors.Processor):
     """get_signal(**get_controls(...)) (processors.py:53-68) as ONE fused C-ABI call.
 
     When an input tensor requires grad the call is recorded for torch.autograd: backward()
-    produces dL/d amplitudes and dL/d harmonic_distribution (ddsp_harmonic_backward_f32);
-    f0_hz is treated as a constant.
+    produces dL/d amplitudes and dL/d harmonic_distribution (ddsp_harmonic_backward_f32) and, when
+    f0_hz itself requires grad (the reference's models take f0 from CREPE, a constant; a learned f0
+    decoder does not), dL/d f0_hz (ddsp_harmonic_f0_grad_f32).
     """
     for k in ['training', 'mask']:
       kwargs.pop(k, None)
     if kwargs:
       raise TypeError('unexpected keyword arguments: {}'.format(sorted(kwargs)))
+    raw_amplitudes, raw_harmonic_distribution = amplitudes, harmonic_distribution
     amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0_hz = core.tf_float32(f0_hz)
     b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
     core._check_amp_method(self.amp_resample_method, f, int(self.n_samples))
-    needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or
-                                              harmonic_distribution.requires_grad)
+    needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or harmonic_distribution.requires_grad or
+                                              f0_hz.requires_grad)
+    if not core._on_closed_form_kernels(self.amp_resample_method, f, int(self.n_samples)):
+      # 'nearest' / 'cubic' envelopes, or n_samples not a multiple of n_frames: the reference's own two
+      # steps, get_signal following its chain of materialised envelopes (core.harmonic_synthesis)
+      if needs_grad:
+        raise NotImplementedError(
+            "the backward pass of Harmonic covers amp_resample_method 'window' / 'linear' with n_samples a "
+            'multiple of n_frames')
+      controls = self.get_controls(raw_amplitudes, raw_harmonic_distribution, f0_hz)
+      signal = self.get_signal(**controls)
+      return dict(signal=signal, controls=controls) if return_outputs_dict else signal
     if needs_grad:
       # one launch gives the audio and, if asked for, the controls dict (not differentiable here)
       audio, ctl_amp, ctl_hd = _HarmonicFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse,
@@ -148,6 +160,30 @@ class Harmonic(processors.Processor):
     return grad_amp, grad_hd
 
 
+  def _backward_f0(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
+    """dL/d f0_hz [B,F,1]: the controls once more (one small launch), then ddsp_harmonic_f0_grad_f32."""
+    b, f, k = harmonic_distribution.shape
+    n = int(self.n_samples)
+    lib = _lib.load()
+    dev = amplitudes.device
+    grad_audio = core.tf_float32(grad_audio)
+    ctl_amp = torch.empty_like(amplitudes)
+    ctl_hd = torch.empty_like(harmonic_distribution)
+    rc = lib.ddsp_harmonic_controls_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(), ctl_amp.data_ptr(),
+        ctl_hd.data_ptr(), b, f, k, int(self.sample_rate),
+        core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False), core._stream())
+    _lib.check(rc, 'ddsp_harmonic_controls_f32')
+    grad_f0 = torch.empty_like(f0_hz)
+    ws = self._ws_bwd.get(core.cached_workspace_bytes('ddsp_harmonic_f0_grad_workspace_bytes', b, f, k, n), dev)
+    rc = lib.ddsp_harmonic_f0_grad_f32(
+        ctl_amp.data_ptr(), ctl_hd.data_ptr(), f0_hz.data_ptr(), grad_audio.data_ptr(), grad_f0.data_ptr(),
+        ws.data_ptr(), ws.numel(), b, f, k, n, int(self.sample_rate),
+        _lib.HARM_AMP_LINEAR if self.amp_resample_method == 'linear' else 0, core._stream())
+    _lib.check(rc, 'ddsp_harmonic_f0_grad_f32')
+    return grad_f0
+
+
 class _HarmonicFunction(torch.autograd.Function):
   """torch.autograd node of Harmonic.__call__ (plumbing: both directions are C-ABI calls)."""
 
@@ -167,9 +203,13 @@ class _HarmonicFunction(torch.autograd.Function):
   @staticmethod
   def backward(ctx, grad_audio, _grad_ctl_amp, _grad_ctl_hd):
     amplitudes, harmonic_distribution, f0_hz = ctx.saved_tensors
-    grad_amp, grad_hd = ctx.synth._backward(amplitudes.detach(), harmonic_distribution.detach(),
-                                            f0_hz.detach(), ctx.fuse, grad_audio)
-    return grad_amp, grad_hd, None, None, None, None
+    amplitudes, harmonic_distribution, f0_hz = amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach()
+    grad_amp = grad_hd = grad_f0 = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+      grad_amp, grad_hd = ctx.synth._backward(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
+    if ctx.needs_input_grad[2]:
+      grad_f0 = ctx.synth._backward_f0(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
+    return grad_amp, grad_hd, grad_f0, None, None, None
 
 
 class FilteredNoise(processors.Processor):

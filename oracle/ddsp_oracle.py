@@ -453,10 +453,11 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1,
 
 
 def time_varying_fir_direct(audio, impulse_response, delay_compensation=-1,
-                            dtype=np.float64):
-  """Direct-form equivalent of fft_convolve(padding='same').
+                            dtype=np.float64, n_out=None):
+  """Direct-form equivalent of fft_convolve: padding='same' by default, any crop with
+  n_out (padding='valid' is n_out = ir_size + n - 1).
 
-  z[m] = sum_k x[m-k] * h_{frame(m-k)}[k];  out[n] = z[n + start].
+  z[m] = sum_k x[m-k] * h_{frame(m-k)}[k];  out[n] = z[n + start], zero beyond the support of z.
   The tap set is chosen by the frame of the INPUT sample.  This is the form the
   HIP kernel evaluates; used to cross-check fft_convolve on small cases.
   """
@@ -472,7 +473,10 @@ def time_varying_fir_direct(audio, impulse_response, delay_compensation=-1,
   for i in range(n):
     z[:, i:i + ir_size] += audio[:, i:i + 1] * ir[:, i // frame_size, :]
   start = ((ir_size - 1) // 2 - 1 if delay_compensation < 0 else delay_compensation)
-  return z[:, start:start + n]
+  n_out = n if n_out is None else int(n_out)
+  if start + n_out > z.shape[1]:
+    z = np.concatenate([z, np.zeros((b, start + n_out - z.shape[1]), dtype)], axis=1)
+  return z[:, start:start + n_out]
 
 
 def apply_window_to_impulse_response(impulse_response, window_size=0, causal=False,

@@ -158,6 +158,62 @@ def main():
       linear_576=a(core.resample(x, 576, method='linear')),
       linear_1728=a(core.resample(x, 1728, method='linear')),   # hop 192
       linear_900=a(core.resample(x, 900, method='linear')))     # hop 100
+  # every method x add_endpoint, up- and down-sampling (core_test.py:219-293), and a 4-D input
+  xs = (1.0 - np.sin(np.linspace(0, np.pi, 5)))[None, :, None].astype(np.float32)
+  rng2 = np.random.default_rng(22)        # its own stream: the Add case below keeps drawing from rng
+  x4 = rng2.standard_normal((2, 6, 3, 2)).astype(np.float32)
+  d = dict(x=x, x_small=xs, x_4d=x4)
+  for method in ('nearest', 'linear', 'cubic', 'window'):
+    for add_endpoint in (True, False):
+      tag = '%s_%s' % (method, 'endpoint' if add_endpoint else 'noendpoint')
+      n_up = 576 if add_endpoint else 640                     # 9 frames: 576 = 9 * 64, 640 = 8 * 80
+      d['up_' + tag] = a(core.resample(x, n_up, method=method, add_endpoint=add_endpoint))
+      d['small_' + tag] = a(core.resample(xs, 160, method=method, add_endpoint=add_endpoint))
+      if method != 'window':
+        d['ragged_' + tag] = a(core.resample(x, 100, method=method, add_endpoint=add_endpoint))
+        d['down_' + tag] = a(core.resample(d['up_' + tag], 7, method=method, add_endpoint=add_endpoint))
+        d['x4d_' + tag] = a(core.resample(x4, 48, method=method, add_endpoint=add_endpoint))
+  cases['resample_methods'] = d
+
+  # --- core.fft_convolve with padding='valid' / explicit delay (core_test.py:730-757 and beyond) ---
+  audio_v = rng2.standard_normal((2, 640)).astype(np.float32)
+  ir_v = (rng2.standard_normal((2, 10, 33)) / np.sqrt(33)).astype(np.float32)
+  ir_one = (rng2.standard_normal((1, 1, 50)) / np.sqrt(50)).astype(np.float32)
+  cases['fft_convolve_crops'] = dict(
+      audio=audio_v, ir=ir_v, ir_one=ir_one,
+      valid_d0=a(core.fft_convolve(audio_v, ir_v, padding='valid', delay_compensation=0)),
+      valid_d5=a(core.fft_convolve(audio_v, ir_v, padding='valid', delay_compensation=5)),
+      valid_auto=a(core.fft_convolve(audio_v, ir_v, padding='valid', delay_compensation=-1)),
+      same_d40=a(core.fft_convolve(audio_v, ir_v, padding='same', delay_compensation=40)),
+      one_valid_d0=a(core.fft_convolve(audio_v, ir_one, padding='valid', delay_compensation=0)),
+      one_valid_auto=a(core.fft_convolve(audio_v, ir_one, padding='valid', delay_compensation=-1)))
+
+  # --- core.harmonic_synthesis with harmonic_shifts / 'cubic' / 'nearest' envelopes / ragged n_samples ---
+  def synthesis_case(seed, batch, n_frames, n_harm, n_samples, sr, method, shifts, with_hd=True, angular=False):
+    r = np.random.default_rng(seed)
+    f0 = r.uniform(150.0, 500.0, (batch, n_frames, 1)).astype(np.float32)
+    amps = r.uniform(0.1, 1.0, (batch, n_frames, 1)).astype(np.float32)
+    hd = r.uniform(0.0, 1.0, (batch, n_frames, n_harm)).astype(np.float32) if with_hd else None
+    sh = (0.02 * r.standard_normal((batch, n_frames, n_harm))).astype(np.float32) if shifts else None
+    audio = core.harmonic_synthesis(frequencies=f0, amplitudes=amps, harmonic_shifts=sh,
+                                    harmonic_distribution=hd, n_samples=n_samples, sample_rate=sr,
+                                    amp_resample_method=method, use_angular_cumsum=angular)
+    out = dict(f0_hz=f0, amplitudes=amps, n_samples=n_samples, sample_rate=sr, amp_method=method,
+               angular=int(angular), audio=a(audio))
+    if with_hd:
+      out['harmonic_distribution'] = hd
+    if shifts:
+      out['harmonic_shifts'] = sh
+    return out
+  cases['synthesis_shifts_window'] = synthesis_case(61, 2, 10, 12, 640, 16000, 'window', True)
+  cases['synthesis_shifts_only'] = synthesis_case(62, 1, 8, 6, 512, 16000, 'linear', True, with_hd=False)
+  cases['synthesis_cubic'] = synthesis_case(63, 2, 10, 12, 640, 16000, 'cubic', False)
+  cases['synthesis_nearest_angular'] = synthesis_case(64, 1, 10, 20, 640, 16000, 'nearest', False, angular=True)
+  cases['synthesis_linear_ragged'] = synthesis_case(65, 2, 9, 10, 1000, 16000, 'linear', False)   # 1000 % 9 != 0
+
+  # synths.Harmonic with a 'cubic' amplitude envelope (constructor argument, synths.py:59-66)
+  cases['harmonic_cubic_amp'] = harmonic_case(7, 2, 25, 12, 1600, 16000, 200.0, 700.0, 'cubic', False)
+
   # --- Add ---
   s1 = rng.standard_normal((2, 64)).astype(np.float32)
   s2 = rng.standard_normal((2, 64)).astype(np.float32)
@@ -165,9 +221,14 @@ def main():
 
   for name, d in cases.items():
     path = os.path.join(HERE, name + '.npz')
-    np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
-    print('wrote', os.path.relpath(path), {k: np.asarray(v).shape for k, v in d.items()
-                                            if np.asarray(v).ndim})
+    d = {k: np.asarray(v) for k, v in d.items()}
+    if os.path.exists(path):                       # leave identical fixtures alone (zip timestamps differ)
+      with np.load(path) as z:
+        if sorted(z.files) == sorted(d) and all(np.array_equal(z[k], d[k]) for k in d):
+          print('unchanged', os.path.relpath(path))
+          continue
+    np.savez_compressed(path, **d)
+    print('wrote', os.path.relpath(path), {k: v.shape for k, v in d.items() if v.ndim})
 
 
 if __name__ == '__main__':

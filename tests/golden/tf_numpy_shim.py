@@ -10,7 +10,7 @@ executes the reference's own, unmodified source files on numpy arrays.
 
 Only `tests/golden/make_golden.py` uses this, and only in the build container
 (the GPU box has no /root/reference).  Op semantics follow TF <= 2.11 as listed in
-SURVEY.md Appendix A: legacy bilinear resize, inclusive sequential cumsum,
+SURVEY.md Appendix A: legacy bilinear / nearest / bicubic resize, inclusive sequential cumsum,
 periodic Hann, zero-padded framing, plain overlap-add, fp32 FFTs.
 """
 
@@ -178,12 +178,78 @@ def _interp_weights(out_size, in_size, align_corners):
   return lo.astype(np.int64), hi.astype(np.int64), (pos - lo).astype(np.float32)
 
 
+def _resize_scale(in_size, out_size, align_corners):
+  """CalculateResizeScale (image_resizer_state.h), fp32."""
+  if align_corners and out_size > 1:
+    return np.float32(in_size - 1) / np.float32(out_size - 1)
+  return np.float32(in_size) / np.float32(out_size)
+
+
+def _nearest_rows(x, out_size, align_corners):
+  """ResizeNearestNeighbor, legacy scaler (half_pixel_centers=False), along axis 1:
+  in = min(align_corners ? roundf(out*scale) : floorf(out*scale), in_size - 1)."""
+  in_size = x.shape[1]
+  scale = _resize_scale(in_size, out_size, align_corners)
+  src = np.empty(out_size, np.int64)
+  for o in range(out_size):
+    pos = np.float32(o) * scale
+    r = np.floor(pos + np.float32(0.5)) if align_corners else np.floor(pos)   # roundf: half away from zero, pos >= 0
+    src[o] = min(int(r), in_size - 1)
+  return x[:, src]
+
+
+_BICUBIC_TABLE = None
+
+
+def _bicubic_table():
+  """InitCoeffsTable(A = -0.75) of resize_bicubic_op.cc: 1025 pairs, float storage, double arithmetic."""
+  global _BICUBIC_TABLE
+  if _BICUBIC_TABLE is None:
+    a = -0.75
+    tab = np.zeros((1024 + 1) * 2, np.float32)
+    for i in range(1024 + 1):
+      x = float(np.float32(i * 1.0 / 1024))
+      tab[i * 2] = ((a + 2) * x - (a + 3)) * x * x + 1
+      x = float(np.float32(x + 1.0))
+      tab[i * 2 + 1] = ((a * x - 5 * a) * x + 8 * a) * x - 4 * a
+    _BICUBIC_TABLE = tab
+  return _BICUBIC_TABLE
+
+
+def _bicubic_rows(x, out_size, align_corners):
+  """ResizeBicubic, legacy scaler, along axis 1 (GetWeightsAndIndices<LegacyScaler, false> +
+  Interpolate1D: v0 w0 + v1 w1 + v2 w2 + v3 w3 in float, indices clamped)."""
+  tab = _bicubic_table()
+  in_size = x.shape[1]
+  scale = _resize_scale(in_size, out_size, align_corners)
+  out = np.empty((x.shape[0], out_size) + x.shape[2:], np.float32)
+  bound = lambda i: min(max(i, 0), in_size - 1)
+  for o in range(out_size):
+    in_loc_f = np.float32(o) * scale
+    in_loc = int(np.floor(in_loc_f))
+    delta = np.float32(in_loc_f - np.float32(in_loc))
+    offset = int(np.rint(delta * np.float32(1024)))
+    w = (tab[offset * 2 + 1], tab[offset * 2], tab[(1024 - offset) * 2], tab[(1024 - offset) * 2 + 1])
+    idx = (bound(in_loc - 1), bound(in_loc), bound(in_loc + 1), bound(in_loc + 2))
+    acc = x[:, idx[0]] * w[0]
+    for q in (1, 2, 3):
+      acc = acc + x[:, idx[q]] * w[q]
+    out[:, o] = acc
+  return out
+
+
 def image_resize_v1(images, size, method=ResizeMethod.BILINEAR, align_corners=False):
-  """[B, H, W, C] legacy resize; bilinear only (the hot path's 'linear')."""
-  if method != ResizeMethod.BILINEAR:
-    raise NotImplementedError(method)
+  """[B, H, W, C] legacy resize (tf.compat.v1.image.resize: no half-pixel centres).  The reference only
+  ever resizes the H axis (W stays as it is, core.py:613-621); nearest / bicubic assert that."""
   x = _np(images).astype(np.float32)
   out_h, out_w = int(size[0]), int(size[1])
+  if method in (ResizeMethod.NEAREST_NEIGHBOR, ResizeMethod.BICUBIC):
+    # along W the scale is 1: nearest picks the same column, bicubic has weights (0, 1, 0, 0)
+    assert out_w == x.shape[2], 'the reference never resizes the width axis'
+    rows = _nearest_rows if method == ResizeMethod.NEAREST_NEIGHBOR else _bicubic_rows
+    return _t(rows(x, out_h, align_corners))
+  if method != ResizeMethod.BILINEAR:
+    raise NotImplementedError(method)
   ylo, yhi, ylerp = _interp_weights(out_h, x.shape[1], align_corners)
   xlo, xhi, xlerp = _interp_weights(out_w, x.shape[2], align_corners)
   top_rows, bot_rows = x[:, ylo], x[:, yhi]

@@ -202,3 +202,40 @@ def test_f0_grad_argument_checks(lib):
   assert lib.ddsp_harmonic_f0_grad_f32(*args, ws.ctypes.data + off, 16, 2, 4, 3, 64, 16000, 0, None) == -4
   assert lib.ddsp_harmonic_f0_grad_f32(*args, ws.ctypes.data + off, 4096, 2, 4, 3, 66, 16000, 0, None) == -3
   assert lib.ddsp_harmonic_f0_grad_f32(*args, None, 4096, 2, 4, 3, 64, 16000, 0, None) == -1
+
+
+# ---- the same entry points against the golden vectors (reference source on the TF stand-in) ------------------
+from conftest import load_golden   # noqa: E402
+
+
+def test_resample_golden(lib):
+  g = load_golden('resample_methods')
+  seen = 0
+  for key in g:
+    parts = key.split('_')
+    if parts[0] not in ('up', 'small', 'ragged', 'down', 'x4d') or len(parts) != 3:
+      continue
+    kind, method, add_endpoint = parts[0], parts[1], parts[2] == 'endpoint'
+    src = {'up': g['x'], 'ragged': g['x'], 'small': g['x_small']}.get(kind)
+    if kind == 'down':
+      src = g['up_%s_%s' % (method, parts[2])]
+    if kind == 'x4d':                                 # [B,F,n_freq,C]: the host layer flattens the last two axes
+      src = g['x_4d'].reshape(2, 6, 6)
+    n = g[key].shape[1]
+    rc, out = run_resample(lib, src, n, method, add_endpoint)
+    assert rc == 0, key
+    np.testing.assert_allclose(out.reshape(g[key].shape), g[key], rtol=0, atol=2e-6 if method == 'window' else 0.0,
+                               err_msg=key)
+    seen += 1
+  assert seen == 34
+
+
+def test_fft_convolve_golden(lib):
+  g = load_golden('fft_convolve_crops')
+  for key, ir, delay in [('valid_d0', 'ir', 0), ('valid_d5', 'ir', 5), ('valid_auto', 'ir', -1), ('same_d40', 'ir', 40),
+                         ('one_valid_d0', 'ir_one', 0), ('one_valid_auto', 'ir_one', -1)]:
+    l = g[ir].shape[2]
+    start = (l - 1) // 2 - 1 if delay < 0 else delay
+    rc, out = run_fir(lib, g['audio'], g[ir], g[key].shape[1], start)
+    assert rc == 0, key
+    np.testing.assert_allclose(out, g[key], rtol=0, atol=2e-6, err_msg=key)

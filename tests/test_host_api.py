@@ -60,10 +60,39 @@ def test_amp_method_errors_match_reference():           # core_test.py:295-381
     core._check_amp_method('window', 10, 105)
   with pytest.raises(ValueError, match='downsampling'):
     core._check_amp_method('window', 10, 5)
-  with pytest.raises(NotImplementedError):
-    core._check_amp_method('cubic', 10, 100)
-  core._check_amp_method('window', 10, 100)
-  core._check_amp_method('linear', 10, 100)
+  for method in ('window', 'linear', 'nearest', 'cubic'):
+    core._check_amp_method(method, 10, 100)
+  core._check_amp_method('cubic', 10, 105)               # only 'window' needs divisibility (core.py:687)
+  # which argument combinations the closed-form synthesis kernels take; the rest follows the
+  # reference's chain of materialised envelopes
+  assert core._on_closed_form_kernels('window', 1000, 64000)
+  assert core._on_closed_form_kernels('linear', 1000, 64000)
+  assert not core._on_closed_form_kernels('cubic', 1000, 64000)
+  assert not core._on_closed_form_kernels('nearest', 1000, 64000)
+  assert not core._on_closed_form_kernels('linear', 1000, 64001)
+
+
+@pytest.mark.parametrize('padding', ['same', 'valid'])
+@pytest.mark.parametrize('delay', [-1, 0, 3, 40])
+@pytest.mark.parametrize('n,f,l', [(64000, 1000, 128), (1000, 1, 10), (10, 1, 100), (250, 25, 7), (777, 7, 16),
+                                   (500, 5, 31), (100, 7, 1), (100, 7, 2), (3000, 1, 2000), (96, 1, 200)])
+def test_crop_range_is_the_reference_slice(padding, delay, n, f, l):          # core.py:1338-1379
+  """The host layer sizes the output by the same python slice the reference takes; compared with the
+  oracle's literal restatement (framed FFTs, overlap-add, audio[:, start:-end]) on an index ramp."""
+  from oracle import ddsp_oracle as oracle
+  audio = np.ones((1, n), np.float64)
+  ir = np.ones((1, f, l), np.float64)
+  ref = oracle.fft_convolve(audio, ir, padding=padding, delay_compensation=delay, dtype=np.float64)
+  start_requested, start, n_out = core._crop_range(n, f, l, padding, delay)
+  assert n_out == ref.shape[1]
+  assert start_requested == ((l - 1) // 2 - 1 if delay < 0 else delay)
+  if n_out:
+    # z[m] of all-ones inputs counts the (sample, tap) pairs that land on m: check the first kept sample
+    z = np.convolve(np.ones(n), np.ones(l)) if f == 1 else None
+    if z is not None and start < z.size:
+      assert abs(ref[0, 0] - z[start]) < 1e-6
+  with pytest.raises(ValueError, match='Padding'):
+    core._crop_range(n, f, l, 'bogus', delay)
 
 
 def test_frame_count_error_matches_reference():         # core_test.py:868-886

@@ -352,3 +352,94 @@ def test_harmonic_backward_f0_matches_finite_differences(method):
     d = np.zeros_like(f0); d[0, j, 0] = eps
     fd = (loss(f0 + d) - loss(f0 - d)) / (2 * eps)
     np.testing.assert_allclose(gf[0, j, 0], fd, rtol=1e-5, atol=1e-9)
+
+
+# ---- the rest of the path's argument space (golden: reference source on the TF stand-in) -------------
+def _resample_golden_entries(g):
+  for key in g:
+    parts = key.split('_')
+    if parts[0] in ('up', 'small', 'ragged', 'down', 'x4d') and len(parts) == 3:
+      yield key, parts[0], parts[1], parts[2] == 'endpoint'
+
+
+def test_resample_every_method_matches_reference_source():         # core.py:573-642
+  g = load_golden('resample_methods')
+  seen = 0
+  for key, kind, method, add_endpoint in _resample_golden_entries(g):
+    n = g[key].shape[1]
+    src = {'up': g['x'], 'ragged': g['x'], 'small': g['x_small'], 'x4d': g['x_4d']}.get(kind)
+    if kind == 'down':
+      src = g['up_%s_%s' % (method, 'endpoint' if add_endpoint else 'noendpoint')]
+    out = O.resample(src, n, method=method, add_endpoint=add_endpoint)
+    assert out.shape == g[key].shape and out.dtype == np.float32
+    np.testing.assert_array_equal(out, g[key], err_msg=key)
+    seen += 1
+  assert seen == 4 * 2 * 2 + 3 * 2 * 3
+
+
+@pytest.mark.parametrize('method', ['nearest', 'linear', 'cubic', 'window'])
+@pytest.mark.parametrize('add_endpoint', [True, False])
+def test_upsample_and_downsample_accuracy_every_method(method, add_endpoint):      # core_test.py:219-293
+  n_small, n_large = 5, 16000
+  n_total = int(n_large / n_small * (n_small - 1)) if add_endpoint else n_large - 1
+  idx = np.linspace(0, n_total, n_small).astype(int)
+  before = (1.0 - np.sin(np.linspace(0, np.pi, n_small)))[None, :, None]
+  if method == 'window' and not add_endpoint:
+    after = O.resample(before, n_large, method=method, add_endpoint=add_endpoint)   # 16000 % 4 == 0
+  else:
+    after = O.resample(before, n_large, method=method, add_endpoint=add_endpoint)
+  np.testing.assert_allclose(after[0, idx, 0], before[0, :, 0], atol=1e-3)
+  if method != 'window':
+    big = (1.0 - np.sin(np.linspace(0, np.pi, n_large)))[None, :, None]
+    small = O.resample(big, n_small, method=method, add_endpoint=add_endpoint)
+    np.testing.assert_allclose(big[0, idx, 0], small[0, :, 0], atol=1e-3)
+  with pytest.raises(ValueError):
+    O.resample(np.ones((2, 5, 3, 2)), 100, method='window')         # 4-D: core_test.py:175-198
+
+
+def test_bicubic_weights_are_a_partition_of_unity_and_interpolate():
+  near, far = O._cubic_coeffs_table()
+  off = np.arange(1025)
+  total = far[off].astype(np.float64) + near[off] + near[1024 - off] + far[1024 - off]
+  np.testing.assert_allclose(total, 1.0, atol=3e-7)
+  assert (far[0], near[0], near[1024], far[1024]) == (0.0, 1.0, 0.0, 0.0)      # exact at the frame points
+  # (the A = -0.75 kernel reproduces constants, not straight lines: only Keys' A = -0.5 does)
+  flat = np.full((1, 8, 1), 3.25, np.float32)
+  np.testing.assert_allclose(O.resample(flat, 64, method='cubic'), 3.25, atol=1e-6)
+  x = np.random.default_rng(0).standard_normal((1, 8, 1)).astype(np.float32)
+  np.testing.assert_array_equal(O.resample(x, 64, method='cubic')[0, ::8, 0], x[0, :, 0])
+
+
+def test_fft_convolve_crops_match_reference_source():               # core.py:1338-1379
+  g = load_golden('fft_convolve_crops')
+  for key, ir, padding, delay in [('valid_d0', 'ir', 'valid', 0), ('valid_d5', 'ir', 'valid', 5),
+                                  ('valid_auto', 'ir', 'valid', -1), ('same_d40', 'ir', 'same', 40),
+                                  ('one_valid_d0', 'ir_one', 'valid', 0), ('one_valid_auto', 'ir_one', 'valid', -1)]:
+    out = O.fft_convolve(g['audio'], g[ir], padding=padding, delay_compensation=delay)
+    assert out.shape == g[key].shape, key
+    np.testing.assert_allclose(out, g[key], rtol=0, atol=1e-6, err_msg=key)
+    direct = O.time_varying_fir_direct(g['audio'], np.broadcast_to(g[ir], (2,) + g[ir].shape[1:]),
+                                       delay_compensation=delay, n_out=out.shape[1])
+    np.testing.assert_allclose(direct, g[key], rtol=0, atol=2e-6, err_msg=key)
+
+
+SYNTHESIS_CASES = ['synthesis_shifts_window', 'synthesis_shifts_only', 'synthesis_cubic',
+                   'synthesis_nearest_angular', 'synthesis_linear_ragged']
+
+
+@pytest.mark.parametrize('name', SYNTHESIS_CASES)
+def test_harmonic_synthesis_argument_space_matches_reference_source(name):     # core.py:1048-1111
+  g = load_golden(name)
+  out = O.harmonic_synthesis(g['f0_hz'], g['amplitudes'], g.get('harmonic_shifts'), g.get('harmonic_distribution'),
+                             n_samples=int(g['n_samples']), sample_rate=int(g['sample_rate']),
+                             amp_resample_method=str(g['amp_method']), use_angular_cumsum=bool(g['angular']))
+  assert out.shape == g['audio'].shape
+  np.testing.assert_allclose(out, g['audio'], rtol=0, atol=2e-6)
+
+
+def test_harmonic_with_cubic_envelope_matches_reference_source():
+  g = load_golden('harmonic_cubic_amp')
+  c = O.harmonic_get_controls(g['amplitudes'], g['harmonic_distribution'], g['f0_hz'], int(g['sample_rate']))
+  sig = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'], int(g['n_samples']),
+                              int(g['sample_rate']), str(g['amp_method']), bool(g['angular']))
+  np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=2e-6)
