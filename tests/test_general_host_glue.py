@@ -1,0 +1,188 @@
+"""CPU checks of the PYTHON GLUE in ddsp_amd/core.py / synths.py around the general-shape entry points:
+argument order of the ctypes calls, output shapes, routing between the fast and the general entries, the
+autograd node's f0 branch.  The host layer is pointed at host memory for the duration of a test: tensors
+stay on the CPU, the general kernels come from the host build of general.hip (tests/hip_emu), and the two
+entries that build cannot provide (harmonic controls, oscillator bank) are TEST DOUBLES that fill their
+output buffers from the oracle.  Nothing here says anything about the GPU kernels themselves; the product
+never runs this way (ddsp_amd has no CPU path: see test_host_api.test_no_gpu_fails_loudly_not_silently)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from ddsp_amd import _lib, core, synths
+from oracle import ddsp_oracle as O
+from tests.hip_emu import emu
+
+
+def _view(ptr, shape, dtype=np.float32):
+  n = int(np.prod(shape))
+  ctype = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+  return np.ctypeslib.as_array((ctype * n).from_address(ptr)).reshape(shape)
+
+
+class _HostLib:
+  """emu entry points + oracle-backed doubles, behind the attribute names core.py calls."""
+
+  def __init__(self):
+    self._emu = emu.load()
+    self.calls = []
+
+  def __getattr__(self, name):
+    if name in emu.ENTRY_POINTS:
+      fn = getattr(self._emu, name)
+
+      def traced(*args):
+        self.calls.append(name)
+        return fn(*args)
+      return traced
+    raise AttributeError('no host stand-in for ' + name)
+
+  def ddsp_harmonic_controls_f32(self, amp, hd, f0, ctl_amp, ctl_hd, b, f, k, sample_rate, flags, stream):
+    self.calls.append('ddsp_harmonic_controls_f32')
+    scale = O.exp_sigmoid if flags & _lib.HARM_SCALE_EXP_SIGMOID else None
+    c = O.harmonic_get_controls(_view(amp, (b, f, 1)), _view(hd, (b, f, k)), _view(f0, (b, f, 1)), sample_rate,
+                                scale, bool(flags & _lib.HARM_NORMALIZE_NYQUIST))
+    _view(ctl_amp, (b, f, 1))[:] = c['amplitudes']
+    _view(ctl_hd, (b, f, k))[:] = c['harmonic_distribution']
+    return 0
+
+  def ddsp_oscillator_bank_workspace_bytes(self, b, n, k):
+    return 64
+
+  def ddsp_oscillator_bank_f32(self, freq, amp, out, ws, ws_bytes, b, n, k, sample_rate, sum_sinusoids, stream):
+    self.calls.append('ddsp_oscillator_bank_f32')
+    audio = O.oscillator_bank(_view(freq, (b, n, k)).astype(np.float64), _view(amp, (b, n, k)).astype(np.float64),
+                              sample_rate, sum_sinusoids=bool(sum_sinusoids))
+    _view(out, audio.shape)[:] = audio
+    return 0
+
+  def ddsp_fft_convolve_same_f32(self, audio, ir, out, b, bir, f, l, n, delay, stream):
+    self.calls.append('ddsp_fft_convolve_same_f32')
+    start = (l - 1) // 2 - 1 if delay < 0 else delay
+    return self._emu.ddsp_fft_convolve_f32(audio, ir, out, b, bir, f, l, n, n, max(start, 0), stream)
+
+  def ddsp_resample_f32(self, x, out, b, f, n, c, window, stream):
+    self.calls.append('ddsp_resample_f32')
+    return self._emu.ddsp_resample_ex_f32(x, out, b, f, n, c, 3 if window else 1, 1, stream)
+
+
+@pytest.fixture
+def host(monkeypatch):
+  lib = _HostLib()
+  monkeypatch.setattr(_lib, 'load', lambda: lib)
+  monkeypatch.setattr(core, '_device', lambda: torch.device('cpu'))
+  monkeypatch.setattr(core, '_stream', lambda: None)
+  monkeypatch.setattr(core, '_ws_bytes_cache', {})
+  return lib
+
+
+def npy(t):
+  return t.detach().numpy()
+
+
+def test_resample_glue_every_method(host):
+  g = load_golden('resample_methods')
+  for key in g:
+    parts = key.split('_')
+    if parts[0] not in ('up', 'small', 'ragged', 'down', 'x4d') or len(parts) != 3:
+      continue
+    kind, method, add_endpoint = parts[0], parts[1], parts[2] == 'endpoint'
+    src = {'up': g['x'], 'ragged': g['x'], 'small': g['x_small'], 'x4d': g['x_4d']}.get(kind)
+    if kind == 'down':
+      src = g['up_%s_%s' % (method, parts[2])]
+    host.calls.clear()
+    out = npy(core.resample(src, g[key].shape[1], method=method, add_endpoint=add_endpoint))
+    assert out.shape == g[key].shape, key
+    np.testing.assert_allclose(out, g[key], rtol=0, atol=2e-6 if method == 'window' else 0.0, err_msg=key)
+    fast = add_endpoint and method in ('linear', 'window')
+    assert host.calls == ['ddsp_resample_f32' if fast else 'ddsp_resample_ex_f32'], key
+  # 1-D and 2-D inputs come back 1-D and 2-D (core_test.py:153-173)
+  assert tuple(core.resample(np.ones(5, np.float32), 160, method='cubic').shape) == (160,)
+  assert tuple(core.resample(np.ones((5, 5), np.float32), 160, method='nearest', add_endpoint=False).shape) == (5, 160)
+  with pytest.raises(ValueError, match='3 dimensions'):
+    core.resample(np.ones((5, 5, 5, 5), np.float32), 160, method='window')
+  with pytest.raises(ValueError, match='is invalid'):
+    core.resample(np.ones((1, 5, 1), np.float32), 160, method='bogus')
+  with pytest.raises(ValueError, match=r'frames - 1'):
+    core.upsample_with_windows(np.ones((1, 5, 1), np.float32), 161, add_endpoint=False)
+
+
+def test_fft_convolve_glue_crops_and_routing(host):
+  g = load_golden('fft_convolve_crops')
+  for key, ir, padding, delay, entry in [
+      ('valid_d0', 'ir', 'valid', 0, 'ddsp_fft_convolve_f32'), ('valid_d5', 'ir', 'valid', 5, 'ddsp_fft_convolve_f32'),
+      ('valid_auto', 'ir', 'valid', -1, 'ddsp_fft_convolve_f32'), ('same_d40', 'ir', 'same', 40, 'ddsp_fft_convolve_same_f32'),
+      ('one_valid_d0', 'ir_one', 'valid', 0, 'ddsp_fft_convolve_f32'),
+      ('one_valid_auto', 'ir_one', 'valid', -1, 'ddsp_fft_convolve_f32')]:
+    host.calls.clear()
+    out = npy(core.fft_convolve(g['audio'], g[ir], padding=padding, delay_compensation=delay))
+    assert out.shape == g[key].shape, key
+    np.testing.assert_allclose(out, g[key], rtol=0, atol=2e-6, err_msg=key)
+    assert host.calls == [entry], key
+  host.calls.clear()
+  empty = core.fft_convolve(np.ones((1, 250), np.float32), np.ones((1, 25, 7), np.float32), padding='valid',
+                            delay_compensation=0)
+  assert tuple(empty.shape) == (1, 0) and host.calls == []
+  with pytest.raises(ValueError, match='Padding'):
+    core.fft_convolve(g['audio'], g['ir'], padding='bogus')
+  with pytest.raises(ValueError, match='do not match'):
+    core.fft_convolve(np.ones((1, 100), np.float32), np.ones((1, 30, 5), np.float32), padding='valid')
+
+
+@pytest.mark.parametrize('name', ['synthesis_shifts_window', 'synthesis_shifts_only', 'synthesis_cubic',
+                                  'synthesis_nearest_angular', 'synthesis_linear_ragged'])
+def test_harmonic_synthesis_glue_materialised_chain(host, name):
+  g = load_golden(name)
+  out = npy(core.harmonic_synthesis(
+      frequencies=g['f0_hz'], amplitudes=g['amplitudes'], harmonic_shifts=g.get('harmonic_shifts'),
+      harmonic_distribution=g.get('harmonic_distribution'), n_samples=int(g['n_samples']),
+      sample_rate=int(g['sample_rate']), amp_resample_method=str(g['amp_method']),
+      use_angular_cumsum=bool(g['angular'])))
+  assert out.shape == g['audio'].shape
+  amp_sum = float(np.abs(g['amplitudes']).max()) * (float(np.abs(g['harmonic_distribution']).sum(-1).max())
+                                                     if 'harmonic_distribution' in g else g['harmonic_shifts'].shape[-1])
+  np.testing.assert_allclose(out, g['audio'], rtol=0, atol=2e-3 * max(1.0, amp_sum))
+  assert host.calls[0] == 'ddsp_harmonic_envelopes_f32' and host.calls[-1] == 'ddsp_oscillator_bank_f32'
+  assert len(host.calls) == 4                                 # envelopes, two resamples, oscillator bank
+
+
+def test_harmonic_processor_glue_cubic_envelope(host):
+  g = load_golden('harmonic_cubic_amp')
+  synth = synths.Harmonic(n_samples=int(g['n_samples']), sample_rate=int(g['sample_rate']),
+                          amp_resample_method='cubic')
+  out = synth(g['amplitudes'], g['harmonic_distribution'], g['f0_hz'], return_outputs_dict=True)
+  np.testing.assert_allclose(npy(out['controls']['harmonic_distribution']), g['ctl_harmonic_distribution'],
+                             rtol=2e-5, atol=1e-9)
+  np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=2e-3)
+  a = torch.tensor(g['amplitudes'], requires_grad=True)
+  with pytest.raises(NotImplementedError, match='backward'):
+    synth(a, g['harmonic_distribution'], g['f0_hz'])
+
+
+def test_harmonic_f0_gradient_glue(host):
+  rng = np.random.default_rng(9)
+  b, f, k, hop, sr = 2, 12, 8, 64, 16000
+  n = f * hop
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = rng.uniform(100.0, 400.0, (b, f, 1)).astype(np.float32)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  for method in ('window', 'linear'):
+    synth = synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)
+    grad_f0 = npy(synth._backward_f0(torch.tensor(amps), torch.tensor(hd), torch.tensor(f0), True, torch.tensor(g)))
+    ref = O.harmonic_backward(amps, hd, f0, g, n_samples=n, sample_rate=sr, amp_resample_method=method,
+                              with_f0=True)[2]
+    assert grad_f0.shape == (b, f, 1)
+    np.testing.assert_allclose(grad_f0, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+  # the autograd node routes needs_input_grad[2] to it and returns None for the inputs that need nothing
+  class _Ctx:
+    needs_input_grad = (False, False, True, False, False, False)
+    saved_tensors = (torch.tensor(amps), torch.tensor(hd), torch.tensor(f0))
+    fuse = True
+  _Ctx.synth = synth
+  grads = synths._HarmonicFunction.backward(_Ctx, torch.tensor(g), None, None)
+  assert grads[0] is None and grads[1] is None and grads[3:] == (None, None, None)
+  np.testing.assert_allclose(npy(grads[2]), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
