@@ -99,7 +99,7 @@ int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amplitudes,
  * (inputs_are_controls = 1): the gradients tf.GradientTape forms through
  * ddsp/synths.py:94-146 in ddsp/training/trainers.py:162-171.
  *   grad_audio [B,N] in;  grad_amplitudes [B,F,1], grad_harmonic_distribution [B,F,K] out.
- * f0_hz is a constant of the differentiation (no gradient is formed for it); the Nyquist masks
+ * f0_hz is a constant of this call (its gradient is ddsp_harmonic_f0_grad_f32); the Nyquist masks
  * have zero gradient, as tf.where gives them.  flags as ddsp_harmonic_f32.  K <= 256, N/F <= 2048.
  * workspace: ddsp_harmonic_backward_workspace_bytes(B,F,K,N).
  */
