@@ -81,6 +81,18 @@ def algorithmic_bytes(a, batch):
   return harm, noise
 
 
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CUs x 2.4 GHz x 256 flop/clk, packed fp32
+
+
+def algorithmic_flops(a, batch):
+  """SURVEY.md 8(d), the ALU note beside the HBM roofline: 3 FMAs per (sample, live harmonic) for the
+  oscillator bank, 2 L flops per sample for the L-tap time-varying FIR (L = 2 (M - 1))."""
+  live = min(a.n_harmonics, int((a.sample_rate / 2.0) / max(a.f0, 1e-6)))
+  harm = batch * a.n_samples * 3 * live * 2
+  noise = batch * a.n_samples * 2 * 2 * (a.n_bands - 1)
+  return harm, noise
+
+
 def cpu_baseline(a):
   """The oracle (numpy, fp32, op by op as TF executes it) on `cpu_clips` clips, one at a time."""
   from oracle import ddsp_oracle as O
@@ -249,6 +261,8 @@ def main():
         except (ValueError, OSError):
           traffic = None
     step_bytes = harm_bytes + noise_bytes
+    harm_flops, noise_flops = algorithmic_flops(a, B)
+    dom_flops = harm_flops if dominant.startswith('harm') else noise_flops
     result = {
         'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
         'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': a.steps,
@@ -272,7 +286,15 @@ def main():
                       'every event_stride-th launch inside the timed region',
             'whole_step': {'algorithmic_bytes': step_bytes,
                            'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
-                           'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS}},
+                           'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
+            # the path sits above the fp32 ridge point: the vector-ALU ceiling beside the
+            # HBM fraction, on the reference formulation's flop count (the wavetable kernel does fewer)
+            'alu_note': {'algorithmic_flop_per_launch': dom_flops,
+                         'achieved_TFLOPs': dom_flops / dom_avg_s / 1e12,
+                         'peak_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
+                         'frac': dom_flops / dom_avg_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         'whole_step_frac': (harm_flops + noise_flops) / (elapsed / a.steps) / 1e12 /
+                                            FP32_VECTOR_PEAK_TFLOPS}},
         'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
     }
     if alt_elapsed is not None:
