@@ -66,6 +66,9 @@ SIGNATURES = {
     'ddsp_harmonic_f0_grad_workspace_bytes': (c_size_t, [c_int] * 4),
     'ddsp_harmonic_f0_grad_f32': (c_int, [c_f32p] * 5 + [c_voidp, c_size_t] + [c_int] * 5 +
                                   [c_uint, c_voidp]),
+    'ddsp_exp_decay_ir_f32': (c_int, [c_f32p] * 4 + [c_int] * 2 + [c_uint, c_voidp]),
+    'ddsp_exp_decay_ir_backward_workspace_bytes': (c_size_t, [c_int] * 2),
+    'ddsp_exp_decay_ir_backward_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 2 + [c_uint, c_voidp]),
     'ddsp_profile_kernel_count': (c_int, []),
     'ddsp_profile_kernel_name': (ctypes.c_char_p, [c_int]),
     'ddsp_profile_begin': (c_int, [c_uint, c_int]),
@@ -81,6 +84,7 @@ HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
 NOISE_SCALE_EXP_SIGMOID = 0x1
+DECAY_SCALE_EXP_SIGMOID = 0x1
 RESAMPLE_METHODS = {'nearest': 0, 'linear': 1, 'cubic': 2, 'window': 3}
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2

@@ -10,6 +10,8 @@
 //                                 (ddsp/core.py:1080-1098, 1028-1045)
 //   ddsp_harmonic_f0_grad_f32     dL/d f0_hz of Harmonic (what tf.GradientTape forms through tf.cumsum and
 //                                 tf.sin, ddsp/core.py:950-960; trainers.py:162-171)
+//   ddsp_exp_decay_ir_f32 (+ _backward)   effects.ExpDecayReverb's impulse response and its gradient with
+//                                 respect to gain and decay (ddsp/effects.py:120-199)
 //
 // These are generality paths: one thread per output value, HBM / L2 reads only, no LDS, no cross-lane
 // traffic, no inline assembly.  Their cost is irrelevant next to the fused kernels of harmonic*.hip and
@@ -270,6 +272,83 @@ __global__ __launch_bounds__(kThreads) void f0grad_scan_kernel(const double* __r
   }
 }
 
+// =====================================================================================
+// effects.ExpDecayReverb._get_ir (ddsp/effects.py:144-151): an exponentially decaying burst of noise
+//   ir[b, i] = G_b * exp(-(2 + exp(decay_b)) * t_i) * noise[i],  t = linspace(0, 1, L),  G = scale_fn(gain)
+// and its gradient with respect to gain and decay (two-stage sums, fp64):
+//   dL/d gain_b  = G'(gain_b) * sum_i g[b,i] E_b(t_i) noise[i]
+//   dL/d decay_b = -exp(decay_b) * G_b * sum_i g[b,i] E_b(t_i) noise[i] t_i
+// =====================================================================================
+constexpr int kDecayPartials = 256;
+
+__device__ __forceinline__ float linspace01(int i, int L, float step) {
+  return (i == L - 1 && L > 1) ? 1.0f : (float)i * step;      // tf.linspace ends on `stop` exactly
+}
+// core.exp_sigmoid with its default constants (core.py:386-404): 2 sigmoid(x)^log(10) + 1e-7
+__device__ __forceinline__ float exp_sigmoid_default(float x) {
+  const float softplus_neg = (x >= 0.0f) ? log1pf(expf(-x)) : (-x + log1pf(expf(x)));   // log(1 + e^-x)
+  return 2.0f * expf(-2.302585092994046f * softplus_neg) + 1e-7f;
+}
+
+__global__ __launch_bounds__(kThreads) void exp_decay_ir_kernel(const float* __restrict__ gain /*[Bg]*/,
+                                                                const float* __restrict__ decay /*[Bg]*/,
+                                                                const float* __restrict__ noise /*[L]*/,
+                                                                float* __restrict__ ir /*[B,L]*/, int B, int L,
+                                                                int scale_exp_sigmoid) {
+  const size_t total = (size_t)B * L;
+  const float step = L > 1 ? 1.0f / (float)(L - 1) : 0.0f;
+  for (size_t idx = global_thread(); idx < total; idx += grid_threads()) {
+    const int b = (int)(idx / L), i = (int)(idx - (size_t)b * L);
+    const float g = scale_exp_sigmoid ? exp_sigmoid_default(gain[b]) : gain[b];
+    const float decay_exponent = 2.0f + expf(decay[b]);
+    ir[idx] = g * expf(-decay_exponent * linspace01(i, L, step)) * noise[i];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void exp_decay_bwd_partial_kernel(
+    const float* __restrict__ decay /*[B]*/, const float* __restrict__ noise /*[L]*/,
+    const float* __restrict__ grad_ir /*[B,L]*/, double* __restrict__ partial /*[B,kDecayPartials,2]*/, int B,
+    int L) {
+  const size_t total = (size_t)B * kDecayPartials;
+  const float step = L > 1 ? 1.0f / (float)(L - 1) : 0.0f;
+  for (size_t idx = global_thread(); idx < total; idx += grid_threads()) {
+    const int b = (int)(idx / kDecayPartials), q = (int)(idx - (size_t)b * kDecayPartials);
+    const float decay_exponent = 2.0f + expf(decay[b]);
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = q; i < L; i += kDecayPartials) {
+      const float t = linspace01(i, L, step);
+      const double v = (double)(grad_ir[(size_t)b * L + i] * noise[i]) * (double)expf(-decay_exponent * t);
+      s0 += v;
+      s1 += v * (double)t;
+    }
+    partial[idx * 2 + 0] = s0;
+    partial[idx * 2 + 1] = s1;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void exp_decay_bwd_finish_kernel(
+    const float* __restrict__ gain, const float* __restrict__ decay, const double* __restrict__ partial,
+    float* __restrict__ grad_gain, float* __restrict__ grad_decay, int B, int scale_exp_sigmoid) {
+  for (size_t b = global_thread(); b < (size_t)B; b += grid_threads()) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = 0; q < kDecayPartials; ++q) {
+      s0 += partial[(b * kDecayPartials + q) * 2 + 0];
+      s1 += partial[(b * kDecayPartials + q) * 2 + 1];
+    }
+    double g = (double)gain[b], dg = 1.0;
+    if (scale_exp_sigmoid) {
+      // d/dx exp_sigmoid(x) = log(10) (y - threshold) (1 - sigmoid(x))
+      const double x = g;
+      const double sig = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+      const double y = (double)exp_sigmoid_default((float)x);
+      dg = 2.302585092994046 * (y - 1e-7) * (1.0 - sig);
+      g = y;
+    }
+    grad_gain[b] = (float)(dg * s0);
+    grad_decay[b] = (float)(-exp((double)decay[b]) * g * s1);
+  }
+}
+
 static inline unsigned grid_for(size_t n, unsigned cap = 256 * 32) {
   size_t g = (n + kThreads - 1) / kThreads;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -367,5 +446,38 @@ extern "C" int ddsp_harmonic_f0_grad_f32(const float* ctl_amplitudes, const floa
                      (const float*)c, sums, p);
   hipLaunchKernelGGL(f0grad_scan_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st,
                      (const double*)sums, grad_f0, p);
+  return check_launch();
+}
+
+extern "C" int ddsp_exp_decay_ir_f32(const float* gain, const float* decay, const float* noise, float* ir, int B,
+                                     int L, unsigned flags, void* stream) {
+  if (!gain || !decay || !noise || !ir) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || L <= 0) return DDSP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(exp_decay_ir_kernel, dim3(grid_for((size_t)B * L)), dim3(kThreads), 0, (hipStream_t)stream,
+                     gain, decay, noise, ir, B, L, (flags & DDSP_DECAY_SCALE_EXP_SIGMOID) ? 1 : 0);
+  return check_launch();
+}
+
+extern "C" size_t ddsp_exp_decay_ir_backward_workspace_bytes(int B, int L) {
+  (void)L;
+  return B > 0 ? (size_t)B * kDecayPartials * 2 * sizeof(double) : 0;
+}
+
+extern "C" int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* decay, const float* noise,
+                                              const float* grad_ir, float* grad_gain, float* grad_decay,
+                                              void* workspace, size_t workspace_bytes, int B, int L,
+                                              unsigned flags, void* stream) {
+  if (!gain || !decay || !noise || !grad_ir || !grad_gain || !grad_decay || !workspace)
+    return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || L <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_exp_decay_ir_backward_workspace_bytes(B, L) || ((uintptr_t)workspace & 15))
+    return DDSP_ERR_WORKSPACE;
+  double* partial = (double*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const int scale = (flags & DDSP_DECAY_SCALE_EXP_SIGMOID) ? 1 : 0;
+  hipLaunchKernelGGL(exp_decay_bwd_partial_kernel, dim3(grid_for((size_t)B * kDecayPartials)), dim3(kThreads), 0,
+                     st, decay, noise, grad_ir, partial, B, L);
+  hipLaunchKernelGGL(exp_decay_bwd_finish_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st, gain, decay,
+                     (const double*)partial, grad_gain, grad_decay, B, scale);
   return check_launch();
 }

@@ -3,10 +3,11 @@
 SURVEY.md section 8(f) rank 1.  The reference convolves with one 131 072-point FFT per clip; here
 `core.fft_convolve_long` runs a partitioned overlap-save convolution with LDS-resident FFTs
 (csrc/reverb.hip).  FilteredNoiseReverb and FIRFilter are compositions of kernels that exist;
-ExpDecayReverb and ModDelay are not built.
+ExpDecayReverb's impulse response has its own small kernels (csrc/general.hip); ModDelay is not built.
 """
 import torch
 
+from ddsp_amd import _lib
 from ddsp_amd import core
 from ddsp_amd import processors
 
@@ -117,6 +118,110 @@ class _ReverbFunction(torch.autograd.Function):
     if gi is not None:
       gi = gi.reshape(ctx.ir_shape)
     return ga, gi, None
+
+
+class ExpDecayReverb(Reverb):
+  """Parameterize impulse response as a simple exponential decay (ddsp/effects.py:120-199).
+
+  `seed` is this package's extension: the reference draws a fresh tf.random.uniform([1, reverb_length])
+  burst from TensorFlow's global generator on every call; here the burst is Philox4x32-10 keyed by
+  (seed, call counter).  `get_controls(..., noise=...)` is the parity entry with a supplied burst.
+  """
+
+  def __init__(self, trainable=False, reverb_length=48000, scale_fn=core.exp_sigmoid, add_dry=True,
+               name='exp_decay_reverb', seed=0):
+    super().__init__(name=name, add_dry=add_dry, trainable=trainable)
+    self._reverb_length = reverb_length
+    self._scale_fn = scale_fn
+    self._gain = None
+    self._decay = None
+    self.seed = int(seed)
+    self._calls = 0
+
+  def build(self, unused_input_shape=None, device=None, seed=0):
+    """gain = 2.0, decay = 4.0, one value each, when trainable (effects.py:153-168)."""
+    del seed
+    if self.trainable and self._gain is None:
+      device = device if device is not None else core._device()
+      self._gain = torch.full((1,), 2.0, dtype=torch.float32, device=device)
+      self._decay = torch.full((1,), 4.0, dtype=torch.float32, device=device)
+    self.built = True
+
+  def _get_ir(self, gain, decay, noise=None):
+    """Simple exponential decay of white noise (effects.py:144-151): gain, decay [batch, 1] -> [batch, L]."""
+    gain, decay = tf_float32(gain), tf_float32(decay)
+    fused = self._scale_fn is core.exp_sigmoid
+    if not fused and self._scale_fn is not None:
+      gain = tf_float32(self._scale_fn(gain))       # any other callable runs as given, on device tensors
+    if gain.numel() != decay.numel() or gain.dim() > 2 or decay.dim() > 2:
+      raise ValueError('gain and decay must both be [batch, 1], got {} and {}'.format(
+          tuple(gain.shape), tuple(decay.shape)))
+    if noise is None:
+      seed = (self.seed & 0xFFFFFFFF) | ((self._calls & 0xFFFFFFFF) << 32)
+      self._calls += 1
+      noise = core.uniform_noise(1, self._reverb_length, seed=seed)
+    else:
+      noise = tf_float32(noise).reshape(1, -1)
+      if noise.shape[1] != self._reverb_length:
+        raise ValueError('noise must hold reverb_length = {} samples, got {}'.format(
+            self._reverb_length, noise.shape[1]))
+    if torch.is_grad_enabled() and (gain.requires_grad or decay.requires_grad):
+      return _ExpDecayIrFunction.apply(gain, decay, noise.contiguous(), fused)
+    return _exp_decay_ir(gain, decay, noise.contiguous(), fused)
+
+  def get_controls(self, audio, gain=None, decay=None, noise=None):
+    """Convert network outputs into the impulse response (effects.py:170-199).
+
+    Raises:
+      ValueError: if trainable=False and gain and decay are not provided.
+    """
+    if self.trainable:
+      if not self.built:
+        self.build(device=tf_float32(audio).device)
+      gain, decay = self._gain[None, :], self._decay[None, :]
+    elif gain is None or decay is None:
+      raise ValueError('Must provide "gain" and "decay" tensors if '
+                       'ExpDecayReverb trainable=False.')
+    ir = self._get_ir(gain, decay, noise)   # trainable: [1, L]; _match_dimensions' tile happens in the kernel
+    return {'audio': audio, 'ir': ir}
+
+
+def _exp_decay_ir(gain, decay, noise, fused_scale):
+  b, l = gain.numel(), noise.shape[1]
+  gain, decay = gain.reshape(b).contiguous(), decay.reshape(b).contiguous()
+  ir = torch.empty((b, l), dtype=torch.float32, device=gain.device)
+  rc = _lib.load().ddsp_exp_decay_ir_f32(gain.data_ptr(), decay.data_ptr(), noise.data_ptr(), ir.data_ptr(), b, l,
+                                         _lib.DECAY_SCALE_EXP_SIGMOID if fused_scale else 0, core._stream())
+  _lib.check(rc, 'ddsp_exp_decay_ir_f32')
+  return ir
+
+
+class _ExpDecayIrFunction(torch.autograd.Function):
+  """torch.autograd node of ExpDecayReverb._get_ir (plumbing: both directions are C-ABI calls)."""
+
+  @staticmethod
+  def forward(ctx, gain, decay, noise, fused_scale):
+    ctx.save_for_backward(gain, decay, noise)
+    ctx.fused_scale = fused_scale
+    return _exp_decay_ir(gain.detach(), decay.detach(), noise, fused_scale)
+
+  @staticmethod
+  def backward(ctx, grad_ir):
+    gain, decay, noise = ctx.saved_tensors
+    b, l = gain.numel(), noise.shape[1]
+    lib = _lib.load()
+    g = tf_float32(grad_ir)
+    gain_flat, decay_flat = gain.detach().reshape(b).contiguous(), decay.detach().reshape(b).contiguous()
+    grad_gain = torch.empty(b, dtype=torch.float32, device=g.device)
+    grad_decay = torch.empty(b, dtype=torch.float32, device=g.device)
+    ws = core.Workspace().get(core.cached_workspace_bytes('ddsp_exp_decay_ir_backward_workspace_bytes', b, l),
+                              g.device)
+    rc = lib.ddsp_exp_decay_ir_backward_f32(
+        gain_flat.data_ptr(), decay_flat.data_ptr(), noise.data_ptr(), g.data_ptr(), grad_gain.data_ptr(),
+        grad_decay.data_ptr(), ws.data_ptr(), ws.numel(), b, l,
+        _lib.DECAY_SCALE_EXP_SIGMOID if ctx.fused_scale else 0, core._stream())
+    _lib.check(rc, 'ddsp_exp_decay_ir_backward_f32')
+    return grad_gain.reshape(gain.shape), grad_decay.reshape(decay.shape), None, None
 
 
 class FilteredNoiseReverb(Reverb):

@@ -345,6 +345,22 @@ int ddsp_harmonic_f0_grad_f32(const float* ctl_amplitudes, const float* ctl_harm
                               void* workspace, size_t workspace_bytes, int B, int F, int K, int N,
                               int sample_rate, unsigned flags, void* stream);
 
+/* effects.ExpDecayReverb._get_ir (ddsp/effects.py:144-151):
+ *     ir[b][i] = G(gain[b]) * exp(-(2 + exp(decay[b])) * t_i) * noise[i],   t = linspace(0, 1, L)
+ * gain, decay [B] (the reference's [B,1]); noise [L]: ONE burst shared by the batch, as the reference draws
+ * tf.random.uniform([1, L], -1, 1) (ddsp_uniform_noise_f32 with B = 1 is the on-chip stand-in); ir [B,L] out.
+ * flags: DDSP_DECAY_SCALE_EXP_SIGMOID = scale_fn is core.exp_sigmoid (else gain is used as given).
+ * _backward: grad_ir [B,L] in, grad_gain / grad_decay [B] out; workspace:
+ * ddsp_exp_decay_ir_backward_workspace_bytes(B, L). */
+#define DDSP_DECAY_SCALE_EXP_SIGMOID 0x1u
+int ddsp_exp_decay_ir_f32(const float* gain, const float* decay, const float* noise, float* ir, int B, int L,
+                          unsigned flags, void* stream);
+size_t ddsp_exp_decay_ir_backward_workspace_bytes(int B, int L);
+int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* decay, const float* noise,
+                                   const float* grad_ir, float* grad_gain, float* grad_decay,
+                                   void* workspace, size_t workspace_bytes, int B, int L, unsigned flags,
+                                   void* stream);
+
 /* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
 int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
                          float max_value, float threshold, void* stream);

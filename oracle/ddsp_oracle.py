@@ -611,6 +611,33 @@ def reverb(audio, ir, add_dry=True, dtype=np.float32):
   return (wet + audio) if add_dry else wet
 
 
+def exp_decay_ir(gain, decay, noise, scale_fn=exp_sigmoid, dtype=np.float32):
+  """effects.ExpDecayReverb._get_ir (effects.py:144-151): gain, decay [B,1], noise [1,L] -> ir [B,L].
+
+  ir = scale_fn(gain) * exp(-(2 + exp(decay)) * linspace(0, 1, L)) * noise.  The reference draws the noise
+  from tf.random.uniform([1, L], -1, 1) inside; here it is an argument (the parity entry)."""
+  gain, decay, noise = as_float(gain, dtype), as_float(decay, dtype), as_float(noise, dtype)
+  if scale_fn is not None:
+    gain = scale_fn(gain, dtype=dtype)
+  decay_exponent = dtype(2.0) + np.exp(decay)
+  length = noise.shape[-1]
+  time = np.linspace(0.0, 1.0, length).astype(dtype)[None, :]
+  return gain.reshape(-1, 1) * np.exp(-decay_exponent.reshape(-1, 1) * time) * noise.reshape(1, -1)
+
+
+def exp_decay_ir_backward(gain, decay, noise, grad_ir, scale_fn=exp_sigmoid):
+  """(dL/d gain [B,1], dL/d decay [B,1]) of exp_decay_ir given dL/d ir [B,L] (fp64 truth)."""
+  gain, decay = as_float(gain, np.float64).reshape(-1, 1), as_float(decay, np.float64).reshape(-1, 1)
+  noise, g = as_float(noise, np.float64).reshape(1, -1), as_float(grad_ir, np.float64)
+  time = np.linspace(0.0, 1.0, noise.shape[-1])[None, :]
+  envelope = np.exp(-(2.0 + np.exp(decay)) * time)
+  scaled = scale_fn(gain, dtype=np.float64) if scale_fn is not None else gain
+  d_scaled = exp_sigmoid_grad(gain) if scale_fn is not None else np.ones_like(gain)
+  s0 = np.sum(g * envelope * noise, axis=1, keepdims=True)
+  s1 = np.sum(g * envelope * noise * time, axis=1, keepdims=True)
+  return d_scaled * s0, -np.exp(decay) * scaled * s1
+
+
 def reverb_direct(audio, ir, add_dry=True):
   """fp64 direct-form truth for reverb(): y[n] = sum_{k>=1} ir[k] x[n-k] (+ x[n])."""
   audio = as_float(audio, np.float64)

@@ -117,6 +117,30 @@ def main():
   cases['reverb_b2_wet_rank3'] = reverb_case(32, 2, 777, 1200, 2, False, ir_rank=3)   # IR longer than the audio
   cases['reverb_trainable'] = reverb_case(33, 3, 640, 200, 1, True, trainable=True)
 
+  # --- effects.ExpDecayReverb: network gain / decay [B, 1]; trainable (gain 2.0, decay 4.0) ---
+  def exp_decay_case(seed, batch, n_samples, ir_size, add_dry, trainable):
+    r = np.random.default_rng(seed)
+    audio = r.standard_normal((batch, n_samples)).astype(np.float32)
+    rev = effects.ExpDecayReverb(trainable=trainable, reverb_length=ir_size, add_dry=add_dry)
+    # the burst _get_ir is about to draw: the stand-in's tf.random.uniform is a fixed stream per call
+    noise = a(tf_numpy_shim.build_tf_module()[0].random.uniform([1, ir_size], minval=-1.0, maxval=1.0))
+    if trainable:                   # the weights tf would create in build() (effects.py:153-168)
+      rev._gain = np.full((1,), 2.0, np.float32)
+      rev._decay = np.full((1,), 4.0, np.float32)
+      rev.built = True
+      out = rev(audio, return_outputs_dict=True)
+      d = dict(gain=rev._gain, decay=rev._decay)
+    else:
+      gain = r.standard_normal((batch, 1)).astype(np.float32)
+      decay = r.uniform(-1.0, 3.0, (batch, 1)).astype(np.float32)
+      out = rev(audio, gain, decay, return_outputs_dict=True)
+      d = dict(gain=gain, decay=decay)
+    d.update(audio=audio, noise=noise, add_dry=int(add_dry), trainable=int(trainable),
+             ir=a(out['controls']['ir']), signal=a(out['signal']))
+    return d
+  cases['exp_decay_reverb_b3'] = exp_decay_case(34, 3, 800, 250, True, False)
+  cases['exp_decay_reverb_trainable'] = exp_decay_case(35, 2, 640, 1500, False, True)   # IR longer than the audio
+
   # --- losses.SpectralLoss (mag + logmag terms, L1), and the magnitudes of one scale ---
   rng = np.random.default_rng(41)
   tgt = (rng.standard_normal((2, 3000)) * 0.3).astype(np.float32)

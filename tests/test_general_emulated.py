@@ -239,3 +239,40 @@ def test_fft_convolve_golden(lib):
     rc, out = run_fir(lib, g['audio'], g[ir], g[key].shape[1], start)
     assert rc == 0, key
     np.testing.assert_allclose(out, g[key], rtol=0, atol=2e-6, err_msg=key)
+
+
+# ---- effects.ExpDecayReverb: impulse response and its gradient ---------------------------------------------
+@pytest.mark.parametrize('b,l,scale', [(3, 1000, True), (1, 4801, True), (2, 257, False), (2, 1, True)])
+def test_exp_decay_ir_and_backward(lib, b, l, scale):
+  rng = np.random.default_rng(b * 100 + l)
+  gain = rng.standard_normal((b, 1)).astype(np.float32) + (0.0 if scale else 2.0)
+  decay = rng.uniform(-1.0, 3.0, (b, 1)).astype(np.float32)
+  noise = rng.uniform(-1.0, 1.0, (1, l)).astype(np.float32)
+  ir = np.full((b, l), np.nan, np.float32)
+  flags = _lib.DECAY_SCALE_EXP_SIGMOID if scale else 0
+  assert lib.ddsp_exp_decay_ir_f32(emu.ptr(gain), emu.ptr(decay), emu.ptr(noise), emu.ptr(ir), b, l, flags, None) == 0
+  scale_fn = oracle.exp_sigmoid if scale else None
+  ref = oracle.exp_decay_ir(gain, decay, noise, scale_fn, dtype=np.float64)
+  np.testing.assert_allclose(ir, ref, rtol=2e-5, atol=1e-7)
+  g = rng.standard_normal((b, l)).astype(np.float32)
+  nbytes = lib.ddsp_exp_decay_ir_backward_workspace_bytes(b, l)
+  ws = np.zeros(nbytes // 8 + 2, np.float64)
+  off = (-ws.ctypes.data) % 16
+  gg, gd = np.full((b, 1), np.nan, np.float32), np.full((b, 1), np.nan, np.float32)
+  rc = lib.ddsp_exp_decay_ir_backward_f32(emu.ptr(gain), emu.ptr(decay), emu.ptr(noise), emu.ptr(g), emu.ptr(gg),
+                                          emu.ptr(gd), ws.ctypes.data + off, nbytes, b, l, flags, None)
+  assert rc == 0
+  ref_g, ref_d = oracle.exp_decay_ir_backward(gain, decay, noise, g, scale_fn)
+  np.testing.assert_allclose(gg, ref_g, rtol=1e-4, atol=1e-5 * np.abs(ref_g).max() + 1e-12)
+  np.testing.assert_allclose(gd, ref_d, rtol=1e-4, atol=1e-5 * np.abs(ref_d).max() + 1e-12)
+
+
+@pytest.mark.parametrize('name', ['exp_decay_reverb_b3', 'exp_decay_reverb_trainable'])
+def test_exp_decay_ir_golden(lib, name):
+  g = load_golden(name)
+  gain, decay, noise = emu.f32(g['gain'].reshape(-1)), emu.f32(g['decay'].reshape(-1)), emu.f32(g['noise'])
+  b, l = gain.size, noise.shape[1]
+  ir = np.full((b, l), np.nan, np.float32)
+  assert lib.ddsp_exp_decay_ir_f32(emu.ptr(gain), emu.ptr(decay), emu.ptr(noise), emu.ptr(ir), b, l,
+                                   _lib.DECAY_SCALE_EXP_SIGMOID, None) == 0
+  np.testing.assert_allclose(np.broadcast_to(ir, g['ir'].shape), g['ir'], rtol=2e-5, atol=1e-7)

@@ -64,6 +64,33 @@ class _HostLib:
     start = (l - 1) // 2 - 1 if delay < 0 else delay
     return self._emu.ddsp_fft_convolve_f32(audio, ir, out, b, bir, f, l, n, n, max(start, 0), stream)
 
+  def ddsp_uniform_noise_f32(self, out, b, n, seed, batch_offset, stream):
+    self.calls.append('ddsp_uniform_noise_f32')
+    _view(out, (b, n))[:] = O.device_uniform_noise(b, n, seed=seed, batch_offset=batch_offset)
+    return 0
+
+  def ddsp_fft_convolve_long_ex_workspace_bytes(self, b, bir, n, l, n_out, delay):
+    return 64
+
+  def ddsp_fft_convolve_long_ex_f32(self, audio, ir, out, ws, ws_bytes, b, bir, n, l, n_out, delay, flags, stream):
+    """out[b][k] = y[k + delay], y = the full linear convolution (include/ddsp_amd.h), in fp64."""
+    self.calls.append('ddsp_fft_convolve_long_ex_f32')
+    a = _view(audio, (b, n)).astype(np.float64)
+    h = np.broadcast_to(_view(ir, (bir, l)).astype(np.float64), (b, l)).copy()
+    if flags & _lib.CONV_REVERSE_AUDIO:
+      a = a[:, ::-1]
+    if flags & _lib.CONV_REVERSE_IR:
+      h = h[:, ::-1]
+    if flags & _lib.CONV_MASK_TAP0:
+      h[:, 0] = 0.0
+    o = _view(out, (b, n_out))
+    for row in range(b):
+      y = np.concatenate([np.convolve(a[row], h[row]), np.zeros(delay + n_out)])[delay:delay + n_out]
+      if flags & _lib.CONV_ADD_DRY:
+        y = y + a[row]
+      o[row] = y[::-1] if flags & _lib.CONV_REVERSE_OUT else y
+    return 0
+
   def ddsp_resample_f32(self, x, out, b, f, n, c, window, stream):
     self.calls.append('ddsp_resample_f32')
     return self._emu.ddsp_resample_ex_f32(x, out, b, f, n, c, 3 if window else 1, 1, stream)
@@ -186,3 +213,47 @@ def test_harmonic_f0_gradient_glue(host):
   grads = synths._HarmonicFunction.backward(_Ctx, torch.tensor(g), None, None)
   assert grads[0] is None and grads[1] is None and grads[3:] == (None, None, None)
   np.testing.assert_allclose(npy(grads[2]), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
+# ---- effects.ExpDecayReverb (ddsp/effects.py:120-199; effects_test.py:96-110) --------------------------------
+def test_exp_decay_reverb_glue(host):
+  from ddsp_amd import effects
+  rng = np.random.default_rng(4)
+  b, n, l = 3, 400, 100
+  audio = rng.standard_normal((b, n)).astype(np.float32)
+  gain = rng.standard_normal((b, 1)).astype(np.float32)
+  decay = rng.uniform(-1.0, 2.0, (b, 1)).astype(np.float32)
+  noise = rng.uniform(-1.0, 1.0, (1, l)).astype(np.float32)
+  rev = effects.ExpDecayReverb(trainable=False, reverb_length=l)
+  with pytest.raises(ValueError, match='gain'):                      # test_non_trainable_raises_value_error
+    rev(audio)
+  out = rev(audio, gain, decay, noise=noise, return_outputs_dict=True)
+  assert sorted(out['controls']) == ['audio', 'ir']                  # test_get_controls_returns_correct_keys
+  ir_ref = O.exp_decay_ir(gain, decay, noise, dtype=np.float64)
+  np.testing.assert_allclose(npy(out['controls']['ir']), ir_ref, rtol=2e-5, atol=1e-7)
+  np.testing.assert_allclose(npy(out['signal']), O.reverb(audio, ir_ref, add_dry=True, dtype=np.float64),
+                             rtol=0, atol=2e-5)
+  # generated burst: one Philox row of reverb_length samples, a new one per call
+  host.calls.clear()
+  y1, y2 = rev(audio, gain, decay), rev(audio, gain, decay)
+  assert tuple(y1.shape) == (b, n) and host.calls.count('ddsp_uniform_noise_f32') == 2
+  assert float((y1 - y2).abs().max()) > 0
+  burst = O.device_uniform_noise(1, l, seed=0 | (0 << 32))
+  ir0 = O.exp_decay_ir(gain, decay, burst, dtype=np.float64)
+  np.testing.assert_allclose(npy(y1), O.reverb(audio, ir0, add_dry=True, dtype=np.float64), rtol=0, atol=2e-5)
+  # trainable: gain 2.0 / decay 4.0 (effects.py:158-168), one IR tiled over the batch
+  trev = effects.ExpDecayReverb(trainable=True, reverb_length=l, add_dry=False)
+  ctl = trev.get_controls(torch.tensor(audio), noise=noise)
+  assert tuple(ctl['ir'].shape) == (1, l) and float(trev._gain) == 2.0 and float(trev._decay) == 4.0
+  ir_t = O.exp_decay_ir(np.full((1, 1), 2.0), np.full((1, 1), 4.0), noise, dtype=np.float64)
+  np.testing.assert_allclose(npy(trev.get_signal(**ctl)), O.reverb(audio, ir_t, add_dry=False, dtype=np.float64),
+                             rtol=0, atol=2e-5)
+  # gradients with respect to gain and decay, through the reverb's own autograd node
+  tg = torch.tensor(gain, requires_grad=True)
+  td = torch.tensor(decay, requires_grad=True)
+  g_out = rng.standard_normal((b, n)).astype(np.float32)
+  rev(audio, tg, td, noise=noise).backward(torch.tensor(g_out))
+  g_ir = O.reverb_backward(audio, ir_ref, g_out, add_dry=True)[1]
+  ref_g, ref_d = O.exp_decay_ir_backward(gain, decay, noise, g_ir)
+  np.testing.assert_allclose(npy(tg.grad), ref_g, rtol=1e-3, atol=1e-4 * np.abs(ref_g).max())
+  np.testing.assert_allclose(npy(td.grad), ref_d, rtol=1e-3, atol=1e-4 * np.abs(ref_d).max())

@@ -233,3 +233,49 @@ def test_harmonic_f0_gradient_descends_towards_a_target_pitch(ddsp):
     predicted = float(loss) - eps * float((grad ** 2).sum())
   assert float(stepped) < float(loss)
   assert abs(float(stepped) - predicted) <= 0.2 * abs(float(loss) - predicted)
+
+
+# ---- effects.ExpDecayReverb (ddsp/effects.py:120-199; effects_test.py:96-110) ---------------------------------------
+@pytest.mark.parametrize('name', ['exp_decay_reverb_b3', 'exp_decay_reverb_trainable'])
+def test_exp_decay_reverb_golden(ddsp, name):
+  g = load_golden(name)
+  l = g['noise'].shape[1]
+  rev = ddsp.effects.ExpDecayReverb(trainable=bool(g['trainable']), reverb_length=l, add_dry=bool(g['add_dry']))
+  if int(g['trainable']):
+    out = rev(g['audio'], noise=g['noise'], return_outputs_dict=True)
+    assert float(rev._gain) == 2.0 and float(rev._decay) == 4.0           # effects.py:158-168
+  else:
+    out = rev(g['audio'], g['gain'], g['decay'], noise=g['noise'], return_outputs_dict=True)
+  assert sorted(out['controls']) == ['audio', 'ir']
+  np.testing.assert_allclose(np.broadcast_to(npy(out['controls']['ir']), g['ir'].shape), g['ir'], rtol=2e-5, atol=1e-7)
+  np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=2e-6 + 1e-5 * np.abs(g['signal']).max())
+
+
+def test_exp_decay_reverb_reference_tests_and_gradients(ddsp):
+  rng = np.random.default_rng(14)
+  b, n, l = 3, 16000, 4800
+  audio = rng.standard_normal((b, n)).astype(np.float32)
+  gain = rng.standard_normal((b, 1)).astype(np.float32)
+  decay = rng.uniform(-1.0, 3.0, (b, 1)).astype(np.float32)
+  rev = ddsp.effects.ExpDecayReverb(trainable=False, reverb_length=l)
+  with pytest.raises(ValueError, match='gain'):                      # test_non_trainable_raises_value_error
+    rev(audio)
+  y1, y2 = rev(audio, gain, decay), rev(audio, gain, decay)          # a fresh burst per call, as the reference
+  assert tuple(y1.shape) == (b, n) and float((y1 - y2).abs().max()) > 0
+  burst = O.device_uniform_noise(1, l, seed=0)
+  ir0 = O.exp_decay_ir(gain, decay, burst, dtype=np.float64)
+  ref = O.reverb_direct(audio, ir0, add_dry=True)
+  np.testing.assert_allclose(npy(y1), ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max())
+  trev = ddsp.effects.ExpDecayReverb(trainable=True, reverb_length=100)          # effects_test.py:31-47
+  assert tuple(trev(np.zeros((3, 16000), np.float32)).shape) == (3, 16000) and trev.trainable
+  # dL/d gain, dL/d decay through the reverb's own autograd node
+  noise = rng.uniform(-1.0, 1.0, (1, l)).astype(np.float32)
+  tg = torch.tensor(gain, device='cuda', requires_grad=True)
+  td = torch.tensor(decay, device='cuda', requires_grad=True)
+  g_out = rng.standard_normal((b, n)).astype(np.float32)
+  rev(audio, tg, td, noise=noise).backward(torch.tensor(g_out, device='cuda'))
+  ir_ref = O.exp_decay_ir(gain, decay, noise, dtype=np.float64)
+  g_ir = O.reverb_backward(audio, ir_ref, g_out, add_dry=True)[1]
+  ref_g, ref_d = O.exp_decay_ir_backward(gain, decay, noise, g_ir)
+  np.testing.assert_allclose(npy(tg.grad), ref_g, rtol=0, atol=2e-4 * np.abs(ref_g).max())
+  np.testing.assert_allclose(npy(td.grad), ref_d, rtol=0, atol=2e-4 * np.abs(ref_d).max())

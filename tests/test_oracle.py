@@ -443,3 +443,28 @@ def test_harmonic_with_cubic_envelope_matches_reference_source():
   sig = O.harmonic_get_signal(c['amplitudes'], c['harmonic_distribution'], c['f0_hz'], int(g['n_samples']),
                               int(g['sample_rate']), str(g['amp_method']), bool(g['angular']))
   np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=2e-6)
+
+
+def test_exp_decay_ir_backward_matches_finite_differences():        # effects.py:144-151
+  rng = np.random.default_rng(17)
+  b, l = 2, 300
+  gain, decay = rng.standard_normal((b, 1)), rng.uniform(-1.0, 2.0, (b, 1))
+  noise, g = rng.uniform(-1, 1, (1, l)), rng.standard_normal((b, l))
+  loss = lambda ga, de: float(np.sum(O.exp_decay_ir(ga, de, noise, dtype=np.float64) * g))
+  gg, gd = O.exp_decay_ir_backward(gain, decay, noise, g)
+  eps = 1e-6
+  for i in range(b):
+    e = np.zeros((b, 1)); e[i] = eps
+    assert abs((loss(gain + e, decay) - loss(gain - e, decay)) / (2 * eps) - gg[i, 0]) <= 1e-6 * max(1, abs(gg[i, 0]))
+    assert abs((loss(gain, decay + e) - loss(gain, decay - e)) / (2 * eps) - gd[i, 0]) <= 1e-6 * max(1, abs(gd[i, 0]))
+  ir = O.exp_decay_ir(np.full((1, 1), 2.0), np.full((1, 1), 4.0), np.ones((1, l)))      # the trainable initial values
+  assert ir.shape == (1, l) and ir[0, 0] > ir[0, 1] > ir[0, -1] > 0                      # effects.py:158-168
+
+
+@pytest.mark.parametrize('name', ['exp_decay_reverb_b3', 'exp_decay_reverb_trainable'])
+def test_exp_decay_reverb_matches_reference_source(name):          # effects.py:120-199
+  g = load_golden(name)
+  ir = O.exp_decay_ir(g['gain'].reshape(-1, 1), g['decay'].reshape(-1, 1), g['noise'])
+  np.testing.assert_allclose(np.broadcast_to(ir, g['ir'].shape), g['ir'], rtol=2e-6, atol=1e-9)
+  sig = O.reverb(g['audio'], ir, add_dry=bool(g['add_dry']))
+  np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=1e-5)
