@@ -60,6 +60,9 @@ def parse_args():
                   help='after the timed region, run K more steps in the other stream mode and report '
                        'them as other_issue_mode (off by default so that a rocprofv3 trace of the '
                        'default command sees one mode only)')
+  ap.add_argument('--no-aux', action='store_true',
+                  help='skip the auxiliary yardsticks after the timed region (measured device-copy bandwidth, '
+                       'the f0 = 200 Hz regime of SURVEY.md 8d)')
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
   return ap.parse_args()
@@ -228,6 +231,50 @@ def main():
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       alt_elapsed = float(t.item())
 
+  # ---- auxiliary yardsticks (untimed for the headline; a failure here never costs the JSON line) ----
+  aux = {}
+  if not a.no_aux:
+    try:
+      # (i) SURVEY.md 8(d): the fraction is quoted against the 8 TB/s spec peak; the device-to-device copy
+      # rate measured in the same run says what this box's HBM actually sustains (read + write counted)
+      src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device='cuda').normal_()
+      dst = torch.empty_like(src)
+      for _ in range(3):
+        dst.copy_(src)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(10):
+        dst.copy_(src)
+      e1.record()
+      torch.cuda.synchronize()
+      aux['measured_copy_GBs'] = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+      del src, dst
+      # (ii) SURVEY.md 8(d)'s second f0 regime: "test-like" f0 = 200 + N(0,1) Hz (processors_test.py:40),
+      # 39 of 100 harmonics below Nyquist; same step, same stream mode, a fifth of the steps
+      x200 = make_inputs(B, a, seed=2000 + rank)
+      x200['f0_hz'] = (200.0 + (x200['f0_hz'] - a.f0)).astype(np.float32)
+      dev200 = {k: ddsp.core.tf_float32(v) for k, v in x200.items()}
+      dev_headline = dict(dev)
+      k200 = max(a.steps // 5, 10)
+      dev.update(dev200)
+      for _ in range(20):
+        step()
+      sync_all()
+      t200 = time.perf_counter()
+      for _ in range(k200):
+        step()
+      sync_all()
+      dt200 = time.perf_counter() - t200
+      dev.update(dev_headline)
+      if world > 1:
+        t = torch.tensor([dt200], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt200 = float(t.item())
+      aux['f0_200_regime'] = {'ms_per_step': dt200 / k200 * 1e3, 'steps': k200,
+                              'value': world * B * a.n_samples * k200 / dt200 / 1e6}
+    except Exception as exc:                      # noqa: BLE001 - diagnostics only
+      aux['error'] = repr(exc)
+
   gather_ms = None
   if a.allgather and world > 1:
     h = out[0]
@@ -297,6 +344,13 @@ def main():
                                             FP32_VECTOR_PEAK_TFLOPS}},
         'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
     }
+    if 'measured_copy_GBs' in aux:
+      result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
+      result['roofline']['frac_of_measured_copy'] = achieved / aux['measured_copy_GBs']
+    if 'f0_200_regime' in aux:
+      result['f0_200_regime'] = aux['f0_200_regime']
+    if 'error' in aux:
+      result['aux_error'] = aux['error']
     if alt_elapsed is not None:
       result['other_issue_mode'] = {
           'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',

@@ -16,11 +16,11 @@ timeout 600 python bench.py --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b3
 echo "== bench (batch 128)"
 timeout 600 python bench.py --batch 128 --no-cpu-baseline --also-other-mode 2>&1 | tail -3 | tee $OUT/bench_b128.json
 echo "== rocprofv3 kernel trace"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-aux > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 ls -R $OUT/prof | head -20
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -2); do echo "--- $f"; head -15 $f; done
 echo "== rocprofv3 kernel trace, batch 128 (north-star shape: one stream, harm_table_kernel dominant)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --no-cpu-baseline --no-aux > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
 for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do echo "--- $f"; head -8 $f | cut -c1-220; done
 echo "== Harmonic: wavetable kernel vs direct sum, and the wavetable kernel's per-tick timeline"
 timeout 120 python tools/exp_table.py 32 128 2>&1 | tail -2 | tee $OUT/harm_table_vs_direct.json
