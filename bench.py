@@ -118,6 +118,90 @@ def cpu_baseline(a):
                 (a.cpu_clips, a.n_samples, a.n_harmonics, a.n_bands, dt, os.cpu_count())}
 
 
+def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=None, alt_elapsed=None,
+                 gather_ms=None, cpu_baseline_fn=None):
+  """The JSON line of the bench contract from the measured quantities (pure: unit-tested on the CPU).
+
+  elapsed: seconds for a.steps steps, max over ranks; prof / breakdown: {kernel: (total_ms, launches)} of the
+  timed region's sampled dispatch events / of the untimed single-stream diagnostic pass."""
+  aux = aux or {}
+  cpu_baseline_fn = cpu_baseline_fn or cpu_baseline
+  total_samples = world * B * a.n_samples * a.steps
+  value = total_samples / elapsed / 1e6
+  harm_bytes, noise_bytes = algorithmic_bytes(a, B)
+  dom_ms, dom_n = prof[dominant]
+  dom_avg_s = dom_ms / dom_n * 1e-3
+  # algorithmic bytes of the launch = those of the Processor the kernel belongs to
+  dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes   # its Processor's bytes
+  achieved = dom_bytes / dom_avg_s / 1e9
+  traffic = None
+  for tname in ('pmc_traffic_b%d.json' % B, 'pmc_traffic.json'):     # PMC passes are per batch size
+    tpath = os.path.join(ROOT, 'profiles', tname)
+    if traffic is None and os.path.exists(tpath):
+      try:
+        rec = json.load(open(tpath))
+        if rec.get('batch') == B:
+          traffic = rec.get('kernels', {}).get(dominant)
+      except (ValueError, OSError):
+        traffic = None
+  step_bytes = harm_bytes + noise_bytes
+  harm_flops, noise_flops = algorithmic_flops(a, B)
+  dom_flops = harm_flops if dominant.startswith('harm') else noise_flops
+  result = {
+      'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
+      'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': a.steps,
+      'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {
+          'workload': 'BASELINE configs[1]: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
+                      '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
+                      'controls in (get_controls fused), noise generated on chip' %
+                      (B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
+          'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
+          'no collective' % world,
+          'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
+                     else 'one stream, back to back'},
+      'roofline': {
+          'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+          'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': dom_avg_s * 1e6,
+          'launches': dom_n, 'event_stride': a.event_stride,
+          'timing': 'dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
+                    'every event_stride-th launch inside the timed region',
+          'whole_step': {'algorithmic_bytes': step_bytes,
+                         'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
+                         'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
+          # the path sits above the fp32 ridge point (SURVEY.md F6): the vector-ALU ceiling beside the
+          # HBM fraction, on the reference formulation's flop count (the wavetable kernel does fewer)
+          'alu_note': {'algorithmic_flop_per_launch': dom_flops,
+                       'achieved_TFLOPs': dom_flops / dom_avg_s / 1e12,
+                       'peak_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
+                       'frac': dom_flops / dom_avg_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                       'whole_step_frac': (harm_flops + noise_flops) / (elapsed / a.steps) / 1e12 /
+                                          FP32_VECTOR_PEAK_TFLOPS}},
+      'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
+  }
+  if 'measured_copy_GBs' in aux:
+    result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
+    result['roofline']['frac_of_measured_copy'] = achieved / aux['measured_copy_GBs']
+  if 'f0_200_regime' in aux:
+    result['f0_200_regime'] = aux['f0_200_regime']
+  if 'error' in aux:
+    result['aux_error'] = aux['error']
+  if alt_elapsed is not None:
+    result['other_issue_mode'] = {
+        'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',
+        'ms_per_step': alt_elapsed / a.steps * 1e3,
+        'value': world * B * a.n_samples * a.steps / alt_elapsed / 1e6}
+  if gather_ms is not None:
+    result['allgather_ms'] = gather_ms
+  if not a.no_cpu_baseline and world == 1:
+    result['cpu_baseline'] = cpu_baseline_fn(a)
+  elif not a.no_cpu_baseline:
+    result['cpu_baseline'] = None     # rank 0 at N=1 only (bench contract)
+  return result
+
+
 def main():
   a = parse_args()
   import torch
@@ -289,79 +373,7 @@ def main():
     gather_ms = (time.perf_counter() - t1) / 10 * 1e3
 
   if rank == 0:
-    total_samples = world * B * a.n_samples * a.steps
-    value = total_samples / elapsed / 1e6
-    harm_bytes, noise_bytes = algorithmic_bytes(a, B)
-    dom_ms, dom_n = prof[dominant]
-    dom_avg_s = dom_ms / dom_n * 1e-3
-    # algorithmic bytes of the launch = those of the Processor the kernel belongs to
-    dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes   # its Processor's bytes
-    achieved = dom_bytes / dom_avg_s / 1e9
-    traffic = None
-    for tname in ('pmc_traffic_b%d.json' % B, 'pmc_traffic.json'):     # PMC passes are per batch size
-      tpath = os.path.join(ROOT, 'profiles', tname)
-      if traffic is None and os.path.exists(tpath):
-        try:
-          rec = json.load(open(tpath))
-          if rec.get('batch') == B:
-            traffic = rec.get('kernels', {}).get(dominant)
-        except (ValueError, OSError):
-          traffic = None
-    step_bytes = harm_bytes + noise_bytes
-    harm_flops, noise_flops = algorithmic_flops(a, B)
-    dom_flops = harm_flops if dominant.startswith('harm') else noise_flops
-    result = {
-        'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
-        'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': a.steps,
-        'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {
-            'workload': 'BASELINE configs[1]: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
-                        '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
-                        'controls in (get_controls fused), noise generated on chip' %
-                        (B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
-            'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
-            'no collective' % world,
-            'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
-                       else 'one stream, back to back'},
-        'roofline': {
-            'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-            'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': dom_avg_s * 1e6,
-            'launches': dom_n, 'event_stride': a.event_stride,
-            'timing': 'dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
-                      'every event_stride-th launch inside the timed region',
-            'whole_step': {'algorithmic_bytes': step_bytes,
-                           'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
-                           'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
-            # the path sits above the fp32 ridge point: the vector-ALU ceiling beside the
-            # HBM fraction, on the reference formulation's flop count (the wavetable kernel does fewer)
-            'alu_note': {'algorithmic_flop_per_launch': dom_flops,
-                         'achieved_TFLOPs': dom_flops / dom_avg_s / 1e12,
-                         'peak_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
-                         'frac': dom_flops / dom_avg_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                         'whole_step_frac': (harm_flops + noise_flops) / (elapsed / a.steps) / 1e12 /
-                                            FP32_VECTOR_PEAK_TFLOPS}},
-        'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
-    }
-    if 'measured_copy_GBs' in aux:
-      result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
-      result['roofline']['frac_of_measured_copy'] = achieved / aux['measured_copy_GBs']
-    if 'f0_200_regime' in aux:
-      result['f0_200_regime'] = aux['f0_200_regime']
-    if 'error' in aux:
-      result['aux_error'] = aux['error']
-    if alt_elapsed is not None:
-      result['other_issue_mode'] = {
-          'streams': 'one stream, back to back' if overlap else 'two free-running HIP streams',
-          'ms_per_step': alt_elapsed / a.steps * 1e3,
-          'value': world * B * a.n_samples * a.steps / alt_elapsed / 1e6}
-    if gather_ms is not None:
-      result['allgather_ms'] = gather_ms
-    if not a.no_cpu_baseline and world == 1:
-      result['cpu_baseline'] = cpu_baseline(a)
-    elif not a.no_cpu_baseline:
-      result['cpu_baseline'] = None     # rank 0 at N=1 only (bench contract)
+    result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms)
     print(json.dumps(result), flush=True)
 
   if world > 1:

@@ -1,0 +1,172 @@
+"""CPU checks of bench.py's JSON line (the driver's contract): build_result() is pure, so the fields, the
+roofline arithmetic and the optional blocks are exercised here on the numbers of profiles/r01_bench_*.json;
+parse_args() defaults must describe BASELINE.json configs[1]."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def bench():
+  spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def _args(bench, *argv):
+  old = sys.argv
+  sys.argv = ['bench.py'] + list(argv)
+  try:
+    return bench.parse_args()
+  finally:
+    sys.argv = old
+
+
+def test_defaults_are_baseline_config_1(bench):
+  a = _args(bench)
+  assert (a.gpus, a.batch, a.n_frames, a.n_harmonics, a.n_bands, a.n_samples, a.sample_rate) == (
+      1, 32, 1000, 100, 65, 64000, 16000)
+  assert a.f0 == 70.0 and a.steps > 0 and a.warmup > 0
+  # 664 000 + 516 000 bytes per clip
+  assert bench.algorithmic_bytes(a, 1) == (664000, 516000)
+  assert bench.algorithmic_bytes(a, 128)[0] + bench.algorithmic_bytes(a, 128)[1] == 151040000
+  harm_flops, noise_flops = bench.algorithmic_flops(a, 1)
+  assert harm_flops == 64000 * 3 * 100 * 2 and noise_flops == 64000 * 2 * 128
+
+
+@pytest.mark.parametrize('world,batch,dominant', [(1, 32, 'noise_fused65_kernel'), (8, 128, 'harm_table_kernel')])
+def test_json_line_fields_and_roofline_arithmetic(bench, world, batch, dominant):
+  a = _args(bench, '--gpus', str(world), '--batch', str(batch), '--steps', '1000', '--warmup', '500')
+  elapsed = 0.0368 if batch == 32 else 0.1172                       # seconds for 1000 steps (profiles/r01_bench_*)
+  launch_us = 31.0 if batch == 32 else 59.96
+  prof = {dominant: (launch_us * 125 * 1e-3, 125)}
+  breakdown = {'noise_fused65_kernel': (0.0247 * 3, 3), 'harm_table_kernel': (0.0204 * 3, 3)}
+  aux = {'measured_copy_GBs': 4000.0, 'f0_200_regime': {'ms_per_step': 0.03, 'steps': 200, 'value': 1.0}}
+  r = bench.build_result(a, world, batch, elapsed, prof, breakdown, dominant, overlap=batch < 64, aux=aux,
+                         alt_elapsed=0.05, gather_ms=0.4 if world > 1 else None,
+                         cpu_baseline_fn=lambda args: {'value': 0.77, 'unit': 'Msamples/s', 'cores': 1,
+                                                       'kind': 'port', 'sample': 'stub'})
+  line = json.loads(json.dumps(r))                                   # serialisable, one line
+  for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert key in line, key
+  assert line['unit'] == 'Msamples/s' and line['higher_is_better'] is True and line['scaling'] == 'weak'
+  assert line['vs_baseline'] is None and line['dtype'] == 'f32' and line['data'] == 'synthetic'
+  assert line['n_gpus'] == world and line['steps'] == 1000 and line['warmup'] == 500
+  assert 'model' not in line['config'] and 'workload' in line['config']
+  assert line['config']['global_batch'] == world * batch
+  # whole-job aggregate: every rank's samples over the max-over-ranks time
+  assert line['value'] == pytest.approx(world * batch * 64000 * 1000 / elapsed / 1e6)
+  assert line['ms_per_step'] == pytest.approx(elapsed)
+  roof = line['roofline']
+  per_clip = 664000 if dominant.startswith('harm') else 516000
+  assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+  assert roof['achieved'] == pytest.approx(per_clip * batch / (launch_us * 1e-6) / 1e9)
+  assert roof['frac'] == pytest.approx(roof['achieved'] / 8000.0)
+  assert roof['frac_of_measured_copy'] == pytest.approx(roof['achieved'] / 4000.0)
+  assert 0 < roof['alu_note']['frac'] < 1 and 0 < roof['alu_note']['whole_step_frac'] < 1
+  assert roof['traffic'] is None or roof['traffic'] > 0
+  assert line['f0_200_regime']['steps'] == 200 and line['other_issue_mode']['value'] > 0
+  if world == 1:
+    assert line['cpu_baseline']['kind'] == 'port' and 'allgather_ms' not in line
+  else:
+    assert line['cpu_baseline'] is None and line['allgather_ms'] == 0.4       # rank 0 at N=1 only
+
+
+def test_minimal_call_without_optional_blocks(bench):
+  a = _args(bench, '--no-cpu-baseline')
+  r = bench.build_result(a, 1, 32, 0.04, {'harm_table_kernel': (2.0, 100)}, {'harm_table_kernel': (0.06, 3)},
+                         'harm_table_kernel', overlap=True)
+  assert 'cpu_baseline' not in r and 'other_issue_mode' not in r and 'f0_200_regime' not in r
+  assert 'measured_copy_GBs' not in r['roofline']
+  json.dumps(r)
+
+
+def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
+  """bench.main() end to end with every device call replaced by a stand-in: guards the control flow of the
+  timed region, the auxiliary yardsticks and the JSON print against NameErrors / TypeErrors that would only
+  show at round end on the GPU box.  No kernel runs and no number printed here means anything."""
+  import numpy as np
+  import torch
+  import ddsp_amd
+  from ddsp_amd import _lib, build
+
+  class _Stream:
+    pass
+
+  class _Event:
+    def __init__(self, enable_timing=False):
+      pass
+
+    def record(self):
+      pass
+
+    def elapsed_time(self, other):
+      return 1.0
+
+  calls = {'harm': 0, 'noise': 0, 'begin': 0}
+  monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+  monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
+  monkeypatch.setattr(torch.cuda, 'Stream', _Stream)
+  monkeypatch.setattr(torch.cuda, 'Event', _Event)
+  monkeypatch.setattr(torch.cuda, 'current_stream', lambda: _Stream())
+  monkeypatch.setattr(torch.cuda, 'set_stream', lambda s: None)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda: None)
+  real_empty = torch.empty
+  monkeypatch.setattr(torch, 'empty', lambda *a, device=None, **k: real_empty(*a, **k))
+  monkeypatch.setattr(build, 'build', lambda *a, **k: None)
+  monkeypatch.setattr(_lib, 'load', lambda: None)
+
+  def fake_begin(names, max_records=0, stride=1):
+    calls['begin'] += 1
+    calls['names'] = names
+
+  def fake_end():
+    if calls['names'] is None:       # the diagnostic pass: every kernel
+      return {'harm_table_kernel': (0.06, 3), 'noise_fused65_kernel': (0.075, 3)}
+    return {calls['names'][0]: (3.1, 100)}
+  monkeypatch.setattr(_lib, 'profile_begin', fake_begin)
+  monkeypatch.setattr(_lib, 'profile_end', fake_end)
+  monkeypatch.setattr(ddsp_amd.core, 'tf_float32', lambda x: torch.as_tensor(np.asarray(x, np.float32)))
+
+  class _Harmonic:
+    def __init__(self, n_samples, sample_rate):
+      self.n = n_samples
+
+    def __call__(self, amplitudes, harmonic_distribution, f0_hz):
+      calls['harm'] += 1
+      calls['last_f0'] = float(f0_hz.mean())
+      return torch.zeros(amplitudes.shape[0], self.n)
+
+  class _Noise:
+    def __init__(self, n_samples, window_size, seed):
+      self.n = n_samples
+
+    def __call__(self, magnitudes):
+      calls['noise'] += 1
+      return torch.zeros(magnitudes.shape[0], self.n)
+  monkeypatch.setattr(ddsp_amd.synths, 'Harmonic', _Harmonic)
+  monkeypatch.setattr(ddsp_amd.synths, 'FilteredNoise', _Noise)
+  monkeypatch.setattr(bench, 'cpu_baseline', lambda a: {'value': 1.0, 'unit': 'Msamples/s', 'cores': 1,
+                                                        'kind': 'port', 'sample': 'stub'})
+  monkeypatch.setenv('WORLD_SIZE', '1')
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '7', '--warmup', '2', '--batch', '2', '--n-frames', '10',
+                                    '--n-samples', '640', '--also-other-mode'])
+  bench.main()
+  out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')]
+  assert len(out) == 1                                               # ONE JSON line
+  line = json.loads(out[0])
+  assert line['steps'] == 7 and line['warmup'] == 2 and line['n_gpus'] == 1
+  assert line['roofline']['kernel'] == 'noise_fused65_kernel'         # the larger isolated time above
+  assert 'aux_error' not in line, line.get('aux_error')
+  assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 10
+  assert line['cpu_baseline']['kind'] == 'port' and 'other_issue_mode' in line
+  assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
+  assert abs(calls['last_f0'] - 200.0) < 2.0                           # the last steps ran the f0 = 200 regime...
+  # ...and the headline inputs were put back afterwards (nothing after the regime reads them, but a later edit might)
