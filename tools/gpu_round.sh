@@ -36,3 +36,5 @@ timeout 300 python tools/bench_backward.py 128 2>&1 | tail -1 | tee $OUT/bench_b
 echo "== rocprofv3 kernel trace of the training step (synths + loss, forward + backward)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_train -o trace -- python $GRAFT_REPO_ROOT/tools/bench_backward.py 32 > $GRAFT_REPO_ROOT/$OUT/rocprof_train.log 2>&1 )
 for f in $(find $OUT/prof_train -name "*kernel_stats*.csv" | head -1); do echo "--- $f"; head -20 $f | cut -c1-200; done
+echo "== streaming latency (VST frame call)"
+timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json
