@@ -16,7 +16,8 @@ The JSON line also carries
                  with HIP events on the launch stream during the timed region (ddsp_profile_*),
                  against the 8 TB/s HBM peak (the path is in fact ALU-bound).
   cpu_baseline : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
-                 here) timed on this host on a bounded sample of the same workload.
+                 here) timed on this host's cores (concurrent worker processes) on a bounded
+                 sample of the same workload.
 """
 import argparse
 import json
@@ -45,7 +46,9 @@ def parse_args():
   ap.add_argument('--n-samples', type=int, default=64000)
   ap.add_argument('--sample-rate', type=int, default=16000)
   ap.add_argument('--f0', type=float, default=70.0, help='f0 centre in Hz (70: all harmonics live)')
-  ap.add_argument('--cpu-clips', type=int, default=12, help='clips timed by the CPU oracle leg')
+  ap.add_argument('--cpu-clips', type=int, default=6, help='clips per worker process of the CPU oracle leg')
+  ap.add_argument('--cpu-procs', type=int, default=0,
+                  help='worker processes of the CPU oracle leg (0: the logical CPUs, at most 32)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--event-stride', type=int, default=8,
                   help='bracket every n-th launch of the dominant kernel with HIP events inside the '
@@ -97,25 +100,13 @@ def algorithmic_flops(a, batch):
 
 
 def cpu_baseline(a):
-  """The oracle (numpy, fp32, op by op as TF executes it) on `cpu_clips` clips, one at a time."""
-  from oracle import ddsp_oracle as O
-  x = make_inputs(a.cpu_clips, a, seed=123)
-  rng = np.random.default_rng(5)
-  t0 = time.perf_counter()
-  for i in range(a.cpu_clips):
-    s = slice(i, i + 1)
-    O.harmonic(x['amplitudes'][s], x['harmonic_distribution'][s], x['f0_hz'][s], a.n_samples,
-               a.sample_rate)
-    noise = rng.uniform(-1, 1, (1, a.n_samples)).astype(np.float32)   # tf.random.uniform stand-in
-    O.filtered_noise(x['magnitudes'][s], noise, 0)
-  dt = time.perf_counter() - t0
-  return {
-      'value': a.cpu_clips * a.n_samples / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1,
-      'kind': 'port',
-      'sample': '%d clip(s) of the same workload (B=1 each, %d samples, K=%d, M=%d) through '
-                'oracle/ddsp_oracle.py (numpy fp32 restatement of the TF op chain; TF is not '
-                'installable here), %.1f s wall, host has %d logical CPUs' %
-                (a.cpu_clips, a.n_samples, a.n_harmonics, a.n_bands, dt, os.cpu_count())}
+  """The oracle (numpy, fp32, op by op as TF executes it) on the host's cores: oracle/cpu_baseline.py runs
+  `cpu_procs` concurrent worker processes of `cpu_clips` clips each (TF's CPU kernels are multi-threaded;
+  `cores` = the workers actually used, the one-process figure is reported beside it)."""
+  from oracle import cpu_baseline as leg
+  procs = a.cpu_procs if a.cpu_procs > 0 else leg.default_procs()
+  return leg.measure(a.cpu_clips, procs, a.n_frames, a.n_harmonics, a.n_bands, a.n_samples, a.sample_rate,
+                     a.f0)
 
 
 def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=None, alt_elapsed=None,

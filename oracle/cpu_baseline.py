@@ -1,0 +1,97 @@
+"""The CPU leg of bench.py: the numpy fp32 restatement of the TF op chain (oracle/ddsp_oracle.py) timed on the
+host's cores.  TEST / MEASUREMENT INFRASTRUCTURE - the product never imports this.
+
+One clip = synths.Harmonic + synths.FilteredNoise of BASELINE.json configs[1] (4 s @ 16 kHz, 100 harmonics,
+65 bands), op by op with the [N, K] tensors materialised as TensorFlow does.  TensorFlow's CPU kernels are
+multi-threaded, so the port is run as P concurrent worker processes (plain child interpreters, one clip at a
+time each) and `cores` reports P; the single-process figure is kept beside it."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+
+def _make_inputs(n_clips, n_frames, n_harmonics, n_bands, f0, seed):
+  rng = np.random.default_rng(seed)
+  return dict(
+      amplitudes=rng.standard_normal((n_clips, n_frames, 1)).astype(np.float32),
+      harmonic_distribution=rng.standard_normal((n_clips, n_frames, n_harmonics)).astype(np.float32),
+      f0_hz=(f0 + rng.standard_normal((n_clips, n_frames, 1))).astype(np.float32),
+      magnitudes=rng.standard_normal((n_clips, n_frames, n_bands)).astype(np.float32))
+
+
+def run_clips(n_clips, n_frames, n_harmonics, n_bands, n_samples, sample_rate, f0, seed):
+  """n_clips clips through the oracle, one at a time; returns the seconds spent in the op chain."""
+  from oracle import ddsp_oracle as O
+  x = _make_inputs(n_clips, n_frames, n_harmonics, n_bands, f0, seed)
+  rng = np.random.default_rng(seed + 1)
+  t0 = time.perf_counter()
+  for i in range(n_clips):
+    s = slice(i, i + 1)
+    O.harmonic(x['amplitudes'][s], x['harmonic_distribution'][s], x['f0_hz'][s], n_samples, sample_rate)
+    noise = rng.uniform(-1, 1, (1, n_samples)).astype(np.float32)     # tf.random.uniform stand-in
+    O.filtered_noise(x['magnitudes'][s], noise, 0)
+  return time.perf_counter() - t0
+
+
+def default_procs():
+  """Worker processes: the host's logical CPUs, capped at 32 (a clip's op chain holds ~0.4 GB of
+  materialised tensors, and numpy's elementwise passes stop scaling at memory bandwidth long before)."""
+  return max(1, min(32, os.cpu_count() or 1))
+
+
+def measure(clips_per_proc, procs, n_frames, n_harmonics, n_bands, n_samples, sample_rate, f0, timeout_s=180.0):
+  """{'value', 'unit', 'cores', 'kind', 'sample', ...}: Msamples/s of `procs` concurrent workers.
+
+  Workers are plain child interpreters (`python -m oracle.cpu_baseline ...`: no fork of a parent that holds an
+  initialised HIP runtime, no re-import of the parent's main module); each runs one warm-up clip, then reports
+  the seconds its own `clips_per_proc` clips took.  They do equal work and start together, so the throughput is
+  all their clips over the slowest worker's time.  Any failure falls back to the single-process figure."""
+  shape = (n_frames, n_harmonics, n_bands, n_samples, sample_rate, f0)
+  run_clips(1, *shape, seed=99)                                           # warm-up: imports, page faults
+  single_s = run_clips(2, *shape, seed=100) / 2.0                        # this process alone, per clip
+  single = n_samples / single_s / 1e6
+  result = {'unit': 'Msamples/s', 'kind': 'port', 'single_process_value': single}
+  value, cores, wall, note = single, 1, single_s, ''
+  if procs > 1:
+    children = []
+    try:
+      root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+      cmd = [sys.executable, '-m', 'oracle.cpu_baseline', str(clips_per_proc)] + [repr(v) for v in shape]
+      env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+      for p in range(procs):
+        children.append(subprocess.Popen(cmd + [str(300 + p)], cwd=root, env=env, stdout=subprocess.PIPE,
+                                         stderr=subprocess.DEVNULL, text=True))
+      deadline = time.monotonic() + timeout_s
+      times = []
+      for child in children:
+        out, _ = child.communicate(timeout=max(1.0, deadline - time.monotonic()))
+        if child.returncode != 0:
+          raise RuntimeError('worker exit code %d' % child.returncode)
+        times.append(float(out.strip().splitlines()[-1]))
+      wall = max(times)
+      value, cores = procs * clips_per_proc * n_samples / wall / 1e6, procs
+    except Exception as exc:                       # noqa: BLE001 - the single-process figure stands
+      note = '; workers failed (%r), single process reported' % (exc,)
+    finally:
+      for child in children:                       # our own children, by handle
+        if child.poll() is None:
+          child.kill()
+          child.wait()
+  result.update(value=value, cores=cores, sample=(
+      '%d clip(s) of the same workload (one clip = %d samples, K=%d, M=%d) through oracle/ddsp_oracle.py '
+      '(numpy fp32 restatement of the TF op chain; TF is not installable here) on %d concurrent worker '
+      'process(es), slowest worker %.1f s; one process alone: %.2f Msamples/s; host has %d logical CPUs%s' %
+      (cores * (clips_per_proc if cores > 1 else 1), n_samples, n_harmonics, n_bands, cores, wall, single,
+       os.cpu_count() or 1, note)))
+  return result
+
+
+if __name__ == '__main__':
+  # worker: python -m oracle.cpu_baseline <clips> <n_frames> <n_harmonics> <n_bands> <n_samples> <sample_rate> <f0> <seed>
+  _clips, _f, _k, _m, _n, _sr = (int(v) for v in sys.argv[1:7])
+  _f0, _seed = float(sys.argv[7]), int(sys.argv[8])
+  run_clips(1, _f, _k, _m, _n, _sr, _f0, _seed + 1000)                   # warm-up: imports, page faults
+  print(run_clips(_clips, _f, _k, _m, _n, _sr, _f0, _seed), flush=True)

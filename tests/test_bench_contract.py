@@ -170,3 +170,15 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
   assert abs(calls['last_f0'] - 200.0) < 2.0                           # the last steps ran the f0 = 200 regime...
   # ...and the headline inputs were put back afterwards (nothing after the regime reads them, but a later edit might)
+
+
+def test_cpu_baseline_leg_runs_concurrent_workers_and_falls_back(monkeypatch):
+  from oracle import cpu_baseline as leg
+  r = leg.measure(2, 2, 10, 8, 9, 640, 16000, 200.0, timeout_s=60.0)
+  assert r['kind'] == 'port' and r['unit'] == 'Msamples/s' and r['cores'] == 2
+  assert r['value'] > 0 and r['single_process_value'] > 0 and '2 concurrent worker' in r['sample']
+  assert leg.measure(1, 1, 10, 8, 9, 640, 16000, 200.0)['cores'] == 1
+  monkeypatch.setattr(leg.sys, 'executable', '/nonexistent/python')            # workers cannot start
+  r = leg.measure(1, 2, 10, 8, 9, 640, 16000, 200.0, timeout_s=10.0)
+  assert r['cores'] == 1 and r['value'] == r['single_process_value'] and 'workers failed' in r['sample']
+  assert 1 <= leg.default_procs() <= 32
