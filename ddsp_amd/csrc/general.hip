@@ -12,6 +12,7 @@
 //                                 tf.sin, ddsp/core.py:950-960; trainers.py:162-171)
 //   ddsp_exp_decay_ir_f32 (+ _backward)   effects.ExpDecayReverb's impulse response and its gradient with
 //                                 respect to gain and decay (ddsp/effects.py:120-199)
+//   ddsp_mix_f32, ddsp_sigmoid_f32        processors.Mix (ddsp/processors.py:180-233)
 //
 // These are generality paths: one thread per output value, HBM / L2 reads only, no LDS, no cross-lane
 // traffic, no inline assembly.  Their cost is irrelevant next to the fused kernels of harmonic*.hip and
@@ -349,6 +350,34 @@ __global__ __launch_bounds__(kThreads) void exp_decay_bwd_finish_kernel(
   }
 }
 
+// =====================================================================================
+// processors.Mix (ddsp/processors.py:180-233): constant-power crossfade.
+//   get_controls: mix_level = sigmoid(nn_out_mix_level) (then core.resample to the signals' length)
+//   get_signal:   out = sqrt(|m|) * signal_one + (1 - sqrt(|m - 1|)) * signal_two,  m [rows] per time step,
+//                 signals [rows, C]
+// =====================================================================================
+__global__ __launch_bounds__(kThreads) void sigmoid_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           size_t n) {
+  for (size_t i = global_thread(); i < n; i += grid_threads()) {
+    const float x = in[i];
+    const float e = expf(-fabsf(x));
+    out[i] = (x >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mix_kernel(const float* __restrict__ signal_one,
+                                                       const float* __restrict__ signal_two,
+                                                       const float* __restrict__ mix_level, float* __restrict__ out,
+                                                       size_t rows, int C) {
+  const size_t total = rows * (size_t)C;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const float m = mix_level[i / C];
+    const float level_one = sqrtf(fabsf(m));
+    const float level_two = 1.0f - sqrtf(fabsf(m - 1.0f));
+    out[i] = __fadd_rn(__fmul_rn(level_one, signal_one[i]), __fmul_rn(level_two, signal_two[i]));
+  }
+}
+
 static inline unsigned grid_for(size_t n, unsigned cap = 256 * 32) {
   size_t g = (n + kThreads - 1) / kThreads;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -479,5 +508,22 @@ extern "C" int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* de
                      st, decay, noise, grad_ir, partial, B, L);
   hipLaunchKernelGGL(exp_decay_bwd_finish_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st, gain, decay,
                      (const double*)partial, grad_gain, grad_decay, B, scale);
+  return check_launch();
+}
+
+extern "C" int ddsp_sigmoid_f32(const float* in, float* out, size_t n, void* stream) {
+  if (!in || !out) return DDSP_ERR_NULL_POINTER;
+  if (n == 0) return DDSP_OK;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, out, n);
+  return check_launch();
+}
+
+extern "C" int ddsp_mix_f32(const float* signal_one, const float* signal_two, const float* mix_level, float* out,
+                            size_t rows, int C, void* stream) {
+  if (!signal_one || !signal_two || !mix_level || !out) return DDSP_ERR_NULL_POINTER;
+  if (C <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (rows == 0) return DDSP_OK;
+  hipLaunchKernelGGL(mix_kernel, dim3(grid_for(rows * (size_t)C)), dim3(kThreads), 0, (hipStream_t)stream,
+                     signal_one, signal_two, mix_level, out, rows, C);
   return check_launch();
 }

@@ -101,6 +101,73 @@ class Add(Processor):
     return out
 
 
+class Mix(Processor):
+  """Constant-power crossfade between two signals (ddsp/processors.py:180-233)."""
+
+  def __init__(self, name='mix'):
+    super().__init__(name=name)
+
+  def get_controls(self, signal_one, signal_two, nn_out_mix_level):
+    """Standardize inputs to same length, mix_level to range [0, 1].
+
+    Raises:
+      ValueError: if signal_one and signal_two are not the same length.
+    """
+    signal_one, signal_two = core.tf_float32(signal_one), core.tf_float32(signal_two)
+    n_time_one, n_time_two = int(signal_one.shape[1]), int(signal_two.shape[1])
+    if n_time_one != n_time_two:
+      raise ValueError('The two signals must have the same length instead of'
+                       '{} and {}'.format(n_time_one, n_time_two))
+    level = core.tf_float32(nn_out_mix_level)
+    if torch.is_grad_enabled() and level.requires_grad:
+      mix_level = torch.sigmoid(level)          # recorded by torch.autograd (plumbing), as in Add
+    else:
+      mix_level = torch.empty_like(level)
+      rc = _lib.load().ddsp_sigmoid_f32(level.data_ptr(), mix_level.data_ptr(), level.numel(), core._stream())
+      _lib.check(rc, 'ddsp_sigmoid_f32')
+    if mix_level.requires_grad:
+      mix_level = _resample_linear_autograd(mix_level, n_time_one)
+    else:
+      mix_level = core.resample(mix_level, n_time_one)       # 'linear' (core.py:573-642), as the reference
+    return {'signal_one': signal_one, 'signal_two': signal_two, 'mix_level': mix_level}
+
+  def get_signal(self, signal_one, signal_two, mix_level):
+    """sqrt(|m|) * signal_one + (1 - sqrt(|m - 1|)) * signal_two; signals [batch, n_time, channels]
+    (a [batch, n_time] signal is taken as one channel and comes back 2-D), mix_level [batch, n_time, 1]."""
+    one, two = core.tf_float32(signal_one), core.tf_float32(signal_two)
+    level = core.tf_float32(mix_level)
+    if one.shape != two.shape or one.dim() not in (2, 3):
+      raise ValueError('signals must have the same [batch, n_time(, channels)] shape, got {} and {}'.format(
+          tuple(one.shape), tuple(two.shape)))
+    if level.numel() != one.shape[0] * one.shape[1]:
+      raise ValueError('mix_level must be [batch, n_time, 1] = [{}, {}, 1], got {}'.format(
+          one.shape[0], one.shape[1], tuple(level.shape)))
+    if torch.is_grad_enabled() and (one.requires_grad or two.requires_grad or level.requires_grad):
+      m = level.reshape(one.shape[0], one.shape[1], *([1] * (one.dim() - 2)))
+      return torch.sqrt(torch.abs(m)) * one + (1.0 - torch.sqrt(torch.abs(m - 1.0))) * two
+    out = torch.empty_like(one)
+    channels = int(one.shape[2]) if one.dim() == 3 else 1
+    rc = _lib.load().ddsp_mix_f32(one.data_ptr(), two.data_ptr(), level.data_ptr(), out.data_ptr(),
+                                  one.shape[0] * one.shape[1], channels, core._stream())
+    _lib.check(rc, 'ddsp_mix_f32')
+    return out
+
+
+def _resample_linear_autograd(x, n_timesteps):
+  """core.resample(method='linear') as torch ops, only so that a mix level that requires grad stays on the
+  autograd tape (plumbing; same index arithmetic as the kernel: pos = t * fl32(F / N))."""
+  f = int(x.shape[1])
+  if f == n_timesteps:
+    return x
+  scale = torch.tensor(f, dtype=torch.float32) / torch.tensor(n_timesteps, dtype=torch.float32)
+  pos = torch.arange(n_timesteps, dtype=torch.float32, device=x.device) * scale.to(x.device)
+  lo = torch.floor(pos)
+  hi = torch.clamp(torch.ceil(pos), max=f - 1)
+  lerp = (pos - lo).reshape(1, -1, 1)
+  top, bottom = x[:, lo.long()], x[:, hi.long()]
+  return top + (bottom - top) * lerp
+
+
 class Crop(Processor):
   """Remove audio generated from padding frames (ddsp/processors.py:237-263; last node of vst.gin's DAG).
 

@@ -10,6 +10,22 @@ from ddsp_amd import core
 from ddsp_amd import processors
 
 
+class TensorToAudio(processors.Processor):
+  """Identity "synth" returning input samples with channel dimension removed (synths.py:23-52)."""
+
+  def __init__(self, name='tensor_to_audio'):
+    super().__init__(name=name)
+
+  def get_controls(self, samples):
+    return {'samples': samples}
+
+  def get_signal(self, samples):
+    samples = core.tf_float32(samples)
+    if samples.dim() != 3 or samples.shape[2] != 1:
+      raise ValueError('samples must be [batch, time, 1], got {}'.format(tuple(samples.shape)))
+    return samples[:, :, 0]
+
+
 class Harmonic(processors.Processor):
   """Synthesize audio with a bank of harmonic sinusoidal oscillators (synths.py:55-146).
 

@@ -361,6 +361,14 @@ int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* decay, const 
                                    void* workspace, size_t workspace_bytes, int B, int L, unsigned flags,
                                    void* stream);
 
+/* processors.Mix (ddsp/processors.py:180-233), the constant-power crossfade next to processors.Add:
+ *   ddsp_sigmoid_f32: tf.nn.sigmoid on n values (get_controls, :207; in may equal out);
+ *   ddsp_mix_f32:     out[r][c] = sqrt(|m[r]|) * signal_one[r][c] + (1 - sqrt(|m[r] - 1|)) * signal_two[r][c]
+ *                     for rows = batch * n_time time steps of C channels (get_signal, :231-233). */
+int ddsp_sigmoid_f32(const float* in, float* out, size_t n, void* stream);
+int ddsp_mix_f32(const float* signal_one, const float* signal_two, const float* mix_level, float* out,
+                 size_t rows, int C, void* stream);
+
 /* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
 int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
                          float max_value, float threshold, void* stream);

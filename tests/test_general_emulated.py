@@ -276,3 +276,19 @@ def test_exp_decay_ir_golden(lib, name):
   assert lib.ddsp_exp_decay_ir_f32(emu.ptr(gain), emu.ptr(decay), emu.ptr(noise), emu.ptr(ir), b, l,
                                    _lib.DECAY_SCALE_EXP_SIGMOID, None) == 0
   np.testing.assert_allclose(np.broadcast_to(ir, g['ir'].shape), g['ir'], rtol=2e-5, atol=1e-7)
+
+
+# ---- processors.Mix ------------------------------------------------------------------------------------------
+def test_sigmoid_and_mix_kernels(lib):
+  rng = np.random.default_rng(6)
+  x = np.concatenate([rng.standard_normal(1000) * 5, [-100.0, 100.0, 0.0]]).astype(np.float32)
+  y = np.full_like(x, np.nan)
+  assert lib.ddsp_sigmoid_f32(emu.ptr(x), emu.ptr(y), x.size, None) == 0
+  np.testing.assert_allclose(y, oracle.sigmoid(x.astype(np.float64)), rtol=3e-7, atol=1e-38)
+  rows, c = 2 * 100, 3
+  one, two = rng.standard_normal((rows, c)).astype(np.float32), rng.standard_normal((rows, c)).astype(np.float32)
+  m = rng.uniform(0.0, 1.0, rows).astype(np.float32)
+  out = np.full((rows, c), np.nan, np.float32)
+  assert lib.ddsp_mix_f32(emu.ptr(one), emu.ptr(two), emu.ptr(m), emu.ptr(out), rows, c, None) == 0
+  ref = np.sqrt(np.abs(m))[:, None] * one + (np.float32(1.0) - np.sqrt(np.abs(m - np.float32(1.0))))[:, None] * two
+  np.testing.assert_array_equal(out, ref)                             # processors.py:231-233, fp32 op for op

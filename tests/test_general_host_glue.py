@@ -257,3 +257,36 @@ def test_exp_decay_reverb_glue(host):
   ref_g, ref_d = O.exp_decay_ir_backward(gain, decay, noise, g_ir)
   np.testing.assert_allclose(npy(tg.grad), ref_g, rtol=1e-3, atol=1e-4 * np.abs(ref_g).max())
   np.testing.assert_allclose(npy(td.grad), ref_d, rtol=1e-3, atol=1e-4 * np.abs(ref_d).max())
+
+
+# ---- processors.Mix, synths.TensorToAudio (processors_test.py:103-114, synths.py:23-52) --------------------------
+def test_mix_and_tensor_to_audio_glue(host):
+  from ddsp_amd import processors
+  x1 = np.zeros((2, 100, 3), np.float32) + 1.0
+  x2 = np.zeros((2, 100, 3), np.float32) + 2.0
+  level = np.zeros((2, 100, 1), np.float32) + 0.1                     # will be passed to sigmoid
+  out = processors.Mix(name='mix')(x1, x2, level)
+  assert list(out.shape) == [2, 100, 3]                               # MixTest.test_output_shape_is_correct
+  m = 1.0 / (1.0 + np.exp(-0.1))
+  np.testing.assert_allclose(npy(out), np.sqrt(m) * 1.0 + (1.0 - np.sqrt(1.0 - m)) * 2.0, rtol=1e-6)
+  # a frame-rate mix level is resampled to the signals' length (processors.py:208), 2-D signals come back 2-D
+  rng = np.random.default_rng(2)
+  s1, s2 = rng.standard_normal((2, 64)).astype(np.float32), rng.standard_normal((2, 64)).astype(np.float32)
+  coarse = rng.standard_normal((2, 8, 1)).astype(np.float32)
+  ctl = processors.Mix().get_controls(s1, s2, coarse)
+  ml = O.resample(O.sigmoid(coarse), 64)
+  np.testing.assert_allclose(npy(ctl['mix_level']), ml, rtol=1e-6, atol=1e-7)
+  out2 = npy(processors.Mix().get_signal(**ctl))
+  ref2 = np.sqrt(np.abs(ml[:, :, 0])) * s1 + (1.0 - np.sqrt(np.abs(ml[:, :, 0] - 1.0))) * s2
+  assert out2.shape == (2, 64)
+  np.testing.assert_allclose(out2, ref2, rtol=1e-5, atol=1e-6)
+  with pytest.raises(ValueError, match='same length'):
+    processors.Mix()(np.zeros((2, 100, 3), np.float32), np.zeros((2, 90, 3), np.float32), level)
+  # with a mix level on the autograd tape the same numbers come out of the torch path
+  t = torch.tensor(coarse, requires_grad=True)
+  out3 = processors.Mix()(s1, s2, t)
+  np.testing.assert_allclose(npy(out3), ref2, rtol=1e-5, atol=1e-6)
+  out3.sum().backward()
+  assert t.grad is not None and float(t.grad.abs().max()) > 0
+  samples = rng.standard_normal((2, 50, 1)).astype(np.float32)
+  np.testing.assert_array_equal(npy(synths.TensorToAudio()(samples)), samples[:, :, 0])

@@ -279,3 +279,29 @@ def test_exp_decay_reverb_reference_tests_and_gradients(ddsp):
   ref_g, ref_d = O.exp_decay_ir_backward(gain, decay, noise, g_ir)
   np.testing.assert_allclose(npy(tg.grad), ref_g, rtol=0, atol=2e-4 * np.abs(ref_g).max())
   np.testing.assert_allclose(npy(td.grad), ref_d, rtol=0, atol=2e-4 * np.abs(ref_d).max())
+
+
+# ---- processors.Mix, synths.TensorToAudio (processors_test.py:103-114, synths.py:23-52) -----------------------------
+def test_mix_and_tensor_to_audio(ddsp):
+  x1 = np.zeros((2, 100, 3), np.float32) + 1.0
+  x2 = np.zeros((2, 100, 3), np.float32) + 2.0
+  level = np.zeros((2, 100, 1), np.float32) + 0.1
+  out = ddsp.processors.Mix(name='mix')(x1, x2, level)
+  assert list(out.shape) == [2, 100, 3]                               # MixTest.test_output_shape_is_correct
+  m = 1.0 / (1.0 + np.exp(-0.1))
+  np.testing.assert_allclose(npy(out), np.sqrt(m) * 1.0 + (1.0 - np.sqrt(1.0 - m)) * 2.0, rtol=1e-6)
+  rng = np.random.default_rng(2)
+  s1, s2 = rng.standard_normal((4, 64000)).astype(np.float32), rng.standard_normal((4, 64000)).astype(np.float32)
+  coarse = rng.standard_normal((4, 1000, 1)).astype(np.float32)
+  ml = O.resample(O.sigmoid(coarse), 64000)[:, :, 0]
+  ref = np.sqrt(np.abs(ml)) * s1 + (1.0 - np.sqrt(np.abs(ml - 1.0))) * s2
+  np.testing.assert_allclose(npy(ddsp.processors.Mix()(s1, s2, coarse)), ref, rtol=1e-5, atol=1e-6)
+  t = torch.tensor(coarse, device='cuda', requires_grad=True)
+  out3 = ddsp.processors.Mix()(s1, s2, t)
+  np.testing.assert_allclose(npy(out3), ref, rtol=1e-5, atol=1e-6)
+  out3.sum().backward()
+  assert float(t.grad.abs().max()) > 0
+  with pytest.raises(ValueError, match='same length'):
+    ddsp.processors.Mix()(x1, x2[:, :90], level)
+  samples = rng.standard_normal((2, 50, 1)).astype(np.float32)
+  np.testing.assert_array_equal(npy(ddsp.synths.TensorToAudio()(samples)), samples[:, :, 0])
