@@ -1,0 +1,490 @@
+// TEST INFRASTRUCTURE ONLY - never shipped, never loaded by ddsp_amd.
+//
+// A SIMT stand-in for <hip/hip_runtime.h>: lets the host clang++ compile the gfx950 kernel sources of
+// ddsp_amd/csrc UNCHANGED into a host shared object and run them on the CPU, so that the logic of a
+// kernel (indexing, LDS layouts, barriers, cross-lane traffic, MFMA fragment layouts) can be checked against the
+// oracle without a GPU.  It models, per launch:
+//   * blocks one after another; the threads of a block as fibers (ucontext) on ONE OS thread, so `__shared__`
+//     variables are plain statics and there are no data races - a fiber runs until it reaches a
+//     synchronisation point (__syncthreads, a cross-lane operation, a wave barrier) or returns;
+//   * wavefronts of 64 lanes: readlane / readfirstlane / DPP (the controls the kernels use) / ds_swizzle /
+//     __shfl_* / v_mfma_f32_16x16x32_f16 are evaluated when every live lane of the wavefront has arrived
+//     (lanes that already returned are masked off, as EXEC would);
+//   * the transcendental instructions (v_sin/v_cos in revolutions, v_exp/v_log base 2, v_rcp) in double.
+// It says nothing about performance, occupancy, bank conflicts or memory ordering, and inline assembly is out
+// of its reach (harm_fused_kernel's scalar loads).  The product is libddsp_amd.so built by hipcc for gfx950;
+// the `-m gpu` tests are the parity tests proper.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------
+// vector types
+// ---------------------------------------------------------------------------------------------------
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
+struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct int2 { int x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---------------------------------------------------------------------------------------------------
+// runtime API subset (host side)
+// ---------------------------------------------------------------------------------------------------
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+  const char* e = getenv("DDSP_EMU_CUS");          // a small "chip" keeps emulated persistent kernels short
+  *v = e ? atoi(e) : 4;
+  return hipSuccess;
+}
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+template <class T> hipError_t hipMalloc(T** p, size_t n) { *p = (T*)calloc(n, 1); return hipSuccess; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __constant__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+using std::max;
+using std::min;
+
+// ---------------------------------------------------------------------------------------------------
+// the SIMT machine
+// ---------------------------------------------------------------------------------------------------
+namespace ddsp_emu {
+
+constexpr int kWaveSize = 64;
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr size_t kDynLdsBytes = 160 * 1024;
+
+enum WaitKind { kRunnable = 0, kBlockBarrier, kWaveOp, kDone };
+
+// a cross-lane operation in flight: every live lane deposits `in`, the last arrival lets the scheduler run
+// `apply` once for the wavefront (it sees all inputs and the live mask and fills all outputs)
+struct WaveOp {
+  int id = 0;                          // which operation (all lanes must agree)
+  unsigned long long param = 0;        // its immediate operands (must agree too)
+  alignas(16) unsigned char in[kWaveSize][64];
+  alignas(16) unsigned char out[kWaveSize][64];
+  void (*apply)(WaveOp&, unsigned long long live) = nullptr;
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  dim3 tid;
+  int linear = 0;
+  WaitKind wait = kRunnable;
+};
+
+struct Machine {
+  std::vector<Fiber> fibers;
+  std::vector<WaveOp> waves;
+  ucontext_t scheduler;
+  int current = -1;
+  std::function<void()> body;
+  alignas(16) unsigned char dyn_lds[kDynLdsBytes];
+};
+inline Machine g_m;
+
+}  // namespace ddsp_emu
+
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace ddsp_emu {
+
+inline void yield_to_scheduler(WaitKind why) {
+  Fiber& f = g_m.fibers[g_m.current];
+  f.wait = why;
+  swapcontext(&f.ctx, &g_m.scheduler);
+}
+
+inline void fiber_main() {
+  g_m.body();
+  yield_to_scheduler(kDone);
+}
+
+inline int lane_id() { return g_m.fibers[g_m.current].linear % kWaveSize; }
+inline int wave_id() { return g_m.fibers[g_m.current].linear / kWaveSize; }
+
+[[noreturn]] inline void die(const char* what) {
+  fprintf(stderr, "[hip_emu] %s (block %u,%u thread %d)\n", what, blockIdx.x, blockIdx.y, g_m.current);
+  abort();
+}
+
+// run one block of `nthreads` fibers to completion
+inline void run_block(int nthreads) {
+  Machine& m = g_m;
+  const int nwaves = (nthreads + kWaveSize - 1) / kWaveSize;
+  if ((int)m.fibers.size() < nthreads) {
+    const size_t old = m.fibers.size();
+    m.fibers.resize(nthreads);
+    for (size_t i = old; i < m.fibers.size(); ++i) m.fibers[i].stack = (char*)malloc(kStackBytes);
+  }
+  if ((int)m.waves.size() < nwaves) m.waves.resize(nwaves);
+  for (int i = 0; i < nthreads; ++i) {
+    Fiber& f = m.fibers[i];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStackBytes;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    f.linear = i;
+    f.tid = dim3(i % blockDim.x, (i / blockDim.x) % blockDim.y, i / (blockDim.x * blockDim.y));
+    f.wait = kRunnable;
+  }
+  int done = 0;
+  while (done < nthreads) {
+    bool progressed = false;
+    for (int i = 0; i < nthreads; ++i) {
+      Fiber& f = m.fibers[i];
+      if (f.wait != kRunnable) continue;
+      m.current = i;
+      threadIdx = f.tid;
+      swapcontext(&m.scheduler, &f.ctx);
+      progressed = true;
+      if (f.wait == kDone) ++done;
+    }
+    // cross-lane operations: a wavefront proceeds when all its live lanes wait at the same operation
+    for (int w = 0; w < nwaves; ++w) {
+      const int lo = w * kWaveSize, hi = min(lo + kWaveSize, nthreads);
+      unsigned long long live = 0, at_op = 0;
+      bool any_runnable = false;
+      for (int i = lo; i < hi; ++i) {
+        if (m.fibers[i].wait == kDone) continue;
+        live |= 1ull << (i - lo);
+        if (m.fibers[i].wait == kWaveOp) at_op |= 1ull << (i - lo);
+        if (m.fibers[i].wait == kRunnable) any_runnable = true;
+      }
+      if (at_op == 0 || any_runnable) continue;
+      // lanes waiting at the block barrier skipped this operation (they sit in a later part of the program):
+      // the operation runs with the lanes that took the branch, as EXEC would have it
+      WaveOp& op = m.waves[w];
+      op.apply(op, at_op);
+      for (int i = lo; i < hi; ++i)
+        if (m.fibers[i].wait == kWaveOp) m.fibers[i].wait = kRunnable;
+      progressed = true;
+    }
+    // the block barrier opens when every live fiber waits at it
+    bool all_at_barrier = done < nthreads;
+    for (int i = 0; i < nthreads && all_at_barrier; ++i)
+      if (m.fibers[i].wait != kDone && m.fibers[i].wait != kBlockBarrier) all_at_barrier = false;
+    if (all_at_barrier) {
+      for (int i = 0; i < nthreads; ++i)
+        if (m.fibers[i].wait == kBlockBarrier) m.fibers[i].wait = kRunnable;
+      progressed = true;
+    }
+    if (!progressed && done < nthreads) die("deadlock: no fiber can make progress");
+  }
+}
+
+template <class Kernel, class... Args>
+void launch(Kernel kernel, dim3 grid, dim3 block, Args... args) {
+  gridDim = grid;
+  blockDim = block;
+  g_m.body = [=]() { kernel(args...); };
+  const int nthreads = (int)(block.x * block.y * block.z);
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = dim3(bx, by, bz);
+        run_block(nthreads);
+      }
+}
+
+// one cross-lane operation from the calling lane's point of view
+template <class In, class Out>
+Out wave_op(int id, unsigned long long param, const In& in, void (*apply)(WaveOp&, unsigned long long)) {
+  static_assert(sizeof(In) <= 64 && sizeof(Out) <= 64, "operand too large for the exchange buffer");
+  WaveOp& op = g_m.waves[wave_id()];
+  const int l = lane_id();
+  bool first = true;
+  for (int i = wave_id() * kWaveSize; i < wave_id() * kWaveSize + kWaveSize && i < (int)g_m.fibers.size(); ++i)
+    if (i != g_m.current && g_m.fibers[i].wait == kWaveOp) first = false;
+  if (first) { op.id = id; op.param = param; op.apply = apply; }
+  else if (op.id != id || op.param != param) die("lanes of one wavefront wait at different cross-lane operations");
+  memcpy(op.in[l], &in, sizeof(In));
+  yield_to_scheduler(kWaveOp);
+  Out out;
+  memcpy(&out, op.out[l], sizeof(Out));
+  return out;
+}
+
+template <class T> T& in_of(WaveOp& op, int lane) { return *reinterpret_cast<T*>(op.in[lane]); }
+template <class T> T& out_of(WaveOp& op, int lane) { return *reinterpret_cast<T*>(op.out[lane]); }
+inline bool is_live(unsigned long long live, int lane) { return lane >= 0 && lane < kWaveSize && ((live >> lane) & 1ull); }
+
+}  // namespace ddsp_emu
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...) \
+  ddsp_emu::launch(kernel, grid, block, __VA_ARGS__)
+#define hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ev0, ev1, flags, ...) \
+  ddsp_emu::launch(kernel, grid, block, __VA_ARGS__)
+// `extern __shared__ T name[];` -> the block's dynamic LDS
+#define DDSP_EMU_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(ddsp_emu::g_m.dyn_lds)
+
+// ---------------------------------------------------------------------------------------------------
+// synchronisation
+// ---------------------------------------------------------------------------------------------------
+inline void __syncthreads() { ddsp_emu::yield_to_scheduler(ddsp_emu::kBlockBarrier); }
+inline void ddsp_emu_wave_sync() {
+  struct None {};
+  ddsp_emu::wave_op<int, int>(1, 0, 0, [](ddsp_emu::WaveOp&, unsigned long long) {});
+}
+// within a wavefront the hardware runs in lockstep; here its lanes run one after another between
+// synchronisation points, so the wave-level ordering points of the source become real joins
+inline void __builtin_amdgcn_wave_barrier() { ddsp_emu_wave_sync(); }
+inline void __builtin_amdgcn_s_waitcnt(int) { ddsp_emu_wave_sync(); }
+inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
+inline void __builtin_amdgcn_s_dcache_inv() {}
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---------------------------------------------------------------------------------------------------
+// cross-lane data movement
+// ---------------------------------------------------------------------------------------------------
+inline int __builtin_amdgcn_readfirstlane(int v) {
+  return ddsp_emu::wave_op<int, int>(2, 0, v, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    int first = 0;
+    while (first < 64 && !ddsp_emu::is_live(live, first)) ++first;
+    for (int l = 0; l < 64; ++l) ddsp_emu::out_of<int>(op, l) = ddsp_emu::in_of<int>(op, first);
+  });
+}
+inline int __builtin_amdgcn_readlane(int v, int src_lane) {
+  return ddsp_emu::wave_op<int, int>(3, (unsigned long long)src_lane, v, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    const int src = (int)op.param & 63;
+    const int val = ddsp_emu::is_live(live, src) ? ddsp_emu::in_of<int>(op, src) : 0;
+    for (int l = 0; l < 64; ++l) ddsp_emu::out_of<int>(op, l) = val;
+  });
+}
+
+// DPP: lane i reads `src` from the lane its control selects; a lane whose source is invalid (outside the
+// row / wave), not live, or whose row / bank is masked off keeps `old` (bound_ctrl = false).
+inline int ddsp_emu_dpp_source(int lane, int ctrl) {
+  const int row = lane & ~15, pos = lane & 15;
+  if (ctrl <= 0xFF) return (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);              // quad_perm
+  if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = pos + (ctrl & 15); return s < 16 ? row + s : -1; }   // row_shl:n
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = pos - (ctrl & 15); return s >= 0 ? row + s : -1; }   // row_shr:n
+  if (ctrl >= 0x121 && ctrl <= 0x12F) return row + ((pos - (ctrl & 15)) & 15);          // row_ror:n
+  if (ctrl == 0x130) return lane + 1 < 64 ? lane + 1 : -1;                              // wave_shl:1
+  if (ctrl == 0x138) return lane >= 1 ? lane - 1 : -1;                                  // wave_shr:1
+  if (ctrl == 0x140) return row + 15 - pos;                                             // row_mirror
+  if (ctrl == 0x141) return (lane & ~7) + 7 - (lane & 7);                               // row_half_mirror
+  if (ctrl == 0x142) return row >= 16 ? row - 1 : -1;                                   // row_bcast:15 (lane 15 of the previous row)
+  if (ctrl == 0x143) return lane >= 32 ? 31 : -1;                                       // row_bcast:31
+  if (ctrl >= 0x150 && ctrl <= 0x15F) return row + (ctrl & 15);                         // row_newbcast:n
+  return -2;
+}
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  struct In { int old, src; };
+  const unsigned long long param = (unsigned long long)ctrl | ((unsigned long long)row_mask << 16) |
+                                   ((unsigned long long)bank_mask << 20) | ((unsigned long long)bound_ctrl << 24);
+  return ddsp_emu::wave_op<In, int>(4, param, In{old, src}, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    const int ctrl = (int)(op.param & 0xFFFF), row_mask = (int)((op.param >> 16) & 15);
+    const int bank_mask = (int)((op.param >> 20) & 15), bound = (int)((op.param >> 24) & 1);
+    for (int l = 0; l < 64; ++l) {
+      const In me = ddsp_emu::in_of<In>(op, l);
+      int result = me.old;
+      const bool enabled = ((row_mask >> (l >> 4)) & 1) && ((bank_mask >> ((l >> 2) & 3)) & 1);
+      if (enabled) {
+        const int s = ddsp_emu_dpp_source(l, ctrl);
+        if (s == -2) ddsp_emu::die("DPP control not modelled");
+        if (s >= 0 && ddsp_emu::is_live(live, s)) result = ddsp_emu::in_of<In>(op, s).src;
+        else if (s >= 0 || bound) result = 0;            // a masked-off source lane reads as 0; bound_ctrl: 0 for out-of-range
+      }
+      ddsp_emu::out_of<int>(op, l) = result;
+    }
+  });
+}
+// ds_swizzle, bit-mask mode (offset < 0x8000): src = ((lane & and) | or) ^ xor within groups of 32 lanes
+inline int __builtin_amdgcn_ds_swizzle(int v, int pattern) {
+  return ddsp_emu::wave_op<int, int>(5, (unsigned long long)pattern, v, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    const int p = (int)op.param;
+    if (p & 0x8000) ddsp_emu::die("ds_swizzle quad-permute mode not modelled");
+    const int and_m = p & 31, or_m = (p >> 5) & 31, xor_m = (p >> 10) & 31;
+    for (int l = 0; l < 64; ++l) {
+      const int s = (l & 32) | ((((l & 31) & and_m) | or_m) ^ xor_m);
+      ddsp_emu::out_of<int>(op, l) = ddsp_emu::is_live(live, s) ? ddsp_emu::in_of<int>(op, s) : 0;
+    }
+  });
+}
+template <class T>
+T ddsp_emu_shfl(T v, int kind, int arg) {
+  struct In { T v; int arg; };
+  return ddsp_emu::wave_op<In, T>(6 + kind, 0, In{v, arg}, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    const int kind = op.id - 6;
+    for (int l = 0; l < 64; ++l) {
+      const In me = ddsp_emu::in_of<In>(op, l);
+      int s = kind == 0 ? (l ^ me.arg) : kind == 1 ? (l - me.arg) : kind == 2 ? (l + me.arg) : me.arg;
+      if (s < 0 || s > 63 || !ddsp_emu::is_live(live, s)) s = l;       // out of range: own value
+      ddsp_emu::out_of<T>(op, l) = ddsp_emu::in_of<In>(op, s).v;
+    }
+  });
+}
+template <class T> T __shfl_xor(T v, int mask, int = 64) { return ddsp_emu_shfl(v, 0, mask); }
+template <class T> T __shfl_up(T v, unsigned delta, int = 64) { return ddsp_emu_shfl(v, 1, (int)delta); }
+template <class T> T __shfl_down(T v, unsigned delta, int = 64) { return ddsp_emu_shfl(v, 2, (int)delta); }
+template <class T> T __shfl(T v, int src, int = 64) { return ddsp_emu_shfl(v, 3, src); }
+
+// ---------------------------------------------------------------------------------------------------
+// matrix cores: v_mfma_f32_16x16x32_f16  D[16x16] = A[16x32] B[32x16] + C
+//   lane l holds A[i = l % 16][k = 8 (l / 16) .. + 7], B[k = 8 (l / 16) .. + 7][j = l % 16],
+//   and C / D[i = 4 (l / 16) + r][j = l % 16], r = 0..3
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 ddsp_emu_half8 __attribute__((ext_vector_type(8)));
+typedef float ddsp_emu_float4v __attribute__((ext_vector_type(4)));
+inline ddsp_emu_float4v __builtin_amdgcn_mfma_f32_16x16x32_f16(ddsp_emu_half8 a, ddsp_emu_half8 b, ddsp_emu_float4v c,
+                                                               int, int, int) {
+  struct In { _Float16 a[8], b[8]; float c[4]; };
+  struct Out { float d[4]; };
+  In in;
+  for (int i = 0; i < 8; ++i) { in.a[i] = a[i]; in.b[i] = b[i]; }
+  for (int i = 0; i < 4; ++i) in.c[i] = c[i];
+  const Out o = ddsp_emu::wave_op<In, Out>(20, 0, in, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    if (live != ~0ull) ddsp_emu::die("MFMA with a partial wavefront");
+    float A[16][32], B[32][16];
+    for (int l = 0; l < 64; ++l) {
+      const In& me = ddsp_emu::in_of<In>(op, l);
+      for (int q = 0; q < 8; ++q) {
+        A[l % 16][8 * (l / 16) + q] = (float)me.a[q];
+        B[8 * (l / 16) + q][l % 16] = (float)me.b[q];
+      }
+    }
+    for (int l = 0; l < 64; ++l) {
+      const In& me = ddsp_emu::in_of<In>(op, l);
+      Out& out = ddsp_emu::out_of<Out>(op, l);
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l / 16) + r, j = l % 16;
+        double acc = (double)me.c[r];
+        for (int k = 0; k < 32; ++k) acc += (double)A[i][k] * (double)B[k][j];
+        out.d[r] = (float)acc;
+      }
+    }
+  });
+  return ddsp_emu_float4v{o.d[0], o.d[1], o.d[2], o.d[3]};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-lane instructions
+// ---------------------------------------------------------------------------------------------------
+inline float __builtin_amdgcn_sinf(float rev) { return (float)std::sin(6.283185307179586476925 * (double)rev); }
+inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos(6.283185307179586476925 * (double)rev); }
+inline float __builtin_amdgcn_exp2f(float x) { return (float)std::exp2((double)x); }
+inline float __builtin_amdgcn_logf(float x) { return (float)std::log2((double)x); }       // v_log_f32: base 2
+inline float __builtin_amdgcn_rcpf(float x) { return (float)(1.0 / (double)x); }
+inline float __builtin_amdgcn_rsqf(float x) { return (float)(1.0 / std::sqrt((double)x)); }
+inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
+inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }
+typedef __fp16 ddsp_emu_half2 __attribute__((ext_vector_type(2)));      // the builtin's own return type
+// v_cvt_pkrtz_f16_f32: both halves rounded toward zero
+inline _Float16 ddsp_emu_f16_rtz(float x) {
+  _Float16 h = (_Float16)x;                                      // round to nearest even
+  if (std::isfinite(x) && std::fabs((float)h) > std::fabs(x)) {  // stepped away from zero: one ulp back
+    uint16_t bits;
+    memcpy(&bits, &h, 2);
+    bits -= 1;
+    memcpy(&h, &bits, 2);
+  }
+  return h;
+}
+inline ddsp_emu_half2 __builtin_amdgcn_cvt_pkrtz(float a, float b) {
+  return ddsp_emu_half2{(__fp16)ddsp_emu_f16_rtz(a), (__fp16)ddsp_emu_f16_rtz(b)};
+}
+// s_load_dwordxN pairs (wave-uniform addresses; here every lane loads the same values itself)
+template <int N, class V>
+void ddsp_emu_sload(V& a0, V& a1, const float* p0, const float* p1, int byte_offset) {
+  for (int i = 0; i < N; ++i) {
+    a0[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p0) + byte_offset + 4 * i);
+    a1[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p1) + byte_offset + 4 * i);
+  }
+}
+inline long long wall_clock64() { return 0; }
+inline long long clock64() { return 0; }
+inline long long __builtin_readcyclecounter_emu() { return 0; }
+
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline double __dadd_rn(double a, double b) { return a + b; }
+inline double __dmul_rn(double a, double b) { return a * b; }
+inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
+inline float __expf(float x) { return std::exp(x); }
+inline float __logf(float x) { return std::log(x); }
+inline float __sinf(float x) { return std::sin(x); }
+inline float __cosf(float x) { return std::cos(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float cospif(float x) { return (float)std::cos(3.14159265358979323846 * (double)x); }
+inline float sinpif(float x) { return (float)std::sin(3.14159265358979323846 * (double)x); }
+inline double cospi(double x) { return std::cos(3.14159265358979323846 * x); }
+inline double sinpi(double x) { return std::sin(3.14159265358979323846 * x); }
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+inline void sincospif(float x, float* s, float* c) { *s = sinpif(x); *c = cospif(x); }
+inline void sincosf(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline double __longlong_as_double(long long u) { double f; memcpy(&f, &u, 8); return f; }
+inline long long __double_as_longlong(double f) { long long u; memcpy(&u, &f, 8); return u; }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+
+// atomics: one OS thread, so plain read-modify-write
+template <class T> T atomicAdd(T* p, T v) { const T old = *p; *p = old + v; return old; }
+template <class T> T unsafeAtomicAdd(T* p, T v) { return atomicAdd(p, v); }
+template <class T> T atomicMax(T* p, T v) { const T old = *p; *p = std::max(old, v); return old; }
+template <class T> T atomicExch(T* p, T v) { const T old = *p; *p = v; return old; }
+// __hip_atomic_load / _store / _fetch_add are generic clang builtins: they work on the host as they are
+#ifndef __HIP_MEMORY_SCOPE_SINGLETHREAD
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif

@@ -16,6 +16,8 @@ from oracle import ddsp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+DEV = 'cuda'      # tests/test_simt_emulated.py re-runs a subset of these tests on host memory with DEV = 'cpu'
+
 HARM_TRUTH_ATOL = 2e-4
 HARM_FAITHFUL_ATOL = 2e-3
 
@@ -507,8 +509,8 @@ def test_harmonic_table_kernel_controls_dict(ddsp, batch, n_frames, k):
   np.testing.assert_array_equal(npy(out['controls']['f0_hz']), f0)
   np.testing.assert_array_equal(npy(out['signal']), npy(synth(amps, hd, f0)))
   # with autograd on, one launch still yields audio and controls, and the gradient flows through the audio
-  a_t = torch.tensor(amps, device='cuda', requires_grad=True)
-  h_t = torch.tensor(hd, device='cuda', requires_grad=True)
+  a_t = torch.tensor(amps, device=DEV, requires_grad=True)
+  h_t = torch.tensor(hd, device=DEV, requires_grad=True)
   out_g = synth(a_t, h_t, f0, return_outputs_dict=True)
   np.testing.assert_array_equal(npy(out_g['signal']), npy(out['signal']))
   np.testing.assert_array_equal(npy(out_g['controls']['harmonic_distribution']), npy(out['controls']['harmonic_distribution']))
@@ -635,7 +637,7 @@ def test_reverb_properties_full_size_batch32(ddsp):
   scale = float(rhs.abs().max())
   assert float((lhs - rhs).abs().max()) <= 2e-5 * scale
   # a unit tap at k delays by k samples; tap 0 is masked; add_dry adds the input back
-  delta = torch.zeros((1, l), device='cuda')
+  delta = torch.zeros((1, l), device=DEV)
   delta[0, 0], delta[0, 4097] = 5.0, 1.0
   y = wet(x1, delta)
   assert float(y[:, :4097].abs().max()) <= 1e-5
@@ -669,7 +671,7 @@ def test_reverb_in_processor_group(ddsp):                            # gin/model
   noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=3)
   add = ddsp.processors.Add()
   rev = ddsp.effects.Reverb(trainable=True, reverb_length=l)
-  rev.build(device=torch.device('cuda'))
+  rev.build(device=torch.device(DEV))
   rev._ir = ddsp.core.tf_float32(rng.standard_normal(l) * np.exp(-np.arange(l) / 2000.0) * 0.05)
   dag = [(harm, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
          (add, ['filtered_noise/signal', 'harmonic/signal']), (rev, ['add/signal'])]
@@ -953,7 +955,7 @@ def test_synth_plus_trainable_reverb_trains(ddsp):                   # solo_inst
   hd = ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True)
   f0 = 200 + rng.standard_normal((b, f, 1))
   rev = ddsp.effects.Reverb(trainable=True, reverb_length=l)
-  rev.build(device=torch.device('cuda'))
+  rev.build(device=torch.device(DEV))
   rev._ir = ddsp.core.tf_float32(0.02 * rng.standard_normal(l)).requires_grad_(True)
   dag = [(ddsp.synths.Harmonic(n_samples=n), ['amps', 'harmonic_distribution', 'f0_hz']),
          (rev, ['harmonic/signal'])]
@@ -1061,7 +1063,7 @@ def test_vst_dag_with_trainable_filtered_noise_reverb_trains(ddsp):   # gin/mode
            'noise_magnitudes': ddsp.core.tf_float32(rng.standard_normal((b, f, m))).requires_grad_(True)}
   rev = ddsp.effects.FilteredNoiseReverb(trainable=True, reverb_length=1200, n_frames=25, n_filter_banks=32,
                                          name='reverb')
-  rev.build(device=torch.device('cuda'))
+  rev.build(device=torch.device(DEV))
   rev._magnitudes.requires_grad_(True)
   crop = ddsp.processors.Crop(frame_size=64, crop_location='back')
   dag = [(ddsp.synths.Harmonic(n_samples=n), ['amps', 'harmonic_distribution', 'f0_hz']),
@@ -1085,7 +1087,7 @@ def test_spectral_loss_fused_and_separate_gradient_entries_agree(ddsp):
   a = ddsp.core.tf_float32(0.25 * rng.standard_normal((2, 5000)))
   loss = ddsp.losses.SpectralLoss(fft_sizes=(1024, 256, 64), logmag_weight=1.0)
   value, grad = loss._value_and_grad(t, a)                          # ddsp_spectral_loss_value_and_grad_f32
-  sep = loss._backward(t, a, torch.ones((), device='cuda'))         # ddsp_spectral_loss_backward_f32
+  sep = loss._backward(t, a, torch.ones((), device=DEV))         # ddsp_spectral_loss_backward_f32
   fwd = loss._forward(t, a)                                         # ddsp_spectral_loss_f32
   np.testing.assert_allclose(float(value), float(fwd), rtol=1e-6)
   scale = float(grad.abs().max())

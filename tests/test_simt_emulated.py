@@ -1,0 +1,58 @@
+"""The GPU parity tests, re-run on the CPU through the SIMT emulation of tests/hip_emu (TEST INFRASTRUCTURE).
+
+tests/hip_emu/emu_simt.py compiles the gfx950 kernel sources of ddsp_amd/csrc unchanged for the host (threads of
+a block as fibers, wavefront operations - DPP, readlane, swizzle, MFMA - evaluated when all live lanes have
+arrived); this module points the Python layer of ddsp_amd at that build and at host memory, then runs the very
+test functions of test_gpu_parity.py / test_gpu_parity_general.py whose shapes finish in seconds.  What it
+checks is kernel LOGIC (indexing, LDS layouts, barriers, cross-lane traffic, MFMA fragment layouts, launch
+geometry) and the host glue; it says nothing about performance and does not replace the `-m gpu` run, which is
+the parity gate.  Every kernel exercised here has also passed on the MI355X, which is what pins the emulation
+itself; the point of keeping it is that a kernel change can be checked without GPU time.
+
+The product never runs this way: ddsp_amd has no CPU path (test_host_api.test_no_gpu_fails_loudly_not_silently)."""
+import os
+
+import pytest
+import torch
+
+import test_gpu_parity as P
+import test_gpu_parity_general as G
+from ddsp_amd import _lib, core
+from tests.hip_emu import emu_simt
+
+
+@pytest.fixture(scope='module')
+def ddsp():
+  import ddsp_amd
+  os.environ.setdefault('DDSP_EMU_CUS', '4')          # the emulated chip's CU count (persistent kernels size their grid by it)
+  lib = emu_simt.load()
+  saved = (_lib.load, core._device, core._stream, dict(core._ws_bytes_cache), P.DEV, G.DEV)
+  _lib.load = lambda: lib
+  core._device = lambda: torch.device('cpu')
+  core._stream = lambda: None
+  core._ws_bytes_cache.clear()
+  P.DEV = G.DEV = 'cpu'
+  yield ddsp_amd
+  _lib.load, core._device, core._stream = saved[0], saved[1], saved[2]
+  core._ws_bytes_cache.clear()
+  core._ws_bytes_cache.update(saved[3])
+  P.DEV, G.DEV = saved[4], saved[5]
+
+
+@pytest.fixture(params=['auto', 'direct'])
+def harm_kernel(request, ddsp):
+  old = ddsp.synths.Harmonic.kernel
+  ddsp.synths.Harmonic.kernel = request.param
+  yield request.param
+  ddsp.synths.Harmonic.kernel = old
+
+
+# the tests of the two GPU modules whose shapes the emulation finishes in seconds (full 4 s clips at batch 32 are
+# left to the GPU); re-exported under their own names so that their parametrisations come along
+EMULATED = {
+    P: ['test_harmonic_golden'],
+    G: [],
+}
+for _module, _names in EMULATED.items():
+  for _name in _names:
+    globals()[_name] = getattr(_module, _name)
