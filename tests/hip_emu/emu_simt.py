@@ -73,7 +73,9 @@ def build(verbose=False):
       f.write(_preprocess(text))
     if name in SOURCES:
       staged.append(dst)
-  cmd = [CLANG, '-std=c++17', '-O1', '-g0', '-ffp-contract=off', '-shared', '-fPIC', '-w',
+  # -ffp-contract=fast -mfma: a*b+c contracts to an FMA as in hipcc's default mode (the FFT butterflies of the
+  # SpectralLoss are measurably less accurate without); the *_rn intrinsics stay uncontracted (see the header)
+  cmd = [CLANG, '-std=c++17', '-O1', '-g0', '-ffp-contract=fast', '-mfma', '-shared', '-fPIC', '-w',
          '-I' + os.path.join(HERE, 'include_simt'), '-I' + os.path.join(ROOT, 'include'),
          '-include', os.path.join(HERE, 'include_simt', 'hip', 'hip_runtime.h')] + staged + ['-o', OUT]
   if verbose:

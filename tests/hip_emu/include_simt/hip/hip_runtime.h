@@ -445,12 +445,14 @@ inline long long wall_clock64() { return 0; }
 inline long long clock64() { return 0; }
 inline long long __builtin_readcyclecounter_emu() { return 0; }
 
-inline float __fadd_rn(float a, float b) { return a + b; }
-inline float __fsub_rn(float a, float b) { return a - b; }
-inline float __fmul_rn(float a, float b) { return a * b; }
-inline float __fdiv_rn(float a, float b) { return a / b; }
-inline double __dadd_rn(double a, double b) { return a + b; }
-inline double __dmul_rn(double a, double b) { return a * b; }
+// the *_rn intrinsics are the source's way of forbidding contraction; the build lets the compiler contract
+// a*b+c elsewhere (as hipcc does by default), so these results are pinned through a volatile
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
 inline float __expf(float x) { return std::exp(x); }
 inline float __logf(float x) { return std::log(x); }
