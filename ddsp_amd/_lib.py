@@ -94,6 +94,7 @@ CONV_REVERSE_AUDIO = 0x4
 CONV_REVERSE_IR = 0x8
 CONV_REVERSE_OUT = 0x10
 
+ERR_UNSUPPORTED = -3
 ERRORS = {-1: 'DDSP_ERR_NULL_POINTER', -2: 'DDSP_ERR_BAD_SHAPE', -3: 'DDSP_ERR_UNSUPPORTED',
           -4: 'DDSP_ERR_WORKSPACE', -5: 'DDSP_ERR_LAUNCH'}
 

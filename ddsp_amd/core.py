@@ -518,12 +518,14 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
     return fft_convolve_long(audio, impulse_response[:, 0, :], delay=start, n_out=n_out)
   out = torch.empty((batch_size, n_out), dtype=torch.float32, device=audio.device)
   lib = _lib.load()
+  rc = _lib.ERR_UNSUPPORTED
   if n_out == audio_size and start == start_requested:
     rc = lib.ddsp_fft_convolve_same_f32(
         audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
         n_ir_frames, ir_size, audio_size, int(delay_compensation), _stream())
-    _lib.check(rc, 'ddsp_fft_convolve_same_f32')
-  else:
+    if rc != _lib.ERR_UNSUPPORTED:     # a time-varying IR beyond the tiled kernel's LDS budget takes the general one
+      _lib.check(rc, 'ddsp_fft_convolve_same_f32')
+  if rc == _lib.ERR_UNSUPPORTED:
     rc = lib.ddsp_fft_convolve_f32(
         audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(), batch_size, batch_size_ir,
         n_ir_frames, ir_size, audio_size, n_out, start, _stream())

@@ -308,3 +308,16 @@ def test_mix_and_tensor_to_audio(ddsp):
     ddsp.processors.Mix()(x1, x2[:, :90], level)
   samples = rng.standard_normal((2, 50, 1)).astype(np.float32)
   np.testing.assert_array_equal(npy(ddsp.synths.TensorToAudio()(samples)), samples[:, :, 0])
+
+
+def test_fft_convolve_time_varying_ir_beyond_the_tiled_kernels_lds_budget(ddsp):
+  """8 frames of 4096 taps each: the LDS-tiled FIR declines (DDSP_ERR_UNSUPPORTED), the host layer takes the
+  general one-thread-per-output kernel instead of raising."""
+  rng = np.random.default_rng(77)
+  audio = rng.standard_normal((2, 4096)).astype(np.float32)
+  ir = (rng.standard_normal((2, 8, 4096)) / 64.0).astype(np.float32)
+  for delay in (-1, 0):
+    out = npy(ddsp.core.fft_convolve(audio, ir, padding='same', delay_compensation=delay))
+    ref = O.time_varying_fir_direct(audio, ir, delay_compensation=delay)
+    assert out.shape == ref.shape == (2, 4096)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max())
