@@ -25,6 +25,8 @@ from tests.hip_emu import emu_simt
 def ddsp():
   import ddsp_amd
   os.environ.setdefault('DDSP_EMU_CUS', '4')          # the emulated chip's CU count (persistent kernels size their grid by it)
+  if not os.path.exists(emu_simt.CLANG):
+    pytest.skip('the SIMT emulation builds with the ROCm clang++ (%s), which this machine does not have' % emu_simt.CLANG)
   lib = emu_simt.load()
   saved = (_lib.load, core._device, core._stream, dict(core._ws_bytes_cache), P.DEV, G.DEV)
   _lib.load = lambda: lib
