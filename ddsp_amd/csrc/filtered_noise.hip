@@ -506,7 +506,24 @@ struct FusedNoiseArgs {
   uint64_t batch_offset;
 };
 
-template <bool GEN_NOISE, int NW>   // NW wavefronts per block: 4, or 8 (the FIR's tap range split in two halves)
+typedef _Float16 fn_f16x8 __attribute__((ext_vector_type(8)));
+typedef float fn_f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kFnLoScale = 2048.0f;     // x = hi + lo / 2048 in two fp16 numbers (as harmonic_table.hip)
+
+__device__ __forceinline__ void fn_split8(const float (&v)[8], fn_f16x8& hi, fn_f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    hi[e] = h;
+    lo[e] = (_Float16)((v[e] - (float)h) * kFnLoScale);
+  }
+}
+
+// NW wavefronts per block: 4, or 8 (the FIR's tap range split in two halves).
+// IRMF (experimental; flag DDSP_NOISE_IR_MATRIX_CORES or DDSP_EXP_NOISE_IR_MFMA=1): the IR design's cosine transform - a [32 x 32] . [32 x 64 rows]
+// product per parity with a constant left factor - on the fp16 matrix cores with both factors split hi + lo / 2048
+// (three products, fp32 accumulation), instead of lanes = frames on the vector ALUs.
+template <bool GEN_NOISE, int NW, bool IRMF = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/,
@@ -532,6 +549,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   if (dbg_time) ctl_out = nullptr;
   const int do_scale = p.scale & 1;
   DDSP_STAMP();
+
+  // IRMF: this wavefront's share of the constant factor in MFMA A-operand layout, fetched before anything else
+  // so that the loads fly under stage 1.  Wavefront w designs the taps of rows 16 (w & 3) .. + 15; with 4
+  // wavefronts it takes both tap tiles n = 0..15 and 16..31, with 8 the tile w >> 2.  Element e of lane
+  // (i = lane & 15, g = lane >> 4): coefficient of tap n = 16 mt + i and bin 2 k' (+ 1), k' = 8 g + e.
+  constexpr int kMt = (NW == 8) ? 1 : 2;
+  const int mt0 = (NW == 8) ? (wave >> 2) : 0;
+  fn_f16x8 ae_hi[kMt], ae_lo[kMt], ao_hi[kMt], ao_lo[kMt];
+  if constexpr (IRMF) {
+#pragma unroll
+    for (int q = 0; q < kMt; ++q) {
+      const float* __restrict__ crow = kIr65.c + (16 * (mt0 + q) + (lane & 15)) * kIrRowStride + 8 * (lane >> 4);
+      float ve[8], vo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ve[e] = crow[e]; vo[e] = crow[40 + e]; }
+      fn_split8(ve, ae_hi[q], ae_lo[q]);
+      fn_split8(vo, ao_hi[q], ao_lo[q]);
+    }
+  }
 
   // ---- 1. magnitude rows of frames J0-2 .. J0+61 -------------------------------------------------
   // The 64 rows are one contiguous span of 4160 floats in HBM: 16-byte loads from the span's
@@ -573,8 +609,64 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   }
   __syncthreads();
   DDSP_STAMP();    // 1: magnitudes staged
-  // ---- 2. IR design, lanes = frames ------------------------------------------------------------------
-  {
+  // ---- 2. IR design ------------------------------------------------------------------------------------
+  if constexpr (IRMF) {
+    // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1] for n = 0..31 as matrix products: B holds the
+    // magnitudes of this wavefront's 16 rows (element e of lane (j = lane & 15, g): bin 2 (8 g + e) (+ 1) of
+    // row j), D[n = 4 g + r][row j] comes back four taps per lane.  Bin 64 (the 33rd even bin) is a rank-1
+    // update; tap 32 (cos(pi m / 2): odd bins drop out, even bins alternate in sign) and tap 0 are done by
+    // wavefront 0 with lanes = rows.
+    const int mi = lane & 15, mg = lane >> 4;
+    const int row = 16 * (wave & 3) + mi;
+    const float* __restrict__ mrow = s_u + row * 65 + 16 * mg;
+    float ve[8], vo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ve[e] = mrow[2 * e]; vo[e] = mrow[2 * e + 1]; }
+    fn_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+    fn_split8(ve, be_hi, be_lo);
+    fn_split8(vo, bo_hi, bo_lo);
+    const float m_last = s_u[row * 65 + 64];
+    float* __restrict__ hrow = s_h + row * kTapStride;
+#pragma unroll
+    for (int q = 0; q < kMt; ++q) {
+      const fn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      fn_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_hi, zero, 0, 0, 0);
+      fn_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_hi, zero, 0, 0, 0);
+      fn_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_lo, zero, 0, 0, 0);
+      fn_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_lo, zero, 0, 0, 0);
+      ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_lo[q], be_hi, ex, 0, 0, 0);
+      ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_lo[q], bo_hi, ox, 0, 0, 0);
+      const fn_f32x4 ev = ea + ex * (1.0f / kFnLoScale), ov = oa + ox * (1.0f / kFnLoScale);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * (mt0 + q) + 4 * mg + r;                    // 0 .. 31
+        const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);
+        const float o = ov[r];
+        const float g0 = kIr65.win[n] * (e + o);                       // g[n]:    taps 64+n and 64-n
+        hrow[64 + n] = g0;
+        if (n >= 1) {
+          hrow[64 - n] = g0;
+          const float g1 = kIr65.win[64 - n] * (e - o);                // g[64-n]: taps 128-n and n
+          hrow[128 - n] = g1;
+          hrow[n] = g1;
+        }
+      }
+    }
+    if (wave == 0) {                                                   // lanes = rows
+      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride;
+      float e0 = 0.0f, e1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 32; i += 2) {
+        e0 = fmaf(c32[i], s_u[lane * 65 + 2 * i], e0);
+        e1 = fmaf(c32[i + 1], s_u[lane * 65 + 2 * i + 2], e1);
+      }
+      const float e = fmaf(c32[32], s_u[lane * 65 + 64], e0 + e1);
+      const float g0 = kIr65.win[32] * e;                               // o(32) = 0: cos(pi m / 2) vanishes for odd m
+      s_h[lane * kTapStride + 96] = g0;
+      s_h[lane * kTapStride + 32] = g0;
+      s_h[lane * kTapStride] = 0.0f;                                   // h[0] = Hann(128)[0] * hz[-64] = 0
+    }
+  } else {
     // magnitudes in 64-bit VGPR pairs: the coefficients of a pair are adjacent SGPRs, so the inner
     // products run as v_pk_fma_f32 with an SGPR-pair operand (2.9 ns per two FMAs against 2 x 1.9 ns,
     // tools/microbench4) and as two independent partial sums each
@@ -880,6 +972,21 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       // other stream does better with 4-wavefront blocks (measured: profiles/README.md)
       static const int nw_env = [] { const char* e = getenv("DDSP_EXP_NOISE_WAVES"); return e ? atoi(e) : 0; }();
       const int nw = nw_env ? nw_env : ((size_t)grid.x * grid.y > 768 ? 8 : 4);
+      static const int ir_mfma_env = [] { const char* e = getenv("DDSP_EXP_NOISE_IR_MFMA"); return e ? atoi(e) : 0; }();
+      if (ir_mfma_env || (flags & DDSP_NOISE_IR_MATRIX_CORES)) {   // experimental: the IR design's cosine transform on the matrix cores
+        if (nw == 8) {
+          if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8, true>), grid, dim3(512), 0, st, ev0, ev1, 0,
+                                           magnitudes, noise, ctl_magnitudes, audio, q);
+          else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 8, true>), grid, dim3(512), 0, st, ev0, ev1, 0,
+                                     magnitudes, noise, ctl_magnitudes, audio, q);
+        } else {
+          if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 4, true>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                           magnitudes, noise, ctl_magnitudes, audio, q);
+          else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 4, true>), grid, dim3(256), 0, st, ev0, ev1, 0,
+                                     magnitudes, noise, ctl_magnitudes, audio, q);
+        }
+        return check_launch();
+      }
       if (nw == 8) {
         if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8>), grid, dim3(512), 0, st, ev0, ev1, 0,
                                          magnitudes, noise, ctl_magnitudes, audio, q);

@@ -234,7 +234,12 @@ class FilteredNoise(processors.Processor):
   `seed` is an extension: the reference draws from TensorFlow's stateful global generator;
   here noise is Philox4x32-10 keyed by (seed, call counter), generated inside the FIR
   kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
+
+  `ir_design` (an attribute, like Harmonic.kernel) selects how the fused kernel turns a frame's 65 magnitudes
+  into 128 taps: 'vector' (default: lanes = frames on the vector ALUs) or 'matrix' (experimental: the cosine
+  transform on the fp16 matrix cores, hi/lo split operands).  Same result within the parity tolerance.
   """
+  ir_design = 'vector'
 
   def __init__(self,
                n_samples=64000,
@@ -271,6 +276,13 @@ class FilteredNoise(processors.Processor):
     _lib.check(rc, 'ddsp_filtered_noise_controls_f32')
     return {'magnitudes': ctl}
 
+  def _ir_flag(self):
+    if self.ir_design == 'matrix':
+      return _lib.NOISE_IR_MATRIX_CORES
+    if self.ir_design != 'vector':
+      raise ValueError("FilteredNoise.ir_design must be 'vector' or 'matrix', got {!r}".format(self.ir_design))
+    return 0
+
   def _next_seed(self):
     s = (self.seed & 0xFFFFFFFF) | ((self._calls & 0xFFFFFFFF) << 32)
     self._calls += 1
@@ -298,7 +310,7 @@ class FilteredNoise(processors.Processor):
         magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
         audio.data_ptr(), ctl.data_ptr() if want_controls else None, ws.data_ptr(), ws.numel(),
         b, f, m, n, int(self.window_size), float(self.initial_bias),
-        _lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0, self._next_seed(), 0,
+        (_lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0) | self._ir_flag(), self._next_seed(), 0,
         core._stream())
     _lib.check(rc, 'ddsp_filtered_noise_f32')
     return audio, ctl

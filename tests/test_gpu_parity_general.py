@@ -321,3 +321,55 @@ def test_fft_convolve_time_varying_ir_beyond_the_tiled_kernels_lds_budget(ddsp):
     ref = O.time_varying_fir_direct(audio, ir, delay_compensation=delay)
     assert out.shape == ref.shape == (2, 4096)
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max())
+
+
+# ---- FilteredNoise.ir_design = 'matrix': the IR design's cosine transform on the fp16 matrix cores ----------------
+@pytest.fixture
+def matrix_ir(ddsp):
+  old = ddsp.synths.FilteredNoise.ir_design
+  ddsp.synths.FilteredNoise.ir_design = 'matrix'
+  yield
+  ddsp.synths.FilteredNoise.ir_design = old
+
+
+def noise_tol(ref):
+  return 2e-6 + 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('name', ['noise_m65_w257', 'noise_m65_w0'])
+def test_filtered_noise_matrix_ir_design_golden(ddsp, matrix_ir, name):
+  g = load_golden(name)
+  synth = ddsp.synths.FilteredNoise(n_samples=int(g['n_samples']), window_size=int(g['window_size']))
+  out = synth(g['magnitudes'], noise=g['noise'], return_outputs_dict=True)
+  np.testing.assert_allclose(npy(out['controls']['magnitudes']), g['ctl_magnitudes'], rtol=2e-5, atol=1e-9)
+  np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=noise_tol(g['signal']))
+
+
+@pytest.mark.parametrize('batch,n_frames,n', [(3, 125, 8000), (1, 1, 64), (2, 62, 3968), (2, 63, 4032), (1, 40, 2543),
+                                              (2, 30, 9600), (770, 1, 64)])     # 770 blocks: the 8-wavefront variant
+def test_filtered_noise_matrix_ir_design_vs_oracle_and_vector(ddsp, batch, n_frames, n):
+  rng = np.random.default_rng(n_frames + n)
+  mags = rng.standard_normal((batch, n_frames, 65)).astype(np.float32)
+  mags[0, : max(n_frames // 8, 1)] = -60.0                        # exp_sigmoid's floor (1e-7): fp16 subnormal territory
+  mags[-1, n_frames // 2] = 40.0                                  # and its ceiling (2.0)
+  noise = rng.uniform(-1.0, 1.0, (batch, n)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
+  vector = npy(synth(mags, noise=noise))
+  ddsp.synths.FilteredNoise.ir_design = 'matrix'
+  try:
+    matrix = npy(synth(mags, noise=noise))
+    generated = npy(synth(mags))                                  # noise generated on chip, same kernel variant
+  finally:
+    ddsp.synths.FilteredNoise.ir_design = 'vector'
+  rows = slice(0, min(batch, 4))                                  # the oracle on a few rows is enough at batch 770
+  ref = O.filtered_noise(mags[rows], noise[rows], 0, dtype=np.float64)
+  np.testing.assert_allclose(matrix[rows], ref, rtol=0, atol=noise_tol(ref))
+  # the two designs differ by the rounding of the taps only: far inside the parity tolerance
+  assert np.abs(matrix - vector).max() <= 0.2 * noise_tol(ref)
+  assert generated.shape == (batch, n) and np.isfinite(generated).all() and np.abs(generated).max() > 0
+  with pytest.raises(ValueError, match='ir_design'):
+    ddsp.synths.FilteredNoise.ir_design = 'bogus'
+    try:
+      synth(mags, noise=noise)
+    finally:
+      ddsp.synths.FilteredNoise.ir_design = 'vector'

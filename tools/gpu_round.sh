@@ -38,3 +38,5 @@ echo "== rocprofv3 kernel trace of the training step (synths + loss, forward + b
 for f in $(find $OUT/prof_train -name "*kernel_stats*.csv" | head -1); do echo "--- $f"; head -20 $f | cut -c1-200; done
 echo "== streaming latency (VST frame call)"
 timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json
+echo "== FilteredNoise IR design: vector ALUs vs matrix cores (experimental variant)"
+timeout 120 python tools/exp_noise_ir.py 32 128 2>&1 | tail -2 | tee $OUT/noise_ir_vector_vs_matrix.json
