@@ -523,7 +523,11 @@ __device__ __forceinline__ void fn_split8(const float (&v)[8], fn_f16x8& hi, fn_
 // IRMF (experimental; flag DDSP_NOISE_IR_MATRIX_CORES or DDSP_EXP_NOISE_IR_MFMA=1): the IR design's cosine transform - a [32 x 32] . [32 x 64 rows]
 // product per parity with a constant left factor - on the fp16 matrix cores with both factors split hi + lo / 2048
 // (three products, fp32 accumulation), instead of lanes = frames on the vector ALUs.
-template <bool GEN_NOISE, int NW, bool IRMF = false>
+// IRMF == 2 (flag DDSP_NOISE_IR_FROM_REGISTERS on top, or DDSP_EXP_NOISE_IR_MFMA=2) additionally drops the LDS
+// staging of the magnitudes: every lane loads the 16 bins of its B-fragments straight from HBM, the noise tile is
+// generated while those loads are in flight, and exp_sigmoid runs on the registers - one barrier and one LDS round
+// trip less on the block's latency chain, and the Philox stage moves under the HBM latency.
+template <bool GEN_NOISE, int NW, int IRMF = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/,
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   constexpr int kMt = (NW == 8) ? 1 : 2;
   const int mt0 = (NW == 8) ? (wave >> 2) : 0;
   fn_f16x8 ae_hi[kMt], ae_lo[kMt], ao_hi[kMt], ao_lo[kMt];
-  if constexpr (IRMF) {
+  if constexpr (IRMF != 0) {
 #pragma unroll
     for (int q = 0; q < kMt; ++q) {
       const float* __restrict__ crow = kIr65.c + (16 * (mt0 + q) + (lane & 15)) * kIrRowStride + 8 * (lane >> 4);
@@ -569,10 +573,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
     }
   }
 
+  // IRMF == 2: the 16 bins of this lane's B-fragments (row = 16 (wave & 3) + (lane & 15), bins 16 (lane >> 4) .. + 15)
+  // and bin 64 of that row, straight from HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards
+  // (unconditional loads: nothing waits on them until the noise tile below is done)
+  struct __attribute__((packed, aligned(4))) U4f { float x, y, z, w; };      // a 16-byte load from a 4-byte aligned address
+  U4f rq[4];
+  float r_last = 0.0f;
+  const int rrow = 16 * (wave & 3) + (lane & 15);
+  const int rfr = f_first + rrow;
+  const bool rvalid = rfr >= 0 && rfr < p.F;
+  if constexpr (IRMF == 2) {
+    const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const U4f*>(src + 16 * (lane >> 4) + 4 * c4);
+    r_last = src[64];
+  }
+
   // ---- 1. magnitude rows of frames J0-2 .. J0+61 -------------------------------------------------
   // The 64 rows are one contiguous span of 4160 floats in HBM: 16-byte loads from the span's
   // aligned-down start (vector-memory instruction issue, not bandwidth, is the cost here).
-  {
+  if constexpr (IRMF != 2) {
     const long row_first = (long)b * p.F + f_first;                 // may be < b*F for the first tile
     const long e0 = row_first * 65;                                 // first element wanted
     const long lo = (long)b * p.F * 65, hi = ((long)b + 1) * p.F * 65;   // this batch row's elements
@@ -607,10 +627,107 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       }
     }
   }
-  __syncthreads();
+  if constexpr (IRMF != 2) __syncthreads();
   DDSP_STAMP();    // 1: magnitudes staged
   // ---- 2. IR design ------------------------------------------------------------------------------------
-  if constexpr (IRMF) {
+  if constexpr (IRMF == 2) {
+    // ---- 3'. the noise tile first: it depends on nothing that is in flight ---------------------------------
+    for (int qd = tid; qd < kFnXLen / 4; qd += 64 * NW) {
+      const int i = z0 - 128 + 4 * qd;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i >= 0 && i < p.N) {
+        if (GEN_NOISE) {
+          const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
+                                     p.k0, p.k1);
+          v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+          if (i + 1 >= p.N) v.y = 0.f;
+          if (i + 2 >= p.N) v.z = 0.f;
+          if (i + 3 >= p.N) v.w = 0.f;
+        } else {
+          const float* src = x + (size_t)b * p.N + i;
+          if (i + 3 < p.N && ((p.N & 3) == 0)) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            v.x = src[0];
+            if (i + 1 < p.N) v.y = src[1];
+            if (i + 2 < p.N) v.z = src[2];
+            if (i + 3 < p.N) v.w = src[3];
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
+    }
+    // ---- 2'. controls in registers, fragments, products -----------------------------------------------------
+    const int mi = lane & 15, mg = lane >> 4;
+    float y[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
+    float m_last = r_last;
+    if (do_scale) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
+      m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+    }
+    if (!rvalid) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) y[c] = 0.0f;
+      m_last = 0.0f;
+    }
+    if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi && (NW == 4 || wave < 4)) {    // written by the owning tile only
+      float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+        *reinterpret_cast<U4f*>(dst + 16 * mg + 4 * c4) = U4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
+      if (mg == 0) dst[64] = m_last;
+    }
+    float ve[8], vo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
+    fn_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+    fn_split8(ve, be_hi, be_lo);
+    fn_split8(vo, bo_hi, bo_lo);
+    float* __restrict__ hrow = s_h + rrow * kTapStride;
+#pragma unroll
+    for (int q = 0; q < kMt; ++q) {
+      const fn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      fn_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_hi, zero, 0, 0, 0);
+      fn_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_hi, zero, 0, 0, 0);
+      fn_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_lo, zero, 0, 0, 0);
+      fn_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_lo, zero, 0, 0, 0);
+      ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_lo[q], be_hi, ex, 0, 0, 0);
+      ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_lo[q], bo_hi, ox, 0, 0, 0);
+      const fn_f32x4 ev = ea + ex * (1.0f / kFnLoScale), ov = oa + ox * (1.0f / kFnLoScale);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * (mt0 + q) + 4 * mg + r;                    // 0 .. 31
+        const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);
+        const float o = ov[r];
+        const float g0 = kIr65.win[n] * (e + o);                       // g[n]:    taps 64+n and 64-n
+        hrow[64 + n] = g0;
+        if (n >= 1) {
+          hrow[64 - n] = g0;
+          const float g1 = kIr65.win[64 - n] * (e - o);                // g[64-n]: taps 128-n and n
+          hrow[128 - n] = g1;
+          hrow[n] = g1;
+        }
+      }
+    }
+    if (NW == 4 || wave < 4) {
+      // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
+      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
+      float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (mg == 0) {
+        const float g0 = kIr65.win[32] * part;
+        hrow[96] = g0;
+        hrow[32] = g0;
+        hrow[0] = 0.0f;                                                // h[0] = Hann(128)[0] * hz[-64] = 0
+      }
+    }
+  } else if constexpr (IRMF == 1) {
     // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1] for n = 0..31 as matrix products: B holds the
     // magnitudes of this wavefront's 16 rows (element e of lane (j = lane & 15, g): bin 2 (8 g + e) (+ 1) of
     // row j), D[n = 4 g + r][row j] comes back four taps per lane.  Bin 64 (the 33rd even bin) is a rank-1
@@ -701,9 +818,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       }
     }
   }
-  __syncthreads();                                      // magnitudes consumed: s_u is free
+  if constexpr (IRMF != 2) __syncthreads();             // magnitudes consumed: s_u is free
   DDSP_STAMP();    // 2: IR designed
   // ---- 3. noise tile x[z0-128 .. z0+3967] into s_u (four 16-byte-chunk planes) ----------------------
+  if constexpr (IRMF != 2)
   for (int qd = tid; qd < kFnXLen / 4; qd += 64 * NW) {
     const int i = z0 - 128 + 4 * qd;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -973,20 +1091,31 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       static const int nw_env = [] { const char* e = getenv("DDSP_EXP_NOISE_WAVES"); return e ? atoi(e) : 0; }();
       const int nw = nw_env ? nw_env : ((size_t)grid.x * grid.y > 768 ? 8 : 4);
       static const int ir_mfma_env = [] { const char* e = getenv("DDSP_EXP_NOISE_IR_MFMA"); return e ? atoi(e) : 0; }();
-      if (ir_mfma_env || (flags & DDSP_NOISE_IR_MATRIX_CORES)) {   // experimental: the IR design's cosine transform on the matrix cores
-        if (nw == 8) {
-          if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8, true>), grid, dim3(512), 0, st, ev0, ev1, 0,
-                                           magnitudes, noise, ctl_magnitudes, audio, q);
-          else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 8, true>), grid, dim3(512), 0, st, ev0, ev1, 0,
-                                     magnitudes, noise, ctl_magnitudes, audio, q);
-        } else {
-          if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 4, true>), grid, dim3(256), 0, st, ev0, ev1, 0,
-                                           magnitudes, noise, ctl_magnitudes, audio, q);
-          else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 4, true>), grid, dim3(256), 0, st, ev0, ev1, 0,
-                                     magnitudes, noise, ctl_magnitudes, audio, q);
-        }
+      const int ir_variant = ir_mfma_env ? ir_mfma_env
+                             : (flags & DDSP_NOISE_IR_MATRIX_CORES) ? ((flags & DDSP_NOISE_IR_FROM_REGISTERS) ? 2 : 1) : 0;
+#define DDSP_LAUNCH_NOISE_IR(V)                                                                                       \
+  do {                                                                                                                \
+    if (nw == 8) {                                                                                                    \
+      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8, V>), grid, dim3(512), 0, st, ev0, ev1, 0,       \
+                                       magnitudes, noise, ctl_magnitudes, audio, q);                                  \
+      else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 8, V>), grid, dim3(512), 0, st, ev0, ev1, 0, magnitudes,  \
+                                 noise, ctl_magnitudes, audio, q);                                                    \
+    } else {                                                                                                          \
+      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 4, V>), grid, dim3(256), 0, st, ev0, ev1, 0,       \
+                                       magnitudes, noise, ctl_magnitudes, audio, q);                                  \
+      else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 4, V>), grid, dim3(256), 0, st, ev0, ev1, 0, magnitudes,  \
+                                 noise, ctl_magnitudes, audio, q);                                                    \
+    }                                                                                                                 \
+  } while (0)
+      if (ir_variant == 1) {         // experimental: the IR design's cosine transform on the matrix cores
+        DDSP_LAUNCH_NOISE_IR(1);
         return check_launch();
       }
+      if (ir_variant == 2) {         // ... with the magnitudes going from HBM to the fragments without LDS staging
+        DDSP_LAUNCH_NOISE_IR(2);
+        return check_launch();
+      }
+#undef DDSP_LAUNCH_NOISE_IR
       if (nw == 8) {
         if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8>), grid, dim3(512), 0, st, ev0, ev1, 0,
                                          magnitudes, noise, ctl_magnitudes, audio, q);

@@ -236,8 +236,10 @@ class FilteredNoise(processors.Processor):
   kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
 
   `ir_design` (an attribute, like Harmonic.kernel) selects how the fused kernel turns a frame's 65 magnitudes
-  into 128 taps: 'vector' (default: lanes = frames on the vector ALUs) or 'matrix' (experimental: the cosine
-  transform on the fp16 matrix cores, hi/lo split operands).  Same result within the parity tolerance.
+  into 128 taps: 'vector' (default: lanes = frames on the vector ALUs), 'matrix' (experimental: the cosine
+  transform on the fp16 matrix cores, hi/lo split operands) or 'matrix_direct' (the same with the magnitudes going
+  from HBM to the fragments without LDS staging and the noise tile generated under that latency).  Same result
+  within the parity tolerance.
   """
   ir_design = 'vector'
 
@@ -279,8 +281,11 @@ class FilteredNoise(processors.Processor):
   def _ir_flag(self):
     if self.ir_design == 'matrix':
       return _lib.NOISE_IR_MATRIX_CORES
+    if self.ir_design == 'matrix_direct':
+      return _lib.NOISE_IR_MATRIX_CORES | _lib.NOISE_IR_FROM_REGISTERS
     if self.ir_design != 'vector':
-      raise ValueError("FilteredNoise.ir_design must be 'vector' or 'matrix', got {!r}".format(self.ir_design))
+      raise ValueError("FilteredNoise.ir_design must be 'vector', 'matrix' or 'matrix_direct', got {!r}".format(
+          self.ir_design))
     return 0
 
   def _next_seed(self):

@@ -48,6 +48,8 @@ extern "C" {
 
 /* ---- flags for the FilteredNoise entry points (ddsp/synths.py:153-163) ------------ */
 #define DDSP_NOISE_SCALE_EXP_SIGMOID 0x1u /* scale_fn=core.exp_sigmoid on (mag + initial_bias) */
+#define DDSP_NOISE_IR_FROM_REGISTERS 0x4u /* with DDSP_NOISE_IR_MATRIX_CORES: magnitudes go from HBM to the MFMA fragments
+                                             without LDS staging, the noise tile is generated under the load latency */
 #define DDSP_NOISE_IR_MATRIX_CORES 0x2u   /* ddsp_filtered_noise_f32, fused shape (65 bands, full window): experimental -
                                              the IR design's cosine transform on the fp16 matrix cores (hi/lo split) */
 

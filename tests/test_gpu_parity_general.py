@@ -324,11 +324,13 @@ def test_fft_convolve_time_varying_ir_beyond_the_tiled_kernels_lds_budget(ddsp):
 
 
 # ---- FilteredNoise.ir_design = 'matrix': the IR design's cosine transform on the fp16 matrix cores ----------------
-@pytest.fixture
-def matrix_ir(ddsp):
+@pytest.fixture(params=['matrix', 'matrix_direct'])
+def matrix_ir(request, ddsp):
+  """'matrix': the cosine transform on the matrix cores; 'matrix_direct': the same with the magnitudes going from HBM
+  to the MFMA fragments without LDS staging and the noise tile generated under the load latency."""
   old = ddsp.synths.FilteredNoise.ir_design
-  ddsp.synths.FilteredNoise.ir_design = 'matrix'
-  yield
+  ddsp.synths.FilteredNoise.ir_design = request.param
+  yield request.param
   ddsp.synths.FilteredNoise.ir_design = old
 
 
@@ -347,20 +349,24 @@ def test_filtered_noise_matrix_ir_design_golden(ddsp, matrix_ir, name):
 
 @pytest.mark.parametrize('batch,n_frames,n', [(3, 125, 8000), (1, 1, 64), (2, 62, 3968), (2, 63, 4032), (1, 40, 2543),
                                               (2, 30, 9600), (770, 1, 64)])     # 770 blocks: the 8-wavefront variant
-def test_filtered_noise_matrix_ir_design_vs_oracle_and_vector(ddsp, batch, n_frames, n):
+def test_filtered_noise_matrix_ir_design_vs_oracle_and_vector(ddsp, matrix_ir, batch, n_frames, n):
+  ddsp.synths.FilteredNoise.ir_design = 'vector'
   rng = np.random.default_rng(n_frames + n)
   mags = rng.standard_normal((batch, n_frames, 65)).astype(np.float32)
   mags[0, : max(n_frames // 8, 1)] = -60.0                        # exp_sigmoid's floor (1e-7): fp16 subnormal territory
   mags[-1, n_frames // 2] = 40.0                                  # and its ceiling (2.0)
   noise = rng.uniform(-1.0, 1.0, (batch, n)).astype(np.float32)
   synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
-  vector = npy(synth(mags, noise=noise))
-  ddsp.synths.FilteredNoise.ir_design = 'matrix'
+  vector_out = synth(mags, noise=noise, return_outputs_dict=True)
+  vector = npy(vector_out['signal'])
+  ddsp.synths.FilteredNoise.ir_design = matrix_ir
   try:
-    matrix = npy(synth(mags, noise=noise))
+    matrix_out = synth(mags, noise=noise, return_outputs_dict=True)
+    matrix = npy(matrix_out['signal'])
     generated = npy(synth(mags))                                  # noise generated on chip, same kernel variant
   finally:
     ddsp.synths.FilteredNoise.ir_design = 'vector'
+  np.testing.assert_array_equal(npy(matrix_out['controls']['magnitudes']), npy(vector_out['controls']['magnitudes']))
   rows = slice(0, min(batch, 4))                                  # the oracle on a few rows is enough at batch 770
   ref = O.filtered_noise(mags[rows], noise[rows], 0, dtype=np.float64)
   np.testing.assert_allclose(matrix[rows], ref, rtol=0, atol=noise_tol(ref))

@@ -1,5 +1,6 @@
 """FilteredNoise.ir_design 'vector' (lanes = frames on the vector ALUs) vs 'matrix' (cosine transform on the fp16
-matrix cores) on the bench workload: per-launch time (dispatch events), back-to-back time and agreement.
+matrix cores) vs 'matrix_direct' (the same, magnitudes from HBM to the fragments without LDS staging, noise tile
+generated under the load latency) on the bench workload: per-launch time (dispatch events), back-to-back time and agreement.
 
     python tools/exp_noise_ir.py [batch ...]
 """
@@ -17,7 +18,7 @@ for B in batches:
   noise = ddsp.core.uniform_noise(B, N, seed=1)
   res = {'batch': B}
   outs = {}
-  for design in ('vector', 'matrix'):
+  for design in ('vector', 'matrix', 'matrix_direct'):
     synth = ddsp.synths.FilteredNoise(n_samples=N, window_size=0)
     synth.ir_design = design
     for _ in range(20): synth(mags)
@@ -35,5 +36,5 @@ for B in batches:
     for _ in range(steps): synth(mags)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     res[design] = {'us_per_call_back_to_back': dt * 1e6, 'kernel_us': {k: v[0] / v[1] * 1e3 for k, v in bd.items()}}
-  res['max_abs_diff'] = float((outs['vector'] - outs['matrix']).abs().max())
+  res['max_abs_diff'] = {d: float((outs['vector'] - outs[d]).abs().max()) for d in ('matrix', 'matrix_direct')}
   print(json.dumps(res))
