@@ -129,6 +129,43 @@ __device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const flo
   if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
 }
 
+// The per-frame phase tables of a chunk (one wavefront, lanes = frames): the S-wavefront that builds them in the
+// default kernel is the slowest wavefront of every tick (profiles/r01_timeline_harm_table_b32.txt: 3450 clocks
+// against 2900 for the others, while the T-wavefronts wait 1100 at the barrier), so the TPH variant hands this
+// block of fp64 work to T-wavefront 0, between the issue of its MFMAs and the use of their results.
+// frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
+// which telescopes over j < J to hop sum_{j<J} f_j + (f_J - f_0)(hop-1)/2
+__device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, ChunkTables& t, int lane, int nfr, int K,
+                                                const TableArgs& p) {
+  const double* psum = reinterpret_cast<const double*>(raw + kWtRows * kWtRS);
+  const double before = (psum[0] + psum[1]) + (psum[2] + psum[3]);                 // sum_{j < j0} f_j
+  const float f0_first = raw[kWtRows * kWtRS + 8];
+  const float fj = raw[min(lane, nfr) * kWtRS + 128], fj1 = raw[min(lane + 1, nfr) * kWtRS + 128];
+  const double fa = (double)fj, fb = (double)fj1;
+  const double mine = (lane < nfr) ? fa : 0.0;
+  double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..15)
+  incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
+  incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
+  incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
+  incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
+  const double s_excl = before + (incl - mine);
+  const double run = p.hop_d * s_excl + (fa - (double)f0_first) * p.half_hm1;
+  const double cyc = run * p.inv_sr;
+  const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+  int kA = K, kN = K;
+  if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
+  if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
+  kA = max(min(kA, kN), 0);
+  if (lane <= kWtRows) t.f0[lane] = fj;
+  if (lane < kWtRows) {
+    t.theta[lane] = cyc - floor(cyc);
+    t.w[lane] = fa * p.inv_sr;
+    t.dw[lane] = (fb - fa) * p.inv_sr * p.inv_2hop;
+    t.kA[lane] = kA;
+    t.kN[lane] = kN;
+  }
+}
+
 // One block = 12 wavefronts in two roles, one block per CU.  T-wavefronts (0..3, one per SIMD) own the
 // matrix cores and the loads: each holds its share of the constant sine matrix in registers (two position
 // tiles x two parities) and turns the amplitude planes of a chunk into its table; around that it fetches
@@ -150,7 +187,8 @@ __device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const flo
 // dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
 // reproduces the split), below the fp32 round-off of the sum itself.
 // NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
-template <int W, int NK, bool ONE_TILE>
+// TPH (experimental, flag DDSP_HARM_TABLE_PHASE_ON_T): the phase tables on T-wavefront 0 instead of S-wavefront 7
+template <int W, int NK, bool ONE_TILE, bool TPH = false>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
@@ -205,6 +243,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             alo[par][tt][ks][e] = (_Float16)((v - (float)h) * kWtLoScale);
           }
     int lb = first_b, lc = first_c;               // position of the chunk whose rows are fetched next
+    int qb = first_b, qc = first_c;               // TPH: position of the chunk whose phase tables are built next
 
     for (int tick = -3; tick < n_my; ++tick) {
       DDSP_WT_STAMP(0);
@@ -228,6 +267,14 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
       const float ptail = f0row[min(jt, F - 1)];
       const float f0_first = f0row[0];
       DDSP_WT_STAMP(1);
+      // TPH: the phase tables of chunk tick+2 (rows staged during the previous tick), on T-wavefront 0
+      const bool tph_now = TPH && rw == 0 && tick + 2 >= 0 && tick + 2 < n_my;
+      int tph_nfr = 0;
+      if (TPH && tick + 2 >= 0 && tick + 2 < n_my) {
+        tph_nfr = min(kWtFrames, F - qc * kWtFrames);
+        DDSP_WT_ADVANCE(qb, qc);
+      }
+      if (tph_now && tick + 1 < 0) wt_phase_tables(raw_all[(tick + 2) & 1], t_all[(tick + 2) % 3], lane, tph_nfr, K, p);
       // ---------------- table of chunk tick+1: O and E on the quarter range -----------------------------------
       if (tick + 1 >= 0 && tick + 1 < n_my) {
         // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row j][32 ks + 8 g + e]
@@ -256,6 +303,8 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             for (int tt = 0; tt < 2; ++tt)
               accx[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[par][tt], 0, 0, 0);
           }
+        // TPH: vector work that does not depend on the products, issued while the matrix pipe runs
+        if (tph_now) wt_phase_tables(raw_all[(tick + 2) & 1], t_all[(tick + 2) % 3], lane, tph_nfr, K, p);
         // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
         float* trow = tab_all[(tick + 1) & 1] + mi * kWtTS + kWtH;
 #pragma unroll
@@ -454,7 +503,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
         // frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
         // which telescopes over j < J to hop sum_{j<J} f_j + (f_J - f_0)(hop-1)/2
-        if (rw == 7) {
+        if (!TPH && rw == 7) {
           const double* psum = reinterpret_cast<const double*>(raw + kWtRows * kWtRS);
           const double before = (psum[0] + psum[1]) + (psum[2] + psum[3]);                 // sum_{j < j0} f_j
           const float f0_first = raw[kWtRows * kWtRS + 8];
@@ -539,19 +588,26 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-#define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
+#define DDSP_LAUNCH_TABLE(W, NK, TPH)                                                                         \
   do {                                                                                                        \
     if (p.hop == 64)                                                                                          \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, TPH>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, ctl_amp, ctl_hd, p);                                                                        \
     else                                                                                                      \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false, TPH>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, ctl_amp, ctl_hd, p);                                                                        \
   } while (0)
+  static const bool tph_env = getenv("DDSP_EXP_TABLE_PHASE_ON_T") != nullptr;
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
-  if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);
-  else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
-  else DDSP_LAUNCH_TABLE(8, 2);
+  if (tph_env || (flags & DDSP_HARM_TABLE_PHASE_ON_T)) {     // experimental: phase tables on a T-wavefront
+    if (K <= 64) DDSP_LAUNCH_TABLE(6, 1, true);
+    else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2, true);
+    else DDSP_LAUNCH_TABLE(8, 2, true);
+  } else {
+    if (K <= 64) DDSP_LAUNCH_TABLE(6, 1, false);
+    else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2, false);
+    else DDSP_LAUNCH_TABLE(8, 2, false);
+  }
 #undef DDSP_LAUNCH_TABLE
   if (p.dbg) {
     static long long host[3 * 64 * 8];
