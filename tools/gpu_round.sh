@@ -40,3 +40,9 @@ echo "== streaming latency (VST frame call)"
 timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json
 echo "== FilteredNoise IR design: vector ALUs vs matrix cores (experimental variant)"
 timeout 120 python tools/exp_noise_ir.py 32 128 2>&1 | tail -2 | tee $OUT/noise_ir_vector_vs_matrix.json
+echo "== bench with the experimental kernel variants (whole step, batch 32 and 128)"
+for V in "--harm-kernel table_tphase" "--noise-ir matrix" "--noise-ir matrix_direct" "--harm-kernel table_tphase --noise-ir matrix_direct"; do
+  for B in 32 128; do
+    timeout 300 python bench.py --batch $B --no-cpu-baseline --no-aux $V 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$V', 'batch', $B, 'ms_per_step', round(r['ms_per_step'],5), 'value', round(r['value']), r['kernel_breakdown_us_isolated'])" | tee -a $OUT/bench_variants.txt
+  done
+done
