@@ -66,6 +66,11 @@ def parse_args():
   ap.add_argument('--no-aux', action='store_true',
                   help='skip the auxiliary yardsticks after the timed region (measured device-copy bandwidth, '
                        'the f0 = 200 Hz regime of SURVEY.md 8d)')
+  ap.add_argument('--harm-kernel', choices=['auto', 'direct', 'table_tphase'], default='auto',
+                  help="Harmonic.kernel: 'auto' (default), 'direct' (sum harmonic by harmonic) or the experimental "
+                       "'table_tphase' variant of the wavetable kernel")
+  ap.add_argument('--noise-ir', choices=['vector', 'matrix', 'matrix_direct'], default='vector',
+                  help="FilteredNoise.ir_design: 'vector' (default) or the experimental matrix-core designs")
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
   return ap.parse_args()
@@ -151,7 +156,8 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
           'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
           'no collective' % world,
           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
-                     else 'one stream, back to back'},
+                     else 'one stream, back to back',
+          'kernel_variants': {'harmonic': a.harm_kernel, 'noise_ir_design': a.noise_ir}},
       'roofline': {
           'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
           'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -225,6 +231,7 @@ def main():
   dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
   harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
   fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
+  harmonic.kernel, fnoise.ir_design = a.harm_kernel, a.noise_ir          # instance attributes: the defaults unless asked
 
   # The two Processor calls of a step are independent (nothing on this path joins them; the
   # reference's Add would): Harmonic and FilteredNoise are issued on two free-running HIP streams so
