@@ -46,3 +46,6 @@ for V in "--harm-kernel table_tphase" "--noise-ir matrix" "--noise-ir matrix_dir
     timeout 300 python bench.py --batch $B --no-cpu-baseline --no-aux $V 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$V', 'batch', $B, 'ms_per_step', round(r['ms_per_step'],5), 'value', round(r['value']), r['kernel_breakdown_us_isolated'])" | tee -a $OUT/bench_variants.txt
   done
 done
+echo "== timelines of the experimental variants"
+DDSP_EXP_TABLE_PHASE_ON_T=1 timeout 120 python tools/exp_table_timeline.py 32 2>&1 | grep -A40 "launch 2" | tee $OUT/timeline_harm_table_tphase_b32.txt | head -5
+for FL in 0x2 0x6; do for B in 32 128; do timeout 120 python tools/exp_timeline_noise.py $B $FL 2>&1 | tail -9 | tee -a $OUT/timeline_noise_variants.txt; done; done
