@@ -268,7 +268,6 @@ inline bool is_live(unsigned long long live, int lane) { return lane >= 0 && lan
 // ---------------------------------------------------------------------------------------------------
 inline void __syncthreads() { ddsp_emu::yield_to_scheduler(ddsp_emu::kBlockBarrier); }
 inline void ddsp_emu_wave_sync() {
-  struct None {};
   ddsp_emu::wave_op<int, int>(1, 0, 0, [](ddsp_emu::WaveOp&, unsigned long long) {});
 }
 // within a wavefront the hardware runs in lockstep; here its lanes run one after another between
