@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
     }
     // ---- 2'. controls in registers, fragments, products -----------------------------------------------------
-    const int mi = lane & 15, mg = lane >> 4;
+    const int mg = lane >> 4;
     float y[16];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
