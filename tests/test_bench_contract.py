@@ -172,6 +172,100 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   # ...and the headline inputs were put back afterwards (nothing after the regime reads them, but a later edit might)
 
 
+def _mock_device(monkeypatch, bench, calls):
+  """Everything bench.main() touches on the device, replaced by stand-ins (shared by the two main() tests)."""
+  import numpy as np
+  import torch
+  import ddsp_amd
+  from ddsp_amd import _lib, build
+
+  class _Stream:
+    pass
+
+  class _Event:
+    def __init__(self, enable_timing=False):
+      pass
+
+    def record(self):
+      pass
+
+    def elapsed_time(self, other):
+      return 1.0
+  monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+  monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
+  monkeypatch.setattr(torch.cuda, 'Stream', _Stream)
+  monkeypatch.setattr(torch.cuda, 'Event', _Event)
+  monkeypatch.setattr(torch.cuda, 'current_stream', lambda: _Stream())
+  monkeypatch.setattr(torch.cuda, 'set_stream', lambda s: None)
+  monkeypatch.setattr(torch.cuda, 'synchronize', lambda: None)
+  real_empty, real_tensor = torch.empty, torch.tensor
+  monkeypatch.setattr(torch, 'empty', lambda *a, device=None, **k: real_empty(*a, **k))
+  monkeypatch.setattr(torch, 'tensor', lambda *a, device=None, **k: real_tensor(*a, **k))
+  monkeypatch.setattr(build, 'build', lambda *a, **k: None)
+  monkeypatch.setattr(_lib, 'load', lambda: None)
+
+  def fake_begin(names, max_records=0, stride=1):
+    calls['names'] = names
+
+  def fake_end():
+    if calls['names'] is None:
+      return {'harm_table_kernel': (0.06, 3), 'noise_fused65_kernel': (0.075, 3)}
+    return {calls['names'][0]: (3.1, 100)}
+  monkeypatch.setattr(_lib, 'profile_begin', fake_begin)
+  monkeypatch.setattr(_lib, 'profile_end', fake_end)
+  monkeypatch.setattr(ddsp_amd.core, 'tf_float32', lambda x: torch.as_tensor(np.asarray(x, np.float32)))
+
+  class _Harmonic:
+    def __init__(self, n_samples, sample_rate):
+      self.n = n_samples
+
+    def __call__(self, amplitudes, harmonic_distribution, f0_hz):
+      calls['harm'] = calls.get('harm', 0) + 1
+      return torch.zeros(amplitudes.shape[0], self.n)
+
+  class _Noise:
+    def __init__(self, n_samples, window_size, seed):
+      self.n = n_samples
+
+    def __call__(self, magnitudes):
+      calls['noise'] = calls.get('noise', 0) + 1
+      return torch.zeros(magnitudes.shape[0], self.n)
+  monkeypatch.setattr(ddsp_amd.synths, 'Harmonic', _Harmonic)
+  monkeypatch.setattr(ddsp_amd.synths, 'FilteredNoise', _Noise)
+  monkeypatch.setattr(bench, 'cpu_baseline', lambda a: {'value': 1.0, 'unit': 'Msamples/s', 'cores': 1,
+                                                        'kind': 'port', 'sample': 'stub'})
+
+
+def test_main_multi_rank_branches_with_device_and_collectives_mocked_out(bench, monkeypatch, capsys):
+  """The N > 1 branches of bench.main() as rank 0 of a world of 2 (process group, barriers, the max-over-ranks
+  reduction, --allgather, no CPU leg): collectives are no-ops here, only the control flow is exercised."""
+  import torch.distributed as dist
+  calls = {}
+  _mock_device(monkeypatch, bench, calls)
+  log = []
+  monkeypatch.setattr(dist, 'init_process_group', lambda *a, **k: log.append(('init', a, sorted(k))))
+  monkeypatch.setattr(dist, 'barrier', lambda *a, **k: log.append('barrier'))
+  monkeypatch.setattr(dist, 'all_reduce', lambda t, op=None: log.append('all_reduce'))
+  monkeypatch.setattr(dist, 'all_gather_into_tensor', lambda out, x: log.append('all_gather'))
+  monkeypatch.setattr(dist, 'destroy_process_group', lambda: log.append('destroy'))
+  for key, value in (('WORLD_SIZE', '2'), ('RANK', '0'), ('LOCAL_RANK', '0')):
+    monkeypatch.setenv(key, value)
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '5', '--warmup', '2', '--batch', '2',
+                                    '--n-frames', '10', '--n-samples', '640', '--allgather'])
+  bench.main()
+  out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')]
+  assert len(out) == 1
+  line = json.loads(out[0])
+  assert line['n_gpus'] == 2 and line['config']['global_batch'] == 4 and line['scaling'] == 'weak'
+  assert line['cpu_baseline'] is None and 'allgather_ms' in line and 'aux_error' not in line
+  assert line['value'] > 0 and line['config']['parallelism'].startswith('batch-sharded x2')
+  assert log[0][0] == 'init' and log[0][1][0] == 'nccl' and log[-1] == 'destroy'
+  assert log.count('all_reduce') >= 2 and log.count('all_gather') == 13 and log.count('barrier') >= 6
+  with pytest.raises(SystemExit, match='WORLD_SIZE'):
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4'])
+    bench.main()
+
+
 def test_cpu_baseline_leg_runs_concurrent_workers_and_falls_back(monkeypatch):
   from oracle import cpu_baseline as leg
   r = leg.measure(2, 2, 10, 8, 9, 640, 16000, 200.0, timeout_s=60.0)
