@@ -115,6 +115,26 @@ def test_constructor_defaults_match_reference():        # synths.py:59-66, 153-1
     assert hasattr(cls, 'get_controls') and hasattr(cls, 'get_signal')   # dags.py:44 duck typing
 
 
+def test_constructor_defaults_of_the_neighbouring_processors():   # effects.py:123-129, 204-214; processors.py:183, 240; synths.py:27
+  from ddsp_amd import effects
+  e = effects.ExpDecayReverb()
+  assert (e.name, e.trainable, e._reverb_length, e._add_dry) == ('exp_decay_reverb', False, 48000, True)
+  assert e._scale_fn is core.exp_sigmoid
+  r = effects.Reverb()
+  assert (r.name, r.trainable, r._reverb_length, r._add_dry) == ('reverb', False, 48000, True)
+  f = effects.FilteredNoiseReverb()
+  assert (f.name, f._n_frames, f._n_filter_banks) == ('filtered_noise_reverb', 1000, 16)
+  assert (f._synth.n_samples, f._synth.window_size, f._synth.initial_bias) == (48000, 257, -3.0)
+  assert effects.FIRFilter().window_size == 257 and effects.FIRFilter().name == 'fir_filter'
+  assert processors.Mix().name == 'mix' and synths.TensorToAudio().name == 'tensor_to_audio'
+  assert processors.Crop(frame_size=64).crop_location == 'back'
+  assert synths.Harmonic.kernel == 'auto' and synths.FilteredNoise.ir_design == 'vector'     # the measured defaults
+  with pytest.raises(ValueError, match='gain'):                       # effects_test.py:49-52 (raised before any launch)
+    effects.ExpDecayReverb(trainable=False).get_controls(np.zeros((1, 8), np.float32))
+  with pytest.raises(ValueError, match='ir'):
+    effects.Reverb(trainable=False).get_controls(np.zeros((1, 8), np.float32))
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
 def test_no_gpu_fails_loudly_not_silently():
   h = synths.Harmonic(n_samples=640)
