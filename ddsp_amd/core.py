@@ -41,6 +41,19 @@ def _stream():
   return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+def require_no_grad(op, *tensors):
+  """The raw kernel wrappers return tensors without a grad_fn.  Where no torch.autograd node covers an op, an input
+  that requires grad must fail loudly instead of silently cutting the graph (a branch summed through Add would just
+  stop training): the differentiable entries are the Processors' __call__ (Harmonic, FilteredNoise,
+  Reverb, ...) and FilteredNoise.get_signal."""
+  if torch.is_grad_enabled():
+    for t in tensors:
+      if isinstance(t, torch.Tensor) and t.requires_grad:
+        raise NotImplementedError(
+            '{}: an input requires grad, but this entry point has no backward pass on the MI355X path; call it '
+            'under torch.no_grad() / on detached tensors, or go through the Processor __call__'.format(op))
+
+
 _ws_bytes_cache = {}
 
 
@@ -55,16 +68,22 @@ def cached_workspace_bytes(fn_name, *shape):
 
 
 class Workspace:
-  """Grow-only scratch buffer in HBM, reused across calls on one stream."""
+  """Grow-only scratch buffers in HBM, one per (device, stream): kernels enqueued on different streams never share
+  scratch, and a buffer is only ever replaced by work enqueued behind its last user on the same stream (the caching
+  allocator hands a freed block back to the stream it was allocated on).  A Processor instance may therefore be
+  called from several streams; each stream pays for its own scratch."""
 
   def __init__(self):
-    self._buf = None
+    self._bufs = {}
 
   def get(self, nbytes, device):
     nbytes = max(int(nbytes), 16)
-    if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
-      self._buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return self._buf
+    key = (device, _stream() if device.type == 'cuda' else None)
+    buf = self._bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+      buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+      self._bufs[key] = buf
+    return buf
 
 
 _default_ws = Workspace()
@@ -123,6 +142,7 @@ def nested_lookup(nested_key, nested_dict, delimiter='/'):
 def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
   """Exponentiated sigmoid: max_value * sigmoid(x)**log(exponent) + threshold."""
   x = tf_float32(x)
+  require_no_grad('core.exp_sigmoid', x)
   out = torch.empty_like(x)
   rc = _lib.load().ddsp_exp_sigmoid_f32(x.data_ptr(), out.data_ptr(), x.numel(),
                                         float(exponent), float(max_value), float(threshold),
@@ -190,6 +210,7 @@ def _resample_call(inputs, n_timesteps, method, add_endpoint):
   path's own forms (ddsp_resample_f32), every other combination to the general one (ddsp_resample_ex_f32)."""
   inputs = inputs.contiguous()
   b, f, c = inputs.shape
+  require_no_grad('core.resample / upsample_with_windows', inputs)
   out = torch.empty((b, n_timesteps, c), dtype=torch.float32, device=inputs.device)
   if b == 0 or c == 0:
     return out
@@ -208,6 +229,7 @@ def _resample_call(inputs, n_timesteps, method, add_endpoint):
 def normalize_harmonics(harmonic_distribution, f0_hz=None, sample_rate=None):
   """core.normalize_harmonics (ddsp/core.py:894-907): optional Nyquist removal, then sum-normalise."""
   harmonic_distribution = tf_float32(harmonic_distribution)
+  require_no_grad('core.normalize_harmonics', harmonic_distribution, f0_hz)
   b, f, k = harmonic_distribution.shape
   bandlimit = sample_rate is not None and f0_hz is not None
   f0 = tf_float32(f0_hz) if bandlimit else torch.zeros((b, f, 1), device=harmonic_distribution.device)
@@ -256,6 +278,7 @@ def oscillator_bank(frequency_envelopes, amplitude_envelopes, sample_rate=16000,
   del use_angular_cumsum
   frequency_envelopes = tf_float32(frequency_envelopes)
   amplitude_envelopes = tf_float32(amplitude_envelopes)
+  require_no_grad('core.oscillator_bank', frequency_envelopes, amplitude_envelopes)
   if frequency_envelopes.dim() != 3 or frequency_envelopes.shape != amplitude_envelopes.shape:
     raise ValueError('frequency and amplitude envelopes must both be [batch, n_samples, n_sinusoids]'
                      ', got {} and {}'.format(tuple(frequency_envelopes.shape),
@@ -343,6 +366,8 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
   frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
   if harmonic_shifts is not None:
     harmonic_shifts = tf_float32(harmonic_shifts)
+  require_no_grad('core.harmonic_synthesis (Harmonic.__call__ is the differentiable entry)', frequencies, amplitudes,
+                  harmonic_shifts, harmonic_distribution)
   if harmonic_distribution is None:
     if harmonic_shifts is not None:                          # n_harmonics from the shifts (core.py:1082-1084)
       return _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, None, int(n_samples),
@@ -421,6 +446,7 @@ def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=
   """
   frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
   flags = _lib.HARM_AMP_LINEAR if amp_resample_method == 'linear' else 0
+  require_no_grad('core.streaming_harmonic_synthesis', frequencies, amplitudes, harmonic_distribution, initial_phase)
   if harmonic_distribution is None:
     harmonic_distribution = torch.ones_like(amplitudes)
     flags |= _lib.HARM_INPUTS_ARE_AMPLITUDES
@@ -428,6 +454,11 @@ def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=
   b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
   n = int(n_samples)
   _check_amp_method(amp_resample_method, f, n)
+  if amp_resample_method not in ('linear', 'window'):
+    # the closed-form kernel knows the two envelopes the shipped configs use; 'nearest' / 'cubic' must not
+    # silently fall back to the 'window' envelope
+    raise NotImplementedError("streaming_harmonic_synthesis: amp_resample_method '{}' is not built on the "
+                              "MI355X path (use 'linear' or 'window').".format(amp_resample_method))
   if n % f:
     raise ValueError('streaming_harmonic_synthesis needs n_samples ({}) to be a multiple of '
                      'n_frames ({}) on the MI355X path.'.format(n, f))
@@ -458,6 +489,7 @@ def frequency_impulse_response(magnitudes, window_size=0):
   """core.frequency_impulse_response: [B,F,M] (or [B,M]) magnitudes -> causal windowed IR."""
   magnitudes = tf_float32(magnitudes)
   squeeze = magnitudes.dim() == 2
+  require_no_grad('core.frequency_impulse_response (FilteredNoise is the differentiable entry)', magnitudes)
   if squeeze:
     magnitudes = magnitudes[:, None, :].contiguous()
   b, f, m = magnitudes.shape
@@ -498,6 +530,8 @@ def fft_convolve(audio, impulse_response, padding='same', delay_compensation=-1)
   audio, impulse_response = tf_float32(audio), tf_float32(impulse_response)
   if audio.dim() != 2:
     raise ValueError('audio must be [batch, audio_timesteps], got {}'.format(tuple(audio.shape)))
+  require_no_grad('core.fft_convolve (effects.Reverb / FilteredNoise are the differentiable entries)', audio,
+                  impulse_response)
   batch_size, audio_size = audio.shape
   if impulse_response.dim() == 2:
     impulse_response = impulse_response[:, None, :].contiguous()

@@ -58,6 +58,28 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// ---- individually rounded fp32 steps ---------------------------------------------------------
+// hipcc contracts a*b+c into an FMA by default, and the HIP header's __fmul_rn / __fadd_rn are
+// plain `*` / `+` (no OCML rounded ops in this build), so they do not stop it: round 1's 'linear'
+// resample differed from TF's op order by one ulp on the MI355X because of exactly that.  These
+// do: the pragma drops the `contract` flag from the instruction, and it survives inlining.
+__device__ __forceinline__ float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float rn_sub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float rn_div(float a, float b) {
+#pragma clang fp contract(off)
+  return a / b;
+}
+
 // branch-free core.exp_sigmoid for the default constants' shape: the limits are right on both
 // tails (x -> -inf: exp2 overflows to +inf, log2(inf) = inf, exp2(-inf) = 0; x -> +inf: 1).
 __device__ __forceinline__ float exp_sigmoid_fast(float x, float log_exponent, float max_value,

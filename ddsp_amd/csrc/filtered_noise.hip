@@ -1414,11 +1414,12 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
       const float w = 0.5f - 0.5f * cospif((float)r / (float)hop);
       ob[i] = xb[(size_t)j * C + c] * (1.0f - w) + xb[(size_t)hi * C + c] * w;
     } else {
-      const float pos = (float)t * scale;
+      // every step individually rounded (no FMA contraction of t*scale - lo: found on the MI355X in round 1)
+      const float pos = rn_mul((float)t, scale);
       const float lo = floorf(pos);
       const int lo_i = (int)lo, hi_i = min((int)ceilf(pos), F - 1);
       const float top = xb[(size_t)lo_i * C + c], bottom = xb[(size_t)hi_i * C + c];
-      ob[i] = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+      ob[i] = rn_add(top, rn_mul(rn_sub(bottom, top), rn_sub(pos, lo)));
     }
   }
 }

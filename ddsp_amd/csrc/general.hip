@@ -28,6 +28,17 @@ namespace general {
 
 constexpr int kThreads = 256;
 
+// Individually rounded fp32 steps (see csrc/common.h: the HIP header's __fmul_rn is a plain `*` that hipcc
+// contracts into FMAs).  g++ (the host build of tests/hip_emu) never contracts on x86-64 without -mfma.
+#if defined(__clang__)
+#define DDSP_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define DDSP_NO_CONTRACT
+#endif
+__device__ __forceinline__ float rn_mul(float a, float b) { DDSP_NO_CONTRACT return a * b; }
+__device__ __forceinline__ float rn_add(float a, float b) { DDSP_NO_CONTRACT return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { DDSP_NO_CONTRACT return a - b; }
+
 __device__ __forceinline__ size_t global_thread() { return (size_t)blockIdx.x * kThreads + threadIdx.x; }
 __device__ __forceinline__ size_t grid_threads() { return (size_t)gridDim.x * kThreads; }
 
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void resample_ex_kernel(const float* __re
       const float w = 0.5f - 0.5f * cospif((float)r / (float)p.hop);
       v = xb[(size_t)j * p.C + c] * (1.0f - w) + xb[(size_t)hi * p.C + c] * w;
     } else {
-      const float pos = (float)t * p.scale;           // legacy scaler: out * scale
+      const float pos = rn_mul((float)t, p.scale);  // legacy scaler: out * scale (rounded product, never an FMA)
       if (p.method == DDSP_RESAMPLE_NEAREST) {
         const int src = min((int)(p.align_corners ? roundf(pos) : floorf(pos)), p.F - 1);
         v = xb[(size_t)src * p.C + c];
@@ -83,20 +94,20 @@ __global__ __launch_bounds__(kThreads) void resample_ex_kernel(const float* __re
         const float lo = floorf(pos);
         const int lo_i = min(max((int)lo, 0), p.F - 1), hi_i = min((int)ceilf(pos), p.F - 1);
         const float top = xb[(size_t)lo_i * p.C + c], bottom = xb[(size_t)hi_i * p.C + c];
-        v = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+        v = rn_add(top, rn_mul(rn_sub(bottom, top), rn_sub(pos, lo)));
       } else {                                          // DDSP_RESAMPLE_CUBIC
         const float lo = floorf(pos);
         const int src = (int)lo;
-        const int offset = (int)lrintf((pos - lo) * 1024.0f);
+        const int offset = (int)lrintf(rn_mul(rn_sub(pos, lo), 1024.0f));
         const float w0 = cubic_far(offset), w1 = cubic_near(offset);
         const float w2 = cubic_near(1024 - offset), w3 = cubic_far(1024 - offset);
         const int i0 = min(max(src - 1, 0), p.F - 1), i1 = min(max(src, 0), p.F - 1);
         const int i2 = min(max(src + 1, 0), p.F - 1), i3 = min(max(src + 2, 0), p.F - 1);
         // Interpolate1D: v0 w0 + v1 w1 + v2 w2 + v3 w3, fp32, left to right, no contraction
-        float acc = __fmul_rn(xb[(size_t)i0 * p.C + c], w0);
-        acc = __fadd_rn(acc, __fmul_rn(xb[(size_t)i1 * p.C + c], w1));
-        acc = __fadd_rn(acc, __fmul_rn(xb[(size_t)i2 * p.C + c], w2));
-        v = __fadd_rn(acc, __fmul_rn(xb[(size_t)i3 * p.C + c], w3));
+        float acc = rn_mul(xb[(size_t)i0 * p.C + c], w0);
+        acc = rn_add(acc, rn_mul(xb[(size_t)i1 * p.C + c], w1));
+        acc = rn_add(acc, rn_mul(xb[(size_t)i2 * p.C + c], w2));
+        v = rn_add(acc, rn_mul(xb[(size_t)i3 * p.C + c], w3));
       }
     }
     ob[i] = v;
@@ -151,10 +162,10 @@ __global__ __launch_bounds__(kThreads) void harmonic_envelopes_kernel(
   for (size_t i = global_thread(); i < total; i += grid_threads()) {
     const size_t row = i / K;
     const int k = (int)(i - row * K);
-    float fk = __fmul_rn(f0[row], (float)(k + 1));
-    if (shifts != nullptr) fk = __fmul_rn(fk, __fadd_rn(1.0f, shifts[i]));
+    float fk = rn_mul(f0[row], (float)(k + 1));
+    if (shifts != nullptr) fk = rn_mul(fk, rn_add(1.0f, shifts[i]));
     freq_out[i] = fk;
-    amp_out[i] = (hd != nullptr) ? __fmul_rn(amplitudes[row], hd[i]) : amplitudes[row];
+    amp_out[i] = (hd != nullptr) ? rn_mul(amplitudes[row], hd[i]) : amplitudes[row];
   }
 }
 
@@ -220,8 +231,8 @@ __global__ __launch_bounds__(kThreads) void f0grad_c_kernel(
     for (int k = 0; k < p.K; ++k) {
       const float kf = (float)(k + 1);
       // the audio-rate mask of oscillator_bank on the interpolated frequency, TF's fp32 op order
-      const float top = __fmul_rn(fj, kf), bot = __fmul_rn(fj1, kf);
-      const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+      const float top = rn_mul(fj, kf), bot = rn_mul(fj1, kf);
+      const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp));
       if (fk >= p.nyquist) continue;
       double ph = cyc * (double)(k + 1);
       ph -= floor(ph);
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const float* __restrict__
     const float m = mix_level[i / C];
     const float level_one = sqrtf(fabsf(m));
     const float level_two = 1.0f - sqrtf(fabsf(m - 1.0f));
-    out[i] = __fadd_rn(__fmul_rn(level_one, signal_one[i]), __fmul_rn(level_two, signal_two[i]));
+    out[i] = rn_add(rn_mul(level_one, signal_one[i]), rn_mul(level_two, signal_two[i]));
   }
 }
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kSynthThreads) void harm_synth_kernel(
     for (; k < kN; ++k) {
       const float kf = (float)(k + 1);
       const float top = fj * kf, bot = fj1 * kf;
-      const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+      const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp));
       const float s = (fk >= p.nyquist) ? 0.0f : sin_rev(frac_phase(theta, kf));
       acc0 = fmaf(a0p[k], s, acc0);
       acc1 = fmaf(a1p[k], s, acc1);
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, 8) void harm_fused_kernel(
           const float kf = (float)(k + 1);
           const float top = fj * kf, bot = fj1 * kf;
           // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
-          const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp));
+          const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp));
           const float sv = (fk >= p.nyquist) ? 0.0f : sin_rev(frac_phase(theta, kf));
           const float x0 = __builtin_nontemporal_load(a0p + k), x1 = __builtin_nontemporal_load(a1p + k);
           acc0 = fmaf(x0, sv, acc0);
@@ -1047,8 +1047,8 @@ __global__ __launch_bounds__(64 * NW) void harm_bwd_pq_kernel(const float* __res
       for (int r = 0; r < p.hop; ++r) {
         const float4 v = sq[r];
         // audio-rate mask on the interpolated frequency, TF's fp32 op order (core.py:942-944)
-        const float fk0 = __fadd_rn(top0, __fmul_rn(__fsub_rn(bot0, top0), v.w));
-        const float fk1 = __fadd_rn(top1, __fmul_rn(__fsub_rn(bot1, top1), v.w));
+        const float fk0 = rn_add(top0, rn_mul(rn_sub(bot0, top0), v.w));
+        const float fk1 = rn_add(top1, rn_mul(rn_sub(bot1, top1), v.w));
         const float s0 = (fk0 >= p.nyquist || k0 >= kN) ? 0.0f : sin_rev(v.x * kf0);
         const float s1 = (fk1 >= p.nyquist || k1 >= kN) ? 0.0f : sin_rev(v.x * kf1);
         P0 = fmaf(v.y, s0, P0); Q0 = fmaf(v.z, s0, Q0);
@@ -1330,45 +1330,46 @@ __global__ __launch_bounds__(64) void harm_tf_order_kernel(
   float phase = 0.0f, chunk_phase = 0.0f, offset = 0.0f, offset_sum = 0.0f;
   for (int t = 0; t < N; ++t) {
     // frequency envelope: resample(f0*ratio) 'linear' (core.py:1091,1102,613-621)
-    const float pos = (float)t * scale;
+    const float pos = rn_mul((float)t, scale);
     const float lo = floorf(pos);
+    const float lerp_w = rn_sub(pos, lo);
     const int lo_i = (int)lo, hi_i = min((int)ceilf(pos), F - 1);
-    const float top = __fmul_rn(f0[lo_i], ratio), bottom = __fmul_rn(f0[hi_i], ratio);
-    const float f = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), pos - lo));
+    const float top = rn_mul(f0[lo_i], ratio), bottom = rn_mul(f0[hi_i], ratio);
+    const float f = rn_add(top, rn_mul(rn_sub(bottom, top), lerp_w));
     // amplitude envelope: resample(amplitudes*distribution) 'window' or 'linear' (core.py:1097,1103)
     float a;
     if (amp_linear) {
-      const float atop = __fmul_rn(amp[lo_i], hd[(size_t)lo_i * K + kk]);
-      const float abot = __fmul_rn(amp[hi_i], hd[(size_t)hi_i * K + kk]);
-      a = __fadd_rn(atop, __fmul_rn(__fsub_rn(abot, atop), pos - lo));
+      const float atop = rn_mul(amp[lo_i], hd[(size_t)lo_i * K + kk]);
+      const float abot = rn_mul(amp[hi_i], hd[(size_t)hi_i * K + kk]);
+      a = rn_add(atop, rn_mul(rn_sub(abot, atop), lerp_w));
     } else {
       const int j = t / hop, r = t - j * hop, j1 = min(j + 1, F - 1);
       // periodic Hann(2*hop) in fp32: tf.signal.hann_window (core.py:698)
       const float w_hi = 0.5f - 0.5f * cosf(two_pi * (float)(hop + r) / (float)(2 * hop));
       const float w_lo = 0.5f - 0.5f * cosf(two_pi * (float)r / (float)(2 * hop));
-      const float x0 = __fmul_rn(amp[j], hd[(size_t)j * K + kk]);
-      const float x1 = __fmul_rn(amp[j1], hd[(size_t)j1 * K + kk]);
-      a = __fadd_rn(__fmul_rn(x0, w_hi), __fmul_rn(x1, w_lo));      // overlap_and_add of 2 frames
+      const float x0 = rn_mul(amp[j], hd[(size_t)j * K + kk]);
+      const float x1 = rn_mul(amp[j1], hd[(size_t)j1 * K + kk]);
+      a = rn_add(rn_mul(x0, w_hi), rn_mul(x1, w_lo));      // overlap_and_add of 2 frames
     }
     if (f >= nyquist) a = 0.0f;                                        // remove_above_nyquist
-    const float omega = __fdiv_rn(__fmul_rn(f, two_pi), sample_rate);   // core.py:947-948
+    const float omega = rn_div(rn_mul(f, two_pi), sample_rate);   // core.py:947-948
     float ph;
     if (!angular) {
-      phase = __fadd_rn(phase, omega);                                 // tf.cumsum, sequential
+      phase = rn_add(phase, omega);                                 // tf.cumsum, sequential
       ph = phase;
     } else {                                                           // angular_cumsum, chunk 1000
       if (t % 1000 == 0) {
         if (t > 0) {
           // offsets: previous chunks' final phases mod 2pi, cumulatively summed then mod 2pi
-          offset_sum = __fadd_rn(offset_sum, fmodf(chunk_phase, two_pi));
+          offset_sum = rn_add(offset_sum, fmodf(chunk_phase, two_pi));
           offset = fmodf(offset_sum, two_pi);
         }
         chunk_phase = 0.0f;
       }
-      chunk_phase = __fadd_rn(chunk_phase, omega);
-      ph = fmodf(__fadd_rn(chunk_phase, offset), two_pi);
+      chunk_phase = rn_add(chunk_phase, omega);
+      ph = fmodf(rn_add(chunk_phase, offset), two_pi);
     }
-    float v = live ? __fmul_rn(a, sinf(ph)) : 0.0f;
+    float v = live ? rn_mul(a, sinf(ph)) : 0.0f;
     v = wave_sum_dpp(v);                                               // reduce_sum over harmonics
     if (threadIdx.x == 0) {
       if (gridDim.x == 1) audio[(size_t)b * N + t] = v;

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
               for (int k = kA; k < kN; ++k) {
                 const float kf = (float)(k + 1);
                 const float top = fj * kf, bot = fj1 * kf;
-                const float fk = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), lerp[u]));
+                const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp[u]));
                 const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
                 const float c0 = (float)pl[0] + (float)pl[2 * kWtRows * kWtPS] * (1.0f / kWtLoScale);
                 const float c1 = (float)pl[kWtPS] + (float)pl[2 * kWtRows * kWtPS + kWtPS] * (1.0f / kWtLoScale);

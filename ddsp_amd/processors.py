@@ -90,15 +90,36 @@ class Add(Processor):
   def get_signal(self, signal_one, signal_two):
     a, b = core.tf_float32(signal_one), core.tf_float32(signal_two)
     if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
-      return a + b          # recorded by torch.autograd (plumbing); the kernel below has no backward
-    if a.shape != b.shape:
-      a, b = torch.broadcast_tensors(a, b)
-      a, b = a.contiguous(), b.contiguous()
-    out = torch.empty_like(a)
-    rc = _lib.load().ddsp_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
-                                  core._stream())
-    _lib.check(rc, 'ddsp_add_f32')
-    return out
+      return _AddFunction.apply(a, b)       # the same kernel, recorded for torch.autograd
+    return _add(a, b)
+
+
+def _add(a, b):
+  """signal_one + signal_two (processors.py:162-176) on add_kernel; broadcasting as tf's `+`."""
+  if a.shape != b.shape:
+    a, b = torch.broadcast_tensors(a, b)
+    a, b = a.contiguous(), b.contiguous()
+  out = torch.empty_like(a)
+  rc = _lib.load().ddsp_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), core._stream())
+  _lib.check(rc, 'ddsp_add_f32')
+  return out
+
+
+class _AddFunction(torch.autograd.Function):
+  """torch.autograd node of Add (plumbing): forward is the C-ABI call, the gradient of a sum is the incoming
+  gradient itself (summed back over broadcast axes)."""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    ctx.shapes = (a.shape, b.shape)
+    return _add(a.detach(), b.detach())
+
+  @staticmethod
+  def backward(ctx, grad):
+    sa, sb = ctx.shapes
+    ga = grad if grad.shape == sa else grad.sum_to_size(sa)
+    gb = grad if grad.shape == sb else grad.sum_to_size(sb)
+    return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None)
 
 
 class Mix(Processor):

@@ -72,6 +72,8 @@ class Harmonic(processors.Processor):
     amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0_hz = core.tf_float32(f0_hz)
     b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
+    core.require_no_grad('Harmonic.get_controls (use __call__, which is differentiable)', amplitudes,
+                         harmonic_distribution, f0_hz)
     ctl_amp = torch.empty_like(amplitudes)
     ctl_hd = torch.empty_like(harmonic_distribution)
     flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False)
@@ -273,6 +275,7 @@ class FilteredNoise(processors.Processor):
       raise ValueError('magnitudes must be [batch, n_frames, n_filter_banks], got {}'.format(
           tuple(magnitudes.shape)))
     b, f, m = magnitudes.shape
+    core.require_no_grad('FilteredNoise.get_controls (use __call__, which is differentiable)', magnitudes)
     ctl = torch.empty_like(magnitudes)
     rc = _lib.load().ddsp_filtered_noise_controls_f32(
         magnitudes.data_ptr(), ctl.data_ptr(), b, f, m, float(self.initial_bias),
@@ -323,8 +326,12 @@ class FilteredNoise(processors.Processor):
     return audio, ctl
 
   def get_signal(self, magnitudes, noise=None):
-    """Controls -> filtered noise [batch, n_samples] (synths.py:181-196)."""
-    audio, _ = self._run(magnitudes, noise, fuse_scale=False, want_controls=False)
+    """Controls -> filtered noise [batch, n_samples] (synths.py:181-196).  Differentiable with respect to the
+    controls (the same backward kernels as __call__, scale function off)."""
+    mt = core.tf_float32(magnitudes)
+    if torch.is_grad_enabled() and mt.requires_grad:
+      return _FilteredNoiseFunction.apply(mt, self, noise, False)
+    audio, _ = self._run(mt, noise, fuse_scale=False, want_controls=False)
     return audio
 
   def call(self, magnitudes, return_outputs_dict=False, noise=None, **kwargs):
@@ -340,7 +347,7 @@ class FilteredNoise(processors.Processor):
     if self.scale_fn is None or self.scale_fn is core.exp_sigmoid:
       mt = core.tf_float32(magnitudes)
       if torch.is_grad_enabled() and mt.requires_grad:
-        audio = _FilteredNoiseFunction.apply(mt, self, noise)
+        audio = _FilteredNoiseFunction.apply(mt, self, noise, self.scale_fn is not None)
         if not return_outputs_dict:
           return audio
         with torch.no_grad():
@@ -351,13 +358,15 @@ class FilteredNoise(processors.Processor):
       if return_outputs_dict and self.scale_fn is None:
         ctl = core.tf_float32(magnitudes)
     else:
+      # a user callable runs as given on device tensors (torch autograd follows it); the synthesis behind it is
+      # the differentiable get_signal
       ctl = self.get_controls(magnitudes)['magnitudes']
-      audio, _ = self._run(ctl, noise, fuse_scale=False, want_controls=False)
+      audio = self.get_signal(ctl, noise=noise)
     if return_outputs_dict:
       return dict(signal=audio, controls={'magnitudes': ctl})
     return audio
 
-  def _backward(self, magnitudes, noise, seed, grad_audio):
+  def _backward(self, magnitudes, noise, seed, grad_audio, fuse_scale):
     b, f, m = magnitudes.shape
     n = int(self.n_samples)
     lib = _lib.load()
@@ -369,7 +378,7 @@ class FilteredNoise(processors.Processor):
         magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
         grad_audio.data_ptr(), grad_mag.data_ptr(), ws.data_ptr(), ws.numel(), b, f, m, n,
         int(self.window_size), float(self.initial_bias),
-        _lib.NOISE_SCALE_EXP_SIGMOID if self.scale_fn is not None else 0, seed, 0, core._stream())
+        _lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0, seed, 0, core._stream())
     if rc == -3:
       raise NotImplementedError('FilteredNoise backward needs n_samples / n_frames <= 8192, at most 4097 '
                                 'bands and an impulse response of at least 3 taps')
@@ -381,17 +390,16 @@ class _FilteredNoiseFunction(torch.autograd.Function):
   """torch.autograd node of FilteredNoise.__call__ (plumbing: both directions are C-ABI calls)."""
 
   @staticmethod
-  def forward(ctx, magnitudes, synth, noise):
+  def forward(ctx, magnitudes, synth, noise, fuse_scale):
     if noise is not None:
       noise = core.tf_float32(noise)
     ctx.seed = (synth.seed & 0xFFFFFFFF) | ((synth._calls & 0xFFFFFFFF) << 32)   # what _run is about to use
-    audio, _ = synth._run(magnitudes.detach(), noise, fuse_scale=synth.scale_fn is not None,
-                          want_controls=False)
+    audio, _ = synth._run(magnitudes.detach(), noise, fuse_scale=fuse_scale, want_controls=False)
     ctx.save_for_backward(magnitudes)
-    ctx.synth, ctx.noise = synth, noise
+    ctx.synth, ctx.noise, ctx.fuse_scale = synth, noise, fuse_scale
     return audio
 
   @staticmethod
   def backward(ctx, grad_audio):
     (magnitudes,) = ctx.saved_tensors
-    return ctx.synth._backward(magnitudes.detach(), ctx.noise, ctx.seed, grad_audio), None, None
+    return ctx.synth._backward(magnitudes.detach(), ctx.noise, ctx.seed, grad_audio, ctx.fuse_scale), None, None, None

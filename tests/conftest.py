@@ -33,3 +33,16 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
   return load_golden
+
+
+def parity_check(ours, ref, atol, what=''):
+  """max |ours - ref| <= atol, with the measured error appended to $DDSP_PARITY_LOG (json lines) when that is set, so
+  that the tolerances can be kept at a small multiple of what the MI355X actually delivers (VERDICT r1, weak #4)."""
+  import json
+  err = float(np.abs(np.asarray(ours, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max())
+  log = os.environ.get('DDSP_PARITY_LOG')
+  if log:
+    with open(log, 'a') as f:
+      f.write(json.dumps({'test': os.environ.get('PYTEST_CURRENT_TEST', ''), 'what': what, 'err': err,
+                          'atol': float(atol), 'frac_of_tol': err / float(atol) if atol else None}) + '\n')
+  assert err <= atol, 'max |ours - ref| = %.3e > %.3e %s' % (err, atol, what)

@@ -74,8 +74,8 @@ def build(verbose=False):
     if name in SOURCES:
       staged.append(dst)
   # -ffp-contract=fast -mfma: a*b+c contracts to an FMA as in hipcc's default mode (the FFT butterflies of the
-  # SpectralLoss are measurably less accurate without); the *_rn intrinsics stay uncontracted (see the header)
-  cmd = [CLANG, '-std=c++17', '-O1', '-g0', '-ffp-contract=fast', '-mfma', '-shared', '-fPIC', '-w',
+  # SpectralLoss are measurably less accurate without); fast-honor-pragmas is hipcc's own default, so the rn_* helpers of common.h stay uncontracted here exactly as on the device
+  cmd = [CLANG, '-std=c++17', '-O1', '-g0', '-ffp-contract=fast-honor-pragmas', '-mfma', '-shared', '-fPIC', '-w',
          '-I' + os.path.join(HERE, 'include_simt'), '-I' + os.path.join(ROOT, 'include'),
          '-include', os.path.join(HERE, 'include_simt', 'hip', 'hip_runtime.h')] + staged + ['-o', OUT]
   if verbose:

@@ -1,7 +1,9 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
 vectors.  Tolerances (fp32 path, stated per SURVEY.md H1 / DESIGN.md "Parity contract"):
 
-  HARM_TRUTH_ATOL  |ours - fp64 truth| <= 2e-4 * max(1, sum_k a_k)    (both phase modes)
+  HARM_TRUTH_ATOL  |ours - fp64 truth| <= 6e-5 * max(1, sum_k a_k)    (both phase modes; ~5x what the direct sum
+                   measures on the MI355X, 1.3e-5; the wavetable kernel measures 4.7e-6 and is held to 2.5e-5 in
+                   test_harm_table_*; every comparison is logged to $DDSP_PARITY_LOG when that is set)
   HARM_FAITHFUL    |ours - fp32 TF-faithful oracle| <= 2e-3 on clips <= 2k samples, where
                    the sequential fp32 cumsum has not yet drifted
   NOISE            |ours - fp64 oracle| <= 2e-6 + 1e-5 * max|ref|
@@ -11,15 +13,20 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, parity_check
 from oracle import ddsp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda'      # tests/test_simt_emulated.py re-runs a subset of these tests on host memory with DEV = 'cpu'
 
-HARM_TRUTH_ATOL = 2e-4
+HARM_TRUTH_ATOL = 6e-5
+HARM_TABLE_ATOL = 2.5e-5
 HARM_FAITHFUL_ATOL = 2e-3
+
+
+def harm_truth_check(ours, truth, scale=1.0, atol=None):
+  parity_check(ours, truth, (HARM_TRUTH_ATOL if atol is None else atol) * scale)
 
 
 @pytest.fixture(scope='module')
@@ -88,7 +95,7 @@ def test_harmonic_golden(ddsp, harm_kernel, name):
                      int(g['n_samples']), int(g['sample_rate']), scale_fn,
                      bool(g['normalize']), str(g['amp_method']), dtype=np.float64)
   amp_sum = max(1.0, float(np.abs(g['ctl_amplitudes']).max()))
-  assert np.abs(sig - truth).max() <= HARM_TRUTH_ATOL * amp_sum
+  harm_truth_check(sig, truth, amp_sum)
   # unfused path (get_controls then get_signal; always the direct sum) gives the same audio as the fused call:
   # to round-off under 'direct', within the contract when the fused call ran on the wavetable kernel
   c = synth.get_controls(*args)
@@ -151,7 +158,7 @@ def test_harmonic_canonical_vs_truth_and_faithful(ddsp, harm_kernel, f0_center):
   err_ang = np.abs(faithful_ang - truth).max()
   print('canonical f0~%g: |ours-truth| %.2e  |tf.cumsum fp32-truth| %.2e  |angular fp32-truth| %.2e'
         % (f0_center, err_ours, err_seq, err_ang))
-  assert err_ours <= HARM_TRUTH_ATOL * 2.0          # amplitudes are <= 2 (exp_sigmoid max)
+  harm_truth_check(ours, truth, 2.0)                 # amplitudes are <= 2 (exp_sigmoid max)
   assert err_ours <= err_seq and err_ours <= err_ang   # closer to truth than TF's own fp32 paths
   # default path: direct parity on the prefix where fp32 sequential cumsum has not drifted
   assert np.abs(ours[:, :2000] - faithful_seq[:, :2000]).max() <= HARM_FAITHFUL_ATOL
@@ -200,7 +207,7 @@ def test_harmonic_edge_shapes(ddsp, harm_kernel, k, n_frames, hop, sr, method):
   ours = npy(ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)(
       amps, hd, f0))
   truth = O.harmonic(amps, hd, f0, n, sr, amp_resample_method=method, dtype=np.float64)
-  assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(ours, truth, 2.0)
 
 
 def test_harmonic_silent_above_nyquist_and_exact_boundary(ddsp, harm_kernel):      # core_test.py:484-503
@@ -216,7 +223,7 @@ def test_harmonic_silent_above_nyquist_and_exact_boundary(ddsp, harm_kernel):   
   f0 = np.full((1, 10, 1), 80.0, np.float32)
   ours = npy(ddsp.synths.Harmonic(n_samples=640, scale_fn=None)(amps, hd, f0))
   truth = O.harmonic(amps, hd, f0, 640, scale_fn=None, dtype=np.float64)
-  assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL
+  harm_truth_check(ours, truth)
 
 
 def test_harmonic_nyquist_crossing_between_frames(ddsp, harm_kernel):
@@ -231,7 +238,7 @@ def test_harmonic_nyquist_crossing_between_frames(ddsp, harm_kernel):
                      dtype=np.float64)
   faithful = O.harmonic(amps, hd, f0, n_frames * hop, scale_fn=None,
                         normalize_below_nyquist=False)
-  assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL
+  harm_truth_check(ours, truth)
   assert np.abs(ours - faithful).max() <= HARM_FAITHFUL_ATOL
 
 
@@ -308,7 +315,7 @@ def test_full_size_properties_batch32(ddsp, harm_kernel):
   np.testing.assert_array_equal(one, full[7:8])
   # spot rows against fp64 truth
   truth = O.harmonic(*[a[7:8] for a in args], dtype=np.float64)
-  assert np.abs(one - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(one, truth, 2.0)
   # |audio| <= sum_k a_k = amplitude (distribution is normalised)
   amp = O.exp_sigmoid(x['amplitudes'], dtype=np.float64).max()
   assert np.abs(full).max() <= amp * (1 + 1e-5)
@@ -354,7 +361,7 @@ def test_processor_group_harmonic_noise_add(ddsp):           # gin/models/ae.gin
   h, z = npy(c['harmonic']['signal']), npy(c['filtered_noise']['signal'])
   np.testing.assert_array_equal(npy(out['signal']), h + z)
   truth = O.harmonic(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'], n, dtype=np.float64)
-  assert np.abs(h - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(h, truth, 2.0)
   zref = O.filtered_noise(x['magnitudes'], O.device_uniform_noise(2, n, 3, 0), 0, dtype=np.float64)
   assert np.abs(z - zref).max() <= noise_tol(zref)
   np.testing.assert_allclose(npy(c['harmonic']['controls']['harmonic_distribution']).sum(-1), 1.0,
@@ -371,7 +378,7 @@ def test_harmonic_48k_200_harmonics(ddsp, harm_kernel):                   # BASE
                                use_angular_cumsum=True)
   ours = npy(synth(amps, hd, f0))
   truth = O.harmonic(amps, hd, f0, n_frames * hop, sr, amp_resample_method='linear', dtype=np.float64)
-  assert np.abs(ours - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(ours, truth, 2.0)
 
 
 def test_standalone_resample_and_normalize(ddsp):            # core_test.py:153-267, golden 'resample'
@@ -451,14 +458,14 @@ def test_harmonic_fused_unit_edges(ddsp, harm_kernel, batch, n_frames):
     truth = O.harmonic(amps[:2], hd[:2], f0[:2], n, dtype=np.float64)
     c = O.harmonic_get_controls(amps[:2], hd[:2], f0[:2])
   nb = truth.shape[0]
-  assert np.abs(npy(out['signal'])[:nb] - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(npy(out['signal'])[:nb], truth, 2.0)
   np.testing.assert_allclose(npy(out['controls']['harmonic_distribution'])[:nb],
                              c['harmonic_distribution'], rtol=2e-5, atol=1e-9)
   np.testing.assert_allclose(npy(out['controls']['amplitudes'])[:nb], c['amplitudes'], rtol=2e-5)
   # repeated launches reuse the self-resetting work counters; without the controls dict the call may
   # take the other kernel ('auto'): same audio within the tolerance, bit-identical run to run
   again = npy(synth(amps, hd, f0))
-  assert np.abs(again[:nb] - truth).max() <= HARM_TRUTH_ATOL * 2.0
+  harm_truth_check(again[:nb], truth, 2.0)
   np.testing.assert_array_equal(again, npy(synth(amps, hd, f0)))
 
 
@@ -485,7 +492,7 @@ def test_harmonic_table_kernel_vs_truth_model_and_direct(ddsp, batch, n_frames, 
   truth = O.harmonic(amps[:nb], hd[:nb], f0[:nb], n, sr, amp_resample_method=method, dtype=np.float64)
   err, err_direct = np.abs(ours[:nb] - truth).max(), np.abs(direct[:nb] - truth).max()
   print('table %.2e direct %.2e' % (err, err_direct))
-  assert err <= 2e-5 * 2.0                 # a tenth of the contract: the window's aliasing is <= 6.5e-6 per harmonic
+  harm_truth_check(ours[:nb], truth, 2.0, atol=HARM_TABLE_ATOL)      # the window's aliasing is <= 6.5e-6 per harmonic
   assert np.abs(ours - direct).max() <= HARM_TRUTH_ATOL * 2.0
   model = harmonic_table_model(amps[:nb], hd[:nb], f0[:nb], n, sr, W=6 if k <= 100 else 8,
                                amp_linear=(method == 'linear'))
@@ -747,7 +754,7 @@ def test_streaming_synthesis_golden(ddsp, name):
       g['f0_hz'], g['amplitudes'], hd, g['initial_phase'], int(g['n_samples']), int(g['sample_rate']),
       str(g['amp_method']), dtype=np.float64)
   amp_sum = float(np.abs(g['amplitudes']).max()) * (1.0 if hd is not None else 1.0)
-  np.testing.assert_allclose(npy(audio), a64, rtol=0, atol=HARM_TRUTH_ATOL * max(1.0, amp_sum))
+  harm_truth_check(npy(audio), a64, max(1.0, amp_sum))
   np.testing.assert_allclose(npy(audio), g['audio'], rtol=0, atol=HARM_FAITHFUL_ATOL)
   # the carried phase: equal modulo 2 pi to fp64 truth (the reference wraps before adding initial_phase)
   d = (npy(final_phase) - p64 + np.pi) % (2 * np.pi) - np.pi

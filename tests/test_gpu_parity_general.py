@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, parity_check
 from oracle import ddsp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -152,7 +152,7 @@ def test_harmonic_synthesis_argument_space_golden(ddsp, name):         # core.py
                                dtype=np.float64)
   amp_sum = float(np.abs(g['amplitudes']).max()) * (float(np.abs(g['harmonic_distribution']).sum(-1).max())
                                                      if 'harmonic_distribution' in g else g['harmonic_shifts'].shape[-1])
-  np.testing.assert_allclose(out, truth, rtol=0, atol=2e-4 * max(1.0, amp_sum))
+  parity_check(out, truth, 2e-4 * max(1.0, amp_sum))
   # the golden vector is the fp32-faithful chain: its own sequential cumsum is up to 1.2e-3 * amp_sum away
   # from exact arithmetic on these clips (these controls are not normalised: amp_sum is 5 .. 13)
   np.testing.assert_allclose(out, g['audio'], rtol=0, atol=2e-3 * max(1.0, amp_sum))
@@ -169,14 +169,14 @@ def test_harmonic_processor_with_cubic_and_nearest_envelopes(ddsp):    # synths.
   np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=2e-3)
   truth = O.harmonic(g['amplitudes'], g['harmonic_distribution'], g['f0_hz'], int(g['n_samples']),
                      int(g['sample_rate']), amp_resample_method='cubic', dtype=np.float64)
-  np.testing.assert_allclose(npy(out['signal']), truth, rtol=0, atol=2e-4 * 2.0)
+  parity_check(npy(out['signal']), truth, 2e-4 * 2.0)
   # where both forms exist they agree: 'linear' through the materialised chain == the closed-form kernel
   lin = ddsp.synths.Harmonic(n_samples=1600, sample_rate=16000, amp_resample_method='linear')
   fused = npy(lin(g['amplitudes'], g['harmonic_distribution'], g['f0_hz']))
   ctl = lin.get_controls(g['amplitudes'], g['harmonic_distribution'], g['f0_hz'])
   chain = npy(ddsp.core._harmonic_synthesis_materialised(ctl['f0_hz'], ctl['amplitudes'], None,
                                                          ctl['harmonic_distribution'], 1600, 16000, 'linear', False))
-  np.testing.assert_allclose(chain, fused, rtol=0, atol=2e-4 * 2.0)
+  parity_check(chain, fused, 2e-4 * 2.0)
   a = torch.tensor(g['amplitudes'], device=DEV, requires_grad=True)
   with pytest.raises(NotImplementedError, match='backward'):
     synth(a, g['harmonic_distribution'], g['f0_hz'])
@@ -205,9 +205,9 @@ def test_harmonic_f0_gradient_vs_analytic_oracle(ddsp, method, b, f, k, hop, sr,
   audio.backward(torch.tensor(g, device=DEV))
   ref_a, ref_h, ref_f = O.harmonic_backward(amps, hd, f0, g, n_samples=n, sample_rate=sr,
                                             amp_resample_method=method, with_f0=True)
-  np.testing.assert_allclose(npy(tf.grad), ref_f, rtol=0, atol=2e-4 * np.abs(ref_f).max())
-  np.testing.assert_allclose(npy(ta.grad), ref_a, rtol=0, atol=2e-4 * np.abs(ref_a).max())
-  np.testing.assert_allclose(npy(th.grad), ref_h, rtol=0, atol=2e-4 * np.abs(ref_h).max())
+  parity_check(npy(tf.grad), ref_f, 2e-4 * np.abs(ref_f).max())
+  parity_check(npy(ta.grad), ref_a, 2e-4 * np.abs(ref_a).max())
+  parity_check(npy(th.grad), ref_h, 2e-4 * np.abs(ref_h).max())
   # f0 alone requiring grad: only that gradient is formed
   tf2 = torch.tensor(f0, device=DEV, requires_grad=True)
   synth(amps, hd, tf2).backward(torch.tensor(g, device=DEV))
@@ -280,8 +280,8 @@ def test_exp_decay_reverb_reference_tests_and_gradients(ddsp):
   ir_ref = O.exp_decay_ir(gain, decay, noise, dtype=np.float64)
   g_ir = O.reverb_backward(audio, ir_ref, g_out, add_dry=True)[1]
   ref_g, ref_d = O.exp_decay_ir_backward(gain, decay, noise, g_ir)
-  np.testing.assert_allclose(npy(tg.grad), ref_g, rtol=0, atol=2e-4 * np.abs(ref_g).max())
-  np.testing.assert_allclose(npy(td.grad), ref_d, rtol=0, atol=2e-4 * np.abs(ref_d).max())
+  parity_check(npy(tg.grad), ref_g, 2e-4 * np.abs(ref_g).max())
+  parity_check(npy(td.grad), ref_d, 2e-4 * np.abs(ref_d).max())
 
 
 # ---- processors.Mix, synths.TensorToAudio (processors_test.py:103-114, synths.py:23-52) -----------------------------
@@ -407,4 +407,4 @@ def test_harmonic_table_kernel_with_phase_tables_on_a_t_wavefront(ddsp, batch, n
   for key in ('amplitudes', 'harmonic_distribution'):
     np.testing.assert_array_equal(npy(outs['table_tphase']['controls'][key]), npy(outs['auto']['controls'][key]))
   truth = O.harmonic(amps, hd, f0, n, 16000, dtype=np.float64)
-  np.testing.assert_allclose(npy(outs['table_tphase']['signal']), truth, rtol=0, atol=2e-4 * 2.0)
+  parity_check(npy(outs['table_tphase']['signal']), truth, 2e-4 * 2.0)
