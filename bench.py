@@ -2,7 +2,11 @@
 """bench.py - Msamples/s of the Harmonic + FilteredNoise hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N)
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`, one
+rank per GPU over RCCL) and passes rank 0's JSON line through; under an external torchrun it is one of the ranks.
+It never prints `n_gpus: 1` when more were asked for.
 
 One "step" = one pass of the hot path over one batch of synthetic control tensors:
 `synths.Harmonic(amplitudes, harmonic_distribution, f0_hz)` + `synths.FilteredNoise(magnitudes)`
@@ -11,17 +15,31 @@ each output sample counted once.  Inputs are resident in HBM before the timed re
 Workload (per GPU, weak scaling): BASELINE.json configs[1] - batch 32, 4 s @ 16 kHz,
 F=1000 frames, K=100 harmonics (all below Nyquist: f0 = 70 + N(0,1) Hz), M=65 noise bands.
 
+Timing.  After W warm-up steps (and a clock-settle phase) the region "exactly K steps, barrier +
+torch.cuda.synchronize() on both sides" is run `--repeats` times (>= 10 by default).  Each region is timed
+twice: by the host clock around the bracket, and by HIP events recorded on the stream(s) at its first and after
+its last launch (the two-stream mode forks from / joins into the base stream with events).  `ms_per_step` and
+`value` are the MEDIAN event-timed region (max over ranks) - at the driver's K = 20 a region is under a
+millisecond and the host-side synchronize alone is 2-8 % of it; the host-clock median and the first region are
+reported beside it (`timing`).
+
 The JSON line also carries
-  roofline     : dominant kernel, algorithmic bytes per launch / its mean duration measured
-                 with HIP events on the launch stream during the timed region (ddsp_profile_*),
-                 against the 8 TB/s HBM peak (the path is in fact ALU-bound).
-  cpu_baseline : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
-                 here) timed on this host's cores (concurrent worker processes) on a bounded
-                 sample of the same workload.
+  roofline         : dominant kernel, algorithmic bytes per launch / its mean duration measured
+                     with HIP events on the launch stream during the timed regions (ddsp_profile_*),
+                     against the 8 TB/s HBM peak (the path is in fact ALU-bound).
+  north_star_shape : the same step at BASELINE.json's target shape (batch 128 per GPU, one stream), timed the
+                     same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
+                     fractions of the HBM roofline.
+  cpu_baseline     : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
+                     here) timed on this host's cores (concurrent worker processes) on a bounded
+                     sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,13 +50,17 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DTYPE = 'f32 (Harmonic wavetables and the FilteredNoise FIR/IR products: fp16 hi/lo-split MFMA operands, fp32 accumulate)'
 
 
-def parse_args():
+def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=1000)
   ap.add_argument('--warmup', type=int, default=500)   # ~20 ms of load: the GPU needs that long to reach its sustained clock (43 vs 37 us/step)
+  ap.add_argument('--repeats', type=int, default=0,
+                  help='timed regions of K steps each (0: at least 10, more when a region is short, so that '
+                       'about 0.1 s is measured in all); the median is reported')
   ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
   ap.add_argument('--n-frames', type=int, default=1000)
   ap.add_argument('--n-harmonics', type=int, default=100)
@@ -48,11 +70,12 @@ def parse_args():
   ap.add_argument('--f0', type=float, default=70.0, help='f0 centre in Hz (70: all harmonics live)')
   ap.add_argument('--cpu-clips', type=int, default=6, help='clips per worker process of the CPU oracle leg')
   ap.add_argument('--cpu-procs', type=int, default=0,
-                  help='worker processes of the CPU oracle leg (0: the logical CPUs, at most 32)')
+                  help='worker processes of the CPU oracle leg (0: the physical cores this process may run on, '
+                       'bounded by free memory)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--event-stride', type=int, default=8,
                   help='bracket every n-th launch of the dominant kernel with HIP events inside the '
-                       'timed region (a bracketed launch costs ~5 us of queue time; 1 = all of them)')
+                       'timed regions (a bracketed launch costs ~5 us of queue time; 1 = all of them)')
   ap.add_argument('--streams', choices=['auto', '1', '2'], default='auto',
                   help='issue the two Processor calls on one stream or on two free-running streams; auto = two '
                        'when the per-GPU batch is below 64 (the kernels leave CUs idle for each other), one above')
@@ -60,20 +83,25 @@ def parse_args():
                   help='issue the two Processor calls back to back on one stream instead of on two '
                        'free-running HIP streams')
   ap.add_argument('--also-other-mode', action='store_true',
-                  help='after the timed region, run K more steps in the other stream mode and report '
+                  help='after the timed regions, run K more steps in the other stream mode and report '
                        'them as other_issue_mode (off by default so that a rocprofv3 trace of the '
                        'default command sees one mode only)')
   ap.add_argument('--no-aux', action='store_true',
-                  help='skip the auxiliary yardsticks after the timed region (measured device-copy bandwidth, '
+                  help='skip the auxiliary yardsticks after the timed regions (measured device-copy bandwidth, '
                        'the f0 = 200 Hz regime of SURVEY.md 8d)')
-  ap.add_argument('--harm-kernel', choices=['auto', 'direct', 'table_tphase'], default='auto',
-                  help="Harmonic.kernel: 'auto' (default), 'direct' (sum harmonic by harmonic) or the experimental "
-                       "'table_tphase' variant of the wavetable kernel")
-  ap.add_argument('--noise-ir', choices=['vector', 'matrix', 'matrix_direct'], default='vector',
-                  help="FilteredNoise.ir_design: 'vector' (default) or the experimental matrix-core designs")
+  ap.add_argument('--no-north-star', action='store_true',
+                  help='skip the north_star_shape block (batch 128 per GPU, one stream)')
+  ap.add_argument('--north-star-batch', type=int, default=128)
+  ap.add_argument('--harm-kernel', default='auto', help="Harmonic.kernel ('auto', 'direct', ...)")
+  ap.add_argument('--noise-kernel', default='auto', help="FilteredNoise.kernel ('auto', ...)")
+  ap.add_argument('--noise-ir', default='auto', help='FilteredNoise.ir_design')
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
-  return ap.parse_args()
+  ap.add_argument('--dry-run', action='store_true',
+                  help='PLUMBING TEST ONLY (tests/test_bench_contract.py): no device, no kernels - the step is a '
+                       'sleep, the process group is gloo; exercises the launcher, the rank logic, the collectives '
+                       'and the JSON line on a CPU box.  The line says "dry_run": true and measures nothing.')
+  return ap.parse_args(argv)
 
 
 def make_inputs(batch, a, seed):
@@ -92,7 +120,7 @@ def algorithmic_bytes(a, batch):
   return harm, noise
 
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CUs x 2.4 GHz x 256 flop/clk, packed fp32
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # 256 CUs x 2.4 GHz x 256 flop/clk
 
 
 def algorithmic_flops(a, batch):
@@ -114,40 +142,56 @@ def cpu_baseline(a):
                      a.f0)
 
 
-def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=None, alt_elapsed=None,
-                 gather_ms=None, cpu_baseline_fn=None):
-  """The JSON line of the bench contract from the measured quantities (pure: unit-tested on the CPU).
+def load_traffic(dominant, batch):
+  """HBM bytes per launch of `dominant` from the committed PMC passes (profiles/pmc_traffic*.json), or None."""
+  for tname in ('pmc_traffic_b%d.json' % batch, 'pmc_traffic.json'):     # PMC passes are per batch size
+    tpath = os.path.join(ROOT, 'profiles', tname)
+    if os.path.exists(tpath):
+      try:
+        with open(tpath) as f:
+          rec = json.load(f)
+        if rec.get('batch') == batch and rec.get('kernels', {}).get(dominant) is not None:
+          return rec['kernels'][dominant]
+      except (ValueError, OSError):
+        pass
+  return None
 
-  elapsed: seconds for a.steps steps, max over ranks; prof / breakdown: {kernel: (total_ms, launches)} of the
-  timed region's sampled dispatch events / of the untimed single-stream diagnostic pass."""
+
+def kernel_roofline(a, batch, dominant, dom_ms, dom_n):
+  """achieved = algorithmic bytes of the kernel's Processor / its mean launch duration."""
+  harm_bytes, noise_bytes = algorithmic_bytes(a, batch)
+  harm_flops, noise_flops = algorithmic_flops(a, batch)
+  dom_avg_s = dom_ms / dom_n * 1e-3
+  is_harm = dominant.startswith('harm')
+  dom_bytes = harm_bytes if is_harm else noise_bytes
+  if dominant.startswith('synth'):          # a fused Harmonic + FilteredNoise launch carries both
+    dom_bytes = harm_bytes + noise_bytes
+  achieved = dom_bytes / dom_avg_s / 1e9
+  dom_flops = (harm_flops + noise_flops) if dominant.startswith('synth') else (harm_flops if is_harm else noise_flops)
+  return {'kernel': dominant, 'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
+          'traffic': load_traffic(dominant, batch), 'algorithmic_bytes_per_launch': dom_bytes,
+          'avg_launch_us': dom_avg_s * 1e6, 'launches': dom_n, '_flops': dom_flops, '_avg_s': dom_avg_s}
+
+
+def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=None, alt_elapsed=None,
+                 gather_ms=None, cpu_baseline_fn=None, timing=None, north_star=None):
+  """The JSON line of the bench contract from the measured quantities (pure: unit-tested on the CPU).
+  elapsed: seconds of the median K-step region, max over ranks; prof / breakdown: {kernel: (total_ms, launches)}
+  of the timed regions' sampled dispatch events / of the untimed single-stream diagnostic pass."""
   aux = aux or {}
   cpu_baseline_fn = cpu_baseline_fn or cpu_baseline
   total_samples = world * B * a.n_samples * a.steps
   value = total_samples / elapsed / 1e6
   harm_bytes, noise_bytes = algorithmic_bytes(a, B)
-  dom_ms, dom_n = prof[dominant]
-  dom_avg_s = dom_ms / dom_n * 1e-3
-  # algorithmic bytes of the launch = those of the Processor the kernel belongs to
-  dom_bytes = harm_bytes if dominant.startswith('harm') else noise_bytes   # its Processor's bytes
-  achieved = dom_bytes / dom_avg_s / 1e9
-  traffic = None
-  for tname in ('pmc_traffic_b%d.json' % B, 'pmc_traffic.json'):     # PMC passes are per batch size
-    tpath = os.path.join(ROOT, 'profiles', tname)
-    if traffic is None and os.path.exists(tpath):
-      try:
-        rec = json.load(open(tpath))
-        if rec.get('batch') == B:
-          traffic = rec.get('kernels', {}).get(dominant)
-      except (ValueError, OSError):
-        traffic = None
+  roof = kernel_roofline(a, B, dominant, *prof[dominant])
+  dom_flops, dom_avg_s = roof.pop('_flops'), roof.pop('_avg_s')
   step_bytes = harm_bytes + noise_bytes
   harm_flops, noise_flops = algorithmic_flops(a, B)
-  dom_flops = harm_flops if dominant.startswith('harm') else noise_flops
   result = {
       'metric': 'Msamples/s (Harmonic+FilteredNoise, 16kHz, 100 harmonics)',
       'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': a.steps,
       'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
-      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
       'config': {
           'workload': 'BASELINE configs[1]: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
                       '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
@@ -157,30 +201,33 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
           'no collective' % world,
           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
                      else 'one stream, back to back',
-          'kernel_variants': {'harmonic': a.harm_kernel, 'noise_ir_design': a.noise_ir}},
-      'roofline': {
-          'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-          'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': dom_avg_s * 1e6,
-          'launches': dom_n, 'event_stride': a.event_stride,
+          'kernel_variants': {'harmonic': a.harm_kernel, 'filtered_noise': a.noise_kernel,
+                              'noise_ir_design': a.noise_ir}},
+      'per_gpu_value': value / world,
+      'roofline': dict(roof, **{
+          'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'event_stride': a.event_stride,
           'timing': 'dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
-                    'every event_stride-th launch inside the timed region',
+                    'every event_stride-th launch inside the timed regions',
           'whole_step': {'algorithmic_bytes': step_bytes,
                          'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
                          'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
           # the path sits above the fp32 ridge point: the vector-ALU ceiling beside the
-          # HBM fraction, on the reference formulation's flop count (the wavetable kernel does fewer)
+          # HBM fraction, on the reference formulation's flop count (the wavetable / matrix-core kernels do fewer)
           'alu_note': {'algorithmic_flop_per_launch': dom_flops,
                        'achieved_TFLOPs': dom_flops / dom_avg_s / 1e12,
                        'peak_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
                        'frac': dom_flops / dom_avg_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                        'whole_step_frac': (harm_flops + noise_flops) / (elapsed / a.steps) / 1e12 /
-                                          FP32_VECTOR_PEAK_TFLOPS}},
+                                          FP32_VECTOR_PEAK_TFLOPS}}),
       'kernel_breakdown_us_isolated': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()},
   }
+  if timing:
+    result['timing'] = timing
+  if north_star:
+    result['north_star_shape'] = north_star
   if 'measured_copy_GBs' in aux:
     result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
-    result['roofline']['frac_of_measured_copy'] = achieved / aux['measured_copy_GBs']
+    result['roofline']['frac_of_measured_copy'] = roof['achieved'] / aux['measured_copy_GBs']
   if 'f0_200_regime' in aux:
     result['f0_200_regime'] = aux['f0_200_regime']
   if 'error' in aux:
@@ -196,126 +243,270 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
     result['cpu_baseline'] = cpu_baseline_fn(a)
   elif not a.no_cpu_baseline:
     result['cpu_baseline'] = None     # rank 0 at N=1 only (bench contract)
+  if a.dry_run:
+    result.update(dry_run=True, data='none (dry run: no device work; plumbing test only, not a measurement)')
   return result
 
 
-def main():
-  a = parse_args()
+def north_star_block(a, world, B, elapsed, steps, prof, breakdown):
+  """The step at the north-star shape (batch 128 per GPU, one stream): same definitions as the headline."""
+  harm_bytes, noise_bytes = algorithmic_bytes(a, B)
+  step_bytes = harm_bytes + noise_bytes
+  per_step = elapsed / steps
+  block = {'batch_per_gpu': B, 'streams': 'one stream, back to back', 'steps': steps,
+           'ms_per_step': per_step * 1e3, 'value': world * B * a.n_samples / per_step / 1e6,
+           'whole_step': {'algorithmic_bytes': step_bytes, 'achieved_GBs': step_bytes / per_step / 1e9,
+                          'frac': step_bytes / per_step / 1e9 / HBM_PEAK_GBS},
+           'target': '>= 0.5 of the HBM roofline (BASELINE.json north_star)',
+           'kernel_breakdown_us': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()}}
+  if prof:
+    dominant = max(prof, key=lambda k: prof[k][0] / prof[k][1])
+    roof = kernel_roofline(a, B, dominant, *prof[dominant])
+    roof.pop('_flops'), roof.pop('_avg_s')
+    block['dominant_kernel'] = roof
+  return block
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _free_port():
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def self_launch(a, argv):
+  """`python bench.py --gpus N` with no launcher around it: become the launcher.  One rank per GPU through
+  torch.distributed.run on 127.0.0.1; rank 0 prints the JSON line, which is passed through unchanged."""
+  if not a.dry_run:
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+      raise SystemExit('bench.py: --gpus %d asked for but this node shows %d GPU(s); refusing to report a '
+                       'smaller job under that label' % (a.gpus, have))
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes needs it on this driver)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+  proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+  for ln in proc.stdout.splitlines():
+    if not ln.startswith('{'):
+      print(ln, file=sys.stderr)
+  if proc.returncode != 0 or len(lines) != 1:
+    raise SystemExit('bench.py: the %d-rank run failed (exit code %d, %d JSON lines)' %
+                     (a.gpus, proc.returncode, len(lines)))
+  if json.loads(lines[0]).get('n_gpus') != a.gpus:
+    raise SystemExit('bench.py: the ranks reported n_gpus=%r, not %d' % (json.loads(lines[0]).get('n_gpus'), a.gpus))
+  print(lines[0], flush=True)
+
+
+class _HostClockEvent:
+  """--dry-run stand-in for torch.cuda.Event (no device)."""
+
+  def __init__(self, enable_timing=True):
+    self.t = 0.0
+
+  def record(self, stream=None):
+    self.t = time.perf_counter()
+
+  def elapsed_time(self, other):
+    return (other.t - self.t) * 1e3
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  a = parse_args(argv)
+  if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    return self_launch(a, argv)
+
   import torch
   import torch.distributed as dist
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != a.gpus and world > 1:
+  if world != a.gpus:
     raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
-  assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-  torch.cuda.set_device(local_rank)
+  dry = a.dry_run
+  if not dry:
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+  dev_name = 'cpu' if dry else 'cuda'
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
-
-  from ddsp_amd import build
-  if rank == 0:
-    build.build()            # no-op when the shipped .so is current
-  if world > 1:
-    dist.barrier()
-  import ddsp_amd as ddsp
-  from ddsp_amd import _lib
-  _lib.load()
-
-  # ---- per-rank shard of the global batch: independent rows, no data-path collective ----
-  B = a.batch
-  x = make_inputs(B, a, seed=1000 + rank)
-  dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
-  harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
-  fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
-  harmonic.kernel, fnoise.ir_design = a.harm_kernel, a.noise_ir          # instance attributes: the defaults unless asked
-
-  # The two Processor calls of a step are independent (nothing on this path joins them; the
-  # reference's Add would): Harmonic and FilteredNoise are issued on two free-running HIP streams so
-  # FilteredNoise's latency-bound stages run under Harmonic's ALU-bound synthesis (the persistent
-  # harmonic kernel hands its units out dynamically and uses whatever share of the CUs it gets).
-  # Joining the streams every step costs more than it gains (88 vs 62 us at batch 32), so the join is
-  # the barrier + synchronize that closes the timed region.  --no-overlap: one stream, back to back.
-  stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
-  stream_0 = torch.cuda.current_stream()
-  overlap = (a.streams == '2' or (a.streams == 'auto' and a.batch < 64)) and not a.no_overlap
-
-  def step(two_streams=None):
-    two_streams = overlap if two_streams is None else two_streams
-    if two_streams:
-      # set_stream, not the `with torch.cuda.stream()` context manager: the manager costs ~15 us of
-      # host time per use, which at batch 32 is as long as the kernels it is trying to overlap
-      torch.cuda.set_stream(stream_h)
-      h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
-      torch.cuda.set_stream(stream_z)
-      z = fnoise(dev['magnitudes'])
-      torch.cuda.set_stream(stream_0)
+    if dry:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
     else:
-      h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
-      z = fnoise(dev['magnitudes'])
-    return h, z
+      dist.init_process_group('nccl', rank=rank, world_size=world,
+                              device_id=torch.device('cuda', local_rank))
+
+  # ---- the two Processors (or, --dry-run, sleeps of their rough duration) --------------------------------
+  if dry:
+    _lib = None
+
+    def make_step(B, seed, streams2):
+      out = (torch.zeros((B, 1)), torch.zeros((B, 1)))
+
+      def step(two_streams=None):
+        time.sleep(2e-4)
+        return out
+      return step, {}
+  else:
+    from ddsp_amd import build
+    if rank == 0:
+      build.build()            # no-op when the shipped .so is current
+    if world > 1:
+      dist.barrier()
+    import ddsp_amd as ddsp
+    from ddsp_amd import _lib
+    _lib.load()
+    stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
+    stream_0 = torch.cuda.current_stream()
+
+    def make_step(B, seed, streams2):
+      # ---- per-rank shard of the global batch: independent rows, no data-path collective ----
+      x = make_inputs(B, a, seed=seed)
+      dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
+      harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
+      fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
+      harmonic.kernel = a.harm_kernel                          # instance attributes: the defaults unless asked
+      if a.noise_kernel != 'auto':
+        fnoise.kernel = a.noise_kernel
+      if a.noise_ir != 'auto':
+        fnoise.ir_design = a.noise_ir
+
+      # The two Processor calls of a step are independent (nothing on this path joins them; the
+      # reference's Add would): at small batches Harmonic and FilteredNoise are issued on two free-running HIP
+      # streams so each runs in the CUs the other leaves idle.  Joining the streams every step costs more than
+      # it gains (88 vs 62 us at batch 32), so the join is the event pair that closes a timed region.
+      def step(two_streams=None):
+        two_streams = streams2 if two_streams is None else two_streams
+        if two_streams:
+          # set_stream, not the `with torch.cuda.stream()` context manager: the manager costs ~15 us of
+          # host time per use, which at batch 32 is as long as the kernels it is trying to overlap
+          torch.cuda.set_stream(stream_h)
+          h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
+          torch.cuda.set_stream(stream_z)
+          z = fnoise(dev['magnitudes'])
+          torch.cuda.set_stream(stream_0)
+        else:
+          h = harmonic(dev['amplitudes'], dev['harmonic_distribution'], dev['f0_hz'])
+          z = fnoise(dev['magnitudes'])
+        return h, z
+      return step, dev
 
   def sync_all():
     if world > 1:
       dist.barrier()
-    torch.cuda.synchronize()
+    if not dry:
+      torch.cuda.synchronize()
 
+  def max_over_ranks(seconds):
+    if world > 1:
+      t = torch.tensor([seconds], dtype=torch.float64, device=dev_name)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      return float(t.item())
+    return seconds
+
+  Event = _HostClockEvent if dry else torch.cuda.Event
+
+  def timed_region(step, steps, two_streams):
+    """Exactly `steps` steps, barrier + synchronize on both sides; -> (event seconds, host-clock seconds, last output).
+    The events sit on the base stream; in the two-stream mode both streams start behind the first event and the
+    base stream waits for both before the second."""
+    e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
+    sync_all()
+    t0 = time.perf_counter()
+    if dry:
+      e0.record()
+    else:
+      e0.record(stream_0)
+      if two_streams:
+        stream_h.wait_event(e0)
+        stream_z.wait_event(e0)
+    out = None
+    for _ in range(steps):
+      out = step(two_streams)
+    if dry:
+      e1.record()
+    else:
+      if two_streams:
+        eh, ez = Event(), Event()
+        eh.record(stream_h)
+        ez.record(stream_z)
+        stream_0.wait_event(eh)
+        stream_0.wait_event(ez)
+      e1.record(stream_0)
+    sync_all()
+    wall = time.perf_counter() - t0
+    return e0.elapsed_time(e1) * 1e-3, wall, out
+
+  def repeated_regions(step, steps, two_streams, repeats):
+    ev, wall, out = [], [], None
+    for _ in range(repeats):
+      e, w, out = timed_region(step, steps, two_streams)
+      ev.append(e)
+      wall.append(w)
+    return ev, wall, out
+
+  def settle(step, seconds):
+    # Clock settle (untimed): an idle MI355X needs ~20 ms of load to reach its sustained clock - the
+    # same step measures 43 us right after a 5-step warm-up and 37 us from then on.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < seconds:
+      for _ in range(20):
+        step()
+      if not dry:
+        torch.cuda.synchronize()
+
+  # ---- headline: BASELINE configs[1] ---------------------------------------------------------------------
+  B = a.batch
+  overlap = (a.streams == '2' or (a.streams == 'auto' and a.batch < 64)) and not a.no_overlap
+  step, dev = make_step(B, 1000 + rank, overlap)
   for _ in range(a.warmup):
     step()
-  torch.cuda.synchronize()
-  # Clock settle (untimed): an idle MI355X needs ~20 ms of load to reach its sustained clock - the
-  # same step measures 43 us right after a 5-step warm-up and 37 us from then on.  Whatever W is,
-  # keep the GPU busy for 50 ms before anything is measured.
-  t_settle = time.perf_counter()
-  while time.perf_counter() - t_settle < 0.05:
-    for _ in range(20):
-      step()
+  if not dry:
     torch.cuda.synchronize()
+  settle(step, 0.05 if not dry else 0.0)
 
   # diagnostic pass (untimed, one stream so every kernel runs alone): every kernel bracketed, to
   # find the dominant one and give the isolated per-kernel times
-  _lib.profile_begin(None, max_records=64)
-  for _ in range(3):
-    step(two_streams=False)
-  torch.cuda.synchronize()
-  breakdown = _lib.profile_end()
+  if dry:
+    breakdown = {'dry_run_step': (0.6, 3)}
+  else:
+    _lib.profile_begin(None, max_records=64)
+    for _ in range(3):
+      step(two_streams=False)
+    torch.cuda.synchronize()
+    breakdown = _lib.profile_end()
   dominant = max(breakdown, key=lambda k: breakdown[k][0] / breakdown[k][1])
 
-  # ---- timed region: exactly K steps, barrier + synchronize on both sides ----------------
-  _lib.profile_begin([dominant], max_records=2 * a.steps + 8, stride=a.event_stride)
-  sync_all()
-  t0 = time.perf_counter()
-  for _ in range(a.steps):
-    out = step()
-  sync_all()
-  elapsed = time.perf_counter() - t0
-  prof = _lib.profile_end()
-
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  # ---- timed regions: exactly K steps each, barrier + synchronize on both sides --------------------------
+  e_probe, _, _ = timed_region(step, a.steps, overlap)          # untimed probe: sizes the repeat count
+  repeats = a.repeats if a.repeats > 0 else int(min(200, max(10, 0.1 / max(e_probe, 1e-6))))
+  if not dry:
+    _lib.profile_begin([dominant], max_records=2 * a.steps * repeats // max(a.event_stride, 1) + 64,
+                       stride=a.event_stride)
+  ev, wall, out = repeated_regions(step, a.steps, overlap, repeats)
+  prof = {dominant: (0.6, 3)} if dry else _lib.profile_end()
+  elapsed = max_over_ranks(statistics.median(ev))
+  timing = {'method': 'median of %d regions of K=%d steps; each region bracketed by barrier + synchronize and '
+                      'timed by HIP events on the stream(s) (value) and by the host clock (beside it)' %
+                      (repeats, a.steps),
+            'repeats': repeats, 'region_ms_median': statistics.median(ev) * 1e3,
+            'region_ms_min': min(ev) * 1e3, 'region_ms_max': max(ev) * 1e3, 'region_ms_first': ev[0] * 1e3,
+            'host_clock_ms_per_step_median': max_over_ranks(statistics.median(wall)) / a.steps * 1e3,
+            'host_clock_ms_per_step_first': wall[0] / a.steps * 1e3}
 
   # optionally the other issue mode, same K steps, reported next to the headline
   alt_elapsed = None
   if a.also_other_mode:
-    sync_all()
-    t_alt = time.perf_counter()
-    for _ in range(a.steps):
-      step(two_streams=not overlap)
-    sync_all()
-    alt_elapsed = time.perf_counter() - t_alt
-    if world > 1:
-      t = torch.tensor([alt_elapsed], dtype=torch.float64, device='cuda')
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      alt_elapsed = float(t.item())
+    ev_alt, _, _ = repeated_regions(step, a.steps, not overlap, max(3, repeats // 3))
+    alt_elapsed = max_over_ranks(statistics.median(ev_alt))
 
   # ---- auxiliary yardsticks (untimed for the headline; a failure here never costs the JSON line) ----
   aux = {}
-  if not a.no_aux:
+  if not a.no_aux and not dry:
     try:
       # (i) SURVEY.md 8(d): the fraction is quoted against the 8 TB/s spec peak; the device-to-device copy
       # rate measured in the same run says what this box's HBM actually sustains (read + write counted)
@@ -341,17 +532,9 @@ def main():
       dev.update(dev200)
       for _ in range(20):
         step()
-      sync_all()
-      t200 = time.perf_counter()
-      for _ in range(k200):
-        step()
-      sync_all()
-      dt200 = time.perf_counter() - t200
+      ev200, _, _ = repeated_regions(step, k200, overlap, 3)
       dev.update(dev_headline)
-      if world > 1:
-        t = torch.tensor([dt200], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt200 = float(t.item())
+      dt200 = max_over_ranks(statistics.median(ev200))
       aux['f0_200_regime'] = {'ms_per_step': dt200 / k200 * 1e3, 'steps': k200,
                               'value': world * B * a.n_samples * k200 / dt200 / 1e6}
     except Exception as exc:                      # noqa: BLE001 - diagnostics only
@@ -360,7 +543,7 @@ def main():
   gather_ms = None
   if a.allgather and world > 1:
     h = out[0]
-    full = torch.empty((world * B, a.n_samples), dtype=torch.float32, device='cuda')
+    full = torch.empty((world * h.shape[0], h.shape[1]), dtype=torch.float32, device=dev_name)
     for _ in range(3):
       dist.all_gather_into_tensor(full, h)
     sync_all()
@@ -368,10 +551,39 @@ def main():
     for _ in range(10):
       dist.all_gather_into_tensor(full, h)
     sync_all()
-    gather_ms = (time.perf_counter() - t1) / 10 * 1e3
+    gather_ms = max_over_ranks(time.perf_counter() - t1) / 10 * 1e3
+
+  # ---- the north-star shape: batch 128 per GPU, one stream (BASELINE.json target) --------------------------
+  north_star = None
+  if not a.no_north_star and a.north_star_batch != B:
+    try:
+      BN = a.north_star_batch
+      del step, dev
+      step_n, dev_n = make_step(BN, 3000 + rank, False)
+      ns_steps = max(10, min(a.steps, 200))
+      for _ in range(20):
+        step_n()
+      settle(step_n, 0.02 if not dry else 0.0)
+      if dry:
+        bd_n, prof_n = {'dry_run_step': (0.6, 3)}, None
+      else:
+        _lib.profile_begin(None, max_records=64)
+        for _ in range(3):
+          step_n(two_streams=False)
+        torch.cuda.synchronize()
+        bd_n = _lib.profile_end()
+        _lib.profile_begin(list(bd_n), max_records=4 * ns_steps * 10 // max(a.event_stride, 1) + 64,
+                           stride=a.event_stride)
+      ev_n, _, _ = repeated_regions(step_n, ns_steps, False, 10)
+      if not dry:
+        prof_n = _lib.profile_end()
+      north_star = north_star_block(a, world, BN, max_over_ranks(statistics.median(ev_n)), ns_steps, prof_n, bd_n)
+    except Exception as exc:                      # noqa: BLE001 - the headline line must survive
+      north_star = {'error': repr(exc)}
 
   if rank == 0:
-    result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms)
+    result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms,
+                          timing=timing, north_star=north_star)
     print(json.dumps(result), flush=True)
 
   if world > 1:

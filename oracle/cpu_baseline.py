@@ -36,10 +36,34 @@ def run_clips(n_clips, n_frames, n_harmonics, n_bands, n_samples, sample_rate, f
   return time.perf_counter() - t0
 
 
+def _physical_cores():
+  """Physical cores this process may run on: its CPU affinity with SMT siblings counted once."""
+  try:
+    cpus = sorted(os.sched_getaffinity(0))
+  except AttributeError:
+    cpus = list(range(os.cpu_count() or 1))
+  cores = set()
+  for c in cpus:
+    try:
+      with open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c) as f:
+        cores.add(f.read().strip())
+    except OSError:
+      cores.add(str(c))
+  return max(1, len(cores))
+
+
 def default_procs():
-  """Worker processes: the host's logical CPUs, capped at 32 (a clip's op chain holds ~0.4 GB of
-  materialised tensors, and numpy's elementwise passes stop scaling at memory bandwidth long before)."""
-  return max(1, min(32, os.cpu_count() or 1))
+  """Worker processes: one per physical core this process may use (TF's own CPU kernels would use them all), bounded
+  by memory - a clip's op chain holds ~0.5 GB of materialised [N, K] tensors, so at most half of MemAvailable is
+  committed - and by 256."""
+  procs = _physical_cores()
+  try:
+    with open('/proc/meminfo') as f:
+      avail_kb = [int(line.split()[1]) for line in f if line.startswith('MemAvailable:')][0]
+    procs = min(procs, max(1, int(avail_kb / 1024 / 1024 * 0.5 / 0.5)))
+  except (OSError, IndexError, ValueError):
+    procs = min(procs, 32)
+  return max(1, min(256, procs))
 
 
 def measure(clips_per_proc, procs, n_frames, n_harmonics, n_bands, n_samples, sample_rate, f0, timeout_s=180.0):

@@ -57,7 +57,8 @@ def test_json_line_fields_and_roofline_arithmetic(bench, world, batch, dominant)
               'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
     assert key in line, key
   assert line['unit'] == 'Msamples/s' and line['higher_is_better'] is True and line['scaling'] == 'weak'
-  assert line['vs_baseline'] is None and line['dtype'] == 'f32' and line['data'] == 'synthetic'
+  assert line['vs_baseline'] is None and line['dtype'].startswith('f32') and 'MFMA' in line['dtype']
+  assert line['data'] == 'synthetic' and line['per_gpu_value'] == pytest.approx(line['value'] / world)
   assert line['n_gpus'] == world and line['steps'] == 1000 and line['warmup'] == 500
   assert 'model' not in line['config'] and 'workload' in line['config']
   assert line['config']['global_batch'] == world * batch
@@ -98,13 +99,14 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   from ddsp_amd import _lib, build
 
   class _Stream:
-    pass
+    def wait_event(self, event):
+      pass
 
   class _Event:
     def __init__(self, enable_timing=False):
       pass
 
-    def record(self):
+    def record(self, stream=None):
       pass
 
     def elapsed_time(self, other):
@@ -142,6 +144,8 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
     def __call__(self, amplitudes, harmonic_distribution, f0_hz):
       calls['harm'] += 1
       calls['last_f0'] = float(f0_hz.mean())
+      calls.setdefault('f0s', []).append(calls['last_f0'])
+      calls.setdefault('batches', set()).add(int(amplitudes.shape[0]))
       return torch.zeros(amplitudes.shape[0], self.n)
 
   class _Noise:
@@ -168,7 +172,12 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 10
   assert line['cpu_baseline']['kind'] == 'port' and 'other_issue_mode' in line
   assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
-  assert abs(calls['last_f0'] - 200.0) < 2.0                           # the last steps ran the f0 = 200 regime...
+  assert any(abs(f - 200.0) < 2.0 for f in calls['f0s'])              # the f0 = 200 regime ran...
+  assert abs(calls['last_f0'] - 70.0) < 2.0                            # ...and the north-star shape after it, on its own inputs
+  assert calls['batches'] == {2, 128}
+  ns = line['north_star_shape']
+  assert ns['batch_per_gpu'] == 128 and ns['value'] > 0 and 0 < ns['whole_step']['frac'] and 'dominant_kernel' in ns
+  assert line['timing']['repeats'] >= 10 and line['timing']['region_ms_median'] > 0
   # ...and the headline inputs were put back afterwards (nothing after the regime reads them, but a later edit might)
 
 
@@ -180,13 +189,14 @@ def _mock_device(monkeypatch, bench, calls):
   from ddsp_amd import _lib, build
 
   class _Stream:
-    pass
+    def wait_event(self, event):
+      pass
 
   class _Event:
     def __init__(self, enable_timing=False):
       pass
 
-    def record(self):
+    def record(self, stream=None):
       pass
 
     def elapsed_time(self, other):
@@ -275,4 +285,33 @@ def test_cpu_baseline_leg_runs_concurrent_workers_and_falls_back(monkeypatch):
   monkeypatch.setattr(leg.sys, 'executable', '/nonexistent/python')            # workers cannot start
   r = leg.measure(1, 2, 10, 8, 9, 640, 16000, 200.0, timeout_s=10.0)
   assert r['cores'] == 1 and r['value'] == r['single_process_value'] and 'workers failed' in r['sample']
-  assert 1 <= leg.default_procs() <= 32
+  assert 1 <= leg.default_procs() <= 256
+
+
+def _run_bench(*argv, timeout=300):
+  import subprocess
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), cwd=ROOT, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+  """`python bench.py --gpus 2` with no torchrun around it becomes the launcher: two ranks through
+  torch.distributed.run on 127.0.0.1, rank 0's single JSON line passed through.  --dry-run (gloo, no device, the
+  step is a sleep) is the plumbing-test mode: what is checked is the launch, the rank logic, the barriers, the
+  max-over-ranks reduction, the all-gather and the shape of the line - no number in it is a measurement."""
+  r = _run_bench('--gpus', '2', '--dry-run', '--steps', '5', '--warmup', '2', '--batch', '2', '--n-frames', '10',
+                 '--n-samples', '640', '--allgather', '--no-cpu-baseline', '--north-star-batch', '4')
+  assert r.returncode == 0, r.stderr[-2000:]
+  out = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(out) == 1
+  line = json.loads(out[0])
+  assert line['n_gpus'] == 2 and line['dry_run'] is True and line['config']['global_batch'] == 4
+  assert line['scaling'] == 'weak' and line['per_gpu_value'] == pytest.approx(line['value'] / 2)
+  assert 'allgather_ms' in line and line['north_star_shape']['batch_per_gpu'] == 4
+  assert 'cpu_baseline' not in line and line['steps'] == 5 and line['timing']['repeats'] >= 10
+
+
+def test_gpus_2_on_a_box_without_two_gpus_refuses_instead_of_reporting_one():
+  r = _run_bench('--gpus', '2', '--steps', '5', '--warmup', '2')
+  assert r.returncode != 0 and 'refusing' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

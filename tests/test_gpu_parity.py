@@ -31,7 +31,8 @@ def harm_truth_check(ours, truth, scale=1.0, atol=None):
 
 @pytest.fixture(scope='module')
 def ddsp():
-  assert torch.cuda.is_available(), 'gpu tests need a GPU'
+  if not torch.cuda.is_available():
+    pytest.skip('gpu tests need a GPU (run with -m gpu on an MI355X)')
   from ddsp_amd import build
   build.build()
   import ddsp_amd
