@@ -134,12 +134,27 @@ def algorithmic_flops(a, batch):
 
 def cpu_baseline(a):
   """The oracle (numpy, fp32, op by op as TF executes it) on the host's cores: oracle/cpu_baseline.py runs
-  `cpu_procs` concurrent worker processes of `cpu_clips` clips each (TF's CPU kernels are multi-threaded;
-  `cores` = the workers actually used, the one-process figure is reported beside it)."""
+  P concurrent worker processes of `cpu_clips` clips each (TF's CPU kernels are multi-threaded; `cores` = the
+  workers actually used, the one-process figure is reported beside it).  The op chain is memory-bound (it
+  materialises the [N, K] tensors as TF does), so more workers is not monotonically faster - measured on the
+  2 x 64-core GPU host: 32 workers 10.5 Msamples/s, 128 workers 3.4.  With --cpu-procs 0 the leg therefore tries
+  32, 64 and the physical core count (each bounded by the cores there are) and reports the BEST as the baseline,
+  listing every count it tried."""
   from oracle import cpu_baseline as leg
-  procs = a.cpu_procs if a.cpu_procs > 0 else leg.default_procs()
-  return leg.measure(a.cpu_clips, procs, a.n_frames, a.n_harmonics, a.n_bands, a.n_samples, a.sample_rate,
-                     a.f0)
+  shape = (a.n_frames, a.n_harmonics, a.n_bands, a.n_samples, a.sample_rate, a.f0)
+  if a.cpu_procs > 0:
+    return leg.measure(a.cpu_clips, a.cpu_procs, *shape)
+  top = leg.default_procs()
+  tried, best = [], None
+  for procs in sorted({min(32, top), min(64, top), top}):
+    r = leg.measure(a.cpu_clips if procs <= 64 else max(2, a.cpu_clips // 2), procs, *shape)
+    tried.append({'workers': r['cores'], 'value': r['value']})
+    if best is None or r['value'] > best['value']:
+      best = r
+    elif r['value'] < 0.7 * best['value']:
+      break                       # past the memory-bandwidth knee: larger counts only get slower (and take longer)
+  best['worker_counts_tried'] = tried
+  return best
 
 
 def load_traffic(dominant, batch):

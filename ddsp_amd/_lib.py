@@ -85,7 +85,6 @@ HARM_AMP_LINEAR = 0x4
 HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
-HARM_TABLE_PHASE_ON_T = 0x80
 NOISE_SCALE_EXP_SIGMOID = 0x1
 NOISE_IR_MATRIX_CORES = 0x2
 NOISE_IR_FROM_REGISTERS = 0x4

@@ -65,6 +65,7 @@ struct ChunkTables {
   double theta[kWtRows], w[kWtRows], dw[kWtRows];
   float f0[kWtRows + 2];
   int kA[kWtRows], kN[kWtRows];
+  int cross;           // any frame of the chunk with a harmonic crossing Nyquist inside it (kA < kN)
 };
 
 template <int W> struct WtPoly;
@@ -129,10 +130,9 @@ __device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const flo
   if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
 }
 
-// The per-frame phase tables of a chunk (one wavefront, lanes = frames): the S-wavefront that builds them in the
-// default kernel is the slowest wavefront of every tick (profiles/r01_timeline_harm_table_b32.txt: 3450 clocks
-// against 2900 for the others, while the T-wavefronts wait 1100 at the barrier), so the TPH variant hands this
-// block of fp64 work to T-wavefront 0, between the issue of its MFMAs and the use of their results.
+// The per-frame phase tables of a chunk (one wavefront, lanes = frames).  (Handing this block of fp64 work to a
+// T-wavefront, between the issue of its MFMAs and the use of their results, was measured in round 2 and lost:
+// 21.3 against 20.0 us at batch 32, profiles/r02a_harm_table_vs_direct.json - the variant is gone.)
 // frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
 // which telescopes over j < J to hop sum_{j<J} f_j + (f_J - f_0)(hop-1)/2
 __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, ChunkTables& t, int lane, int nfr, int K,
@@ -156,6 +156,12 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
   if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
   if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
   kA = max(min(kA, kN), 0);
+  // harmonics [0,kA) are below Nyquist at every sample of the frame, [kN,K) at none: both rows carry zeros
+  // there; [kA,kN) is decided per sample.  v_rcp_f32 (1 ulp) is well inside the 4e-6 guard band.  Phase B
+  // looks at the per-frame bounds only when some frame of the chunk has a crossing at all.
+  const bool crossing = lane < nfr && kA < kN;
+  const unsigned long long any = __builtin_amdgcn_ballot_w64(crossing);
+  if (lane == 0) t.cross = any != 0ull ? 1 : 0;
   if (lane <= kWtRows) t.f0[lane] = fj;
   if (lane < kWtRows) {
     t.theta[lane] = cyc - floor(cyc);
@@ -187,8 +193,7 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
 // dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
 // reproduces the split), below the fp32 round-off of the sum itself.
 // NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
-// TPH (experimental, flag DDSP_HARM_TABLE_PHASE_ON_T): the phase tables on T-wavefront 0 instead of S-wavefront 7
-template <int W, int NK, bool ONE_TILE, bool TPH = false>
+template <int W, int NK, bool ONE_TILE>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
@@ -243,7 +248,6 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             alo[par][tt][ks][e] = (_Float16)((v - (float)h) * kWtLoScale);
           }
     int lb = first_b, lc = first_c;               // position of the chunk whose rows are fetched next
-    int qb = first_b, qc = first_c;               // TPH: position of the chunk whose phase tables are built next
 
     for (int tick = -3; tick < n_my; ++tick) {
       DDSP_WT_STAMP(0);
@@ -267,14 +271,6 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
       const float ptail = f0row[min(jt, F - 1)];
       const float f0_first = f0row[0];
       DDSP_WT_STAMP(1);
-      // TPH: the phase tables of chunk tick+2 (rows staged during the previous tick), on T-wavefront 0
-      const bool tph_now = TPH && rw == 0 && tick + 2 >= 0 && tick + 2 < n_my;
-      int tph_nfr = 0;
-      if (TPH && tick + 2 >= 0 && tick + 2 < n_my) {
-        tph_nfr = min(kWtFrames, F - qc * kWtFrames);
-        DDSP_WT_ADVANCE(qb, qc);
-      }
-      if (tph_now && tick + 1 < 0) wt_phase_tables(raw_all[(tick + 2) & 1], t_all[(tick + 2) % 3], lane, tph_nfr, K, p);
       // ---------------- table of chunk tick+1: O and E on the quarter range -----------------------------------
       if (tick + 1 >= 0 && tick + 1 < n_my) {
         // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row j][32 ks + 8 g + e]
@@ -303,8 +299,6 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             for (int tt = 0; tt < 2; ++tt)
               accx[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[par][tt], 0, 0, 0);
           }
-        // TPH: vector work that does not depend on the products, issued while the matrix pipe runs
-        if (tph_now) wt_phase_tables(raw_all[(tick + 2) & 1], t_all[(tick + 2) % 3], lane, tph_nfr, K, p);
         // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
         float* trow = tab_all[(tick + 1) & 1] + mi * kWtTS + kWtH;
 #pragma unroll
@@ -370,6 +364,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const ChunkTables& t = t_all[tick % 3];
         const int hop = p.hop;
         const float inv_hop = 1.0f / (float)hop;
+        const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
         const int tiles_per_frame = hop >> 6;
         const int n_tiles = nfr * tiles_per_frame;
         // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
@@ -400,9 +395,11 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             z[u] = (pos - fl) - 0.5f;
             t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
           }
+          if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
           float acc0[2] = {0.0f, 0.0f}, acc1[2] = {0.0f, 0.0f};
           if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z[0] * z[0], z[1] * z[1], acc0, acc1);
           else wt_taps<W, 0>(t0[0], z[0], z[0] * z[0], acc0[0], acc1[0]);
+          if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
           float out[2], w_cur[2], w_next[2], lerp[2];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
@@ -414,6 +411,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             const float v = w_cur[u] * acc0[u] + w_next[u] * acc1[u];
             out[u] = neg[u] ? -v : v;
           }
+          if (chunk_cross)
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             const int kA = __builtin_amdgcn_readfirstlane(t.kA[q[u]]);
@@ -433,6 +431,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
               }
             }
           }
+          if (tile == rw) DDSP_WT_STAMP(7);                    // envelope, Nyquist corrections done
           audio[(size_t)(row0 + q[0]) * hop + r[0]] = out[0];            // N == F * hop
           if constexpr (NT == 2) audio[(size_t)(row0 + q[1]) * hop + r[1]] = out[1];
         };
@@ -501,39 +500,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
-        // frame j carries f[t] = f_j + (f_{j+1}-f_j) r/hop; its sum over the frame is hop f_j + (f_{j+1}-f_j)(hop-1)/2,
-        // which telescopes over j < J to hop sum_{j<J} f_j + (f_J - f_0)(hop-1)/2
-        if (!TPH && rw == 7) {
-          const double* psum = reinterpret_cast<const double*>(raw + kWtRows * kWtRS);
-          const double before = (psum[0] + psum[1]) + (psum[2] + psum[3]);                 // sum_{j < j0} f_j
-          const float f0_first = raw[kWtRows * kWtRS + 8];
-          const float fj = raw[min(lane, nfr) * kWtRS + 128], fj1 = raw[min(lane + 1, nfr) * kWtRS + 128];
-          const double fa = (double)fj, fb = (double)fj1;
-          const double mine = (lane < nfr) ? fa : 0.0;
-          double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..15)
-          incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
-          incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
-          incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
-          incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
-          const double s_excl = before + (incl - mine);
-          const double run = p.hop_d * s_excl + (fa - (double)f0_first) * p.half_hm1;
-          const double cyc = run * p.inv_sr;
-          // harmonics [0,kA) are below Nyquist at every sample of the frame, [kN,K) at none: both rows carry
-          // zeros there; [kA,kN) is decided per sample.  v_rcp_f32 (1 ulp) is well inside the 4e-6 guard band.
-          const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
-          int kA = K, kN = K;
-          if (fmx > 0.0f) kA = (int)fminf((float)K, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
-          if (fmn > 0.0f) kN = (int)fminf((float)K, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
-          kA = max(min(kA, kN), 0);
-          if (lane <= kWtRows) t.f0[lane] = fj;
-          if (lane < kWtRows) {
-            t.theta[lane] = cyc - floor(cyc);
-            t.w[lane] = fa * p.inv_sr;
-            t.dw[lane] = (fb - fa) * p.inv_sr * p.inv_2hop;
-            t.kA[lane] = kA;
-            t.kN[lane] = kN;
-          }
-        }
+        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);
       }
       DDSP_WT_STAMP(3);
       __syncthreads();
@@ -588,26 +555,19 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-#define DDSP_LAUNCH_TABLE(W, NK, TPH)                                                                         \
+#define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
   do {                                                                                                        \
     if (p.hop == 64)                                                                                          \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, TPH>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, p);                                                                        \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, ctl_amp, ctl_hd, p);                                                               \
     else                                                                                                      \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false, TPH>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, p);                                                                        \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, ctl_amp, ctl_hd, p);                                                               \
   } while (0)
-  static const bool tph_env = getenv("DDSP_EXP_TABLE_PHASE_ON_T") != nullptr;
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
-  if (tph_env || (flags & DDSP_HARM_TABLE_PHASE_ON_T)) {     // experimental: phase tables on a T-wavefront
-    if (K <= 64) DDSP_LAUNCH_TABLE(6, 1, true);
-    else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2, true);
-    else DDSP_LAUNCH_TABLE(8, 2, true);
-  } else {
-    if (K <= 64) DDSP_LAUNCH_TABLE(6, 1, false);
-    else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2, false);
-    else DDSP_LAUNCH_TABLE(8, 2, false);
-  }
+  if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);
+  else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
+  else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
   if (p.dbg) {
     static long long host[3 * 64 * 8];
@@ -618,8 +578,12 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
       for (int w = 0; w < 3; ++w)
         for (int i = 0; i < 64 && host[(w * 64 + i) * 8] != 0; ++i) {
           const long long* r = host + (w * 64 + i) * 8;
-          fprintf(stderr, "[timeline] %s tick %3d  start %8lld  +%6lld +%6lld +%6lld  barrier +%6lld\n", names[w], i - 3,
+          fprintf(stderr, "[timeline] %s tick %3d  start %8lld  +%6lld +%6lld +%6lld  barrier +%6lld", names[w], i - 3,
                   r[0] - t0, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]);
+          if (w > 0 && r[5] != 0)      // S-wavefronts: inside phase B's first tile pair (since tick start)
+            fprintf(stderr, "   | B: coord +%5lld taps +%5lld env +%5lld store..end +%5lld", r[5] - r[0], r[6] - r[5],
+                    r[7] - r[6], r[1] - r[7]);
+          fprintf(stderr, "\n");
         }
     }
   }

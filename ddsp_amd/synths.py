@@ -136,10 +136,8 @@ class Harmonic(processors.Processor):
                                  self.use_angular_cumsum)
     if self.kernel == 'direct':
       flags |= _lib.HARM_DIRECT_SUM
-    elif self.kernel == 'table_tphase':          # experimental variant of the wavetable kernel (see harmonic_table.hip)
-      flags |= _lib.HARM_TABLE_PHASE_ON_T
     elif self.kernel != 'auto':
-      raise ValueError("Harmonic.kernel must be 'auto', 'direct' or 'table_tphase', got {!r}".format(self.kernel))
+      raise ValueError("Harmonic.kernel must be 'auto' or 'direct', got {!r}".format(self.kernel))
     return flags
 
   def _forward(self, amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict=False):

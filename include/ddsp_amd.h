@@ -43,8 +43,6 @@ extern "C" {
 #define DDSP_HARM_ANGULAR_CUMSUM 0x8u     /* use_angular_cumsum=True (phase) */
 #define DDSP_HARM_NO_AUDIO_RATE_MASK 0x10u      /* internal to the streaming entry: no per-sample Nyquist mask */
 #define DDSP_HARM_INPUTS_ARE_AMPLITUDES 0x20u   /* streaming entry: harmonic_distribution=None (core.py:1149-1150) */
-#define DDSP_HARM_TABLE_PHASE_ON_T 0x80u  /* ddsp_harmonic_f32, wavetable kernel: experimental - the per-frame fp64 phase tables
-                                             are built by a T-wavefront under its MFMAs instead of by the slowest S-wavefront */
 #define DDSP_HARM_DIRECT_SUM 0x40u        /* ddsp_harmonic_f32: sum the harmonics sample by sample (sine recurrence on the
                                              vector ALUs) even where the matrix-core wavetable kernel applies */
 

@@ -300,6 +300,16 @@ inline int __builtin_amdgcn_readlane(int v, int src_lane) {
   });
 }
 
+// v_cmp + s_mov of the result: one bit per live lane whose predicate holds, the same 64-bit value in every lane
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) {
+  return ddsp_emu::wave_op<int, unsigned long long>(30, 0, pred ? 1 : 0, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    unsigned long long mask = 0;
+    for (int l = 0; l < 64; ++l)
+      if (ddsp_emu::is_live(live, l) && ddsp_emu::in_of<int>(op, l)) mask |= 1ull << l;
+    for (int l = 0; l < 64; ++l) ddsp_emu::out_of<unsigned long long>(op, l) = mask;
+  });
+}
+
 // DPP: lane i reads `src` from the lane its control selects; a lane whose source is invalid (outside the
 // row / wave), not live, or whose row / bank is masked off keeps `old` (bound_ctrl = false).
 inline int ddsp_emu_dpp_source(int lane, int ctrl) {

@@ -380,32 +380,3 @@ def test_filtered_noise_matrix_ir_design_vs_oracle_and_vector(ddsp, matrix_ir, b
       synth(mags, noise=noise)
     finally:
       ddsp.synths.FilteredNoise.ir_design = 'vector'
-
-
-# ---- Harmonic.kernel = 'table_tphase': the wavetable kernel with the phase tables built by a T-wavefront ---------
-@pytest.mark.parametrize('batch,n_frames,k,hop,f0c', [(2, 50, 100, 64, 70.0), (3, 15, 100, 64, 70.0), (1, 16, 100, 64, 200.0),
-                                                      (2, 17, 128, 64, 50.0), (1, 31, 64, 128, 110.0), (1, 7, 60, 192, 300.0),
-                                                      (1, 1, 4, 64, 100.0), (5, 1, 100, 64, 70.0), (1, 250, 100, 64, 79.9)])
-def test_harmonic_table_kernel_with_phase_tables_on_a_t_wavefront(ddsp, batch, n_frames, k, hop, f0c):
-  """Same arithmetic, another wavefront: the variant must reproduce the default wavetable kernel (controls dict bit
-  for bit, audio to an fp32 ulp), and so inherit its parity with the oracle."""
-  rng = np.random.default_rng(n_frames * 7 + k)
-  n = n_frames * hop
-  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
-  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
-  f0 = (f0c * (1.0 + 0.01 * rng.standard_normal((batch, n_frames, 1)))).astype(np.float32)
-  old = ddsp.synths.Harmonic.kernel
-  try:
-    outs = {}
-    for kernel in ('auto', 'table_tphase'):
-      ddsp.synths.Harmonic.kernel = kernel
-      outs[kernel] = ddsp.synths.Harmonic(n_samples=n, sample_rate=16000)(amps, hd, f0, return_outputs_dict=True)
-  finally:
-    ddsp.synths.Harmonic.kernel = old
-  # the same expressions on another wavefront: identical on the CPU emulation; on the GPU the two instantiations are
-  # compiled separately and may contract a*b+c differently in the fp64 phase, hence one fp32 ulp of slack
-  np.testing.assert_allclose(npy(outs['table_tphase']['signal']), npy(outs['auto']['signal']), rtol=0, atol=1e-6)
-  for key in ('amplitudes', 'harmonic_distribution'):
-    np.testing.assert_array_equal(npy(outs['table_tphase']['controls'][key]), npy(outs['auto']['controls'][key]))
-  truth = O.harmonic(amps, hd, f0, n, 16000, dtype=np.float64)
-  parity_check(npy(outs['table_tphase']['signal']), truth, 2e-4 * 2.0)

@@ -17,7 +17,7 @@ for B in batches:
   f0 = ddsp.core.tf_float32(70 + rng.standard_normal((B, F, 1)))
   res = {'batch': B}
   outs = {}
-  for kernel in ('auto', 'table_tphase', 'direct'):
+  for kernel in ('auto', 'direct'):
     synth = ddsp.synths.Harmonic(n_samples=N)
     synth.kernel = kernel
     for _ in range(20): synth(amps, hd, f0)
@@ -35,5 +35,4 @@ for B in batches:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     res[kernel] = {'us_per_call_back_to_back': dt * 1e6, 'kernel_us': {k: v[0] / v[1] * 1e3 for k, v in bd.items()}}
   res['max_abs_diff'] = float((outs['auto'] - outs['direct']).abs().max())
-  res['tphase_max_abs_diff'] = float((outs['auto'] - outs['table_tphase']).abs().max())      # same arithmetic: 0
   print(json.dumps(res))
