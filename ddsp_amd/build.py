@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'filtered_noise.hip', 'reverb.hip', 'spectral_loss.hip', 'general.hip', 'profile.hip']
+SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'filtered_noise.hip', 'filtered_noise_mfma.hip', 'reverb.hip', 'spectral_loss.hip', 'general.hip', 'profile.hip']
 OUT = os.path.join(HERE, 'lib', 'libddsp_amd.so')
 
 
@@ -46,9 +46,23 @@ def build(force=False, verbose=True):
     return OUT
   hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
   os.makedirs(os.path.dirname(OUT), exist_ok=True)
-  cmd = [hipcc] + FLAGS + ['-I' + os.path.join(ROOT, 'include')]
-  cmd += [os.path.join(HERE, 'csrc', s) for s in SOURCES]
-  cmd += ['-o', OUT]
+  objdir = os.path.join(HERE, 'lib', 'obj')
+  os.makedirs(objdir, exist_ok=True)
+  compile_flags = [f for f in FLAGS if f != '-shared'] + ['-I' + os.path.join(ROOT, 'include')]
+
+  def compile_one(src):
+    obj = os.path.join(objdir, src.replace('.hip', '.o'))
+    cmd = [hipcc] + compile_flags + ['-c', os.path.join(HERE, 'csrc', src), '-o', obj]
+    if verbose:
+      print('[ddsp_amd.build]', ' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+  # one hipcc per translation unit, side by side (the sources are independent: no relocatable device code)
+  from concurrent.futures import ThreadPoolExecutor
+  with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+    objs = list(pool.map(compile_one, SOURCES))
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT]
   if verbose:
     print('[ddsp_amd.build]', ' '.join(cmd), flush=True)
   subprocess.run(cmd, check=True)

@@ -11,6 +11,8 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #include "common.h"
+#include "noise_ir65.h"
+#include "filtered_noise_mfma.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
 
@@ -184,52 +186,7 @@ __global__ __launch_bounds__(256) void tv_fir_kernel(FirArgs p) {
 // full-length Hann window (window_size <= 0 or >= 128), frame_size = 64, L = 128.
 // ====================================================================================
 
-// ---- compile-time cosine tables -----------------------------------------------------
-constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr double cos_taylor(double x) {        // |x| <= pi/4
-  double x2 = x * x, term = 1.0, sum = 1.0;
-  for (int i = 1; i <= 12; ++i) { term *= -x2 / ((2 * i - 1) * (2 * i)); sum += term; }
-  return sum;
-}
-constexpr double sin_taylor(double x) {        // |x| <= pi/4
-  double x2 = x * x, term = x, sum = x;
-  for (int i = 1; i <= 12; ++i) { term *= -x2 / ((2 * i) * (2 * i + 1)); sum += term; }
-  return sum;
-}
-constexpr double cos_q128(int q) {             // cos(2 pi q / 128), exact octant reduction
-  q = ((q % 128) + 128) % 128;
-  if (q > 64) q = 128 - q;                     // cos(2pi - x) = cos x        -> q in [0,64]
-  bool neg = false;
-  if (q > 32) { q = 64 - q; neg = true; }      // cos(pi - x) = -cos x        -> q in [0,32]
-  const double v = (q <= 16) ? cos_taylor(2.0 * kPi * q / 128.0)
-                             : sin_taylor(2.0 * kPi * (32 - q) / 128.0);   // cos x = sin(pi/2 - x)
-  return neg ? -v : v;
-}
-constexpr int kIrRowStride = 80;               // floats per table row (16-dword aligned halves)
-struct Ir65Table {
-  // row n (0..32): [0..32] = w_m * cos(2 pi (2i) n / 128) for even m = 2i,
-  //                [40..71] = w_m * cos(2 pi (2i+1) n / 128) for odd m = 2i+1,
-  // w_m = irfft weight: 1/128 for the DC and Nyquist bins, 2/128 otherwise.
-  float c[33 * kIrRowStride];
-  float win[64];                               // Hann(128)[64 + d] = 0.5 + 0.5 cos(2 pi d / 128)
-};
-constexpr Ir65Table make_ir65_table() {
-  Ir65Table t{};
-  for (int n = 0; n <= 32; ++n) {
-    for (int i = 0; i <= 32; ++i) {
-      const int m = 2 * i;
-      const double w = (m == 0 || m == 64) ? 1.0 / 128.0 : 2.0 / 128.0;
-      t.c[n * kIrRowStride + i] = (float)(w * cos_q128(m * n));
-    }
-    for (int i = 0; i < 32; ++i) {
-      const int m = 2 * i + 1;
-      t.c[n * kIrRowStride + 40 + i] = (float)((2.0 / 128.0) * cos_q128(m * n));
-    }
-  }
-  for (int d = 0; d < 64; ++d) t.win[d] = (float)(0.5 + 0.5 * cos_q128(d));
-  return t;
-}
-__constant__ Ir65Table kIr65 = make_ir65_table();
+// (the compile-time cosine tables live in noise_ir65.h, shared with filtered_noise_mfma.hip)
 
 // ---- IR design, lanes = frames --------------------------------------------------------
 // One block = 64 consecutive (batch*frame) rows, 4 wavefronts.  Every lane keeps ITS row's 65
@@ -1074,6 +1031,15 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   {
     const IrGeom g = ir_geom(M, window_size);
     const int frame_size = (N + F - 1) / F;
+    // default for the canonical filter: IR design AND the FIR on the matrix cores (filtered_noise_mfma.hip);
+    // DDSP_NOISE_FIR_VECTOR_ALU (or DDSP_EXP_NOISE_FIR=vector) keeps the FIR on the vector ALUs (noise_fused65_kernel)
+    static const bool fir_vector_env = [] { const char* e = getenv("DDSP_EXP_NOISE_FIR"); return e && e[0] == 'v'; }();
+    if (!(flags & DDSP_NOISE_FIR_VECTOR_ALU) && !fir_vector_env && B <= 65535 &&
+        noise_mfma65_ok(F, M, N, g.padding, noise)) {
+      long long* dbg = (flags & 0x40000000u) ? reinterpret_cast<long long*>(ctl_magnitudes) : nullptr;   // debug timeline
+      return launch_noise_mfma65(magnitudes, noise, audio, dbg ? nullptr : ctl_magnitudes, B, F, N, (g.L - 1) / 2 - 1,
+                                 initial_bias, scale, seed, batch_offset, dbg, st);
+    }
     if (M == 65 && g.padding == 0 && frame_size >= 64 && (frame_size % 16) == 0 && frame_size <= 4096 &&
         (N + frame_size - 1) / frame_size == F && B <= 65535 &&
         (noise == nullptr || (((uintptr_t)noise) & 15) == 0)) {

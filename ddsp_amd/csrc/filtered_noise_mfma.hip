@@ -1,0 +1,387 @@
+// FilteredNoise.__call__ (ddsp/synths.py:165-196) for the canonical filter (65 bands -> 128 taps, full Hann window)
+// with BOTH of its contractions on the gfx950 matrix cores: the cosine transform of the IR design
+// (core.frequency_impulse_response, ddsp/core.py:1534-1565) and the time-varying FIR that core.fft_convolve
+// (ddsp/core.py:1382-1473) is algebraically equal to.
+//
+// The FIR as a matrix product.  core.fft_convolve frames the audio (frame = 64 samples here), convolves frame f with
+// ITS taps h_f and overlap-adds; in the time domain
+//     z[m] = sum_i x[i] h_{frame(i)}[m - i],          out[n] = z[n + start]     (crop_and_compensate_delay, :1338-1379).
+// Take a PAIR of frames (f, f+1) whose first sample is Z: they only reach the 256 outputs z[Z .. Z+255] (64 + 64 + 127).
+// Write an output index as Z + 16 a + b (a = 0..15 the column, b = 0..15 the row), a sample of frame f as
+// j = 16 p + b - d (p = 0..4, d = 0..15; 16 p - d runs over -15..64 once, samples outside 0..63 are zero).  Then
+//     C[b][a] = sum_{p,d} X_f[b][(p,d)] H_f[(p,d)][a],    X_f[b][(p,d)] = x_f[16 p + b - d],   H_f[(p,d)][a] = h_f[16 (a - p) + d]
+// (h outside 0..127 is zero), and the second frame of the pair adds the same with a -> a - 4.  That is a
+// [16 x 160] . [160 x 16] product per pair: five v_mfma_f32_16x16x32_f16 steps.  X is Toeplitz in the noise, H is dense
+// in the taps; a lane's 8 consecutive k values are 8 consecutive samples (descending: the noise is stored reversed) and
+// 8 consecutive taps.  fp32 results come from fp16 matrix cores the way harmonic_table.hip gets them: both factors are
+// split hi + lo / 2048 and hi.hi, hi.lo + lo.hi are accumulated in fp32 (3 MFMAs per step, 15 per pair = 7.5 per
+// frame against 128 v_fma per lane and frame on the vector ALUs).  Successive pairs overlap by 128 outputs: the right
+// half of a pair's tile is shifted 8 columns (DPP row_shl:8) into the accumulator of the next pair, the left half is
+// complete and is stored.
+//
+// Alignment.  The Toeplitz operand wants 16 bytes of fp16 from an address that moves by ONE element (2 bytes) from row
+// to row.  gfx950 reads such a thing correctly (ds_read_b128 at 2-byte alignment) but ten times slower than an aligned
+// one; at 4-byte alignment two ds_read2_b32 cost 1.7x (profiles/r02a_microbench_lds_unaligned.txt).  The reversed noise
+// is therefore kept twice, the second copy shifted by one element, and a row reads the copy its parity selects.
+//
+// One block = 62 output frames (3968 samples) of one batch row = 64 staged frames (two of halo), 8 wavefronts:
+//   1. every wavefront fetches its 16 x 16 magnitudes straight from HBM into the B-fragment layout of the IR design
+//      (no LDS staging), 2. generates its share of the Philox noise tile while those loads fly (reversed, hi / lo split,
+//      two copies), 3. exp_sigmoid, split, 6 MFMAs against the constant cosine fragments, window, split the taps
+//      hi / lo into the LDS tap table; one barrier; 4. FIR: a wavefront walks 4 pairs (one extra pair before them
+//      only to build the carry), stores 128 samples per pair.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <cstdlib>
+#include "../../include/ddsp_amd.h"
+#include "common.h"
+#include "noise_ir65.h"
+#include "profile.h"
+#include "filtered_noise_mfma.h"
+
+namespace ddsp {
+
+constexpr int kMfFrames = 62;                  // output frames per block
+constexpr int kMfRows = 64;                    // staged frames: 2 of halo + 62
+constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per block
+constexpr int kMfWaves = 8;
+constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
+// tap table: per row 16 groups of {8 hi halves, 8 lo halves} (32 bytes) + one group of zeros that lanes outside the
+// filter's support read
+constexpr int kMfTapRowBytes = 17 * 32;        // 544
+// noise: reversed frames, sample j of staged frame s at element 16 + 80 s + 63 - j; the 16 elements between frames
+// stay zero (the Toeplitz blocks run over both ends of a frame).  Stored as dwords of two elements, hi and lo parts in
+// separate planes: copy E holds elements (2k, 2k+1) in dword k, copy O holds elements (2k-1, 2k).  A fragment is then
+// four consecutive dwords of one plane at a 4-byte aligned address: two ds_read2_b32 into four consecutive registers.
+constexpr int kMfXStride = 80;
+constexpr int kMfXElems = 16 + kMfRows * kMfXStride + 16;     // 5152
+constexpr int kMfXPairs = kMfXElems / 2 + 1;                   // 2577 (copy O needs one more)
+constexpr int kMfXPlane = ((kMfXPairs * 4 + 15) / 16) * 16;    // bytes of one plane: 10320
+
+typedef _Float16 mf_f16x8 __attribute__((ext_vector_type(8)));
+typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 mf_h16x2 __attribute__((ext_vector_type(2)));
+
+struct MfArgs {
+  int N, F, start, scale, fs;       // fs = frame size (64: one tap row per staged frame; 64 c: c staged frames per row)
+  float inv_fs;
+  float bias;
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+  long long* dbg;                   // per-block phase stamps (tools/exp_timeline_noise.py), or null
+};
+
+struct __attribute__((packed, aligned(4))) MfU4f { float x, y, z, w; };        // 16 bytes from a 4-byte aligned address
+struct __attribute__((packed, aligned(4))) MfU4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t mf_pack(_Float16 a, _Float16 b) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+__device__ __forceinline__ void mf_split(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * kMfLoScale);
+}
+__device__ __forceinline__ void mf_split8(const float (&v)[8], mf_f16x8& hi, mf_f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 h, l;
+    mf_split(v[e], h, l);
+    hi[e] = h;
+    lo[e] = l;
+  }
+}
+__device__ __forceinline__ mf_f16x8 mf_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(mf_f16x8, v);
+}
+
+// FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s
+template <bool GEN_NOISE, bool FS64>
+__global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
+    const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
+    float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_taps[kMfRows * kMfTapRowBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char s_x[4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
+  unsigned char* const s_xe = s_x;
+  unsigned char* const s_xo = s_x + 2 * kMfXPlane;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int z0 = blockIdx.x * kMfTile;                 // first output (z index) of the block; a multiple of 64
+  // tap rows: frames f_first .. f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile
+  const int f_first = (z0 - 128 >= 0) ? (z0 - 128) / p.fs : -((128 - z0 + p.fs - 1) / p.fs);
+  const int rel0 = (z0 - 128) - f_first * p.fs;
+  // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+  const int own_lo = (blockIdx.x == 0) ? 0 : f_first + 2;
+  const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
+  const float kLog10 = 2.302585092994046f;
+  const int do_scale = p.scale & 1;
+  long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  int dbg_n = 0;
+#define DDSP_MF_STAMP() do { if (dbg && tid == 0 && dbg_n < 8) dbg[dbg_n++] = wall_clock64(); } while (0)
+  DDSP_MF_STAMP();     // 0: start
+
+  const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
+
+  // ---- 0. loads that nothing waits for yet ---------------------------------------------------------------------
+  // this wavefront's share of the constant cosine factor in A-operand layout: taps n = 16 mt + i, bins 2 k' (+ 1),
+  // k' = 8 g + e (wavefront w designs rows 16 (w & 3) .. + 15, tap tile mt = w >> 2)
+  const int mt = wave >> 2;
+  mf_f16x8 ae_hi, ae_lo, ao_hi, ao_lo;
+  {
+    const float* __restrict__ crow = kIr65.c + (16 * mt + mi) * kIrRowStride + 8 * mg;
+    float ve[8], vo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ve[e] = crow[e]; vo[e] = crow[40 + e]; }
+    mf_split8(ve, ae_hi, ae_lo);
+    mf_split8(vo, ao_hi, ao_lo);
+  }
+  // the 16 bins of this lane's B-fragments (row = 16 (wave & 3) + i, bins 16 g .. + 15) and bin 64 of that row;
+  // rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
+  const int rrow = 16 * (wave & 3) + mi;
+  const int rfr = f_first + rrow;
+  const bool rvalid = rfr >= 0 && rfr < p.F;
+  MfU4f rq[4];
+  float r_last;
+  {
+    const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+    r_last = src[64];
+  }
+
+  // ---- 1. zeros: the 16 elements between the reversed frames (both copies), the zero group of every tap row --------
+  for (int i = tid; i < 65 * 16; i += 64 * kMfWaves) {
+    const int e = 80 * (i >> 4) + (i & 15);                         // element index of a padding element
+    // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
+    *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
+    *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
+    *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
+    *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
+  }
+  if (tid < kMfRows * 2)
+    *reinterpret_cast<uint4*>(s_taps + (tid >> 1) * kMfTapRowBytes + 512 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
+
+  // ---- 2. the noise tile x[z0-128 .. z0+3967]: reversed, hi / lo split, two copies -------------------------------------
+  for (int qd = tid; qd < (kMfTile + 128) / 4; qd += 64 * kMfWaves) {
+    const int i = z0 - 128 + 4 * qd;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < p.N) {
+      if (GEN_NOISE) {
+        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+        if (i + 1 >= p.N) v.y = 0.f;
+        if (i + 2 >= p.N) v.z = 0.f;
+        if (i + 3 >= p.N) v.w = 0.f;
+      } else {
+        const float* src = x + (size_t)b * p.N + i;
+        if (i + 3 < p.N && ((p.N & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (i + 1 < p.N) v.y = src[1];
+          if (i + 2 < p.N) v.z = src[2];
+          if (i + 3 < p.N) v.w = src[3];
+        }
+      }
+    }
+    _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+    mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+    mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+    mf_split(v.y, h2, l2);
+    mf_split(v.x, h3, l3);
+    const int s = qd >> 4, j = 4 * (qd & 15);
+    const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+    // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+    *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+    *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+    // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of dword
+    // u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+    unsigned char* po = s_xo + (u0 + 1) * 2;
+    *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+    *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+    *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+    *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+  }
+  DDSP_MF_STAMP();     // 1: noise tile staged
+
+  // ---- 3. IR design: controls in registers, fragments, products, windowed taps -> tap table ----------------------------
+  {
+    float y[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
+    float m_last = r_last;
+    if (do_scale) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
+      m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+    }
+    if (!rvalid) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) y[c] = 0.0f;
+      m_last = 0.0f;
+    }
+    if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi && wave < 4) {       // written by the owning tile only
+      float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+        *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
+      if (mg == 0) dst[64] = m_last;
+    }
+    float ve[8], vo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
+    mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+    mf_split8(ve, be_hi, be_lo);
+    mf_split8(vo, bo_hi, bo_lo);
+    const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi, be_hi, zero, 0, 0, 0);
+    mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi, bo_hi, zero, 0, 0, 0);
+    mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi, be_lo, zero, 0, 0, 0);
+    mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi, bo_lo, zero, 0, 0, 0);
+    ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_lo, be_hi, ex, 0, 0, 0);
+    ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_lo, bo_hi, ox, 0, 0, 0);
+    const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
+    unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
+    // tap t of the row: group t >> 3 (32 bytes: 8 hi halves, 8 lo halves), element t & 7
+    auto put = [&](int t, float val) {
+      _Float16 h, l;
+      mf_split(val, h, l);
+      unsigned char* q = hrow + (t >> 3) * 32 + (t & 7) * 2;
+      *reinterpret_cast<uint16_t*>(q) = __builtin_bit_cast(uint16_t, h);
+      *reinterpret_cast<uint16_t*>(q + 16) = __builtin_bit_cast(uint16_t, l);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 16 * mt + 4 * mg + r;                           // 0 .. 31
+      const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);
+      const float o = ov[r];
+      const float g0 = kIr65.win[n] * (e + o);                       // g[n]:    taps 64+n and 64-n
+      put(64 + n, g0);
+      if (n >= 1) {
+        put(64 - n, g0);
+        const float g1 = kIr65.win[64 - n] * (e - o);                // g[64-n]: taps 128-n and n
+        put(128 - n, g1);
+        put(n, g1);
+      }
+    }
+    if (wave < 4) {
+      // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
+      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
+      float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      if (mg == 0) {
+        const float g0 = kIr65.win[32] * part;
+        put(96, g0);
+        put(32, g0);
+        put(0, 0.0f);                                                  // h[0] = Hann(128)[0] * hz[-64] = 0
+      }
+    }
+  }
+  __syncthreads();
+  DDSP_MF_STAMP();     // 2: IR designed, everything staged
+
+  // ---- 4. FIR: pairs of frames on the matrix cores ------------------------------------------------------------------
+  // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block P = 2 c + (g >> 1) of the
+  // pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
+  //   A (row b = i): x_frame[16 p + b - d], e = 0..7  =  reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
+  //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
+  int a_off[5], b_off[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int P = 2 * c + (mg >> 1);
+    const int second = P >= 5 ? 1 : 0;
+    const int pp = P - 5 * second;
+    const int u = 79 + kMfXStride * second - 16 * pp - mi + 8 * (mg & 1);            // relative to the pair's first frame
+    // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
+    a_off[c] = ((u + 1) >> 1) * 4;
+    const int q = (mi - 4 * second) - pp;
+    b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 32 : 512;
+  }
+  const unsigned char* xsel = (mi & 1) ? s_xe : s_xo;                 // i odd -> u even -> copy E
+  // wavefront w: output pairs 4 w + 1 .. 4 w + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are output),
+  // preceded by pair 4 w, whose left half belongs to the previous wavefront (or, pair 0, to the previous block)
+  const int p_first = 4 * wave, p_last = min(4 * wave + 4, kMfRows / 2 - 1);
+  mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+  float* __restrict__ o = out + (size_t)b * p.N;
+#pragma unroll 1
+  for (int P = p_first; P <= p_last; ++P) {
+    // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
+    const int rowA = FS64 ? 2 * P : (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
+    const int rowB = FS64 ? 2 * P + 1 : (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
+    const unsigned char* xa = xsel + 2 * kMfXStride * 2 * P;         // 2 frames = 160 elements = 320 bytes of a plane
+    const unsigned char* ta = s_taps + rowA * kMfTapRowBytes;
+    const unsigned char* tb = s_taps + rowB * kMfTapRowBytes;
+    mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const unsigned char* pa = xa + a_off[c];
+      const MfU4 qh = *reinterpret_cast<const MfU4*>(pa), ql = *reinterpret_cast<const MfU4*>(pa + kMfXPlane);
+      const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
+      // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
+      const unsigned char* tr = (c < 2) ? ta : (c > 2) ? tb : ((mg >> 1) ? tb : ta);
+      const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr + b_off[c]);
+      const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + b_off[c] + 16);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
+      acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
+      acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
+    }
+    const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
+    // D[row b = 4 g + r][col a = i]: z = z0 - 128 + 128 P + 16 a + b; columns 0..7 are complete
+    if (P > p_first && mi < 8) {
+      const long n = (long)z0 - 128 + 128L * P + 16 * mi + 4 * mg - p.start;       // out index of comb[0]
+      if (n >= 0 && n + 3 < p.N && (((n | p.N) & 1) == 0)) {
+        *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
+        *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r >= 0 && n + r < p.N) o[n + r] = comb[r];
+      }
+    }
+    // columns 8..15 -> columns 0..7 of the next pair's tile (row_shl:8, out-of-row lanes read 0)
+    // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - clang 22)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = comb[r];
+      carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
+    }
+  }
+  DDSP_MF_STAMP();     // 3: FIR done and stored
+#undef DDSP_MF_STAMP
+}
+
+bool noise_mfma65_ok(int F, int M, int N, int padding, const void* noise) {
+  const int frame_size = (N + F - 1) / F;
+  return M == 65 && padding == 0 && frame_size >= 64 && (frame_size % 64) == 0 && frame_size <= 4096 &&
+         (N + frame_size - 1) / frame_size == F && (noise == nullptr || (((uintptr_t)noise) & 15) == 0);
+}
+
+int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audio, float* ctl_magnitudes, int B, int F,
+                        int N, int start, float initial_bias, int scale, uint64_t seed, uint64_t batch_offset,
+                        long long* dbg, hipStream_t st) {
+  MfArgs q;
+  q.N = N; q.F = F; q.start = start; q.bias = initial_bias; q.scale = scale;
+  q.fs = (N + F - 1) / F; q.inv_fs = 1.0f / (float)q.fs;
+  q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
+  q.dbg = dbg;
+  const dim3 grid((unsigned)((N + start + kMfTile - 1) / kMfTile), (unsigned)B);
+  hipEvent_t ev0, ev1;
+  profile_kernel_events(kNoiseMfma, &ev0, &ev1);
+#define DDSP_LAUNCH_MF(GEN, FS64)                                                                                      \
+  hipExtLaunchKernelGGL((noise_mfma65_kernel<GEN, FS64>), grid, dim3(64 * kMfWaves), 0, st, ev0, ev1, 0, magnitudes, noise, \
+                        ctl_magnitudes, audio, q)
+  if (q.fs == 64) { if (noise) DDSP_LAUNCH_MF(false, true); else DDSP_LAUNCH_MF(true, true); }
+  else { if (noise) DDSP_LAUNCH_MF(false, false); else DDSP_LAUNCH_MF(true, false); }
+#undef DDSP_LAUNCH_MF
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+}  // namespace ddsp

@@ -27,6 +27,7 @@ enum KernelId {
   kNoiseBwdMags,
   kStftL1Bwd,
   kHarmTable,
+  kNoiseMfma,
   kNumKernels
 };
 

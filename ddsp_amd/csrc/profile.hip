@@ -18,7 +18,8 @@ const char* const kNames[kNumKernels] = {
     "tv_fir_kernel", "uniform_noise_kernel", "add_kernel", "exp_sigmoid_kernel",
     "harm_fused_kernel", "noise_fused65_kernel", "rv_fft_kernel", "rv_mac_kernel",
     "rv_ifft_kernel", "stft_l1_kernel", "harm_bwd_pq_kernel", "harm_bwd_chain_kernel",
-    "noise_bwd_taps_kernel", "noise_bwd_mags_kernel", "stft_l1_bwd_kernel", "harm_table_kernel"};
+    "noise_bwd_taps_kernel", "noise_bwd_mags_kernel", "stft_l1_bwd_kernel", "harm_table_kernel",
+    "noise_mfma65_kernel"};
 }  // namespace
 
 void profile_record(int kernel_id, hipStream_t st, bool start) {

@@ -244,6 +244,10 @@ class FilteredNoise(processors.Processor):
   within the parity tolerance.
   """
   ir_design = 'vector'
+  # 'auto': the canonical filter (65 bands, full window, frames of 64 c samples) runs noise_mfma65_kernel - IR design and
+  # the time-varying FIR on the fp16 matrix cores (hi/lo-split operands, fp32 accumulation); 'vector': the FIR on the
+  # vector ALUs (noise_fused65_kernel, with `ir_design` choosing its IR design).  Same result within the parity tolerance.
+  kernel = 'auto'
 
   def __init__(self,
                n_samples=64000,
@@ -282,6 +286,13 @@ class FilteredNoise(processors.Processor):
     return {'magnitudes': ctl}
 
   def _ir_flag(self):
+    if self.kernel == 'auto':
+      return 0
+    if self.kernel != 'vector':
+      raise ValueError("FilteredNoise.kernel must be 'auto' or 'vector', got {!r}".format(self.kernel))
+    return _lib.NOISE_FIR_VECTOR_ALU | self._ir_design_flag()
+
+  def _ir_design_flag(self):
     if self.ir_design == 'matrix':
       return _lib.NOISE_IR_MATRIX_CORES
     if self.ir_design == 'matrix_direct':

@@ -51,6 +51,16 @@ def harm_kernel(request, ddsp):
   ddsp.synths.Harmonic.kernel = old
 
 
+@pytest.fixture(params=['auto', 'vector'])
+def noise_kernel(request, ddsp):
+  """Runs a test under both FilteredNoise kernels: 'auto' (IR design and FIR on the matrix cores where the shape
+  allows) and 'vector' (the FIR on the vector ALUs)."""
+  old = ddsp.synths.FilteredNoise.kernel
+  ddsp.synths.FilteredNoise.kernel = request.param
+  yield request.param
+  ddsp.synths.FilteredNoise.kernel = old
+
+
 def npy(t):
   return t.detach().cpu().numpy()
 
@@ -107,7 +117,7 @@ def test_harmonic_golden(ddsp, harm_kernel, name):
 
 
 @pytest.mark.parametrize('name', NOISE_CASES)
-def test_filtered_noise_golden(ddsp, name):
+def test_filtered_noise_golden(ddsp, noise_kernel, name):
   g = load_golden(name)
   ws = int(g['window_size'])
   synth = ddsp.synths.FilteredNoise(n_samples=int(g['n_samples']), window_size=ws,
@@ -169,7 +179,7 @@ def test_harmonic_canonical_vs_truth_and_faithful(ddsp, harm_kernel, f0_center):
   np.testing.assert_array_equal(ours_ang, ours)
 
 
-def test_filtered_noise_canonical_vs_oracle(ddsp):
+def test_filtered_noise_canonical_vs_oracle(ddsp, noise_kernel):
   x = canonical_inputs(2, seed=2)
   noise = np.random.default_rng(3).uniform(-1, 1, (2, 64000)).astype(np.float32)
   for ws in (0, 257):                      # ae.gin uses 0; the class default is 257 (same IR)
@@ -179,7 +189,7 @@ def test_filtered_noise_canonical_vs_oracle(ddsp):
 
 
 # ---- generated noise: integer work, bit exact ------------------------------------------------
-def test_generated_noise_is_bit_exact_and_fused_path_matches_injection(ddsp):
+def test_generated_noise_is_bit_exact_and_fused_path_matches_injection(ddsp, noise_kernel):
   b, n = 3, 6400
   dev_noise = npy(ddsp.core.uniform_noise(b, n, seed=1234, batch_offset=5))
   np.testing.assert_array_equal(dev_noise, O.device_uniform_noise(b, n, 1234, 5))
@@ -246,7 +256,7 @@ def test_harmonic_nyquist_crossing_between_frames(ddsp, harm_kernel):
 @pytest.mark.parametrize('m,ws,n_frames,n', [(3, 0, 4, 64), (9, 0, 7, 100), (65, 0, 1000, 64000), (65, 0, 3, 192), (65, 0, 1, 300),
                                              (65, 257, 10, 640), (129, 65, 5, 1000),
                                              (1025, 257, 1, 4096), (33, 17, 16, 4096)])
-def test_filtered_noise_edge_shapes(ddsp, m, ws, n_frames, n):
+def test_filtered_noise_edge_shapes(ddsp, noise_kernel, m, ws, n_frames, n):
   rng = np.random.default_rng(m + n)
   mags = rng.standard_normal((2, n_frames, m)).astype(np.float32)
   noise = rng.uniform(-1, 1, (2, n)).astype(np.float32)
@@ -428,7 +438,7 @@ def test_standalone_oscillator_bank(ddsp):                    # core_test.py:460
 
 
 @pytest.mark.parametrize('n_frames,n', [(40, 2560 - 17), (62, 3968), (63, 4032), (125, 8000 - 63), (1, 64)])
-def test_filtered_noise_fused_tile_edges(ddsp, n_frames, n):
+def test_filtered_noise_fused_tile_edges(ddsp, noise_kernel, n_frames, n):
   """Canonical M=65 / frame 64 shapes around the fused kernel's 62-frame tile boundary, ragged N."""
   rng = np.random.default_rng(n)
   mags = rng.standard_normal((3, n_frames, 65)).astype(np.float32)
@@ -570,7 +580,7 @@ def test_tf_op_order_kernel_matches_faithful_oracle_full_length(ddsp, angular, m
 
 
 @pytest.mark.parametrize('fs,n_frames,ragged', [(128, 40, 0), (192, 50, 5), (320, 30, 0), (80, 70, 3), (960, 9, 0)])
-def test_filtered_noise_fused_other_frame_sizes(ddsp, fs, n_frames, ragged):
+def test_filtered_noise_fused_other_frame_sizes(ddsp, noise_kernel, fs, n_frames, ragged):
   """M=65 with frame sizes other than 64 (48 kHz / VST configs: hop 192, 320, 960) on the fused kernel."""
   n = fs * n_frames - ragged
   rng = np.random.default_rng(fs)
@@ -863,7 +873,7 @@ def test_harmonic_backward_full_size_properties(ddsp):
     (1, 50, 50 * 192 - 5, True, False), # frame size 192
     (2, 30, 30 * 80, False, True),      # frame size 80 (not a multiple of 64), scale_fn=None
     (3, 130, 130 * 64, True, False)])   # several blocks per row
-def test_filtered_noise_backward_vs_analytic_oracle(ddsp, batch, n_frames, n, scale, given_noise):
+def test_filtered_noise_backward_vs_analytic_oracle(ddsp, noise_kernel, batch, n_frames, n, scale, given_noise):
   rng = np.random.default_rng(n_frames)
   mags = (rng.standard_normal((batch, n_frames, 65)) + (4.0 if scale else 0.0)).astype(np.float32)
   if not scale:

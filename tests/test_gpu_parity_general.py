@@ -329,10 +329,11 @@ def test_fft_convolve_time_varying_ir_beyond_the_tiled_kernels_lds_budget(ddsp):
 def matrix_ir(request, ddsp):
   """'matrix': the cosine transform on the matrix cores; 'matrix_direct': the same with the magnitudes going from HBM
   to the MFMA fragments without LDS staging and the noise tile generated under the load latency."""
-  old = ddsp.synths.FilteredNoise.ir_design
+  old = ddsp.synths.FilteredNoise.ir_design, ddsp.synths.FilteredNoise.kernel
   ddsp.synths.FilteredNoise.ir_design = request.param
+  ddsp.synths.FilteredNoise.kernel = 'vector'            # the IR designs are variants of the vector-ALU FIR kernel
   yield request.param
-  ddsp.synths.FilteredNoise.ir_design = old
+  ddsp.synths.FilteredNoise.ir_design, ddsp.synths.FilteredNoise.kernel = old
 
 
 def noise_tol(ref):

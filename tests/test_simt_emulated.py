@@ -49,6 +49,14 @@ def harm_kernel(request, ddsp):
   ddsp.synths.Harmonic.kernel = old
 
 
+@pytest.fixture(params=['auto', 'vector'])
+def noise_kernel(request, ddsp):
+  old = ddsp.synths.FilteredNoise.kernel
+  ddsp.synths.FilteredNoise.kernel = request.param
+  yield request.param
+  ddsp.synths.FilteredNoise.kernel = old
+
+
 # Every test function of the two GPU modules is re-exported under its own name (so its parametrisation comes
 # along); the cases below are left to the GPU run - minutes each under the emulation (clips of 4 s at batch 32).
 # DDSP_EMU_ALL=1 runs them too (about 17 minutes in all; every one of them passes).

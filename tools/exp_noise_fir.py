@@ -1,0 +1,57 @@
+"""FilteredNoise at the bench shape: the matrix-core kernel (noise_mfma65_kernel: IR design + FIR as fp16 hi/lo-split MFMA
+products) against noise_fused65_kernel (FIR on the vector ALUs) with its IR designs; per-launch time from dispatch events,
+agreement between them, and the in-kernel phase timeline of the matrix-core kernel.
+
+    python tools/exp_noise_fir.py [batch ...]
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import ddsp_amd as ddsp
+from ddsp_amd import _lib, core, build
+build.build()
+lib = _lib.load()
+F, M, N = 1000, 65, 64000
+for B in [int(v) for v in sys.argv[1:]] or [32, 128]:
+  rng = np.random.default_rng(0)
+  mags = core.tf_float32(rng.standard_normal((B, F, M)))
+  res, outs = {'batch': B}, {}
+  for name, kernel, ir in (('mfma', 'auto', 'vector'), ('vector_fir+matrix_direct_ir', 'vector', 'matrix_direct'),
+                           ('vector_fir+vector_ir', 'vector', 'vector')):
+    synth = ddsp.synths.FilteredNoise(n_samples=N, window_size=0, seed=7)
+    synth.kernel, synth.ir_design = kernel, ir
+    for _ in range(20): synth(mags)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.05:
+      for _ in range(20): synth(mags)
+      torch.cuda.synchronize()
+    _lib.profile_begin(None, max_records=512)
+    for _ in range(50): synth(mags)
+    torch.cuda.synchronize()
+    bd = _lib.profile_end()
+    steps = 300
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): synth(mags)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    synth._calls = 0
+    outs[name] = synth(mags)
+    res[name] = {'us_per_call_back_to_back': dt * 1e6, 'kernel_us': {k: v[0] / v[1] * 1e3 for k, v in bd.items()}}
+  res['max_abs_diff_vs_vector_ir'] = {k: float((outs[k] - outs['vector_fir+vector_ir']).abs().max()) for k in outs}
+  res['max_abs_out'] = float(outs['mfma'].abs().max())
+  print(json.dumps(res))
+  # phase timeline of the matrix-core kernel (debug flag 0x40000000: the controls pointer carries the stamp buffer)
+  audio = torch.empty((B, N), device='cuda')
+  ws = torch.empty(max(lib.ddsp_filtered_noise_workspace_bytes(B, F, M, N, 0), 16), dtype=torch.uint8, device='cuda')
+  nblk = B * 17
+  dbg = torch.zeros((nblk, 8), dtype=torch.int64, device='cuda')
+  rc = lib.ddsp_filtered_noise_f32(mags.data_ptr(), None, audio.data_ptr(), dbg.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   B, F, M, N, 0, -5.0, 1 | 0x40000000, 1, 0, torch.cuda.current_stream().cuda_stream)
+  assert rc == 0, rc
+  torch.cuda.synchronize()
+  d = dbg.cpu().numpy().astype(np.float64)
+  d = (d - d[:, 0].min()) * 0.01
+  print('noise_mfma65_kernel B=%d blocks=%d  (us since first block start; min / median / max over blocks)' % (B, nblk))
+  for i, nm in enumerate(['start', 'noise tile staged', 'IR designed + barrier', 'FIR done, stored']):
+    print('  %-24s %7.2f %7.2f %7.2f' % (nm, d[:, i].min(), np.median(d[:, i]), d[:, i].max()))
+  print('  per block: noise %.2f  IR %.2f  FIR %.2f us (medians of the differences)' % (
+      np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]), np.median(d[:, 3] - d[:, 2])))
