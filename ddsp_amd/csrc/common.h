@@ -58,6 +58,14 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Keeps a value in its register: the compiler may not rematerialise it from its parts at every use (used for LDS
+// byte offsets that every unrolled iteration reuses with an immediate added; without it each use recomputes base + plane).
+#if defined(__AMDGCN__)
+#define DDSP_KEEP_IN_VGPR(v) __asm__ volatile("" : "+v"(v))
+#else
+#define DDSP_KEEP_IN_VGPR(v) ((void)0)
+#endif
+
 // ---- individually rounded fp32 steps ---------------------------------------------------------
 // hipcc contracts a*b+c into an FMA by default, and the HIP header's __fmul_rn / __fadd_rn are
 // plain `*` / `+` (no OCML rounded ops in this build), so they do not stop it: round 1's 'linear'

@@ -25,11 +25,12 @@
 // is therefore kept twice, the second copy shifted by one element, and a row reads the copy its parity selects.
 //
 // One block = 62 output frames (3968 samples) of one batch row = 64 staged frames (two of halo), 8 wavefronts:
-//   1. every wavefront fetches its 16 x 16 magnitudes straight from HBM into the B-fragment layout of the IR design
-//      (no LDS staging), 2. generates its share of the Philox noise tile while those loads fly (reversed, hi / lo split,
-//      two copies), 3. exp_sigmoid, split, 6 MFMAs against the constant cosine fragments, window, split the taps
-//      hi / lo into the LDS tap table; one barrier; 4. FIR: a wavefront walks 4 pairs (one extra pair before them
-//      only to build the carry), stores 128 samples per pair.
+//   wavefronts 0-3 design the taps: each fetches the 16 x 65 magnitudes of its 16 frames straight from HBM into the
+//      B-fragment layout (no LDS staging), exp_sigmoid, hi / lo split, 12 MFMAs against the constant cosine fragments
+//      (fp16 hi / lo pairs made at compile time), window, hi / lo split of the taps into the LDS tap table;
+//   wavefronts 4-7 meanwhile generate the Philox noise tile (reversed, hi / lo split, two copies);
+//   one barrier; then all eight run the FIR: a wavefront walks 4 pairs (one extra pair before them only to build the
+//   carry; fully unrolled: every LDS address is a per-lane base plus an immediate), stores 128 samples per pair.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -97,6 +98,35 @@ __device__ __forceinline__ mf_f16x8 mf_frag(uint32_t a, uint32_t b, uint32_t c, 
   return __builtin_bit_cast(mf_f16x8, v);
 }
 
+static __constant__ Ir65Frags kIr65Frags = make_ir65_frags();
+
+// Four taps that sit next to each other in a row of the tap table, v[0] at tap t0 (t0 a multiple of 4): split and
+// stored as two 8-byte pieces (hi part, lo part).
+__device__ __forceinline__ void mf_put4(unsigned char* hrow, int t0, float v0, float v1, float v2, float v3) {
+  _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+  mf_split(v0, h0, l0); mf_split(v1, h1, l1); mf_split(v2, h2, l2); mf_split(v3, h3, l3);
+  unsigned char* q = hrow + (t0 >> 3) * 32 + (t0 & 7) * 2;
+  *reinterpret_cast<uint2*>(q) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+  *reinterpret_cast<uint2*>(q + 16) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+}
+// The mirror image: v[0] at tap t1, v[1] at t1 - 1, ... v[3] at t1 - 3 (t1 a multiple of 4; t1 itself is skipped when
+// `first` is false).  t1 - 1, t1 - 2 share a dword; t1 - 3 and t1 are single halves.
+__device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool first, float v0, float v1, float v2, float v3) {
+  _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+  mf_split(v0, h0, l0); mf_split(v1, h1, l1); mf_split(v2, h2, l2); mf_split(v3, h3, l3);
+  const int ta = t1 - 3;
+  unsigned char* q = hrow + (ta >> 3) * 32 + (ta & 7) * 2;          // taps t1-3 (odd element), t1-2, t1-1 in one group
+  *reinterpret_cast<uint16_t*>(q) = __builtin_bit_cast(uint16_t, h3);
+  *reinterpret_cast<uint16_t*>(q + 16) = __builtin_bit_cast(uint16_t, l3);
+  *reinterpret_cast<uint32_t*>(q + 2) = mf_pack(h2, h1);
+  *reinterpret_cast<uint32_t*>(q + 18) = mf_pack(l2, l1);
+  if (first) {
+    unsigned char* q1 = hrow + (t1 >> 3) * 32 + (t1 & 7) * 2;
+    *reinterpret_cast<uint16_t*>(q1) = __builtin_bit_cast(uint16_t, h0);
+    *reinterpret_cast<uint16_t*>(q1 + 16) = __builtin_bit_cast(uint16_t, l0);
+  }
+}
+
 // FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s
 template <bool GEN_NOISE, bool FS64>
 __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
@@ -113,109 +143,49 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
   // tap rows: frames f_first .. f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile
   const int f_first = (z0 - 128 >= 0) ? (z0 - 128) / p.fs : -((128 - z0 + p.fs - 1) / p.fs);
   const int rel0 = (z0 - 128) - f_first * p.fs;
-  // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
-  const int own_lo = (blockIdx.x == 0) ? 0 : f_first + 2;
-  const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
-  const float kLog10 = 2.302585092994046f;
-  const int do_scale = p.scale & 1;
   long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
-  int dbg_n = 0;
-#define DDSP_MF_STAMP() do { if (dbg && tid == 0 && dbg_n < 8) dbg[dbg_n++] = wall_clock64(); } while (0)
-  DDSP_MF_STAMP();     // 0: start
-
+#define DDSP_MF_STAMP(i) do { if (dbg && lane == 0) dbg[i] = wall_clock64(); } while (0)
+  if (wave == 0) DDSP_MF_STAMP(0);     // start
   const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
 
-  // ---- 0. loads that nothing waits for yet ---------------------------------------------------------------------
-  // this wavefront's share of the constant cosine factor in A-operand layout: taps n = 16 mt + i, bins 2 k' (+ 1),
-  // k' = 8 g + e (wavefront w designs rows 16 (w & 3) .. + 15, tap tile mt = w >> 2)
-  const int mt = wave >> 2;
-  mf_f16x8 ae_hi, ae_lo, ao_hi, ao_lo;
-  {
-    const float* __restrict__ crow = kIr65.c + (16 * mt + mi) * kIrRowStride + 8 * mg;
-    float ve[8], vo[8];
+  if (wave < 4) {
+    // =========================== design wavefronts: the taps of rows 16 w .. 16 w + 15 ===============================
+    // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+    const int own_lo = (blockIdx.x == 0) ? 0 : f_first + 2;
+    const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
+    const float kLog10 = 2.302585092994046f;
+    // the 16 bins of this lane's B-fragments (row = 16 w + i, bins 16 g .. + 15) and bin 64 of that row, straight from
+    // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
+    const int rrow = 16 * wave + mi;
+    const int rfr = f_first + rrow;
+    const bool rvalid = rfr >= 0 && rfr < p.F;
+    MfU4f rq[4];
+    float r_last;
+    {
+      const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ve[e] = crow[e]; vo[e] = crow[40 + e]; }
-    mf_split8(ve, ae_hi, ae_lo);
-    mf_split8(vo, ao_hi, ao_lo);
-  }
-  // the 16 bins of this lane's B-fragments (row = 16 (wave & 3) + i, bins 16 g .. + 15) and bin 64 of that row;
-  // rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
-  const int rrow = 16 * (wave & 3) + mi;
-  const int rfr = f_first + rrow;
-  const bool rvalid = rfr >= 0 && rfr < p.F;
-  MfU4f rq[4];
-  float r_last;
-  {
-    const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-    r_last = src[64];
-  }
-
-  // ---- 1. zeros: the 16 elements between the reversed frames (both copies), the zero group of every tap row --------
-  for (int i = tid; i < 65 * 16; i += 64 * kMfWaves) {
-    const int e = 80 * (i >> 4) + (i & 15);                         // element index of a padding element
-    // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
-    *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
-    *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
-    *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
-    *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
-  }
-  if (tid < kMfRows * 2)
-    *reinterpret_cast<uint4*>(s_taps + (tid >> 1) * kMfTapRowBytes + 512 + 16 * (tid & 1)) = make_uint4(0u, 0u, 0u, 0u);
-
-  // ---- 2. the noise tile x[z0-128 .. z0+3967]: reversed, hi / lo split, two copies -------------------------------------
-  for (int qd = tid; qd < (kMfTile + 128) / 4; qd += 64 * kMfWaves) {
-    const int i = z0 - 128 + 4 * qd;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i >= 0 && i < p.N) {
-      if (GEN_NOISE) {
-        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-        if (i + 1 >= p.N) v.y = 0.f;
-        if (i + 2 >= p.N) v.z = 0.f;
-        if (i + 3 >= p.N) v.w = 0.f;
-      } else {
-        const float* src = x + (size_t)b * p.N + i;
-        if (i + 3 < p.N && ((p.N & 3) == 0)) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (i + 1 < p.N) v.y = src[1];
-          if (i + 2 < p.N) v.z = src[2];
-          if (i + 3 < p.N) v.w = src[3];
-        }
-      }
+      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+      r_last = src[64];
     }
-    _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
-    mf_split(v.w, h0, l0);               // element u0     = sample j + 3
-    mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
-    mf_split(v.y, h2, l2);
-    mf_split(v.x, h3, l3);
-    const int s = qd >> 4, j = 4 * (qd & 15);
-    const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
-    // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
-    *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-    *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
-    // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of dword
-    // u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
-    unsigned char* po = s_xo + (u0 + 1) * 2;
-    *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
-    *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
-    *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
-    *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
-    *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
-    *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
-  }
-  DDSP_MF_STAMP();     // 1: noise tile staged
+    // the constant cosine factor as fp16 hi / lo A-fragments, made at compile time: [tap tile][even / odd bins][hi / lo]
+    mf_f16x8 afr[2][2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[q][par][hl][lane]);
+          afr[q][par][hl] = mf_frag(v.x, v.y, v.z, v.w);
+        }
+    // the zero group of this wavefront's tap rows (what lanes outside the filter's support read)
+    if (lane < 32) *reinterpret_cast<uint4*>(s_taps + (16 * wave + (lane >> 1)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
 
-  // ---- 3. IR design: controls in registers, fragments, products, windowed taps -> tap table ----------------------------
-  {
     float y[16];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
     float m_last = r_last;
-    if (do_scale) {
+    if (p.scale & 1) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
       m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
@@ -225,7 +195,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       for (int c = 0; c < 16; ++c) y[c] = 0.0f;
       m_last = 0.0f;
     }
-    if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi && wave < 4) {       // written by the owning tile only
+    if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
       float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4)
@@ -238,38 +208,34 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
     mf_split8(ve, be_hi, be_lo);
     mf_split8(vo, bo_hi, bo_lo);
-    const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi, be_hi, zero, 0, 0, 0);
-    mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi, bo_hi, zero, 0, 0, 0);
-    mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi, be_lo, zero, 0, 0, 0);
-    mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi, bo_lo, zero, 0, 0, 0);
-    ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_lo, be_hi, ex, 0, 0, 0);
-    ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_lo, bo_hi, ox, 0, 0, 0);
-    const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
     unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
-    // tap t of the row: group t >> 3 (32 bytes: 8 hi halves, 8 lo halves), element t & 7
-    auto put = [&](int t, float val) {
-      _Float16 h, l;
-      mf_split(val, h, l);
-      unsigned char* q = hrow + (t >> 3) * 32 + (t & 7) * 2;
-      *reinterpret_cast<uint16_t*>(q) = __builtin_bit_cast(uint16_t, h);
-      *reinterpret_cast<uint16_t*>(q + 16) = __builtin_bit_cast(uint16_t, l);
-    };
+    const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = 16 * mt + 4 * mg + r;                           // 0 .. 31
-      const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);
-      const float o = ov[r];
-      const float g0 = kIr65.win[n] * (e + o);                       // g[n]:    taps 64+n and 64-n
-      put(64 + n, g0);
-      if (n >= 1) {
-        put(64 - n, g0);
-        const float g1 = kIr65.win[64 - n] * (e - o);                // g[64-n]: taps 128-n and n
-        put(128 - n, g1);
-        put(n, g1);
+    for (int q = 0; q < 2; ++q) {
+      // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 q + 4 g + r: D[n][row i]
+      mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_hi, zero, 0, 0, 0);
+      mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_hi, zero, 0, 0, 0);
+      mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_lo, zero, 0, 0, 0);
+      mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_lo, zero, 0, 0, 0);
+      ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][1], be_hi, ex, 0, 0, 0);
+      ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][1], bo_hi, ox, 0, 0, 0);
+      const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
+      const int n0 = 16 * q + 4 * mg;                                 // this lane's taps n0 .. n0 + 3
+      float g0[4], g1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);      // + bin 64 (a rank-1 update)
+        const float o = ov[r];
+        g0[r] = kIr65.win[n] * (e + o);                                // g[n]:    taps 64 + n and 64 - n
+        g1[r] = (n >= 1) ? kIr65.win[64 - n] * (e - o) : 0.0f;        // g[64-n]: taps 128 - n and n; tap 0 is 0
       }
+      mf_put4(hrow, 64 + n0, g0[0], g0[1], g0[2], g0[3]);
+      mf_put4(hrow, n0, g1[0], g1[1], g1[2], g1[3]);
+      mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
+      mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
     }
-    if (wave < 4) {
+    {
       // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
       const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
       float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
@@ -278,22 +244,90 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       part += __shfl_xor(part, 16);
       part += __shfl_xor(part, 32);
       if (mg == 0) {
-        const float g0 = kIr65.win[32] * part;
-        put(96, g0);
-        put(32, g0);
-        put(0, 0.0f);                                                  // h[0] = Hann(128)[0] * hz[-64] = 0
+        _Float16 h, l;
+        mf_split(kIr65.win[32] * part, h, l);
+        const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
+        *reinterpret_cast<uint16_t*>(hrow + 12 * 32) = hb;             // tap 96: group 12, element 0
+        *reinterpret_cast<uint16_t*>(hrow + 12 * 32 + 16) = lb;
+        *reinterpret_cast<uint16_t*>(hrow + 4 * 32) = hb;              // tap 32: group 4, element 0
+        *reinterpret_cast<uint16_t*>(hrow + 4 * 32 + 16) = lb;
       }
     }
+  } else {
+    // =========================== noise wavefronts: the tile x[z0-128 .. z0+3967] =====================================
+    const int t = tid - 256;
+    // zeros: the 16 elements between the reversed frames (both copies)
+    for (int i = t; i < 65 * 16; i += 256) {
+      const int e = 80 * (i >> 4) + (i & 15);                         // element index of a padding element
+      // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
+      *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
+    }
+    // reversed, hi / lo split, two copies
+#pragma unroll 1
+    for (int qd = t; qd < (kMfTile + 128) / 4; qd += 256) {
+      const int i = z0 - 128 + 4 * qd;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i >= 0 && i < p.N) {
+        if (GEN_NOISE) {
+          const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+          v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+          if (i + 1 >= p.N) v.y = 0.f;
+          if (i + 2 >= p.N) v.z = 0.f;
+          if (i + 3 >= p.N) v.w = 0.f;
+        } else {
+          const float* src = x + (size_t)b * p.N + i;
+          if (i + 3 < p.N && ((p.N & 3) == 0)) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            v.x = src[0];
+            if (i + 1 < p.N) v.y = src[1];
+            if (i + 2 < p.N) v.z = src[2];
+            if (i + 3 < p.N) v.w = src[3];
+          }
+        }
+      }
+      _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+      mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+      mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+      mf_split(v.y, h2, l2);
+      mf_split(v.x, h3, l3);
+      const int s = qd >> 4, j = 4 * (qd & 15);
+      const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+      // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+      *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+      *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+      // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of dword
+      // u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+      unsigned char* po = s_xo + (u0 + 1) * 2;
+      *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+      *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+      *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+      *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+      *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+      *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+    }
   }
+  if (wave == 0) DDSP_MF_STAMP(1);     // design wavefront 0 done
+  if (wave == 4) DDSP_MF_STAMP(2);     // noise wavefront 4 done
   __syncthreads();
-  DDSP_MF_STAMP();     // 2: IR designed, everything staged
+  if (wave == 0) DDSP_MF_STAMP(3);     // everything staged
 
-  // ---- 4. FIR: pairs of frames on the matrix cores ------------------------------------------------------------------
+  // ---- FIR: pairs of frames on the matrix cores ------------------------------------------------------------------------
   // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block P = 2 c + (g >> 1) of the
   // pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
   //   A (row b = i): x_frame[16 p + b - d], e = 0..7  =  reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
   //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
-  int a_off[5], b_off[5];
+  // wavefront w: output pairs 4 w + 1 .. 4 w + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are output),
+  // preceded by pair 4 w, whose left half belongs to the previous wavefront (or, pair 0, to the previous block).
+  // All addresses are those of pair 4 w plus a constant per pair, so the unrolled pair loop carries no address arithmetic.
+  const int p_first = 4 * wave;
+  const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
+  int a_hi[5], a_lo[5];                   // byte offsets into s_x of the hi / lo fragments of pair 4 w
+  int b_ptr[5];                           // byte offsets into s_taps; FS64: tap row 2 P (+ 1 for the second frame) folded in
+  int b_off[5];
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
     const int P = 2 * c + (mg >> 1);
@@ -301,60 +335,78 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     const int pp = P - 5 * second;
     const int u = 79 + kMfXStride * second - 16 * pp - mi + 8 * (mg & 1);            // relative to the pair's first frame
     // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
-    a_off[c] = ((u + 1) >> 1) * 4;
+    a_hi[c] = xsel + ((u + 1) >> 1) * 4;
+    a_lo[c] = a_hi[c] + kMfXPlane;
     const int q = (mi - 4 * second) - pp;
     b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 32 : 512;
+    b_ptr[c] = (2 * p_first + second) * kMfTapRowBytes + b_off[c];
+    DDSP_KEEP_IN_VGPR(a_hi[c]);
+    DDSP_KEEP_IN_VGPR(a_lo[c]);
+    DDSP_KEEP_IN_VGPR(b_ptr[c]);
+    // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32 each;
+    // a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
+    __builtin_assume((a_hi[c] & 3) == 0);
+    __builtin_assume((a_lo[c] & 3) == 0);
+    __builtin_assume((b_ptr[c] & 15) == 0);
   }
-  const unsigned char* xsel = (mi & 1) ? s_xe : s_xo;                 // i odd -> u even -> copy E
-  // wavefront w: output pairs 4 w + 1 .. 4 w + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are output),
-  // preceded by pair 4 w, whose left half belongs to the previous wavefront (or, pair 0, to the previous block)
-  const int p_first = 4 * wave, p_last = min(4 * wave + 4, kMfRows / 2 - 1);
   mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   float* __restrict__ o = out + (size_t)b * p.N;
-#pragma unroll 1
-  for (int P = p_first; P <= p_last; ++P) {
-    // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
-    const int rowA = FS64 ? 2 * P : (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
-    const int rowB = FS64 ? 2 * P + 1 : (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
-    const unsigned char* xa = xsel + 2 * kMfXStride * 2 * P;         // 2 frames = 160 elements = 320 bytes of a plane
-    const unsigned char* ta = s_taps + rowA * kMfTapRowBytes;
-    const unsigned char* tb = s_taps + rowB * kMfTapRowBytes;
-    mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+  // out index of this lane's first value of pair 4 w: z = z0 - 128 + 128 P + 16 a + 4 g (+ r)
+  const long n_base = (long)z0 - 128 + 128L * p_first + 16 * mi + 4 * mg - p.start;
+  // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
+  const bool interior = n_base - 16 * mi - 4 * mg + 128 >= 0 && n_base - 16 * mi - 4 * mg + 128 * 5 + 128 <= (long)p.N &&
+                        (((p.start | p.N) & 1) == 0);
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const unsigned char* pa = xa + a_off[c];
-      const MfU4 qh = *reinterpret_cast<const MfU4*>(pa), ql = *reinterpret_cast<const MfU4*>(pa + kMfXPlane);
-      const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
-      // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
-      const unsigned char* tr = (c < 2) ? ta : (c > 2) ? tb : ((mg >> 1) ? tb : ta);
-      const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr + b_off[c]);
-      const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + b_off[c] + 16);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
-      acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
-      acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
-    }
-    const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
-    // D[row b = 4 g + r][col a = i]: z = z0 - 128 + 128 P + 16 a + b; columns 0..7 are complete
-    if (P > p_first && mi < 8) {
-      const long n = (long)z0 - 128 + 128L * P + 16 * mi + 4 * mg - p.start;       // out index of comb[0]
-      if (n >= 0 && n + 3 < p.N && (((n | p.N) & 1) == 0)) {
-        *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
-        *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
-      } else {
+  for (int it = 0; it < 5; ++it) {
+    const int P = p_first + it;
+    if (P < kMfRows / 2) {                                            // wavefront 7 has three output pairs
+      mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+      int rowA = 0, rowB = 0;
+      if (!FS64) {
+        // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
+        rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
+        rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r >= 0 && n + r < p.N) o[n + r] = comb[r];
+      for (int c = 0; c < 5; ++c) {
+        const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it);
+        const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it);
+        const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
+        // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
+        const unsigned char* tr;
+        if (FS64) tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it;
+        else tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
+        const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr);
+        const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
+        acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
+        acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
+      }
+      const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
+      // D[row b = 4 g + r][col a = i]: columns 0..7 are complete
+      if (it > 0 && mi < 8) {
+        const long n = n_base + 128L * it;
+        if (interior) {
+          *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
+          *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = comb[r];
+            if (n + r >= 0 && n + r < p.N) o[n + r] = v;
+          }
+        }
+      }
+      // columns 8..15 -> columns 0..7 of the next pair's tile (row_shl:8, out-of-row lanes read 0)
+      // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - clang 22)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = comb[r];
+        carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
       }
     }
-    // columns 8..15 -> columns 0..7 of the next pair's tile (row_shl:8, out-of-row lanes read 0)
-    // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - clang 22)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = comb[r];
-      carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
-    }
   }
-  DDSP_MF_STAMP();     // 3: FIR done and stored
+  if (wave == 0) DDSP_MF_STAMP(4);     // FIR of wavefront 0 done
 #undef DDSP_MF_STAMP
 }
 

@@ -54,4 +54,61 @@ constexpr Ir65Table make_ir65_table() {
 static __constant__ Ir65Table kIr65 = make_ir65_table();
 
 
+// ---- the same cosine factor as fp16 hi / lo MFMA A-fragments (noise_mfma65_kernel) -------------------------------
+// x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) 2048), both rounded to nearest even at compile time.
+constexpr double ir65_pow2(int e) { double v = 1.0; for (int i = 0; i < (e < 0 ? -e : e); ++i) v = e < 0 ? v * 0.5 : v * 2.0; return v; }
+constexpr double ir65_round_half_even(double v) {          // v >= 0, < 2^52
+  const long long k = (long long)v;
+  const double frac = v - (double)k;
+  if (frac > 0.5 || (frac == 0.5 && (k & 1))) return (double)(k + 1);
+  return (double)k;
+}
+// value and bit pattern of the nearest fp16 number (normal or subnormal; |x| far below the fp16 maximum)
+constexpr double ir65_f16_value(double x, unsigned short* bits) {
+  const bool neg = x < 0.0;
+  const double a = neg ? -x : x;
+  int e = 0;                                               // a = m 2^e, 1 <= m < 2
+  if (a != 0.0) { double m = a; while (m >= 2.0) { m *= 0.5; ++e; } while (m < 1.0) { m *= 2.0; --e; } }
+  int qe = (a == 0.0 || e < -14) ? -24 : e - 10;           // exponent of the quantum (subnormals: 2^-24)
+  double r = ir65_round_half_even(a / ir65_pow2(qe)) * ir65_pow2(qe);
+  if (bits) {
+    unsigned short b = 0;
+    if (r != 0.0) {
+      int re = 0; double m = r; while (m >= 2.0) { m *= 0.5; ++re; } while (m < 1.0) { m *= 2.0; --re; }
+      if (re < -14) b = (unsigned short)(r / ir65_pow2(-24));                                   // subnormal: mantissa only
+      else b = (unsigned short)(((re + 15) << 10) | ((int)((m - 1.0) * 1024.0 + 0.5) & 1023));
+    }
+    *bits = (unsigned short)(b | (neg ? 0x8000 : 0));
+  }
+  return neg ? -r : r;
+}
+struct Ir65Frags {
+  // [tap tile mt][parity: even / odd bins][part: hi / lo][lane][dword d]: elements 2 d, 2 d + 1 of the lane's A-fragment
+  // (tap n = 16 mt + (lane & 15), bin index k' = 8 (lane >> 4) + e)
+  unsigned int v[2][2][2][64][4];
+};
+constexpr Ir65Frags make_ir65_frags() {
+  Ir65Frags f{};
+  const Ir65Table t = make_ir65_table();
+  for (int mt = 0; mt < 2; ++mt)
+    for (int par = 0; par < 2; ++par)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int d = 0; d < 4; ++d) {
+          unsigned int hi2 = 0, lo2 = 0;
+          for (int h = 0; h < 2; ++h) {
+            const int e = 2 * d + h;
+            const double x = (double)t.c[(16 * mt + (lane & 15)) * kIrRowStride + 40 * par + 8 * (lane >> 4) + e];
+            unsigned short hb = 0, lb = 0;
+            const double hv = ir65_f16_value(x, &hb);
+            // (x - hi) * 2048 is exact in fp32 as well as here: x has 24 bits, hi its leading 11
+            ir65_f16_value((x - hv) * 2048.0, &lb);
+            hi2 |= (unsigned int)hb << (16 * h);
+            lo2 |= (unsigned int)lb << (16 * h);
+          }
+          f.v[mt][par][0][lane][d] = hi2;
+          f.v[mt][par][1][lane][d] = lo2;
+        }
+  return f;
+}
+
 }  // namespace ddsp
