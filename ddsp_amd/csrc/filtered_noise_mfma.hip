@@ -46,7 +46,7 @@ namespace ddsp {
 constexpr int kMfFrames = 62;                  // output frames per block
 constexpr int kMfRows = 64;                    // staged frames: 2 of halo + 62
 constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per block
-constexpr int kMfWaves = 8;
+constexpr int kMfWaves = 12;                 // 4 design + 4 noise + 4 FIR wavefronts
 constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
 // tap table: per row 16 groups of {8 hi halves, 8 lo halves} (32 bytes) + one group of zeros that lanes outside the
 // filter's support read
@@ -70,7 +70,8 @@ struct MfArgs {
   float bias;
   uint32_t k0, k1;
   uint64_t batch_offset;
-  long long* dbg;                   // per-block phase stamps (tools/exp_timeline_noise.py), or null
+  int tiles_per_row, n_tiles;       // tiles of 62 frames per batch row; B * tiles_per_row
+  long long* dbg;                   // block 0's per-tick stamps [16 ticks][3 roles][begin, end] (tools/exp_noise_fir.py), or null
 };
 
 struct __attribute__((packed, aligned(4))) MfU4f { float x, y, z, w; };        // 16 bytes from a 4-byte aligned address
@@ -127,46 +128,36 @@ __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool f
   }
 }
 
-// FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s
+// FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s.
+//
+// Persistent, one block of 12 wavefronts per CU, tiles dealt round-robin; two LDS buffers; one barrier per tick:
+//     tick k:   design wavefronts 0-3 and noise wavefronts 4-7 fill buffer (k+1) & 1 with tile k+1 (vector ALUs),
+//               FIR wavefronts 8-11 turn buffer k & 1 (tile k) into audio (matrix cores + LDS reads).
+// The design wavefronts fetch the magnitudes of tile k+2 at the top of the tick and use them a tick later, so no
+// wavefront ever waits for HBM.
 template <bool GEN_NOISE, bool FS64>
-__global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
+__global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char s_taps[kMfRows * kMfTapRowBytes];
-  __shared__ __attribute__((aligned(16))) unsigned char s_x[4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
-  unsigned char* const s_xe = s_x;
-  unsigned char* const s_xo = s_x + 2 * kMfXPlane;
+  __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][kMfRows * kMfTapRowBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
-  const int z0 = blockIdx.x * kMfTile;                 // first output (z index) of the block; a multiple of 64
-  // tap rows: frames f_first .. f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile
-  const int f_first = (z0 - 128 >= 0) ? (z0 - 128) / p.fs : -((128 - z0 + p.fs - 1) / p.fs);
-  const int rel0 = (z0 - 128) - f_first * p.fs;
-  long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
-#define DDSP_MF_STAMP(i) do { if (dbg && lane == 0) dbg[i] = wall_clock64(); } while (0)
-  if (wave == 0) DDSP_MF_STAMP(0);     // start
   const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
+  const int n_my = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this block
+  long long* dbg = (p.dbg && blockIdx.x == 0) ? p.dbg : nullptr;                              // block 0: [tick][role][2]
+#define DDSP_MF_STAMP(tick, role, i) do { if (dbg && lane == 0 && (tick) + 1 < 16) dbg[(((tick) + 1) * 3 + (role)) * 2 + (i)] = wall_clock64(); } while (0)
+  // tile T -> (batch row, tile of the row): first output z0 = 3968 tx (a multiple of 64); tap rows: frames f_first ..
+  // f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile
+#define DDSP_MF_TILE(T, b_, z0_, ffirst_, rel0_)                                                        \
+  const int b_ = (T) / p.tiles_per_row;                                                                 \
+  const int z0_ = ((T) - b_ * p.tiles_per_row) * kMfTile;                                               \
+  const int ffirst_ = (z0_ - 128 >= 0) ? (z0_ - 128) / p.fs : -((128 - z0_ + p.fs - 1) / p.fs);         \
+  const int rel0_ = (z0_ - 128) - ffirst_ * p.fs
 
   if (wave < 4) {
     // =========================== design wavefronts: the taps of rows 16 w .. 16 w + 15 ===============================
-    // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
-    const int own_lo = (blockIdx.x == 0) ? 0 : f_first + 2;
-    const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
     const float kLog10 = 2.302585092994046f;
-    // the 16 bins of this lane's B-fragments (row = 16 w + i, bins 16 g .. + 15) and bin 64 of that row, straight from
-    // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
-    const int rrow = 16 * wave + mi;
-    const int rfr = f_first + rrow;
-    const bool rvalid = rfr >= 0 && rfr < p.F;
-    MfU4f rq[4];
-    float r_last;
-    {
-      const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-      r_last = src[64];
-    }
     // the constant cosine factor as fp16 hi / lo A-fragments, made at compile time: [tap tile][even / odd bins][hi / lo]
     mf_f16x8 afr[2][2][2];
 #pragma unroll
@@ -178,236 +169,328 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
           const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[q][par][hl][lane]);
           afr[q][par][hl] = mf_frag(v.x, v.y, v.z, v.w);
         }
-    // the zero group of this wavefront's tap rows (what lanes outside the filter's support read)
-    if (lane < 32) *reinterpret_cast<uint4*>(s_taps + (16 * wave + (lane >> 1)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
-
-    float y[16];
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
-    float m_last = r_last;
-    if (p.scale & 1) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
-      m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
-    }
-    if (!rvalid) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) y[c] = 0.0f;
-      m_last = 0.0f;
-    }
-    if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
-      float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4)
-        *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
-      if (mg == 0) dst[64] = m_last;
-    }
-    float ve[8], vo[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
-    mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
-    mf_split8(ve, be_hi, be_lo);
-    mf_split8(vo, bo_hi, bo_lo);
-    unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
-    const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 q + 4 g + r: D[n][row i]
-      mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_hi, zero, 0, 0, 0);
-      mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_hi, zero, 0, 0, 0);
-      mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_lo, zero, 0, 0, 0);
-      mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_lo, zero, 0, 0, 0);
-      ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][1], be_hi, ex, 0, 0, 0);
-      ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][1], bo_hi, ox, 0, 0, 0);
-      const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
-      const int n0 = 16 * q + 4 * mg;                                 // this lane's taps n0 .. n0 + 3
-      float g0[4], g1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + r;
-        const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);      // + bin 64 (a rank-1 update)
-        const float o = ov[r];
-        g0[r] = kIr65.win[n] * (e + o);                                // g[n]:    taps 64 + n and 64 - n
-        g1[r] = (n >= 1) ? kIr65.win[64 - n] * (e - o) : 0.0f;        // g[64-n]: taps 128 - n and n; tap 0 is 0
-      }
-      mf_put4(hrow, 64 + n0, g0[0], g0[1], g0[2], g0[3]);
-      mf_put4(hrow, n0, g1[0], g1[1], g1[2], g1[3]);
-      mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
-      mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
-    }
+    // the zero group of this wavefront's tap rows, both buffers (what lanes outside the filter's support read)
+    *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (16 * wave + ((lane >> 1) & 15)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
+    const int rrow = 16 * wave + mi;
+    // the 16 bins of this lane's B-fragments (row = 16 w + i, bins 16 g .. + 15) and bin 64 of that row, straight from
+    // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
+    MfU4f rq[4];
+    float r_last;
     {
-      // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
-      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
-      float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+      const int T = (int)blockIdx.x;                   // the block's first tile
+      DDSP_MF_TILE(T, b, z0, f_first, rel0);
+      (void)rel0;
+      const int rfr = f_first + rrow;
+      const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
-      part += __shfl_xor(part, 16);
-      part += __shfl_xor(part, 32);
-      if (mg == 0) {
-        _Float16 h, l;
-        mf_split(kIr65.win[32] * part, h, l);
-        const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
-        *reinterpret_cast<uint16_t*>(hrow + 12 * 32) = hb;             // tap 96: group 12, element 0
-        *reinterpret_cast<uint16_t*>(hrow + 12 * 32 + 16) = lb;
-        *reinterpret_cast<uint16_t*>(hrow + 4 * 32) = hb;              // tap 32: group 4, element 0
-        *reinterpret_cast<uint16_t*>(hrow + 4 * 32 + 16) = lb;
-      }
+      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+      r_last = src[64];
     }
-  } else {
+#pragma unroll 1
+    for (int tick = -1; tick < n_my; ++tick) {
+      DDSP_MF_STAMP(tick, 0, 0);
+      // magnitudes of tile tick + 2, to be used a tick from now (past the block's last tile: the last one again)
+      MfU4f nq[4];
+      float n_last;
+      {
+        const int T = (int)blockIdx.x + min(tick + 2, n_my - 1) * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)rel0;
+        const int rfr = f_first + rrow;
+        const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) nq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+        n_last = src[64];
+      }
+      if (tick + 1 < n_my) {
+        const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)rel0;
+        unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
+        // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+        const int own_lo = (z0 == 0) ? 0 : f_first + 2;
+        const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
+        const int rfr = f_first + rrow;
+        const bool rvalid = rfr >= 0 && rfr < p.F;
+        float y[16];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
+        float m_last = r_last;
+        if (p.scale & 1) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
+          m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+        }
+        if (!rvalid) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) y[c] = 0.0f;
+          m_last = 0.0f;
+        }
+        if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
+          float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+            *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
+          if (mg == 0) dst[64] = m_last;
+        }
+        float ve[8], vo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
+        mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+        mf_split8(ve, be_hi, be_lo);
+        mf_split8(vo, bo_hi, bo_lo);
+        unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
+        const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 q + 4 g + r: D[n][row i]
+          mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_hi, zero, 0, 0, 0);
+          mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_hi, zero, 0, 0, 0);
+          mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_lo, zero, 0, 0, 0);
+          mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_lo, zero, 0, 0, 0);
+          ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][1], be_hi, ex, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][1], bo_hi, ox, 0, 0, 0);
+          const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
+          const int n0 = 16 * q + 4 * mg;                                 // this lane's taps n0 .. n0 + 3
+          float g0[4], g1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + r;
+            const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);      // + bin 64 (a rank-1 update)
+            const float o = ov[r];
+            g0[r] = kIr65.win[n] * (e + o);                                // g[n]:    taps 64 + n and 64 - n
+            g1[r] = (n >= 1) ? kIr65.win[64 - n] * (e - o) : 0.0f;        // g[64-n]: taps 128 - n and n; tap 0 is 0
+          }
+          mf_put4(hrow, 64 + n0, g0[0], g0[1], g0[2], g0[3]);
+          mf_put4(hrow, n0, g1[0], g1[1], g1[2], g1[3]);
+          mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
+          mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
+        }
+        {
+          // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
+          const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
+          float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
+          part += __shfl_xor(part, 16);
+          part += __shfl_xor(part, 32);
+          if (mg == 0) {
+            _Float16 h, l;
+            mf_split(kIr65.win[32] * part, h, l);
+            const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
+            *reinterpret_cast<uint16_t*>(hrow + 12 * 32) = hb;             // tap 96: group 12, element 0
+            *reinterpret_cast<uint16_t*>(hrow + 12 * 32 + 16) = lb;
+            *reinterpret_cast<uint16_t*>(hrow + 4 * 32) = hb;              // tap 32: group 4, element 0
+            *reinterpret_cast<uint16_t*>(hrow + 4 * 32 + 16) = lb;
+          }
+        }
+      }
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = nq[c4];
+      r_last = n_last;
+      DDSP_MF_STAMP(tick, 0, 1);
+      __syncthreads();
+    }
+  } else if (wave < 8) {
     // =========================== noise wavefronts: the tile x[z0-128 .. z0+3967] =====================================
     const int t = tid - 256;
-    // zeros: the 16 elements between the reversed frames (both copies)
-    for (int i = t; i < 65 * 16; i += 256) {
-      const int e = 80 * (i >> 4) + (i & 15);                         // element index of a padding element
+    // zeros: the 16 elements between the reversed frames (both copies, both buffers); they stay zero
+    for (int i = t; i < 2 * 65 * 16; i += 256) {
+      unsigned char* const s_xe = s_x_all[i >= 65 * 16 ? 1 : 0];
+      unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
+      const int ii = i >= 65 * 16 ? i - 65 * 16 : i;
+      const int e = 80 * (ii >> 4) + (ii & 15);                       // element index of a padding element
       // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
       *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
       *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
       *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
       *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
     }
-    // reversed, hi / lo split, two copies
 #pragma unroll 1
-    for (int qd = t; qd < (kMfTile + 128) / 4; qd += 256) {
-      const int i = z0 - 128 + 4 * qd;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i >= 0 && i < p.N) {
-        if (GEN_NOISE) {
-          const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-          v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-          if (i + 1 >= p.N) v.y = 0.f;
-          if (i + 2 >= p.N) v.z = 0.f;
-          if (i + 3 >= p.N) v.w = 0.f;
-        } else {
-          const float* src = x + (size_t)b * p.N + i;
-          if (i + 3 < p.N && ((p.N & 3) == 0)) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            v.x = src[0];
-            if (i + 1 < p.N) v.y = src[1];
-            if (i + 2 < p.N) v.z = src[2];
-            if (i + 3 < p.N) v.w = src[3];
+    for (int tick = -1; tick < n_my; ++tick) {
+      if (wave == 4) DDSP_MF_STAMP(tick, 1, 0);
+      if (tick + 1 < n_my) {
+        const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)f_first; (void)rel0;
+        unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
+        unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
+        // reversed, hi / lo split, two copies; two quads per lane and pass (two independent Philox chains)
+#pragma unroll 1
+        for (int q0 = t; q0 < (kMfTile + 128) / 4; q0 += 512) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int qd = q0 + 256 * h;
+            const int i = z0 - 128 + 4 * qd;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= 0 && i < p.N) {
+              if (GEN_NOISE) {
+                const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+                v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+                if (i + 1 >= p.N) v.y = 0.f;
+                if (i + 2 >= p.N) v.z = 0.f;
+                if (i + 3 >= p.N) v.w = 0.f;
+              } else {
+                const float* src = x + (size_t)b * p.N + i;
+                if (i + 3 < p.N && ((p.N & 3) == 0)) {
+                  v = *reinterpret_cast<const float4*>(src);
+                } else {
+                  v.x = src[0];
+                  if (i + 1 < p.N) v.y = src[1];
+                  if (i + 2 < p.N) v.z = src[2];
+                  if (i + 3 < p.N) v.w = src[3];
+                }
+              }
+            }
+            _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+            mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+            mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+            mf_split(v.y, h2, l2);
+            mf_split(v.x, h3, l3);
+            const int s = qd >> 4, j = 4 * (qd & 15);
+            const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+            // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+            *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+            *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+            // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
+            // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+            unsigned char* po = s_xo + (u0 + 1) * 2;
+            *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+            *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+            *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+            *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+            *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+            *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
           }
         }
       }
-      _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
-      mf_split(v.w, h0, l0);               // element u0     = sample j + 3
-      mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
-      mf_split(v.y, h2, l2);
-      mf_split(v.x, h3, l3);
-      const int s = qd >> 4, j = 4 * (qd & 15);
-      const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
-      // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
-      *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-      *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
-      // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of dword
-      // u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
-      unsigned char* po = s_xo + (u0 + 1) * 2;
-      *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
-      *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
-      *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
-      *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
-      *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
-      *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+      if (wave == 4) DDSP_MF_STAMP(tick, 1, 1);
+      __syncthreads();
     }
-  }
-  if (wave == 0) DDSP_MF_STAMP(1);     // design wavefront 0 done
-  if (wave == 4) DDSP_MF_STAMP(2);     // noise wavefront 4 done
-  __syncthreads();
-  if (wave == 0) DDSP_MF_STAMP(3);     // everything staged
-
-  // ---- FIR: pairs of frames on the matrix cores ------------------------------------------------------------------------
-  // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block P = 2 c + (g >> 1) of the
-  // pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
-  //   A (row b = i): x_frame[16 p + b - d], e = 0..7  =  reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
-  //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
-  // wavefront w: output pairs 4 w + 1 .. 4 w + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are output),
-  // preceded by pair 4 w, whose left half belongs to the previous wavefront (or, pair 0, to the previous block).
-  // All addresses are those of pair 4 w plus a constant per pair, so the unrolled pair loop carries no address arithmetic.
-  const int p_first = 4 * wave;
-  const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
-  int a_hi[5], a_lo[5];                   // byte offsets into s_x of the hi / lo fragments of pair 4 w
-  int b_ptr[5];                           // byte offsets into s_taps; FS64: tap row 2 P (+ 1 for the second frame) folded in
-  int b_off[5];
+  } else {
+    // =========================== FIR wavefronts: pairs of frames on the matrix cores =================================
+    // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block P = 2 c + (g >> 1) of
+    // the pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
+    //   A (row b = i): x_frame[16 p + b - d], e = 0..7 = reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
+    //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
+    // FIR wavefront cw: output pairs 8 cw + 1 .. 8 cw + 8 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are
+    // output), preceded by pair 8 cw, whose left half belongs to the previous wavefront (or, pair 0, to the previous
+    // tile).  Nine pairs in three groups of three: within a group every LDS address is a per-lane register plus an
+    // immediate; the registers move on by three pairs between groups.
+    const int cw = wave - 8;
+    const int p_first = 8 * cw;
+    const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
+    int a_hi0[5], a_lo0[5], b_ptr0[5], b_off[5];
 #pragma unroll
-  for (int c = 0; c < 5; ++c) {
-    const int P = 2 * c + (mg >> 1);
-    const int second = P >= 5 ? 1 : 0;
-    const int pp = P - 5 * second;
-    const int u = 79 + kMfXStride * second - 16 * pp - mi + 8 * (mg & 1);            // relative to the pair's first frame
-    // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
-    a_hi[c] = xsel + ((u + 1) >> 1) * 4;
-    a_lo[c] = a_hi[c] + kMfXPlane;
-    const int q = (mi - 4 * second) - pp;
-    b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 32 : 512;
-    b_ptr[c] = (2 * p_first + second) * kMfTapRowBytes + b_off[c];
-    DDSP_KEEP_IN_VGPR(a_hi[c]);
-    DDSP_KEEP_IN_VGPR(a_lo[c]);
-    DDSP_KEEP_IN_VGPR(b_ptr[c]);
-    // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32 each;
-    // a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
-    __builtin_assume((a_hi[c] & 3) == 0);
-    __builtin_assume((a_lo[c] & 3) == 0);
-    __builtin_assume((b_ptr[c] & 15) == 0);
-  }
-  mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-  float* __restrict__ o = out + (size_t)b * p.N;
-  // out index of this lane's first value of pair 4 w: z = z0 - 128 + 128 P + 16 a + 4 g (+ r)
-  const long n_base = (long)z0 - 128 + 128L * p_first + 16 * mi + 4 * mg - p.start;
-  // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
-  const bool interior = n_base - 16 * mi - 4 * mg + 128 >= 0 && n_base - 16 * mi - 4 * mg + 128 * 5 + 128 <= (long)p.N &&
-                        (((p.start | p.N) & 1) == 0);
+    for (int c = 0; c < 5; ++c) {
+      const int P = 2 * c + (mg >> 1);
+      const int second = P >= 5 ? 1 : 0;
+      const int pp = P - 5 * second;
+      const int u = 79 + kMfXStride * second - 16 * pp - mi + 8 * (mg & 1);            // relative to the pair's first frame
+      // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
+      a_hi0[c] = xsel + ((u + 1) >> 1) * 4;
+      a_lo0[c] = a_hi0[c] + kMfXPlane;
+      const int q = (mi - 4 * second) - pp;
+      b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 32 : 512;
+      b_ptr0[c] = (2 * p_first + second) * kMfTapRowBytes + b_off[c];
+    }
+#pragma unroll 1
+    for (int tick = -1; tick < n_my; ++tick) {
+      if (wave == 8) DDSP_MF_STAMP(tick, 2, 0);
+      if (tick >= 0) {
+        const int T = (int)blockIdx.x + tick * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)f_first;
+        const unsigned char* const s_taps = s_taps_all[tick & 1];
+        const unsigned char* const s_x = s_x_all[tick & 1];
+        float* __restrict__ o = out + (size_t)b * p.N;
+        // out index of this lane's first value of pair 8 cw: z = z0 - 128 + 128 P + 16 a + 4 g (+ r)
+        const long n_tile = (long)z0 - 128 + 128L * p_first - p.start;
+        // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
+        const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 9 <= (long)p.N && (((p.start | p.N) & 1) == 0);
+        const long n_base = n_tile + 16 * mi + 4 * mg;
+        mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+        int a_hi[5], a_lo[5], b_ptr[5];
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int P = p_first + it;
-    if (P < kMfRows / 2) {                                            // wavefront 7 has three output pairs
-      mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
-      int rowA = 0, rowB = 0;
-      if (!FS64) {
-        // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
-        rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
-        rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
-      }
+        for (int c = 0; c < 5; ++c) { a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c]; b_ptr[c] = b_ptr0[c]; }
+#pragma unroll 1
+        for (int grp = 0; grp < 3; ++grp) {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it);
-        const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it);
-        const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
-        // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
-        const unsigned char* tr;
-        if (FS64) tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it;
-        else tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
-        const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr);
-        const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + 16);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
-        acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
-        acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
-      }
-      const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
-      // D[row b = 4 g + r][col a = i]: columns 0..7 are complete
-      if (it > 0 && mi < 8) {
-        const long n = n_base + 128L * it;
-        if (interior) {
-          *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
-          *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
-        } else {
+          for (int c = 0; c < 5; ++c) {
+            DDSP_KEEP_IN_VGPR(a_hi[c]);
+            DDSP_KEEP_IN_VGPR(a_lo[c]);
+            DDSP_KEEP_IN_VGPR(b_ptr[c]);
+            // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32
+            // each; a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
+            __builtin_assume((a_hi[c] & 3) == 0);
+            __builtin_assume((a_lo[c] & 3) == 0);
+            __builtin_assume((b_ptr[c] & 15) == 0);
+          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = comb[r];
-            if (n + r >= 0 && n + r < p.N) o[n + r] = v;
+          for (int it3 = 0; it3 < 3; ++it3) {
+            const int it = 3 * grp + it3;
+            const int P = p_first + it;
+            if (P < kMfRows / 2) {                                            // the last FIR wavefront has seven output pairs
+              mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+              int rowA = 0, rowB = 0;
+              if (!FS64) {
+                // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
+                rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
+                rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
+              }
+#pragma unroll
+              for (int c = 0; c < 5; ++c) {
+                const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it3);
+                const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it3);
+                const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
+                // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
+                const unsigned char* tr;
+                if (FS64) tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it3;
+                else tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
+                const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr);
+                const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
+                acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
+                acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
+              }
+              const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
+              // D[row b = 4 g + r][col a = i]: columns 0..7 are complete
+              if (it > 0 && mi < 8) {
+                const long n = n_base + 128L * it;
+                if (interior) {
+                  *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
+                  *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const float v = comb[r];
+                    if (n + r >= 0 && n + r < p.N) o[n + r] = v;
+                  }
+                }
+              }
+              // columns 8..15 -> columns 0..7 of the next pair's tile (row_shl:8, out-of-row lanes read 0)
+              // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - clang 22)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = comb[r];
+                carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            a_hi[c] += 3 * 2 * kMfXStride * 2;
+            a_lo[c] += 3 * 2 * kMfXStride * 2;
+            b_ptr[c] += 3 * 2 * kMfTapRowBytes;
           }
         }
       }
-      // columns 8..15 -> columns 0..7 of the next pair's tile (row_shl:8, out-of-row lanes read 0)
-      // (through a scalar temporary: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - clang 22)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = comb[r];
-        carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
-      }
+      if (wave == 8) DDSP_MF_STAMP(tick, 2, 1);
+      __syncthreads();
     }
   }
-  if (wave == 0) DDSP_MF_STAMP(4);     // FIR of wavefront 0 done
 #undef DDSP_MF_STAMP
+#undef DDSP_MF_TILE
 }
 
 bool noise_mfma65_ok(int F, int M, int N, int padding, const void* noise) {
@@ -424,7 +507,17 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
   q.fs = (N + F - 1) / F; q.inv_fs = 1.0f / (float)q.fs;
   q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
   q.dbg = dbg;
-  const dim3 grid((unsigned)((N + start + kMfTile - 1) / kMfTile), (unsigned)B);
+  q.tiles_per_row = (N + start + kMfTile - 1) / kMfTile;
+  q.n_tiles = B * q.tiles_per_row;
+  // persistent grid: one block of 12 wavefronts per CU (two LDS buffers of 76 KB)
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  const dim3 grid((unsigned)(q.n_tiles < n_cu ? q.n_tiles : n_cu));
   hipEvent_t ev0, ev1;
   profile_kernel_events(kNoiseMfma, &ev0, &ev1);
 #define DDSP_LAUNCH_MF(GEN, FS64)                                                                                      \

@@ -39,19 +39,21 @@ for B in [int(v) for v in sys.argv[1:]] or [32, 128]:
   res['max_abs_diff_vs_vector_ir'] = {k: float((outs[k] - outs['vector_fir+vector_ir']).abs().max()) for k in outs}
   res['max_abs_out'] = float(outs['mfma'].abs().max())
   print(json.dumps(res))
-  # phase timeline of the matrix-core kernel (debug flag 0x40000000: the controls pointer carries the stamp buffer)
+  # per-tick timeline of block 0 of the persistent matrix-core kernel (debug flag 0x40000000: the controls pointer
+  # carries the stamp buffer [tick + 1][role: design, noise, FIR][begin, end], 100 MHz wall clock)
   audio = torch.empty((B, N), device='cuda')
   ws = torch.empty(max(lib.ddsp_filtered_noise_workspace_bytes(B, F, M, N, 0), 16), dtype=torch.uint8, device='cuda')
-  nblk = B * 17
-  dbg = torch.zeros((nblk, 8), dtype=torch.int64, device='cuda')
+  dbg = torch.zeros((16, 3, 2), dtype=torch.int64, device='cuda')
   rc = lib.ddsp_filtered_noise_f32(mags.data_ptr(), None, audio.data_ptr(), dbg.data_ptr(), ws.data_ptr(), ws.numel(),
                                    B, F, M, N, 0, -5.0, 1 | 0x40000000, 1, 0, torch.cuda.current_stream().cuda_stream)
   assert rc == 0, rc
   torch.cuda.synchronize()
   d = dbg.cpu().numpy().astype(np.float64)
-  d = (d - d[:, 0].min()) * 0.01
-  print('noise_mfma65_kernel B=%d blocks=%d  (us since first block start; min / median / max over blocks)' % (B, nblk))
-  for i, nm in enumerate(['start', 'noise tile staged', 'IR designed + barrier', 'FIR done, stored']):
-    print('  %-24s %7.2f %7.2f %7.2f' % (nm, d[:, i].min(), np.median(d[:, i]), d[:, i].max()))
-  print('  per block: noise %.2f  IR %.2f  FIR %.2f us (medians of the differences)' % (
-      np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]), np.median(d[:, 3] - d[:, 2])))
+  t0 = d[0, 0, 0]
+  print('noise_mfma65_kernel B=%d, block 0: per tick (us since the block started) role begin..end' % B)
+  for k in range(16):
+    if d[k].max() == 0: break
+    row = ['tick %2d' % (k - 1)]
+    for r, nm in enumerate(('design', 'noise', 'FIR')):
+      if d[k, r, 0] > 0: row.append('%s %6.2f..%6.2f (%.2f)' % (nm, (d[k, r, 0] - t0) * 0.01, (d[k, r, 1] - t0) * 0.01, (d[k, r, 1] - d[k, r, 0]) * 0.01))
+    print('  ' + '   '.join(row))

@@ -7,11 +7,11 @@ export TMPDIR=/tmp
 export DDSP_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl
 rm -f $DDSP_PARITY_LOG
 echo "== pytest (noise / DAG / smoke-relevant cases), no -x"
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_general.py -m gpu -q -k "noise or processor_group or full_size or fir_filter or vst_dag or training_loop" 2>&1 | tail -15 | tee $OUT/pytest_noise.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_general.py -m gpu -q -k "noise or processor_group or full_size or fir_filter or vst_dag or training_loop" 2>&1 | tee $OUT/pytest_noise_full.txt | tail -15
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 echo "== FilteredNoise: matrix-core kernel vs vector-ALU FIR"
-timeout 300 python tools/exp_noise_fir.py 32 128 2>&1 | tail -16 | tee $OUT/noise_mfma_vs_vector.txt
+timeout 300 python tools/exp_noise_fir.py 32 128 2>&1 | tail -40 | tee $OUT/noise_mfma_vs_vector.txt
 echo "== Harmonic (chunk-level Nyquist flag)"
 timeout 120 python tools/exp_table.py 32 128 2>&1 | tail -2 | tee $OUT/harm_table_vs_direct.json
 echo "== bench (1000 steps), then driver-like"
