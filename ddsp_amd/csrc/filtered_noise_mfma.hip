@@ -46,7 +46,7 @@ namespace ddsp {
 constexpr int kMfFrames = 62;                  // output frames per block
 constexpr int kMfRows = 64;                    // staged frames: 2 of halo + 62
 constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per block
-constexpr int kMfWaves = 12;                 // 4 design + 4 noise + 4 FIR wavefronts
+constexpr int kMfWaves = 16;                 // 8 producer (taps + noise) + 8 FIR wavefronts
 constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
 // tap table: per row 16 groups of {8 hi halves, 8 lo halves} (32 bytes) + one group of zeros that lanes outside the
 // filter's support read
@@ -130,13 +130,16 @@ __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool f
 
 // FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s.
 //
-// Persistent, one block of 12 wavefronts per CU, tiles dealt round-robin; two LDS buffers; one barrier per tick:
-//     tick k:   design wavefronts 0-3 and noise wavefronts 4-7 fill buffer (k+1) & 1 with tile k+1 (vector ALUs),
-//               FIR wavefronts 8-11 turn buffer k & 1 (tile k) into audio (matrix cores + LDS reads).
-// The design wavefronts fetch the magnitudes of tile k+2 at the top of the tick and use them a tick later, so no
-// wavefront ever waits for HBM.
+// Persistent, one block of 16 wavefronts per CU, tiles dealt round-robin; two LDS buffers; one barrier per tick:
+//     tick k:   producer wavefronts 0-7 fill buffer (k+1) & 1 with tile k+1 (vector ALUs): wavefront w designs the taps
+//               n = 16 (w >> 2) .. + 15 of rows 16 (w & 3) .. + 15 and generates an eighth of the noise tile;
+//               FIR wavefronts 8-15 turn buffer k & 1 (tile k) into audio (matrix cores + LDS reads), two per SIMD so
+//               that one's LDS latency hides behind the other's MFMAs (with one per SIMD a pair took 1400 clocks,
+//               profiles/r02e_noise_mfma_v3_persistent_12waves.txt).
+// The producers fetch the magnitudes of tile k+2 at the top of the tick and use them a tick later, so no wavefront
+// ever waits for HBM.
 template <bool GEN_NOISE, bool FS64>
-__global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
+__global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][kMfRows * kMfTapRowBytes];
@@ -155,24 +158,36 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
   const int ffirst_ = (z0_ - 128 >= 0) ? (z0_ - 128) / p.fs : -((128 - z0_ + p.fs - 1) / p.fs);         \
   const int rel0_ = (z0_ - 128) - ffirst_ * p.fs
 
-  if (wave < 4) {
-    // =========================== design wavefronts: the taps of rows 16 w .. 16 w + 15 ===============================
+  if (wave < 8) {
+    // =========================== producer wavefronts ==================================================================
     const float kLog10 = 2.302585092994046f;
-    // the constant cosine factor as fp16 hi / lo A-fragments, made at compile time: [tap tile][even / odd bins][hi / lo]
-    mf_f16x8 afr[2][2][2];
+    const int rg = wave & 3, mt = wave >> 2;           // row group, tap tile
+    // the constant cosine factor of this tap tile as fp16 hi / lo A-fragments, made at compile time: [even / odd bins][hi / lo]
+    mf_f16x8 afr[2][2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int par = 0; par < 2; ++par)
 #pragma unroll
-      for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-          const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[q][par][hl][lane]);
-          afr[q][par][hl] = mf_frag(v.x, v.y, v.z, v.w);
-        }
-    // the zero group of this wavefront's tap rows, both buffers (what lanes outside the filter's support read)
-    *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (16 * wave + ((lane >> 1) & 15)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
-    const int rrow = 16 * wave + mi;
-    // the 16 bins of this lane's B-fragments (row = 16 w + i, bins 16 g .. + 15) and bin 64 of that row, straight from
+      for (int hl = 0; hl < 2; ++hl) {
+        const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[mt][par][hl][lane]);
+        afr[par][hl] = mf_frag(v.x, v.y, v.z, v.w);
+      }
+    // zeros that stay: the zero group of the tap rows (what lanes outside the filter's support read) and the 16 elements
+    // between the reversed noise frames (both copies), in both buffers
+    if (mt == 0)
+      *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * 65 * 16; i += 512) {
+      unsigned char* const s_xe = s_x_all[i >= 65 * 16 ? 1 : 0];
+      unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
+      const int ii = i >= 65 * 16 ? i - 65 * 16 : i;
+      const int e = 80 * (ii >> 4) + (ii & 15);                       // element index of a padding element
+      // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
+      *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
+      *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
+    }
+    const int rrow = 16 * rg + mi;
+    // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
     // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
     MfU4f rq[4];
     float r_last;
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
     }
 #pragma unroll 1
     for (int tick = -1; tick < n_my; ++tick) {
-      DDSP_MF_STAMP(tick, 0, 0);
+      if (wave == 0) DDSP_MF_STAMP(tick, 0, 0);
       // magnitudes of tile tick + 2, to be used a tick from now (past the block's last tile: the last one again)
       MfU4f nq[4];
       float n_last;
@@ -207,6 +222,56 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)rel0;
         unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
+        unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
+        unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
+        // ---- the noise tile x[z0-128 .. z0+3967]: reversed, hi / lo split, two copies; two quads per lane (two
+        //      independent Philox chains) ----------------------------------------------------------------------------
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int qd = tid + 512 * h;
+          const int i = z0 - 128 + 4 * qd;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i >= 0 && i < p.N) {
+            if (GEN_NOISE) {
+              const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+              v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+              if (i + 1 >= p.N) v.y = 0.f;
+              if (i + 2 >= p.N) v.z = 0.f;
+              if (i + 3 >= p.N) v.w = 0.f;
+            } else {
+              const float* src = x + (size_t)b * p.N + i;
+              if (i + 3 < p.N && ((p.N & 3) == 0)) {
+                v = *reinterpret_cast<const float4*>(src);
+              } else {
+                v.x = src[0];
+                if (i + 1 < p.N) v.y = src[1];
+                if (i + 2 < p.N) v.z = src[2];
+                if (i + 3 < p.N) v.w = src[3];
+              }
+            }
+          }
+          _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+          mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+          mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+          mf_split(v.y, h2, l2);
+          mf_split(v.x, h3, l3);
+          const int s = qd >> 4, j = 4 * (qd & 15);
+          const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+          // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+          *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+          *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+          // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
+          // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+          unsigned char* po = s_xo + (u0 + 1) * 2;
+          *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+          *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+          *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+          *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+          *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+          *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+        }
+        if (wave == 0) DDSP_MF_STAMP(tick, 1, 0);
+        // ---- the taps n = 16 mt .. + 15 (and their mirror images) of rows 16 rg .. + 15 ---------------------------------
         // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
         const int own_lo = (z0 == 0) ? 0 : f_first + 2;
         const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
@@ -226,7 +291,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
           for (int c = 0; c < 16; ++c) y[c] = 0.0f;
           m_last = 0.0f;
         }
-        if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
+        if (ctl_out && mt == 0 && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
           float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
 #pragma unroll
           for (int c4 = 0; c4 < 4; ++c4)
@@ -241,17 +306,16 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
         mf_split8(vo, bo_hi, bo_lo);
         unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
         const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 q + 4 g + r: D[n][row i]
-          mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_hi, zero, 0, 0, 0);
-          mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_hi, zero, 0, 0, 0);
-          mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][0], be_lo, zero, 0, 0, 0);
-          mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][0], bo_lo, zero, 0, 0, 0);
-          ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][0][1], be_hi, ex, 0, 0, 0);
-          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[q][1][1], bo_hi, ox, 0, 0, 0);
+        {
+          // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 mt + 4 g + r: D[n][row i]
+          mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][0], be_hi, zero, 0, 0, 0);
+          mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][0], bo_hi, zero, 0, 0, 0);
+          mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][0], be_lo, zero, 0, 0, 0);
+          mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][0], bo_lo, zero, 0, 0, 0);
+          ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][1], be_hi, ex, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][1], bo_hi, ox, 0, 0, 0);
           const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
-          const int n0 = 16 * q + 4 * mg;                                 // this lane's taps n0 .. n0 + 3
+          const int n0 = 16 * mt + 4 * mg;                                // this lane's taps n0 .. n0 + 3
           float g0[4], g1[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -266,7 +330,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
           mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
           mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
         }
-        {
+        if (mt == 0) {
           // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
           const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
           float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
@@ -284,87 +348,12 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
             *reinterpret_cast<uint16_t*>(hrow + 4 * 32 + 16) = lb;
           }
         }
+        if (wave == 0) DDSP_MF_STAMP(tick, 1, 1);
       }
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) rq[c4] = nq[c4];
       r_last = n_last;
-      DDSP_MF_STAMP(tick, 0, 1);
-      __syncthreads();
-    }
-  } else if (wave < 8) {
-    // =========================== noise wavefronts: the tile x[z0-128 .. z0+3967] =====================================
-    const int t = tid - 256;
-    // zeros: the 16 elements between the reversed frames (both copies, both buffers); they stay zero
-    for (int i = t; i < 2 * 65 * 16; i += 256) {
-      unsigned char* const s_xe = s_x_all[i >= 65 * 16 ? 1 : 0];
-      unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
-      const int ii = i >= 65 * 16 ? i - 65 * 16 : i;
-      const int e = 80 * (ii >> 4) + (ii & 15);                       // element index of a padding element
-      // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
-      *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
-      *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
-      *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
-      *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
-    }
-#pragma unroll 1
-    for (int tick = -1; tick < n_my; ++tick) {
-      if (wave == 4) DDSP_MF_STAMP(tick, 1, 0);
-      if (tick + 1 < n_my) {
-        const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
-        DDSP_MF_TILE(T, b, z0, f_first, rel0);
-        (void)f_first; (void)rel0;
-        unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
-        unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
-        // reversed, hi / lo split, two copies; two quads per lane and pass (two independent Philox chains)
-#pragma unroll 1
-        for (int q0 = t; q0 < (kMfTile + 128) / 4; q0 += 512) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int qd = q0 + 256 * h;
-            const int i = z0 - 128 + 4 * qd;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i >= 0 && i < p.N) {
-              if (GEN_NOISE) {
-                const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-                v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-                if (i + 1 >= p.N) v.y = 0.f;
-                if (i + 2 >= p.N) v.z = 0.f;
-                if (i + 3 >= p.N) v.w = 0.f;
-              } else {
-                const float* src = x + (size_t)b * p.N + i;
-                if (i + 3 < p.N && ((p.N & 3) == 0)) {
-                  v = *reinterpret_cast<const float4*>(src);
-                } else {
-                  v.x = src[0];
-                  if (i + 1 < p.N) v.y = src[1];
-                  if (i + 2 < p.N) v.z = src[2];
-                  if (i + 3 < p.N) v.w = src[3];
-                }
-              }
-            }
-            _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
-            mf_split(v.w, h0, l0);               // element u0     = sample j + 3
-            mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
-            mf_split(v.y, h2, l2);
-            mf_split(v.x, h3, l3);
-            const int s = qd >> 4, j = 4 * (qd & 15);
-            const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
-            // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
-            *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-            *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
-            // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
-            // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
-            unsigned char* po = s_xo + (u0 + 1) * 2;
-            *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
-            *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
-            *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
-            *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
-            *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
-            *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
-          }
-        }
-      }
-      if (wave == 4) DDSP_MF_STAMP(tick, 1, 1);
+      if (wave == 0) DDSP_MF_STAMP(tick, 0, 1);
       __syncthreads();
     }
   } else {
@@ -373,12 +362,11 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
     // the pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
     //   A (row b = i): x_frame[16 p + b - d], e = 0..7 = reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
     //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
-    // FIR wavefront cw: output pairs 8 cw + 1 .. 8 cw + 8 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are
-    // output), preceded by pair 8 cw, whose left half belongs to the previous wavefront (or, pair 0, to the previous
-    // tile).  Nine pairs in three groups of three: within a group every LDS address is a per-lane register plus an
-    // immediate; the registers move on by three pairs between groups.
+    // FIR wavefront cw: output pairs 4 cw + 1 .. 4 cw + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are
+    // output), preceded by pair 4 cw, whose left half belongs to the previous wavefront (or, pair 0, to the previous
+    // tile).  Five pairs, unrolled: every LDS address is a per-lane register plus an immediate.
     const int cw = wave - 8;
-    const int p_first = 8 * cw;
+    const int p_first = 4 * cw;
     const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
     int a_hi0[5], a_lo0[5], b_ptr0[5], b_off[5];
 #pragma unroll
@@ -407,14 +395,13 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
         // out index of this lane's first value of pair 8 cw: z = z0 - 128 + 128 P + 16 a + 4 g (+ r)
         const long n_tile = (long)z0 - 128 + 128L * p_first - p.start;
         // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
-        const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 9 <= (long)p.N && (((p.start | p.N) & 1) == 0);
+        const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 5 <= (long)p.N && (((p.start | p.N) & 1) == 0);
         const long n_base = n_tile + 16 * mi + 4 * mg;
         mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
         int a_hi[5], a_lo[5], b_ptr[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) { a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c]; b_ptr[c] = b_ptr0[c]; }
-#pragma unroll 1
-        for (int grp = 0; grp < 3; ++grp) {
+        {
 #pragma unroll
           for (int c = 0; c < 5; ++c) {
             DDSP_KEEP_IN_VGPR(a_hi[c]);
@@ -427,10 +414,10 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
             __builtin_assume((b_ptr[c] & 15) == 0);
           }
 #pragma unroll
-          for (int it3 = 0; it3 < 3; ++it3) {
-            const int it = 3 * grp + it3;
+          for (int it3 = 0; it3 < 5; ++it3) {
+            const int it = it3;
             const int P = p_first + it;
-            if (P < kMfRows / 2) {                                            // the last FIR wavefront has seven output pairs
+            if (P < kMfRows / 2) {                                            // the last FIR wavefront has three output pairs
               mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
               int rowA = 0, rowB = 0;
               if (!FS64) {
@@ -476,12 +463,6 @@ __global__ __launch_bounds__(64 * kMfWaves, 3) void noise_mfma65_kernel(
                 carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
               }
             }
-          }
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            a_hi[c] += 3 * 2 * kMfXStride * 2;
-            a_lo[c] += 3 * 2 * kMfXStride * 2;
-            b_ptr[c] += 3 * 2 * kMfTapRowBytes;
           }
         }
       }

@@ -54,6 +54,6 @@ for B in [int(v) for v in sys.argv[1:]] or [32, 128]:
   for k in range(16):
     if d[k].max() == 0: break
     row = ['tick %2d' % (k - 1)]
-    for r, nm in enumerate(('design', 'noise', 'FIR')):
+    for r, nm in enumerate(('producer', 'its design part', 'FIR')):
       if d[k, r, 0] > 0: row.append('%s %6.2f..%6.2f (%.2f)' % (nm, (d[k, r, 0] - t0) * 0.01, (d[k, r, 1] - t0) * 0.01, (d[k, r, 1] - d[k, r, 0]) * 0.01))
     print('  ' + '   '.join(row))
