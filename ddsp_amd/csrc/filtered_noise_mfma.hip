@@ -35,6 +35,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/ddsp_amd.h"
 #include "common.h"
 #include "noise_ir65.h"
@@ -396,62 +397,83 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         const long n_tile = (long)z0 - 128 + 128L * p_first - p.start;
         // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
         const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 5 <= (long)p.N && (((p.start | p.N) & 1) == 0);
-        const long n_base = n_tile + 16 * mi + 4 * mg;
+        float* __restrict__ ot = o + n_tile;                               // wave-uniform base; lanes add a 32-bit offset
+        const int lane_off = 16 * mi + 4 * mg;
         mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
         int a_hi[5], a_lo[5], b_ptr[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) { a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c]; b_ptr[c] = b_ptr0[c]; }
-        {
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            DDSP_KEEP_IN_VGPR(a_hi[c]);
-            DDSP_KEEP_IN_VGPR(a_lo[c]);
-            DDSP_KEEP_IN_VGPR(b_ptr[c]);
-            // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32
-            // each; a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
-            __builtin_assume((a_hi[c] & 3) == 0);
-            __builtin_assume((a_lo[c] & 3) == 0);
-            __builtin_assume((b_ptr[c] & 15) == 0);
-          }
-#pragma unroll
-          for (int it3 = 0; it3 < 5; ++it3) {
-            const int it = it3;
+        for (int c = 0; c < 5; ++c) {
+          a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c]; b_ptr[c] = b_ptr0[c];
+          DDSP_KEEP_IN_VGPR(a_hi[c]);
+          DDSP_KEEP_IN_VGPR(a_lo[c]);
+          DDSP_KEEP_IN_VGPR(b_ptr[c]);
+          // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32
+          // each; a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
+          __builtin_assume((a_hi[c] & 3) == 0);
+          __builtin_assume((a_lo[c] & 3) == 0);
+          __builtin_assume((b_ptr[c] & 15) == 0);
+        }
+        // (the last FIR wavefront has three output pairs: its fifth pair reads past the staged frames - whatever the LDS
+        // holds there, or zeros beyond its end - and is not stored; no control flow inside the pipeline, so the
+        // compiler's s_waitcnt counts stay exact)
+        // The 5 x 5 (pair, k-step) sequence runs as ONE software pipeline: the fragment reads of step j + 3 are issued right
+        // after the MFMAs of step j (three steps = 18 LDS operations in flight per wavefront: the LDS only reaches its rate
+        // with many operations outstanding, and two FIR wavefronts share a SIMD), the epilogue of a pair (combine, store,
+        // shift the right half over) runs under the reads of the next pair.  The carry enters in the epilogue, not as
+        // the accumulator's start value, so no MFMA waits for a previous pair.
+        mf_f16x8 fah[3], fal[3], fbh[3], fbl[3];
+        auto load_step = [&](int j, int slot) {
+          const int it = j / 5, c = j - 5 * it;
+          const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it);
+          const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it);
+          fah[slot] = mf_frag(qh.x, qh.y, qh.z, qh.w);
+          fal[slot] = mf_frag(ql.x, ql.y, ql.z, ql.w);
+          // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
+          const unsigned char* tr;
+          if (FS64) {
+            tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it;
+          } else {
+            // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
             const int P = p_first + it;
-            if (P < kMfRows / 2) {                                            // the last FIR wavefront has three output pairs
-              mf_f32x4 acc = carry, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
-              int rowA = 0, rowB = 0;
-              if (!FS64) {
-                // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
-                rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
-                rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
-              }
+            const int rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
+            const int rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
+            tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
+          }
+          fbh[slot] = *reinterpret_cast<const mf_f16x8*>(tr);
+          fbl[slot] = *reinterpret_cast<const mf_f16x8*>(tr + 16);
+        };
+        load_step(0, 0);
+        load_step(1, 1);
+        load_step(2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};   // three independent chains
+        auto pipeline = [&](auto interior_tag) {
+          constexpr bool kInterior = decltype(interior_tag)::value;
 #pragma unroll
-              for (int c = 0; c < 5; ++c) {
-                const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it3);
-                const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it3);
-                const mf_f16x8 ahi = mf_frag(qh.x, qh.y, qh.z, qh.w), alo = mf_frag(ql.x, ql.y, ql.z, ql.w);
-                // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
-                const unsigned char* tr;
-                if (FS64) tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it3;
-                else tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
-                const mf_f16x8 bhi = *reinterpret_cast<const mf_f16x8*>(tr);
-                const mf_f16x8 blo = *reinterpret_cast<const mf_f16x8*>(tr + 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc, 0, 0, 0);
-                acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc_hl, 0, 0, 0);
-                acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc_lh, 0, 0, 0);
-              }
-              const mf_f32x4 comb = acc + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
+          for (int j = 0; j < 25; ++j) {
+            const int it = j / 5, c = j - 5 * it, slot = j % 3;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbh[slot], acc, 0, 0, 0);
+            acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbl[slot], acc_hl, 0, 0, 0);
+            acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh[slot], acc_lh, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 3 < 25) load_step(j + 3, slot);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 4) {
+              const mf_f32x4 comb = (acc + carry) + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
+              acc = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
+              acc_hl = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
+              acc_lh = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
               // D[row b = 4 g + r][col a = i]: columns 0..7 are complete
-              if (it > 0 && mi < 8) {
-                const long n = n_base + 128L * it;
-                if (interior) {
-                  *reinterpret_cast<float2*>(o + n) = make_float2(comb[0], comb[1]);
-                  *reinterpret_cast<float2*>(o + n + 2) = make_float2(comb[2], comb[3]);
+              if (it > 0 && mi < 8 && p_first + it < kMfRows / 2) {
+                const int idx = lane_off + 128 * it;                         // out index n = n_tile + idx
+                if (kInterior) {
+                  *reinterpret_cast<float2*>(ot + idx) = make_float2(comb[0], comb[1]);
+                  *reinterpret_cast<float2*>(ot + idx + 2) = make_float2(comb[2], comb[3]);
                 } else {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
                     const float v = comb[r];
-                    if (n + r >= 0 && n + r < p.N) o[n + r] = v;
+                    if (n_tile + idx + r >= 0 && n_tile + idx + r < p.N) ot[idx + r] = v;
                   }
                 }
               }
@@ -464,7 +486,9 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
               }
             }
           }
-        }
+        };
+        if (interior) pipeline(std::true_type{});
+        else pipeline(std::false_type{});
       }
       if (wave == 8) DDSP_MF_STAMP(tick, 2, 1);
       __syncthreads();
