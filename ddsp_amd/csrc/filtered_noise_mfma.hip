@@ -49,9 +49,12 @@ constexpr int kMfRows = 64;                    // staged frames: 2 of halo + 62
 constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per block
 constexpr int kMfWaves = 16;                 // 8 producer (taps + noise) + 8 FIR wavefronts
 constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
-// tap table: per row 16 groups of {8 hi halves, 8 lo halves} (32 bytes) + one group of zeros that lanes outside the
-// filter's support read
-constexpr int kMfTapRowBytes = 17 * 32;        // 544
+// tap table: a hi plane and a lo plane; per row 16 groups of 8 taps (16 bytes) + one group of zeros that lanes outside the
+// filter's support read.  The 16 lanes of a ds_read_b128 pass read 16 DIFFERENT groups of one row (or the zero group):
+// with 16-byte groups they cover all 64 banks once (32-byte {hi, lo} groups were a 2-way conflict, and the LDS is what
+// bounds the FIR phase: profiles/r02g_noise_mfma_v5_pipelined_fir.txt)
+constexpr int kMfTapRowBytes = 17 * 16;        // 272
+constexpr int kMfTapPlane = kMfRows * kMfTapRowBytes;          // 17408: hi plane, then lo plane
 // noise: reversed frames, sample j of staged frame s at element 16 + 80 s + 63 - j; the 16 elements between frames
 // stay zero (the Toeplitz blocks run over both ends of a frame).  Stored as dwords of two elements, hi and lo parts in
 // separate planes: copy E holds elements (2k, 2k+1) in dword k, copy O holds elements (2k-1, 2k).  A fragment is then
@@ -59,7 +62,10 @@ constexpr int kMfTapRowBytes = 17 * 32;        // 544
 constexpr int kMfXStride = 80;
 constexpr int kMfXElems = 16 + kMfRows * kMfXStride + 16;     // 5152
 constexpr int kMfXPairs = kMfXElems / 2 + 1;                   // 2577 (copy O needs one more)
-constexpr int kMfXPlane = ((kMfXPairs * 4 + 15) / 16) * 16;    // bytes of one plane: 10320
+// bytes of one plane: 10336 = 2584 dwords, so that copy O starts 5168 = 16 (mod 32) dwords after copy E: the E lanes
+// (odd rows) and the O lanes (even rows) of one ds_read2_b32 pass then sit in different halves of the banks
+constexpr int kMfXPlane = 10336;
+static_assert(kMfXPlane >= kMfXPairs * 4 && kMfXPlane % 16 == 0 && (2 * kMfXPlane / 4) % 32 == 16, "noise plane layout");
 
 typedef _Float16 mf_f16x8 __attribute__((ext_vector_type(8)));
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
@@ -107,25 +113,23 @@ static __constant__ Ir65Frags kIr65Frags = make_ir65_frags();
 __device__ __forceinline__ void mf_put4(unsigned char* hrow, int t0, float v0, float v1, float v2, float v3) {
   _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
   mf_split(v0, h0, l0); mf_split(v1, h1, l1); mf_split(v2, h2, l2); mf_split(v3, h3, l3);
-  unsigned char* q = hrow + (t0 >> 3) * 32 + (t0 & 7) * 2;
+  unsigned char* q = hrow + t0 * 2;
   *reinterpret_cast<uint2*>(q) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-  *reinterpret_cast<uint2*>(q + 16) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+  *reinterpret_cast<uint2*>(q + kMfTapPlane) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
 }
 // The mirror image: v[0] at tap t1, v[1] at t1 - 1, ... v[3] at t1 - 3 (t1 a multiple of 4; t1 itself is skipped when
 // `first` is false).  t1 - 1, t1 - 2 share a dword; t1 - 3 and t1 are single halves.
 __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool first, float v0, float v1, float v2, float v3) {
   _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
   mf_split(v0, h0, l0); mf_split(v1, h1, l1); mf_split(v2, h2, l2); mf_split(v3, h3, l3);
-  const int ta = t1 - 3;
-  unsigned char* q = hrow + (ta >> 3) * 32 + (ta & 7) * 2;          // taps t1-3 (odd element), t1-2, t1-1 in one group
+  unsigned char* q = hrow + (t1 - 3) * 2;                            // taps t1-3 (odd element), then the dword (t1-2, t1-1)
   *reinterpret_cast<uint16_t*>(q) = __builtin_bit_cast(uint16_t, h3);
-  *reinterpret_cast<uint16_t*>(q + 16) = __builtin_bit_cast(uint16_t, l3);
+  *reinterpret_cast<uint16_t*>(q + kMfTapPlane) = __builtin_bit_cast(uint16_t, l3);
   *reinterpret_cast<uint32_t*>(q + 2) = mf_pack(h2, h1);
-  *reinterpret_cast<uint32_t*>(q + 18) = mf_pack(l2, l1);
+  *reinterpret_cast<uint32_t*>(q + kMfTapPlane + 2) = mf_pack(l2, l1);
   if (first) {
-    unsigned char* q1 = hrow + (t1 >> 3) * 32 + (t1 & 7) * 2;
-    *reinterpret_cast<uint16_t*>(q1) = __builtin_bit_cast(uint16_t, h0);
-    *reinterpret_cast<uint16_t*>(q1 + 16) = __builtin_bit_cast(uint16_t, l0);
+    *reinterpret_cast<uint16_t*>(q + 6) = __builtin_bit_cast(uint16_t, h0);
+    *reinterpret_cast<uint16_t*>(q + kMfTapPlane + 6) = __builtin_bit_cast(uint16_t, l0);
   }
 }
 
@@ -143,7 +147,7 @@ template <bool GEN_NOISE, bool FS64>
 __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][kMfRows * kMfTapRowBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][2 * kMfTapPlane];       // hi plane, lo plane
   __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     // zeros that stay: the zero group of the tap rows (what lanes outside the filter's support read) and the 16 elements
     // between the reversed noise frames (both copies), in both buffers
     if (mt == 0)
-      *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 512 + 16 * (lane & 1)) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (lane & 1) * kMfTapPlane + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 256) = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * 65 * 16; i += 512) {
       unsigned char* const s_xe = s_x_all[i >= 65 * 16 ? 1 : 0];
       unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
@@ -343,10 +347,10 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             _Float16 h, l;
             mf_split(kIr65.win[32] * part, h, l);
             const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
-            *reinterpret_cast<uint16_t*>(hrow + 12 * 32) = hb;             // tap 96: group 12, element 0
-            *reinterpret_cast<uint16_t*>(hrow + 12 * 32 + 16) = lb;
-            *reinterpret_cast<uint16_t*>(hrow + 4 * 32) = hb;              // tap 32: group 4, element 0
-            *reinterpret_cast<uint16_t*>(hrow + 4 * 32 + 16) = lb;
+            *reinterpret_cast<uint16_t*>(hrow + 96 * 2) = hb;              // tap 96
+            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 96 * 2) = lb;
+            *reinterpret_cast<uint16_t*>(hrow + 32 * 2) = hb;              // tap 32
+            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
           }
         }
         if (wave == 0) DDSP_MF_STAMP(tick, 1, 1);
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       a_hi0[c] = xsel + ((u + 1) >> 1) * 4;
       a_lo0[c] = a_hi0[c] + kMfXPlane;
       const int q = (mi - 4 * second) - pp;
-      b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 32 : 512;
+      b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 16 : 256;
       b_ptr0[c] = (2 * p_first + second) * kMfTapRowBytes + b_off[c];
     }
 #pragma unroll 1
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
           }
           fbh[slot] = *reinterpret_cast<const mf_f16x8*>(tr);
-          fbl[slot] = *reinterpret_cast<const mf_f16x8*>(tr + 16);
+          fbl[slot] = *reinterpret_cast<const mf_f16x8*>(tr + kMfTapPlane);
         };
         load_step(0, 0);
         load_step(1, 1);
