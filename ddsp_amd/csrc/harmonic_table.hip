@@ -114,20 +114,26 @@ __device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, f
   if constexpr (P + 1 < W / 2) wt_taps<W, P + 1>(t0, z, z2, acc0, acc1);
 }
 
-// the same for two tiles at once (two independent chains per instruction slot)
-template <int W, int P>
-__device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const float* __restrict__ tb, float za, float zb,
-                                         float za2, float zb2, float (&acc0)[2], float (&acc1)[2]) {
-  float la, ha, lb, hb;
-  wt_pair<W, P>(za, za2, la, ha);
-  wt_pair<W, P>(zb, zb2, lb, hb);
-  const float a0 = ta[-P], a1 = ta[1 + P], a2 = ta[kWtTS - P], a3 = ta[kWtTS + 1 + P];
-  const float b0 = tb[-P], b1 = tb[1 + P], b2 = tb[kWtTS - P], b3 = tb[kWtTS + 1 + P];
-  acc0[0] = fmaf(la, a0, acc0[0]);  acc0[1] = fmaf(lb, b0, acc0[1]);
-  acc1[0] = fmaf(la, a2, acc1[0]);  acc1[1] = fmaf(lb, b2, acc1[1]);
-  acc0[0] = fmaf(ha, a1, acc0[0]);  acc0[1] = fmaf(hb, b1, acc0[1]);
-  acc1[0] = fmaf(ha, a3, acc1[0]);  acc1[1] = fmaf(hb, b3, acc1[1]);
-  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
+// the same for NT tiles at once (NT independent chains per instruction slot)
+template <int W, int P, int NT>
+__device__ __forceinline__ void wt_tapsN(const float* const (&t0)[4], const float (&z)[4], const float (&z2)[4],
+                                         float (&acc0)[4], float (&acc1)[4]) {
+  float lo[NT], hi[NT], a0[NT], a1[NT], a2[NT], a3[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) wt_pair<W, P>(z[u], z2[u], lo[u], hi[u]);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    a0[u] = t0[u][-P]; a1[u] = t0[u][1 + P]; a2[u] = t0[u][kWtTS - P]; a3[u] = t0[u][kWtTS + 1 + P];
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc0[u] = fmaf(lo[u], a0[u], acc0[u]);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc1[u] = fmaf(lo[u], a2[u], acc1[u]);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc0[u] = fmaf(hi[u], a1[u], acc0[u]);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) acc1[u] = fmaf(hi[u], a3[u], acc1[u]);
+  if constexpr (P + 1 < W / 2) wt_tapsN<W, P + 1, NT>(t0, z, z2, acc0, acc1);
 }
 
 // The per-frame phase tables of a chunk (one wavefront, lanes = frames).  (Handing this block of fp64 work to a
@@ -193,7 +199,8 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
 // dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
 // reproduces the split), below the fp32 round-off of the sum itself.
 // NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
-template <int W, int NK, bool ONE_TILE>
+// S4 (experiment, DDSP_EXP_TABLE_S4=1): phase B on four S-wavefronts with four tiles each instead of eight with two
+template <int W, int NK, bool ONE_TILE, bool S4 = false>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
@@ -369,22 +376,23 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const int n_tiles = nfr * tiles_per_frame;
         // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
         // instructions, and a wavefront with a single chain leaves most issue slots empty
+        constexpr int kStride = S4 ? 4 : 8;                    // S-wavefronts sharing phase B
         auto tiles = [&](int tile, auto nt_tag) {
-          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + 8 (NT == 2) or tile alone
-          int q[2], r[2];
-          double cyc[2];
+          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + kStride, ... (NT of them)
+          int q[4], r[4];
+          double cyc[4];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
-            const int tl = tile + 8 * u;
+            const int tl = tile + kStride * u;
             q[u] = ONE_TILE ? tl : tl / tiles_per_frame;
             r[u] = ONE_TILE ? lane : (tl - q[u] * tiles_per_frame) * 64 + lane;
             const double rr = (double)r[u];
             // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
             cyc[u] = t.theta[q[u]] + (rr + 1.0) * (t.w[q[u]] + t.dw[q[u]] * rr);
           }
-          float theta[2], z[2];
-          bool neg[2];
-          const float* t0[2];
+          float theta[4], z[4], z2[4];
+          bool neg[4];
+          const float* t0[4];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             theta[u] = (float)(cyc[u] - floor(cyc[u]));                     // [0, 1]
@@ -393,14 +401,14 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
             const float fl = floorf(pos);
             z[u] = (pos - fl) - 0.5f;
+            z2[u] = z[u] * z[u];
             t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
           }
           if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
-          float acc0[2] = {0.0f, 0.0f}, acc1[2] = {0.0f, 0.0f};
-          if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z[0] * z[0], z[1] * z[1], acc0, acc1);
-          else wt_taps<W, 0>(t0[0], z[0], z[0] * z[0], acc0[0], acc1[0]);
+          float acc0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          wt_tapsN<W, 0, NT>(t0, z, z2, acc0, acc1);
           if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
-          float out[2], w_cur[2], w_next[2], lerp[2];
+          float out[4], w_cur[4], w_next[4], lerp[4];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             lerp[u] = (float)r[u] * inv_hop;
@@ -432,13 +440,18 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             }
           }
           if (tile == rw) DDSP_WT_STAMP(7);                    // envelope, Nyquist corrections done
-          audio[(size_t)(row0 + q[0]) * hop + r[0]] = out[0];            // N == F * hop
-          if constexpr (NT == 2) audio[(size_t)(row0 + q[1]) * hop + r[1]] = out[1];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
         };
-        for (int tile = rw; tile < n_tiles; tile += 16) {
-          if (tile + 8 < n_tiles) tiles(tile, std::integral_constant<int, 2>{});
-          else tiles(tile, std::integral_constant<int, 1>{});
-        }
+        constexpr int kMaxNt = S4 ? 4 : 2;
+        if (!S4 || rw < 4)
+          for (int tile = rw; tile < n_tiles; tile += kStride * kMaxNt) {
+            const int left = (n_tiles - tile + kStride - 1) / kStride;       // tiles of this wavefront still to do
+            if (kMaxNt == 4 && left >= 4) tiles(tile, std::integral_constant<int, 4>{});
+            else if (kMaxNt == 4 && left == 3) tiles(tile, std::integral_constant<int, 3>{});
+            else if (left >= 2) tiles(tile, std::integral_constant<int, 2>{});
+            else tiles(tile, std::integral_constant<int, 1>{});
+          }
       }
       DDSP_WT_STAMP(1);
       if (tick + 2 >= 0 && tick + 2 < n_my) {
@@ -555,9 +568,13 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
+  static const bool s4_env = getenv("DDSP_EXP_TABLE_S4") != nullptr;
 #define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
   do {                                                                                                        \
-    if (p.hop == 64)                                                                                          \
+    if (p.hop == 64 && s4_env)                                                                                \
+      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, ctl_amp, ctl_hd, p);                                                               \
+    else if (p.hop == 64)                                                                                     \
       hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, ctl_amp, ctl_hd, p);                                                               \
     else                                                                                                      \
