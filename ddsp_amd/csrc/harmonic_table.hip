@@ -199,8 +199,13 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
 // dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
 // reproduces the split), below the fp32 round-off of the sum itself.
 // NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
-// S4 (experiment, DDSP_EXP_TABLE_S4=1): phase B on four S-wavefronts with four tiles each instead of eight with two
-template <int W, int NK, bool ONE_TILE, bool S4 = false>
+// NB: how the eight S-wavefronts share their two jobs.  NB == 8: every S-wavefront interpolates two tiles (phase B of
+// chunk tau) and then prepares two rows (phase A of chunk tau + 2), one after the other.  NB < 8: the first NB
+// S-wavefronts only interpolate (ceil(15 / NB) tiles each, carried through the stages together), the other 8 - NB only
+// prepare rows (two per pass) - the two jobs then overlap instead of adding up, and a wavefront with three or four
+// independent tiles fills the issue slots a two-tile wavefront leaves empty (four tiles cost 1.37x two tiles:
+// profiles/r02i_timeline_harm_table_s4_1.txt).
+template <int W, int NK, bool ONE_TILE, int NB = 8>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
@@ -354,7 +359,6 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     float ipsi[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
-    const int arow = rw * 2 + sub;                 // the chunk row this lane works on in phase A
     int bb = first_b, bc = first_c;                // position of the chunk of the next phase B
     int ab = first_b, ac = first_c;                // position of the chunk of the next phase A
 
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const int n_tiles = nfr * tiles_per_frame;
         // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
         // instructions, and a wavefront with a single chain leaves most issue slots empty
-        constexpr int kStride = S4 ? 4 : 8;                    // S-wavefronts sharing phase B
+        constexpr int kStride = NB;                            // S-wavefronts sharing phase B
         auto tiles = [&](int tile, auto nt_tag) {
           constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + kStride, ... (NT of them)
           int q[4], r[4];
@@ -443,29 +447,35 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
 #pragma unroll
           for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
         };
-        constexpr int kMaxNt = S4 ? 4 : 2;
-        if (!S4 || rw < 4)
+        constexpr int kMaxNt = NB >= 8 ? 2 : NB >= 5 ? 3 : 4;
+        if (rw < NB)
           for (int tile = rw; tile < n_tiles; tile += kStride * kMaxNt) {
             const int left = (n_tiles - tile + kStride - 1) / kStride;       // tiles of this wavefront still to do
-            if (kMaxNt == 4 && left >= 4) tiles(tile, std::integral_constant<int, 4>{});
-            else if (kMaxNt == 4 && left == 3) tiles(tile, std::integral_constant<int, 3>{});
+            if (kMaxNt >= 4 && left >= 4) tiles(tile, std::integral_constant<int, 4>{});
+            else if (kMaxNt >= 3 && left >= 3) tiles(tile, std::integral_constant<int, 3>{});
             else if (left >= 2) tiles(tile, std::integral_constant<int, 2>{});
             else tiles(tile, std::integral_constant<int, 1>{});
           }
       }
       DDSP_WT_STAMP(1);
-      if (tick + 2 >= 0 && tick + 2 < n_my) {
+      if (tick + 2 >= 0 && tick + 2 < n_my && (NB == 8 || rw >= NB)) {
         // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+15 (clamped at F-1) -> planes ----
         // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
         // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
         const int j0 = ac * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
-        const int crow = ab * F + j0 + arow;           // this lane's (batch * frame) row, if arow < nfr
+        const int arow_base = ab * F + j0;
         DDSP_WT_ADVANCE(ab, ac);
         const float* raw = raw_all[(tick + 2) & 1];
         _Float16* planes = planes_all[(tick + 2) % 3];
         ChunkTables& t = t_all[(tick + 2) % 3];
-        {
+        // row pairs 0 .. 7 of the chunk, dealt to the phase-A wavefronts (NB == 8: one pair each)
+        constexpr int kNA = NB == 8 ? 8 : 8 - NB;
+        const int ra = NB == 8 ? rw : rw - NB;
+#pragma unroll 1
+        for (int pr = ra; pr < 8; pr += kNA) {
+          const int arow = pr * 2 + sub;               // the chunk row this lane works on
+          const int crow = arow_base + arow;           // this lane's (batch * frame) row, if arow < nfr
           const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
           const float2 fa2 = *reinterpret_cast<const float2*>(raw + arow * kWtRS + 128);
           const float f0r = fa2.x;
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
-        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);
+        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);       // (the last phase-A wavefront: it has the fewest passes)
       }
       DDSP_WT_STAMP(3);
       __syncthreads();
@@ -568,12 +578,15 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-  static const bool s4_env = getenv("DDSP_EXP_TABLE_S4") != nullptr;
+  static const int nb_env = [] { const char* e = getenv("DDSP_EXP_TABLE_NB"); return e ? atoi(e) : 0; }();
+#define DDSP_LAUNCH_TABLE_NB(W, NK, NBV)                                                                       \
+  hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, NBV>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                        audio, ctl_amp, ctl_hd, p)
 #define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
   do {                                                                                                        \
-    if (p.hop == 64 && s4_env)                                                                                \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, p);                                                               \
+    if (p.hop == 64 && nb_env == 4) DDSP_LAUNCH_TABLE_NB(W, NK, 4);                                            \
+    else if (p.hop == 64 && nb_env == 5) DDSP_LAUNCH_TABLE_NB(W, NK, 5);                                       \
+    else if (p.hop == 64 && nb_env == 6) DDSP_LAUNCH_TABLE_NB(W, NK, 6);                                       \
     else if (p.hop == 64)                                                                                     \
       hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, ctl_amp, ctl_hd, p);                                                               \
@@ -586,6 +599,7 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
   else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
+#undef DDSP_LAUNCH_TABLE_NB
   if (p.dbg) {
     static long long host[3 * 64 * 8];
     if (hipStreamSynchronize(st) == hipSuccess &&
