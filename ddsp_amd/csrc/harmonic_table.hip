@@ -114,6 +114,22 @@ __device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, f
   if constexpr (P + 1 < W / 2) wt_taps<W, P + 1>(t0, z, z2, acc0, acc1);
 }
 
+// the same for two tiles at once (two independent chains per instruction slot)
+template <int W, int P>
+__device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const float* __restrict__ tb, float za, float zb,
+                                         float za2, float zb2, float& a00, float& a01, float& a10, float& a11) {
+  float la, ha, lb, hb;
+  wt_pair<W, P>(za, za2, la, ha);
+  wt_pair<W, P>(zb, zb2, lb, hb);
+  const float a0 = ta[-P], a1 = ta[1 + P], a2 = ta[kWtTS - P], a3 = ta[kWtTS + 1 + P];
+  const float b0 = tb[-P], b1 = tb[1 + P], b2 = tb[kWtTS - P], b3 = tb[kWtTS + 1 + P];
+  a00 = fmaf(la, a0, a00);  a01 = fmaf(lb, b0, a01);
+  a10 = fmaf(la, a2, a10);  a11 = fmaf(lb, b2, a11);
+  a00 = fmaf(ha, a1, a00);  a01 = fmaf(hb, b1, a01);
+  a10 = fmaf(ha, a3, a10);  a11 = fmaf(hb, b3, a11);
+  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, a00, a01, a10, a11);
+}
+
 // the same for NT tiles at once (NT independent chains per instruction slot)
 template <int W, int P, int NT>
 __device__ __forceinline__ void wt_tapsN(const float* const (&t0)[4], const float (&z)[4], const float (&z2)[4],
@@ -410,7 +426,9 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           }
           if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
           float acc0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          wt_tapsN<W, 0, NT>(t0, z, z2, acc0, acc1);
+          if constexpr (NT == 1) wt_taps<W, 0>(t0[0], z[0], z2[0], acc0[0], acc1[0]);
+          else if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z2[0], z2[1], acc0[0], acc0[1], acc1[0], acc1[1]);
+          else wt_tapsN<W, 0, NT>(t0, z, z2, acc0, acc1);
           if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
           float out[4], w_cur[4], w_next[4], lerp[4];
 #pragma unroll
@@ -469,57 +487,88 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const float* raw = raw_all[(tick + 2) & 1];
         _Float16* planes = planes_all[(tick + 2) % 3];
         ChunkTables& t = t_all[(tick + 2) % 3];
-        // row pairs 0 .. 7 of the chunk, dealt to the phase-A wavefronts (NB == 8: one pair each)
+        // row pairs 0 .. 7 of the chunk, dealt to the phase-A wavefronts (NB == 8: one pair each).  A wavefront with
+        // several pairs carries two of them through the stages together: a pass is one long chain of dependent
+        // instructions (LDS read -> exp_sigmoid -> row sum by DPP -> rcp -> fp16 split -> LDS write), ~1000 clocks of
+        // which few are issue slots (profiles/r02j_timeline_harm_table_nb_5.txt)
         constexpr int kNA = NB == 8 ? 8 : 8 - NB;
         const int ra = NB == 8 ? rw : rw - NB;
+        auto rows = [&](int pr0, auto np_tag) {
+          constexpr int NP = decltype(np_tag)::value;          // row pairs pr0, pr0 + kNA (NP == 2) or pr0 alone
+          int arow[2];
+          float4 xv[2];
+          float2 fa2[2];
+#pragma unroll
+          for (int v = 0; v < NP; ++v) {
+            arow[v] = (pr0 + kNA * v) * 2 + sub;       // the chunk row this lane works on
+            xv[v] = *reinterpret_cast<const float4*>(raw + arow[v] * kWtRS + 4 * kq);
+            fa2[v] = *reinterpret_cast<const float2*>(raw + arow[v] * kWtRS + 128);
+          }
+          float x[2][4], part[2];
+#pragma unroll
+          for (int v = 0; v < NP; ++v) {
+            const float f0r = fa2[v].x;
+            x[v][0] = xv[v].x; x[v][1] = xv[v].y; x[v][2] = xv[v].z; x[v][3] = xv[v].w;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              x[v][u] = exp_sigmoid_fast(x[v][u], kLog10, 2.0f, 1e-7f);
+              if (!live || f0r * (float)(4 * kq + u + 1) >= p.nyquist) x[v][u] = 0.0f;
+            }
+            part[v] = (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+          }
+#pragma unroll
+          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0xB1, 0xF>(part[v]);      // quad_perm [1,0,3,2]
+#pragma unroll
+          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x4E, 0xF>(part[v]);      // quad_perm [2,3,0,1]
+#pragma unroll
+          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x141, 0xF>(part[v]);     // row_half_mirror
+#pragma unroll
+          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x140, 0xF>(part[v]);     // row_mirror: every lane holds its 16-lane row's sum
+#pragma unroll
+          for (int v = 0; v < NP; ++v) {           // + the other row of the pair, through SGPRs (no LDS round trip)
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 16));
+            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 32));
+            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 48));
+            part[v] = sub ? s2 + s3 : s0 + s1;
+          }
+#pragma unroll
+          for (int v = 0; v < NP; ++v) {
+            const int crow = arow_base + arow[v];      // this lane's (batch * frame) row, if arow < nfr
+            const float inv = __builtin_amdgcn_rcpf(part[v] == 0.0f ? 1e-7f : part[v]);
+            const float a_ctl = exp_sigmoid_fast(fa2[v].y, kLog10, 2.0f, 1e-7f);
+            const float a = a_ctl * inv;
+            // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
+            // belongs to the next chunk
+            if (ctl_hd != nullptr && arow[v] < nfr) {
+              if (live)
+                reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] =
+                    make_float4(x[v][0] * inv, x[v][1] * inv, x[v][2] * inv, x[v][3] * inv);
+              if (kq == 0) ctl_amp[crow] = a_ctl;
+            }
+            // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
+            // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
+            float c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = a * x[v][u] * ipsi[u];
+            _Float16* dst = planes + arow[v] * kWtPS + 2 * kq;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
+              const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
+              const h16x2 lo = __builtin_amdgcn_cvt_pkrtz((c[par] - (float)hi[0]) * kWtLoScale,
+                                                          (c[par + 2] - (float)hi[1]) * kWtLoScale);
+              *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
+              *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
+            }
+          }
+        };
+        if constexpr (NB == 8) {
+          rows(ra, std::integral_constant<int, 1>{});
+        } else {
 #pragma unroll 1
-        for (int pr = ra; pr < 8; pr += kNA) {
-          const int arow = pr * 2 + sub;               // the chunk row this lane works on
-          const int crow = arow_base + arow;           // this lane's (batch * frame) row, if arow < nfr
-          const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
-          const float2 fa2 = *reinterpret_cast<const float2*>(raw + arow * kWtRS + 128);
-          const float f0r = fa2.x;
-          float x[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            x[u] = exp_sigmoid_fast(x[u], kLog10, 2.0f, 1e-7f);
-            if (!live || f0r * (float)(4 * kq + u + 1) >= p.nyquist) x[u] = 0.0f;
-          }
-          float part = (x[0] + x[1]) + (x[2] + x[3]);
-          part += dpp_mov0<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]
-          part += dpp_mov0<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]
-          part += dpp_mov0<0x141, 0xF>(part);     // row_half_mirror
-          part += dpp_mov0<0x140, 0xF>(part);     // row_mirror: every lane holds its 16-lane row's sum
-          {                                        // + the other row of the pair, through SGPRs (no LDS round trip)
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
-            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
-            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
-            part = sub ? s2 + s3 : s0 + s1;
-          }
-          const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
-          const float a_ctl = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f);
-          const float a = a_ctl * inv;
-          // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
-          // belongs to the next chunk
-          if (ctl_hd != nullptr && arow < nfr) {
-            if (live)
-              reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv);
-            if (kq == 0) ctl_amp[crow] = a_ctl;
-          }
-          // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
-          // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
-          float c[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) c[u] = a * x[u] * ipsi[u];
-          _Float16* dst = planes + arow * kWtPS + 2 * kq;
-#pragma unroll
-          for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
-            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
-            const h16x2 lo = __builtin_amdgcn_cvt_pkrtz((c[par] - (float)hi[0]) * kWtLoScale,
-                                                        (c[par + 2] - (float)hi[1]) * kWtLoScale);
-            *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
-            *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
+          for (int pr = ra; pr < 8; pr += 2 * kNA) {
+            if (pr + kNA < 8) rows(pr, std::integral_constant<int, 2>{});
+            else rows(pr, std::integral_constant<int, 1>{});
           }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
