@@ -117,39 +117,17 @@ __device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, f
 // the same for two tiles at once (two independent chains per instruction slot)
 template <int W, int P>
 __device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const float* __restrict__ tb, float za, float zb,
-                                         float za2, float zb2, float& a00, float& a01, float& a10, float& a11) {
+                                         float za2, float zb2, float (&acc0)[2], float (&acc1)[2]) {
   float la, ha, lb, hb;
   wt_pair<W, P>(za, za2, la, ha);
   wt_pair<W, P>(zb, zb2, lb, hb);
   const float a0 = ta[-P], a1 = ta[1 + P], a2 = ta[kWtTS - P], a3 = ta[kWtTS + 1 + P];
   const float b0 = tb[-P], b1 = tb[1 + P], b2 = tb[kWtTS - P], b3 = tb[kWtTS + 1 + P];
-  a00 = fmaf(la, a0, a00);  a01 = fmaf(lb, b0, a01);
-  a10 = fmaf(la, a2, a10);  a11 = fmaf(lb, b2, a11);
-  a00 = fmaf(ha, a1, a00);  a01 = fmaf(hb, b1, a01);
-  a10 = fmaf(ha, a3, a10);  a11 = fmaf(hb, b3, a11);
-  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, a00, a01, a10, a11);
-}
-
-// the same for NT tiles at once (NT independent chains per instruction slot)
-template <int W, int P, int NT>
-__device__ __forceinline__ void wt_tapsN(const float* const (&t0)[4], const float (&z)[4], const float (&z2)[4],
-                                         float (&acc0)[4], float (&acc1)[4]) {
-  float lo[NT], hi[NT], a0[NT], a1[NT], a2[NT], a3[NT];
-#pragma unroll
-  for (int u = 0; u < NT; ++u) wt_pair<W, P>(z[u], z2[u], lo[u], hi[u]);
-#pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    a0[u] = t0[u][-P]; a1[u] = t0[u][1 + P]; a2[u] = t0[u][kWtTS - P]; a3[u] = t0[u][kWtTS + 1 + P];
-  }
-#pragma unroll
-  for (int u = 0; u < NT; ++u) acc0[u] = fmaf(lo[u], a0[u], acc0[u]);
-#pragma unroll
-  for (int u = 0; u < NT; ++u) acc1[u] = fmaf(lo[u], a2[u], acc1[u]);
-#pragma unroll
-  for (int u = 0; u < NT; ++u) acc0[u] = fmaf(hi[u], a1[u], acc0[u]);
-#pragma unroll
-  for (int u = 0; u < NT; ++u) acc1[u] = fmaf(hi[u], a3[u], acc1[u]);
-  if constexpr (P + 1 < W / 2) wt_tapsN<W, P + 1, NT>(t0, z, z2, acc0, acc1);
+  acc0[0] = fmaf(la, a0, acc0[0]);  acc0[1] = fmaf(lb, b0, acc0[1]);
+  acc1[0] = fmaf(la, a2, acc1[0]);  acc1[1] = fmaf(lb, b2, acc1[1]);
+  acc0[0] = fmaf(ha, a1, acc0[0]);  acc0[1] = fmaf(hb, b1, acc0[1]);
+  acc1[0] = fmaf(ha, a3, acc1[0]);  acc1[1] = fmaf(hb, b3, acc1[1]);
+  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
 }
 
 // The per-frame phase tables of a chunk (one wavefront, lanes = frames).  (Handing this block of fp64 work to a
@@ -215,13 +193,7 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
 // dropped lo.lo term and the roundings of the lo parts leave an error <= 5e-8 sum_k |a_k| (tests/wavetable_model.py
 // reproduces the split), below the fp32 round-off of the sum itself.
 // NK: k-steps of 32 per parity (ceil(K/2) <= 32 NK); ONE_TILE: hop == 64
-// NB: how the eight S-wavefronts share their two jobs.  NB == 8: every S-wavefront interpolates two tiles (phase B of
-// chunk tau) and then prepares two rows (phase A of chunk tau + 2), one after the other.  NB < 8: the first NB
-// S-wavefronts only interpolate (ceil(15 / NB) tiles each, carried through the stages together), the other 8 - NB only
-// prepare rows (two per pass) - the two jobs then overlap instead of adding up, and a wavefront with three or four
-// independent tiles fills the issue slots a two-tile wavefront leaves empty (four tiles cost 1.37x two tiles:
-// profiles/r02i_timeline_harm_table_s4_1.txt).
-template <int W, int NK, bool ONE_TILE, int NB = 8>
+template <int W, int NK, bool ONE_TILE>
 __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, TableArgs p) {
@@ -375,6 +347,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     float ipsi[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
+    const int arow = rw * 2 + sub;                 // the chunk row this lane works on in phase A
     int bb = first_b, bc = first_c;                // position of the chunk of the next phase B
     int ab = first_b, ac = first_c;                // position of the chunk of the next phase A
 
@@ -396,23 +369,22 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const int n_tiles = nfr * tiles_per_frame;
         // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
         // instructions, and a wavefront with a single chain leaves most issue slots empty
-        constexpr int kStride = NB;                            // S-wavefronts sharing phase B
         auto tiles = [&](int tile, auto nt_tag) {
-          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + kStride, ... (NT of them)
-          int q[4], r[4];
-          double cyc[4];
+          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + 8 (NT == 2) or tile alone
+          int q[2], r[2];
+          double cyc[2];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
-            const int tl = tile + kStride * u;
+            const int tl = tile + 8 * u;
             q[u] = ONE_TILE ? tl : tl / tiles_per_frame;
             r[u] = ONE_TILE ? lane : (tl - q[u] * tiles_per_frame) * 64 + lane;
             const double rr = (double)r[u];
             // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
             cyc[u] = t.theta[q[u]] + (rr + 1.0) * (t.w[q[u]] + t.dw[q[u]] * rr);
           }
-          float theta[4], z[4], z2[4];
-          bool neg[4];
-          const float* t0[4];
+          float theta[2], z[2];
+          bool neg[2];
+          const float* t0[2];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             theta[u] = (float)(cyc[u] - floor(cyc[u]));                     // [0, 1]
@@ -421,16 +393,14 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
             const float fl = floorf(pos);
             z[u] = (pos - fl) - 0.5f;
-            z2[u] = z[u] * z[u];
             t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
           }
           if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
-          float acc0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if constexpr (NT == 1) wt_taps<W, 0>(t0[0], z[0], z2[0], acc0[0], acc1[0]);
-          else if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z2[0], z2[1], acc0[0], acc0[1], acc1[0], acc1[1]);
-          else wt_tapsN<W, 0, NT>(t0, z, z2, acc0, acc1);
+          float acc0[2] = {0.0f, 0.0f}, acc1[2] = {0.0f, 0.0f};
+          if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z[0] * z[0], z[1] * z[1], acc0, acc1);
+          else wt_taps<W, 0>(t0[0], z[0], z[0] * z[0], acc0[0], acc1[0]);
           if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
-          float out[4], w_cur[4], w_next[4], lerp[4];
+          float out[2], w_cur[2], w_next[2], lerp[2];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             lerp[u] = (float)r[u] * inv_hop;
@@ -462,117 +432,75 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             }
           }
           if (tile == rw) DDSP_WT_STAMP(7);                    // envelope, Nyquist corrections done
-#pragma unroll
-          for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
+          audio[(size_t)(row0 + q[0]) * hop + r[0]] = out[0];            // N == F * hop
+          if constexpr (NT == 2) audio[(size_t)(row0 + q[1]) * hop + r[1]] = out[1];
         };
-        constexpr int kMaxNt = NB >= 8 ? 2 : NB >= 5 ? 3 : 4;
-        if (rw < NB)
-          for (int tile = rw; tile < n_tiles; tile += kStride * kMaxNt) {
-            const int left = (n_tiles - tile + kStride - 1) / kStride;       // tiles of this wavefront still to do
-            if (kMaxNt >= 4 && left >= 4) tiles(tile, std::integral_constant<int, 4>{});
-            else if (kMaxNt >= 3 && left >= 3) tiles(tile, std::integral_constant<int, 3>{});
-            else if (left >= 2) tiles(tile, std::integral_constant<int, 2>{});
-            else tiles(tile, std::integral_constant<int, 1>{});
-          }
+        for (int tile = rw; tile < n_tiles; tile += 16) {
+          if (tile + 8 < n_tiles) tiles(tile, std::integral_constant<int, 2>{});
+          else tiles(tile, std::integral_constant<int, 1>{});
+        }
       }
       DDSP_WT_STAMP(1);
-      if (tick + 2 >= 0 && tick + 2 < n_my && (NB == 8 || rw >= NB)) {
+      if (tick + 2 >= 0 && tick + 2 < n_my) {
         // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+15 (clamped at F-1) -> planes ----
         // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
         // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
         const int j0 = ac * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
-        const int arow_base = ab * F + j0;
+        const int crow = ab * F + j0 + arow;           // this lane's (batch * frame) row, if arow < nfr
         DDSP_WT_ADVANCE(ab, ac);
         const float* raw = raw_all[(tick + 2) & 1];
         _Float16* planes = planes_all[(tick + 2) % 3];
         ChunkTables& t = t_all[(tick + 2) % 3];
-        // row pairs 0 .. 7 of the chunk, dealt to the phase-A wavefronts (NB == 8: one pair each).  A wavefront with
-        // several pairs carries two of them through the stages together: a pass is one long chain of dependent
-        // instructions (LDS read -> exp_sigmoid -> row sum by DPP -> rcp -> fp16 split -> LDS write), ~1000 clocks of
-        // which few are issue slots (profiles/r02j_timeline_harm_table_nb_5.txt)
-        constexpr int kNA = NB == 8 ? 8 : 8 - NB;
-        const int ra = NB == 8 ? rw : rw - NB;
-        auto rows = [&](int pr0, auto np_tag) {
-          constexpr int NP = decltype(np_tag)::value;          // row pairs pr0, pr0 + kNA (NP == 2) or pr0 alone
-          int arow[2];
-          float4 xv[2];
-          float2 fa2[2];
+        {
+          const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
+          const float2 fa2 = *reinterpret_cast<const float2*>(raw + arow * kWtRS + 128);
+          const float f0r = fa2.x;
+          float x[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-          for (int v = 0; v < NP; ++v) {
-            arow[v] = (pr0 + kNA * v) * 2 + sub;       // the chunk row this lane works on
-            xv[v] = *reinterpret_cast<const float4*>(raw + arow[v] * kWtRS + 4 * kq);
-            fa2[v] = *reinterpret_cast<const float2*>(raw + arow[v] * kWtRS + 128);
+          for (int u = 0; u < 4; ++u) {
+            x[u] = exp_sigmoid_fast(x[u], kLog10, 2.0f, 1e-7f);
+            if (!live || f0r * (float)(4 * kq + u + 1) >= p.nyquist) x[u] = 0.0f;
           }
-          float x[2][4], part[2];
-#pragma unroll
-          for (int v = 0; v < NP; ++v) {
-            const float f0r = fa2[v].x;
-            x[v][0] = xv[v].x; x[v][1] = xv[v].y; x[v][2] = xv[v].z; x[v][3] = xv[v].w;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              x[v][u] = exp_sigmoid_fast(x[v][u], kLog10, 2.0f, 1e-7f);
-              if (!live || f0r * (float)(4 * kq + u + 1) >= p.nyquist) x[v][u] = 0.0f;
-            }
-            part[v] = (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+          float part = (x[0] + x[1]) + (x[2] + x[3]);
+          part += dpp_mov0<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]
+          part += dpp_mov0<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]
+          part += dpp_mov0<0x141, 0xF>(part);     // row_half_mirror
+          part += dpp_mov0<0x140, 0xF>(part);     // row_mirror: every lane holds its 16-lane row's sum
+          {                                        // + the other row of the pair, through SGPRs (no LDS round trip)
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
+            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
+            part = sub ? s2 + s3 : s0 + s1;
           }
-#pragma unroll
-          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0xB1, 0xF>(part[v]);      // quad_perm [1,0,3,2]
-#pragma unroll
-          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x4E, 0xF>(part[v]);      // quad_perm [2,3,0,1]
-#pragma unroll
-          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x141, 0xF>(part[v]);     // row_half_mirror
-#pragma unroll
-          for (int v = 0; v < NP; ++v) part[v] += dpp_mov0<0x140, 0xF>(part[v]);     // row_mirror: every lane holds its 16-lane row's sum
-#pragma unroll
-          for (int v = 0; v < NP; ++v) {           // + the other row of the pair, through SGPRs (no LDS round trip)
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 16));
-            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 32));
-            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[v]), 48));
-            part[v] = sub ? s2 + s3 : s0 + s1;
+          const float inv = __builtin_amdgcn_rcpf(part == 0.0f ? 1e-7f : part);
+          const float a_ctl = exp_sigmoid_fast(fa2.y, kLog10, 2.0f, 1e-7f);
+          const float a = a_ctl * inv;
+          // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
+          // belongs to the next chunk
+          if (ctl_hd != nullptr && arow < nfr) {
+            if (live)
+              reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv);
+            if (kq == 0) ctl_amp[crow] = a_ctl;
           }
+          // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
+          // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
+          float c[4];
 #pragma unroll
-          for (int v = 0; v < NP; ++v) {
-            const int crow = arow_base + arow[v];      // this lane's (batch * frame) row, if arow < nfr
-            const float inv = __builtin_amdgcn_rcpf(part[v] == 0.0f ? 1e-7f : part[v]);
-            const float a_ctl = exp_sigmoid_fast(fa2[v].y, kLog10, 2.0f, 1e-7f);
-            const float a = a_ctl * inv;
-            // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
-            // belongs to the next chunk
-            if (ctl_hd != nullptr && arow[v] < nfr) {
-              if (live)
-                reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] =
-                    make_float4(x[v][0] * inv, x[v][1] * inv, x[v][2] * inv, x[v][3] * inv);
-              if (kq == 0) ctl_amp[crow] = a_ctl;
-            }
-            // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
-            // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
-            float c[4];
+          for (int u = 0; u < 4; ++u) c[u] = a * x[u] * ipsi[u];
+          _Float16* dst = planes + arow * kWtPS + 2 * kq;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = a * x[v][u] * ipsi[u];
-            _Float16* dst = planes + arow[v] * kWtPS + 2 * kq;
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
-              const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
-              const h16x2 lo = __builtin_amdgcn_cvt_pkrtz((c[par] - (float)hi[0]) * kWtLoScale,
-                                                          (c[par + 2] - (float)hi[1]) * kWtLoScale);
-              *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
-              *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
-            }
-          }
-        };
-        if constexpr (NB == 8) {
-          rows(ra, std::integral_constant<int, 1>{});
-        } else {
-#pragma unroll 1
-          for (int pr = ra; pr < 8; pr += 2 * kNA) {
-            if (pr + kNA < 8) rows(pr, std::integral_constant<int, 2>{});
-            else rows(pr, std::integral_constant<int, 1>{});
+          for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
+            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
+            const h16x2 lo = __builtin_amdgcn_cvt_pkrtz((c[par] - (float)hi[0]) * kWtLoScale,
+                                                        (c[par + 2] - (float)hi[1]) * kWtLoScale);
+            *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
+            *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
           }
         }
         // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
-        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);       // (the last phase-A wavefront: it has the fewest passes)
+        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);
       }
       DDSP_WT_STAMP(3);
       __syncthreads();
@@ -627,16 +555,9 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   }
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-  static const int nb_env = [] { const char* e = getenv("DDSP_EXP_TABLE_NB"); return e ? atoi(e) : 0; }();
-#define DDSP_LAUNCH_TABLE_NB(W, NK, NBV)                                                                       \
-  hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true, NBV>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                        audio, ctl_amp, ctl_hd, p)
 #define DDSP_LAUNCH_TABLE(W, NK)                                                                              \
   do {                                                                                                        \
-    if (p.hop == 64 && nb_env == 4) DDSP_LAUNCH_TABLE_NB(W, NK, 4);                                            \
-    else if (p.hop == 64 && nb_env == 5) DDSP_LAUNCH_TABLE_NB(W, NK, 5);                                       \
-    else if (p.hop == 64 && nb_env == 6) DDSP_LAUNCH_TABLE_NB(W, NK, 6);                                       \
-    else if (p.hop == 64)                                                                                     \
+    if (p.hop == 64)                                                                                          \
       hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                             audio, ctl_amp, ctl_hd, p);                                                               \
     else                                                                                                      \
@@ -648,7 +569,6 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
   else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
-#undef DDSP_LAUNCH_TABLE_NB
   if (p.dbg) {
     static long long host[3 * 64 * 8];
     if (hipStreamSynchronize(st) == hipSuccess &&
