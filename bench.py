@@ -94,7 +94,6 @@ def parse_args(argv=None):
   ap.add_argument('--north-star-batch', type=int, default=128)
   ap.add_argument('--harm-kernel', default='auto', help="Harmonic.kernel ('auto', 'direct', ...)")
   ap.add_argument('--noise-kernel', default='auto', help="FilteredNoise.kernel ('auto', ...)")
-  ap.add_argument('--noise-ir', default='auto', help='FilteredNoise.ir_design')
   ap.add_argument('--allgather', action='store_true',
                   help='also time an RCCL all_gather of the audio (reported separately)')
   ap.add_argument('--dry-run', action='store_true',
@@ -216,8 +215,7 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
           'no collective' % world,
           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
                      else 'one stream, back to back',
-          'kernel_variants': {'harmonic': a.harm_kernel, 'filtered_noise': a.noise_kernel,
-                              'noise_ir_design': a.noise_ir}},
+          'kernel_variants': {'harmonic': a.harm_kernel, 'filtered_noise': a.noise_kernel}},
       'per_gpu_value': value / world,
       'roofline': dict(roof, **{
           'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'event_stride': a.event_stride,
@@ -387,8 +385,6 @@ def main(argv=None):
       harmonic.kernel = a.harm_kernel                          # instance attributes: the defaults unless asked
       if a.noise_kernel != 'auto':
         fnoise.kernel = a.noise_kernel
-      if a.noise_ir != 'auto':
-        fnoise.ir_design = a.noise_ir
 
       # The two Processor calls of a step are independent (nothing on this path joins them; the
       # reference's Add would): at small batches Harmonic and FilteredNoise are issued on two free-running HIP

@@ -86,8 +86,6 @@ HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
 NOISE_SCALE_EXP_SIGMOID = 0x1
-NOISE_IR_MATRIX_CORES = 0x2
-NOISE_IR_FROM_REGISTERS = 0x4
 NOISE_FIR_VECTOR_ALU = 0x8
 DECAY_SCALE_EXP_SIGMOID = 0x1
 RESAMPLE_METHODS = {'nearest': 0, 'linear': 1, 'cubic': 2, 'window': 3}

@@ -477,14 +477,13 @@ __device__ __forceinline__ void fn_split8(const float (&v)[8], fn_f16x8& hi, fn_
 }
 
 // NW wavefronts per block: 4, or 8 (the FIR's tap range split in two halves).
-// IRMF (experimental; flag DDSP_NOISE_IR_MATRIX_CORES or DDSP_EXP_NOISE_IR_MFMA=1): the IR design's cosine transform - a [32 x 32] . [32 x 64 rows]
-// product per parity with a constant left factor - on the fp16 matrix cores with both factors split hi + lo / 2048
-// (three products, fp32 accumulation), instead of lanes = frames on the vector ALUs.
-// IRMF == 2 (flag DDSP_NOISE_IR_FROM_REGISTERS on top, or DDSP_EXP_NOISE_IR_MFMA=2) additionally drops the LDS
-// staging of the magnitudes: every lane loads the 16 bins of its B-fragments straight from HBM, the noise tile is
-// generated while those loads are in flight, and exp_sigmoid runs on the registers - one barrier and one LDS round
-// trip less on the block's latency chain, and the Philox stage moves under the HBM latency.
-template <bool GEN_NOISE, int NW, int IRMF = 0>
+// The IR design's cosine transform - a [32 x 32] . [32 x 64 rows] product per parity with a constant left factor -
+// runs on the fp16 matrix cores with both factors split hi + lo / 2048 (three products, fp32 accumulation), and the
+// magnitudes go from HBM straight into the B-fragments: every lane loads the 16 bins of its fragments, the noise tile
+// is generated while those loads are in flight, and exp_sigmoid runs on the registers.  (Round 2 timed three designs
+// at batch 32 / 128: lanes = frames on the vector ALUs 23.6 / 56.6 us, matrix cores behind an LDS staging of the
+// magnitudes 21.5 / 52.3, this one 19.6 / 47.3 - profiles/r02a_noise_ir_variants.json; the other two are gone.)
+template <bool GEN_NOISE, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/,
@@ -511,14 +510,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   const int do_scale = p.scale & 1;
   DDSP_STAMP();
 
-  // IRMF: this wavefront's share of the constant factor in MFMA A-operand layout, fetched before anything else
-  // so that the loads fly under stage 1.  Wavefront w designs the taps of rows 16 (w & 3) .. + 15; with 4
+  // this wavefront's share of the constant factor in MFMA A-operand layout, fetched before anything else.  Wavefront w designs the taps of rows 16 (w & 3) .. + 15; with 4
   // wavefronts it takes both tap tiles n = 0..15 and 16..31, with 8 the tile w >> 2.  Element e of lane
   // (i = lane & 15, g = lane >> 4): coefficient of tap n = 16 mt + i and bin 2 k' (+ 1), k' = 8 g + e.
   constexpr int kMt = (NW == 8) ? 1 : 2;
   const int mt0 = (NW == 8) ? (wave >> 2) : 0;
   fn_f16x8 ae_hi[kMt], ae_lo[kMt], ao_hi[kMt], ao_lo[kMt];
-  if constexpr (IRMF != 0) {
+  {
 #pragma unroll
     for (int q = 0; q < kMt; ++q) {
       const float* __restrict__ crow = kIr65.c + (16 * (mt0 + q) + (lane & 15)) * kIrRowStride + 8 * (lane >> 4);
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
     }
   }
 
-  // IRMF == 2: the 16 bins of this lane's B-fragments (row = 16 (wave & 3) + (lane & 15), bins 16 (lane >> 4) .. + 15)
+  // the 16 bins of this lane's B-fragments (row = 16 (wave & 3) + (lane & 15), bins 16 (lane >> 4) .. + 15)
   // and bin 64 of that row, straight from HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards
   // (unconditional loads: nothing waits on them until the noise tile below is done)
   struct __attribute__((packed, aligned(4))) U4f { float x, y, z, w; };      // a 16-byte load from a 4-byte aligned address
@@ -539,56 +537,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
   const int rrow = 16 * (wave & 3) + (lane & 15);
   const int rfr = f_first + rrow;
   const bool rvalid = rfr >= 0 && rfr < p.F;
-  if constexpr (IRMF == 2) {
+  {
     const float* __restrict__ src = mag + ((size_t)b * p.F + (rvalid ? rfr : 0)) * 65;
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const U4f*>(src + 16 * (lane >> 4) + 4 * c4);
     r_last = src[64];
   }
 
-  // ---- 1. magnitude rows of frames J0-2 .. J0+61 -------------------------------------------------
-  // The 64 rows are one contiguous span of 4160 floats in HBM: 16-byte loads from the span's
-  // aligned-down start (vector-memory instruction issue, not bandwidth, is the cost here).
-  if constexpr (IRMF != 2) {
-    const long row_first = (long)b * p.F + f_first;                 // may be < b*F for the first tile
-    const long e0 = row_first * 65;                                 // first element wanted
-    const long lo = (long)b * p.F * 65, hi = ((long)b + 1) * p.F * 65;   // this batch row's elements
-    const long a0 = e0 & ~3L;                                       // aligned-down start (may be < 0)
-    const long total = ((long)p.F * 65) * (long)gridDim.y;          // elements in the whole tensor
-    for (int i4 = tid; i4 < (64 * 65 + 3) / 4 + 1; i4 += 64 * NW) {
-      const long ea = a0 + 4L * i4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ea >= 0 && ea + 3 < total) v = *reinterpret_cast<const float4*>(mag + ea);
-      else if (ea + 3 >= 0 && ea < total) {
-        if (ea >= 0 && ea < total) v.x = mag[ea];
-        if (ea + 1 >= 0 && ea + 1 < total) v.y = mag[ea + 1];
-        if (ea + 2 >= 0 && ea + 2 < total) v.z = mag[ea + 2];
-        if (ea + 3 >= 0 && ea + 3 < total) v.w = mag[ea + 3];
-      }
-      const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long e = ea + u;
-        const int i = (int)(e - e0);                                // index into the 64x65 stage
-        if (i >= 0 && i < 64 * 65) {
-          float y = 0.0f;
-          if (e >= lo && e < hi) {                                  // frame inside [0,F) of this row
-            y = do_scale ? exp_sigmoid_fast(x[u] + p.bias, kLog10, 2.0f, 1e-7f) : x[u];
-            if (ctl_out) {                                          // written by the owning tile only
-              const int fr = f_first + (int)(((float)i + 0.5f) * (1.0f / 65.0f));
-              if (fr >= own_lo && fr < own_hi) ctl_out[e] = y;
-            }
-          }
-          s_u[i] = y;
-        }
-      }
-    }
-  }
-  if constexpr (IRMF != 2) __syncthreads();
-  DDSP_STAMP();    // 1: magnitudes staged
-  // ---- 2. IR design ------------------------------------------------------------------------------------
-  if constexpr (IRMF == 2) {
-    // ---- 3'. the noise tile first: it depends on nothing that is in flight ---------------------------------
+  DDSP_STAMP();    // 1: loads issued
+  {
+    // ---- the noise tile first: it depends on nothing that is in flight ---------------------------------
     for (int qd = tid; qd < kFnXLen / 4; qd += 64 * NW) {
       const int i = z0 - 128 + 4 * qd;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -614,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       }
       *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
     }
-    // ---- 2'. controls in registers, fragments, products -----------------------------------------------------
+    // ---- IR design: controls in registers, fragments, products -----------------------------------------------------
     const int mg = lane >> 4;
     float y[16];
 #pragma unroll
@@ -684,126 +642,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
         hrow[0] = 0.0f;                                                // h[0] = Hann(128)[0] * hz[-64] = 0
       }
     }
-  } else if constexpr (IRMF == 1) {
-    // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1] for n = 0..31 as matrix products: B holds the
-    // magnitudes of this wavefront's 16 rows (element e of lane (j = lane & 15, g): bin 2 (8 g + e) (+ 1) of
-    // row j), D[n = 4 g + r][row j] comes back four taps per lane.  Bin 64 (the 33rd even bin) is a rank-1
-    // update; tap 32 (cos(pi m / 2): odd bins drop out, even bins alternate in sign) and tap 0 are done by
-    // wavefront 0 with lanes = rows.
-    const int mi = lane & 15, mg = lane >> 4;
-    const int row = 16 * (wave & 3) + mi;
-    const float* __restrict__ mrow = s_u + row * 65 + 16 * mg;
-    float ve[8], vo[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ve[e] = mrow[2 * e]; vo[e] = mrow[2 * e + 1]; }
-    fn_f16x8 be_hi, be_lo, bo_hi, bo_lo;
-    fn_split8(ve, be_hi, be_lo);
-    fn_split8(vo, bo_hi, bo_lo);
-    const float m_last = s_u[row * 65 + 64];
-    float* __restrict__ hrow = s_h + row * kTapStride;
-#pragma unroll
-    for (int q = 0; q < kMt; ++q) {
-      const fn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      fn_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_hi, zero, 0, 0, 0);
-      fn_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_hi, zero, 0, 0, 0);
-      fn_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_hi[q], be_lo, zero, 0, 0, 0);
-      fn_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_hi[q], bo_lo, zero, 0, 0, 0);
-      ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(ae_lo[q], be_hi, ex, 0, 0, 0);
-      ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao_lo[q], bo_hi, ox, 0, 0, 0);
-      const fn_f32x4 ev = ea + ex * (1.0f / kFnLoScale), ov = oa + ox * (1.0f / kFnLoScale);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = 16 * (mt0 + q) + 4 * mg + r;                    // 0 .. 31
-        const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);
-        const float o = ov[r];
-        const float g0 = kIr65.win[n] * (e + o);                       // g[n]:    taps 64+n and 64-n
-        hrow[64 + n] = g0;
-        if (n >= 1) {
-          hrow[64 - n] = g0;
-          const float g1 = kIr65.win[64 - n] * (e - o);                // g[64-n]: taps 128-n and n
-          hrow[128 - n] = g1;
-          hrow[n] = g1;
-        }
-      }
-    }
-    if (wave == 0) {                                                   // lanes = rows
-      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride;
-      float e0 = 0.0f, e1 = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 32; i += 2) {
-        e0 = fmaf(c32[i], s_u[lane * 65 + 2 * i], e0);
-        e1 = fmaf(c32[i + 1], s_u[lane * 65 + 2 * i + 2], e1);
-      }
-      const float e = fmaf(c32[32], s_u[lane * 65 + 64], e0 + e1);
-      const float g0 = kIr65.win[32] * e;                               // o(32) = 0: cos(pi m / 2) vanishes for odd m
-      s_h[lane * kTapStride + 96] = g0;
-      s_h[lane * kTapStride + 32] = g0;
-      s_h[lane * kTapStride] = 0.0f;                                   // h[0] = Hann(128)[0] * hz[-64] = 0
-    }
-  } else {
-    // magnitudes in 64-bit VGPR pairs: the coefficients of a pair are adjacent SGPRs, so the inner
-    // products run as v_pk_fma_f32 with an SGPR-pair operand (2.9 ns per two FMAs against 2 x 1.9 ns,
-    // tools/microbench4) and as two independent partial sums each
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 me2[16], mo2[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      me2[i] = (f2){s_u[lane * 65 + 4 * i], s_u[lane * 65 + 4 * i + 2]};        // even bins 2(2i), 2(2i+1)
-      mo2[i] = (f2){s_u[lane * 65 + 4 * i + 1], s_u[lane * 65 + 4 * i + 3]};    // odd bins
-    }
-    const float me_last = s_u[lane * 65 + 64];
-    float* __restrict__ hrow = s_h + lane * kTapStride;
-    if (wave == 0) hrow[0] = 0.0f;                     // h[0] = Hann(128)[0] * hz[-64] = 0
-    for (int n = __builtin_amdgcn_readfirstlane(wave); n <= 32; n += NW) {
-      const float* __restrict__ ce = kIr65.c + n * kIrRowStride;
-      const float* __restrict__ co = ce + 40;
-      f2 ea = {0.0f, 0.0f}, oa = {0.0f, 0.0f};
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        ea = __builtin_elementwise_fma((f2){ce[2 * i], ce[2 * i + 1]}, me2[i], ea);
-        oa = __builtin_elementwise_fma((f2){co[2 * i], co[2 * i + 1]}, mo2[i], oa);
-      }
-      const float e = fmaf(me_last, ce[32], ea.x + ea.y);
-      const float o = oa.x + oa.y;
-      const float g0 = kIr65.win[n] * (e + o);         // g[n]:    taps 64+n and 64-n
-      hrow[64 + n] = g0;
-      if (n >= 1) hrow[64 - n] = g0;
-      if (n >= 1 && n < 32) {
-        const float g1 = kIr65.win[64 - n] * (e - o);  // g[64-n]: taps 128-n and n
-        hrow[128 - n] = g1;
-        hrow[n] = g1;
-      }
-    }
   }
-  if constexpr (IRMF != 2) __syncthreads();             // magnitudes consumed: s_u is free
   DDSP_STAMP();    // 2: IR designed
-  // ---- 3. noise tile x[z0-128 .. z0+3967] into s_u (four 16-byte-chunk planes) ----------------------
-  if constexpr (IRMF != 2)
-  for (int qd = tid; qd < kFnXLen / 4; qd += 64 * NW) {
-    const int i = z0 - 128 + 4 * qd;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i >= 0 && i < p.N) {
-      if (GEN_NOISE) {
-        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
-                                   p.k0, p.k1);
-        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-        if (i + 1 >= p.N) v.y = 0.f;
-        if (i + 2 >= p.N) v.z = 0.f;
-        if (i + 3 >= p.N) v.w = 0.f;
-      } else {
-        const float* src = x + (size_t)b * p.N + i;
-        if (i + 3 < p.N && ((p.N & 3) == 0)) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (i + 1 < p.N) v.y = src[1];
-          if (i + 2 < p.N) v.z = src[2];
-          if (i + 3 < p.N) v.w = src[3];
-        }
-      }
-    }
-    *reinterpret_cast<float4*>(&s_u[(qd & 3) * kFnPlane + ((qd >> 2) << 2)]) = v;
-  }
   __syncthreads();
   DDSP_STAMP();    // 3: noise tile staged
   // ---- 4. FIR: 16 outputs per lane; with 8 wavefronts, threads 256..511 take taps 64..127 of the
@@ -1056,32 +896,6 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       // other stream does better with 4-wavefront blocks (measured: profiles/README.md)
       static const int nw_env = [] { const char* e = getenv("DDSP_EXP_NOISE_WAVES"); return e ? atoi(e) : 0; }();
       const int nw = nw_env ? nw_env : ((size_t)grid.x * grid.y > 768 ? 8 : 4);
-      static const int ir_mfma_env = [] { const char* e = getenv("DDSP_EXP_NOISE_IR_MFMA"); return e ? atoi(e) : 0; }();
-      const int ir_variant = ir_mfma_env ? ir_mfma_env
-                             : (flags & DDSP_NOISE_IR_MATRIX_CORES) ? ((flags & DDSP_NOISE_IR_FROM_REGISTERS) ? 2 : 1) : 0;
-#define DDSP_LAUNCH_NOISE_IR(V)                                                                                       \
-  do {                                                                                                                \
-    if (nw == 8) {                                                                                                    \
-      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8, V>), grid, dim3(512), 0, st, ev0, ev1, 0,       \
-                                       magnitudes, noise, ctl_magnitudes, audio, q);                                  \
-      else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 8, V>), grid, dim3(512), 0, st, ev0, ev1, 0, magnitudes,  \
-                                 noise, ctl_magnitudes, audio, q);                                                    \
-    } else {                                                                                                          \
-      if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 4, V>), grid, dim3(256), 0, st, ev0, ev1, 0,       \
-                                       magnitudes, noise, ctl_magnitudes, audio, q);                                  \
-      else hipExtLaunchKernelGGL((noise_fused65_kernel<true, 4, V>), grid, dim3(256), 0, st, ev0, ev1, 0, magnitudes,  \
-                                 noise, ctl_magnitudes, audio, q);                                                    \
-    }                                                                                                                 \
-  } while (0)
-      if (ir_variant == 1) {         // experimental: the IR design's cosine transform on the matrix cores
-        DDSP_LAUNCH_NOISE_IR(1);
-        return check_launch();
-      }
-      if (ir_variant == 2) {         // ... with the magnitudes going from HBM to the fragments without LDS staging
-        DDSP_LAUNCH_NOISE_IR(2);
-        return check_launch();
-      }
-#undef DDSP_LAUNCH_NOISE_IR
       if (nw == 8) {
         if (noise) hipExtLaunchKernelGGL((noise_fused65_kernel<false, 8>), grid, dim3(512), 0, st, ev0, ev1, 0,
                                          magnitudes, noise, ctl_magnitudes, audio, q);

@@ -237,16 +237,11 @@ class FilteredNoise(processors.Processor):
   here noise is Philox4x32-10 keyed by (seed, call counter), generated inside the FIR
   kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
 
-  `ir_design` (an attribute, like Harmonic.kernel) selects how the fused kernel turns a frame's 65 magnitudes
-  into 128 taps: 'vector' (default: lanes = frames on the vector ALUs), 'matrix' (experimental: the cosine
-  transform on the fp16 matrix cores, hi/lo split operands) or 'matrix_direct' (the same with the magnitudes going
-  from HBM to the fragments without LDS staging and the noise tile generated under that latency).  Same result
-  within the parity tolerance.
+  `kernel` (an attribute, like Harmonic.kernel; the constructor is the reference's): 'auto' runs the canonical filter
+  (65 bands, full window, frames of 64 c samples) on noise_mfma65_kernel - IR design and the time-varying FIR on the fp16
+  matrix cores (hi/lo-split operands, fp32 accumulation); 'vector' keeps the FIR on the vector ALUs
+  (noise_fused65_kernel).  Same result within the parity tolerance.
   """
-  ir_design = 'vector'
-  # 'auto': the canonical filter (65 bands, full window, frames of 64 c samples) runs noise_mfma65_kernel - IR design and
-  # the time-varying FIR on the fp16 matrix cores (hi/lo-split operands, fp32 accumulation); 'vector': the FIR on the
-  # vector ALUs (noise_fused65_kernel, with `ir_design` choosing its IR design).  Same result within the parity tolerance.
   kernel = 'auto'
 
   def __init__(self,
@@ -290,17 +285,7 @@ class FilteredNoise(processors.Processor):
       return 0
     if self.kernel != 'vector':
       raise ValueError("FilteredNoise.kernel must be 'auto' or 'vector', got {!r}".format(self.kernel))
-    return _lib.NOISE_FIR_VECTOR_ALU | self._ir_design_flag()
-
-  def _ir_design_flag(self):
-    if self.ir_design == 'matrix':
-      return _lib.NOISE_IR_MATRIX_CORES
-    if self.ir_design == 'matrix_direct':
-      return _lib.NOISE_IR_MATRIX_CORES | _lib.NOISE_IR_FROM_REGISTERS
-    if self.ir_design != 'vector':
-      raise ValueError("FilteredNoise.ir_design must be 'vector', 'matrix' or 'matrix_direct', got {!r}".format(
-          self.ir_design))
-    return 0
+    return _lib.NOISE_FIR_VECTOR_ALU
 
   def _next_seed(self):
     s = (self.seed & 0xFFFFFFFF) | ((self._calls & 0xFFFFFFFF) << 32)

@@ -48,14 +48,10 @@ extern "C" {
 
 /* ---- flags for the FilteredNoise entry points (ddsp/synths.py:153-163) ------------ */
 #define DDSP_NOISE_SCALE_EXP_SIGMOID 0x1u /* scale_fn=core.exp_sigmoid on (mag + initial_bias) */
-#define DDSP_NOISE_IR_FROM_REGISTERS 0x4u /* with DDSP_NOISE_IR_MATRIX_CORES: magnitudes go from HBM to the MFMA fragments
-                                             without LDS staging, the noise tile is generated under the load latency */
 #define DDSP_NOISE_FIR_VECTOR_ALU 0x8u    /* ddsp_filtered_noise_f32, canonical filter (65 bands, full window, frames of 64 c samples):
                                              keep the time-varying FIR on the vector ALUs (noise_fused65_kernel) instead of the
                                              default matrix-core kernel (noise_mfma65_kernel: IR design and FIR as fp16 hi/lo-split
                                              MFMA products, fp32 accumulation) */
-#define DDSP_NOISE_IR_MATRIX_CORES 0x2u   /* ddsp_filtered_noise_f32, fused shape (65 bands, full window): experimental -
-                                             the IR design's cosine transform on the fp16 matrix cores (hi/lo split) */
 
 /* Library / build identification: "ddsp_amd <version> gfx950". */
 const char* ddsp_version(void);

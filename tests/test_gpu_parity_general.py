@@ -324,60 +324,40 @@ def test_fft_convolve_time_varying_ir_beyond_the_tiled_kernels_lds_budget(ddsp):
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max())
 
 
-# ---- FilteredNoise.ir_design = 'matrix': the IR design's cosine transform on the fp16 matrix cores ----------------
-@pytest.fixture(params=['matrix', 'matrix_direct'])
-def matrix_ir(request, ddsp):
-  """'matrix': the cosine transform on the matrix cores; 'matrix_direct': the same with the magnitudes going from HBM
-  to the MFMA fragments without LDS staging and the noise tile generated under the load latency."""
-  old = ddsp.synths.FilteredNoise.ir_design, ddsp.synths.FilteredNoise.kernel
-  ddsp.synths.FilteredNoise.ir_design = request.param
-  ddsp.synths.FilteredNoise.kernel = 'vector'            # the IR designs are variants of the vector-ALU FIR kernel
-  yield request.param
-  ddsp.synths.FilteredNoise.ir_design, ddsp.synths.FilteredNoise.kernel = old
-
-
+# ---- FilteredNoise.kernel = 'vector' (FIR on the vector ALUs) against 'auto' (IR design and FIR on the matrix cores) ------
 def noise_tol(ref):
   return 2e-6 + 1e-5 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('name', ['noise_m65_w257', 'noise_m65_w0'])
-def test_filtered_noise_matrix_ir_design_golden(ddsp, matrix_ir, name):
-  g = load_golden(name)
-  synth = ddsp.synths.FilteredNoise(n_samples=int(g['n_samples']), window_size=int(g['window_size']))
-  out = synth(g['magnitudes'], noise=g['noise'], return_outputs_dict=True)
-  np.testing.assert_allclose(npy(out['controls']['magnitudes']), g['ctl_magnitudes'], rtol=2e-5, atol=1e-9)
-  np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=noise_tol(g['signal']))
-
-
 @pytest.mark.parametrize('batch,n_frames,n', [(3, 125, 8000), (1, 1, 64), (2, 62, 3968), (2, 63, 4032), (1, 40, 2543),
-                                              (2, 30, 9600), (770, 1, 64)])     # 770 blocks: the 8-wavefront variant
-def test_filtered_noise_matrix_ir_design_vs_oracle_and_vector(ddsp, matrix_ir, batch, n_frames, n):
-  ddsp.synths.FilteredNoise.ir_design = 'vector'
+                                              (2, 30, 9600), (770, 1, 64), (2, 124, 7936), (5, 200, 12800)])
+def test_filtered_noise_matrix_core_kernel_vs_oracle_and_vector_kernel(ddsp, batch, n_frames, n):
+  """Both kernels at the edges of their tiles (62 frames), with the magnitudes at exp_sigmoid's floor (fp16 subnormal
+  territory for the hi / lo split) and ceiling, supplied and generated noise; 770 rows: more tiles than CUs."""
   rng = np.random.default_rng(n_frames + n)
   mags = rng.standard_normal((batch, n_frames, 65)).astype(np.float32)
-  mags[0, : max(n_frames // 8, 1)] = -60.0                        # exp_sigmoid's floor (1e-7): fp16 subnormal territory
+  mags[0, : max(n_frames // 8, 1)] = -60.0                        # exp_sigmoid's floor (1e-7)
   mags[-1, n_frames // 2] = 40.0                                  # and its ceiling (2.0)
   noise = rng.uniform(-1.0, 1.0, (batch, n)).astype(np.float32)
-  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
-  vector_out = synth(mags, noise=noise, return_outputs_dict=True)
-  vector = npy(vector_out['signal'])
-  ddsp.synths.FilteredNoise.ir_design = matrix_ir
+  outs, gen = {}, {}
+  old = ddsp.synths.FilteredNoise.kernel
   try:
-    matrix_out = synth(mags, noise=noise, return_outputs_dict=True)
-    matrix = npy(matrix_out['signal'])
-    generated = npy(synth(mags))                                  # noise generated on chip, same kernel variant
+    for kernel in ('vector', 'auto'):
+      ddsp.synths.FilteredNoise.kernel = kernel
+      synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=11)
+      outs[kernel] = synth(mags, noise=noise, return_outputs_dict=True)
+      gen[kernel] = npy(synth(mags))                              # noise generated on chip (call counter 1 in both)
+    with pytest.raises(ValueError, match='kernel'):
+      ddsp.synths.FilteredNoise.kernel = 'bogus'
+      ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(mags, noise=noise)
   finally:
-    ddsp.synths.FilteredNoise.ir_design = 'vector'
-  np.testing.assert_array_equal(npy(matrix_out['controls']['magnitudes']), npy(vector_out['controls']['magnitudes']))
+    ddsp.synths.FilteredNoise.kernel = old
+  np.testing.assert_array_equal(npy(outs['auto']['controls']['magnitudes']), npy(outs['vector']['controls']['magnitudes']))
   rows = slice(0, min(batch, 4))                                  # the oracle on a few rows is enough at batch 770
   ref = O.filtered_noise(mags[rows], noise[rows], 0, dtype=np.float64)
-  np.testing.assert_allclose(matrix[rows], ref, rtol=0, atol=noise_tol(ref))
-  # the two designs differ by the rounding of the taps only: far inside the parity tolerance
-  assert np.abs(matrix - vector).max() <= 0.2 * noise_tol(ref)
-  assert generated.shape == (batch, n) and np.isfinite(generated).all() and np.abs(generated).max() > 0
-  with pytest.raises(ValueError, match='ir_design'):
-    ddsp.synths.FilteredNoise.ir_design = 'bogus'
-    try:
-      synth(mags, noise=noise)
-    finally:
-      ddsp.synths.FilteredNoise.ir_design = 'vector'
+  for kernel in ('vector', 'auto'):
+    np.testing.assert_allclose(npy(outs[kernel]['signal'])[rows], ref, rtol=0, atol=noise_tol(ref))
+  # same taps (the same IR design), the FIR in fp32 FMAs against split fp16 products: far inside the parity tolerance
+  assert np.abs(npy(outs['auto']['signal']) - npy(outs['vector']['signal'])).max() <= 0.5 * noise_tol(ref)
+  # generated noise: the same Philox stream in both kernels
+  assert np.abs(gen['auto'] - gen['vector']).max() <= 0.5 * noise_tol(ref) and np.abs(gen['auto']).max() > 0

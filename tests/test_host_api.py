@@ -128,7 +128,7 @@ def test_constructor_defaults_of_the_neighbouring_processors():   # effects.py:1
   assert effects.FIRFilter().window_size == 257 and effects.FIRFilter().name == 'fir_filter'
   assert processors.Mix().name == 'mix' and synths.TensorToAudio().name == 'tensor_to_audio'
   assert processors.Crop(frame_size=64).crop_location == 'back'
-  assert synths.Harmonic.kernel == 'auto' and synths.FilteredNoise.ir_design == 'vector'     # the measured defaults
+  assert synths.Harmonic.kernel == 'auto' and synths.FilteredNoise.kernel == 'auto'           # the measured defaults
   with pytest.raises(ValueError, match='gain'):                       # effects_test.py:49-52 (raised before any launch)
     effects.ExpDecayReverb(trainable=False).get_controls(np.zeros((1, 8), np.float32))
   with pytest.raises(ValueError, match='ir'):

@@ -64,7 +64,6 @@ for _module in (P, G):
   for _name in dir(_module):
     if _name.startswith('test_') and callable(getattr(_module, _name)):
       globals()[_name] = getattr(_module, _name)
-matrix_ir = G.matrix_ir              # fixtures the re-exported tests ask for by name
 
 SLOW_UNDER_EMULATION = () if os.environ.get('DDSP_EMU_ALL') == '1' else (
     'test_spectral_loss_on_the_synth_output_batch32',                  # 293 s
