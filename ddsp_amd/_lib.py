@@ -63,6 +63,8 @@ SIGNATURES = {
     'ddsp_resample_ex_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
     'ddsp_fft_convolve_f32': (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_voidp]),
     'ddsp_harmonic_envelopes_f32': (c_int, [c_f32p] * 6 + [c_int] * 3 + [c_voidp]),
+    'ddsp_harmonic_oscillator_bank_workspace_bytes': (c_size_t, [c_int] * 2),
+    'ddsp_harmonic_oscillator_bank_f32': (c_int, [c_f32p] * 5 + [c_voidp, c_size_t] + [c_int] * 5 + [c_voidp]),
     'ddsp_harmonic_f0_grad_workspace_bytes': (c_size_t, [c_int] * 4),
     'ddsp_harmonic_f0_grad_f32': (c_int, [c_f32p] * 5 + [c_voidp, c_size_t] + [c_int] * 5 +
                                   [c_uint, c_voidp]),

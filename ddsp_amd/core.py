@@ -434,6 +434,43 @@ def _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, h
                          use_angular_cumsum=use_angular_cumsum)
 
 
+def harmonic_oscillator_bank(frequency, amplitude_envelopes, initial_phase=None, sample_rate=16000,
+                             use_angular_cumsum=True, workspace=None):
+  """core.harmonic_oscillator_bank (ddsp/core.py:966-1025) -> (audio [batch, n_samples], final_phase [batch, 1, 1]).
+
+  Audio-rate inputs: `frequency` [batch, n_samples, 1] (one fundamental per clip), `amplitude_envelopes`
+  [batch, n_samples, n_sinusoids], `initial_phase` [batch, 1, 1] radians.  audio = sum_k A_k sin((k+1) phase),
+  phase = cumsum(2 pi f / sr) + initial_phase, no Nyquist mask (as the reference); final_phase is the phase of the
+  last sample, with the scan's part wrapped to [0, 2 pi) when use_angular_cumsum (the reference's default here).
+  """
+  frequency, amplitude_envelopes = tf_float32(frequency), tf_float32(amplitude_envelopes)
+  require_no_grad('core.harmonic_oscillator_bank', frequency, amplitude_envelopes, initial_phase)
+  if amplitude_envelopes.dim() != 3 or frequency.dim() != 3 or frequency.shape[2] != 1 or \
+      tuple(frequency.shape[:2]) != tuple(amplitude_envelopes.shape[:2]):
+    raise ValueError('frequency must be [batch, n_samples, 1] and amplitude_envelopes [batch, n_samples, n_sinusoids], '
+                     'got {} and {}'.format(tuple(frequency.shape), tuple(amplitude_envelopes.shape)))
+  b, n, k = amplitude_envelopes.shape
+  dev = amplitude_envelopes.device
+  if initial_phase is not None:
+    initial_phase = tf_float32(initial_phase).reshape(-1)
+    if initial_phase.numel() != b:
+      raise ValueError('initial_phase must be [batch, 1, 1], got {} values for batch {}'.format(
+          initial_phase.numel(), b))
+    initial_phase = initial_phase.contiguous()
+  audio = torch.empty((b, n), dtype=torch.float32, device=dev)
+  final_phase = torch.empty((b, 1, 1), dtype=torch.float32, device=dev)
+  if b == 0 or n == 0:
+    return audio, final_phase
+  lib = _lib.load()
+  ws = (workspace or _default_ws).get(cached_workspace_bytes('ddsp_harmonic_oscillator_bank_workspace_bytes', b, n), dev)
+  rc = lib.ddsp_harmonic_oscillator_bank_f32(
+      frequency.data_ptr(), amplitude_envelopes.data_ptr(),
+      initial_phase.data_ptr() if initial_phase is not None else None, audio.data_ptr(), final_phase.data_ptr(),
+      ws.data_ptr(), ws.numel(), b, n, k, int(sample_rate), 1 if use_angular_cumsum else 0, _stream())
+  _lib.check(rc, 'ddsp_harmonic_oscillator_bank_f32')
+  return audio, final_phase
+
+
 def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=None,
                                  initial_phase=None, n_samples=64000, sample_rate=16000,
                                  amp_resample_method='linear', workspace=None):
@@ -454,11 +491,25 @@ def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=
   b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
   n = int(n_samples)
   _check_amp_method(amp_resample_method, f, n)
-  if amp_resample_method not in ('linear', 'window'):
-    # the closed-form kernel knows the two envelopes the shipped configs use; 'nearest' / 'cubic' must not
-    # silently fall back to the 'window' envelope
-    raise NotImplementedError("streaming_harmonic_synthesis: amp_resample_method '{}' is not built on the "
-                              "MI355X path (use 'linear' or 'window').".format(amp_resample_method))
+  if amp_resample_method not in ('linear', 'window') or n % f:
+    # the closed-form kernel knows the two envelopes the shipped configs use on whole frames; everything else follows
+    # the reference's own chain on materialised envelopes (core.py:1144-1164): normalize_harmonics, resample both,
+    # harmonic_oscillator_bank - each a kernel of this library
+    if flags & _lib.HARM_INPUTS_ARE_AMPLITUDES:
+      harmonic_amplitudes = amplitudes
+    else:
+      hd_norm = normalize_harmonics(harmonic_distribution, frequencies, sample_rate)
+      # amplitudes * distribution on ddsp_harmonic_envelopes_f32 (its harmonic-frequency output is not needed here)
+      harmonic_amplitudes = torch.empty_like(hd_norm)
+      unused = torch.empty_like(hd_norm)
+      rc = _lib.load().ddsp_harmonic_envelopes_f32(
+          amplitudes.data_ptr(), hd_norm.data_ptr(), frequencies.data_ptr(), None, unused.data_ptr(),
+          harmonic_amplitudes.data_ptr(), b, f, k, _stream())
+      _lib.check(rc, 'ddsp_harmonic_envelopes_f32')
+    frequency_envelope = resample(frequencies, n)
+    amplitude_envelopes = resample(harmonic_amplitudes, n, method=amp_resample_method)
+    return harmonic_oscillator_bank(frequency_envelope, amplitude_envelopes, initial_phase, sample_rate=sample_rate,
+                                    workspace=workspace)
   if n % f:
     raise ValueError('streaming_harmonic_synthesis needs n_samples ({}) to be a multiple of '
                      'n_frames ({}) on the MI355X path.'.format(n, f))

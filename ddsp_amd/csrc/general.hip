@@ -170,6 +170,80 @@ __global__ __launch_bounds__(kThreads) void harmonic_envelopes_kernel(
 }
 
 // =====================================================================================
+// core.harmonic_oscillator_bank (ddsp/core.py:966-1025) on AUDIO-RATE inputs: one fundamental per clip,
+//   omega = f 2 pi / sr,  phase[n] = cumsum(omega)[n] + initial_phase,  audio[n] = sum_k A[n,k] sin(k phase[n]),
+//   final_phase = phase[N-1]  (with use_angular_cumsum, the reference's default here, wrapped to [0, 2 pi) + initial_phase
+//   as core.angular_cumsum leaves it; without, the plain sum).
+// No Nyquist mask, as in the reference.  The scan runs in fp64 revolutions: chunk sums (one thread per chunk of 256
+// samples), a serial exclusive prefix per clip, then one thread per sample (its part of the chunk summed again:
+// 256 L2-resident adds - a generality path; the frame-rate closed forms of harmonic.hip are the fast one).
+// =====================================================================================
+constexpr int kHobChunk = 256;
+
+__global__ __launch_bounds__(kThreads) void hob_chunk_sums_kernel(const float* __restrict__ freq /*[B,N]*/,
+                                                                  double* __restrict__ sums /*[B,C]*/, int B, int N, int C) {
+  const size_t total = (size_t)B * C;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const size_t b = i / C;
+    const int c = (int)(i - b * C);
+    const float* __restrict__ f = freq + b * N;
+    const int n1 = min((c + 1) * kHobChunk, N);
+    double acc = 0.0;
+    for (int n = c * kHobChunk; n < n1; ++n) acc += (double)f[n];
+    sums[i] = acc;
+  }
+}
+
+// sums[b][c] <- cycles before chunk c (wrapped to [0,1)); total[b] <- cycles of the whole clip (not wrapped)
+__global__ __launch_bounds__(kThreads) void hob_prefix_kernel(double* __restrict__ sums /*[B,C]*/,
+                                                              double* __restrict__ total /*[B]*/, int B, int C,
+                                                              double inv_sr) {
+  for (size_t b = global_thread(); b < (size_t)B; b += grid_threads()) {
+    double* __restrict__ s = sums + b * C;
+    double acc = 0.0, all = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double v = s[c] * inv_sr;
+      s[c] = acc;
+      acc += v;
+      acc -= floor(acc);
+      all += v;
+    }
+    total[b] = all;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void hob_synth_kernel(
+    const float* __restrict__ freq /*[B,N]*/, const float* __restrict__ amps /*[B,N,K]*/,
+    const float* __restrict__ initial_phase /*[B] radians, or null*/, const double* __restrict__ prefix /*[B,C]*/,
+    const double* __restrict__ total /*[B]*/, float* __restrict__ audio /*[B,N]*/, float* __restrict__ final_phase /*[B]*/,
+    int B, int N, int K, int C, double inv_sr, int angular) {
+  const double kInv2Pi = 0.15915494309189533577, k2Pi = 6.283185307179586476925;
+  const size_t count = (size_t)B * N;
+  for (size_t i = global_thread(); i < count; i += grid_threads()) {
+    const size_t b = i / N;
+    const int n = (int)(i - b * N);
+    const float* __restrict__ f = freq + b * N;
+    const int c = n / kHobChunk;
+    double acc = 0.0;
+    for (int m = c * kHobChunk; m <= n; ++m) acc += (double)f[m];          // inclusive: tf.cumsum starts at omega_0
+    const double phi0 = initial_phase ? (double)initial_phase[b] * kInv2Pi : 0.0;
+    double theta = prefix[b * C + c] + acc * inv_sr + phi0;                  // revolutions
+    theta -= floor(theta);
+    const float* __restrict__ a = amps + i * K;
+    float out = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const double kt = (double)(k + 1) * theta;
+      out = fmaf(a[k], sinpif(2.0f * (float)(kt - floor(kt))), out);
+    }
+    audio[i] = out;
+    if (n == N - 1) {
+      const double cyc = total[b];
+      final_phase[b] = (float)((angular ? (cyc - floor(cyc)) : cyc) * k2Pi + (initial_phase ? (double)initial_phase[b] : 0.0));
+    }
+  }
+}
+
+// =====================================================================================
 // dL/d f0_hz of Harmonic.  With phase_k[n] = (2 pi / sr) k cumsum(f_env)[n] and f_env = U f0 (the legacy
 // bilinear resize, linear in f0; the Nyquist masks have zero gradient, as tf.where gives them):
 //   dL/d f_env[t] = (2 pi / sr) sum_{n >= t} c[n],   c[n] = g[n] sum_k k A_k[n] m_k[n] cos(phase_k[n])
@@ -447,6 +521,31 @@ extern "C" int ddsp_harmonic_envelopes_f32(const float* amplitudes, const float*
   hipLaunchKernelGGL(harmonic_envelopes_kernel, dim3(grid_for(rows * K)), dim3(kThreads), 0,
                      (hipStream_t)stream, amplitudes, harmonic_distribution, f0_hz, harmonic_shifts,
                      harmonic_frequencies, harmonic_amplitudes, rows, K);
+  return check_launch();
+}
+
+extern "C" size_t ddsp_harmonic_oscillator_bank_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  const size_t chunks = ((size_t)N + kHobChunk - 1) / kHobChunk;
+  return ((size_t)B * chunks + (size_t)B) * sizeof(double);
+}
+
+extern "C" int ddsp_harmonic_oscillator_bank_f32(const float* frequency, const float* amplitude_envelopes,
+                                                 const float* initial_phase, float* audio, float* final_phase,
+                                                 void* workspace, size_t workspace_bytes, int B, int N, int K,
+                                                 int sample_rate, int use_angular_cumsum, void* stream) {
+  if (!frequency || !amplitude_envelopes || !audio || !final_phase || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || K <= 0 || sample_rate <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_harmonic_oscillator_bank_workspace_bytes(B, N) || ((uintptr_t)workspace & 7)) return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = (N + kHobChunk - 1) / kHobChunk;
+  double* sums = (double*)workspace;
+  double* total = sums + (size_t)B * C;
+  const double inv_sr = 1.0 / (double)sample_rate;
+  hipLaunchKernelGGL(hob_chunk_sums_kernel, dim3(grid_for((size_t)B * C)), dim3(kThreads), 0, st, frequency, sums, B, N, C);
+  hipLaunchKernelGGL(hob_prefix_kernel, dim3(grid_for((size_t)B)), dim3(kThreads), 0, st, sums, total, B, C, inv_sr);
+  hipLaunchKernelGGL(hob_synth_kernel, dim3(grid_for((size_t)B * N)), dim3(kThreads), 0, st, frequency, amplitude_envelopes,
+                     initial_phase, sums, total, audio, final_phase, B, N, K, C, inv_sr, use_angular_cumsum ? 1 : 0);
   return check_launch();
 }
 

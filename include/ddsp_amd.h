@@ -327,6 +327,18 @@ int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, int N, int C,
 int ddsp_fft_convolve_f32(const float* audio, const float* impulse_response, float* out, int B, int Bir,
                           int F, int L, int N, int n_out, int start, void* stream);
 
+/* core.harmonic_oscillator_bank (ddsp/core.py:966-1025) on audio-rate inputs: frequency [B,N,1] (one fundamental per clip),
+ * amplitude_envelopes [B,N,K], initial_phase [B] radians or NULL -> audio [B,N] = sum_k A[n,k] sin((k+1) phase[n]),
+ * phase = cumsum(2 pi f / sr) + initial_phase, and final_phase [B] = phase[N-1] (use_angular_cumsum != 0: the scan's
+ * part wrapped to [0, 2 pi) as core.angular_cumsum leaves it, ddsp/core.py:800-866).  No Nyquist mask, as in the
+ * reference.  The phase scan runs in fp64 revolutions.  Caller: core.streaming_harmonic_synthesis with envelopes
+ * the closed-form kernel does not take, ddsp/training/inference.py:446-472 through it. */
+size_t ddsp_harmonic_oscillator_bank_workspace_bytes(int B, int N);
+int ddsp_harmonic_oscillator_bank_f32(const float* frequency, const float* amplitude_envelopes,
+                                      const float* initial_phase, float* audio, float* final_phase,
+                                      void* workspace, size_t workspace_bytes, int B, int N, int K,
+                                      int sample_rate, int use_angular_cumsum, void* stream);
+
 /* The frame-rate tensors core.harmonic_synthesis builds before resampling (ddsp/core.py:1080-1098,
  * get_harmonic_frequencies :1028-1045), fp32 in the reference's op order:
  *   harmonic_frequencies[B,F,K] = (f0_hz * (k+1)) * (1 + harmonic_shifts)      (shifts may be NULL)

@@ -172,6 +172,20 @@ def main():
   cases['streaming_2frames_window'] = streaming_case(2, 2, 100, 320, 16000, 'window', f_lo=60.0, f_hi=90.0)
   cases['streaming_nyquist_crossing'] = streaming_case(2, 4, 30, 256, 16000, 'linear', f_lo=250.0, f_hi=600.0)
   cases['streaming_no_distribution'] = streaming_case(3, 5, 1, 640, 48000, 'linear', with_hd=False)
+  # (round 2) the envelopes the closed-form kernel does not take: the reference's chain on audio-rate envelopes
+  cases['streaming_cubic'] = streaming_case(2, 6, 20, 384, 16000, 'cubic')
+  cases['streaming_nearest_ragged'] = streaming_case(1, 3, 10, 100, 16000, 'nearest')
+  cases['streaming_linear_ragged'] = streaming_case(2, 7, 16, 450, 16000, 'linear')
+
+  # --- core.harmonic_oscillator_bank on audio-rate inputs (core.py:966-1025), both phase accumulations ---
+  hf = rng.uniform(80.0, 700.0, (2, 2300, 1)).astype(np.float32)
+  ha = rng.uniform(0.0, 1.0, (2, 2300, 12)).astype(np.float32)
+  hp = rng.uniform(0.0, 6.0, (2, 1, 1)).astype(np.float32)
+  hob_a, hob_pa = core.harmonic_oscillator_bank(hf, ha, hp, sample_rate=16000, use_angular_cumsum=True)
+  hob_c, hob_pc = core.harmonic_oscillator_bank(hf, ha, None, sample_rate=16000, use_angular_cumsum=False)
+  cases['harmonic_oscillator_bank'] = dict(
+      frequency=hf, amplitude_envelopes=ha, initial_phase=hp, sample_rate=16000,
+      audio_angular=a(hob_a), final_phase_angular=a(hob_pa), audio_cumsum=a(hob_c), final_phase_cumsum=a(hob_pc))
 
   # --- resampling pieces on their own ---
   rng = np.random.default_rng(21)

@@ -750,7 +750,7 @@ def test_spectral_loss_on_the_synth_output_batch32(ddsp):          # ae.gin:36-4
 
 # ---- core.streaming_harmonic_synthesis --------------------------------
 STREAMING_CASES = ['streaming_2frames_linear', 'streaming_2frames_window', 'streaming_nyquist_crossing',
-                   'streaming_no_distribution']
+                   'streaming_no_distribution', 'streaming_cubic', 'streaming_nearest_ragged', 'streaming_linear_ragged']
 
 
 @pytest.mark.parametrize('name', STREAMING_CASES)
@@ -770,6 +770,28 @@ def test_streaming_synthesis_golden(ddsp, name):
   # the carried phase: equal modulo 2 pi to fp64 truth (the reference wraps before adding initial_phase)
   d = (npy(final_phase) - p64 + np.pi) % (2 * np.pi) - np.pi
   assert np.abs(d).max() < 2e-5
+
+
+def test_harmonic_oscillator_bank_audio_rate_golden(ddsp):         # core.py:966-1025
+  g = load_golden('harmonic_oscillator_bank')
+  sr = int(g['sample_rate'])
+  for mode, angular, phase0 in (('angular', True, g['initial_phase']), ('cumsum', False, None)):
+    audio, final_phase = ddsp.core.harmonic_oscillator_bank(g['frequency'], g['amplitude_envelopes'], phase0, sr,
+                                                            use_angular_cumsum=angular)
+    assert tuple(audio.shape) == g['audio_' + mode].shape and tuple(final_phase.shape) == (2, 1, 1)
+    a64, p64 = O.harmonic_oscillator_bank(g['frequency'].astype(np.float64), g['amplitude_envelopes'].astype(np.float64),
+                                          None if phase0 is None else phase0.astype(np.float64), sr,
+                                          use_angular_cumsum=angular)
+    harm_truth_check(npy(audio), a64, float(g['amplitude_envelopes'].sum(-1).max()))
+    # against the reference's own fp32 arithmetic: within the drift of its sequential / chunked phase sums
+    np.testing.assert_allclose(npy(audio), g['audio_' + mode], rtol=0, atol=HARM_FAITHFUL_ATOL * 12)
+    if angular:                                  # equal modulo 2 pi (the reference wraps chunk by chunk)
+      d = (npy(final_phase) - p64 + np.pi) % (2 * np.pi) - np.pi
+      assert np.abs(d).max() < 2e-5
+    else:                                        # the plain sum: hundreds of radians, fp32 resolution
+      np.testing.assert_allclose(npy(final_phase), p64, rtol=2e-7, atol=0)
+  with pytest.raises(ValueError, match='frequency'):
+    ddsp.core.harmonic_oscillator_bank(g['frequency'][:, :10], g['amplitude_envelopes'])
 
 
 def test_streaming_chunks_are_phase_continuous(ddsp):               # inference.py:446-472 call pattern

@@ -234,7 +234,7 @@ def test_spectral_loss_is_zero_for_identical_signals_and_counts_padded_frames():
 
 # ---- core.streaming_harmonic_synthesis ---------------------------------
 STREAMING_CASES = ['streaming_2frames_linear', 'streaming_2frames_window', 'streaming_nyquist_crossing',
-                   'streaming_no_distribution']
+                   'streaming_no_distribution', 'streaming_cubic', 'streaming_nearest_ragged', 'streaming_linear_ragged']
 
 
 @pytest.mark.parametrize('name', STREAMING_CASES)
@@ -468,3 +468,19 @@ def test_exp_decay_reverb_matches_reference_source(name):          # effects.py:
   np.testing.assert_allclose(np.broadcast_to(ir, g['ir'].shape), g['ir'], rtol=2e-6, atol=1e-9)
   sig = O.reverb(g['audio'], ir, add_dry=bool(g['add_dry']))
   np.testing.assert_allclose(sig, g['signal'], rtol=0, atol=1e-5)
+
+
+def test_harmonic_oscillator_bank_matches_reference_source():
+  """core.harmonic_oscillator_bank on audio-rate inputs (core.py:966-1025): the restatement against the reference's
+  own source run on the TF stand-in, both phase accumulations; and the fp64 run stays within the drift the fp32
+  sequential sum is known for."""
+  g = load_golden('harmonic_oscillator_bank')
+  for mode, angular, phase0 in (('angular', True, g['initial_phase']), ('cumsum', False, None)):
+    audio, final_phase = O.harmonic_oscillator_bank(g['frequency'], g['amplitude_envelopes'], phase0,
+                                                    int(g['sample_rate']), use_angular_cumsum=angular)
+    np.testing.assert_allclose(audio, g['audio_' + mode], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(final_phase, g['final_phase_' + mode], rtol=0, atol=2e-5)
+    a64, _ = O.harmonic_oscillator_bank(g['frequency'].astype(np.float64), g['amplitude_envelopes'].astype(np.float64),
+                                        None if phase0 is None else phase0.astype(np.float64), int(g['sample_rate']),
+                                        use_angular_cumsum=angular)
+    assert np.abs(a64 - g['audio_' + mode]).max() < 5e-2
