@@ -61,3 +61,4 @@ inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __builtin_amdgcn_sinf(float rev) { return (float)std::sin(6.283185307179586476925 * (double)rev); }
 inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos(6.283185307179586476925 * (double)rev); }
 inline float cospif(float x) { return (float)std::cos(3.14159265358979323846 * (double)x); }
+inline float sinpif(float x) { return (float)std::sin(3.14159265358979323846 * (double)x); }
