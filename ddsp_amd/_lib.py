@@ -54,6 +54,11 @@ SIGNATURES = {
     'ddsp_spectral_loss_value_and_grad_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t, c_int, c_int,
                                                                  ctypes.POINTER(c_int), c_int, c_float,
                                                                  c_float, c_voidp]),
+    'ddsp_stft_mag_f32': (c_int, [c_f32p] * 4 + [c_int] * 3 + [c_voidp]),
+    'ddsp_spectral_terms_workspace_bytes': (c_size_t, [c_int] * 2),
+    'ddsp_spectral_terms_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_f32p, c_voidp, c_f32p, c_voidp, c_size_t] +
+                                [c_int] * 4 + [ctypes.c_float] * 5 + [c_int, c_voidp]),
+    'ddsp_stft_mag_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_voidp]),
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
     'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),
@@ -63,6 +68,7 @@ SIGNATURES = {
     'ddsp_resample_ex_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
     'ddsp_fft_convolve_f32': (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_voidp]),
     'ddsp_harmonic_envelopes_f32': (c_int, [c_f32p] * 6 + [c_int] * 3 + [c_voidp]),
+    'ddsp_scale_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_harmonic_oscillator_bank_workspace_bytes': (c_size_t, [c_int] * 2),
     'ddsp_harmonic_oscillator_bank_f32': (c_int, [c_f32p] * 5 + [c_voidp, c_size_t] + [c_int] * 5 + [c_voidp]),
     'ddsp_harmonic_f0_grad_workspace_bytes': (c_size_t, [c_int] * 4),
@@ -91,6 +97,7 @@ NOISE_SCALE_EXP_SIGMOID = 0x1
 NOISE_FIR_VECTOR_ALU = 0x8
 DECAY_SCALE_EXP_SIGMOID = 0x1
 RESAMPLE_METHODS = {'nearest': 0, 'linear': 1, 'cubic': 2, 'window': 3}
+LOSS_TYPES = {'L1': 0, 'L2': 1, 'COSINE': 2}
 CONV_ADD_DRY = 0x1
 CONV_MASK_TAP0 = 0x2
 CONV_REVERSE_AUDIO = 0x4

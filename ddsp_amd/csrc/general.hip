@@ -169,6 +169,14 @@ __global__ __launch_bounds__(kThreads) void harmonic_envelopes_kernel(
   }
 }
 
+// out[i] = x[i] * scale[0]: the upstream scalar of a loss's backward pass applied to the stored dL/d audio (the chain
+// rule through a scalar; what tf.GradientTape does implicitly, ddsp/training/trainers.py:162-171)
+__global__ __launch_bounds__(kThreads) void scale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         float* __restrict__ out, size_t n) {
+  const float s = scale[0];
+  for (size_t i = global_thread(); i < n; i += grid_threads()) out[i] = x[i] * s;
+}
+
 // =====================================================================================
 // core.harmonic_oscillator_bank (ddsp/core.py:966-1025) on AUDIO-RATE inputs: one fundamental per clip,
 //   omega = f 2 pi / sr,  phase[n] = cumsum(omega)[n] + initial_phase,  audio[n] = sum_k A[n,k] sin(k phase[n]),
@@ -521,6 +529,13 @@ extern "C" int ddsp_harmonic_envelopes_f32(const float* amplitudes, const float*
   hipLaunchKernelGGL(harmonic_envelopes_kernel, dim3(grid_for(rows * K)), dim3(kThreads), 0,
                      (hipStream_t)stream, amplitudes, harmonic_distribution, f0_hz, harmonic_shifts,
                      harmonic_frequencies, harmonic_amplitudes, rows, K);
+  return check_launch();
+}
+
+extern "C" int ddsp_scale_f32(const float* x, const float* scale, float* out, size_t n, void* stream) {
+  if (!x || !scale || !out) return DDSP_ERR_NULL_POINTER;
+  if (n == 0) return DDSP_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, x, scale, out, n);
   return check_launch();
 }
 

@@ -254,6 +254,45 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   }
 }
 
+// ---- spectral_ops.compute_mag (ddsp/spectral_ops.py:67-70) with the magnitudes written out ------------------------
+// The same block as stft_l1_kernel; |STFT| of both signals goes to HBM as [B, frames, S/2+1].  Used by the general form
+// of SpectralLoss (delta / cumsum terms, 'L2' / 'COSINE', weights: csrc/spectral_terms.hip), which needs whole
+// spectrograms side by side; the shipped configs' 'L1' mag + logmag loss never leaves LDS (stft_l1_kernel).
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_mag_kernel(const float* __restrict__ target,
+                                                              const float* __restrict__ audio,
+                                                              float* __restrict__ mag_t, float* __restrict__ mag_a,
+                                                              int N, int n_frames) {
+  constexpr int H = S / 2;
+  constexpr int G = kSlPoints / 2 / H;
+  constexpr int LOG2H = __builtin_ctz(H);
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * G;
+  sl_load_frames<S>(s, target + (size_t)b * N, audio + (size_t)b * N, tid, f0, n_frames, N);
+  __syncthreads();
+  sl_forward<H>(s, tid, 2 * G, 0);
+  if (SlPlan<H>::kWaveLocal) __syncthreads();
+  for (int e = tid; e < G * (H + 1); e += kSlThreads) {
+    const int g = e / (H + 1), k = e - g * (H + 1);
+    if (f0 + g < n_frames) {
+      const int ia = sl_pos<H>(k & (H - 1)), ib = sl_pos<H>((H - k) & (H - 1));
+      const float rev = (float)k * (1.0f / (float)S);
+      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+      const size_t o = ((size_t)b * n_frames + f0 + g) * (H + 1) + k;
+#pragma unroll
+      for (int sig = 0; sig < 2; ++sig) {
+        const int base = (g + sig * G) << LOG2H;
+        const float2 za = s[SP(base + ia)], zb = s[SP(base + ib)];
+        const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
+        const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
+        const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
+        (sig ? mag_a : mag_t)[o] = sqrtf(fmaf(xr, xr, xi * xi));
+      }
+    }
+  }
+}
+
 // ---- backward: dL/d audio ---------------------------------------------------------------------------
 // Same block structure as the forward kernel: frames -> LDS -> forward FFT of target and audio frames.
 // Then, per frame and per PAIR of bins (k, S/2-k) - the pair shares the packed bins Z[k], Z[H-k]:
@@ -263,14 +302,17 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
 // an unscaled inverse FFT (the algebraic inverse of the forward stages) returns the frame's gradient
 // as even/odd samples, which are windowed and added into grad_audio (4 overlapping frames per
 // sample: fp32 atomics, so the last bit may differ from run to run).
-template <int S>
+// COT (the general form of the loss, csrc/spectral_terms.hip): dL/d|X_a| is read from `cot` [B, frames, S/2+1] instead
+// of being formed from the two spectra here; `target` is not looked at (the caller passes `audio` for it).
+template <int S, bool COT = false>
 __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __restrict__ target,
                                                                  const float* __restrict__ audio,
                                                                  const float* __restrict__ grad_loss,
                                                                  float* __restrict__ grad_audio, int N,
                                                                  int n_frames, float safe_eps,
                                                                  float mag_scale, float log_scale,
-                                                                 double* __restrict__ partial) {
+                                                                 double* __restrict__ partial,
+                                                                 const float* __restrict__ cot) {
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;
   constexpr int LOG2H = __builtin_ctz(H);
@@ -308,7 +350,13 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       x2[sig] = make_float2(ex - wx, -(ey - wy));               // X[H-k] = conj(E - W^k O)
     }
     // dL/dX for one bin: coefficient * X_a / |X_a|
-    auto bin_grad = [&](float2 xt, float2 xa, bool count) {
+    auto bin_grad = [&](float2 xt, float2 xa, bool count, int bin) {
+      if constexpr (COT) {
+        const float ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+        if (!(ma > 0.0f)) return make_float2(0.f, 0.f);           // |z| has gradient 0 at z = 0 (tf.abs)
+        const float coef = cot[((size_t)b * n_frames + f0 + g) * (H + 1) + bin] / ma;
+        return make_float2(coef * xa.x, coef * xa.y);
+      }
       const float mt = sqrtf(fmaf(xt.x, xt.x, xt.y * xt.y)), ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
       if (count) {                                              // every bin 0 .. S/2 exactly once
         dm_sum += fabsf(mt - ma);
@@ -323,8 +371,8 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       const float coef = -(ms * sm + ls * sl * inv) * inv;
       return make_float2(coef * xa.x, coef * xa.y);
     };
-    float2 c1 = bin_grad(x1[0], x1[1], true);                   // G[k]
-    float2 c2 = bin_grad(x2[0], x2[1], 2 * k != H);             // G[H-k] (the self-paired bin S/4 counts once)
+    float2 c1 = bin_grad(x1[0], x1[1], true, k);                // G[k]
+    float2 c2 = bin_grad(x2[0], x2[1], 2 * k != H, H - k);      // G[H-k] (the self-paired bin S/4 counts once)
     const int abase = (g + G) << LOG2H;
     if (k == 0) {                                               // bins 0 and S/2: real, C = Re G
       const float e0 = 0.5f * (c1.x + c2.x), o0 = 0.5f * (c1.x - c2.x);
@@ -514,7 +562,8 @@ static int sl_backward_impl(const float* target_audio, const float* audio, const
       const dim3 grid((unsigned)blocks, (unsigned)B);
 #define DDSP_SLB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
                                                       target_audio, audio, grad_loss, grad_audio, N, frames, 1e-5f, \
-                                                      mag_weight * inv_count, logmag_weight * inv_count, dst); break
+                                                      mag_weight * inv_count, logmag_weight * inv_count, dst, \
+                                                      (const float*)nullptr); break
       switch (S) {
         DDSP_SLB_CASE(16); DDSP_SLB_CASE(32); DDSP_SLB_CASE(64); DDSP_SLB_CASE(128); DDSP_SLB_CASE(256);
         DDSP_SLB_CASE(512); DDSP_SLB_CASE(1024); DDSP_SLB_CASE(2048); DDSP_SLB_CASE(4096);
@@ -547,4 +596,45 @@ extern "C" int ddsp_spectral_loss_value_and_grad_f32(const float* target_audio, 
   if (!loss) return DDSP_ERR_NULL_POINTER;
   return sl_backward_impl(target_audio, audio, nullptr, grad_audio, loss, workspace, workspace_bytes, B, N,
                           fft_sizes, n_sizes, mag_weight, logmag_weight, (hipStream_t)stream);
+}
+
+
+// ---- the pieces of the general SpectralLoss (csrc/spectral_terms.hip holds the term arithmetic) --------------------
+extern "C" int ddsp_stft_mag_f32(const float* target_audio, const float* audio, float* target_mag, float* mag, int B,
+                                 int N, int fft_size, void* stream) {
+  if (!target_audio || !audio || !target_mag || !mag) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (!sl_size_ok(fft_size) || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = fft_size, frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+  const dim3 grid((unsigned)blocks, (unsigned)B);
+#define DDSP_SM_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_mag_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
+                                                     target_audio, audio, target_mag, mag, N, frames); break
+  switch (S) {
+    DDSP_SM_CASE(16); DDSP_SM_CASE(32); DDSP_SM_CASE(64); DDSP_SM_CASE(128); DDSP_SM_CASE(256);
+    DDSP_SM_CASE(512); DDSP_SM_CASE(1024); DDSP_SM_CASE(2048); DDSP_SM_CASE(4096);
+    default: return DDSP_ERR_UNSUPPORTED;
+  }
+#undef DDSP_SM_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N,
+                                          int fft_size, void* stream) {
+  if (!audio || !grad_mag || !grad_audio) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (!sl_size_ok(fft_size) || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = fft_size, frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+  const dim3 grid((unsigned)blocks, (unsigned)B);
+#define DDSP_SMB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ, true>), grid, dim3(kSlThreads), 0, st, \
+                                                      audio, audio, (const float*)nullptr, grad_audio, N, frames, 1e-5f, \
+                                                      0.0f, 0.0f, (double*)nullptr, grad_mag); break
+  switch (S) {
+    DDSP_SMB_CASE(16); DDSP_SMB_CASE(32); DDSP_SMB_CASE(64); DDSP_SMB_CASE(128); DDSP_SMB_CASE(256);
+    DDSP_SMB_CASE(512); DDSP_SMB_CASE(1024); DDSP_SMB_CASE(2048); DDSP_SMB_CASE(4096);
+    default: return DDSP_ERR_UNSUPPORTED;
+  }
+#undef DDSP_SMB_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

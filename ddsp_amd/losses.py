@@ -1,8 +1,11 @@
-"""Losses: the multi-scale spectrogram loss, forward pass (mirror of ddsp/losses.py:41-48, 131-243).
+"""Losses: the multi-scale spectrogram loss (mirror of ddsp/losses.py:41-48, 102-128, 131-243).
 
-SURVEY.md section 8(f) rank 2.  Only what `gin/models/ae.gin:36-41` uses is built: loss_type 'L1'
-with the magnitude and log-magnitude terms; the other weights raise NotImplementedError.
-The call is a torch.autograd node: the gradient reaches `audio` (not `target_audio`).
+SURVEY.md section 8(f) rank 2.  What `gin/models/ae.gin:36-41` uses - loss_type 'L1' with the magnitude and
+log-magnitude terms - runs fused kernels whose spectra never leave LDS (csrc/spectral_loss.hip).  The rest of the
+reference's argument space - delta_time / delta_freq / cumsum_freq terms, 'L2' and 'COSINE', the `weights` mask -
+runs on spectrograms materialised in HBM, one FFT size at a time (csrc/spectral_terms.hip).  `loudness_weight` needs
+spectral_ops.compute_loudness (A-weighting through librosa: out of scope) and raises.
+The call is a torch.autograd node: the gradient reaches `audio` (not `target_audio`, as a training step needs it).
 """
 import ctypes
 
@@ -56,12 +59,9 @@ class SpectralLoss(Loss):
     if self.loss_type.upper() not in ('L1', 'L2', 'COSINE'):
       raise ValueError('Loss type ({}), must be '
                        '"L1", "L2", or "COSINE"'.format(self.loss_type.upper()))
-    unsupported = [k for k in ('delta_time_weight', 'delta_freq_weight', 'cumsum_freq_weight',
-                               'loudness_weight') if getattr(self, k) > 0]
-    if unsupported or self.loss_type.upper() != 'L1' or weights is not None:
-      raise NotImplementedError(
-          'the MI355X SpectralLoss implements loss_type="L1" with mag_weight / logmag_weight only '
-          '(asked for: {})'.format(unsupported or [self.loss_type, 'weights']))
+    if self.loudness_weight > 0:
+      raise NotImplementedError('SpectralLoss.loudness_weight needs spectral_ops.compute_loudness (librosa A-weighting), '
+                                'which is outside the MI355X path')
     target_audio, audio = core.tf_float32(target_audio), core.tf_float32(audio)
     if target_audio.dim() == 3:
       target_audio = target_audio[..., 0].contiguous()
@@ -70,9 +70,76 @@ class SpectralLoss(Loss):
     if target_audio.dim() != 2 or target_audio.shape != audio.shape:
       raise ValueError('target_audio and audio must both be [batch, n_samples], got {} and {}'.format(
           tuple(target_audio.shape), tuple(audio.shape)))
+    general = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
+               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0)
+    if general:
+      weights = self._weights_tensor(weights, audio.device)
+      if torch.is_grad_enabled() and audio.requires_grad:
+        return _SpectralLossGeneralFunction.apply(target_audio.detach(), audio, self, weights)
+      return self._general(target_audio, audio, weights, want_grad=False)[0]
     if torch.is_grad_enabled() and audio.requires_grad:
       return _SpectralLossFunction.apply(target_audio.detach(), audio, self)
     return self._forward(target_audio, audio)
+
+  @staticmethod
+  def _weights_tensor(weights, device):
+    """`weights` of losses.mean_difference: None, a number, or a mask of rank <= 3 -> None or a [b, f, k] tensor."""
+    if weights is None:
+      return None
+    w = core.tf_float32(weights if isinstance(weights, torch.Tensor) else torch.as_tensor(weights, dtype=torch.float32))
+    core.require_no_grad('SpectralLoss weights', w)
+    if w.dim() > 3:
+      raise ValueError('weights must broadcast against [batch, frames, bins], got shape {}'.format(tuple(w.shape)))
+    return w.reshape((1,) * (3 - w.dim()) + tuple(w.shape)).contiguous()
+
+  def _general(self, target_audio, audio, weights, want_grad):
+    """The reference's loop over FFT sizes (losses.py:199-236) on materialised spectrograms -> (loss, grad_audio)."""
+    b, n = audio.shape
+    lib = _lib.load()
+    dev = audio.device
+    loss_type = _lib.LOSS_TYPES[self.loss_type.upper()]
+    term_w = [float(self.mag_weight), float(self.delta_time_weight), float(self.delta_freq_weight),
+              float(self.cumsum_freq_weight), float(self.logmag_weight)]
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    acc = torch.empty((), dtype=torch.float64, device=dev)
+    grad_audio = torch.zeros_like(audio) if want_grad else None
+    if not self.fft_sizes:
+      loss.zero_()
+      return loss, grad_audio
+    for z, size in enumerate(self.fft_sizes):
+      size = int(size)
+      if size < 16 or size > 4096 or size & (size - 1):
+        raise ValueError('fft_sizes must be powers of two in [16, 4096], got {}'.format(tuple(self.fft_sizes)))
+      frames, bins = -(-n // (size // 4)), size // 2 + 1
+      wb = wf = wk = 0
+      if weights is not None:
+        wb, wf, wk = (int(v) for v in weights.shape)
+        # the mask must broadcast against every term it meets, as `difference * weights` does in the reference
+        dims = [(frames, bins)] * 5
+        dims[1], dims[2] = (frames - 1, bins), (frames, bins - 1)
+        for on, (tf_, tk) in zip(term_w, dims):
+          if on > 0 and (wb not in (1, b) or wf not in (1, tf_) or wk not in (1, tk)):
+            raise ValueError('weights of shape {} do not broadcast against a term of shape {}'.format(
+                tuple(weights.shape), (b, tf_, tk)))
+        if loss_type == _lib.LOSS_TYPES['COSINE'] and wk != 1:
+          raise ValueError('COSINE weights must broadcast against [batch, frames, 1], got {}'.format(tuple(weights.shape)))
+      target_mag = torch.empty((b, frames, bins), dtype=torch.float32, device=dev)
+      mag = torch.empty_like(target_mag)
+      rc = lib.ddsp_stft_mag_f32(target_audio.data_ptr(), audio.data_ptr(), target_mag.data_ptr(), mag.data_ptr(), b, n,
+                                 size, core._stream())
+      _lib.check(rc, 'ddsp_stft_mag_f32')
+      cot = torch.empty_like(mag) if want_grad else None
+      ws = self._ws.get(core.cached_workspace_bytes('ddsp_spectral_terms_workspace_bytes', b, frames), dev)
+      rc = lib.ddsp_spectral_terms_f32(
+          target_mag.data_ptr(), mag.data_ptr(), weights.data_ptr() if weights is not None else None, wb, wf, wk,
+          cot.data_ptr() if want_grad else None, acc.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(), b, frames,
+          bins, loss_type, *term_w, 1 if z == 0 else 0, core._stream())
+      _lib.check(rc, 'ddsp_spectral_terms_f32')
+      if want_grad:
+        rc = lib.ddsp_stft_mag_backward_f32(audio.data_ptr(), cot.data_ptr(), grad_audio.data_ptr(), b, n, size,
+                                            core._stream())
+        _lib.check(rc, 'ddsp_stft_mag_backward_f32')
+    return loss, grad_audio
 
   def _sizes(self):
     return (ctypes.c_int * len(self.fft_sizes))(*[int(v) for v in self.fft_sizes])
@@ -123,6 +190,16 @@ class SpectralLoss(Loss):
     return grad_audio
 
 
+def _scale(grad_audio, grad_loss):
+  """grad_audio * (the upstream scalar dL/dloss), on ddsp_scale_f32."""
+  grad_loss = core.tf_float32(grad_loss).reshape(1).contiguous()
+  out = torch.empty_like(grad_audio)
+  rc = _lib.load().ddsp_scale_f32(grad_audio.data_ptr(), grad_loss.data_ptr(), out.data_ptr(), grad_audio.numel(),
+                                  core._stream())
+  _lib.check(rc, 'ddsp_scale_f32')
+  return out
+
+
 class _SpectralLossFunction(torch.autograd.Function):
   """torch.autograd node of SpectralLoss.call: the gradient flows to `audio` only."""
 
@@ -136,4 +213,19 @@ class _SpectralLossFunction(torch.autograd.Function):
   @staticmethod
   def backward(ctx, grad_loss):
     (grad_audio,) = ctx.saved_tensors
-    return None, grad_audio * grad_loss, None       # scaling by the upstream scalar: plumbing
+    return None, _scale(grad_audio, grad_loss), None
+
+
+class _SpectralLossGeneralFunction(torch.autograd.Function):
+  """torch.autograd node of the general SpectralLoss: value and dL/d audio come out of the same pass."""
+
+  @staticmethod
+  def forward(ctx, target_audio, audio, loss_obj, weights):
+    loss, grad_audio = loss_obj._general(target_audio, audio.detach(), weights, want_grad=True)
+    ctx.save_for_backward(grad_audio)
+    return loss
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    (grad_audio,) = ctx.saved_tensors
+    return None, _scale(grad_audio, grad_loss), None, None

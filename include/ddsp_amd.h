@@ -278,6 +278,36 @@ int ddsp_spectral_loss_value_and_grad_f32(const float* target_audio, const float
                                           const int* fft_sizes, int n_sizes, float mag_weight,
                                           float logmag_weight, void* stream);
 
+/* ---- the general form of losses.SpectralLoss (ddsp/losses.py:131-243): every term, loss_type and the weights mask ----
+ * The 'L1' mag + logmag loss of the shipped configs is ddsp_spectral_loss_f32 above (spectra stay in LDS).  These three
+ * entries serve the rest of the reference's argument space on spectrograms materialised in HBM, one FFT size at a time:
+ *
+ * ddsp_stft_mag_f32: spectral_ops.compute_mag (ddsp/spectral_ops.py:67-70; tf.signal.stft: frames of fft_size every
+ *   fft_size/4, zero pad_end, periodic Hann) of two signals at once: target_mag, mag [B, frames, fft_size/2+1],
+ *   frames = ceil(N / (fft_size/4)).
+ * ddsp_spectral_terms_f32: for one FFT size, adds
+ *     mag_weight * D(T, V) + delta_time_weight * D(diff_t T, diff_t V) + delta_freq_weight * D(diff_f T, diff_f V)
+ *     + cumsum_freq_weight * D(cumsum_f T, cumsum_f V) + logmag_weight * D(safe_log T, safe_log V)
+ *   to *loss_accumulator (fp64, device; `first` != 0 starts it at 0) and rewrites *loss (fp32) with the running total;
+ *   D = losses.mean_difference (ddsp/losses.py:102-128) with loss_type DDSP_LOSS_L1 / _L2 / _COSINE and the optional
+ *   `weights` mask of shape [weights_b, weights_f, weights_k] (each extent 1 or the term's; NULL: no mask).  Terms
+ *   with weight <= 0 are skipped, as in the reference.  grad_value_mag (may be NULL) [B, frames, bins] receives
+ *   d(this size's contribution)/dV.  Deterministic (fixed-order fp64 sums).
+ * ddsp_stft_mag_backward_f32: grad_audio [B,N] += d|STFT(audio)|^T grad_mag  (|z| has gradient z/|z|, 0 at 0). */
+#define DDSP_LOSS_L1 0
+#define DDSP_LOSS_L2 1
+#define DDSP_LOSS_COSINE 2
+int ddsp_stft_mag_f32(const float* target_audio, const float* audio, float* target_mag, float* mag, int B, int N,
+                      int fft_size, void* stream);
+size_t ddsp_spectral_terms_workspace_bytes(int B, int frames);
+int ddsp_spectral_terms_f32(const float* target_mag, const float* value_mag, const float* weights, int weights_b,
+                            int weights_f, int weights_k, float* grad_value_mag, double* loss_accumulator, float* loss,
+                            void* workspace, size_t workspace_bytes, int B, int frames, int bins, int loss_type,
+                            float mag_weight, float delta_time_weight, float delta_freq_weight,
+                            float cumsum_freq_weight, float logmag_weight, int first, void* stream);
+int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
+                               void* stream);
+
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);
@@ -326,6 +356,10 @@ int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, int N, int C,
  * General shapes, one thread per output; ddsp_fft_convolve_same_f32 is the fast entry for 'same'. */
 int ddsp_fft_convolve_f32(const float* audio, const float* impulse_response, float* out, int B, int Bir,
                           int F, int L, int N, int n_out, int start, void* stream);
+
+/* out[i] = x[i] * scale[0] (scale: one float in device memory): the upstream scalar of a loss's backward pass applied
+ * to a stored gradient - the chain rule tf.GradientTape applies through SpectralLoss (ddsp/training/trainers.py:162-171). */
+int ddsp_scale_f32(const float* x, const float* scale, float* out, size_t n, void* stream);
 
 /* core.harmonic_oscillator_bank (ddsp/core.py:966-1025) on audio-rate inputs: frequency [B,N,1] (one fundamental per clip),
  * amplitude_envelopes [B,N,K], initial_phase [B] radians or NULL -> audio [B,N] = sum_k A[n,k] sin((k+1) phase[n]),

@@ -804,7 +804,9 @@ def safe_log(x, eps=1e-5):
 
 
 def mean_difference(target, value, loss_type='L1', weights=None):
-  """losses.mean_difference (losses.py:102-128), 'L1' and 'L2'."""
+  """losses.mean_difference (losses.py:102-128).  'COSINE' is tf.compat.v1.losses.cosine_distance(target, value,
+  weights, axis=-1): 1 - sum(target * value, -1, keepdims) per row, weighted, summed and divided by the number of
+  non-zero weights (Reduction.SUM_BY_NONZERO_WEIGHTS; 0 if there are none)."""
   difference = target - value
   weights = 1.0 if weights is None else weights
   loss_type = loss_type.upper()
@@ -812,21 +814,42 @@ def mean_difference(target, value, loss_type='L1', weights=None):
     return np.mean(np.abs(difference * weights), dtype=difference.dtype)
   if loss_type == 'L2':
     return np.mean(difference**2 * weights, dtype=difference.dtype)
+  if loss_type == 'COSINE':
+    losses = 1.0 - np.sum(target * value, axis=-1, keepdims=True)
+    w = np.broadcast_to(np.asarray(weights, losses.dtype), losses.shape)
+    present = np.count_nonzero(w)
+    return (np.sum(losses * w) / present).astype(losses.dtype) if present else losses.dtype.type(0.0)
   raise ValueError('Loss type ({}), must be "L1", "L2", or "COSINE"'.format(loss_type))
 
 
+def diff(x, axis=-1):
+  """core.diff (core.py:171-199): x[1:] - x[:-1] along `axis`."""
+  x = np.moveaxis(x, axis, 0)
+  return np.moveaxis(x[1:] - x[:-1], 0, axis)
+
+
 def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type='L1',
-                  mag_weight=1.0, logmag_weight=0.0, dtype=np.float32):
-  """losses.SpectralLoss.call (losses.py:189-243), magnitude and log-magnitude terms."""
+                  mag_weight=1.0, logmag_weight=0.0, dtype=np.float32, delta_time_weight=0.0, delta_freq_weight=0.0,
+                  cumsum_freq_weight=0.0, weights=None):
+  """losses.SpectralLoss.call (losses.py:189-243), every term but the loudness one."""
   loss = dtype(0.0)
+  if weights is not None:
+    weights = np.asarray(weights, dtype)
   for size in fft_sizes:
     target_mag = compute_mag(target_audio, size, dtype=dtype)
     value_mag = compute_mag(audio, size, dtype=dtype)
     if mag_weight > 0:
-      loss += dtype(mag_weight) * mean_difference(target_mag, value_mag, loss_type)
+      loss += dtype(mag_weight) * mean_difference(target_mag, value_mag, loss_type, weights)
+    if delta_time_weight > 0:
+      loss += dtype(delta_time_weight) * mean_difference(diff(target_mag, 1), diff(value_mag, 1), loss_type, weights)
+    if delta_freq_weight > 0:
+      loss += dtype(delta_freq_weight) * mean_difference(diff(target_mag, 2), diff(value_mag, 2), loss_type, weights)
+    if cumsum_freq_weight > 0:
+      loss += dtype(cumsum_freq_weight) * mean_difference(np.cumsum(target_mag, axis=2, dtype=dtype),
+                                                          np.cumsum(value_mag, axis=2, dtype=dtype), loss_type, weights)
     if logmag_weight > 0:
       loss += dtype(logmag_weight) * mean_difference(safe_log(target_mag), safe_log(value_mag),
-                                                     loss_type)
+                                                     loss_type, weights)
   return loss
 
 

@@ -152,6 +152,20 @@ def main():
       loss_ae_gin=a(losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)(tgt, aud)),      # ae.gin:36-41
       loss_two_scales=a(losses.SpectralLoss(fft_sizes=(512, 64), logmag_weight=0.5)(tgt, aud)),
       mag_256=a(spectral_ops.compute_mag(aud, size=256)))
+  # (round 2) the rest of SpectralLoss's argument space: every term, 'L2' / 'COSINE', the weights mask
+  wmask = np.array([[[1.0]], [[0.25]]], np.float32)
+  all_terms = dict(mag_weight=1.0, delta_time_weight=0.5, delta_freq_weight=0.25, cumsum_freq_weight=0.125, logmag_weight=0.75)
+  cases['spectral_loss_terms'] = dict(
+      target_audio=tgt, audio=aud, weights=wmask, fft_sizes=np.array([512, 128, 64]),
+      **{k: np.float32(v) for k, v in all_terms.items()},
+      l1=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), **all_terms)(tgt, aud)),
+      l2=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), loss_type='L2', **all_terms)(tgt, aud)),
+      cosine=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), loss_type='COSINE', **all_terms)(tgt, aud)),
+      l1_weighted=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), **all_terms)(tgt, aud, weights=wmask)),
+      l2_weighted=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), loss_type='L2', **all_terms)(tgt, aud, weights=wmask)),
+      cosine_weighted=a(losses.SpectralLoss(fft_sizes=(512, 128, 64), loss_type='COSINE', **all_terms)(tgt, aud, weights=wmask)),
+      l2_delta_time_only=a(losses.SpectralLoss(fft_sizes=(256,), loss_type='L2', mag_weight=0.0, delta_time_weight=1.0)(tgt, aud)),
+      l1_cumsum_only=a(losses.SpectralLoss(fft_sizes=(2048, 64), mag_weight=0.0, cumsum_freq_weight=1.0)(tgt, aud)))
 
   # --- core.streaming_harmonic_synthesis: the VST model's call (2 frames -> one hop, carried phase) ---
   rng = np.random.default_rng(51)

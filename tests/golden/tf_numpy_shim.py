@@ -329,6 +329,21 @@ def build_tf_module():
       uniform=lambda shape, minval=0.0, maxval=1.0, dtype=np.float32: _t(
           np.random.default_rng(1234).uniform(minval, maxval, shape).astype(np.float32)))
 
+  # core.diff (core.py:171-199): tf.slice(x, begin, size)
+  tf.slice = lambda x, begin, size: _t(_np(x)[tuple(slice(b, b + n) for b, n in zip(begin, size))])
+
+  def cosine_distance(labels, predictions, axis=None, weights=1.0, dim=None):
+    """tf.compat.v1.losses.cosine_distance: 1 - sum(labels * predictions, axis, keepdims), then compute_weighted_loss
+    with Reduction.SUM_BY_NONZERO_WEIGHTS (sum of the weighted losses over the number of non-zero weights)."""
+    axis = axis if axis is not None else dim
+    labels, predictions = _np(labels).astype(np.float32), _np(predictions).astype(np.float32)
+    losses = np.float32(1.0) - np.sum(labels * predictions, axis=axis, keepdims=True, dtype=np.float32)
+    w = np.broadcast_to(np.asarray(weights, np.float32), losses.shape)
+    present = np.count_nonzero(w)
+    total = np.sum(losses * w, dtype=np.float32)
+    return _t(np.float32(total / np.float32(present)) if present else np.float32(0.0))
+  tf.losses = types.SimpleNamespace(cosine_distance=cosine_distance)
+
   tf.math = types.SimpleNamespace(
       log=_wrap(np.log), exp=_wrap(np.exp), real=_wrap(np.real), cumsum=cumsum,
       is_nan=_wrap(np.isnan))

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCE = os.path.join(ROOT, 'ddsp_amd', 'csrc', 'general.hip')
 OUT = os.path.join(HERE, '_build', 'libddsp_general_emu.so')
 ENTRY_POINTS = ['ddsp_resample_ex_f32', 'ddsp_fft_convolve_f32', 'ddsp_harmonic_envelopes_f32',
-                'ddsp_harmonic_oscillator_bank_workspace_bytes', 'ddsp_harmonic_oscillator_bank_f32',
+                'ddsp_scale_f32', 'ddsp_harmonic_oscillator_bank_workspace_bytes', 'ddsp_harmonic_oscillator_bank_f32',
                 'ddsp_harmonic_f0_grad_workspace_bytes', 'ddsp_harmonic_f0_grad_f32', 'ddsp_exp_decay_ir_f32',
                 'ddsp_exp_decay_ir_backward_workspace_bytes', 'ddsp_exp_decay_ir_backward_f32', 'ddsp_sigmoid_f32',
                 'ddsp_mix_f32']

@@ -713,6 +713,54 @@ def test_spectral_loss_golden(ddsp):
     np.testing.assert_allclose(float(out), float(np.ravel(g[key])[0]), rtol=2e-5)
 
 
+def test_spectral_loss_every_term_golden_and_gradient(ddsp):
+  """The general form of SpectralLoss (delta / cumsum terms, 'L2', 'COSINE', the weights mask; losses.py:102-128,
+  199-236) against the reference-source golden values, the fp64 oracle, and - the gradient - a directional finite
+  difference of the fp64 oracle."""
+  g = load_golden('spectral_loss_terms')
+  t, a = g['target_audio'], g['audio']
+  sizes = tuple(int(v) for v in g['fft_sizes'])
+  kw = {k: float(g[k]) for k in ('mag_weight', 'delta_time_weight', 'delta_freq_weight', 'cumsum_freq_weight',
+                                 'logmag_weight')}
+  rng = np.random.default_rng(5)
+  direction = rng.standard_normal(a.shape)
+  direction /= np.abs(direction).max()
+  for key, loss_type, w in (('l1', 'L1', None), ('l2', 'L2', None), ('cosine', 'COSINE', None),
+                            ('l1_weighted', 'L1', g['weights']), ('l2_weighted', 'L2', g['weights']),
+                            ('cosine_weighted', 'COSINE', g['weights'])):
+    loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, loss_type=loss_type, **kw)
+    out = loss(t, a, weights=w)
+    assert out.dim() == 0
+    np.testing.assert_allclose(float(out), float(np.ravel(g[key])[0]), rtol=5e-5, err_msg=key)
+    ref64 = float(O.spectral_loss(t, a, sizes, loss_type, dtype=np.float64, weights=w, **kw))
+    np.testing.assert_allclose(float(out), ref64, rtol=5e-5, err_msg=key)
+    assert float(loss(t, a, weights=w)) == float(out)                    # deterministic
+    # gradient: <dL/d audio, direction> against a central difference of the fp64 oracle
+    ta = torch.tensor(a, device=DEV, requires_grad=True)
+    loss(torch.tensor(t, device=DEV), ta, weights=w).backward()
+    got = float((npy(ta.grad).astype(np.float64) * direction).sum())
+    eps = 1e-5
+    a64 = a.astype(np.float64)
+    up = O.spectral_loss(t, a64 + eps * direction, sizes, loss_type, dtype=np.float64, weights=w, **kw)
+    dn = O.spectral_loss(t, a64 - eps * direction, sizes, loss_type, dtype=np.float64, weights=w, **kw)
+    want = float(up - dn) / (2 * eps)
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * abs(ref64), err_msg=key + ' gradient')
+  # single terms at other sizes
+  for kwargs, key in ((dict(fft_sizes=(256,), loss_type='L2', mag_weight=0.0, delta_time_weight=1.0), 'l2_delta_time_only'),
+                      (dict(fft_sizes=(2048, 64), mag_weight=0.0, cumsum_freq_weight=1.0), 'l1_cumsum_only')):
+    np.testing.assert_allclose(float(ddsp.losses.SpectralLoss(**kwargs)(t, a)), float(np.ravel(g[key])[0]), rtol=5e-5)
+  # the same answer from the general path and the fused one where both apply ('L1' mag + logmag with unit weights)
+  fused = float(ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=1.0, logmag_weight=0.75)(t, a))
+  general = float(ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=1.0, logmag_weight=0.75)(t, a, weights=1.0))
+  np.testing.assert_allclose(general, fused, rtol=1e-5)
+  with pytest.raises(ValueError, match='broadcast'):
+    ddsp.losses.SpectralLoss(fft_sizes=(64,))(t, a, weights=np.ones((2, 7, 1), np.float32))
+  with pytest.raises(NotImplementedError, match='loudness'):
+    ddsp.losses.SpectralLoss(loudness_weight=1.0)(t, a)
+  with pytest.raises(ValueError, match='Loss type'):
+    ddsp.losses.SpectralLoss(loss_type='L3')(t, a)
+
+
 @pytest.mark.parametrize('batch,n', [(2, 64000), (3, 12345), (1, 100)])
 def test_spectral_loss_vs_fp64_oracle(ddsp, batch, n):
   rng = np.random.default_rng(n)

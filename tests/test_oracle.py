@@ -484,3 +484,25 @@ def test_harmonic_oscillator_bank_matches_reference_source():
                                         None if phase0 is None else phase0.astype(np.float64), int(g['sample_rate']),
                                         use_angular_cumsum=angular)
     assert np.abs(a64 - g['audio_' + mode]).max() < 5e-2
+
+
+def test_spectral_loss_every_term_matches_reference_source():
+  """losses.SpectralLoss with every term, loss type and the weights mask (losses.py:102-128, 199-236): the restatement
+  against the reference's own source run on the TF stand-in."""
+  g = load_golden('spectral_loss_terms')
+  t, a = g['target_audio'], g['audio']
+  sizes = tuple(int(v) for v in g['fft_sizes'])
+  kw = {k: float(g[k]) for k in ('mag_weight', 'delta_time_weight', 'delta_freq_weight', 'cumsum_freq_weight',
+                                 'logmag_weight')}
+  for key, loss_type, w in (('l1', 'L1', None), ('l2', 'L2', None), ('cosine', 'COSINE', None),
+                            ('l1_weighted', 'L1', g['weights']), ('l2_weighted', 'L2', g['weights']),
+                            ('cosine_weighted', 'COSINE', g['weights'])):
+    np.testing.assert_allclose(O.spectral_loss(t, a, sizes, loss_type, weights=w, **kw), np.ravel(g[key])[0], rtol=1e-6)
+  np.testing.assert_allclose(O.spectral_loss(t, a, (256,), 'L2', mag_weight=0.0, delta_time_weight=1.0),
+                             np.ravel(g['l2_delta_time_only'])[0], rtol=1e-6)
+  np.testing.assert_allclose(O.spectral_loss(t, a, (2048, 64), 'L1', mag_weight=0.0, cumsum_freq_weight=1.0),
+                             np.ravel(g['l1_cumsum_only'])[0], rtol=1e-6)
+  # core.diff / cumsum by hand on a tiny spectrogram
+  x = np.arange(24, dtype=np.float32).reshape(1, 4, 6) ** 2
+  np.testing.assert_array_equal(O.diff(x, 1), x[:, 1:] - x[:, :-1])
+  np.testing.assert_array_equal(O.diff(x, 2), x[:, :, 1:] - x[:, :, :-1])
