@@ -1,0 +1,47 @@
+#!/bin/bash
+# One GPU-box session for the round's evidence: parity tests, smoke, bench, rocprof kernel traces, PMC traffic, SQ counters.
+# Usage (from the build container): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+export DDSP_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl
+rm -f $DDSP_PARITY_LOG
+echo "== pytest -m gpu (general first, no -x)"
+timeout 900 python -m pytest tests/test_gpu_parity_general.py tests/test_gpu_parity.py -m gpu -q 2>&1 | tee $OUT/pytest_gpu_full.txt | tail -8
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
+echo "== bench, as the driver runs it (--steps 20 --warmup 5)"
+timeout 600 python bench.py --steps 20 --warmup 5 2>$OUT/bench_driver.err | tail -1 > $OUT/bench_driver_like.json; cut -c1-300 $OUT/bench_driver_like.json
+echo "== bench (defaults: 1000 steps)"
+timeout 600 python bench.py --no-cpu-baseline --also-other-mode 2>$OUT/bench_1000.err | tail -1 > $OUT/bench_1000.json
+python - <<PY
+import json
+d = json.load(open('$OUT/bench_1000.json'))
+print('B=32:', round(d['value']), 'Msamples/s', round(d['ms_per_step'] * 1e3, 2), 'us  whole-step frac', round(d['roofline']['whole_step']['frac'], 4),
+      'dominant', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'], 2), 'us frac', round(d['roofline']['frac'], 4), 'other mode', d.get('other_issue_mode'))
+print('isolated', d['kernel_breakdown_us_isolated'])
+ns = d['north_star_shape']
+print('B=128:', round(ns['value']), round(ns['ms_per_step'] * 1e3, 2), 'us frac', round(ns['whole_step']['frac'], 4), ns['kernel_breakdown_us'], ns.get('dominant_kernel', {}).get('frac'))
+PY
+echo "== rocprofv3 kernel trace (bench defaults, batch 32)"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b32.csv; head -6 $f | cut -c1-200; done
+tail -1 $OUT/rocprof_bench.log > $OUT/bench_b32_under_rocprof.json
+echo "== rocprofv3 kernel trace, batch 128 (north-star shape, one stream)"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
+for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b128.csv; head -6 $f | cut -c1-200; done
+tail -1 $OUT/rocprof_bench_b128.log > $OUT/bench_b128_under_rocprof.json
+rm -rf $OUT/prof $OUT/prof128
+echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
+bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 | tail -30 > $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
+bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 | tail -30 > $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
+echo "== PMC: SQ counters, batch 128"
+bash tools/pmc.sh $TAG/pmc_sq_b128 128 > $OUT/pmc_sq_counters_b128.log 2>&1; cp $OUT/pmc_sq_b128/summary.txt $OUT/pmc_sq_counters_b128.txt 2>/dev/null; grep -A30 "== harm_table\|== noise_mfma" $OUT/pmc_sq_counters_b128.txt | grep "==\|SQ_WAIT_ANY\|SQ_WAVE_CYCLES\|SQ_LDS_BANK\|SQ_LDS_IDX\|SQ_INSTS_VALU \|SQ_ACTIVE_INST_ANY\|SQ_WAIT_INST_ANY" | head -20
+rm -rf $OUT/pmc_traffic_b32 $OUT/pmc_traffic_b128 $OUT/pmc_sq_b128
+echo "== next-row benches (Reverb, SpectralLoss, backward, streaming)"
+timeout 300 python tools/bench_reverb.py 32 2>&1 | tail -1 | tee $OUT/bench_reverb_b32.json | cut -c1-200
+timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json | cut -c1-200
+timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json | cut -c1-300
+timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json | cut -c1-300
+echo "== done"
