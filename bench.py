@@ -485,8 +485,11 @@ def main(argv=None):
   if dry:
     breakdown = {'dry_run_step': (0.6, 3)}
   else:
-    _lib.profile_begin(None, max_records=64)
-    for _ in range(3):
+    for _ in range(5):               # the first one-stream launches after the two-stream phase are not representative
+      step(two_streams=False)
+    torch.cuda.synchronize()
+    _lib.profile_begin(None, max_records=256)
+    for _ in range(10):
       step(two_streams=False)
     torch.cuda.synchronize()
     breakdown = _lib.profile_end()

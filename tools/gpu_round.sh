@@ -34,8 +34,8 @@ for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do cp $f $OU
 tail -1 $OUT/rocprof_bench_b128.log > $OUT/bench_b128_under_rocprof.json
 rm -rf $OUT/prof $OUT/prof128
 echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
-bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 | tail -30 > $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
-bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 | tail -30 > $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
+bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 > /dev/null 2>&1; cp $OUT/pmc_traffic_b32/pmc_traffic.json $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
+bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 > /dev/null 2>&1; cp $OUT/pmc_traffic_b128/pmc_traffic.json $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
 echo "== PMC: SQ counters, batch 128"
 bash tools/pmc.sh $TAG/pmc_sq_b128 128 > $OUT/pmc_sq_counters_b128.log 2>&1; cp $OUT/pmc_sq_b128/summary.txt $OUT/pmc_sq_counters_b128.txt 2>/dev/null; grep -A30 "== harm_table\|== noise_mfma" $OUT/pmc_sq_counters_b128.txt | grep "==\|SQ_WAIT_ANY\|SQ_WAVE_CYCLES\|SQ_LDS_BANK\|SQ_LDS_IDX\|SQ_INSTS_VALU \|SQ_ACTIVE_INST_ANY\|SQ_WAIT_INST_ANY" | head -20
 rm -rf $OUT/pmc_traffic_b32 $OUT/pmc_traffic_b128 $OUT/pmc_sq_b128
