@@ -497,6 +497,7 @@ def main(argv=None):
 
   # ---- timed regions: exactly K steps each, barrier + synchronize on both sides --------------------------
   e_probe, _, _ = timed_region(step, a.steps, overlap)          # untimed probe: sizes the repeat count
+  e_probe = max_over_ranks(e_probe)                             # every rank must run the SAME number of regions (collectives inside)
   repeats = a.repeats if a.repeats > 0 else int(min(200, max(10, 0.1 / max(e_probe, 1e-6))))
   if not dry:
     _lib.profile_begin([dominant], max_records=2 * a.steps * repeats // max(a.event_stride, 1) + 64,
