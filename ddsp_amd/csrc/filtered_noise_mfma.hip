@@ -24,13 +24,15 @@
 // one; at 4-byte alignment two ds_read2_b32 cost 1.7x (profiles/r02a_microbench_lds_unaligned.txt).  The reversed noise
 // is therefore kept twice, the second copy shifted by one element, and a row reads the copy its parity selects.
 //
-// One block = 62 output frames (3968 samples) of one batch row = 64 staged frames (two of halo), 8 wavefronts:
-//   wavefronts 0-3 design the taps: each fetches the 16 x 65 magnitudes of its 16 frames straight from HBM into the
-//      B-fragment layout (no LDS staging), exp_sigmoid, hi / lo split, 12 MFMAs against the constant cosine fragments
-//      (fp16 hi / lo pairs made at compile time), window, hi / lo split of the taps into the LDS tap table;
-//   wavefronts 4-7 meanwhile generate the Philox noise tile (reversed, hi / lo split, two copies);
-//   one barrier; then all eight run the FIR: a wavefront walks 4 pairs (one extra pair before them only to build the
-//   carry; fully unrolled: every LDS address is a per-lane base plus an immediate), stores 128 samples per pair.
+// One tile = 62 output frames (3968 samples) of one batch row = 64 staged frames (the first two are history).  A persistent
+// block of 16 wavefronts per CU walks its tiles with two LDS buffers and one barrier per tile (see the kernel):
+//   wavefronts 0-7 make the NEXT tile: the 64 x 65 magnitudes straight from HBM into B-fragments (no LDS staging),
+//      exp_sigmoid, hi / lo split, 6 MFMAs each against the constant cosine fragments (fp16 hi / lo pairs made at compile
+//      time), window, hi / lo split of the taps into the LDS tap table; and the Philox noise tile (reversed, hi / lo
+//      split, two copies);
+//   wavefronts 8-15 run the FIR of the CURRENT tile: four pairs each, fully unrolled (every LDS address is a per-lane
+//      base plus an immediate), 128 samples stored per pair; the 128 outputs that straddle two wavefronts are finished
+//      a tile later from a right half left in LDS.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -44,9 +46,11 @@
 
 namespace ddsp {
 
-constexpr int kMfFrames = 62;                  // output frames per block
-constexpr int kMfRows = 64;                    // staged frames: 2 of halo + 62
-constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per block
+// A tile: 64 staged frames = 32 pairs; the first pair is only history (the 128 taps reach 127 samples back), 31 pairs
+// = 62 frames are output.
+constexpr int kMfFrames = 62;                  // output frames per tile
+constexpr int kMfRows = 64;                    // staged frames: 2 of history + 62
+constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per tile
 constexpr int kMfWaves = 16;                 // 8 producer (taps + noise) + 8 FIR wavefronts
 constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
 // tap table: a hi plane and a lo plane; per row 16 groups of 8 taps (16 bytes) + one group of zeros that lanes outside the
@@ -78,6 +82,8 @@ struct MfArgs {
   uint32_t k0, k1;
   uint64_t batch_offset;
   int tiles_per_row, n_tiles;       // tiles of 62 frames per batch row; B * tiles_per_row
+  int dbg_skip;
+  int dbg_wave;                     // the FIR wavefront (8 .. 15) whose times are stamped; the producer is dbg_wave - 8
   long long* dbg;                   // block 0's per-tick stamps [16 ticks][3 roles][begin, end] (tools/exp_noise_fir.py), or null
 };
 
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][2 * kMfTapPlane];       // hi plane, lo plane
   __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
+  __shared__ __attribute__((aligned(16))) float s_carry[2][7][128];       // right halves handed from FIR wavefront w to w + 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     }
 #pragma unroll 1
     for (int tick = -1; tick < n_my; ++tick) {
-      if (wave == 0) DDSP_MF_STAMP(tick, 0, 0);
+      if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
       // magnitudes of tile tick + 2, to be used a tick from now (past the block's last tile: the last one again)
       MfU4f nq[4];
       float n_last;
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         for (int c4 = 0; c4 < 4; ++c4) nq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
         n_last = src[64];
       }
-      if (tick + 1 < n_my) {
+      if (tick + 1 < n_my && !((p.dbg_skip & 1) && tick >= 1)) {
         const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)rel0;
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
           *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
           *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
         }
-        if (wave == 0) DDSP_MF_STAMP(tick, 1, 0);
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
         // ---- the taps n = 16 mt .. + 15 (and their mirror images) of rows 16 rg .. + 15 ---------------------------------
         // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
         const int own_lo = (z0 == 0) ? 0 : f_first + 2;
@@ -353,44 +360,64 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
           }
         }
-        if (wave == 0) DDSP_MF_STAMP(tick, 1, 1);
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 1);
       }
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) rq[c4] = nq[c4];
       r_last = n_last;
-      if (wave == 0) DDSP_MF_STAMP(tick, 0, 1);
+      if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
       __syncthreads();
     }
   } else {
     // =========================== FIR wavefronts: pairs of frames on the matrix cores =================================
-    // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block P = 2 c + (g >> 1) of
-    // the pair's ten 16-sample blocks (P < 5: first frame, block p = P; else second frame, p = P - 5), d = 8 (g & 1) + e.
+    // per-lane constants of the five k-steps.  Step c, lane (i = lane & 15, g = lane >> 4): block p = c of the pair's
+    // first (g < 2) or second (g >= 2) frame, d = 8 (g & 1) + e.
     //   A (row b = i): x_frame[16 p + b - d], e = 0..7 = reversed elements u .. u + 7, u = 79 + 80 s - 16 p - b + 8 (g & 1)
     //   B (col a = i): h_row[16 (a' - p) + 8 (g & 1) + e], a' = a - 4 (second frame); zero group outside 0 <= a' - p <= 7
-    // FIR wavefront cw: output pairs 4 cw + 1 .. 4 cw + 4 (pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are
-    // output), preceded by pair 4 cw, whose left half belongs to the previous wavefront (or, pair 0, to the previous
-    // tile).  Five pairs, unrolled: every LDS address is a per-lane register plus an immediate.
+    // With p = c in every lane, B of step c + 1 is B of step c moved ONE column up (a' - p - 1 is what column a - 1 had),
+    // zeros entering at column 0: only step 0 reads the tap table, steps 1 .. 4 are 8 DPP moves each (row_shr:1).  The LDS
+    // is what bounds the FIR wavefronts; this takes 8 of a pass's 30 reads and 40 % of its bytes away.
+    // Pair P = staged frames 2 P, 2 P + 1; pairs 1 .. 31 are output.  FIR wavefront cw walks the four pairs 4 cw ..
+    // 4 cw + 3 (unrolled: every LDS address is a per-lane register plus an immediate).  Pair 0 only builds the carry
+    // into pair 1 (its own outputs belong to the previous tile).  The left half of wavefront cw >= 1's first pair lacks
+    // what pair 4 cw - 1 spills into it: that right half is left in LDS by wavefront cw - 1 (s_carry), the incomplete
+    // left half stays in registers, and the two are added and stored at the start of the NEXT tick, behind the block's
+    // barrier (a warm-up pair per wavefront instead would be a fifth pass: 25 % more MFMAs and LDS reads, and the LDS is
+    // what bounds this phase).
     const int cw = wave - 8;
     const int p_first = 4 * cw;
+    mf_f32x4 kept = {0.f, 0.f, 0.f, 0.f};      // the incomplete left half of this wavefront's first pair (cw >= 1), last tile
+    float* kept_ot = nullptr;                  // where it goes: the tile's base pointer, offset and bounds of the previous tick
+    long kept_n = 0;
     const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
-    int a_hi0[5], a_lo0[5], b_ptr0[5], b_off[5];
+    const int second = mg >> 1;
+    int a_hi0[5], a_lo0[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      const int P = 2 * c + (mg >> 1);
-      const int second = P >= 5 ? 1 : 0;
-      const int pp = P - 5 * second;
-      const int u = 79 + kMfXStride * second - 16 * pp - mi + 8 * (mg & 1);            // relative to the pair's first frame
+      const int u = 79 + kMfXStride * second - 16 * c - mi + 8 * (mg & 1);             // relative to the pair's first frame
       // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
       a_hi0[c] = xsel + ((u + 1) >> 1) * 4;
       a_lo0[c] = a_hi0[c] + kMfXPlane;
-      const int q = (mi - 4 * second) - pp;
-      b_off[c] = (q >= 0 && q <= 7) ? (2 * q + (mg & 1)) * 16 : 256;
-      b_ptr0[c] = (2 * p_first + second) * kMfTapRowBytes + b_off[c];
     }
+    const int q0 = mi - 4 * second;
+    const int b_off = (q0 >= 0 && q0 <= 7) ? (2 * q0 + (mg & 1)) * 16 : 256;
+    const int b_ptr0 = (2 * p_first + second) * kMfTapRowBytes + b_off;
+    const int lane_off = 16 * mi + 4 * mg;
+    // the deferred boundary outputs of the previous tile: kept left half + the neighbour's right half
+    auto flush_kept = [&](int parity) {
+      if (cw >= 1 && kept_ot != nullptr && mi < 8) {
+        const float4 cr = *reinterpret_cast<const float4*>(&s_carry[parity][cw - 1][lane_off]);
+        const float v[4] = {kept[0] + cr.x, kept[1] + cr.y, kept[2] + cr.z, kept[3] + cr.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kept_n + lane_off + r >= 0 && kept_n + lane_off + r < p.N) kept_ot[lane_off + r] = v[r];
+      }
+    };
 #pragma unroll 1
     for (int tick = -1; tick < n_my; ++tick) {
-      if (wave == 8) DDSP_MF_STAMP(tick, 2, 0);
-      if (tick >= 0) {
+      if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 0);
+      if (tick >= 1) flush_kept((tick - 1) & 1);
+      if (tick >= 0 && !(p.dbg_skip & 2)) {
         const int T = (int)blockIdx.x + tick * (int)gridDim.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)f_first;
@@ -400,51 +427,61 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         // out index of this lane's first value of pair 8 cw: z = z0 - 128 + 128 P + 16 a + 4 g (+ r)
         const long n_tile = (long)z0 - 128 + 128L * p_first - p.start;
         // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
-        const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 5 <= (long)p.N && (((p.start | p.N) & 1) == 0);
+        const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 4 <= (long)p.N && (((p.start | p.N) & 1) == 0);
         float* __restrict__ ot = o + n_tile;                               // wave-uniform base; lanes add a 32-bit offset
-        const int lane_off = 16 * mi + 4 * mg;
         mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-        int a_hi[5], a_lo[5], b_ptr[5];
+        int a_hi[5], a_lo[5], b_ptr = b_ptr0;
+        DDSP_KEEP_IN_VGPR(b_ptr);
+        __builtin_assume((b_ptr & 15) == 0);
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-          a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c]; b_ptr[c] = b_ptr0[c];
+          a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c];
           DDSP_KEEP_IN_VGPR(a_hi[c]);
           DDSP_KEEP_IN_VGPR(a_lo[c]);
-          DDSP_KEEP_IN_VGPR(b_ptr[c]);
           // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32
           // each; a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
           __builtin_assume((a_hi[c] & 3) == 0);
           __builtin_assume((a_lo[c] & 3) == 0);
-          __builtin_assume((b_ptr[c] & 15) == 0);
         }
-        // (the last FIR wavefront has three output pairs: its fifth pair reads past the staged frames - whatever the LDS
-        // holds there, or zeros beyond its end - and is not stored; no control flow inside the pipeline, so the
-        // compiler's s_waitcnt counts stay exact)
-        // The 5 x 5 (pair, k-step) sequence runs as ONE software pipeline: the fragment reads of step j + 3 are issued right
+        // The 4 x 5 (pair, k-step) sequence runs as ONE software pipeline (no control flow inside, so the compiler's
+        // s_waitcnt counts stay exact): the fragment reads of step j + 3 are issued right
         // after the MFMAs of step j (three steps = 18 LDS operations in flight per wavefront: the LDS only reaches its rate
         // with many operations outstanding, and two FIR wavefronts share a SIMD), the epilogue of a pair (combine, store,
         // shift the right half over) runs under the reads of the next pair.  The carry enters in the epilogue, not as
         // the accumulator's start value, so no MFMA waits for a previous pair.
-        mf_f16x8 fah[3], fal[3], fbh[3], fbl[3];
+        mf_f16x8 fah[3], fal[3], fbh_in[2], fbl_in[2], fbh, fbl;
         auto load_step = [&](int j, int slot) {
           const int it = j / 5, c = j - 5 * it;
           const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it);
           const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it);
           fah[slot] = mf_frag(qh.x, qh.y, qh.z, qh.w);
           fal[slot] = mf_frag(ql.x, ql.y, ql.z, ql.w);
-          // steps 0, 1: first frame; 3, 4: second; step 2: first for g < 2, second for g >= 2
-          const unsigned char* tr;
-          if (FS64) {
-            tr = s_taps + b_ptr[c] + 2 * kMfTapRowBytes * it;
-          } else {
-            // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
-            const int P = p_first + it;
-            const int rowA = (int)(((float)(rel0 + 128 * P) + 0.5f) * p.inv_fs);
-            const int rowB = (int)(((float)(rel0 + 128 * P + 64) + 0.5f) * p.inv_fs);
-            tr = s_taps + (((c < 2) || (c == 2 && (mg >> 1) == 0)) ? rowA : rowB) * kMfTapRowBytes + b_off[c];
+          if (c == 0) {
+            // the pair's taps: first frame's row in lanes g < 2, second frame's in g >= 2
+            const unsigned char* tr;
+            if (FS64) {
+              tr = s_taps + b_ptr + 2 * kMfTapRowBytes * it;
+            } else {
+              // tap rows of the pair's two frames (frame size fs = 64 c: c staged frames share a row)
+              const int P = p_first + it;
+              const int row = (int)(((float)(rel0 + 128 * P + 64 * second) + 0.5f) * p.inv_fs);
+              tr = s_taps + row * kMfTapRowBytes + b_off;
+            }
+            fbh_in[it & 1] = *reinterpret_cast<const mf_f16x8*>(tr);
+            fbl_in[it & 1] = *reinterpret_cast<const mf_f16x8*>(tr + kMfTapPlane);
           }
-          fbh[slot] = *reinterpret_cast<const mf_f16x8*>(tr);
-          fbl[slot] = *reinterpret_cast<const mf_f16x8*>(tr + kMfTapPlane);
+        };
+        // one column up (row_shr:1 within the 16 lanes of a g; column 0 receives zeros)
+        auto column_up = [](mf_f16x8 v) {
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          const i32x4 w = __builtin_bit_cast(i32x4, v);
+          i32x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int t = w[k];                // (a scalar temporary: see the carry below)
+            o[k] = __builtin_amdgcn_update_dpp(0, t, 0x111, 0xF, 0xF, true);
+          }
+          return __builtin_bit_cast(mf_f16x8, o);
         };
         load_step(0, 0);
         load_step(1, 1);
@@ -454,21 +491,29 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         auto pipeline = [&](auto interior_tag) {
           constexpr bool kInterior = decltype(interior_tag)::value;
 #pragma unroll
-          for (int j = 0; j < 25; ++j) {
+          for (int j = 0; j < 20; ++j) {
             const int it = j / 5, c = j - 5 * it, slot = j % 3;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbh[slot], acc, 0, 0, 0);
-            acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbl[slot], acc_hl, 0, 0, 0);
-            acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh[slot], acc_lh, 0, 0, 0);
+            if (c == 0) { fbh = fbh_in[it & 1]; fbl = fbl_in[it & 1]; }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbh, acc, 0, 0, 0);
+#ifndef DDSP_MF_X_ONE_MFMA
+            acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbl, acc_hl, 0, 0, 0);
+            acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh, acc_lh, 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            if (j + 3 < 25) load_step(j + 3, slot);
+            if (j + 3 < 20) load_step(j + 3, slot);
+#ifndef DDSP_MF_X_NO_DPP
+            if (c < 4) { fbh = column_up(fbh); fbl = column_up(fbl); }      // under the MFMAs
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (c == 4) {
               const mf_f32x4 comb = (acc + carry) + (acc_hl + acc_lh) * (1.0f / kMfLoScale);
               acc = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
               acc_hl = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
               acc_lh = (mf_f32x4){0.f, 0.f, 0.f, 0.f};
-              // D[row b = 4 g + r][col a = i]: columns 0..7 are complete
-              if (it > 0 && mi < 8 && p_first + it < kMfRows / 2) {
+              // D[row b = 4 g + r][col a = i]: columns 0..7 are complete (the first pair's: see above)
+              if (it == 0) {
+                kept = comb;
+              } else if (mi < 8) {
                 const int idx = lane_off + 128 * it;                         // out index n = n_tile + idx
                 if (kInterior) {
                   *reinterpret_cast<float2*>(ot + idx) = make_float2(comb[0], comb[1]);
@@ -488,15 +533,21 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
                 const float v = comb[r];
                 carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
               }
+              // the last pair's right half: the next wavefront's missing part (the last wavefront's lies past the tile)
+              if (it == 3 && cw < 7 && mi >= 8)
+                *reinterpret_cast<float4*>(&s_carry[tick & 1][cw][lane_off - 128]) = make_float4(comb[0], comb[1], comb[2], comb[3]);
             }
           }
         };
         if (interior) pipeline(std::true_type{});
         else pipeline(std::false_type{});
+        kept_ot = ot;
+        kept_n = n_tile;
       }
-      if (wave == 8) DDSP_MF_STAMP(tick, 2, 1);
+      if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 1);
       __syncthreads();
     }
+    flush_kept((n_my - 1) & 1);                // the last tile's boundaries (nothing writes s_carry any more)
   }
 #undef DDSP_MF_STAMP
 #undef DDSP_MF_TILE
@@ -516,6 +567,10 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
   q.fs = (N + F - 1) / F; q.inv_fs = 1.0f / (float)q.fs;
   q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
   q.dbg = dbg;
+  static const int dbg_wave = [] { const char* e = getenv("DDSP_MF_DBG_WAVE"); const int v = e ? atoi(e) : 8; return v >= 8 && v < 16 ? v : 8; }();
+  q.dbg_wave = dbg_wave;
+  static const int dbg_skip = [] { const char* e = getenv("DDSP_MF_DBG_SKIP"); return e ? atoi(e) : 0; }();
+  q.dbg_skip = dbg_skip;
   q.tiles_per_row = (N + start + kMfTile - 1) / kMfTile;
   q.n_tiles = B * q.tiles_per_row;
   // persistent grid: one block of 12 wavefronts per CU (two LDS buffers of 76 KB)
