@@ -140,4 +140,25 @@ __device__ __forceinline__ float philox_noise(uint32_t n, uint64_t row, uint32_t
   return bits_to_pm1(bits);
 }
 
+// A 16-byte global load that is ISSUED where it is written and whose result is first touched at load_settle():
+// a plain load may be sunk by the optimiser to just before its first use (it moved four of them below a block of
+// MFMAs that was there to hide their latency - harmonic_table.hip), a volatile assembly statement may not.
+typedef float ddsp_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_issue(ddsp_f32x4& dst, const float4* src) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src));
+#else
+  const float4 v = *src;
+  dst = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+#endif
+}
+// every load issued so far has landed; the four values are ordered behind the wait
+__device__ __forceinline__ void load_settle(ddsp_f32x4& a, ddsp_f32x4& b, ddsp_f32x4& c, ddsp_f32x4& d) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#else
+  (void)a; (void)b; (void)c; (void)d;
+#endif
+}
+
 }  // namespace ddsp

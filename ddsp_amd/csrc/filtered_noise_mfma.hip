@@ -495,15 +495,11 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             const int it = j / 5, c = j - 5 * it, slot = j % 3;
             if (c == 0) { fbh = fbh_in[it & 1]; fbl = fbl_in[it & 1]; }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbh, acc, 0, 0, 0);
-#ifndef DDSP_MF_X_ONE_MFMA
             acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbl, acc_hl, 0, 0, 0);
             acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh, acc_lh, 0, 0, 0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if (j + 3 < 20) load_step(j + 3, slot);
-#ifndef DDSP_MF_X_NO_DPP
             if (c < 4) { fbh = column_up(fbh); fbl = column_up(fbl); }      // under the MFMAs
-#endif
             __builtin_amdgcn_sched_barrier(0);
             if (c == 4) {
               const mf_f32x4 comb = (acc + carry) + (acc_hl + acc_lh) * (1.0f / kMfLoScale);

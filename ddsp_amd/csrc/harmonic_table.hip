@@ -43,8 +43,10 @@ constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, kWtHalf + k
 constexpr int kWtNQ = kWtT / 4;      // positions produced by the matrix product
 constexpr int kWtH = 4;              // halo entries on either side (>= W/2)
 constexpr int kWtTS = 268;           // table row stride in floats: 4*odd, so 16 rows' b128 writes spread over the banks
-constexpr int kWtRows = 16;          // amplitude rows per chunk (MFMA N)
-constexpr int kWtFrames = 15;        // frames per chunk: row r+1 is the "next" row of frame r
+constexpr int kWtRowTiles = 2;       // MFMA N-tiles of 16 amplitude rows per chunk
+constexpr int kWtRows = 16 * kWtRowTiles;    // amplitude rows per chunk
+constexpr int kWtFrames = kWtRows - 1;       // frames per chunk (31): row r+1 is the "next" row of frame r
+constexpr int kWtNT = 4;             // tiles of 64 samples an S-wavefront carries through phase B together
 constexpr int kWtPS = 72;            // row stride of an amplitude plane (fp16 elements; odd / even harmonics apart): 144 B
 constexpr float kWtLoScale = 2048.0f; // x = hi + lo / 2048 in two fp16 numbers
 constexpr int kWtRS = 132;           // row stride of the raw staging buffer: 128 harmonics, f0, amplitude
@@ -103,31 +105,23 @@ __device__ __forceinline__ void wt_pair(float z, float z2, float& w_lo, float& w
   w_hi = fmaf(-z, o, e);
 }
 
-template <int W, int P>
-__device__ __forceinline__ void wt_taps(const float* __restrict__ t0, float z, float z2, float& acc0, float& acc1) {
-  float w_lo, w_hi;
-  wt_pair<W, P>(z, z2, w_lo, w_hi);
-  acc0 = fmaf(w_lo, t0[-P], acc0);
-  acc0 = fmaf(w_hi, t0[1 + P], acc0);
-  acc1 = fmaf(w_lo, t0[kWtTS - P], acc1);
-  acc1 = fmaf(w_hi, t0[kWtTS + 1 + P], acc1);
-  if constexpr (P + 1 < W / 2) wt_taps<W, P + 1>(t0, z, z2, acc0, acc1);
-}
-
-// the same for two tiles at once (two independent chains per instruction slot)
-template <int W, int P>
-__device__ __forceinline__ void wt_taps2(const float* __restrict__ ta, const float* __restrict__ tb, float za, float zb,
-                                         float za2, float zb2, float (&acc0)[2], float (&acc1)[2]) {
-  float la, ha, lb, hb;
-  wt_pair<W, P>(za, za2, la, ha);
-  wt_pair<W, P>(zb, zb2, lb, hb);
-  const float a0 = ta[-P], a1 = ta[1 + P], a2 = ta[kWtTS - P], a3 = ta[kWtTS + 1 + P];
-  const float b0 = tb[-P], b1 = tb[1 + P], b2 = tb[kWtTS - P], b3 = tb[kWtTS + 1 + P];
-  acc0[0] = fmaf(la, a0, acc0[0]);  acc0[1] = fmaf(lb, b0, acc0[1]);
-  acc1[0] = fmaf(la, a2, acc1[0]);  acc1[1] = fmaf(lb, b2, acc1[1]);
-  acc0[0] = fmaf(ha, a1, acc0[0]);  acc0[1] = fmaf(hb, b1, acc0[1]);
-  acc1[0] = fmaf(ha, a3, acc1[0]);  acc1[1] = fmaf(hb, b3, acc1[1]);
-  if constexpr (P + 1 < W / 2) wt_taps2<W, P + 1>(ta, tb, za, zb, za2, zb2, acc0, acc1);
+// NT tiles at once (NT independent chains per instruction slot): every stage of a tile is a chain of dependent
+// instructions - fp64 phase, LDS reads, the window polynomials - and a wavefront with one or two chains leaves most of
+// its issue slots empty
+template <int W, int P, int NT>
+__device__ __forceinline__ void wt_taps(const float* const (&t)[kWtNT], const float (&z)[kWtNT], const float (&z2)[kWtNT],
+                                        float (&acc0)[kWtNT], float (&acc1)[kWtNT]) {
+  float lo[NT], hi[NT], a0[NT], a1[NT], a2[NT], a3[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    wt_pair<W, P>(z[u], z2[u], lo[u], hi[u]);
+    a0[u] = t[u][-P]; a1[u] = t[u][1 + P]; a2[u] = t[u][kWtTS - P]; a3[u] = t[u][kWtTS + 1 + P];
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) { acc0[u] = fmaf(lo[u], a0[u], acc0[u]); acc1[u] = fmaf(lo[u], a2[u], acc1[u]); }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) { acc0[u] = fmaf(hi[u], a1[u], acc0[u]); acc1[u] = fmaf(hi[u], a3[u], acc1[u]); }
+  if constexpr (P + 1 < W / 2) wt_taps<W, P + 1, NT>(t, z, z2, acc0, acc1);
 }
 
 // The per-frame phase tables of a chunk (one wavefront, lanes = frames).  (Handing this block of fp64 work to a
@@ -143,11 +137,18 @@ __device__ __forceinline__ void wt_phase_tables(const float* __restrict__ raw, C
   const float fj = raw[min(lane, nfr) * kWtRS + 128], fj1 = raw[min(lane + 1, nfr) * kWtRS + 128];
   const double fa = (double)fj, fb = (double)fj1;
   const double mine = (lane < nfr) ? fa : 0.0;
-  double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..15)
+  double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..31)
   incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
   incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
   incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
   incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
+  {                                                   // lanes 16..31: + the total of lanes 0..15
+    const long long bits = __builtin_bit_cast(long long, incl);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits & 0xffffffffll), 15);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits >> 32), 15);
+    const double first16 = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+    if (lane >= 16) incl += first16;
+  }
   const double s_excl = before + (incl - mine);
   const double run = p.hop_d * s_excl + (fa - (double)f0_first) * p.half_hm1;
   const double cyc = run * p.inv_sr;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             alo[par][tt][ks][e] = (_Float16)((v - (float)h) * kWtLoScale);
           }
     int lb = first_b, lc = first_c;               // position of the chunk whose rows are fetched next
+    int qb = first_b, qc = first_c;               // position of the chunk whose phase tables are made next
 
     for (int tick = -3; tick < n_my; ++tick) {
       DDSP_WT_STAMP(0);
@@ -257,10 +259,16 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
       // block's last chunk the last one is simply fetched again into a staging slot nobody reads.
       const int lj0 = lc * kWtFrames;
       const int kqc = min(kq, K4 - 1);
-      const int lrow0 = lb * F + min(lj0 + rw * 4 + sub, F - 1), lrow1 = lb * F + min(lj0 + rw * 4 + 2 + sub, F - 1);
-      const float4 lx0 = hd4[(size_t)lrow0 * K4 + kqc], lx1 = hd4[(size_t)lrow1 * K4 + kqc];
-      const float lf00 = f0_all[lrow0], lf01 = f0_all[lrow1];
-      const float lamp0 = amplitudes[lrow0], lamp1 = amplitudes[lrow1];
+      // this wavefront's eight rows of the chunk, two (sub = 0, 1) per load instruction
+      ddsp_f32x4 lx[4];
+      float lf0[4], lamp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int lrow = lb * F + min(lj0 + rw * 8 + 2 * i + sub, F - 1);
+        load_issue(lx[i], hd4 + ((size_t)lrow * K4 + kqc));
+        lf0[i] = f0_all[lrow];
+        lamp[i] = amplitudes[lrow];
+      }
       // f0 of the frames before the chunk, for the fp64 phase prefix: float4 number lane + 64 rw of the row
       // (rows of up to 1024 frames in one go), the <= 3 frames past the last whole float4 on wavefront 0
       const float* __restrict__ f0row = f0_all + (size_t)lb * F;
@@ -273,8 +281,10 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
       DDSP_WT_STAMP(1);
       // ---------------- table of chunk tick+1: O and E on the quarter range -----------------------------------
       if (tick + 1 >= 0 && tick + 1 < n_my) {
-        // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row j][32 ks + 8 g + e]
-        const _Float16* bsrc = planes_all[(tick + 1) % 3] + mi * kWtPS + 8 * mg;
+#pragma unroll
+       for (int rt = 0; rt < kWtRowTiles; ++rt) {
+        // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row 16 rt + j][32 ks + 8 g + e]
+        const _Float16* bsrc = planes_all[(tick + 1) % 3] + (16 * rt + mi) * kWtPS + 8 * mg;
         f32x4 acc[2][2], accx[2][2];
 #pragma unroll
         for (int par = 0; par < 2; ++par)
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
               accx[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[par][tt], 0, 0, 0);
           }
         // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
-        float* trow = tab_all[(tick + 1) & 1] + mi * kWtTS + kWtH;
+        float* trow = tab_all[(tick + 1) & 1] + (16 * rt + mi) * kWtTS + kWtH;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int n0 = 16 * (2 * rw + tt) + 4 * mg;
@@ -315,17 +325,18 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             *reinterpret_cast<f32x4*>(trow + kWtHalf) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
           }
         }
+       }
       }
       DDSP_WT_STAMP(2);
       // ---------------- rows of chunk tick+3: into the staging buffer --------------------------------------------
       {
         float* raw = raw_all[(tick + 3) & 1];
-        const int r0 = rw * 4 + sub;
-        *reinterpret_cast<float4*>(raw + r0 * kWtRS + 4 * kq) = lx0;
-        *reinterpret_cast<float4*>(raw + (r0 + 2) * kWtRS + 4 * kq) = lx1;
-        if (kq == 0) {
-          *reinterpret_cast<float2*>(raw + r0 * kWtRS + 128) = make_float2(lf00, lamp0);
-          *reinterpret_cast<float2*>(raw + (r0 + 2) * kWtRS + 128) = make_float2(lf01, lamp1);
+        const int r0 = rw * 8 + sub;
+        load_settle(lx[0], lx[1], lx[2], lx[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<ddsp_f32x4*>(raw + (r0 + 2 * i) * kWtRS + 4 * kq) = lx[i];
+          if (kq == 0) *reinterpret_cast<float2*>(raw + (r0 + 2 * i) * kWtRS + 128) = make_float2(lf0[i], lamp[i]);
         }
         double part = (m4 < n4) ? ((double)pf.x + (double)pf.y) + ((double)pf.z + (double)pf.w) : 0.0;
         if (rw == 0 && jt < lj0 && (jt >> 2) == n4 && p.f0_vec) part += (double)ptail;
@@ -339,6 +350,13 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         }
       }
       if (tick + 3 < n_my - 1) DDSP_WT_ADVANCE(lb, lc);
+      // ---------------- the per-frame phase tables of chunk tick+2 (its rows were staged a tick ago) ------------
+      // one wavefront, lanes = frames; here, in the slack a T-wavefront has before the barrier, and not on the
+      // S-wavefront that finishes last (profiles/r02o_*: that one set the length of the tick)
+      if (tick + 2 >= 0 && tick + 2 < n_my) {
+        if (rw == 3) wt_phase_tables(raw_all[(tick + 2) & 1], t_all[(tick + 2) % 3], lane, min(kWtFrames, F - qc * kWtFrames), K, p);
+        DDSP_WT_ADVANCE(qb, qc);
+      }
       DDSP_WT_STAMP(3);
       __syncthreads();
       DDSP_WT_STAMP(4);
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     float ipsi[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
-    const int arow = rw * 2 + sub;                 // the chunk row this lane works on in phase A
+    const int arow0 = rw * 2 + sub;                // the chunk rows this lane works on in phase A: arow0, arow0 + 16
     int bb = first_b, bc = first_c;                // position of the chunk of the next phase B
     int ab = first_b, ac = first_c;                // position of the chunk of the next phase A
 
@@ -367,12 +385,11 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
         const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
         const int tiles_per_frame = hop >> 6;
         const int n_tiles = nfr * tiles_per_frame;
-        // two tiles per wavefront move through the stages together (u = 0, 1): each stage is a chain of dependent
-        // instructions, and a wavefront with a single chain leaves most issue slots empty
+        // up to four tiles per wavefront move through the stages together (u = 0 .. NT-1), see wt_taps
         auto tiles = [&](int tile, auto nt_tag) {
-          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + 8 (NT == 2) or tile alone
-          int q[2], r[2];
-          double cyc[2];
+          constexpr int NT = decltype(nt_tag)::value;          // tiles tile, tile + 8, .. tile + 8 (NT - 1)
+          int q[kWtNT], r[kWtNT];
+          double cyc[kWtNT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             const int tl = tile + 8 * u;
@@ -382,9 +399,9 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
             cyc[u] = t.theta[q[u]] + (rr + 1.0) * (t.w[q[u]] + t.dw[q[u]] * rr);
           }
-          float theta[2], z[2];
-          bool neg[2];
-          const float* t0[2];
+          float theta[kWtNT], z[kWtNT], z2[kWtNT];
+          bool neg[kWtNT];
+          const float* t0[kWtNT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             theta[u] = (float)(cyc[u] - floor(cyc[u]));                     // [0, 1]
@@ -393,14 +410,14 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
             const float fl = floorf(pos);
             z[u] = (pos - fl) - 0.5f;
+            z2[u] = z[u] * z[u];
             t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
           }
           if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
-          float acc0[2] = {0.0f, 0.0f}, acc1[2] = {0.0f, 0.0f};
-          if constexpr (NT == 2) wt_taps2<W, 0>(t0[0], t0[1], z[0], z[1], z[0] * z[0], z[1] * z[1], acc0, acc1);
-          else wt_taps<W, 0>(t0[0], z[0], z[0] * z[0], acc0[0], acc1[0]);
+          float acc0[kWtNT] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[kWtNT] = {0.0f, 0.0f, 0.0f, 0.0f};
+          wt_taps<W, 0, NT>(t0, z, z2, acc0, acc1);
           if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
-          float out[2], w_cur[2], w_next[2], lerp[2];
+          float out[kWtNT], w_cur[kWtNT], w_next[kWtNT], lerp[kWtNT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
             lerp[u] = (float)r[u] * inv_hop;
@@ -432,27 +449,32 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             }
           }
           if (tile == rw) DDSP_WT_STAMP(7);                    // envelope, Nyquist corrections done
-          audio[(size_t)(row0 + q[0]) * hop + r[0]] = out[0];            // N == F * hop
-          if constexpr (NT == 2) audio[(size_t)(row0 + q[1]) * hop + r[1]] = out[1];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
         };
-        for (int tile = rw; tile < n_tiles; tile += 16) {
-          if (tile + 8 < n_tiles) tiles(tile, std::integral_constant<int, 2>{});
+        for (int tile = rw; tile < n_tiles; tile += 8 * kWtNT) {
+          const int left = (n_tiles - tile + 7) >> 3;          // tiles tile, tile + 8, ... still inside the chunk
+          if (left >= 4) tiles(tile, std::integral_constant<int, 4>{});
+          else if (left == 3) tiles(tile, std::integral_constant<int, 3>{});
+          else if (left == 2) tiles(tile, std::integral_constant<int, 2>{});
           else tiles(tile, std::integral_constant<int, 1>{});
         }
       }
       DDSP_WT_STAMP(1);
       if (tick + 2 >= 0 && tick + 2 < n_my) {
-        // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+15 (clamped at F-1) -> planes ----
+        // ---------------- phase A of chunk tick+2: controls of rows j0 .. j0+31 (clamped at F-1) -> planes ----
         // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
         // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
         const int j0 = ac * kWtFrames;
         const int nfr = min(kWtFrames, F - j0);
-        const int crow = ab * F + j0 + arow;           // this lane's (batch * frame) row, if arow < nfr
+        const int crow0 = ab * F + j0;
         DDSP_WT_ADVANCE(ab, ac);
         const float* raw = raw_all[(tick + 2) & 1];
         _Float16* planes = planes_all[(tick + 2) % 3];
-        ChunkTables& t = t_all[(tick + 2) % 3];
-        {
+#pragma unroll
+        for (int h = 0; h < kWtRowTiles; ++h) {        // independent rows: their chains interleave
+          const int arow = arow0 + 16 * h;
+          const int crow = crow0 + arow;               // this lane's (batch * frame) row, if arow < nfr
           const float4 xv = *reinterpret_cast<const float4*>(raw + arow * kWtRS + 4 * kq);
           const float2 fa2 = *reinterpret_cast<const float2*>(raw + arow * kWtRS + 128);
           const float f0r = fa2.x;
@@ -499,8 +521,6 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
           }
         }
-        // ---------------- one wavefront: the per-frame phase tables --------------------------------------------
-        if (rw == 7) wt_phase_tables(raw, t, lane, nfr, K, p);
       }
       DDSP_WT_STAMP(3);
       __syncthreads();
