@@ -140,6 +140,25 @@ __device__ __forceinline__ float philox_noise(uint32_t n, uint64_t row, uint32_t
   return bits_to_pm1(bits);
 }
 
+// n / d for a divisor fixed at launch, without the divide: an integer division by a runtime value expands to ~40
+// instructions (v_rcp_iflag_f32 and a correction, vector ALU even for wave-uniform operands) whose latency the
+// persistent kernels paid two or three times per tick.  magic = floor(2^32 / d) (2^32 - 1 for d = 1) makes
+// mulhi(n, magic) the quotient or one less for every n < 2^32; one compare puts it right.
+struct FastDiv { uint32_t d, magic; };
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f, uint32_t& rem) {
+  uint32_t q = __umulhi(n, f.magic);
+  uint32_t r = n - q * f.d;
+  if (r >= f.d) { ++q; r -= f.d; }
+  rem = r;
+  return q;
+}
+
 // A 16-byte global load that is ISSUED where it is written and whose result is first touched at load_settle():
 // a plain load may be sunk by the optimiser to just before its first use (it moved four of them below a block of
 // MFMAs that was there to hide their latency - harmonic_table.hip), a volatile assembly statement may not.

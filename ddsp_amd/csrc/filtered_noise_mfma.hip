@@ -82,7 +82,8 @@ struct MfArgs {
   uint32_t k0, k1;
   uint64_t batch_offset;
   int tiles_per_row, n_tiles;       // tiles of 62 frames per batch row; B * tiles_per_row
-  int dbg_skip;
+  FastDiv whole_per_row, fs_div;    // max(tiles_per_row - 1, 1); fs
+  int n_whole;                      // B * (tiles_per_row - 1): the tiles before the rows' last ones
   int dbg_wave;                     // the FIR wavefront (8 .. 15) whose times are stamped; the producer is dbg_wave - 8
   long long* dbg;                   // block 0's per-tick stamps [16 ticks][3 roles][begin, end] (tools/exp_noise_fir.py), or null
 };
@@ -139,6 +140,57 @@ __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool f
   }
 }
 
+// The noise tile x[z0-128 .. z0+3967] into the LDS planes (reversed, hi / lo split, two copies): 512 lanes (ltid), two
+// quads per lane (two independent Philox chains).
+template <bool GEN_NOISE>
+__device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const float* __restrict__ x, unsigned char* s_xe,
+                                              unsigned char* s_xo, const MfArgs& p) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int qd = ltid + 512 * h;
+    const int i = z0 - 128 + 4 * qd;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0 && i < p.N) {
+      if (GEN_NOISE) {
+        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+        if (i + 1 >= p.N) v.y = 0.f;
+        if (i + 2 >= p.N) v.z = 0.f;
+        if (i + 3 >= p.N) v.w = 0.f;
+      } else {
+        const float* src = x + (size_t)b * p.N + i;
+        if (i + 3 < p.N && ((p.N & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (i + 1 < p.N) v.y = src[1];
+          if (i + 2 < p.N) v.z = src[2];
+          if (i + 3 < p.N) v.w = src[3];
+        }
+      }
+    }
+    _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+    mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+    mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+    mf_split(v.y, h2, l2);
+    mf_split(v.x, h3, l3);
+    const int s = qd >> 4, j = 4 * (qd & 15);
+    const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+    // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+    *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+    *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+    // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
+    // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+    unsigned char* po = s_xo + (u0 + 1) * 2;
+    *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+    *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+    *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+    *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+  }
+}
+
 // FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s.
 //
 // Persistent, one block of 16 wavefronts per CU, tiles dealt round-robin; two LDS buffers; one barrier per tick:
@@ -162,12 +214,20 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
   const int n_my = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this block
   long long* dbg = (p.dbg && blockIdx.x == 0) ? p.dbg : nullptr;                              // block 0: [tick][role][2]
 #define DDSP_MF_STAMP(tick, role, i) do { if (dbg && lane == 0 && (tick) + 1 < 16) dbg[(((tick) + 1) * 3 + (role)) * 2 + (i)] = wall_clock64(); } while (0)
-  // tile T -> (batch row, tile of the row): first output z0 = 3968 tx (a multiple of 64); tap rows: frames f_first ..
-  // f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile
+  // tile T -> (batch row, tile tx of the row): first output z0 = 3968 tx (a multiple of 64); tap rows: frames f_first ..
+  // f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile.  The rows' LAST tiles come last in the
+  // order (T >= n_whole): they are mostly beyond the end of the row (a 4 s clip is 16.1 tiles) and cost a fraction of a
+  // tick, so that a block's longest schedule is 8 whole tiles + 1 short one at batch 128 (2 + 1 at batch 32), not 9 (3).
+  // (divisions by launch constants: fastdiv, common.h)
 #define DDSP_MF_TILE(T, b_, z0_, ffirst_, rel0_)                                                        \
-  const int b_ = (T) / p.tiles_per_row;                                                                 \
-  const int z0_ = ((T) - b_ * p.tiles_per_row) * kMfTile;                                               \
-  const int ffirst_ = (z0_ - 128 >= 0) ? (z0_ - 128) / p.fs : -((128 - z0_ + p.fs - 1) / p.fs);         \
+  const bool last_ = (T) >= p.n_whole;                                                                  \
+  uint32_t tx_;                                                                                         \
+  const int bq_ = (int)fastdiv((uint32_t)(T), p.whole_per_row, tx_);                                    \
+  const int b_ = last_ ? (T) - p.n_whole : bq_;                                                         \
+  const int z0_ = (last_ ? p.tiles_per_row - 1 : (int)tx_) * kMfTile;                                   \
+  uint32_t fr_;                                                                                         \
+  const int fq_ = (int)fastdiv((uint32_t)(z0_ >= 128 ? z0_ - 128 : 128 - z0_ + p.fs - 1), p.fs_div, fr_); \
+  const int ffirst_ = (z0_ >= 128) ? fq_ : -fq_;                                                        \
   const int rel0_ = (z0_ - 128) - ffirst_ * p.fs
 
   if (wave < 8) {
@@ -229,66 +289,24 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         for (int c4 = 0; c4 < 4; ++c4) nq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
         n_last = src[64];
       }
-      if (tick + 1 < n_my && !((p.dbg_skip & 1) && tick >= 1)) {
+      if (tick + 1 < n_my) {
         const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)rel0;
         unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
         unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
         unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
-        // ---- the noise tile x[z0-128 .. z0+3967]: reversed, hi / lo split, two copies; two quads per lane (two
-        //      independent Philox chains) ----------------------------------------------------------------------------
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int qd = tid + 512 * h;
-          const int i = z0 - 128 + 4 * qd;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i >= 0 && i < p.N) {
-            if (GEN_NOISE) {
-              const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-              v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-              if (i + 1 >= p.N) v.y = 0.f;
-              if (i + 2 >= p.N) v.z = 0.f;
-              if (i + 3 >= p.N) v.w = 0.f;
-            } else {
-              const float* src = x + (size_t)b * p.N + i;
-              if (i + 3 < p.N && ((p.N & 3) == 0)) {
-                v = *reinterpret_cast<const float4*>(src);
-              } else {
-                v.x = src[0];
-                if (i + 1 < p.N) v.y = src[1];
-                if (i + 2 < p.N) v.z = src[2];
-                if (i + 3 < p.N) v.w = src[3];
-              }
-            }
-          }
-          _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
-          mf_split(v.w, h0, l0);               // element u0     = sample j + 3
-          mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
-          mf_split(v.y, h2, l2);
-          mf_split(v.x, h3, l3);
-          const int s = qd >> 4, j = 4 * (qd & 15);
-          const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
-          // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
-          *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-          *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
-          // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
-          // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
-          unsigned char* po = s_xo + (u0 + 1) * 2;
-          *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
-          *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
-          *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
-          *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
-          *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
-          *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
-        }
+        if (tick >= 0) mf_noise_tile<GEN_NOISE>(tid, b, z0, x, s_xe, s_xo, p);      // (tile 0's: the FIR wavefronts, idle in tick -1)
         if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
         // ---- the taps n = 16 mt .. + 15 (and their mirror images) of rows 16 rg .. + 15 ---------------------------------
         // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
         const int own_lo = (z0 == 0) ? 0 : f_first + 2;
-        const int own_hi = (z0 + kMfTile - 128) / p.fs + 2;
+        uint32_t own_r;
+        const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, own_r) + 2;
         const int rfr = f_first + rrow;
         const bool rvalid = rfr >= 0 && rfr < p.F;
+        // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
+        if (f_first + 16 * rg <= p.F + 1) {
         float y[16];
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
@@ -360,6 +378,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
           }
         }
+        }
         if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 1);
       }
 #pragma unroll
@@ -417,7 +436,22 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     for (int tick = -1; tick < n_my; ++tick) {
       if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 0);
       if (tick >= 1) flush_kept((tick - 1) & 1);
-      if (tick >= 0 && !(p.dbg_skip & 2)) {
+      if (tick < 0) {
+        // nothing to filter yet: the noise of the block's first tile, while the producers design its taps
+        const int T = (int)blockIdx.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)f_first; (void)rel0;
+        mf_noise_tile<GEN_NOISE>(tid - 512, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
+      }
+      bool active = false;
+      if (tick >= 0) {
+        const int T = (int)blockIdx.x + tick * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)f_first;
+        // (a wavefront whose four pairs lie past the end of the row has nothing to store: most of a row's last tile)
+        active = (long)z0 - 128 + 128L * p_first - p.start < (long)p.N;
+      }
+      if (active) {
         const int T = (int)blockIdx.x + tick * (int)gridDim.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)f_first;
@@ -539,6 +573,8 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         else pipeline(std::false_type{});
         kept_ot = ot;
         kept_n = n_tile;
+      } else {
+        kept_ot = nullptr;
       }
       if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 1);
       __syncthreads();
@@ -565,10 +601,11 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
   q.dbg = dbg;
   static const int dbg_wave = [] { const char* e = getenv("DDSP_MF_DBG_WAVE"); const int v = e ? atoi(e) : 8; return v >= 8 && v < 16 ? v : 8; }();
   q.dbg_wave = dbg_wave;
-  static const int dbg_skip = [] { const char* e = getenv("DDSP_MF_DBG_SKIP"); return e ? atoi(e) : 0; }();
-  q.dbg_skip = dbg_skip;
   q.tiles_per_row = (N + start + kMfTile - 1) / kMfTile;
   q.n_tiles = B * q.tiles_per_row;
+  q.whole_per_row = make_fastdiv((uint32_t)(q.tiles_per_row > 1 ? q.tiles_per_row - 1 : 1));
+  q.fs_div = make_fastdiv((uint32_t)q.fs);
+  q.n_whole = B * (q.tiles_per_row - 1);
   // persistent grid: one block of 12 wavefronts per CU (two LDS buffers of 76 KB)
   static const int n_cu = [] {
     int dev = 0, v = 0;
