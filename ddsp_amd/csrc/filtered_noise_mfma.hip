@@ -410,14 +410,12 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     long kept_n = 0;
     const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
     const int second = mg >> 1;
-    int a_hi0[5], a_lo0[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int u = 79 + kMfXStride * second - 16 * c - mi + 8 * (mg & 1);             // relative to the pair's first frame
-      // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2.  (u's parity is the lane's: 79 - i)
-      a_hi0[c] = xsel + ((u + 1) >> 1) * 4;
-      a_lo0[c] = a_hi0[c] + kMfXPlane;
-    }
+    // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2 (u's parity is the lane's: 79 - i).  Step c
+    // reads 32 c bytes below step 0, pair `it` 320 `it` bytes above pair 0: ONE per-lane address per plane and pair of
+    // pairs, the rest immediates (ds_read2_b32 reaches 1020 bytes).  (Ten addresses, one per step and plane, cost ten
+    // VGPRs that the 128-VGPR budget spilled to scratch: 5.8 MB of HBM writes per launch, profiles/pmc_traffic.json.)
+    const int u4 = 79 + kMfXStride * second - 16 * 4 - mi + 8 * (mg & 1);              // step 4, relative to the pair's first frame
+    const int a_base0 = xsel + ((u4 + 1) >> 1) * 4;
     const int q0 = mi - 4 * second;
     const int b_off = (q0 >= 0 && q0 <= 7) ? (2 * q0 + (mg & 1)) * 16 : 256;
     const int b_ptr0 = (2 * p_first + second) * kMfTapRowBytes + b_off;
@@ -464,18 +462,18 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 4 <= (long)p.N && (((p.start | p.N) & 1) == 0);
         float* __restrict__ ot = o + n_tile;                               // wave-uniform base; lanes add a 32-bit offset
         mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-        int a_hi[5], a_lo[5], b_ptr = b_ptr0;
+        int a_hi[2], a_lo[2], b_ptr = b_ptr0;
         DDSP_KEEP_IN_VGPR(b_ptr);
         __builtin_assume((b_ptr & 15) == 0);
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          a_hi[c] = a_hi0[c]; a_lo[c] = a_lo0[c];
-          DDSP_KEEP_IN_VGPR(a_hi[c]);
-          DDSP_KEEP_IN_VGPR(a_lo[c]);
+        for (int k = 0; k < 2; ++k) {                  // pairs 0, 1 and pairs 2, 3
+          a_hi[k] = a_base0 + 640 * k; a_lo[k] = a_base0 + 640 * k + kMfXPlane;
+          DDSP_KEEP_IN_VGPR(a_hi[k]);
+          DDSP_KEEP_IN_VGPR(a_lo[k]);
           // what the compiler no longer sees through the barrier: dword-aligned fragment addresses (two ds_read2_b32
           // each; a ds_read_b128 at 4-byte alignment would take the slow unaligned path), 16-byte aligned tap groups
-          __builtin_assume((a_hi[c] & 3) == 0);
-          __builtin_assume((a_lo[c] & 3) == 0);
+          __builtin_assume((a_hi[k] & 3) == 0);
+          __builtin_assume((a_lo[k] & 3) == 0);
         }
         // The 4 x 5 (pair, k-step) sequence runs as ONE software pipeline (no control flow inside, so the compiler's
         // s_waitcnt counts stay exact): the fragment reads of step j + 3 are issued right
@@ -486,8 +484,8 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         mf_f16x8 fah[3], fal[3], fbh_in[2], fbl_in[2], fbh, fbl;
         auto load_step = [&](int j, int slot) {
           const int it = j / 5, c = j - 5 * it;
-          const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[c] + 2 * kMfXStride * 2 * it);
-          const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[c] + 2 * kMfXStride * 2 * it);
+          const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[it >> 1] + 32 * (4 - c) + 2 * kMfXStride * 2 * (it & 1));
+          const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[it >> 1] + 32 * (4 - c) + 2 * kMfXStride * 2 * (it & 1));
           fah[slot] = mf_frag(qh.x, qh.y, qh.z, qh.w);
           fal[slot] = mf_frag(ql.x, ql.y, ql.z, ql.w);
           if (c == 0) {
