@@ -306,6 +306,18 @@ class FilteredNoise(processors.Processor):
       noise = core.tf_float32(noise)
       if tuple(noise.shape) != (b, n):
         raise ValueError('noise must be [{}, {}], got {}'.format(b, n, tuple(noise.shape)))
+    if m == 2:
+      # an impulse response of 2 taps: crop_and_compensate_delay (core.py:1338-1379) starts its slice at
+      # (ir_size - 1) // 2 - 1 = -1 and the reference returns what python's audio[:, -1:-end] leaves - nothing.
+      # Same answer as core.fft_convolve gives here (core._crop_range), not [batch, n_samples] of something else.
+      size = lib.ddsp_fir_size(m, int(self.window_size))
+      _lib.check(min(size, 0), 'ddsp_fir_size')
+      _, _, n_out = core._crop_range(n, f, size, 'same', -1)
+      if n_out != n:
+        ctl = None
+        if want_controls:
+          ctl = core.exp_sigmoid(magnitudes + float(self.initial_bias)) if fuse_scale else magnitudes
+        return torch.empty((b, n_out), dtype=torch.float32, device=dev), ctl
     audio = torch.empty((b, n), dtype=torch.float32, device=dev)
     ctl = torch.empty_like(magnitudes) if want_controls else None
     ws = self._ws.get(core.cached_workspace_bytes('ddsp_filtered_noise_workspace_bytes', b, f, m, n,

@@ -361,3 +361,21 @@ def test_filtered_noise_matrix_core_kernel_vs_oracle_and_vector_kernel(ddsp, bat
   assert np.abs(npy(outs['auto']['signal']) - npy(outs['vector']['signal'])).max() <= 0.5 * noise_tol(ref)
   # generated noise: the same Philox stream in both kernels
   assert np.abs(gen['auto'] - gen['vector']).max() <= 0.5 * noise_tol(ref) and np.abs(gen['auto']).max() > 0
+
+
+def test_filtered_noise_with_fewer_than_three_bands_crops_like_the_reference(ddsp):
+  """An impulse response of 2 taps: crop_and_compensate_delay (ddsp/core.py:1338-1379) slices audio[:, -1:-end],
+  which python leaves empty; core.fft_convolve reproduces that, and FilteredNoise must not answer with
+  [batch, n_samples] of something else."""
+  rng = np.random.default_rng(3)
+  for m in (2,):
+    mags = rng.standard_normal((2, 10, m)).astype(np.float32)
+    synth = ddsp.synths.FilteredNoise(n_samples=640, window_size=0)
+    out = synth(mags, return_outputs_dict=True)
+    ir = ddsp.core.frequency_impulse_response(ddsp.core.exp_sigmoid(ddsp.core.tf_float32(mags) + synth.initial_bias), 0)
+    via_core = ddsp.core.fft_convolve(ddsp.core.tf_float32(rng.uniform(-1, 1, (2, 640)).astype(np.float32)), ir)
+    assert tuple(out['signal'].shape) == tuple(via_core.shape) == (2, 0)
+    np.testing.assert_allclose(npy(out['controls']['magnitudes']), O.exp_sigmoid(mags + synth.initial_bias), rtol=2e-5)
+  # three bands: a 4-tap filter, the ordinary path
+  mags = rng.standard_normal((2, 10, 3)).astype(np.float32)
+  assert tuple(ddsp.synths.FilteredNoise(n_samples=640, window_size=0)(mags).shape) == (2, 640)
