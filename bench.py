@@ -27,7 +27,7 @@ The JSON line also carries
   roofline         : dominant kernel, algorithmic bytes per launch / its mean duration measured
                      with HIP events on the launch stream during the timed regions (ddsp_profile_*),
                      against the 8 TB/s HBM peak (the path is in fact ALU-bound).
-  north_star_shape : the same step at BASELINE.json's target shape (batch 128 per GPU, one stream), timed the
+  north_star_shape : the same step at BASELINE.json's target shape (batch 128 per GPU; two streams, `one_stream` beside it), timed the
                      same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
                      fractions of the HBM roofline.
   cpu_baseline     : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
@@ -78,7 +78,7 @@ def parse_args(argv=None):
                        'timed regions (a bracketed launch costs ~5 us of queue time; 1 = all of them)')
   ap.add_argument('--streams', choices=['auto', '1', '2'], default='auto',
                   help='issue the two Processor calls on one stream or on two free-running streams; auto = two '
-                       'when the per-GPU batch is below 64 (the kernels leave CUs idle for each other), one above')
+                       '(the two persistent kernels overlap only where one has left CUs idle)')
   ap.add_argument('--no-overlap', action='store_true',
                   help='issue the two Processor calls back to back on one stream instead of on two '
                        'free-running HIP streams')
@@ -90,7 +90,7 @@ def parse_args(argv=None):
                   help='skip the auxiliary yardsticks after the timed regions (measured device-copy bandwidth, '
                        'the f0 = 200 Hz regime of SURVEY.md 8d)')
   ap.add_argument('--no-north-star', action='store_true',
-                  help='skip the north_star_shape block (batch 128 per GPU, one stream)')
+                  help='skip the north_star_shape block (batch 128 per GPU)')
   ap.add_argument('--north-star-batch', type=int, default=128)
   ap.add_argument('--harm-kernel', default='auto', help="Harmonic.kernel ('auto', 'direct', ...)")
   ap.add_argument('--noise-kernel', default='auto', help="FilteredNoise.kernel ('auto', ...)")
@@ -261,21 +261,28 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
   return result
 
 
-def north_star_block(a, world, B, elapsed, steps, prof, breakdown):
-  """The step at the north-star shape (batch 128 per GPU, one stream): same definitions as the headline."""
+def north_star_block(a, world, B, elapsed, steps, prof, breakdown, elapsed_one_stream=None):
+  """The step at the north-star shape (batch 128 per GPU): same definitions as the headline, the two calls on two
+  free-running streams as there; the one-stream figure beside it."""
   harm_bytes, noise_bytes = algorithmic_bytes(a, B)
   step_bytes = harm_bytes + noise_bytes
   per_step = elapsed / steps
-  block = {'batch_per_gpu': B, 'streams': 'one stream, back to back', 'steps': steps,
+  block = {'batch_per_gpu': B, 'streams': 'Harmonic and FilteredNoise on two free-running HIP streams', 'steps': steps,
            'ms_per_step': per_step * 1e3, 'value': world * B * a.n_samples / per_step / 1e6,
            'whole_step': {'algorithmic_bytes': step_bytes, 'achieved_GBs': step_bytes / per_step / 1e9,
                           'frac': step_bytes / per_step / 1e9 / HBM_PEAK_GBS},
            'target': '>= 0.5 of the HBM roofline (BASELINE.json north_star)',
            'kernel_breakdown_us': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()}}
+  if elapsed_one_stream is not None:
+    one = elapsed_one_stream / steps
+    block['one_stream'] = {'ms_per_step': one * 1e3, 'value': world * B * a.n_samples / one / 1e6,
+                           'whole_step_frac': step_bytes / one / 1e9 / HBM_PEAK_GBS}
   if prof:
     dominant = max(prof, key=lambda k: prof[k][0] / prof[k][1])
     roof = kernel_roofline(a, B, dominant, *prof[dominant])
     roof.pop('_flops'), roof.pop('_avg_s')
+    roof['timing'] = ('sampled dispatch events of the one-stream regions (on two streams a dispatch also spans the wait for '
+                      'the CUs the other kernel still holds)')
     block['dominant_kernel'] = roof
   return block
 
@@ -472,7 +479,10 @@ def main(argv=None):
 
   # ---- headline: BASELINE configs[1] ---------------------------------------------------------------------
   B = a.batch
-  overlap = (a.streams == '2' or (a.streams == 'auto' and a.batch < 64)) and not a.no_overlap
+  # two free-running streams at every batch size: the two persistent kernels cannot share a CU (each takes its LDS), so
+  # nothing stretches, and the second kernel's blocks start on the CUs the first one has already left
+  # (batch 128: 87 against 96 us per step, profiles/r02w_streams.txt)
+  overlap = a.streams in ('2', 'auto') and not a.no_overlap
   step, dev = make_step(B, 1000 + rank, overlap)
   for _ in range(a.warmup):
     step()
@@ -568,13 +578,13 @@ def main(argv=None):
     sync_all()
     gather_ms = max_over_ranks(time.perf_counter() - t1) / 10 * 1e3
 
-  # ---- the north-star shape: batch 128 per GPU, one stream (BASELINE.json target) --------------------------
+  # ---- the north-star shape: batch 128 per GPU (BASELINE.json target) ----------------------------------------
   north_star = None
   if not a.no_north_star and a.north_star_batch != B:
     try:
       BN = a.north_star_batch
       del step, dev
-      step_n, dev_n = make_step(BN, 3000 + rank, False)
+      step_n, dev_n = make_step(BN, 3000 + rank, True)
       ns_steps = max(10, min(a.steps, 200))
       for _ in range(20):
         step_n()
@@ -587,12 +597,17 @@ def main(argv=None):
           step_n(two_streams=False)
         torch.cuda.synchronize()
         bd_n = _lib.profile_end()
-        _lib.profile_begin(list(bd_n), max_records=4 * ns_steps * 10 // max(a.event_stride, 1) + 64,
+      ev_n, _, _ = repeated_regions(step_n, ns_steps, True, 10)
+      # the dominant kernel's dispatch events: during the one-stream regions (on two streams a dispatch of one kernel
+      # spans the time its blocks wait for the CUs the other kernel's persistent blocks still hold)
+      if not dry:
+        _lib.profile_begin(list(bd_n), max_records=4 * ns_steps * 5 // max(a.event_stride, 1) + 64,
                            stride=a.event_stride)
-      ev_n, _, _ = repeated_regions(step_n, ns_steps, False, 10)
+      ev_1, _, _ = repeated_regions(step_n, ns_steps, False, 5)
       if not dry:
         prof_n = _lib.profile_end()
-      north_star = north_star_block(a, world, BN, max_over_ranks(statistics.median(ev_n)), ns_steps, prof_n, bd_n)
+      north_star = north_star_block(a, world, BN, max_over_ranks(statistics.median(ev_n)), ns_steps, prof_n, bd_n,
+                                    max_over_ranks(statistics.median(ev_1)))
     except Exception as exc:                      # noqa: BLE001 - the headline line must survive
       north_star = {'error': repr(exc)}
 
