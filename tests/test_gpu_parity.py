@@ -1186,3 +1186,88 @@ def test_spectral_loss_fused_and_separate_gradient_entries_agree(ddsp):
   np.testing.assert_allclose(float(value), float(fwd), rtol=1e-6)
   scale = float(grad.abs().max())
   assert float((grad - sep).abs().max()) <= 1e-5 * scale            # same kernel, atomics order only
+
+
+# ---- random shapes: whatever the hand-picked cases above did not think of ---------------------------------------------
+def _harmonic_exact(amps, hd, f0, n, sr, method):
+  """Harmonic.__call__ in exact (fp64) arithmetic, written from the formulas alone (linear f0 ramps with weights r / hop,
+  raised-cosine or linear amplitude envelopes, inclusive cumsum, frame- and audio-rate Nyquist masks): independent of
+  oracle/ddsp_oracle.py, whose "truth" mode keeps TF's fp32 resize POSITIONS (t * scale rounded to fp32)."""
+  b, f, k = hd.shape
+  hop = n // f
+  a = O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64)
+  h = O.exp_sigmoid(hd.astype(np.float64), dtype=np.float64)
+  fr = f0.astype(np.float64)
+  kk = np.arange(1, k + 1)
+  h = np.where(fr * kk >= sr / 2, 0.0, h)
+  s = h.sum(-1, keepdims=True)
+  h = h / np.where(s == 0, 1e-7, s)
+  amp = a * h
+  t = np.arange(n)
+  j, r = t // hop, t % hop
+  j1 = np.minimum(j + 1, f - 1)
+  lerp = r / hop
+  ft = fr[:, j, 0] + (fr[:, j1, 0] - fr[:, j, 0]) * lerp[None]
+  ph = np.cumsum(ft / sr, axis=1)
+  wn = lerp if method == 'linear' else 0.5 - 0.5 * np.cos(np.pi * lerp)
+  out = np.zeros((b, n))
+  for q in range(1, k + 1):
+    aq = amp[:, j, q - 1] * (1 - wn)[None] + amp[:, j1, q - 1] * wn[None]
+    out += np.where(ft * q >= sr / 2, 0.0, aq) * np.sin(2 * np.pi * q * ph)
+  return out
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_harmonic_random_shapes_vs_exact_arithmetic(ddsp, seed):
+  """Random (batch, frames, frame size 64 / 128 / 192, K, f0 regime, envelope method) through the default kernels
+  against exact arithmetic, HARM_TABLE_ATOL.  Against the oracle's truth mode too when the frame size is a power of two;
+  for 192 that mode (TF's fp32 positions: up to 1.5e-5 off r / hop late in a clip) is up to 5e-4 away from exact
+  arithmetic when f0 jumps by tens of Hz from frame to frame - from the kernels, which use r / hop, just as far
+  (known limits)."""
+  rng = np.random.default_rng(seed)
+  cases = 12 if DEV == 'cuda' else 3                         # (the emulated run keeps three)
+  for _ in range(cases):
+    hop = int(rng.choice([64, 64, 128, 192]))
+    f = int(rng.integers(1, 120 if DEV == 'cuda' else 24))
+    n = f * hop
+    k = 4 * int(rng.integers(1, 33))
+    b = int(rng.integers(1, 4))
+    sr = 16000
+    base = float(rng.choice([40.0, 70.0, 200.0, 440.0, 1000.0, sr / 2 / k * 0.999]))
+    f0 = np.abs(base + rng.standard_normal((b, f, 1)) * float(rng.choice([0.0, 1.0, 30.0]))).astype(np.float32)
+    amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+    hd = rng.standard_normal((b, f, k)).astype(np.float32)
+    method = str(rng.choice(['window', 'linear']))
+    got = npy(ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)(amps, hd, f0))
+    what = dict(hop=hop, frames=f, k=k, batch=b, base=base, method=method)
+    scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+    exact = _harmonic_exact(amps, hd, f0, n, sr, method)
+    assert np.abs(got - exact).max() <= HARM_TABLE_ATOL * scale, what
+    if hop in (64, 128):
+      truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, amp_resample_method=method, dtype=np.float64)
+      assert np.abs(got - truth).max() <= HARM_TABLE_ATOL * scale, what
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_filtered_noise_random_shapes_vs_oracle(ddsp, seed):
+  """Random (batch, frames, frame size 64 .. 256, ragged length, supplied or generated noise) through the default
+  kernel (tile edges, the rows' short last tiles, frames that share a tap row) against the fp64 oracle."""
+  rng = np.random.default_rng(seed)
+  cases = 20 if DEV == 'cuda' else 3
+  for _ in range(cases):
+    fs = int(rng.choice([64, 64, 64, 128, 192, 256]))
+    f = int(rng.integers(1, 260 if DEV == 'cuda' else 70))
+    n = f * fs - int(rng.integers(0, fs))
+    if n < 1:
+      continue
+    b = int(rng.integers(1, 5))
+    mags = (rng.standard_normal((b, f, 65)) + 3.0).astype(np.float32)
+    synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=5)
+    if rng.integers(0, 2):
+      noise = rng.uniform(-1, 1, (b, n)).astype(np.float32)
+      got = npy(synth(mags, noise=noise))
+    else:
+      noise = O.device_uniform_noise(b, n, seed=5)
+      got = npy(synth(mags))
+    ref = O.filtered_noise(mags, noise, 0, O.exp_sigmoid, dtype=np.float64)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=noise_tol(ref), err_msg=str(dict(fs=fs, frames=f, n=n, batch=b)))
