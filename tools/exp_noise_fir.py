@@ -3,6 +3,9 @@ products) against noise_fused65_kernel (FIR on the vector ALUs) with its IR desi
 agreement between them, and the in-kernel phase timeline of the matrix-core kernel.
 
     python tools/exp_noise_fir.py [batch ...]
+
+DDSP_MF_DBG_WAVE=8..15 picks the FIR wavefront (and producer wavefront - 8) whose per-tick stamps the timeline shows: the
+youngest wavefront of a SIMD is the slow one (profiles/r02n_noise_mfma_v7_per_wavefront_timeline.txt).
 """
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
