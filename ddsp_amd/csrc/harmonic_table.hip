@@ -404,7 +404,7 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
           const float* t0[kWtNT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
-            theta[u] = (float)(cyc[u] - floor(cyc[u]));                     // [0, 1]
+            theta[u] = (float)__builtin_amdgcn_fract(cyc[u]);               // v_fract_f64: [0, 1]
             neg[u] = theta[u] >= 0.5f;                                    // S(1 - theta) = -S(theta)
             const float th = neg[u] ? 1.0f - theta[u] : theta[u];         // [0, 0.5]
             const float pos = fmaf(th, (float)kWtT, -0.5f);               // table coordinate, [-0.5, 255.5]
@@ -413,10 +413,14 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
             z2[u] = z[u] * z[u];
             t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                  // (int)fl in [-1, 255]
           }
-          if (tile == rw) DDSP_WT_STAMP(5);                    // phase and table coordinate known
+#ifdef DDSP_WT_TILE_STAMPS
+          if (tile == rw) DDSP_WT_STAMP(5);
+#endif                    // phase and table coordinate known
           float acc0[kWtNT] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[kWtNT] = {0.0f, 0.0f, 0.0f, 0.0f};
           wt_taps<W, 0, NT>(t0, z, z2, acc0, acc1);
-          if (tile == rw) DDSP_WT_STAMP(6);                    // taps read and accumulated
+#ifdef DDSP_WT_TILE_STAMPS
+          if (tile == rw) DDSP_WT_STAMP(6);
+#endif                    // taps read and accumulated
           float out[kWtNT], w_cur[kWtNT], w_next[kWtNT], lerp[kWtNT];
 #pragma unroll
           for (int u = 0; u < NT; ++u) {
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
               }
             }
           }
-          if (tile == rw) DDSP_WT_STAMP(7);                    // envelope, Nyquist corrections done
+#ifdef DDSP_WT_TILE_STAMPS
+          if (tile == rw) DDSP_WT_STAMP(7);
+#endif                    // envelope, Nyquist corrections done
 #pragma unroll
           for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
         };

@@ -427,6 +427,7 @@ inline float __builtin_amdgcn_rcpf(float x) { return (float)(1.0 / (double)x); }
 inline float __builtin_amdgcn_rsqf(float x) { return (float)(1.0 / std::sqrt((double)x)); }
 inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }
+inline double __builtin_amdgcn_fract(double x) { return x - std::floor(x); }
 typedef __fp16 ddsp_emu_half2 __attribute__((ext_vector_type(2)));      // the builtin's own return type
 // v_cvt_pkrtz_f16_f32: both halves rounded toward zero
 inline _Float16 ddsp_emu_f16_rtz(float x) {
