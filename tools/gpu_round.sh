@@ -27,11 +27,11 @@ PY
 echo "== rocprofv3 kernel trace (bench defaults, batch 32)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b32.csv; head -6 $f | cut -c1-200; done
-tail -1 $OUT/rocprof_bench.log > $OUT/bench_b32_under_rocprof.json
+grep "^{\"metric\"" $OUT/rocprof_bench.log | tail -1 > $OUT/bench_b32_under_rocprof.json
 echo "== rocprofv3 kernel trace, batch 128 (north-star shape, one stream)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --streams 1 --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
 for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b128.csv; head -6 $f | cut -c1-200; done
-tail -1 $OUT/rocprof_bench_b128.log > $OUT/bench_b128_under_rocprof.json
+grep "^{\"metric\"" $OUT/rocprof_bench_b128.log | tail -1 > $OUT/bench_b128_under_rocprof.json
 rm -rf $OUT/prof $OUT/prof128
 echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 > /dev/null 2>&1; cp $OUT/pmc_traffic_b32/pmc_traffic.json $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
