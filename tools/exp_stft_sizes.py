@@ -1,4 +1,5 @@
-"""Time of the STFT-L1 kernel per FFT size (forward), batch 32 x 64000."""
+"""Time of the SpectralLoss kernels per FFT size, batch 32 x 64000: forward (stft_l1_kernel) and value + gradient in one
+pass (stft_l1_bwd_kernel, through torch.autograd)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,4 +18,12 @@ for S in (2048, 1024, 512, 256, 128, 64):
   torch.cuda.synchronize(); t1 = time.perf_counter()
   for _ in range(50): loss(t, a)
   torch.cuda.synchronize()
-  print('S=%4d  %.1f us' % (S, (time.perf_counter() - t1) / 50 * 1e6))
+  fwd = (time.perf_counter() - t1) / 50 * 1e6
+  ag = a.clone().requires_grad_(True)
+  for _ in range(5):
+    ag.grad = None; loss(t, ag).backward()
+  torch.cuda.synchronize(); t1 = time.perf_counter()
+  for _ in range(50):
+    ag.grad = None; loss(t, ag).backward()
+  torch.cuda.synchronize()
+  print('S=%4d  forward %.1f us   value + gradient %.1f us' % (S, fwd, (time.perf_counter() - t1) / 50 * 1e6))
