@@ -35,8 +35,12 @@
 #include "harmonic_table.h"
 #define DDSP_WT_TABLE __constant__
 #include "wavetable_coeffs.h"
+#include "harm_table_frags.h"
 
 namespace ddsp {
+
+constexpr WtSinSplit kWtSinSplit = make_wt_sin_split();
+static __device__ const WtFrags kWtFrags = make_wt_frags(kWtSinSplit);      // 64 KB of constants, fetched once per T-wavefront
 
 constexpr int kWtT = 512;            // table points per revolution
 constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, kWtHalf + kWtH); the other half is its mirror image
@@ -230,24 +234,21 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
     // ---- this wavefront's share of the constant factor, in MFMA A-operand layout -----------------------
     // element e of lane (i = lane & 15, g = lane >> 4) of k-step ks, parity par, position tile pt: sin(k phi_n),
     // n = 16 pt + i, k' = 32 ks + 8 g + e, k = 2 k' + 1 + par (the B fragments use the same k'(g, e));
-    // the angle k (2n+1) / (2T) revolutions is exact in fp32.  Rows k > K meet zero amplitudes.
+    // Rows k > K meet zero amplitudes.  Made at compile time (harm_table_frags.h): 16-byte loads, in flight together
+    // with the first chunk's rows.
     f16x8 ahi[2][2][NK], alo[2][2][NK];
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int n = 16 * (2 * rw + tt) + mi;
-            const int k = 2 * (32 * ks + 8 * mg + e) + 1 + par;
-            const int num = (k * (2 * n + 1)) & (2 * kWtT - 1);
-            const float v = sin_rev((float)num * (1.0f / (2 * kWtT)));
-            const _Float16 h = (_Float16)v;
-            ahi[par][tt][ks][e] = h;
-            alo[par][tt][ks][e] = (_Float16)((v - (float)h) * kWtLoScale);
-          }
+        for (int ks = 0; ks < NK; ++ks) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vh = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][0][par][tt][ks][lane]);
+          const u32x4 vl = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][1][par][tt][ks][lane]);
+          ahi[par][tt][ks] = __builtin_bit_cast(f16x8, vh);
+          alo[par][tt][ks] = __builtin_bit_cast(f16x8, vl);
+        }
     int lb = first_b, lc = first_c;               // position of the chunk whose rows are fetched next
     int qb = first_b, qc = first_c;               // position of the chunk whose phase tables are made next
 
