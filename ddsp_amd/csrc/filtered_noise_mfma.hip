@@ -24,13 +24,14 @@
 // one; at 4-byte alignment two ds_read2_b32 cost 1.7x (profiles/r02a_microbench_lds_unaligned.txt).  The reversed noise
 // is therefore kept twice, the second copy shifted by one element, and a row reads the copy its parity selects.
 //
-// One tile = 62 output frames (3968 samples) of one batch row = 64 staged frames (the first two are history).  A persistent
-// block of 16 wavefronts per CU walks its tiles with two LDS buffers and one barrier per tile (see the kernel):
-//   wavefronts 0-7 make the NEXT tile: the 64 x 65 magnitudes straight from HBM into B-fragments (no LDS staging),
+// One tile = 30 output frames (1920 samples) of one batch row = 32 staged frames (the first two are history).  Persistent
+// blocks of 8 wavefronts, two per CU, walk their tiles with two LDS buffers and one barrier per tile (see the kernel;
+// the numbers in the comments below are for the 16-wavefront build, halve them):
+//   wavefronts 0-3 make the NEXT tile: the 32 x 65 magnitudes straight from HBM into B-fragments (no LDS staging),
 //      exp_sigmoid, hi / lo split, 6 MFMAs each against the constant cosine fragments (fp16 hi / lo pairs made at compile
 //      time), window, hi / lo split of the taps into the LDS tap table; and the Philox noise tile (reversed, hi / lo
 //      split, two copies);
-//   wavefronts 8-15 run the FIR of the CURRENT tile: four pairs each, fully unrolled (every LDS address is a per-lane
+//   wavefronts 4-7 run the FIR of the CURRENT tile: four pairs each, fully unrolled (every LDS address is a per-lane
 //      base plus an immediate), 128 samples stored per pair; the 128 outputs that straddle two wavefronts are finished
 //      a tile later from a right half left in LDS.
 #include <hip/hip_runtime.h>
@@ -46,12 +47,21 @@
 
 namespace ddsp {
 
-// A tile: 64 staged frames = 32 pairs; the first pair is only history (the 128 taps reach 127 samples back), 31 pairs
-// = 62 frames are output.
-constexpr int kMfFrames = 62;                  // output frames per tile
-constexpr int kMfRows = 64;                    // staged frames: 2 of history + 62
-constexpr int kMfTile = kMfFrames * 64;        // 3968 output samples per tile
-constexpr int kMfWaves = 16;                 // 8 producer (taps + noise) + 8 FIR wavefronts
+// A tile: kMfRows staged frames = kMfRows / 2 pairs; the first pair is only history (the 128 taps reach 127 samples back),
+// the others are output.
+// Block size.  8 wavefronts (4 producers + 4 FIR) on tiles of 30 output frames, TWO blocks per CU: each block has its own
+// barrier, so one block's wait at it is the other block's time (13.7 / 39.1 us at batch 32 / 128).  16 wavefronts on tiles of
+// 62 frames, one block per CU (-DDDSP_MF_WAVES=16): 3 % less history to recompute, but every tick ends with sixteen
+// wavefronts waiting for the slowest (15.2 / 40.7 us; profiles/r02_final2_noise_mfma_two_blocks_per_cu.txt).
+#ifndef DDSP_MF_WAVES
+#define DDSP_MF_WAVES 8
+#endif
+constexpr int kMfWaves = DDSP_MF_WAVES;
+constexpr int kMfPW = kMfWaves / 2;            // producer wavefronts = FIR wavefronts
+constexpr int kMfRows = 8 * kMfPW;             // staged frames: 2 of history + the tile's (a producer row group = 16 rows
+                                               // x 2 tap tiles; an FIR wavefront = 4 pairs = 8 frames): 32
+constexpr int kMfFrames = kMfRows - 2;         // output frames per tile: 30
+constexpr int kMfTile = kMfFrames * 64;        // 1920 output samples per tile
 constexpr float kMfLoScale = 2048.0f;          // x = hi + lo / 2048 in two fp16 numbers
 // tap table: a hi plane and a lo plane; per row 16 groups of 8 taps (16 bytes) + one group of zeros that lanes outside the
 // filter's support read.  The 16 lanes of a ds_read_b128 pass read 16 DIFFERENT groups of one row (or the zero group):
@@ -68,7 +78,7 @@ constexpr int kMfXElems = 16 + kMfRows * kMfXStride + 16;     // 5152
 constexpr int kMfXPairs = kMfXElems / 2 + 1;                   // 2577 (copy O needs one more)
 // bytes of one plane: 10336 = 2584 dwords, so that copy O starts 5168 = 16 (mod 32) dwords after copy E: the E lanes
 // (odd rows) and the O lanes (even rows) of one ds_read2_b32 pass then sit in different halves of the banks
-constexpr int kMfXPlane = 10336;
+constexpr int kMfXPlane = kMfWaves == 16 ? 10336 : 5216;
 static_assert(kMfXPlane >= kMfXPairs * 4 && kMfXPlane % 16 == 0 && (2 * kMfXPlane / 4) % 32 == 16, "noise plane layout");
 
 typedef _Float16 mf_f16x8 __attribute__((ext_vector_type(8)));
@@ -147,7 +157,7 @@ __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const flo
                                               unsigned char* s_xo, const MfArgs& p) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int qd = ltid + 512 * h;
+    const int qd = ltid + 64 * kMfPW * h;
     const int i = z0 - 128 + 4 * qd;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
@@ -193,12 +203,13 @@ __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const flo
 
 // FS64: frames of exactly 64 samples (the canonical hop): staged frame s uses tap row s.
 //
-// Persistent, one block of 16 wavefronts per CU, tiles dealt round-robin; two LDS buffers; one barrier per tick:
-//     tick k:   producer wavefronts 0-7 fill buffer (k+1) & 1 with tile k+1 (vector ALUs): wavefront w designs the taps
-//               n = 16 (w >> 2) .. + 15 of rows 16 (w & 3) .. + 15 and generates an eighth of the noise tile;
-//               FIR wavefronts 8-15 turn buffer k & 1 (tile k) into audio (matrix cores + LDS reads), two per SIMD so
-//               that one's LDS latency hides behind the other's MFMAs (with one per SIMD a pair took 1400 clocks,
-//               profiles/r02e_noise_mfma_v3_persistent_12waves.txt).
+// Persistent blocks of kMfWaves wavefronts (two blocks of 8 per CU), tiles dealt round-robin; two LDS buffers; one barrier
+// per tick (with P = kMfPW producers):
+//     tick k:   producer wavefronts 0 .. P-1 fill buffer (k+1) & 1 with tile k+1 (vector ALUs): wavefront w designs the
+//               taps n = 16 (w / (P/2)) .. + 15 of rows 16 (w % (P/2)) .. + 15 and generates its share of the noise tile;
+//               FIR wavefronts P .. 2P-1 turn buffer k & 1 (tile k) into audio (matrix cores + LDS reads), two per SIMD
+//               (of the CU's two blocks together) so that one's LDS latency hides behind the other's MFMAs (with one per
+//               SIMD a pair took 1400 clocks, profiles/r02e_noise_mfma_v3_persistent_12waves.txt).
 // The producers fetch the magnitudes of tile k+2 at the top of the tick and use them a tick later, so no wavefront
 // ever waits for HBM.
 template <bool GEN_NOISE, bool FS64>
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][2 * kMfTapPlane];       // hi plane, lo plane
   __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
-  __shared__ __attribute__((aligned(16))) float s_carry[2][7][128];       // right halves handed from FIR wavefront w to w + 1
+  __shared__ __attribute__((aligned(16))) float s_carry[2][kMfPW - 1][128];       // right halves handed from FIR wavefront w to w + 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
@@ -230,10 +241,10 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
   const int ffirst_ = (z0_ >= 128) ? fq_ : -fq_;                                                        \
   const int rel0_ = (z0_ - 128) - ffirst_ * p.fs
 
-  if (wave < 8) {
+  if (wave < kMfPW) {
     // =========================== producer wavefronts ==================================================================
     const float kLog10 = 2.302585092994046f;
-    const int rg = wave & 3, mt = wave >> 2;           // row group, tap tile
+    const int rg = wave & (kMfPW / 2 - 1), mt = wave / (kMfPW / 2);           // row group, tap tile
     // the constant cosine factor of this tap tile as fp16 hi / lo A-fragments, made at compile time: [even / odd bins][hi / lo]
     mf_f16x8 afr[2][2];
 #pragma unroll
@@ -247,10 +258,10 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     // between the reversed noise frames (both copies), in both buffers
     if (mt == 0)
       *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (lane & 1) * kMfTapPlane + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 256) = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < 2 * 65 * 16; i += 512) {
-      unsigned char* const s_xe = s_x_all[i >= 65 * 16 ? 1 : 0];
+    for (int i = tid; i < 2 * (kMfRows + 1) * 16; i += 64 * kMfPW) {
+      unsigned char* const s_xe = s_x_all[i >= (kMfRows + 1) * 16 ? 1 : 0];
       unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
-      const int ii = i >= 65 * 16 ? i - 65 * 16 : i;
+      const int ii = i >= (kMfRows + 1) * 16 ? i - (kMfRows + 1) * 16 : i;
       const int e = 80 * (ii >> 4) + (ii & 15);                       // element index of a padding element
       // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
       *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     // left half stays in registers, and the two are added and stored at the start of the NEXT tick, behind the block's
     // barrier (a warm-up pair per wavefront instead would be a fifth pass: 25 % more MFMAs and LDS reads, and the LDS is
     // what bounds this phase).
-    const int cw = wave - 8;
+    const int cw = wave - kMfPW;
     const int p_first = 4 * cw;
     mf_f32x4 kept = {0.f, 0.f, 0.f, 0.f};      // the incomplete left half of this wavefront's first pair (cw >= 1), last tile
     float* kept_ot = nullptr;                  // where it goes: the tile's base pointer, offset and bounds of the previous tick
@@ -432,14 +443,14 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     };
 #pragma unroll 1
     for (int tick = -1; tick < n_my; ++tick) {
-      if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 0);
+      if (wave == p.dbg_wave - 8 + kMfPW) DDSP_MF_STAMP(tick, 2, 0);
       if (tick >= 1) flush_kept((tick - 1) & 1);
       if (tick < 0) {
         // nothing to filter yet: the noise of the block's first tile, while the producers design its taps
         const int T = (int)blockIdx.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)f_first; (void)rel0;
-        mf_noise_tile<GEN_NOISE>(tid - 512, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
+        mf_noise_tile<GEN_NOISE>(tid - 64 * kMfPW, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
       }
       bool active = false;
       if (tick >= 0) {
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
                 carry[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xF, 0xF, true));
               }
               // the last pair's right half: the next wavefront's missing part (the last wavefront's lies past the tile)
-              if (it == 3 && cw < 7 && mi >= 8)
+              if (it == 3 && cw < kMfPW - 1 && mi >= 8)
                 *reinterpret_cast<float4*>(&s_carry[tick & 1][cw][lane_off - 128]) = make_float4(comb[0], comb[1], comb[2], comb[3]);
             }
           }
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       } else {
         kept_ot = nullptr;
       }
-      if (wave == p.dbg_wave) DDSP_MF_STAMP(tick, 2, 1);
+      if (wave == p.dbg_wave - 8 + kMfPW) DDSP_MF_STAMP(tick, 2, 1);
       __syncthreads();
     }
     flush_kept((n_my - 1) & 1);                // the last tile's boundaries (nothing writes s_carry any more)
@@ -597,7 +608,7 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
   q.fs = (N + F - 1) / F; q.inv_fs = 1.0f / (float)q.fs;
   q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
   q.dbg = dbg;
-  static const int dbg_wave = [] { const char* e = getenv("DDSP_MF_DBG_WAVE"); const int v = e ? atoi(e) : 8; return v >= 8 && v < 16 ? v : 8; }();
+  static const int dbg_wave = [] { const char* e = getenv("DDSP_MF_DBG_WAVE"); const int v = e ? atoi(e) : 8; return v >= 8 && v < 8 + kMfPW ? v : 8; }();
   q.dbg_wave = dbg_wave;
   q.tiles_per_row = (N + start + kMfTile - 1) / kMfTile;
   q.n_tiles = B * q.tiles_per_row;
@@ -612,7 +623,8 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
       v = 256;
     return v;
   }();
-  const dim3 grid((unsigned)(q.n_tiles < n_cu ? q.n_tiles : n_cu));
+  const int slots = n_cu * (kMfWaves == 16 ? 1 : 2);
+  const dim3 grid((unsigned)(q.n_tiles < slots ? q.n_tiles : slots));
   hipEvent_t ev0, ev1;
   profile_kernel_events(kNoiseMfma, &ev0, &ev1);
 #define DDSP_LAUNCH_MF(GEN, FS64)                                                                                      \
