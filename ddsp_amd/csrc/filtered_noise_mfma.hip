@@ -50,7 +50,9 @@ namespace ddsp {
 // A tile: kMfRows staged frames = kMfRows / 2 pairs; the first pair is only history (the 128 taps reach 127 samples back),
 // the others are output.
 // Block size.  8 wavefronts (4 producers + 4 FIR) on tiles of 30 output frames, TWO blocks per CU: each block has its own
-// barrier, so one block's wait at it is the other block's time (13.7 / 39.1 us at batch 32 / 128).  16 wavefronts on tiles of
+// barrier, so one block's wait at it is the other block's time (13.7 / 39.1 us at batch 32 / 128).  The two blocks of a
+// CU do not advance together - the arbiter prefers the older block's wavefronts: its ticks take 2.8 us, the younger
+// block's 4.5-6 us until the older one is done (DDSP_MF_DBG_BLOCK picks the block the timeline shows).  16 wavefronts on tiles of
 // 62 frames, one block per CU (-DDDSP_MF_WAVES=16): 3 % less history to recompute, but every tick ends with sixteen
 // wavefronts waiting for the slowest (15.2 / 40.7 us; profiles/r02_final2_noise_mfma_two_blocks_per_cu.txt).
 #ifndef DDSP_MF_WAVES
@@ -94,6 +96,7 @@ struct MfArgs {
   int tiles_per_row, n_tiles;       // tiles of 62 frames per batch row; B * tiles_per_row
   FastDiv whole_per_row, fs_div;    // max(tiles_per_row - 1, 1); fs
   int n_whole;                      // B * (tiles_per_row - 1): the tiles before the rows' last ones
+  int dbg_block;                    // the block whose times are stamped (DDSP_MF_DBG_BLOCK, default 0)
   int dbg_wave;                     // the FIR wavefront (8 .. 15) whose times are stamped; the producer is dbg_wave - 8
   long long* dbg;                   // block 0's per-tick stamps [16 ticks][3 roles][begin, end] (tools/exp_noise_fir.py), or null
 };
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, mg = lane >> 4;            // MFMA fragment coordinates
   const int n_my = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this block
-  long long* dbg = (p.dbg && blockIdx.x == 0) ? p.dbg : nullptr;                              // block 0: [tick][role][2]
+  long long* dbg = (p.dbg && (int)blockIdx.x == p.dbg_block) ? p.dbg : nullptr;                              // block 0: [tick][role][2]
 #define DDSP_MF_STAMP(tick, role, i) do { if (dbg && lane == 0 && (tick) + 1 < 16) dbg[(((tick) + 1) * 3 + (role)) * 2 + (i)] = wall_clock64(); } while (0)
   // tile T -> (batch row, tile tx of the row): first output z0 = 3968 tx (a multiple of 64); tap rows: frames f_first ..
   // f_first + 63 (frames of the inputs x[z0-128 ..]); negative for the first tile.  The rows' LAST tiles come last in the
@@ -610,6 +613,8 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
   q.dbg = dbg;
   static const int dbg_wave = [] { const char* e = getenv("DDSP_MF_DBG_WAVE"); const int v = e ? atoi(e) : 8; return v >= 8 && v < 8 + kMfPW ? v : 8; }();
   q.dbg_wave = dbg_wave;
+  static const int dbg_block = [] { const char* e = getenv("DDSP_MF_DBG_BLOCK"); return e ? atoi(e) : 0; }();
+  q.dbg_block = dbg_block;
   q.tiles_per_row = (N + start + kMfTile - 1) / kMfTile;
   q.n_tiles = B * q.tiles_per_row;
   q.whole_per_row = make_fastdiv((uint32_t)(q.tiles_per_row > 1 ? q.tiles_per_row - 1 : 1));

@@ -5,7 +5,9 @@ agreement between them, and the in-kernel phase timeline of the matrix-core kern
     python tools/exp_noise_fir.py [batch ...]
 
 DDSP_MF_DBG_WAVE=8..15 picks the FIR wavefront (and producer wavefront - 8) whose per-tick stamps the timeline shows: the
-youngest wavefront of a SIMD is the slow one (profiles/r02n_noise_mfma_v7_per_wavefront_timeline.txt).
+youngest wavefront of a SIMD is the slow one (profiles/r02n_noise_mfma_v7_per_wavefront_timeline.txt).  The FIR wavefronts of
+the default build (two blocks of 8 wavefronts per CU) are 8..11; DDSP_MF_DBG_BLOCK=<block> picks the block (blocks >= the CU
+count are the second, younger blocks of their CUs).
 """
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
