@@ -1,0 +1,166 @@
+"""GPU parity at the shapes the contract is quoted on: BASELINE.json's north-star shape
+(batch 128 x 4 s @ 16 kHz, 100 harmonics, 65 bands; ddsp/training/gin/models/ae.gin:15,31-33,59-68), configs[4] at
+full length (48 kHz, 200 harmonics, 10 s, frame size 192; gin/models/vst/vst_48k.gin:16-17,102), configs[3]'s per-GPU
+node (ProcessorGroup[Harmonic, FilteredNoise, Add, Reverb(48 000 taps)] at batch 128; gin/models/solo_instrument.gin:26-40)
+and every row of configs[1] (batch 32).  What the smaller parity tests cannot see: the multi-tick schedules of the
+persistent kernels (16.5 chunks per block at batch 128 against 4 at batch 32), the buffer rotation over many ticks,
+the fp64 phase prefix over 2500 frames.
+
+Tolerances are the ones of tests/test_gpu_parity.py (HARM_TABLE_ATOL for the wavetable kernel, HARM_TRUTH_ATOL for
+the direct sum, noise_tol for the FIR); every comparison is logged to $DDSP_PARITY_LOG.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_check
+from oracle import ddsp_oracle as O
+from test_gpu_parity import (DEV, HARM_TABLE_ATOL, HARM_TRUTH_ATOL, _harmonic_exact, canonical_inputs, ddsp,  # noqa: F401
+                             noise_tol, npy, reverb_tol)
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_equal_alone(run, args, full, rows):
+  """Row r of the batched result is bit-equal to the same row run as a batch of one (batch rows are independent)."""
+  for r in rows:
+    one = npy(run(*[a[r:r + 1] for a in args]))
+    np.testing.assert_array_equal(one, full[r:r + 1], err_msg='row %d' % r)
+
+
+def test_north_star_shape_batch128_harmonic(ddsp):
+  b = 128
+  x = canonical_inputs(b, seed=21)
+  harm = ddsp.synths.Harmonic()
+  args = tuple(torch.as_tensor(x[k], device=DEV) for k in ('amplitudes', 'harmonic_distribution', 'f0_hz'))
+  full = npy(harm(*args))
+  assert full.shape == (b, 64000) and np.isfinite(full).all()
+  # every row: bit-equal to the row run alone, and to the row inside a batch of 32 (configs[1]'s schedule)
+  _rows_equal_alone(harm, args, full, range(b))
+  for q in range(4):
+    np.testing.assert_array_equal(npy(harm(*[a[32 * q:32 * q + 32] for a in args])), full[32 * q:32 * q + 32])
+  # 8 random rows against exact arithmetic, 2 of them against the oracle's fp64 truth as well
+  rng = np.random.default_rng(22)
+  rows = sorted(rng.choice(b, 8, replace=False).tolist())
+  scale = max(1.0, float(O.exp_sigmoid(x['amplitudes'].astype(np.float64), dtype=np.float64).max()))
+  for i, r in enumerate(rows):
+    sl = slice(r, r + 1)
+    exact = _harmonic_exact(x['amplitudes'][sl], x['harmonic_distribution'][sl], x['f0_hz'][sl], 64000, 16000, 'window')
+    parity_check(full[sl], exact, HARM_TABLE_ATOL * scale, 'batch 128 row %d vs exact arithmetic' % r)
+    if i < 2:
+      truth = O.harmonic(x['amplitudes'][sl], x['harmonic_distribution'][sl], x['f0_hz'][sl], dtype=np.float64)
+      parity_check(full[sl], truth, HARM_TABLE_ATOL * scale, 'batch 128 row %d vs fp64 oracle' % r)
+
+
+def test_north_star_shape_batch128_filtered_noise(ddsp):
+  b = 128
+  x = canonical_inputs(b, seed=23)
+  mags = torch.as_tensor(x['magnitudes'], device=DEV)
+  rng = np.random.default_rng(24)
+  noise_np = rng.uniform(-1, 1, (b, 64000)).astype(np.float32)
+  noise = torch.as_tensor(noise_np, device=DEV)
+  fn = ddsp.synths.FilteredNoise(window_size=0)
+  full = npy(fn(mags, noise=noise))
+  assert full.shape == (b, 64000) and np.isfinite(full).all()
+  _rows_equal_alone(lambda m, z: fn(m, noise=z), (mags, noise), full, range(b))
+  for q in range(4):
+    np.testing.assert_array_equal(npy(fn(mags[32 * q:32 * q + 32], noise=noise[32 * q:32 * q + 32])),
+                                  full[32 * q:32 * q + 32])
+  rows = sorted(rng.choice(b, 8, replace=False).tolist())
+  for r in rows:
+    ref = O.filtered_noise(x['magnitudes'][r:r + 1], noise_np[r:r + 1], 0, dtype=np.float64)
+    parity_check(full[r:r + 1], ref, noise_tol(ref), 'batch 128 row %d vs fp64 oracle' % r)
+  # generated noise (what the bench runs): rows against the generator's restatement pushed through the fp64 oracle
+  gen = ddsp.synths.FilteredNoise(window_size=0, seed=7)
+  y = npy(gen(mags))
+  u = O.device_uniform_noise(b, 64000, 7, 0)
+  for r in rows[:4]:
+    ref = O.filtered_noise(x['magnitudes'][r:r + 1], u[r:r + 1], 0, dtype=np.float64)
+    parity_check(y[r:r + 1], ref, noise_tol(ref), 'batch 128 row %d, generated noise' % r)
+
+
+def test_config5_full_length_48k_200_harmonics(ddsp):
+  """BASELINE configs[4] per clip: 10 s at 48 kHz, 2500 frames of 192 samples, 200 harmonics, 'linear' envelopes,
+  angular cumsum (vst_48k.gin), Harmonic and FilteredNoise, against exact arithmetic / the fp64 oracle."""
+  b, f, hop, k, sr = 2, 2500, 192, 200, 48000
+  n = f * hop
+  rng = np.random.default_rng(31)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = (100 + rng.standard_normal((b, f, 1))).astype(np.float32)
+  mags = rng.standard_normal((b, f, 65)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method='linear', use_angular_cumsum=True)
+  ours = npy(synth(amps, hd, f0))
+  assert ours.shape == (b, n)
+  exact = _harmonic_exact(amps, hd, f0, n, sr, 'linear')
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  # the direct sum is held to HARM_TRUTH_ATOL, the wavetable kernel (K <= 256 since round 3) to HARM_TABLE_ATOL
+  parity_check(ours, exact, HARM_TRUTH_ATOL * scale, 'config 5 full length vs exact arithmetic')
+  np.testing.assert_array_equal(npy(synth(amps[1:], hd[1:], f0[1:])), ours[1:])
+  noise_np = rng.uniform(-1, 1, (b, n)).astype(np.float32)
+  fn = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
+  z = npy(fn(mags, noise=noise_np))
+  ref = O.filtered_noise(mags, noise_np, 0, dtype=np.float64)
+  parity_check(z, ref, noise_tol(ref), 'config 5 full length FilteredNoise vs fp64 oracle')
+
+
+def test_config4_node_processor_group_reverb_batch128(ddsp):
+  """BASELINE configs[3] per GPU: ProcessorGroup[Harmonic, FilteredNoise, Add, Reverb(48 000)] at batch 128
+  (solo_instrument.gin:26-40); two rows against the oracle, every row of the dry mix against its parts."""
+  b, n, l = 128, 64000, 48000
+  x = canonical_inputs(b, seed=41)
+  feats = {'amps': x['amplitudes'], 'harmonic_distribution': x['harmonic_distribution'], 'f0_hz': x['f0_hz'],
+           'magnitudes': x['magnitudes']}
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=3)
+  add = ddsp.processors.Add()
+  rev = ddsp.effects.Reverb(trainable=True, reverb_length=l)
+  rev.build(device=torch.device(DEV))
+  rng = np.random.default_rng(42)
+  rev._ir = ddsp.core.tf_float32(rng.standard_normal(l) * np.exp(-np.arange(l) / 2000.0) * 0.05)
+  dag = [(harm, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
+         (add, ['filtered_noise/signal', 'harmonic/signal']), (rev, ['add/signal'])]
+  group = ddsp.processors.ProcessorGroup(dag=dag)
+  outs = group.get_controls(feats)
+  h, z = npy(outs['harmonic']['signal']), npy(outs['filtered_noise']['signal'])
+  dry = npy(outs['add']['signal'])
+  np.testing.assert_array_equal(dry, h + z)
+  got = npy(group.get_signal(outs))
+  assert got.shape == (b, n) and np.isfinite(got).all()
+  u = O.device_uniform_noise(b, n, 3, 0)
+  scale = max(1.0, float(O.exp_sigmoid(x['amplitudes'].astype(np.float64), dtype=np.float64).max()))
+  for r in (5, 101):
+    sl = slice(r, r + 1)
+    truth_h = O.harmonic(x['amplitudes'][sl], x['harmonic_distribution'][sl], x['f0_hz'][sl], n, dtype=np.float64)
+    parity_check(h[sl], truth_h, HARM_TABLE_ATOL * scale, 'config 4 node, harmonic row %d' % r)
+    truth_z = O.filtered_noise(x['magnitudes'][sl], u[sl], 0, dtype=np.float64)
+    parity_check(z[sl], truth_z, noise_tol(truth_z), 'config 4 node, noise row %d' % r)
+    ref = O.reverb(truth_h + truth_z, npy(rev._ir), add_dry=True, dtype=np.float64)
+    parity_check(got[sl], ref, reverb_tol(ref) + HARM_TABLE_ATOL * scale * 4, 'config 4 node, output row %d' % r)
+    # the Reverb alone, on the dry mix the GPU produced
+    ref2 = O.reverb(dry[sl], npy(rev._ir), add_dry=True, dtype=np.float64)
+    parity_check(got[sl], ref2, reverb_tol(ref2), 'config 4 node, reverb row %d' % r)
+
+
+def test_config1_batch32_every_row(ddsp):
+  """Every row of configs[1] (batch 32): bit-equal to the row run alone (both default kernels), four rows against the
+  oracle (tests/test_gpu_parity.py::test_full_size_properties_batch32 compares one)."""
+  b = 32
+  x = canonical_inputs(b, seed=5)
+  harm, fn = ddsp.synths.Harmonic(), ddsp.synths.FilteredNoise(window_size=0)
+  args = tuple(torch.as_tensor(x[k], device=DEV) for k in ('amplitudes', 'harmonic_distribution', 'f0_hz'))
+  full = npy(harm(*args))
+  _rows_equal_alone(harm, args, full, range(b))
+  scale = max(1.0, float(O.exp_sigmoid(x['amplitudes'].astype(np.float64), dtype=np.float64).max()))
+  for r in (0, 13, 22, 31):
+    sl = slice(r, r + 1)
+    truth = O.harmonic(x['amplitudes'][sl], x['harmonic_distribution'][sl], x['f0_hz'][sl], dtype=np.float64)
+    parity_check(full[sl], truth, HARM_TABLE_ATOL * scale, 'batch 32 row %d vs fp64 oracle' % r)
+  rng = np.random.default_rng(6)
+  noise_np = rng.uniform(-1, 1, (b, 64000)).astype(np.float32)
+  mags, noise = torch.as_tensor(x['magnitudes'], device=DEV), torch.as_tensor(noise_np, device=DEV)
+  y = npy(fn(mags, noise=noise))
+  _rows_equal_alone(lambda m, z: fn(m, noise=z), (mags, noise), y, range(b))
+  for r in (0, 13, 22, 31):
+    ref = O.filtered_noise(x['magnitudes'][r:r + 1], noise_np[r:r + 1], 0, dtype=np.float64)
+    parity_check(y[r:r + 1], ref, noise_tol(ref), 'batch 32 row %d vs fp64 oracle' % r)
