@@ -180,4 +180,40 @@ __device__ __forceinline__ void load_settle(ddsp_f32x4& a, ddsp_f32x4& b, ddsp_f
 #endif
 }
 
+// A global load of one dword / 16 bytes that is ISSUED where it is written (see load_issue) and first touched behind
+// loads_landed(): the S-wavefronts of harm_wt16_kernel fetch the rows of a later chunk a whole tick before they use them.
+__device__ __forceinline__ void load_issue(float& dst, const float* src) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src));
+#else
+  dst = *src;
+#endif
+}
+// every load this wavefront has issued has landed; the listed values are ordered behind the wait
+__device__ __forceinline__ void loads_landed(ddsp_f32x4& a, float& b, float& c) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+#else
+  (void)a; (void)b; (void)c;
+#endif
+}
+__device__ __forceinline__ void loads_landed(float& a, float& b, float& c) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+#else
+  (void)a; (void)b; (void)c;
+#endif
+}
+
+// v_permlane16_swap_b32 with both operands the same value: every lane receives the sum of its own 16-lane row's value
+// and its partner row's (rows 0 <-> 1, 2 <-> 3).  The instruction swaps the odd rows of its first operand with the even
+// rows of its second: afterwards one register holds rows (0, 0, 2, 2), the other rows (1, 1, 3, 3).
+__device__ __forceinline__ float row_pair_sum(float v) {
+  typedef unsigned ddsp_u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned bits = __builtin_bit_cast(unsigned, v);
+  const ddsp_u32x2 r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+
 }  // namespace ddsp

@@ -538,6 +538,617 @@ __global__ __launch_bounds__(768, 3) void harm_table_kernel(
 #undef DDSP_WT_ADVANCE
 }
 
+// =====================================================================================================================
+// Round 3: the same method on SIXTEEN wavefronts (harm_wt16_kernel), the default.
+//
+// What the round-3 microbenchmarks say about this chip (profiles/r03a_*, r03b_*): one wavefront issues at most one
+// instruction per ~6.5 clocks whatever its kind; a SIMD issues one per ~3.4 clocks from two busy wavefronts, ~2.5 from
+// three, ~2.15 from four, 1.6 from eight.  harm_table_kernel above has two busy (S) wavefronts per SIMD, so every
+// instruction it executes costs ~1.6 times its price at full occupancy, and ~a quarter of its instructions are scalar
+// bookkeeping that costs as much as vector work.  Here:
+//   * 4 T + 12 S wavefronts (three busy wavefronts per SIMD), 128 VGPRs: the T-wavefronts no longer fetch rows - every
+//     S-wavefront loads the rows of ITS phase A straight from HBM into registers a tick ahead (no LDS staging buffer,
+//     no staging writes, no re-read) - so the T role is the constant factor (64 VGPRs), the MFMAs and the table;
+//   * a block owns a CONTIGUOUS run of frames, cut into chunks of equal length (<= 31): the fp64 phase prefix is
+//     carried from chunk to chunk instead of re-summed from the start of the row every tick, and a batch of 32 clips
+//     is 5 ticks of 25 frames per block instead of 4.1 -> 5 ticks of 31;
+//   * phase tables by one T-wavefront from its own loads of f0 (33 floats), chunk descriptors walked by another, one
+//     16-byte descriptor read per wavefront and tick: the scalar work per tick is a fraction of what it was;
+//   * the pipeline is three stages deep (phase A, tabulate, phase B): two fill ticks instead of three;
+//   * phase A without v_readlane (v_permlane16_swap for the sum of a row pair) and without compare / select for the
+//     Nyquist mask (v_med3_f32); phase B folds theta into [0, 1/2] with |x| and restores the sign with a xor.
+// Results are independent of how the frames are cut into chunks: every quantity of a frame depends on its own two rows
+// and on an fp64 prefix that is exact for any f0 a synthesiser sees.
+struct WtDesc { int b, j0, nfr, fresh; };        // a chunk: frames j0 .. j0 + nfr - 1 of row b; nfr == 0: none
+
+struct Wt16Args {
+  int B, F, K, N, hop;
+  int total_frames, frames_per_block;
+  FastDiv f_div, tpf_div;        // F; hop / 64
+  float nyquist, nyq_lo, nyq_hi;
+  int amp_linear;
+  double inv_sr, inv_2hop, hop_d, half_hm1;
+  long long* dbg;      // DDSP_EXP_TABLE_TIMELINE=1: shader-clock stamps of block 0, [wavefront][tick + 2][stamp]; or null
+};
+
+struct WtWalk { int pos, end, seg_left, base, rem, b, j; };
+
+// the next chunk of the block's run of frames (one wavefront, wave-uniform arithmetic)
+__device__ __forceinline__ WtDesc wt_next_chunk(WtWalk& w, const Wt16Args& p) {
+  WtDesc d{0, 0, 0, 0};
+  if (w.pos >= w.end) return d;
+  if (w.seg_left == 0) {                      // a new row segment: cut it into equal chunks
+    uint32_t j;
+    w.b = (int)fastdiv((uint32_t)w.pos, p.f_div, j);
+    w.j = (int)j;
+    w.seg_left = min(w.end - w.pos, p.F - w.j);
+    const int n = (w.seg_left + kWtFrames - 1) / kWtFrames;
+    w.base = w.seg_left / n;
+    w.rem = w.seg_left - w.base * n;
+    d.fresh = 1;
+  }
+  const int len = w.base + (w.rem > 0 ? 1 : 0);
+  if (w.rem > 0) --w.rem;
+  d.b = w.b; d.j0 = w.j; d.nfr = len;
+  w.pos += len; w.j += len; w.seg_left -= len;
+  return d;
+}
+
+__device__ __forceinline__ WtDesc wt_read_desc(const WtDesc* ring, int slot) {
+  const int4 v = *reinterpret_cast<const int4*>(ring + slot);
+  WtDesc d;
+  d.b = __builtin_amdgcn_readfirstlane(v.x);
+  d.j0 = __builtin_amdgcn_readfirstlane(v.y);
+  d.nfr = __builtin_amdgcn_readfirstlane(v.z);
+  d.fresh = __builtin_amdgcn_readfirstlane(v.w);
+  return d;
+}
+
+// ---- phase B on packed fp32 pairs (v_pk_fma_f32: two FMAs per issued instruction; a wavefront issues one instruction
+// per ~8 clocks whatever it is, profiles/r03b_*) ---------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (e, o) <- (e, o) * z^2 + (ce, co), zz = (z, z^2)
+__device__ __forceinline__ f32x2 wt_pk_horner(f32x2 eo, f32x2 zz, f32x2 coef) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(eo), "v"(zz), "v"(coef));
+  return r;
+#else
+  return (f32x2){fmaf(eo[0], zz[1], coef[0]), fmaf(eo[1], zz[1], coef[1])};
+#endif
+}
+// the window weights of a tap pair: (e + z o, e - z o)
+__device__ __forceinline__ f32x2 wt_pk_weights(f32x2 eo, f32x2 zz) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(eo), "v"(zz));
+  return r;
+#else
+  return (f32x2){fmaf(eo[1], zz[0], eo[0]), fmaf(eo[1], -zz[0], eo[0])};
+#endif
+}
+__device__ __forceinline__ f32x2 wt_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return (f32x2){fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+#endif
+}
+// coefficient pairs of the window polynomials, highest power first: step s of tap pair P is (E_{3-s}, O_{3-s})
+// (O_3 = 0 for the 6-tap window, whose odd part is a quadratic in z^2)
+template <int W> struct WtPkCoef {
+  static constexpr int D = 3;
+  static_assert(WtPoly<W>::DE == 3 && WtPoly<W>::DO <= 3, "window polynomial degrees");
+  static constexpr float e(int P, int s) { return WtPoly<W>::e(P, D - s); }
+  static constexpr float o(int P, int s) { return (D - s) <= WtPoly<W>::DO ? WtPoly<W>::o(P, D - s) : 0.0f; }
+};
+template <int W, int P, int S> struct WtPkE { static constexpr float v = WtPkCoef<W>::e(P, S); };
+template <int W, int P, int S> struct WtPkO { static constexpr float v = WtPkCoef<W>::o(P, S); };
+
+// NT tiles at once; per tile 4 packed FMAs per tap pair for the weights, 2 for the taps (rows j and j + 1)
+template <int W, int P, int NT>
+__device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const f32x2 (&zz)[kWtNT], const f32x2 (&coef)[W / 2][4],
+                                           f32x2 (&acc0)[kWtNT], f32x2 (&acc1)[kWtNT]) {
+  f32x2 w[NT], d0[NT], d1[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    f32x2 eo = wt_pk_horner(coef[P][0], zz[u], coef[P][1]);
+    eo = wt_pk_horner(eo, zz[u], coef[P][2]);
+    eo = wt_pk_horner(eo, zz[u], coef[P][3]);
+    w[u] = wt_pk_weights(eo, zz[u]);
+    d0[u] = (f32x2){t[u][-P], t[u][1 + P]};
+    d1[u] = (f32x2){t[u][kWtTS - P], t[u][kWtTS + 1 + P]};
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) { acc0[u] = wt_pk_fma(w[u], d0[u], acc0[u]); acc1[u] = wt_pk_fma(w[u], d1[u], acc1[u]); }
+  if constexpr (P + 1 < W / 2) wt_taps_pk<W, P + 1, NT>(t, zz, coef, acc0, acc1);
+}
+template <int W, int P>
+__device__ __forceinline__ void wt_pk_coefs(f32x2 (&coef)[W / 2][4]) {
+  coef[P][0] = (f32x2){WtPkE<W, P, 0>::v, WtPkO<W, P, 0>::v};
+  coef[P][1] = (f32x2){WtPkE<W, P, 1>::v, WtPkO<W, P, 1>::v};
+  coef[P][2] = (f32x2){WtPkE<W, P, 2>::v, WtPkO<W, P, 2>::v};
+  coef[P][3] = (f32x2){WtPkE<W, P, 3>::v, WtPkO<W, P, 3>::v};
+#if defined(__AMDGCN__)
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) __asm__ volatile("" : "+v"(coef[P][s_]));      // resident: not re-made from literals at every use
+#endif
+  if constexpr (P + 1 < W / 2) wt_pk_coefs<W, P + 1>(coef);
+}
+
+template <int W, int NK, bool ONE_TILE>
+__global__ __launch_bounds__(1024) void harm_wt16_kernel(
+    const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
+    float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, Wt16Args p) {
+  __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
+  __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
+  __shared__ ChunkTables t_all[2];
+  __shared__ __attribute__((aligned(16))) WtDesc ring[8];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_t = wave < 4;
+  const int F = p.F, K = p.K;
+  const int K4 = K >> 2;
+  const float kLog10 = 2.302585092994046f;       // tf.math.log(exponent), ddsp/core.py:403
+  const int sub = lane >> 5, kq = lane & 31;     // phase A: 32 lanes per row, lane kq owns harmonics 4 kq + 1 .. 4 kq + 4
+  const bool live = kq < K4;
+  const float4* __restrict__ hd4 = reinterpret_cast<const float4*>(hd);
+  const int mi = lane & 15, mg = lane >> 4;      // MFMA fragment coordinates
+#ifdef DDSP_WT16_TIMELINE
+  const bool dbg_on = p.dbg != nullptr && blockIdx.x == 0 && lane == 0;
+#define DDSP_WT_STAMP(i) do { if (dbg_on && tick + 2 < 24) p.dbg[(wave * 24 + tick + 2) * 8 + (i)] = clock64(); } while (0)
+#else
+#define DDSP_WT_STAMP(i) do { } while (0)
+#endif
+
+  // ---- the first two chunk descriptors (wavefront 0), then everybody reads ----------------------------------------
+  WtWalk walk;
+  walk.pos = (int)blockIdx.x * p.frames_per_block;
+  walk.end = min(walk.pos + p.frames_per_block, p.total_frames);
+  walk.seg_left = 0; walk.base = 0; walk.rem = 0; walk.b = 0; walk.j = 0;
+  if (wave == 0) {
+    const WtDesc d0 = wt_next_chunk(walk, p), d1 = wt_next_chunk(walk, p);
+    if (lane == 0) { ring[0] = d0; ring[1] = d1; }
+  }
+  __syncthreads();
+  // descriptors of the chunks in flight at tick tau: dL = chunk tau + 3 (rows fetched), dA = tau + 2 (phase A),
+  // dM = tau + 1 (tabulated), dB = tau (phase B)
+  WtDesc dL{0, 0, 0, 0}, dA = wt_read_desc(ring, 0), dM{0, 0, 0, 0}, dB{0, 0, 0, 0};
+  int pa = 0, pm = 2, pb = 1;                    // plane buffers of dA, dM, dB: chunk c uses buffer c % 3
+
+  // the descriptor of chunk tick + 3: read issued at the top of a tick, taken into scalar registers at its end
+  int4 dnext = make_int4(0, 0, 0, 0);
+  auto desc_issue = [&](int slot) { dnext = *reinterpret_cast<const int4*>(ring + slot); };
+  auto desc_take = [&]() {
+    dL.b = __builtin_amdgcn_readfirstlane(dnext.x);
+    dL.j0 = __builtin_amdgcn_readfirstlane(dnext.y);
+    dL.nfr = __builtin_amdgcn_readfirstlane(dnext.z);
+    dL.fresh = __builtin_amdgcn_readfirstlane(dnext.w);
+  };
+
+  if (is_t) {
+    const int rw = wave;
+    // ---- this wavefront's share of the constant factor, in MFMA A-operand layout (harm_table_frags.h) ---------------
+    f16x8 ahi[2][2][NK], alo[2][2][NK];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vh = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][0][par][tt][ks][lane]);
+          const u32x4 vl = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][1][par][tt][ks][lane]);
+          ahi[par][tt][ks] = __builtin_bit_cast(f16x8, vh);
+          alo[par][tt][ks] = __builtin_bit_cast(f16x8, vl);
+        }
+    // wavefront 3 builds the per-frame phase tables (lanes = frames 0 .. 32): f0 of the chunk's frames, issued before the
+    // MFMAs of the tick and used after them; `before` = the sum of f0 over the frames of the row before the chunk, carried
+    // from chunk to chunk and summed afresh (fp64: exact, so the same bits in any order) at the start of a row segment
+    float pf_cur = 0.0f, pf_next = 0.0f, pf_first = 0.0f;
+    double before = 0.0;
+    auto fetch_f0 = [&](const WtDesc& d) {
+      int lane_ = lane;
+      DDSP_KEEP_IN_VGPR(lane_);
+      const float* __restrict__ f0row = f0_all + (size_t)d.b * F;
+      load_issue(pf_cur, f0row + min(d.j0 + lane_, F - 1));
+      load_issue(pf_next, f0row + min(d.j0 + lane_ + 1, F - 1));
+      load_issue(pf_first, f0row);
+    };
+    auto row_prefix = [&](const WtDesc& d) -> double {
+      int lane = tid & 63;
+      DDSP_KEEP_IN_VGPR(lane);
+      const float* __restrict__ f0row = f0_all + (size_t)d.b * F;
+      double part = 0.0;
+      if ((F & 3) == 0 && (((uintptr_t)f0_all) & 15) == 0) {
+        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f0row);
+        const int n4 = d.j0 >> 2;
+        for (int i = lane; i < n4; i += 256) {             // four loads in flight per pass
+          const float4 a = f4[i];
+          const float4 b = f4[min(i + 64, n4 - 1)], c = f4[min(i + 128, n4 - 1)], e = f4[min(i + 192, n4 - 1)];
+          part += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+          if (i + 64 < n4) part += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+          if (i + 128 < n4) part += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);
+          if (i + 192 < n4) part += ((double)e.x + (double)e.y) + ((double)e.z + (double)e.w);
+        }
+        const int jt = (n4 << 2) + lane;
+        if (jt < d.j0) part += (double)f0row[jt];
+      } else {
+        for (int j = lane; j < d.j0; j += 64) part += (double)f0row[j];
+      }
+      return wave_sum_dpp(part);
+    };
+
+    for (int tick = -2;; ++tick) {
+      DDSP_WT_STAMP(0);
+      if (rw == 3 && dM.nfr > 0) {
+        if (dM.fresh) before = row_prefix(dM);
+        fetch_f0(dM);
+      }
+      // ---------------- table of chunk tick + 1: O and E on the quarter range ---------------------------------------
+      if (dM.nfr > 0) {
+#pragma unroll
+       for (int rt = 0; rt < kWtRowTiles; ++rt) {
+        // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row 16 rt + j][32 ks + 8 g + e]
+        const _Float16* bsrc = planes_all[pm] + (16 * rt + mi) * kWtPS + 8 * mg;
+        // one parity at a time (four accumulators live, not eight: the constant factor already takes 64 registers)
+        f32x4 soe[2][2];                                     // [parity][position tile]: hi.hi + (hi.lo + lo.hi) / 2048
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          f32x4 acc[2], accx[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) {
+            const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS + 32 * ks);
+            const f16x8 blo = *reinterpret_cast<const f16x8*>(bsrc + (1 * 2 + par) * kWtRows * kWtPS + 32 * ks);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][tt][ks], bhi, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][tt][ks], blo, accx[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[tt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) soe[par][tt] = acc[tt] + accx[tt] * (1.0f / kWtLoScale);
+        }
+        // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
+        float* trow = tab_all[(tick + 1) & 1] + (16 * rt + mi) * kWtTS + kWtH;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int n0 = 16 * (2 * rw + tt) + 4 * mg;
+          const f32x4 so = soe[0][tt], se = soe[1][tt];     // odd, even harmonics
+          const f32x4 sp = so + se;                         // S(n)         = O + E
+          const f32x4 sm = so - se;                         // S(T/2-1-n)   = O - E
+          *reinterpret_cast<f32x4*>(trow + n0) = sp;
+          *reinterpret_cast<f32x4*>(trow + (kWtHalf - 4 - n0)) = (f32x4){sm.w, sm.z, sm.y, sm.x};
+          if (n0 == 0) {                                     // halos: S(-1-m) = -S(m), S(T/2+m) = -S(T/2-1-m)
+            *reinterpret_cast<f32x4*>(trow - kWtH) = (f32x4){-sp.w, -sp.z, -sp.y, -sp.x};
+            *reinterpret_cast<f32x4*>(trow + kWtHalf) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
+          }
+        }
+       }
+      }
+      DDSP_WT_STAMP(1);
+      desc_issue((tick + 3) & 7);
+      // ---------------- wavefront 3: the per-frame phase tables of chunk tick + 1 ---------------------------------------
+      if (rw == 3) {
+        if (dM.nfr > 0) {
+          loads_landed(pf_cur, pf_next, pf_first);
+          // (an opaque lane number and K: what depends on them is made here, once per tick on one wavefront, instead of
+          // being hoisted out of the loop into registers the T-wavefronts do not have)
+          int lane = tid & 63, Kc = K;
+          DDSP_KEEP_IN_VGPR(lane);
+#if defined(__AMDGCN__)
+          __asm__ volatile("" : "+s"(Kc));
+#endif
+          ChunkTables& t = t_all[(tick + 1) & 1];
+          const int nfr = dM.nfr;
+          const float fj = pf_cur, fj1 = pf_next;
+          const double fa = (double)fj, fb = (double)fj1;
+          const double mine = (lane < nfr) ? fa : 0.0;
+          double incl = mine;                                 // inclusive scan over the chunk's frames (lanes 0..31)
+          incl += dpp_mov0<0x111, 0xF>(incl);   // row_shr:1
+          incl += dpp_mov0<0x112, 0xF>(incl);   // row_shr:2
+          incl += dpp_mov0<0x114, 0xF>(incl);   // row_shr:4
+          incl += dpp_mov0<0x118, 0xF>(incl);   // row_shr:8
+          const long long bits15 = __builtin_bit_cast(long long, incl);
+          const unsigned lo15 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits15 & 0xffffffffll), 15);
+          const unsigned hi15 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits15 >> 32), 15);
+          const double first16 = __builtin_bit_cast(double, (long long)(((unsigned long long)hi15 << 32) | lo15));
+          if (lane >= 16) incl += first16;
+          const double s_excl = before + (incl - mine);
+          const double run = p.hop_d * s_excl + (fa - (double)pf_first) * p.half_hm1;
+          const double cyc = run * p.inv_sr;
+          const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
+          int kA = Kc, kN = Kc;
+          if (fmx > 0.0f) kA = (int)fminf((float)Kc, floorf(p.nyq_lo * __builtin_amdgcn_rcpf(fmx)));
+          if (fmn > 0.0f) kN = (int)fminf((float)Kc, floorf(p.nyq_hi * __builtin_amdgcn_rcpf(fmn)));
+          kA = max(min(kA, kN), 0);
+          const bool crossing = lane < nfr && kA < kN;
+          const unsigned long long any = __builtin_amdgcn_ballot_w64(crossing);
+          if (lane == 0) t.cross = any != 0ull ? 1 : 0;
+          if (lane <= kWtRows) t.f0[lane] = fj;
+          if (lane < kWtRows) {
+            t.theta[lane] = cyc - floor(cyc);
+            t.w[lane] = fa * p.inv_sr;
+            t.dw[lane] = (fb - fa) * p.inv_sr * p.inv_2hop;
+            t.kA[lane] = kA;
+            t.kN[lane] = kN;
+          }
+          // the sum over this chunk's frames: lane 31 holds the inclusive sum of lanes 0 .. 31 (lanes >= nfr added 0)
+          const long long bits31 = __builtin_bit_cast(long long, incl);
+          const unsigned lo31 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits31 & 0xffffffffll), 31);
+          const unsigned hi31 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits31 >> 32), 31);
+          before += __builtin_bit_cast(double, (long long)(((unsigned long long)hi31 << 32) | lo31));
+        }
+      }
+      DDSP_WT_STAMP(2);
+      // ---------------- wavefront 0: the descriptor of chunk tick + 4 -------------------------------------------------
+      if (rw == 0) {
+        const WtDesc dn = wt_next_chunk(walk, p);
+        if (lane == 0) ring[(tick + 4) & 7] = dn;
+      }
+      desc_take();
+      DDSP_WT_STAMP(3);
+      __syncthreads();
+      DDSP_WT_STAMP(4);
+      dB = dM; dM = dA; dA = dL;
+      { const int t3 = pb; pb = pm; pm = pa; pa = t3; }
+      if (tick + 1 >= 0 && dB.nfr == 0) break;
+    }
+  } else {
+    const int sw = wave - 4;                       // 0 .. 11
+    if (sw >= 8) {
+      // =================== row makers (S-wavefronts 8 .. 11): phase A of four row pairs per tick =====================
+      // Row pairs ("units": rows 2 u, 2 u + 1 of a chunk, 32 lanes per row, lane kq owns harmonics 4 kq + 1 .. + 4)
+      // 4 (sw - 8) .. + 3 of chunk tick + 2, carried through the stages TOGETHER: a row is one long chain of dependent
+      // instructions (exp, log, exp, the sum, 1 / sum, the split), and a wavefront issues one instruction per ~8 clocks
+      // only if it has independent ones to issue.  The rows come straight from HBM into registers; those of the NEXT
+      // tick's chunk are fetched at the end of a tick (plain loads: loop-carried values, the compiler keeps their wait
+      // count) - these wavefronts have no other work to hide a fetch behind.  Rows past the chunk's halo row are fetched
+      // (clamped) and worked on like the others: nobody reads their planes.
+      constexpr int NU = 4;
+      const int u0 = NU * (sw - 8);
+      // per-lane constants: 1 / psi_hat(k), the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit:
+      // always masked)
+      float ipsi[4], kf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
+        kf[u] = live ? (float)(4 * kq + u + 1) : 0.0f;
+      }
+      const float nyq_l = live ? p.nyquist : -1.0f;
+      ddsp_f32x4 lx[NU];
+      float lf0[NU], lamp[NU];
+      auto prefetch = [&](const WtDesc& d) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          const int row = d.b * F + min(d.j0 + 2 * (u0 + i) + sub, F - 1);      // (an empty descriptor: row 0 of clip 0)
+          const float4 v = hd4[(size_t)row * K4 + min(kq, K4 - 1)];
+          lx[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+          lf0[i] = f0_all[row];
+          lamp[i] = amplitudes[row];
+        }
+      };
+      // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
+      // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
+      // (harmonics as pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 do two lanes' worth per issued instruction)
+      const f32x2 kf01 = {kf[0], kf[1]}, kf23 = {kf[2], kf[3]}, ipsi01 = {ipsi[0], ipsi[1]}, ipsi23 = {ipsi[2], ipsi[3]};
+      auto exp_sigmoid2 = [&](f32x2 v) -> f32x2 {                      // exp_sigmoid_fast on a pair
+        const f32x2 t = v * -1.4426950408889634f;
+        const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+        const f32x2 m = (f32x2){__builtin_amdgcn_logf(e[0]), __builtin_amdgcn_logf(e[1])} * -kLog10;
+        const f32x2 g = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+        return __builtin_elementwise_fma(g, (f32x2){2.0f, 2.0f}, (f32x2){1e-7f, 1e-7f});
+      };
+      auto nyq_mask2 = [&](f32x2 e, float f0r, f32x2 kfp) -> f32x2 {   // e > 0: kept iff fl32(f0 k) < nyquist: median(e, 0, +-huge)
+        f32x2 prod;
+        { _Pragma("clang fp contract(off)") prod = kfp * f0r; }
+        const f32x2 y = (nyq_l - prod) * 1.0e30f;
+        return (f32x2){__builtin_amdgcn_fmed3f(e[0], 0.0f, y[0]), __builtin_amdgcn_fmed3f(e[1], 0.0f, y[1])};
+      };
+      auto phase_a = [&](const WtDesc& d, _Float16* planes) {
+        const int nfr = d.nfr;
+        f32x2 x01[NU], x23[NU];
+        float part[NU], inv[NU], a_ctl[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          x01[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][0], lx[i][1]}), lf0[i], kf01);
+          x23[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][2], lx[i][3]}), lf0[i], kf23);
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const f32x2 h = x01[i] + x23[i]; part[i] = h[0] + h[1]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[i] += dpp_mov0<0xB1, 0xF>(part[i]);      // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[i] += dpp_mov0<0x4E, 0xF>(part[i]);      // quad_perm [2,3,0,1]
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[i] += dpp_mov0<0x141, 0xF>(part[i]);     // row_half_mirror
+#pragma unroll
+        for (int i = 0; i < NU; ++i) part[i] += dpp_mov0<0x140, 0xF>(part[i]);     // row_mirror: every lane holds its 16-lane row's sum
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          part[i] = row_pair_sum(part[i]);            // + the other 16 lanes of this matrix row
+          inv[i] = __builtin_amdgcn_rcpf(part[i] == 0.0f ? 1e-7f : part[i]);
+          a_ctl[i] = exp_sigmoid_fast(lamp[i], kLog10, 2.0f, 1e-7f);
+        }
+        // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
+        // belongs to the next chunk
+        if (ctl_hd != nullptr) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) {
+            const int arow = 2 * (u0 + i) + sub;
+            const int crow = d.b * F + d.j0 + arow;        // this lane's (batch * frame) row, if arow < nfr
+            if (arow < nfr) {
+              const f32x2 h01 = x01[i] * inv[i], h23 = x23[i] * inv[i];
+              if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(h01[0], h01[1], h23[0], h23[1]);
+              if (kq == 0) ctl_amp[crow] = a_ctl[i];
+            }
+          }
+        }
+        // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
+        // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          const float a = a_ctl[i] * inv[i];
+          const f32x2 c01 = (x01[i] * a) * ipsi01, c23 = (x23[i] * a) * ipsi23;
+          const float c[4] = {c01[0], c01[1], c23[0], c23[1]};
+          _Float16* dst = planes + (2 * (u0 + i) + sub) * kWtPS + 2 * kq;
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
+            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
+            const f32x2 rest = ((f32x2){c[par], c[par + 2]} - (f32x2){(float)hi[0], (float)hi[1]}) * kWtLoScale;
+            const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(rest[0], rest[1]);
+            *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
+            *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
+          }
+        }
+      };
+      prefetch(dA);
+      for (int tick = -2;; ++tick) {
+        DDSP_WT_STAMP(0);
+        desc_issue((tick + 3) & 7);
+        DDSP_WT_STAMP(1);
+        DDSP_WT_STAMP(2);
+        if (dA.nfr > 0) phase_a(dA, planes_all[pa]);
+        desc_take();
+        prefetch(dL);                              // the next tick's dA
+        DDSP_WT_STAMP(3);
+        __syncthreads();
+        DDSP_WT_STAMP(4);
+        dB = dM; dM = dA; dA = dL;
+        { const int t3 = pb; pb = pm; pm = pa; pa = t3; }
+        if (tick + 1 >= 0 && dB.nfr == 0) break;
+      }
+    } else {
+      // =================== interpolators (S-wavefronts 0 .. 7): phase B, four tiles at a time ========================
+      // tile slots sw, sw + 8, sw + 16, sw + 24 of every round of 31 (the eighth wavefront has three)
+      f32x2 coef[W / 2][4];
+      wt_pk_coefs<W, 0>(coef);
+      for (int tick = -2;; ++tick) {
+        DDSP_WT_STAMP(0);
+        desc_issue((tick + 3) & 7);
+        DDSP_WT_STAMP(1);
+        if (dB.nfr > 0) {
+          // ---------------- phase B of chunk tick: tiles of 64 samples, lanes = samples ----------------------------
+          const int nfr = dB.nfr;
+          const int row0 = dB.b * F + dB.j0;
+          const float* tab = tab_all[tick & 1];
+          const _Float16* planes = planes_all[pb];
+          const ChunkTables& t = t_all[tick & 1];
+          const int hop = p.hop;
+          const float inv_hop = 1.0f / (float)hop;
+          const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
+          const int n_tiles = ONE_TILE ? nfr : nfr * (hop >> 6);
+          // NT tiles (tile, tile + 8, ..) move through the stages together: every stage of a tile is a chain of
+          // dependent instructions - fp64 phase, LDS reads, the window polynomials
+          auto tiles = [&](int tile, auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            int q[kWtNT], r[kWtNT];
+            double cyc[kWtNT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+              const int tl = tile + 8 * u;
+              if (ONE_TILE) { q[u] = tl; r[u] = lane; }
+              else {
+                uint32_t rem;
+                q[u] = (int)fastdiv((uint32_t)tl, p.tpf_div, rem);
+                r[u] = (int)rem * 64 + lane;
+              }
+              const double rr = (double)r[u];
+              // inclusive cumsum of f[t]/sr inside the frame: (r+1) w + r (r+1) dw, in revolutions
+              // (every product-sum of phase B is spelled out: which of a b + c d becomes the FMA must not depend on the
+              // template instance a tile happens to run in - the cut into chunks depends on the batch size)
+              cyc[u] = fma(rr + 1.0, fma(t.dw[q[u]], rr, t.w[q[u]]), t.theta[q[u]]);
+            }
+            float theta[kWtNT];
+            f32x2 zz[kWtNT];
+            unsigned sgn[kWtNT];
+            const float* t0[kWtNT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+              theta[u] = (float)__builtin_amdgcn_fract(cyc[u]);               // v_fract_f64: [0, 1]
+              const float hm = 0.5f - theta[u];                               // S(1 - theta) = -S(theta): sign bit <=> theta > 1/2
+              sgn[u] = __builtin_bit_cast(unsigned, hm) & 0x80000000u;
+              const float th = 0.5f - fabsf(hm);                              // [0, 0.5]
+              const float pos = fmaf(th, (float)kWtT, -0.5f);                 // table coordinate, [-0.5, 255.5]
+              const float fl = floorf(pos);
+              const float z = (pos - fl) - 0.5f;
+              zz[u] = (f32x2){z, z * z};
+              t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                    // (int)fl in [-1, 255]
+            }
+            f32x2 acc0[kWtNT], acc1[kWtNT];
+#pragma unroll
+            for (int u = 0; u < kWtNT; ++u) { acc0[u] = (f32x2){0.0f, 0.0f}; acc1[u] = (f32x2){0.0f, 0.0f}; }
+            wt_taps_pk<W, 0, NT>(t0, zz, coef, acc0, acc1);
+            float out[kWtNT], w_cur[kWtNT], w_next[kWtNT], lerp[kWtNT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+              lerp[u] = (float)r[u] * inv_hop;
+              // frame-rate -> audio-rate amplitude envelope: weight of frame j+1 is lerp ('linear', core.resample)
+              // or the periodic Hann(2 hop)[r] ('window', core.py:696-698)
+              w_next[u] = p.amp_linear ? lerp[u] : fmaf(-0.5f, __builtin_amdgcn_cosf(0.5f * lerp[u]), 0.5f);
+              w_cur[u] = 1.0f - w_next[u];
+              const float s0 = acc0[u][0] + acc0[u][1], s1 = acc1[u][0] + acc1[u][1];
+              const float v = fmaf(w_next[u], s1, rn_mul(w_cur[u], s0));
+              out[u] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ sgn[u]);
+            }
+            if (chunk_cross)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+              const int kA = __builtin_amdgcn_readfirstlane(t.kA[q[u]]);
+              const int kN = __builtin_amdgcn_readfirstlane(t.kN[q[u]]);
+              if (kA < kN) {         // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
+                const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
+                for (int k = kA; k < kN; ++k) {
+                  const float kfl = (float)(k + 1);
+                  const float top = fj * kfl, bot = fj1 * kfl;
+                  const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp[u]));
+                  const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
+                  const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
+                  const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
+                  const float ak = rn_mul(fmaf(w_next[u], c1, rn_mul(w_cur[u], c0)), WtPoly<W>::psi(k + 1));
+                  const float sv = sin_rev(fmaf(theta[u], kfl, -rintf(theta[u] * kfl)));     // exact fractional part of k theta
+                  if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
+          };
+          for (int base = 0; base < n_tiles; base += kWtFrames) {
+            const int left = min(n_tiles - base, kWtFrames);
+            const int cnt = (left - sw + 7) >> 3;             // slots sw, sw + 8, .. below `left`: 0 .. 4
+            if (cnt >= 4) tiles(base + sw, std::integral_constant<int, 4>{});
+            else if (cnt == 3) tiles(base + sw, std::integral_constant<int, 3>{});
+            else if (cnt == 2) tiles(base + sw, std::integral_constant<int, 2>{});
+            else if (cnt == 1) tiles(base + sw, std::integral_constant<int, 1>{});
+          }
+        }
+        DDSP_WT_STAMP(2);
+        desc_take();
+        DDSP_WT_STAMP(3);
+        __syncthreads();
+        DDSP_WT_STAMP(4);
+        dB = dM; dM = dA; dA = dL;
+        { const int t3 = pb; pb = pm; pm = pa; pa = t3; }
+        if (tick + 1 >= 0 && dB.nfr == 0) break;
+      }
+    }
+  }
+#undef DDSP_WT_STAMP
+}
+
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
                    int inputs_are_controls) {
   if (flags & DDSP_HARM_DIRECT_SUM) return false;
@@ -547,8 +1158,90 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
          (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0;
 }
 
+int launch_harm_wt16(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
+                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
+  Wt16Args p;
+  p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
+  p.total_frames = B * F;
+  p.f_div = make_fastdiv((uint32_t)F);
+  p.tpf_div = make_fastdiv((uint32_t)(p.hop >> 6));
+  p.nyquist = (float)(sample_rate / 2.0);
+  p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
+  p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
+  p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.inv_sr = 1.0 / (double)sample_rate;
+  p.inv_2hop = 0.5 / (double)p.hop;
+  p.hop_d = (double)p.hop;
+  p.half_hm1 = ((double)p.hop - 1.0) * 0.5;
+  // persistent grid: one block of 16 wavefronts per CU, each with a contiguous run of frames
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  int blocks = (p.total_frames + kWtFrames - 1) / kWtFrames;
+  if (blocks > n_cu) blocks = n_cu;
+  p.frames_per_block = (p.total_frames + blocks - 1) / blocks;
+  blocks = (p.total_frames + p.frames_per_block - 1) / p.frames_per_block;       // no empty block
+  const dim3 grid((unsigned)blocks), block(1024);
+  p.dbg = nullptr;
+#ifdef DDSP_WT16_TIMELINE
+  // DDSP_EXP_TABLE_TIMELINE=1 (a -DDDSP_WT16_TIMELINE build): block 0 records shader-clock stamps per tick
+  static const bool timeline = getenv("DDSP_EXP_TABLE_TIMELINE") != nullptr;
+  static long long* dbg_buf = nullptr;
+  if (timeline) {
+    if (!dbg_buf && hipMalloc(&dbg_buf, 16 * 24 * 8 * sizeof(long long)) != hipSuccess) dbg_buf = nullptr;
+    if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 16 * 24 * 8 * sizeof(long long), st);
+    p.dbg = dbg_buf;
+  }
+#endif
+  hipEvent_t ev0, ev1;
+  profile_kernel_events(kHarmTable, &ev0, &ev1);
+#define DDSP_LAUNCH_WT16(W, NK)                                                                                \
+  do {                                                                                                         \
+    if (p.hop == 64)                                                                                           \
+      hipExtLaunchKernelGGL((harm_wt16_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, ctl_amp, ctl_hd, p);                                                                \
+    else                                                                                                       \
+      hipExtLaunchKernelGGL((harm_wt16_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                            audio, ctl_amp, ctl_hd, p);                                                                \
+  } while (0)
+  // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
+  if (K <= 64) DDSP_LAUNCH_WT16(6, 1);
+  else if (K <= 100) DDSP_LAUNCH_WT16(6, 2);
+  else DDSP_LAUNCH_WT16(8, 2);
+#undef DDSP_LAUNCH_WT16
+#ifdef DDSP_WT16_TIMELINE
+  if (p.dbg) {
+    static long long host[16 * 24 * 8];
+    if (hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(host, p.dbg, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess) {
+      const long long t0 = host[0];
+      for (int w = 0; w < 16; ++w)
+        for (int i = 0; i < 24 && host[(w * 24 + i) * 8] != 0; ++i) {
+          const long long* r = host + (w * 24 + i) * 8;
+          if (w < 4)
+            fprintf(stderr, "[timeline] T%d tick %3d  start %8lld  mfma+table +%6lld  tables/desc +%6lld  barrier +%6lld\n", w, i - 2,
+                    r[0] - t0, r[1] - r[0], r[3] - r[1], r[4] - r[3]);
+          else
+            fprintf(stderr, "[timeline] S%-2d tick %3d  start %8lld  fetch +%6lld  phase B +%6lld  phase A +%6lld  barrier +%6lld\n", w - 4,
+                    i - 2, r[0] - t0, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3]);
+        }
+    }
+  }
+#endif
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
                       float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
+  // DDSP_HARM_TABLE_12=1: the round-2 kernel (12 wavefronts), kept for A/B measurements
+  static const bool old12 = getenv("DDSP_HARM_TABLE_12") != nullptr;
+  if (!old12 && (long long)B * F < (1ll << 31))
+    return launch_harm_wt16(amplitudes, hd, f0, audio, ctl_amp, ctl_hd, B, F, K, N, sample_rate, flags, st);
+
   TableArgs p;
   p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
   p.chunks_per_row = (F + kWtFrames - 1) / kWtFrames;

@@ -36,12 +36,14 @@ struct alignas(16) double2 { double x, y; };
 struct uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline double2 make_double2(double x, double y) { return double2{x, y}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
 struct dim3 {
   unsigned x, y, z;
@@ -377,6 +379,34 @@ template <class T> T __shfl_xor(T v, int mask, int = 64) { return ddsp_emu_shfl(
 template <class T> T __shfl_up(T v, unsigned delta, int = 64) { return ddsp_emu_shfl(v, 1, (int)delta); }
 template <class T> T __shfl_down(T v, unsigned delta, int = 64) { return ddsp_emu_shfl(v, 2, (int)delta); }
 template <class T> T __shfl(T v, int src, int = 64) { return ddsp_emu_shfl(v, 3, src); }
+
+// v_permlane16_swap_b32: the odd 16-lane rows of the first operand change places with the even rows of the second;
+// returns {new first operand, new second operand}
+typedef unsigned ddsp_emu_uint2v __attribute__((ext_vector_type(2)));
+inline ddsp_emu_uint2v __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+  struct In { unsigned a, b; };
+  struct Out { unsigned a, b; };
+  const Out o = ddsp_emu::wave_op<In, Out>(31, 0, In{a, b}, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    for (int l = 0; l < 64; ++l) {
+      const In me = ddsp_emu::in_of<In>(op, l);
+      Out& out = ddsp_emu::out_of<Out>(op, l);
+      out.a = me.a;
+      out.b = me.b;
+      const int row = l >> 4;
+      if (row & 1) {                 // first operand, odd row: receives the second operand's row - 1
+        const int s = l - 16;
+        out.a = ddsp_emu::is_live(live, s) ? ddsp_emu::in_of<In>(op, s).b : 0u;
+      } else {                       // second operand, even row: receives the first operand's row + 1
+        const int s = l + 16;
+        out.b = ddsp_emu::is_live(live, s) ? ddsp_emu::in_of<In>(op, s).a : 0u;
+      }
+    }
+  });
+  return ddsp_emu_uint2v{o.a, o.b};
+}
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
+  return std::max(std::min(a, b), std::min(std::max(a, b), c));
+}
 
 // ---------------------------------------------------------------------------------------------------
 // matrix cores: v_mfma_f32_16x16x32_f16  D[16x16] = A[16x32] B[32x16] + C
