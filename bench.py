@@ -12,8 +12,9 @@ One "step" = one pass of the hot path over one batch of synthetic control tensor
 `synths.Harmonic(amplitudes, harmonic_distribution, f0_hz)` + `synths.FilteredNoise(magnitudes)`
 (raw network outputs in, both get_controls prologues included, noise generated on chip),
 each output sample counted once.  Inputs are resident in HBM before the timed region.
-Workload (per GPU, weak scaling): BASELINE.json configs[1] - batch 32, 4 s @ 16 kHz,
-F=1000 frames, K=100 harmonics (all below Nyquist: f0 = 70 + N(0,1) Hz), M=65 noise bands.
+Workload (per GPU, weak scaling): the shape BASELINE.json's metric and target are quoted on - batch 128 of
+configs[1]'s clips: 4 s @ 16 kHz, F=1000 frames, K=100 harmonics (all below Nyquist: f0 = 70 + N(0,1) Hz), M=65
+noise bands.  configs[1] itself (batch 32) is timed the same way right after and reported as `configs_1`.
 
 Timing.  After W warm-up steps (and a clock-settle phase) the region "exactly K steps, barrier +
 torch.cuda.synchronize() on both sides" is run `--repeats` times (>= 10 by default).  Each region is timed
@@ -27,9 +28,9 @@ The JSON line also carries
   roofline         : dominant kernel, algorithmic bytes per launch / its mean duration measured
                      with HIP events on the launch stream during the timed regions (ddsp_profile_*),
                      against the 8 TB/s HBM peak (the path is in fact ALU-bound).
-  north_star_shape : the same step at BASELINE.json's target shape (batch 128 per GPU; two streams, `one_stream` beside it), timed the
-                     same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
-                     fractions of the HBM roofline.
+  configs_1        : the same step at BASELINE.json configs[1] (batch 32 per GPU; two streams, `one_stream` beside it),
+                     timed the same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
+                     fractions of the HBM roofline.  (Rounds 1-2 had the two shapes the other way round.)
   cpu_baseline     : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
                      here) timed on this host's cores (concurrent worker processes) on a bounded
                      sample of the same workload.
@@ -61,7 +62,8 @@ def parse_args(argv=None):
   ap.add_argument('--repeats', type=int, default=0,
                   help='timed regions of K steps each (0: at least 10, more when a region is short, so that '
                        'about 0.1 s is measured in all); the median is reported')
-  ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
+  ap.add_argument('--batch', type=int, default=128,
+                  help='clips per GPU (128: the shape the north-star target is quoted on; configs[1] has 32)')
   ap.add_argument('--n-frames', type=int, default=1000)
   ap.add_argument('--n-harmonics', type=int, default=100)
   ap.add_argument('--n-bands', type=int, default=65)
@@ -89,9 +91,10 @@ def parse_args(argv=None):
   ap.add_argument('--no-aux', action='store_true',
                   help='skip the auxiliary yardsticks after the timed regions (measured device-copy bandwidth, '
                        'the f0 = 200 Hz regime of SURVEY.md 8d)')
-  ap.add_argument('--no-north-star', action='store_true',
-                  help='skip the north_star_shape block (batch 128 per GPU)')
-  ap.add_argument('--north-star-batch', type=int, default=128)
+  ap.add_argument('--no-second-shape', '--no-north-star', dest='no_second_shape', action='store_true',
+                  help='skip the second block (configs[1], batch 32 per GPU)')
+  ap.add_argument('--second-batch', '--north-star-batch', dest='second_batch', type=int, default=32,
+                  help='clips per GPU of the second block (32 = BASELINE configs[1], reported as `configs_1`)')
   ap.add_argument('--harm-kernel', default='auto', help="Harmonic.kernel ('auto', 'direct', ...)")
   ap.add_argument('--noise-kernel', default='auto', help="FilteredNoise.kernel ('auto', ...)")
   ap.add_argument('--allgather', action='store_true',
@@ -188,7 +191,8 @@ def kernel_roofline(a, batch, dominant, dom_ms, dom_n):
 
 
 def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=None, alt_elapsed=None,
-                 gather_ms=None, cpu_baseline_fn=None, timing=None, north_star=None):
+                 gather_ms=None, cpu_baseline_fn=None, timing=None, second=None, one_stream_elapsed=None,
+                 roofline_timing=None):
   """The JSON line of the bench contract from the measured quantities (pure: unit-tested on the CPU).
   elapsed: seconds of the median K-step region, max over ranks; prof / breakdown: {kernel: (total_ms, launches)}
   of the timed regions' sampled dispatch events / of the untimed single-stream diagnostic pass."""
@@ -207,10 +211,10 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
       'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True,
       'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
       'config': {
-          'workload': 'BASELINE configs[1]: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
+          'workload': '%s: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
                       '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
                       'controls in (get_controls fused), noise generated on chip' %
-                      (B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
+                      (shape_name(B), B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
           'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
           'no collective' % world,
           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
@@ -219,8 +223,8 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
       'per_gpu_value': value / world,
       'roofline': dict(roof, **{
           'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'event_stride': a.event_stride,
-          'timing': 'dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
-                    'every event_stride-th launch inside the timed regions',
+          'timing': roofline_timing or ('dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, '
+                                        'every event_stride-th launch inside the timed regions'),
           'whole_step': {'algorithmic_bytes': step_bytes,
                          'achieved_GBs': step_bytes / (elapsed / a.steps) / 1e9,
                          'frac': step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS},
@@ -236,8 +240,16 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
   }
   if timing:
     result['timing'] = timing
-  if north_star:
-    result['north_star_shape'] = north_star
+    if 'host_clock_ms_per_step_median' in timing:           # the clock round 1's headline used: comparable across rounds
+      result['ms_per_step_host_clock'] = timing['host_clock_ms_per_step_median']
+  if one_stream_elapsed is not None:
+    one = one_stream_elapsed / a.steps
+    result['one_stream'] = {'ms_per_step': one * 1e3, 'value': world * B * a.n_samples / one / 1e6,
+                            'whole_step_frac': step_bytes / one / 1e9 / HBM_PEAK_GBS}
+  if B == 128:
+    result['target'] = '>= 0.5 of the HBM roofline at this shape (BASELINE.json north_star): roofline.whole_step.frac'
+  if second:
+    result['configs_1' if second.get('batch_per_gpu') == 32 else 'second_shape'] = second
   if 'measured_copy_GBs' in aux:
     result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
     result['roofline']['frac_of_measured_copy'] = roof['achieved'] / aux['measured_copy_GBs']
@@ -261,17 +273,25 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
   return result
 
 
-def north_star_block(a, world, B, elapsed, steps, prof, breakdown, elapsed_one_stream=None):
-  """The step at the north-star shape (batch 128 per GPU): same definitions as the headline, the two calls on two
-  free-running streams as there; the one-stream figure beside it."""
+def shape_name(B):
+  if B == 128:
+    return 'north-star shape (the batch BASELINE.json quotes its metric and target on; configs[1] x 4)'
+  if B == 32:
+    return 'BASELINE configs[1]'
+  return 'configs[1] clips at another batch size'
+
+
+def second_block(a, world, B, elapsed, steps, prof, breakdown, elapsed_one_stream=None):
+  """The same step at a second batch size (configs[1]: 32 per GPU): same definitions as the headline, the two calls on
+  two free-running streams as there; the one-stream figure beside it."""
   harm_bytes, noise_bytes = algorithmic_bytes(a, B)
   step_bytes = harm_bytes + noise_bytes
   per_step = elapsed / steps
-  block = {'batch_per_gpu': B, 'streams': 'Harmonic and FilteredNoise on two free-running HIP streams', 'steps': steps,
+  block = {'batch_per_gpu': B, 'workload': shape_name(B),
+           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams', 'steps': steps,
            'ms_per_step': per_step * 1e3, 'value': world * B * a.n_samples / per_step / 1e6,
            'whole_step': {'algorithmic_bytes': step_bytes, 'achieved_GBs': step_bytes / per_step / 1e9,
                           'frac': step_bytes / per_step / 1e9 / HBM_PEAK_GBS},
-           'target': '>= 0.5 of the HBM roofline (BASELINE.json north_star)',
            'kernel_breakdown_us': {k: v[0] / v[1] * 1e3 for k, v in breakdown.items()}}
   if elapsed_one_stream is not None:
     one = elapsed_one_stream / steps
@@ -509,12 +529,30 @@ def main(argv=None):
   e_probe, _, _ = timed_region(step, a.steps, overlap)          # untimed probe: sizes the repeat count
   e_probe = max_over_ranks(e_probe)                             # every rank must run the SAME number of regions (collectives inside)
   repeats = a.repeats if a.repeats > 0 else int(min(200, max(10, 0.1 / max(e_probe, 1e-6))))
-  if not dry:
+  # The dominant kernel's dispatch events.  At configs[1]'s batch they are sampled inside the timed regions.  At batch 128
+  # on two streams a dispatch of one kernel also spans the time its blocks wait for the CUs the other kernel's persistent
+  # blocks still hold, so its duration says nothing about the kernel: there the events are sampled in one-stream regions
+  # of the same K steps run right after the timed ones (their step time is reported as `one_stream`).
+  events_in_one_stream_regions = overlap and B >= 64
+  if not dry and not events_in_one_stream_regions:
     _lib.profile_begin([dominant], max_records=2 * a.steps * repeats // max(a.event_stride, 1) + 64,
                        stride=a.event_stride)
   ev, wall, out = repeated_regions(step, a.steps, overlap, repeats)
-  prof = {dominant: (0.6, 3)} if dry else _lib.profile_end()
+  prof = {dominant: (0.6, 3)} if dry else (None if events_in_one_stream_regions else _lib.profile_end())
   elapsed = max_over_ranks(statistics.median(ev))
+  one_stream_elapsed, roofline_timing = None, None
+  if events_in_one_stream_regions:
+    reps1 = max(3, repeats // 3)
+    if not dry:
+      _lib.profile_begin([dominant], max_records=2 * a.steps * reps1 // max(a.event_stride, 1) + 64,
+                         stride=a.event_stride)
+    ev_1s, _, _ = repeated_regions(step, a.steps, False, reps1)
+    if not dry:
+      prof = _lib.profile_end()
+    one_stream_elapsed = max_over_ranks(statistics.median(ev_1s))
+    roofline_timing = ('dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream, every event_stride-th '
+                       'launch inside %d one-stream regions of the same K steps run right after the timed (two-stream) '
+                       'regions: on two streams a dispatch also spans the wait for the CUs the other kernel holds' % reps1)
   timing = {'method': 'median of %d regions of K=%d steps; each region bracketed by barrier + synchronize and '
                       'timed by HIP events on the stream(s) (value) and by the host clock (beside it)' %
                       (repeats, a.steps),
@@ -578,14 +616,17 @@ def main(argv=None):
     sync_all()
     gather_ms = max_over_ranks(time.perf_counter() - t1) / 10 * 1e3
 
-  # ---- the north-star shape: batch 128 per GPU (BASELINE.json target) ----------------------------------------
-  north_star = None
-  if not a.no_north_star and a.north_star_batch != B:
+  # ---- the second shape: BASELINE configs[1], batch 32 per GPU ---------------------------------------------------
+  # (every rank takes the same path through the collectives: a failure on one rank is agreed on before anything is
+  # reduced over the ranks - ADVICE r2)
+  second = None
+  if not a.no_second_shape and a.second_batch > 0 and a.second_batch != B:
+    BN = a.second_batch
+    ns_steps = max(10, min(a.steps, 200))
+    err, med_n, med_1, prof_n, bd_n = None, 0.0, 0.0, None, {}
     try:
-      BN = a.north_star_batch
       del step, dev
       step_n, dev_n = make_step(BN, 3000 + rank, True)
-      ns_steps = max(10, min(a.steps, 200))
       for _ in range(20):
         step_n()
       settle(step_n, 0.02 if not dry else 0.0)
@@ -597,23 +638,26 @@ def main(argv=None):
           step_n(two_streams=False)
         torch.cuda.synchronize()
         bd_n = _lib.profile_end()
+    except Exception as exc:                      # noqa: BLE001 - the headline line must survive
+      err = repr(exc)
+    failed = max_over_ranks(1.0 if err else 0.0) > 0.0
+    if not failed:
       ev_n, _, _ = repeated_regions(step_n, ns_steps, True, 10)
-      # the dominant kernel's dispatch events: during the one-stream regions (on two streams a dispatch of one kernel
-      # spans the time its blocks wait for the CUs the other kernel's persistent blocks still hold)
       if not dry:
         _lib.profile_begin(list(bd_n), max_records=4 * ns_steps * 5 // max(a.event_stride, 1) + 64,
                            stride=a.event_stride)
       ev_1, _, _ = repeated_regions(step_n, ns_steps, False, 5)
       if not dry:
         prof_n = _lib.profile_end()
-      north_star = north_star_block(a, world, BN, max_over_ranks(statistics.median(ev_n)), ns_steps, prof_n, bd_n,
-                                    max_over_ranks(statistics.median(ev_1)))
-    except Exception as exc:                      # noqa: BLE001 - the headline line must survive
-      north_star = {'error': repr(exc)}
+      second = second_block(a, world, BN, max_over_ranks(statistics.median(ev_n)), ns_steps, prof_n, bd_n,
+                            max_over_ranks(statistics.median(ev_1)))
+    else:
+      second = {'batch_per_gpu': BN, 'error': err or 'another rank failed to set this shape up'}
 
   if rank == 0:
     result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms,
-                          timing=timing, north_star=north_star)
+                          timing=timing, second=second, one_stream_elapsed=one_stream_elapsed,
+                          roofline_timing=roofline_timing)
     print(json.dumps(result), flush=True)
 
   if world > 1:

@@ -1,6 +1,6 @@
 """CPU checks of bench.py's JSON line (the driver's contract): build_result() is pure, so the fields, the
 roofline arithmetic and the optional blocks are exercised here on the numbers of profiles/r01_bench_*.json;
-parse_args() defaults must describe BASELINE.json configs[1]."""
+parse_args() defaults must describe the shape BASELINE.json's target is quoted on (configs[1]'s clips at batch 128)."""
 import importlib.util
 import json
 import os
@@ -28,10 +28,11 @@ def _args(bench, *argv):
     sys.argv = old
 
 
-def test_defaults_are_baseline_config_1(bench):
+def test_defaults_are_the_north_star_shape(bench):
   a = _args(bench)
   assert (a.gpus, a.batch, a.n_frames, a.n_harmonics, a.n_bands, a.n_samples, a.sample_rate) == (
-      1, 32, 1000, 100, 65, 64000, 16000)
+      1, 128, 1000, 100, 65, 64000, 16000)
+  assert a.second_batch == 32                      # configs[1] rides along as `configs_1`
   assert a.f0 == 70.0 and a.steps > 0 and a.warmup > 0
   # 664 000 + 516 000 bytes per clip
   assert bench.algorithmic_bytes(a, 1) == (664000, 516000)
@@ -173,10 +174,11 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert line['cpu_baseline']['kind'] == 'port' and 'other_issue_mode' in line
   assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
   assert any(abs(f - 200.0) < 2.0 for f in calls['f0s'])              # the f0 = 200 regime ran...
-  assert abs(calls['last_f0'] - 70.0) < 2.0                            # ...and the north-star shape after it, on its own inputs
-  assert calls['batches'] == {2, 128}
-  ns = line['north_star_shape']
-  assert ns['batch_per_gpu'] == 128 and ns['value'] > 0 and 0 < ns['whole_step']['frac'] and 'dominant_kernel' in ns
+  assert abs(calls['last_f0'] - 70.0) < 2.0                            # ...and the second shape after it, on its own inputs
+  assert calls['batches'] == {2, 32}
+  ns = line['configs_1']
+  assert ns['batch_per_gpu'] == 32 and ns['value'] > 0 and 0 < ns['whole_step']['frac'] and 'dominant_kernel' in ns
+  assert line['ms_per_step_host_clock'] > 0
   assert line['timing']['repeats'] >= 10 and line['timing']['region_ms_median'] > 0
   # ...and the headline inputs were put back afterwards (nothing after the regime reads them, but a later edit might)
 
@@ -308,7 +310,7 @@ def test_gpus_2_without_a_launcher_starts_its_own_ranks():
   line = json.loads(out[0])
   assert line['n_gpus'] == 2 and line['dry_run'] is True and line['config']['global_batch'] == 4
   assert line['scaling'] == 'weak' and line['per_gpu_value'] == pytest.approx(line['value'] / 2)
-  assert 'allgather_ms' in line and line['north_star_shape']['batch_per_gpu'] == 4
+  assert 'allgather_ms' in line and line['second_shape']['batch_per_gpu'] == 4
   assert 'cpu_baseline' not in line and line['steps'] == 5 and line['timing']['repeats'] >= 10
 
 
