@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void uniform_noise_kernel(float* __restrict__ 
   const int b = blockIdx.y;
   const int nq = (N + 3) / 4;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
-    const U4 r = philox4x32_10(U4{(uint32_t)q, (uint32_t)(batch_offset + b), 0u, 0u}, k0, k1);
+    const U4 r = noise_philox(U4{(uint32_t)q, (uint32_t)(batch_offset + b), 0u, 0u}, k0, k1);
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
       if (GEN_NOISE) {
-        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
+        const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
                                    p.k0, p.k1);
         v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
         if (i + 3 >= p.N) {
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 0 && i < p.N) {
         if (GEN_NOISE) {
-          const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
+          const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
                                      p.k0, p.k1);
           v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
           if (i + 1 >= p.N) v.y = 0.f;

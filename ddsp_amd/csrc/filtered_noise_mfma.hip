@@ -153,19 +153,20 @@ __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool f
   }
 }
 
-// The noise tile x[z0-128 .. z0+3967] into the LDS planes (reversed, hi / lo split, two copies): 512 lanes (ltid), two
-// quads per lane (two independent Philox chains).
-template <bool GEN_NOISE>
+// The noise tile x[z0-128 .. z0+128+kMfTile) into the LDS planes (reversed, hi / lo split, two copies): NLANES lanes
+// (ltid), 16 kMfRows / NLANES quads of four samples per lane (independent Philox chains).
+template <bool GEN_NOISE, int NLANES>
 __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const float* __restrict__ x, unsigned char* s_xe,
                                               unsigned char* s_xo, const MfArgs& p) {
+  static_assert((16 * kMfRows) % NLANES == 0, "quads per lane");
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int qd = ltid + 64 * kMfPW * h;
+  for (int h = 0; h < 16 * kMfRows / NLANES; ++h) {
+    const int qd = ltid + NLANES * h;
     const int i = z0 - 128 + 4 * qd;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
       if (GEN_NOISE) {
-        const U4 r = philox4x32_10(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
         v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
         if (i + 1 >= p.N) v.y = 0.f;
         if (i + 2 >= p.N) v.z = 0.f;
@@ -246,20 +247,16 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
 
   if (wave < kMfPW) {
     // =========================== producer wavefronts ==================================================================
+    // Two kinds (round 3).  DESIGNERS (wavefronts 0 .. P/2 - 1): wavefront w turns the 16 x 65 magnitudes of rows
+    // 16 w .. + 15 into BOTH tap tiles - the magnitudes are fetched, scaled (exp_sigmoid) and split into fp16 pairs once
+    // (rounds 1-2: one wavefront per (row group, tap tile), so every row was fetched, scaled and split twice).
+    // NOISE MAKERS (wavefronts P/2 .. P - 1): the Philox noise tile, a half each.
     const float kLog10 = 2.302585092994046f;
-    const int rg = wave & (kMfPW / 2 - 1), mt = wave / (kMfPW / 2);           // row group, tap tile
-    // the constant cosine factor of this tap tile as fp16 hi / lo A-fragments, made at compile time: [even / odd bins][hi / lo]
-    mf_f16x8 afr[2][2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
-        const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[mt][par][hl][lane]);
-        afr[par][hl] = mf_frag(v.x, v.y, v.z, v.w);
-      }
+    const bool designer = wave < kMfPW / 2;
+    const int rg = wave & (kMfPW / 2 - 1);           // a designer's row group
     // zeros that stay: the zero group of the tap rows (what lanes outside the filter's support read) and the 16 elements
     // between the reversed noise frames (both copies), in both buffers
-    if (mt == 0)
+    if (designer)
       *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (lane & 1) * kMfTapPlane + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 256) = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * (kMfRows + 1) * 16; i += 64 * kMfPW) {
       unsigned char* const s_xe = s_x_all[i >= (kMfRows + 1) * 16 ? 1 : 0];
@@ -272,134 +269,157 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
       *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
     }
-    const int rrow = 16 * rg + mi;
-    // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
-    // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
-    MfU4f rq[4];
-    float r_last;
-    {
-      const int T = (int)blockIdx.x;                   // the block's first tile
-      DDSP_MF_TILE(T, b, z0, f_first, rel0);
-      (void)rel0;
-      const int rfr = f_first + rrow;
-      const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-      r_last = src[64];
-    }
+    if (!designer) {
+      // ------------------------- noise makers -------------------------------------------------------------------------
 #pragma unroll 1
-    for (int tick = -1; tick < n_my; ++tick) {
-      if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
-      // magnitudes of tile tick + 2, to be used a tick from now (past the block's last tile: the last one again)
-      MfU4f nq[4];
-      float n_last;
+      for (int tick = -1; tick < n_my; ++tick) {
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
+        if (tick >= 0 && tick + 1 < n_my) {          // (tile 0's noise: the FIR wavefronts, idle in tick -1)
+          const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+          DDSP_MF_TILE(T, b, z0, f_first, rel0);
+          (void)rel0; (void)f_first;
+          unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
+          mf_noise_tile<GEN_NOISE, 32 * kMfPW>(tid - 32 * kMfPW, b, z0, x, s_xe, s_xe + 2 * kMfXPlane, p);
+        }
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
+        __syncthreads();
+      }
+    } else {
+      // ------------------------- designers ----------------------------------------------------------------------------
+      // the constant cosine factor of both tap tiles as fp16 hi / lo A-fragments, made at compile time:
+      // [tap tile][even / odd bins][hi / lo]
+      mf_f16x8 afr[2][2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[mt][par][hl][lane]);
+            afr[mt][par][hl] = mf_frag(v.x, v.y, v.z, v.w);
+          }
+      const int rrow = 16 * rg + mi;
+      // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
+      // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
+      MfU4f rq[4];
+      float r_last;
       {
-        const int T = (int)blockIdx.x + min(tick + 2, n_my - 1) * (int)gridDim.x;
+        const int T = (int)blockIdx.x;                   // the block's first tile
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)rel0;
         const int rfr = f_first + rrow;
         const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) nq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-        n_last = src[64];
+        for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+        r_last = src[64];
       }
-      if (tick + 1 < n_my) {
-        const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
-        DDSP_MF_TILE(T, b, z0, f_first, rel0);
-        (void)rel0;
-        unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
-        unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
-        unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
-        if (tick >= 0) mf_noise_tile<GEN_NOISE>(tid, b, z0, x, s_xe, s_xo, p);      // (tile 0's: the FIR wavefronts, idle in tick -1)
-        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
-        // ---- the taps n = 16 mt .. + 15 (and their mirror images) of rows 16 rg .. + 15 ---------------------------------
-        // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
-        const int own_lo = (z0 == 0) ? 0 : f_first + 2;
-        uint32_t own_r;
-        const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, own_r) + 2;
-        const int rfr = f_first + rrow;
-        const bool rvalid = rfr >= 0 && rfr < p.F;
-        // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
-        if (f_first + 16 * rg <= p.F + 1) {
-        float y[16];
+#pragma unroll 1
+      for (int tick = -1; tick < n_my; ++tick) {
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
+        if (tick + 1 < n_my) {
+          const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+          DDSP_MF_TILE(T, b, z0, f_first, rel0);
+          (void)rel0;
+          unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
+          if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
+          // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+          const int own_lo = (z0 == 0) ? 0 : f_first + 2;
+          uint32_t own_r;
+          const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, own_r) + 2;
+          const int rfr = f_first + rrow;
+          const bool rvalid = rfr >= 0 && rfr < p.F;
+          // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
+          if (f_first + 16 * rg <= p.F + 1) {
+          float y[16];
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
-        float m_last = r_last;
-        if (p.scale & 1) {
+          for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
+          float m_last = r_last;
+          if (p.scale & 1) {
 #pragma unroll
-          for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
-          m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+            for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
+            m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+          }
+          if (!rvalid) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) y[c] = 0.0f;
+            m_last = 0.0f;
+          }
+          if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
+            float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+              *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
+            if (mg == 0) dst[64] = m_last;
+          }
+          float ve[8], vo[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
+          mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+          mf_split8(ve, be_hi, be_lo);
+          mf_split8(vo, bo_hi, bo_lo);
+          unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
+          const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 mt + 4 g + r: D[n][row i]
+            mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][0][0], be_hi, zero, 0, 0, 0);
+            mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][1][0], bo_hi, zero, 0, 0, 0);
+            mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][0][0], be_lo, zero, 0, 0, 0);
+            mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][1][0], bo_lo, zero, 0, 0, 0);
+            ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][0][1], be_hi, ex, 0, 0, 0);
+            ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[mt][1][1], bo_hi, ox, 0, 0, 0);
+            const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
+            const int n0 = 16 * mt + 4 * mg;                                // this lane's taps n0 .. n0 + 3
+            float g0[4], g1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = n0 + r;
+              const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);      // + bin 64 (a rank-1 update)
+              const float o = ov[r];
+              g0[r] = kIr65.win[n] * (e + o);                                // g[n]:    taps 64 + n and 64 - n
+              g1[r] = (n >= 1) ? kIr65.win[64 - n] * (e - o) : 0.0f;        // g[64-n]: taps 128 - n and n; tap 0 is 0
+            }
+            mf_put4(hrow, 64 + n0, g0[0], g0[1], g0[2], g0[3]);
+            mf_put4(hrow, n0, g1[0], g1[1], g1[2], g1[3]);
+            mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
+            mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
+          }
+          {
+            // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
+            const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
+            float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (mg == 0) {
+              _Float16 h, l;
+              mf_split(kIr65.win[32] * part, h, l);
+              const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
+              *reinterpret_cast<uint16_t*>(hrow + 96 * 2) = hb;              // tap 96
+              *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 96 * 2) = lb;
+              *reinterpret_cast<uint16_t*>(hrow + 32 * 2) = hb;              // tap 32
+              *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
+            }
+          }
+          }
+          if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 1);
         }
-        if (!rvalid) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) y[c] = 0.0f;
-          m_last = 0.0f;
-        }
-        if (ctl_out && mt == 0 && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
-          float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4)
-            *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
-          if (mg == 0) dst[64] = m_last;
-        }
-        float ve[8], vo[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
-        mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
-        mf_split8(ve, be_hi, be_lo);
-        mf_split8(vo, bo_hi, bo_lo);
-        unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
-        const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // magnitudes of tile tick + 2, used a tick from now: fetched at the END of the tick, into the registers this
+        // tick's magnitudes have just left (past the block's last tile: the last one again)
         {
-          // e(n) = sum_i ce[n][i] m[2i], o(n) = sum_i co[n][i] m[2i+1], n = 16 mt + 4 g + r: D[n][row i]
-          mf_f32x4 ea = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][0], be_hi, zero, 0, 0, 0);
-          mf_f32x4 oa = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][0], bo_hi, zero, 0, 0, 0);
-          mf_f32x4 ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][0], be_lo, zero, 0, 0, 0);
-          mf_f32x4 ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][0], bo_lo, zero, 0, 0, 0);
-          ex = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[0][1], be_hi, ex, 0, 0, 0);
-          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[1][1], bo_hi, ox, 0, 0, 0);
-          const mf_f32x4 ev = ea + ex * (1.0f / kMfLoScale), ov = oa + ox * (1.0f / kMfLoScale);
-          const int n0 = 16 * mt + 4 * mg;                                // this lane's taps n0 .. n0 + 3
-          float g0[4], g1[4];
+          const int T = (int)blockIdx.x + min(tick + 2, n_my - 1) * (int)gridDim.x;
+          DDSP_MF_TILE(T, b, z0, f_first, rel0);
+          (void)rel0;
+          const int rfr = f_first + rrow;
+          const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int n = n0 + r;
-            const float e = fmaf(m_last, kIr65.c[n * kIrRowStride + 32], ev[r]);      // + bin 64 (a rank-1 update)
-            const float o = ov[r];
-            g0[r] = kIr65.win[n] * (e + o);                                // g[n]:    taps 64 + n and 64 - n
-            g1[r] = (n >= 1) ? kIr65.win[64 - n] * (e - o) : 0.0f;        // g[64-n]: taps 128 - n and n; tap 0 is 0
-          }
-          mf_put4(hrow, 64 + n0, g0[0], g0[1], g0[2], g0[3]);
-          mf_put4(hrow, n0, g1[0], g1[1], g1[2], g1[3]);
-          mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
-          mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
+          for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+          r_last = src[64];
         }
-        if (mt == 0) {
-          // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
-          const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
-          float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
-          part += __shfl_xor(part, 16);
-          part += __shfl_xor(part, 32);
-          if (mg == 0) {
-            _Float16 h, l;
-            mf_split(kIr65.win[32] * part, h, l);
-            const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
-            *reinterpret_cast<uint16_t*>(hrow + 96 * 2) = hb;              // tap 96
-            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 96 * 2) = lb;
-            *reinterpret_cast<uint16_t*>(hrow + 32 * 2) = hb;              // tap 32
-            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
-          }
-        }
-        }
-        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 1);
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
+        __syncthreads();
       }
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = nq[c4];
-      r_last = n_last;
-      if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
-      __syncthreads();
     }
   } else {
     // =========================== FIR wavefronts: pairs of frames on the matrix cores =================================
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         const int T = (int)blockIdx.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)f_first; (void)rel0;
-        mf_noise_tile<GEN_NOISE>(tid - 64 * kMfPW, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
+        mf_noise_tile<GEN_NOISE, 64 * kMfPW>(tid - 64 * kMfPW, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
       }
       bool active = false;
       if (tick >= 0) {

@@ -179,9 +179,16 @@ def test_device_noise_restatement_is_uniform():
   # counter-based: rows and offsets are independent of batch tiling
   y = O.device_uniform_noise(2, 4096, seed=7, batch_offset=2)
   np.testing.assert_array_equal(x[2:], y)
-  # Philox4x32-10 known answer (Random123 kat_vectors: ctr=0,key=0)
+  # Philox4x32 known answers (Random123 kat_vectors): 10 rounds (the paper's default, what the device generator runs)
+  # and 7 rounds (measured in round 3, not adopted), ctr = 0 / key = 0 and ctr = key = all ones
   w = O.philox4x32_10(0, 0, 0, 0, 0, 0)
   assert [int(v) for v in w] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+  assert O.NOISE_ROUNDS == 10
+  w = O.philox4x32(0, 0, 0, 0, 0, 0, 7)
+  assert [int(v) for v in w] == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+  ones = 0xffffffff
+  w = O.philox4x32(ones, ones, ones, ones, ones, ones, 7)
+  assert [int(v) for v in w] == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
 
 
 # ---- effects.Reverb ----------------------------------------------
