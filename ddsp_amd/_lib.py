@@ -23,6 +23,7 @@ SIGNATURES = {
     'ddsp_harmonic_signal_tf_order_f32': (c_int, [c_f32p] * 4 + [c_int] * 5 + [c_uint, c_voidp]),
     'ddsp_harmonic_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 5 +
                           [c_uint, c_voidp]),
+    'ddsp_harmonic_add_f32': (c_int, [c_f32p] * 5 + [c_int] * 5 + [c_uint, c_voidp]),
     'ddsp_filtered_noise_controls_f32': (c_int, [c_f32p] * 2 + [c_int] * 3 +
                                          [c_float, c_uint, c_voidp]),
     'ddsp_fir_size': (c_int, [c_int, c_int]),

@@ -41,6 +41,12 @@ def _stream():
   return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+def _stream_of(device):
+  """Raw handle of torch's current stream ON `device` (which need not be the current device)."""
+  index = device.index if device.index is not None else torch._C._cuda_getDevice()
+  return torch._C._cuda_getCurrentRawStream(index)
+
+
 def require_no_grad(op, *tensors):
   """The raw kernel wrappers return tensors without a grad_fn.  Where no torch.autograd node covers an op, an input
   that requires grad must fail loudly instead of silently cutting the graph (a branch summed through Add would just
@@ -71,18 +77,23 @@ class Workspace:
   """Grow-only scratch buffers in HBM, one per (device, stream): kernels enqueued on different streams never share
   scratch, and a buffer is only ever replaced by work enqueued behind its last user on the same stream (the caching
   allocator hands a freed block back to the stream it was allocated on).  A Processor instance may therefore be
-  called from several streams; each stream pays for its own scratch."""
+  called from several streams; each stream pays for its own scratch.  The stream is the current one of the TENSOR's
+  device; at most `kMaxStreams` buffers are kept, least recently used first out (short-lived streams do not pile up
+  scratch, and a recycled stream handle finds a buffer that was last used on that very handle)."""
+  kMaxStreams = 8
 
   def __init__(self):
-    self._bufs = {}
+    self._bufs = {}            # insertion order = recency (a hit is re-inserted)
 
   def get(self, nbytes, device):
     nbytes = max(int(nbytes), 16)
-    key = (device, _stream() if device.type == 'cuda' else None)
-    buf = self._bufs.get(key)
+    key = (device, _stream_of(device) if device.type == 'cuda' else None)
+    buf = self._bufs.pop(key, None)
     if buf is None or buf.numel() < nbytes:
       buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-      self._bufs[key] = buf
+    self._bufs[key] = buf
+    while len(self._bufs) > self.kMaxStreams:
+      self._bufs.pop(next(iter(self._bufs)))
     return buf
 
 

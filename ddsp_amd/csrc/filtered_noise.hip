@@ -868,6 +868,11 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
+  // bit 30 (the in-kernel timeline of tools/exp_noise_fir.py: the controls pointer then carries a stamp buffer) only
+  // under DDSP_NOISE_DEBUG_TIMELINE=1; any other unknown bit is an error, not a silent reinterpretation
+  static const bool dbg_allowed = getenv("DDSP_NOISE_DEBUG_TIMELINE") != nullptr;
+  const unsigned known = DDSP_NOISE_SCALE_EXP_SIGMOID | DDSP_NOISE_FIR_VECTOR_ALU | (dbg_allowed ? 0x40000000u : 0u);
+  if (flags & ~known) return DDSP_ERR_UNSUPPORTED;
   {
     const IrGeom g = ir_geom(M, window_size);
     const int frame_size = (N + F - 1) / F;

@@ -893,6 +893,22 @@ extern "C" int ddsp_harmonic_signal_f32(const float* ctl_amp, const float* ctl_h
   return launch_synth(f0_hz, workspace, audio, B, F, K, N, sample_rate, flags, st);
 }
 
+// Harmonic.__call__ with processors.Add fused in (ddsp/processors.py:162-176; the node that follows the two synths in every
+// shipped DAG, gin/models/ae.gin:49-56): audio = Harmonic(...) + add_signal in one launch, one [B,N] stream written
+// where the three-kernel form moves three more.  Only where the wavetable kernel applies (ddsp_harmonic_f32's default
+// path: hop % 64 == 0, K % 4 == 0, K <= 128, default flags); DDSP_ERR_UNSUPPORTED otherwise - the caller then runs
+// ddsp_harmonic_f32 and ddsp_add_f32.
+extern "C" int ddsp_harmonic_add_f32(const float* amplitudes, const float* hd, const float* f0_hz, const float* add_signal,
+                                     float* audio, int B, int F, int K, int N, int sample_rate, unsigned flags,
+                                     void* stream) {
+  if (!amplitudes || !hd || !f0_hz || !add_signal || !audio) return DDSP_ERR_NULL_POINTER;
+  int rc = check_harmonic_shape(B, F, K, N, sample_rate);
+  if (rc != DDSP_OK) return rc;
+  if (!harm_table_ok(F, K, N, hd, nullptr, nullptr, flags, /*inputs_are_controls=*/0)) return DDSP_ERR_UNSUPPORTED;
+  return launch_harm_table(amplitudes, hd, f0_hz, audio, nullptr, nullptr, add_signal, B, F, K, N, sample_rate, flags,
+                           (hipStream_t)stream);
+}
+
 extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const float* f0_hz,
                                  float* audio, float* ctl_amp, float* ctl_hd, void* workspace,
                                  size_t workspace_bytes, int B, int F, int K, int N,
@@ -904,7 +920,7 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (harm_table_ok(F, K, N, hd, ctl_amp, ctl_hd, flags, /*inputs_are_controls=*/0))
-    return launch_harm_table(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, B, F, K, N, sample_rate, flags, st);
+    return launch_harm_table(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, nullptr, B, F, K, N, sample_rate, flags, st);
   flags &= ~DDSP_HARM_DIRECT_SUM;
   if (fused_ok(F, K, N, hd, ctl_hd))
     return launch_fused(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, workspace, B, F, K, N,

@@ -11,7 +11,10 @@ namespace ddsp {
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
                    int inputs_are_controls);
 
+// add_in: null, or [B,N] samples added to the synthesised audio before it is stored (processors.Add fused in; may be
+// `audio` itself)
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
-                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st);
+                      float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
+                      hipStream_t st);
 
 }  // namespace ddsp

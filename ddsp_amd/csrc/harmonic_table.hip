@@ -681,7 +681,7 @@ __device__ __forceinline__ void wt_pk_coefs(f32x2 (&coef)[W / 2][4]) {
 template <int W, int NK, bool ONE_TILE>
 __global__ __launch_bounds__(1024) void harm_wt16_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
-    float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, Wt16Args p) {
+    float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, Wt16Args p) {
   __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
   __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
   __shared__ ChunkTables t_all[2];
@@ -1071,6 +1071,12 @@ __global__ __launch_bounds__(1024) void harm_wt16_kernel(
               // template instance a tile happens to run in - the cut into chunks depends on the batch size)
               cyc[u] = fma(rr + 1.0, fma(t.dw[q[u]], rr, t.w[q[u]]), t.theta[q[u]]);
             }
+            // processors.Add fused in (ddsp/processors.py:162-176): the other signal's samples, fetched now, added at the
+            // store (add_in may be the output buffer itself: every element is read and written by the same lane)
+            float addv[kWtNT];
+            if (add_in != nullptr)
+#pragma unroll
+              for (int u = 0; u < NT; ++u) addv[u] = add_in[(size_t)(row0 + q[u]) * hop + r[u]];
             float theta[kWtNT];
             f32x2 zz[kWtNT];
             unsigned sgn[kWtNT];
@@ -1123,6 +1129,9 @@ __global__ __launch_bounds__(1024) void harm_wt16_kernel(
                 }
               }
             }
+            if (add_in != nullptr)
+#pragma unroll
+              for (int u = 0; u < NT; ++u) out[u] += addv[u];
 #pragma unroll
             for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
           };
@@ -1159,7 +1168,8 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
 }
 
 int launch_harm_wt16(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
-                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
+                     float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
+                     hipStream_t st) {
   Wt16Args p;
   p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
   p.total_frames = B * F;
@@ -1203,10 +1213,10 @@ int launch_harm_wt16(const float* amplitudes, const float* hd, const float* f0, 
   do {                                                                                                         \
     if (p.hop == 64)                                                                                           \
       hipExtLaunchKernelGGL((harm_wt16_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, p);                                                                \
+                            audio, ctl_amp, ctl_hd, add_in, p);                                                                \
     else                                                                                                       \
       hipExtLaunchKernelGGL((harm_wt16_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, p);                                                                \
+                            audio, ctl_amp, ctl_hd, add_in, p);                                                                \
   } while (0)
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
   if (K <= 64) DDSP_LAUNCH_WT16(6, 1);
@@ -1236,11 +1246,13 @@ int launch_harm_wt16(const float* amplitudes, const float* hd, const float* f0, 
 }
 
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
-                      float* ctl_hd, int B, int F, int K, int N, int sample_rate, unsigned flags, hipStream_t st) {
-  // DDSP_HARM_TABLE_12=1: the round-2 kernel (12 wavefronts), kept for A/B measurements
+                      float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
+                      hipStream_t st) {
+  // DDSP_HARM_TABLE_12=1: the round-2 kernel (12 wavefronts), kept for A/B measurements (it has no fused Add)
   static const bool old12 = getenv("DDSP_HARM_TABLE_12") != nullptr;
-  if (!old12 && (long long)B * F < (1ll << 31))
-    return launch_harm_wt16(amplitudes, hd, f0, audio, ctl_amp, ctl_hd, B, F, K, N, sample_rate, flags, st);
+  if ((!old12 || add_in != nullptr) && (long long)B * F < (1ll << 31))
+    return launch_harm_wt16(amplitudes, hd, f0, audio, ctl_amp, ctl_hd, add_in, B, F, K, N, sample_rate, flags, st);
+  if (add_in != nullptr) return DDSP_ERR_UNSUPPORTED;
 
   TableArgs p;
   p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;

@@ -32,7 +32,10 @@ struct SpecTermArgs {
 
 __device__ __forceinline__ float st_weight(const float* __restrict__ wts, const SpecTermArgs& p, int b, int f, int k) {
   if (wts == nullptr) return 1.0f;
-  const size_t i = ((size_t)(p.wb > 1 ? b : 0) * p.wf + (p.wf > 1 ? f : 0)) * p.wk + (p.wk > 1 ? k : 0);
+  // (indices clamped to the mask's own extents: a mask made for a difference term has one row / bin less than the
+  // magnitudes, and rows / bins that term does not use are still visited here - their weight is discarded, the read
+  // must stay inside the buffer)
+  const size_t i = ((size_t)min(b, p.wb - 1) * p.wf + min(f, p.wf - 1)) * p.wk + min(k, p.wk - 1);
   return wts[i];
 }
 __device__ __forceinline__ float st_safe_log(float x, float eps) { return __logf(x <= 0.0f ? eps : x); }
@@ -253,6 +256,9 @@ extern "C" int ddsp_spectral_terms_f32(const float* target_mag, const float* val
   if (B <= 0 || frames <= 0 || bins <= 0 || bins > kStMaxBins) return DDSP_ERR_BAD_SHAPE;
   if (loss_type != DDSP_LOSS_L1 && loss_type != DDSP_LOSS_L2 && loss_type != DDSP_LOSS_COSINE) return DDSP_ERR_BAD_SHAPE;
   if (weights && (weights_b < 1 || weights_f < 1 || weights_k < 1 || (weights_b != 1 && weights_b != B))) return DDSP_ERR_BAD_SHAPE;
+  // a mask is broadcast (1), full, or one short along the axis of a difference term (losses.py:102-128)
+  if (weights && ((weights_f != 1 && weights_f != frames && weights_f != frames - 1) ||
+                  (weights_k != 1 && weights_k != bins && weights_k != bins - 1))) return DDSP_ERR_BAD_SHAPE;
   if (workspace_bytes < ddsp_spectral_terms_workspace_bytes(B, frames) || ((uintptr_t)workspace & 7)) return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   SpecTermArgs p;

@@ -131,6 +131,28 @@ class Harmonic(processors.Processor):
       return dict(signal=audio, controls={'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz})
     return self._forward(amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict)
 
+  def call_add(self, amplitudes, harmonic_distribution, f0_hz, add_signal):
+    """`Add()(add_signal, self(amplitudes, harmonic_distribution, f0_hz))` (processors.py:162-176) as ONE launch where
+    the wavetable kernel applies (ddsp_harmonic_add_f32: one [batch, n_samples] stream written instead of three more
+    moved), the two calls otherwise.  Bit-identical to the two calls.  Forward only: ProcessorGroup uses it when
+    nothing asks for the intermediate signals and nothing requires grad."""
+    add_signal = core.tf_float32(add_signal)
+    amps, hd, fuse = self._prescale(amplitudes, harmonic_distribution)
+    f0 = core.tf_float32(f0_hz)
+    core.require_no_grad('Harmonic.call_add (use __call__ and Add, which are differentiable)', amps, hd, f0, add_signal)
+    b, f, k = core._check_harmonic_shapes(amps, hd, f0)
+    n = int(self.n_samples)
+    if (tuple(add_signal.shape) == (b, n) and self.kernel == 'auto' and
+        core._on_closed_form_kernels(self.amp_resample_method, f, n)):
+      audio = torch.empty((b, n), dtype=torch.float32, device=amps.device)
+      rc = _lib.load().ddsp_harmonic_add_f32(amps.data_ptr(), hd.data_ptr(), f0.data_ptr(), add_signal.data_ptr(),
+                                             audio.data_ptr(), b, f, k, n, int(self.sample_rate), self._flags(fuse),
+                                             core._stream())
+      if rc != -3:                   # DDSP_ERR_UNSUPPORTED: this shape / these flags run on the other kernels
+        _lib.check(rc, 'ddsp_harmonic_add_f32')
+        return audio
+    return processors._add(add_signal, self.call(amplitudes, harmonic_distribution, f0_hz))
+
   def _flags(self, fuse):
     flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
                                  self.use_angular_cumsum)
@@ -314,6 +336,7 @@ class FilteredNoise(processors.Processor):
       _lib.check(min(size, 0), 'ddsp_fir_size')
       _, _, n_out = core._crop_range(n, f, size, 'same', -1)
       if n_out != n:
+        self._next_seed()             # the call counts like any other
         ctl = None
         if want_controls:
           ctl = core.exp_sigmoid(magnitudes + float(self.initial_bias)) if fuse_scale else magnitudes

@@ -149,6 +149,18 @@ int ddsp_harmonic_f32(const float* amplitudes, const float* harmonic_distributio
                       size_t workspace_bytes, int B, int F, int K, int N, int sample_rate,
                       unsigned flags, void* stream);
 
+/* Harmonic.__call__ with the processors.Add that follows it fused in (ddsp/processors.py:162-176;
+ * every shipped DAG ends Harmonic, FilteredNoise, Add: ddsp/training/gin/models/ae.gin:49-56):
+ *   audio[B,N] = Harmonic(amplitudes, harmonic_distribution, f0_hz) + add_signal[B,N]
+ * in one launch - one [B,N] stream written (14.44 instead of 18.44 bytes per sample for the
+ * Harmonic + FilteredNoise + Add group).  add_signal may be `audio` itself.
+ * Bit-identical to ddsp_harmonic_f32 followed by ddsp_add_f32.  Returns DDSP_ERR_UNSUPPORTED where
+ * the wavetable kernel does not apply (hop % 64, K % 4, K > 128, non-default flags): the caller
+ * then uses the two separate entries. */
+int ddsp_harmonic_add_f32(const float* amplitudes, const float* harmonic_distribution,
+                          const float* f0_hz, const float* add_signal, float* audio, int B, int F,
+                          int K, int N, int sample_rate, unsigned flags, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * FilteredNoise.get_controls  (ddsp/synths.py:165-179):
  *   ctl_magnitudes[B,F,M] = exp_sigmoid(magnitudes + initial_bias)   (or identity copy).

@@ -149,6 +149,11 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
       calls.setdefault('batches', set()).add(int(amplitudes.shape[0]))
       return torch.zeros(amplitudes.shape[0], self.n)
 
+    def call_add(self, amplitudes, harmonic_distribution, f0_hz, add_signal):
+      calls['harm'] += 1
+      calls['fused'] = calls.get('fused', 0) + 1
+      return add_signal
+
   class _Noise:
     def __init__(self, n_samples, window_size, seed):
       self.n = n_samples
@@ -173,6 +178,7 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 10
   assert line['cpu_baseline']['kind'] == 'port' and 'other_issue_mode' in line
   assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
+  assert calls['fused'] >= 7 and line['fused_add']['bytes_per_sample'] < 18.44 and line['fused_add']['value'] > 0
   assert any(abs(f - 200.0) < 2.0 for f in calls['f0s'])              # the f0 = 200 regime ran...
   assert abs(calls['last_f0'] - 70.0) < 2.0                            # ...and the second shape after it, on its own inputs
   assert calls['batches'] == {2, 32}

@@ -1271,3 +1271,46 @@ def test_filtered_noise_random_shapes_vs_oracle(ddsp, seed):
       got = npy(synth(mags))
     ref = O.filtered_noise(mags, noise, 0, O.exp_sigmoid, dtype=np.float64)
     np.testing.assert_allclose(got, ref, rtol=0, atol=noise_tol(ref), err_msg=str(dict(fs=fs, frames=f, n=n, batch=b)))
+
+
+# ---- processors.Add fused into the Harmonic kernel (ddsp/processors.py:162-176; gin/models/ae.gin:49-56) --------------
+def test_processor_group_fused_add_is_bit_identical(ddsp):
+  """ProcessorGroup[Harmonic, FilteredNoise, Add] asked for the signal only runs Harmonic with the Add fused in
+  (ddsp_harmonic_add_f32); asked for the outputs dict it runs the three processors.  Same samples, bit for bit; with a
+  Reverb behind the Add too; and Harmonic.call_add falls back to the two calls where the wavetable kernel does not apply."""
+  n_frames, n = 100, 6400
+  x = canonical_inputs(3, seed=19, n_frames=n_frames)
+  features = {'amps': x['amplitudes'], 'harmonic_distribution': x['harmonic_distribution'],
+              'f0_hz': x['f0_hz'], 'magnitudes': x['magnitudes']}
+
+  def group(extra=()):
+    harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+    noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, name='filtered_noise', seed=3)
+    add = ddsp.processors.Add(name='add')
+    dag = [(harmonic, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
+           (add, ['filtered_noise/signal', 'harmonic/signal'])] + list(extra)
+    return ddsp.processors.ProcessorGroup(dag=dag, name='processor_group')
+  g1, g2 = group(), group()
+  assert g1._fused_add_plan() == (0, 2)
+  with torch.no_grad():
+    fused = npy(g1(features))
+  full = g2(features, return_outputs_dict=True)
+  np.testing.assert_array_equal(fused, npy(full['signal']))
+  np.testing.assert_array_equal(fused, npy(full['controls']['harmonic']['signal']) + npy(full['controls']['filtered_noise']['signal']))
+  # a node behind the Add
+  rev = ddsp.effects.Reverb(trainable=True, reverb_length=500, name='reverb')
+  rev.build(device=torch.device(DEV))
+  rev._ir = ddsp.core.tf_float32(np.random.default_rng(2).standard_normal(500) * 0.05)
+  g3, g4 = group([(rev, ['add/signal'])]), group([(rev, ['add/signal'])])
+  with torch.no_grad():
+    np.testing.assert_array_equal(npy(g3(features)), npy(g4(features, return_outputs_dict=True)['signal']))
+  # something else reads the harmonic signal: no fusion
+  crop = ddsp.processors.Crop(frame_size=64, name='crop')
+  g5 = group([(crop, ['harmonic/signal'])])
+  assert g5._fused_add_plan() is None
+  # call_add on a shape the wavetable kernel does not take (K % 4 != 0): the two calls
+  h = ddsp.synths.Harmonic(n_samples=n)
+  hd99 = x['harmonic_distribution'][..., :99]
+  z = npy(full['controls']['filtered_noise']['signal'])
+  np.testing.assert_array_equal(npy(h.call_add(x['amplitudes'], hd99, x['f0_hz'], z)),
+                                npy(h(x['amplitudes'], hd99, x['f0_hz'])) + z)

@@ -1,0 +1,92 @@
+"""Build-time guards on the gfx950 instruction stream of the default Harmonic kernels (common.h:166).
+
+`load_issue` / `loads_landed` (csrc/common.h) hide an in-flight global load from the compiler: the inline-asm output is
+"defined" at the issue, the data arrives later, and only the `s_waitcnt vmcnt(0)` of `loads_landed` makes it safe to
+touch.  Nothing in the language stops the compiler from copying or spilling such a register in between (under higher
+register pressure, or with another hipcc) - it would silently capture stale data.  This test compiles
+csrc/harmonic_table.hip to assembly and checks, for every pinned load, that no instruction between the load and the
+wait that covers it names the destination registers; and that the kernels use no scratch memory.  CPU only (hipcc
+cross-compiles), a few seconds."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+def _regs(text):
+  out = set()
+  for lo, hi in re.findall(r'\bv\[(\d+):(\d+)\]', text):
+    out.update(range(int(lo), int(hi) + 1))
+  out.update(int(r) for r in re.findall(r'\bv(\d+)\b', text))
+  return out
+
+
+@pytest.fixture(scope='module')
+def asm(tmp_path_factory):
+  if not os.path.exists(HIPCC):
+    pytest.skip('hipcc not found')
+  out = tmp_path_factory.mktemp('isa') / 'harmonic_table.s'
+  from ddsp_amd import build
+  flags = [f for f in build.FLAGS if f not in ('-shared', '-fPIC')]
+  subprocess.run([HIPCC] + flags + ['-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', '-o', str(out),
+                                    os.path.join(ROOT, 'ddsp_amd', 'csrc', 'harmonic_table.hip')],
+                 check=True, stderr=subprocess.DEVNULL)
+  return out.read_text()
+
+
+def _kernels(asm_text):
+  """{mangled name: body text} of the harm_wt16 / harm_table kernels."""
+  found = {}
+  for m in re.finditer(r'^(_ZN4ddsp\d+harm_(?:wt16|table)_kernel\w+):.*?\n(.*?)\n\s*s_endpgm', asm_text, re.S | re.M):
+    found[m.group(1)] = m.group(2)
+  return found
+
+
+def test_no_scratch_in_the_harmonic_table_kernels(asm):
+  names = re.findall(r'\.name:\s+(_ZN4ddsp\d+harm_(?:wt16|table)_kernel\w+)', asm)
+  assert len(names) >= 6
+  for name in names:
+    block = asm[asm.index('.name:           ' + name) - 400:asm.index('.name:           ' + name) + 400]
+    m = re.search(r'\.private_segment_fixed_size:\s+(\d+)', block)
+    assert m and int(m.group(1)) == 0, '%s uses %s bytes of scratch per lane' % (name, m and m.group(1))
+
+
+def test_pinned_loads_are_not_touched_before_their_wait(asm):
+  kernels = _kernels(asm)
+  assert kernels, 'kernels not found in the assembly'
+  checked = 0
+  for name, body in kernels.items():
+    lines = body.split('\n')
+    in_asm, pending = False, {}            # pending: {register: line number of the load}
+    for n, line in enumerate(lines):
+      code = line.split(';')[0].strip() if not line.strip().startswith(';;#') else line.strip()
+      if code.startswith(';;#ASMSTART'):
+        in_asm = True
+        continue
+      if code.startswith(';;#ASMEND'):
+        in_asm = False
+        continue
+      if not code or code.endswith(':') or code.startswith('.'):
+        continue
+      if in_asm and code.startswith('global_load'):
+        dst = code.split(',')[0]
+        for r in _regs(dst):
+          pending[r] = n
+        checked += 1
+        continue
+      if in_asm and code.startswith('s_waitcnt vmcnt(0)'):
+        pending.clear()
+        continue
+      if code.startswith('s_cbranch') or code.startswith('s_branch') or code.startswith('s_barrier'):
+        continue
+      # any other instruction: must not name a pending destination register (address operands of later pinned loads
+      # are covered by the same rule: they are ordinary instructions' results, never the pending registers)
+      touched = _regs(code) & set(pending)
+      assert not touched, '%s: line %d `%s` touches v%s, the destination of a pinned load still in flight (issued at line %d)' % (
+          name, n, code, sorted(touched), min(pending[r] for r in touched))
+  assert checked >= 6          # the pinned loads of the T-wavefront that builds the phase tables, in every instantiation

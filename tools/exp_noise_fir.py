@@ -10,6 +10,7 @@ the default build (two blocks of 8 wavefronts per CU) are 8..11; DDSP_MF_DBG_BLO
 count are the second, younger blocks of their CUs).
 """
 import json, os, sys, time
+os.environ.setdefault('DDSP_NOISE_DEBUG_TIMELINE', '1')      # lets flag bit 30 through (the stamp buffer of the timeline below)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ddsp_amd as ddsp
