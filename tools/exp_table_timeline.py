@@ -1,20 +1,28 @@
-"""Per-tick timeline of harm_table_kernel's block 0 (shader clocks): DDSP_EXP_TABLE_TIMELINE=1 makes the launch
-record and print it.   python tools/exp_table_timeline.py [batch]"""
+"""Per-tick timeline of harm_table_kernel's block 0 (shader clocks per role and stage), from a -DDDSP_WT_TIMELINE build
+of the library (tools/build_timeline_lib.sh -> tools/bin/libddsp_amd_timeline.so; the product library has no stamps).
+
+    python tools/exp_table_timeline.py [batch] [f0]
+"""
 import os, sys
-os.environ['DDSP_EXP_TABLE_TIMELINE'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['DDSP_EXP_TABLE_TIMELINE'] = '1'
 import numpy as np, torch
+from ddsp_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'libddsp_amd_timeline.so')
 import ddsp_amd as ddsp
-from ddsp_amd import build
-build.build()
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+f0c = float(sys.argv[2]) if len(sys.argv) > 2 else 70.0
 F, K, N = 1000, 100, 64000
 rng = np.random.default_rng(0)
 amps = ddsp.core.tf_float32(rng.standard_normal((B, F, 1)))
 hd = ddsp.core.tf_float32(rng.standard_normal((B, F, K)))
-f0 = ddsp.core.tf_float32(70 + rng.standard_normal((B, F, 1)))
+f0 = ddsp.core.tf_float32(f0c + rng.standard_normal((B, F, 1)))
 synth = ddsp.synths.Harmonic(n_samples=N)
-for i in range(3):
-  sys.stderr.write('--- launch %d\n' % i)
-  synth(amps, hd, f0)
+devnull = os.open(os.devnull, os.O_WRONLY)
+saved = os.dup(2)
+os.dup2(devnull, 2)                      # every launch prints a timeline: keep the last one only
+for _ in range(5): synth(amps, hd, f0)
+torch.cuda.synchronize()
+os.dup2(saved, 2)
+synth(amps, hd, f0)
 torch.cuda.synchronize()

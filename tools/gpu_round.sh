@@ -1,14 +1,14 @@
 #!/bin/bash
 # One GPU-box session for the round's evidence: parity tests, smoke, bench, rocprof kernel traces, PMC traffic, SQ counters.
 # Usage (from the build container): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export DDSP_PARITY_LOG=$PWD/$OUT/parity_errors.jsonl
 rm -f $DDSP_PARITY_LOG
 echo "== pytest -m gpu (general first, no -x)"
-timeout 900 python -m pytest tests/test_gpu_parity_general.py tests/test_gpu_parity.py -m gpu -q 2>&1 | tee $OUT/pytest_gpu_full.txt | tail -8
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tee $OUT/pytest_gpu_full.txt | tail -8
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 echo "== bench, as the driver runs it (--steps 20 --warmup 5)"
@@ -18,18 +18,27 @@ timeout 600 python bench.py --no-cpu-baseline --also-other-mode 2>$OUT/bench_100
 python - <<PY
 import json
 d = json.load(open('$OUT/bench_1000.json'))
+print('B=%d:' % d['config']['batch_per_gpu'], round(d['value']), 'Msamples/s', round(d['ms_per_step'] * 1e3, 2), 'us  whole-step frac', round(d['roofline']['whole_step']['frac'], 4),
+      'dominant', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'], 2), 'us frac', round(d['roofline']['frac'], 4), 'one stream', d.get('one_stream'), 'other mode', d.get('other_issue_mode'))
+print('isolated', d['kernel_breakdown_us_isolated'])
+print('fused add', d.get('fused_add'))
+c1 = d['configs_1']
+print('configs[1] B=32:', round(c1['value']), round(c1['ms_per_step'] * 1e3, 2), 'us frac', round(c1['whole_step']['frac'], 4), c1['kernel_breakdown_us'], c1.get('dominant_kernel', {}).get('frac'))
+PY
+import json
+d = json.load(open('$OUT/bench_1000.json'))
 print('B=32:', round(d['value']), 'Msamples/s', round(d['ms_per_step'] * 1e3, 2), 'us  whole-step frac', round(d['roofline']['whole_step']['frac'], 4),
       'dominant', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'], 2), 'us frac', round(d['roofline']['frac'], 4), 'other mode', d.get('other_issue_mode'))
 print('isolated', d['kernel_breakdown_us_isolated'])
 ns = d['north_star_shape']
 print('B=128:', round(ns['value']), round(ns['ms_per_step'] * 1e3, 2), 'us frac', round(ns['whole_step']['frac'], 4), ns['kernel_breakdown_us'], ns.get('dominant_kernel', {}).get('frac'))
 PY
-echo "== rocprofv3 kernel trace (bench defaults, batch 32)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+echo "== rocprofv3 kernel trace (configs[1], batch 32, two streams)"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 32 --no-cpu-baseline --no-aux --no-second-shape > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b32.csv; head -6 $f | cut -c1-200; done
 grep "^{\"metric\"" $OUT/rocprof_bench.log | tail -1 > $OUT/bench_b32_under_rocprof.json
 echo "== rocprofv3 kernel trace, batch 128 (north-star shape, one stream)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --streams 1 --no-cpu-baseline --no-aux --no-north-star > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof128 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 128 --streams 1 --no-cpu-baseline --no-aux --no-second-shape > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_b128.log 2>&1 )
 for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b128.csv; head -6 $f | cut -c1-200; done
 grep "^{\"metric\"" $OUT/rocprof_bench_b128.log | tail -1 > $OUT/bench_b128_under_rocprof.json
 rm -rf $OUT/prof $OUT/prof128

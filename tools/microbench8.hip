@@ -6,6 +6,9 @@
 // One block per CU, 4 W wavefronts, all of them "S" wavefronts; no T role, no barrier, no phase A: an upper bound for
 // what phase B can run at.  Reported: shader clocks per tile of SIMD time (= clocks x W / tiles per wavefront).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Iinclude tools/microbench8.hip -o tools/bin/microbench8
+// (AS OF the first two sessions of round 3 - commits 36ebdef and 2406a61: the round-2 kernel whose
+// scalar wt_taps / ChunkTables this file includes has since been replaced by the 16-wavefront kernel and wt_taps_pk;
+// the numbers it produced are profiles/r03a_microbench_phase_b_alone.txt and r03b_microbench_phase_ab_alone.txt)
 #include "../ddsp_amd/csrc/harmonic_table.hip"
 #include <vector>
 

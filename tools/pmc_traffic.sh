@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-aux --no-north-star --streams 1 --batch $BATCH"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-aux --no-second-shape --streams 1 --batch $BATCH"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o pmc -- $CMD > $OUT/$C.log 2>&1
   echo "$C rc=$?"
