@@ -25,14 +25,6 @@ print('fused add', d.get('fused_add'))
 c1 = d['configs_1']
 print('configs[1] B=32:', round(c1['value']), round(c1['ms_per_step'] * 1e3, 2), 'us frac', round(c1['whole_step']['frac'], 4), c1['kernel_breakdown_us'], c1.get('dominant_kernel', {}).get('frac'))
 PY
-import json
-d = json.load(open('$OUT/bench_1000.json'))
-print('B=32:', round(d['value']), 'Msamples/s', round(d['ms_per_step'] * 1e3, 2), 'us  whole-step frac', round(d['roofline']['whole_step']['frac'], 4),
-      'dominant', d['roofline']['kernel'], round(d['roofline']['avg_launch_us'], 2), 'us frac', round(d['roofline']['frac'], 4), 'other mode', d.get('other_issue_mode'))
-print('isolated', d['kernel_breakdown_us_isolated'])
-ns = d['north_star_shape']
-print('B=128:', round(ns['value']), round(ns['ms_per_step'] * 1e3, 2), 'us frac', round(ns['whole_step']['frac'], 4), ns['kernel_breakdown_us'], ns.get('dominant_kernel', {}).get('frac'))
-PY
 echo "== rocprofv3 kernel trace (configs[1], batch 32, two streams)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 32 --no-cpu-baseline --no-aux --no-second-shape > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b32.csv; head -6 $f | cut -c1-200; done
