@@ -207,6 +207,13 @@ __device__ __forceinline__ void loads_landed(ddsp_f32x4& a, float& b, float& c) 
   (void)a; (void)b; (void)c;
 #endif
 }
+__device__ __forceinline__ void loads_landed(float& a) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a));
+#else
+  (void)a;
+#endif
+}
 __device__ __forceinline__ void loads_landed(float& a, float& b, float& c) {
 #if defined(__AMDGCN__)
   __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));

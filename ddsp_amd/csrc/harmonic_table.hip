@@ -115,6 +115,18 @@ template <> struct WtPoly<8> {
 // and on an fp64 prefix that is exact for any f0 a synthesiser sees; every product-sum is spelled out, so which
 // template instance a tile runs in cannot change a bit (tests/test_gpu_contract_shapes.py compares rows run alone, in a
 // batch of 32 and in a batch of 128).
+#ifndef DDSP_WT_WALKER
+#define DDSP_WT_WALKER 2
+#endif
+#ifndef DDSP_WT_SLOTS
+#define DDSP_WT_SLOTS 0x73256104u
+#endif
+// Which wavefront does what is chosen for the four SIMDs' totals, not the wavefronts': a SIMD issues for its four
+// wavefronts in turn, oldest first, and a tick ends when the busiest SIMD is done (r03n: the row maker next to
+// tabulator 3, whose SIMD also builds the phase tables, arrives at the barrier 900 clocks after the others).
+constexpr int kWtWalker = DDSP_WT_WALKER;        // the tabulator that walks the chunk descriptors
+constexpr unsigned kWtSlots = DDSP_WT_SLOTS;     // nibble sw: the tile slot of interpolator sw (wavefront 4 + sw, SIMD sw % 4):
+                                                 // the slots that come up short (7, 6, then 5, 4) are SIMD 3's and SIMD 0's
 struct WtDesc { int b, j0, nfr, fresh; };        // a chunk: frames j0 .. j0 + nfr - 1 of row b; nfr == 0: none
 
 struct TableArgs {
@@ -192,46 +204,142 @@ __device__ __forceinline__ f32x2 wt_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
   return (f32x2){fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
 #endif
 }
-// coefficient pairs of the window polynomials, highest power first: step s of tap pair P is (E_{3-s}, O_{3-s})
-// (O_3 = 0 for the 6-tap window, whose odd part is a quadratic in z^2)
-template <int W> struct WtPkCoef {
-  static constexpr int D = 3;
-  static_assert(WtPoly<W>::DE == 3 && WtPoly<W>::DO <= 3, "window polynomial degrees");
-  static constexpr float e(int P, int s) { return WtPoly<W>::e(P, D - s); }
-  static constexpr float o(int P, int s) { return (D - s) <= WtPoly<W>::DO ? WtPoly<W>::o(P, D - s) : 0.0f; }
-};
-template <int W, int P, int S> struct WtPkE { static constexpr float v = WtPkCoef<W>::e(P, S); };
-template <int W, int P, int S> struct WtPkO { static constexpr float v = WtPkCoef<W>::o(P, S); };
-
-// NT tiles at once; per tile 4 packed FMAs per tap pair for the weights, 2 for the taps (rows j and j + 1)
-template <int W, int P, int NT>
-__device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const f32x2 (&zz)[kWtNT], const f32x2 (&coef)[W / 2][4],
-                                           f32x2 (&acc0)[kWtNT], f32x2 (&acc1)[kWtNT]) {
-  f32x2 w[NT], d0[NT], d1[NT];
-#pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    f32x2 eo = wt_pk_horner(coef[P][0], zz[u], coef[P][1]);
-    eo = wt_pk_horner(eo, zz[u], coef[P][2]);
-    eo = wt_pk_horner(eo, zz[u], coef[P][3]);
-    w[u] = wt_pk_weights(eo, zz[u]);
-    d0[u] = (f32x2){t[u][-P], t[u][1 + P]};
-    d1[u] = (f32x2){t[u][kWtTS - P], t[u][kWtTS + 1 + P]};
-  }
-#pragma unroll
-  for (int u = 0; u < NT; ++u) { acc0[u] = wt_pk_fma(w[u], d0[u], acc0[u]); acc1[u] = wt_pk_fma(w[u], d1[u], acc1[u]); }
-  if constexpr (P + 1 < W / 2) wt_taps_pk<W, P + 1, NT>(t, zz, coef, acc0, acc1);
-}
-template <int W, int P>
-__device__ __forceinline__ void wt_pk_coefs(f32x2 (&coef)[W / 2][4]) {
-  coef[P][0] = (f32x2){WtPkE<W, P, 0>::v, WtPkO<W, P, 0>::v};
-  coef[P][1] = (f32x2){WtPkE<W, P, 1>::v, WtPkO<W, P, 1>::v};
-  coef[P][2] = (f32x2){WtPkE<W, P, 2>::v, WtPkO<W, P, 2>::v};
-  coef[P][3] = (f32x2){WtPkE<W, P, 3>::v, WtPkO<W, P, 3>::v};
+// the fp16 pair (c2048[0] - 2048 h[0], c2048[1] - 2048 h[1]), c2048 = 2048 c: what hi = h leaves of c, scaled - the
+// differences are exact in fp32, the fp16 halves of h are read in place and the results written as fp16 halves
+// (v_fma_mixlo_f16 / v_fma_mixhi_f16: no conversion instructions)
+__device__ __forceinline__ h16x2 wt_rest_halves(f32x2 c2048, h16x2 h) {
 #if defined(__AMDGCN__)
-#pragma unroll
-  for (int s_ = 0; s_ < 4; ++s_) __asm__ volatile("" : "+v"(coef[P][s_]));      // resident: not re-made from literals at every use
+  h16x2 r;
+  const float m = -kWtLoScale;
+  __asm__("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(r) : "v"(h), "v"(m), "v"(c2048[0]));
+  __asm__("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(m), "v"(c2048[1]));
+  return r;
+#else
+  return (h16x2){(__fp16)fmaf((float)h[0], -kWtLoScale, c2048[0]), (__fp16)fmaf((float)h[1], -kWtLoScale, c2048[1])};
 #endif
-  if constexpr (P + 1 < W / 2) wt_pk_coefs<W, P + 1>(coef);
+}
+// (a0 b1 + c0, a1 b0 + c1): a packed FMA with the halves of b swapped
+__device__ __forceinline__ f32x2 wt_pk_fma_swap(f32x2 a, f32x2 b, f32x2 c) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return (f32x2){fmaf(a[0], b[1], c[0]), fmaf(a[1], b[0], c[1])};
+#endif
+}
+// the window weights of two tap pairs at once, E = (e_a, e_b), O = (o_a, o_b): E + z O and E - z O
+__device__ __forceinline__ f32x2 wt_pk_plus(f32x2 o, f32x2 zz, f32x2 e) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(o), "v"(zz), "v"(e));
+  return r;
+#else
+  return (f32x2){fmaf(o[0], zz[0], e[0]), fmaf(o[1], zz[0], e[1])};
+#endif
+}
+__device__ __forceinline__ f32x2 wt_pk_minus(f32x2 o, f32x2 zz, f32x2 e) {
+#if defined(__AMDGCN__)
+  f32x2 r;
+  __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(o), "v"(zz), "v"(e));
+  return r;
+#else
+  return (f32x2){fmaf(-o[0], zz[0], e[0]), fmaf(-o[1], zz[0], e[1])};
+#endif
+}
+template <int N, class Fn>
+__device__ __forceinline__ void wt_static_for(Fn&& f) {
+  if constexpr (N > 0) {
+    wt_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+// The window polynomials as packed pairs, Horner order (index 0 = the highest power of z^2).  Tap pair P = taps -P and
+// 1 + P, weights e_P(z^2) +- z o_P(z^2).  What sits next to each other in a table row is taps (-P - 1, -P) and
+// (1 + P, 2 + P): pairs P + 1 and P are therefore evaluated TOGETHER - (e_{P+1}, e_P) and (o_{P+1}, o_P) - so that one
+// packed FMA makes the weights of two neighbouring taps and one 8-byte LDS read brings their table values, with no
+// register moves in between (the (e_P, o_P) packing of rounds 2-3 needed two v_mov per tap pair: a tenth of phase B).
+// With an odd number of pairs (W = 6) pair 0 is left over and keeps the (e_0, o_0) packing: its two taps are neighbours.
+template <int W> struct WtPkCoefs {
+  static constexpr int NG = W / 4, MID = (W / 2) & 1, DE = WtPoly<W>::DE, DO = WtPoly<W>::DO;
+  f32x2 e[NG][DE + 1], o[NG][DO + 1], m[DE + 1];
+  __device__ __forceinline__ void init() {
+    wt_static_for<NG>([&](auto gg) {
+      constexpr int g = decltype(gg)::value, pb = 2 * g + MID, pa = pb + 1;
+      wt_static_for<DE + 1>([&](auto ss) {
+        constexpr int s_ = decltype(ss)::value;
+        constexpr float va = WtPoly<W>::e(pa, DE - s_), vb = WtPoly<W>::e(pb, DE - s_);
+        e[g][s_] = (f32x2){va, vb};
+        DDSP_KEEP_IN_VGPR(e[g][s_]);          // resident: not re-made from literals at every use
+      });
+      wt_static_for<DO + 1>([&](auto ss) {
+        constexpr int s_ = decltype(ss)::value;
+        constexpr float va = WtPoly<W>::o(pa, DO - s_), vb = WtPoly<W>::o(pb, DO - s_);
+        o[g][s_] = (f32x2){va, vb};
+        DDSP_KEEP_IN_VGPR(o[g][s_]);
+      });
+    });
+    wt_static_for<DE + 1>([&](auto ss) {
+      constexpr int s_ = decltype(ss)::value;
+      constexpr float ve = WtPoly<W>::e(0, DE - s_), vo = (DE - s_) <= DO ? WtPoly<W>::o(0, (DE - s_) <= DO ? DE - s_ : 0) : 0.0f;
+      m[s_] = (f32x2){ve, vo};
+      if (MID) DDSP_KEEP_IN_VGPR(m[s_]);
+    });
+  }
+};
+
+// NT tiles at once (rows j and j + 1 of each); per tile and group of two tap pairs DE + DO packed FMAs for the
+// polynomials, 2 for the weights, 4 for the taps
+template <int W, int NT>
+__device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const f32x2 (&zz)[kWtNT], const WtPkCoefs<W>& c,
+                                           f32x2 (&acc0)[kWtNT], f32x2 (&acc1)[kWtNT]) {
+  typedef WtPkCoefs<W> C;
+  // row j + 1 is 1072 bytes further: past what ds_read2_b32 reaches from row j's address (1020) - ONE second address
+  // per tile, made here (left to itself the compiler makes one per read pair)
+  const float* t1[kWtNT];
+  int row_stride = kWtTS;
+  DDSP_KEEP_IN_VGPR(row_stride);               // (opaque: t1 + 4 stays an immediate offset from ONE address)
+#pragma unroll
+  for (int u = 0; u < NT; ++u) t1[u] = t[u] + row_stride;
+  if constexpr (C::MID) {
+    f32x2 w[NT], d0[NT], d1[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      f32x2 eo = c.m[0];
+#pragma unroll
+      for (int s_ = 1; s_ <= C::DE; ++s_) eo = wt_pk_horner(eo, zz[u], c.m[s_]);
+      w[u] = wt_pk_weights(eo, zz[u]);
+      d0[u] = (f32x2){t[u][0], t[u][1]};
+      d1[u] = (f32x2){t1[u][0], t1[u][1]};
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) { acc0[u] = wt_pk_fma(w[u], d0[u], acc0[u]); acc1[u] = wt_pk_fma(w[u], d1[u], acc1[u]); }
+  }
+  wt_static_for<C::NG>([&](auto gg) {
+    constexpr int g = decltype(gg)::value, pb = 2 * g + C::MID, pa = pb + 1;
+    f32x2 wp[NT], wm[NT], lo0[NT], hi0[NT], lo1[NT], hi1[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      f32x2 ee = c.e[g][0], oo = c.o[g][0];
+#pragma unroll
+      for (int s_ = 1; s_ <= C::DE; ++s_) ee = wt_pk_horner(ee, zz[u], c.e[g][s_]);
+#pragma unroll
+      for (int s_ = 1; s_ <= C::DO; ++s_) oo = wt_pk_horner(oo, zz[u], c.o[g][s_]);
+      wp[u] = wt_pk_plus(oo, zz[u], ee);                      // taps -pa, -pb
+      wm[u] = wt_pk_minus(oo, zz[u], ee);                     // taps 1 + pa, 1 + pb: the other way round in the row
+      lo0[u] = (f32x2){t[u][-pa], t[u][-pb]};
+      hi0[u] = (f32x2){t[u][1 + pb], t[u][1 + pa]};
+      lo1[u] = (f32x2){t1[u][-pa], t1[u][-pb]};
+      hi1[u] = (f32x2){t1[u][1 + pb], t1[u][1 + pa]};
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      acc0[u] = wt_pk_fma(wp[u], lo0[u], acc0[u]);
+      acc1[u] = wt_pk_fma(wp[u], lo1[u], acc1[u]);
+      acc0[u] = wt_pk_fma_swap(wm[u], hi0[u], acc0[u]);
+      acc1[u] = wt_pk_fma_swap(wm[u], hi1[u], acc1[u]);
+    }
+  });
 }
 
 template <int W, int NK, bool ONE_TILE>
@@ -242,6 +350,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
   __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
   __shared__ ChunkTables t_all[2];
   __shared__ __attribute__((aligned(16))) WtDesc ring[8];
+  __shared__ float amp_tab[3][kWtRows + 4];          // the frames' amplitudes (scaled), per plane buffer: tabulator 1 -> all tabulators
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -260,12 +369,12 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #define DDSP_WT_STAMP(i) do { } while (0)
 #endif
 
-  // ---- the first two chunk descriptors (wavefront 0), then everybody reads ----------------------------------------
+  // ---- the first two chunk descriptors (the walker), then everybody reads ----------------------------------------
   WtWalk walk;
   walk.pos = (int)blockIdx.x * p.frames_per_block;
   walk.end = min(walk.pos + p.frames_per_block, p.total_frames);
   walk.seg_left = 0; walk.base = 0; walk.rem = 0; walk.b = 0; walk.j = 0;
-  if (wave == 0) {
+  if (wave == kWtWalker) {
     const WtDesc d0 = wt_next_chunk(walk, p), d1 = wt_next_chunk(walk, p);
     if (lane == 0) { ring[0] = d0; ring[1] = d1; }
   }
@@ -338,12 +447,22 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       return wave_sum_dpp(part);
     };
 
+    // wavefront 1 makes the amplitudes of chunk tick + 2 (lanes = frames 0 .. nfr: core.exp_sigmoid of the row's
+    // amplitude, ddsp/synths.py:120-121): fetched at the top of a tick, scaled after its MFMAs, multiplied into the table
+    // by every tabulator a tick later - the row makers' planes hold the normalised distribution only
+    float pamp = 0.0f;
+    auto fetch_amp = [&](const WtDesc& d) {
+      int lane_ = lane;
+      DDSP_KEEP_IN_VGPR(lane_);
+      load_issue(pamp, amplitudes + (size_t)d.b * F + min(d.j0 + lane_, F - 1));
+    };
     for (int tick = -2;; ++tick) {
       DDSP_WT_STAMP(0);
       if (rw == 3 && dM.nfr > 0) {
         if (dM.fresh) before = row_prefix(dM);
         fetch_f0(dM);
       }
+      if (rw == 1 && dA.nfr > 0) fetch_amp(dA);
       // ---------------- table of chunk tick + 1: O and E on the quarter range ---------------------------------------
       if (dM.nfr > 0) {
 #pragma unroll
@@ -351,7 +470,8 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row 16 rt + j][32 ks + 8 g + e]
         const _Float16* bsrc = planes_all[pm] + (16 * rt + mi) * kWtPS + 8 * mg;
         // one parity at a time (four accumulators live, not eight: the constant factor already takes 64 registers)
-        f32x4 soe[2][2];                                     // [parity][position tile]: hi.hi + (hi.lo + lo.hi) / 2048
+        f32x4 soe[2][2];                                     // [parity][position tile]: a_j (hi.hi + (hi.lo + lo.hi) / 2048)
+        const float am = amp_tab[pm][16 * rt + mi], am_lo = am * (1.0f / kWtLoScale);      // this lane's table row's amplitude
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
           f32x4 acc[2], accx[2];
@@ -375,7 +495,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[tt], 0, 0, 0);
           }
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) soe[par][tt] = acc[tt] + accx[tt] * (1.0f / kWtLoScale);
+          for (int tt = 0; tt < 2; ++tt) soe[par][tt] = acc[tt] * am + accx[tt] * am_lo;
         }
         // D[row = 4 (lane >> 4) + reg][col = lane & 15]: this lane holds positions n0 .. n0+3 of table row mi
         float* trow = tab_all[(tick + 1) & 1] + (16 * rt + mi) * kWtTS + kWtH;
@@ -448,9 +568,17 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           before += __builtin_bit_cast(double, (long long)(((unsigned long long)hi31 << 32) | lo31));
         }
       }
+      if (rw == 1 && dA.nfr > 0) {
+        loads_landed(pamp);
+        int lane_ = lane;
+        DDSP_KEEP_IN_VGPR(lane_);
+        const float a = exp_sigmoid_fast(pamp, kLog10, 2.0f, 1e-7f);
+        if (lane_ <= kWtRows) amp_tab[pa][lane_] = a;
+        if (ctl_amp != nullptr && lane_ < dA.nfr) ctl_amp[(size_t)dA.b * F + dA.j0 + lane_] = a;
+      }
       DDSP_WT_STAMP(2);
-      // ---------------- wavefront 0: the descriptor of chunk tick + 4 -------------------------------------------------
-      if (rw == 0) {
+      // ---------------- the walker: the descriptor of chunk tick + 4 ---------------------------------------------------
+      if (rw == kWtWalker) {
         const WtDesc dn = wt_next_chunk(walk, p);
         if (lane == 0) ring[(tick + 4) & 7] = dn;
       }
@@ -485,21 +613,35 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       }
       const float nyq_l = live ? p.nyquist : -1.0f;
       ddsp_f32x4 lx[NU];
-      float lf0[NU], lamp[NU];
+      float lf0[NU];
+      // (addresses: the clip's first row as wave-uniform bases in scalar registers, the rest as 32-bit byte offsets - a
+      // clip's F K floats are < 4 GB and F < 2^24, harm_table_ok: four vector instructions per row pair where 64-bit row
+      // arithmetic took twelve)
+      const unsigned kq16 = 16u * (unsigned)min(kq, K4 - 1), row_bytes = 4u * (unsigned)K;
+      ddsp_f32x4 lxn[NU];                           // the rows after those: in flight for a whole tick
+      float lf0n[NU];
       auto prefetch = [&](const WtDesc& d) {
+        const size_t r0 = (size_t)d.b * (size_t)F;                               // (an empty descriptor: row 0 of clip 0)
+        const char* __restrict__ hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
+        const char* __restrict__ fb = reinterpret_cast<const char*>(f0_all) + r0 * 4;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          const int row = d.b * F + min(d.j0 + 2 * (u0 + i) + sub, F - 1);      // (an empty descriptor: row 0 of clip 0)
-          const float4 v = hd4[(size_t)row * K4 + min(kq, K4 - 1)];
-          lx[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
-          lf0[i] = f0_all[row];
-          lamp[i] = amplitudes[row];
+          const unsigned jr = (unsigned)min(d.j0 + 2 * (u0 + i) + sub, F - 1);
+          const float4 v = *reinterpret_cast<const float4*>(hb + (__umul24(jr, row_bytes) + kq16));   // F < 2^24
+          lxn[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+          lf0n[i] = *reinterpret_cast<const float*>(fb + 4u * jr);
         }
+      };
+      auto rows_arrive = [&]() {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { lx[i] = lxn[i]; lf0[i] = lf0n[i]; }
       };
       // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
       // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
       // (harmonics as pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 do two lanes' worth per issued instruction)
-      const f32x2 kf01 = {kf[0], kf[1]}, kf23 = {kf[2], kf[3]}, ipsi01 = {ipsi[0], ipsi[1]}, ipsi23 = {ipsi[2], ipsi[3]};
+      // (harmonics as pairs of EQUAL parity - (4 kq + 1, 4 kq + 3) and (4 kq + 2, 4 kq + 4): v_pk_mul / v_pk_add /
+      // v_pk_fma_f32 do two lanes' worth per issued instruction, and a pair is what one dword of a parity plane holds)
+      const f32x2 kf_o = {kf[0], kf[2]}, kf_e = {kf[1], kf[3]}, ipsi_o = {ipsi[0], ipsi[2]}, ipsi_e = {ipsi[1], ipsi[3]};
       auto exp_sigmoid2 = [&](f32x2 v) -> f32x2 {                      // exp_sigmoid_fast on a pair
         const f32x2 t = v * -1.4426950408889634f;
         const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
@@ -507,23 +649,26 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         const f32x2 g = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
         return __builtin_elementwise_fma(g, (f32x2){2.0f, 2.0f}, (f32x2){1e-7f, 1e-7f});
       };
-      auto nyq_mask2 = [&](f32x2 e, float f0r, f32x2 kfp) -> f32x2 {   // e > 0: kept iff fl32(f0 k) < nyquist: median(e, 0, +-huge)
+      // e > 0: kept iff fl32(f0 k) < nyquist: median(e, 0, (nyquist - fl32(f0 k)) 2^100) - the scaled difference is one
+      // FMA of exact products: 0 or >= 2^76 in magnitude, its sign the comparison's
+      const float kHuge = 0x1p100f, nyq_s = nyq_l * kHuge;
+      auto nyq_mask2 = [&](f32x2 e, float f0r, f32x2 kfp) -> f32x2 {
         f32x2 prod;
         { _Pragma("clang fp contract(off)") prod = kfp * f0r; }
-        const f32x2 y = (nyq_l - prod) * 1.0e30f;
+        const f32x2 y = __builtin_elementwise_fma(prod, (f32x2){-kHuge, -kHuge}, (f32x2){nyq_s, nyq_s});
         return (f32x2){__builtin_amdgcn_fmed3f(e[0], 0.0f, y[0]), __builtin_amdgcn_fmed3f(e[1], 0.0f, y[1])};
       };
       auto phase_a = [&](const WtDesc& d, _Float16* planes) {
         const int nfr = d.nfr;
-        f32x2 x01[NU], x23[NU];
-        float part[NU], inv[NU], a_ctl[NU];
+        f32x2 xo[NU], xe[NU];
+        float part[NU], inv[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          x01[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][0], lx[i][1]}), lf0[i], kf01);
-          x23[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][2], lx[i][3]}), lf0[i], kf23);
+          xo[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][0], lx[i][2]}), lf0[i], kf_o);
+          xe[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][1], lx[i][3]}), lf0[i], kf_e);
         }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { const f32x2 h = x01[i] + x23[i]; part[i] = h[0] + h[1]; }
+        for (int i = 0; i < NU; ++i) { const f32x2 h = xo[i] + xe[i]; part[i] = h[0] + h[1]; }
 #pragma unroll
         for (int i = 0; i < NU; ++i) part[i] += dpp_mov0<0xB1, 0xF>(part[i]);      // quad_perm [1,0,3,2]
 #pragma unroll
@@ -535,8 +680,8 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
           part[i] = row_pair_sum(part[i]);            // + the other 16 lanes of this matrix row
-          inv[i] = __builtin_amdgcn_rcpf(part[i] == 0.0f ? 1e-7f : part[i]);
-          a_ctl[i] = exp_sigmoid_fast(lamp[i], kLog10, 2.0f, 1e-7f);
+          // safe_divide: a sum of values that are 0 or >= 1e-7 is 0 (everything masked: eps instead) or >= 1e-7
+          inv[i] = __builtin_amdgcn_rcpf(fmaxf(part[i], 1e-7f));
         }
         // the controls dict (return_outputs_dict=True, how dags.py:171-173 calls every processor); the halo row
         // belongs to the next chunk
@@ -546,39 +691,42 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             const int arow = 2 * (u0 + i) + sub;
             const int crow = d.b * F + d.j0 + arow;        // this lane's (batch * frame) row, if arow < nfr
             if (arow < nfr) {
-              const f32x2 h01 = x01[i] * inv[i], h23 = x23[i] * inv[i];
-              if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(h01[0], h01[1], h23[0], h23[1]);
-              if (kq == 0) ctl_amp[crow] = a_ctl[i];
+              const f32x2 ho = xo[i] * inv[i], he = xe[i] * inv[i];
+              if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(ho[0], he[0], ho[1], he[1]);
             }
           }
         }
-        // c_k = a_k / psi_hat(k) as hi + lo / 2048, two fp16 numbers each
-        // (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
+        // c_k = d_k / psi_hat(k) (d = the normalised distribution) as hi + lo / 2048, two fp16 numbers each (hi rounded toward zero by
+        // v_cvt_pkrtz_f16_f32: lo takes up the rest)
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          const float a = a_ctl[i] * inv[i];
-          const f32x2 c01 = (x01[i] * a) * ipsi01, c23 = (x23[i] * a) * ipsi23;
-          const float c[4] = {c01[0], c01[1], c23[0], c23[1]};
+          const f32x2 c[2] = {(xo[i] * inv[i]) * ipsi_o, (xe[i] * inv[i]) * ipsi_e};       // k odd (k' = 2 kq, 2 kq + 1), k even
           _Float16* dst = planes + (2 * (u0 + i) + sub) * kWtPS + 2 * kq;
 #pragma unroll
-          for (int par = 0; par < 2; ++par) {       // k odd: c[0], c[2] (k' = 2 kq, 2 kq + 1); k even: c[1], c[3]
-            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par], c[par + 2]);
-            const f32x2 rest = ((f32x2){c[par], c[par + 2]} - (f32x2){(float)hi[0], (float)hi[1]}) * kWtLoScale;
+          for (int par = 0; par < 2; ++par) {
+            const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par][0], c[par][1]);
+#ifdef DDSP_WT_OLD_SPLIT
+            const f32x2 rest = (c[par] - (f32x2){(float)hi[0], (float)hi[1]}) * kWtLoScale;
             const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(rest[0], rest[1]);
+#else
+            const h16x2 lo = wt_rest_halves(c[par] * kWtLoScale, hi);
+#endif
             *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
             *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
           }
         }
       };
       prefetch(dA);
+      rows_arrive();
       for (int tick = -2;; ++tick) {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
+        desc_take();
+        prefetch(dL);                              // the next tick's dA: a whole tick for HBM to answer
         DDSP_WT_STAMP(1);
         DDSP_WT_STAMP(2);
         if (dA.nfr > 0) phase_a(dA, planes_all[pa]);
-        desc_take();
-        prefetch(dL);                              // the next tick's dA
+        rows_arrive();
         DDSP_WT_STAMP(3);
         __syncthreads();
         DDSP_WT_STAMP(4);
@@ -588,9 +736,10 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       }
     } else {
       // =================== interpolators (S-wavefronts 0 .. 7): phase B, four tiles at a time ========================
-      // tile slots sw, sw + 8, sw + 16, sw + 24 of every round of 31 (the eighth wavefront has three)
-      f32x2 coef[W / 2][4];
-      wt_pk_coefs<W, 0>(coef);
+      // tile slots s, s + 8, s + 16, s + 24 of every round of 31 (slot 7 has three), s = this wavefront's nibble of kWtSlots
+      WtPkCoefs<W> coef;
+      coef.init();
+      const int slot = (int)((kWtSlots >> (4 * sw)) & 7u);
       for (int tick = -2;; ++tick) {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
@@ -652,7 +801,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             f32x2 acc0[kWtNT], acc1[kWtNT];
 #pragma unroll
             for (int u = 0; u < kWtNT; ++u) { acc0[u] = (f32x2){0.0f, 0.0f}; acc1[u] = (f32x2){0.0f, 0.0f}; }
-            wt_taps_pk<W, 0, NT>(t0, zz, coef, acc0, acc1);
+            wt_taps_pk<W, NT>(t0, zz, coef, acc0, acc1);
             float out[kWtNT], w_cur[kWtNT], w_next[kWtNT], lerp[kWtNT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
@@ -672,6 +821,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               const int kN = __builtin_amdgcn_readfirstlane(t.kN[q[u]]);
               if (kA < kN) {         // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
                 const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
+                const float am0 = amp_tab[pb][q[u]], am1 = amp_tab[pb][q[u] + 1];
                 for (int k = kA; k < kN; ++k) {
                   const float kfl = (float)(k + 1);
                   const float top = fj * kfl, bot = fj1 * kfl;
@@ -679,7 +829,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
                   const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
                   const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
                   const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
-                  const float ak = rn_mul(fmaf(w_next[u], c1, rn_mul(w_cur[u], c0)), WtPoly<W>::psi(k + 1));
+                  const float ak = rn_mul(fmaf(w_next[u], rn_mul(c1, am1), rn_mul(w_cur[u], rn_mul(c0, am0))), WtPoly<W>::psi(k + 1));
                   const float sv = sin_rev(fmaf(theta[u], kfl, -rintf(theta[u] * kfl)));     // exact fractional part of k theta
                   if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
                 }
@@ -693,11 +843,11 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           };
           for (int base = 0; base < n_tiles; base += kWtFrames) {
             const int left = min(n_tiles - base, kWtFrames);
-            const int cnt = (left - sw + 7) >> 3;             // slots sw, sw + 8, .. below `left`: 0 .. 4
-            if (cnt >= 4) tiles(base + sw, std::integral_constant<int, 4>{});
-            else if (cnt == 3) tiles(base + sw, std::integral_constant<int, 3>{});
-            else if (cnt == 2) tiles(base + sw, std::integral_constant<int, 2>{});
-            else if (cnt == 1) tiles(base + sw, std::integral_constant<int, 1>{});
+            const int cnt = (left - slot + 7) >> 3;           // slot, slot + 8, .. below `left`: 0 .. 4
+            if (cnt >= 4) tiles(base + slot, std::integral_constant<int, 4>{});
+            else if (cnt == 3) tiles(base + slot, std::integral_constant<int, 3>{});
+            else if (cnt == 2) tiles(base + slot, std::integral_constant<int, 2>{});
+            else if (cnt == 1) tiles(base + slot, std::integral_constant<int, 1>{});
           }
         }
         DDSP_WT_STAMP(2);
@@ -719,7 +869,7 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
   if (flags & DDSP_HARM_DIRECT_SUM) return false;
   if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
   if (inputs_are_controls || (ctl_amp == nullptr) != (ctl_hd == nullptr) || (flags >> 24) != 0) return false;
-  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 &&
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 && F < (1 << 24) &&
          (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0;
 }
 

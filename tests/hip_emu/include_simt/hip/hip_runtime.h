@@ -507,6 +507,7 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline void sincospif(float x, float* s, float* c) { *s = sinpif(x); *c = cospif(x); }
 inline void sincosf(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }

@@ -115,11 +115,12 @@ def main():
   blocks = blocks_of(m.group(1))
   nb = lambda b, p: count(b, lambda o: o.startswith(p))
   # the hot blocks of a tick, by what they contain
-  b_tiles = max((b for b in blocks if nb(b, 'ds_read2_b32') == 24), key=len)            # phase B, four tiles
+  b_tiles = max((b for b in blocks if nb(b, 'ds_read2_b32') >= 24), key=len)            # phase B, four tiles
   b_store = next(b for b in blocks if nb(b, 'global_store') == 3 and len(b) < 40)      # its stores (the fourth rides in the block above)
-  a_main = [b for b in blocks if nb(b, 'v_exp_f32') == 40][-1]                          # phase A, four row pairs (the rotated loop body)
+  a_main = [b for b in blocks if nb(b, 'v_exp_f32') >= 32][-1]                          # phase A, four row pairs (the rotated loop body)
   a_write = [b for b in blocks if nb(b, 'ds_write') == 8 and len(b) > 60][-1]           # the splits and plane writes
-  a_fetch = [b for b in blocks if nb(b, 'global_load') in (4, 12) and nb(b, 's_barrier') == 1][-1]   # next tick's rows, then the barrier
+  a_fetch = [b for b in blocks if nb(b, 'global_load') == 8 and len(b) < 60][-1]          # the top of a tick: the descriptor, the rows of the tick after
+  a_end = [b for b in blocks if nb(b, 's_barrier') == 1 and nb(b, 'v_mov_b32') >= 16][-1]  # those rows have arrived: into this tick's registers, the barrier
   t_mfma = [b for b in blocks if nb(b, 'v_mfma') == 24]                                 # two row tiles
   t_tables = max((b for b in blocks if nb(b, 'v_fma_f64') + nb(b, 'v_add_f64') + nb(b, 'v_mul_f64') >= 6 and nb(b, 'ds_read2_b32') == 0), key=len)
   loop_glue = 45          # per tick and wavefront: descriptor read / take (4 v_readfirstlane), the shifts, the dispatch on the tile count
@@ -127,7 +128,7 @@ def main():
       'T (tabulator, wavefronts 0-2)': [t_mfma[0], t_mfma[1], ['s_add_u32'] * loop_glue],
       'T3 (+ phase tables)': [t_mfma[0], t_mfma[1], t_tables, ['s_add_u32'] * loop_glue],
       'B (interpolator, 4 tiles)': [b_tiles, b_store, ['s_add_u32'] * loop_glue],
-      'A (row maker, 4 row pairs)': [a_main, a_write, a_fetch, ['s_add_u32'] * loop_glue],
+      'A (row maker, 4 row pairs)': [a_fetch, a_main, a_write, a_end, ['s_add_u32'] * (loop_glue - 20)],
   }
   classes = list(PRICE)
   print('harm_table_kernel<6, 2, true> (K = 100, hop 64): instructions per tick and wavefront, by class; price = clocks as ONE wavefront')
