@@ -218,6 +218,16 @@ __device__ __forceinline__ h16x2 wt_rest_halves(f32x2 c2048, h16x2 h) {
   return (h16x2){(__fp16)fmaf((float)h[0], -kWtLoScale, c2048[0]), (__fp16)fmaf((float)h[1], -kWtLoScale, c2048[1])};
 #endif
 }
+// (int)floor(x) in one instruction
+__device__ __forceinline__ int wt_floor_int(float x) {
+#if defined(__AMDGCN__)
+  int r;
+  __asm__("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return (int)floorf(x);
+#endif
+}
 // (a0 b1 + c0, a1 b0 + c1): a packed FMA with the halves of b swapped
 __device__ __forceinline__ f32x2 wt_pk_fma_swap(f32x2 a, f32x2 b, f32x2 c) {
 #if defined(__AMDGCN__)
@@ -301,48 +311,63 @@ __device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const
   DDSP_KEEP_IN_VGPR(row_stride);               // (opaque: t1 + 4 stays an immediate offset from ONE address)
 #pragma unroll
   for (int u = 0; u < NT; ++u) t1[u] = t[u] + row_stride;
+  // (every stage over the NT tiles in turn: neighbouring instructions are independent)
   if constexpr (C::MID) {
-    f32x2 w[NT], d0[NT], d1[NT];
+    f32x2 eo[NT], w[NT], d0[NT], d1[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      f32x2 eo = c.m[0];
-#pragma unroll
-      for (int s_ = 1; s_ <= C::DE; ++s_) eo = wt_pk_horner(eo, zz[u], c.m[s_]);
-      w[u] = wt_pk_weights(eo, zz[u]);
       d0[u] = (f32x2){t[u][0], t[u][1]};
       d1[u] = (f32x2){t1[u][0], t1[u][1]};
+      eo[u] = wt_pk_horner(c.m[0], zz[u], c.m[1]);
     }
 #pragma unroll
-    for (int u = 0; u < NT; ++u) { acc0[u] = wt_pk_fma(w[u], d0[u], acc0[u]); acc1[u] = wt_pk_fma(w[u], d1[u], acc1[u]); }
+    for (int s_ = 2; s_ <= C::DE; ++s_)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) eo[u] = wt_pk_horner(eo[u], zz[u], c.m[s_]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) w[u] = wt_pk_weights(eo[u], zz[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc0[u] = wt_pk_fma(w[u], d0[u], acc0[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc1[u] = wt_pk_fma(w[u], d1[u], acc1[u]);
   }
   wt_static_for<C::NG>([&](auto gg) {
     constexpr int g = decltype(gg)::value, pb = 2 * g + C::MID, pa = pb + 1;
-    f32x2 wp[NT], wm[NT], lo0[NT], hi0[NT], lo1[NT], hi1[NT];
+    f32x2 ee[NT], oo[NT], wp[NT], wm[NT], lo0[NT], hi0[NT], lo1[NT], hi1[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      f32x2 ee = c.e[g][0], oo = c.o[g][0];
-#pragma unroll
-      for (int s_ = 1; s_ <= C::DE; ++s_) ee = wt_pk_horner(ee, zz[u], c.e[g][s_]);
-#pragma unroll
-      for (int s_ = 1; s_ <= C::DO; ++s_) oo = wt_pk_horner(oo, zz[u], c.o[g][s_]);
-      wp[u] = wt_pk_plus(oo, zz[u], ee);                      // taps -pa, -pb
-      wm[u] = wt_pk_minus(oo, zz[u], ee);                     // taps 1 + pa, 1 + pb: the other way round in the row
-      lo0[u] = (f32x2){t[u][-pa], t[u][-pb]};
-      hi0[u] = (f32x2){t[u][1 + pb], t[u][1 + pa]};
+      lo0[u] = (f32x2){t[u][-pa], t[u][-pb]};                 // taps -pa, -pb
+      hi0[u] = (f32x2){t[u][1 + pb], t[u][1 + pa]};           // taps 1 + pb, 1 + pa: the other way round than their weights
       lo1[u] = (f32x2){t1[u][-pa], t1[u][-pb]};
       hi1[u] = (f32x2){t1[u][1 + pb], t1[u][1 + pa]};
+      ee[u] = wt_pk_horner(c.e[g][0], zz[u], c.e[g][1]);
     }
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      acc0[u] = wt_pk_fma(wp[u], lo0[u], acc0[u]);
-      acc1[u] = wt_pk_fma(wp[u], lo1[u], acc1[u]);
-      acc0[u] = wt_pk_fma_swap(wm[u], hi0[u], acc0[u]);
-      acc1[u] = wt_pk_fma_swap(wm[u], hi1[u], acc1[u]);
+    for (int u = 0; u < NT; ++u) oo[u] = wt_pk_horner(c.o[g][0], zz[u], c.o[g][1]);
+#pragma unroll
+    for (int s_ = 2; s_ <= C::DE; ++s_) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) ee[u] = wt_pk_horner(ee[u], zz[u], c.e[g][s_]);
+      if (s_ <= C::DO)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) oo[u] = wt_pk_horner(oo[u], zz[u], c.o[g][s_]);
     }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wp[u] = wt_pk_plus(oo[u], zz[u], ee[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wm[u] = wt_pk_minus(oo[u], zz[u], ee[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc0[u] = wt_pk_fma(wp[u], lo0[u], acc0[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc1[u] = wt_pk_fma(wp[u], lo1[u], acc1[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc0[u] = wt_pk_fma_swap(wm[u], hi0[u], acc0[u]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc1[u] = wt_pk_fma_swap(wm[u], hi1[u], acc1[u]);
   });
 }
 
-template <int W, int NK, bool ONE_TILE>
+template <int W, int NK, bool ONE_TILE, bool ADD>
 __global__ __launch_bounds__(1024) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, TableArgs p) {
@@ -597,10 +622,8 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       // Row pairs ("units": rows 2 u, 2 u + 1 of a chunk, 32 lanes per row, lane kq owns harmonics 4 kq + 1 .. + 4)
       // 4 (sw - 8) .. + 3 of chunk tick + 2, carried through the stages TOGETHER: a row is one long chain of dependent
       // instructions (exp, log, exp, the sum, 1 / sum, the split), and a wavefront issues one instruction per ~8 clocks
-      // only if it has independent ones to issue.  The rows come straight from HBM into registers; those of the NEXT
-      // tick's chunk are fetched at the end of a tick (plain loads: loop-carried values, the compiler keeps their wait
-      // count) - these wavefronts have no other work to hide a fetch behind.  Rows past the chunk's halo row are fetched
-      // (clamped) and worked on like the others: nobody reads their planes.
+      // only if it has independent ones to issue.  The rows come straight from HBM into registers (below).  Rows past the
+      // chunk's halo row are fetched (clamped) and worked on like the others: nobody reads their planes.
       constexpr int NU = 4;
       const int u0 = NU * (sw - 8);
       // per-lane constants: 1 / psi_hat(k), the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit:
@@ -612,15 +635,16 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         kf[u] = live ? (float)(4 * kq + u + 1) : 0.0f;
       }
       const float nyq_l = live ? p.nyquist : -1.0f;
-      ddsp_f32x4 lx[NU];
-      float lf0[NU];
+      // the rows of a chunk in registers: fetched at the top of the tick BEFORE the one that works on them (HBM has a whole
+      // tick to answer; fetched at the end of a tick, as in r03h, every tick of the block's slowest wavefronts began
+      // with the full latency: 41.0 -> 38.8 us), two sets used in turn (the tick loop is unrolled twice: no copies)
+      struct Rows { ddsp_f32x4 x[NU]; float f0[NU]; };
+      Rows rows_a, rows_b;
       // (addresses: the clip's first row as wave-uniform bases in scalar registers, the rest as 32-bit byte offsets - a
       // clip's F K floats are < 4 GB and F < 2^24, harm_table_ok: four vector instructions per row pair where 64-bit row
       // arithmetic took twelve)
       const unsigned kq16 = 16u * (unsigned)min(kq, K4 - 1), row_bytes = 4u * (unsigned)K;
-      ddsp_f32x4 lxn[NU];                           // the rows after those: in flight for a whole tick
-      float lf0n[NU];
-      auto prefetch = [&](const WtDesc& d) {
+      auto prefetch = [&](const WtDesc& d, Rows& r) {
         const size_t r0 = (size_t)d.b * (size_t)F;                               // (an empty descriptor: row 0 of clip 0)
         const char* __restrict__ hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
         const char* __restrict__ fb = reinterpret_cast<const char*>(f0_all) + r0 * 4;
@@ -628,13 +652,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         for (int i = 0; i < NU; ++i) {
           const unsigned jr = (unsigned)min(d.j0 + 2 * (u0 + i) + sub, F - 1);
           const float4 v = *reinterpret_cast<const float4*>(hb + (__umul24(jr, row_bytes) + kq16));   // F < 2^24
-          lxn[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
-          lf0n[i] = *reinterpret_cast<const float*>(fb + 4u * jr);
+          r.x[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+          r.f0[i] = *reinterpret_cast<const float*>(fb + 4u * jr);
         }
-      };
-      auto rows_arrive = [&]() {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) { lx[i] = lxn[i]; lf0[i] = lf0n[i]; }
       };
       // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
       // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
@@ -658,14 +678,14 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         const f32x2 y = __builtin_elementwise_fma(prod, (f32x2){-kHuge, -kHuge}, (f32x2){nyq_s, nyq_s});
         return (f32x2){__builtin_amdgcn_fmed3f(e[0], 0.0f, y[0]), __builtin_amdgcn_fmed3f(e[1], 0.0f, y[1])};
       };
-      auto phase_a = [&](const WtDesc& d, _Float16* planes) {
+      auto phase_a = [&](const WtDesc& d, _Float16* planes, const Rows& r) {
         const int nfr = d.nfr;
         f32x2 xo[NU], xe[NU];
         float part[NU], inv[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          xo[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][0], lx[i][2]}), lf0[i], kf_o);
-          xe[i] = nyq_mask2(exp_sigmoid2((f32x2){lx[i][1], lx[i][3]}), lf0[i], kf_e);
+          xo[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][0], r.x[i][2]}), r.f0[i], kf_o);
+          xe[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][1], r.x[i][3]}), r.f0[i], kf_e);
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) { const f32x2 h = xo[i] + xe[i]; part[i] = h[0] + h[1]; }
@@ -705,34 +725,31 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #pragma unroll
           for (int par = 0; par < 2; ++par) {
             const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par][0], c[par][1]);
-#ifdef DDSP_WT_OLD_SPLIT
-            const f32x2 rest = (c[par] - (f32x2){(float)hi[0], (float)hi[1]}) * kWtLoScale;
-            const h16x2 lo = __builtin_amdgcn_cvt_pkrtz(rest[0], rest[1]);
-#else
             const h16x2 lo = wt_rest_halves(c[par] * kWtLoScale, hi);
-#endif
             *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
             *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
           }
         }
       };
-      prefetch(dA);
-      rows_arrive();
-      for (int tick = -2;; ++tick) {
+      prefetch(dA, rows_a);
+      auto one_tick = [&](int tick, const Rows& cur, Rows& next) -> bool {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
         desc_take();
-        prefetch(dL);                              // the next tick's dA: a whole tick for HBM to answer
+        prefetch(dL, next);                        // the next tick's dA
         DDSP_WT_STAMP(1);
         DDSP_WT_STAMP(2);
-        if (dA.nfr > 0) phase_a(dA, planes_all[pa]);
-        rows_arrive();
+        if (dA.nfr > 0) phase_a(dA, planes_all[pa], cur);
         DDSP_WT_STAMP(3);
         __syncthreads();
         DDSP_WT_STAMP(4);
         dB = dM; dM = dA; dA = dL;
         { const int t3 = pb; pb = pm; pm = pa; pa = t3; }
-        if (tick + 1 >= 0 && dB.nfr == 0) break;
+        return tick + 1 >= 0 && dB.nfr == 0;
+      };
+      for (int tick = -2;; tick += 2) {
+        if (one_tick(tick, rows_a, rows_b)) break;
+        if (one_tick(tick + 1, rows_b, rows_a)) break;
       }
     } else {
       // =================== interpolators (S-wavefronts 0 .. 7): phase B, four tiles at a time ========================
@@ -755,6 +772,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           const float inv_hop = 1.0f / (float)hop;
           const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
           const int n_tiles = ONE_TILE ? nfr : nfr * (hop >> 6);
+          const size_t chunk0 = (size_t)row0 * (size_t)hop;
+          char* out_chunk = reinterpret_cast<char*>(audio + chunk0);          // (add_in may be this very buffer: no __restrict__)
+          const char* add_chunk = ADD ? reinterpret_cast<const char*>(add_in + chunk0) : nullptr;
           // NT tiles (tile, tile + 8, ..) move through the stages together: every stage of a tile is a chain of
           // dependent instructions - fp64 phase, LDS reads, the window polynomials
           auto tiles = [&](int tile, auto nt_tag) {
@@ -778,10 +798,13 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             }
             // processors.Add fused in (ddsp/processors.py:162-176): the other signal's samples, fetched now, added at the
             // store (add_in may be the output buffer itself: every element is read and written by the same lane)
+            // (a tile's samples are elements 64 tile + lane of the chunk, whatever the hop: a wave-uniform base and a
+            // 32-bit offset)
+            const unsigned o32 = 4u * (unsigned)(tile * 64 + lane);          // bytes
             float addv[kWtNT];
-            if (add_in != nullptr)
+            if (ADD)
 #pragma unroll
-              for (int u = 0; u < NT; ++u) addv[u] = add_in[(size_t)(row0 + q[u]) * hop + r[u]];
+              for (int u = 0; u < NT; ++u) addv[u] = *reinterpret_cast<const float*>(add_chunk + (o32 + 2048u * (unsigned)u));
             float theta[kWtNT];
             f32x2 zz[kWtNT];
             unsigned sgn[kWtNT];
@@ -793,10 +816,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               sgn[u] = __builtin_bit_cast(unsigned, hm) & 0x80000000u;
               const float th = 0.5f - fabsf(hm);                              // [0, 0.5]
               const float pos = fmaf(th, (float)kWtT, -0.5f);                 // table coordinate, [-0.5, 255.5]
-              const float fl = floorf(pos);
-              const float z = (pos - fl) - 0.5f;
+              const float z = __builtin_amdgcn_fractf(pos) - 0.5f;            // (v_fract_f32: pos - floor(pos), below 1)
               zz[u] = (f32x2){z, z * z};
-              t0[u] = tab + q[u] * kWtTS + kWtH + (int)fl;                    // (int)fl in [-1, 255]
+              t0[u] = tab + q[u] * kWtTS + kWtH + wt_floor_int(pos);          // floor(pos) in [-1, 255]
             }
             f32x2 acc0[kWtNT], acc1[kWtNT];
 #pragma unroll
@@ -835,11 +857,11 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
                 }
               }
             }
-            if (add_in != nullptr)
+            if (ADD)
 #pragma unroll
               for (int u = 0; u < NT; ++u) out[u] += addv[u];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) audio[(size_t)(row0 + q[u]) * hop + r[u]] = out[u];            // N == F * hop
+            for (int u = 0; u < NT; ++u) *reinterpret_cast<float*>(out_chunk + (o32 + 2048u * (unsigned)u)) = out[u];          // N == F * hop
           };
           for (int base = 0; base < n_tiles; base += kWtFrames) {
             const int left = min(n_tiles - base, kWtFrames);
@@ -916,20 +938,25 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
 #endif
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
+#define DDSP_LAUNCH_TABLE_(W, NK, ONE, ADD)                                                                     \
+  hipExtLaunchKernelGGL((harm_table_kernel<W, NK, ONE, ADD>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+                        audio, ctl_amp, ctl_hd, add_in, p)
 #define DDSP_LAUNCH_TABLE(W, NK)                                                                                \
   do {                                                                                                         \
-    if (p.hop == 64)                                                                                           \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, true>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, add_in, p);                                                                \
-    else                                                                                                       \
-      hipExtLaunchKernelGGL((harm_table_kernel<W, NK, false>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
-                            audio, ctl_amp, ctl_hd, add_in, p);                                                                \
+    if (p.hop == 64) {                                                                                         \
+      if (add_in != nullptr) DDSP_LAUNCH_TABLE_(W, NK, true, true);                                            \
+      else DDSP_LAUNCH_TABLE_(W, NK, true, false);                                                             \
+    } else {                                                                                                   \
+      if (add_in != nullptr) DDSP_LAUNCH_TABLE_(W, NK, false, true);                                           \
+      else DDSP_LAUNCH_TABLE_(W, NK, false, false);                                                            \
+    }                                                                                                          \
   } while (0)
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
   if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);
   else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
   else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
+#undef DDSP_LAUNCH_TABLE_
 #ifdef DDSP_WT_TIMELINE
   if (p.dbg) {
     static long long host[16 * 24 * 8];
