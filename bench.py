@@ -16,7 +16,7 @@ Workload (per GPU, weak scaling): the shape BASELINE.json's metric and target ar
 configs[1]'s clips: 4 s @ 16 kHz, F=1000 frames, K=100 harmonics (all below Nyquist: f0 = 70 + N(0,1) Hz), M=65
 noise bands.  configs[1] itself (batch 32) is timed the same way right after and reported as `configs_1`.
 
-Timing.  After W warm-up steps (and a clock-settle phase) the region "exactly K steps, barrier +
+Timing.  After W warm-up steps (and `--settle` seconds of untimed load: clock settle) the region "exactly K steps, barrier +
 torch.cuda.synchronize() on both sides" is run `--repeats` times (>= 10 by default).  Each region is timed
 twice: by the host clock around the bracket, and by HIP events recorded on the stream(s) at its first and after
 its last launch (the two-stream mode forks from / joins into the base stream with events).  `ms_per_step` and
@@ -59,6 +59,10 @@ def parse_args(argv=None):
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=1000)
   ap.add_argument('--warmup', type=int, default=500)   # ~20 ms of load: the GPU needs that long to reach its sustained clock (43 vs 37 us/step)
+  ap.add_argument('--settle', type=float, default=0.5,
+                  help='seconds of untimed load after the W warm-up steps and before the timed regions: a fresh box reaches '
+                       'its sustained clocks only after some tenths of a second (r03p: the same kernels 4 %% slower in a process '
+                       'that timed its 20-step regions 50 ms after its first launch)')
   ap.add_argument('--repeats', type=int, default=0,
                   help='timed regions of K steps each (0: at least 10, more when a region is short, so that '
                        'about 0.1 s is measured in all); the median is reported')
@@ -523,7 +527,7 @@ def main(argv=None):
     step()
   if not dry:
     torch.cuda.synchronize()
-  settle(step, 0.05 if not dry else 0.0)
+  settle(step, a.settle if not dry else 0.0)
 
   # diagnostic pass (untimed, one stream so every kernel runs alone): every kernel bracketed, to
   # find the dominant one and give the isolated per-kernel times
