@@ -2,7 +2,7 @@
 gfx950 instruction stream hipcc emits for the default instantiation (K = 100, hop 64), priced with the issue costs
 measured on the MI355X (profiles/r03a_microbench_issue_cost_by_class.txt, r03b_microbench_issue_cost_second_pass.txt:
 clocks per instruction AS ONE WAVEFRONT SEES IT with four wavefronts per SIMD - the kernel's occupancy), against the
-measured length of that role's part of a tick (profiles/r03h_timeline_wt16_v5_packed_phase_a.txt).
+measured length of that role's part of a tick (profiles/r03q_timeline_final.txt).
 
 A wavefront is in-order: the length of its tick is the sum of what its instructions cost it.  The tick of the block is
 its slowest wavefront's; the SIMD-side view (clocks of SIMD time = wave price / 4) says how full the issue ports are.
@@ -36,11 +36,11 @@ PRICE = {
     'mfma': 16.7,         # v_mfma_f32_16x16x32_f16, one wavefront per SIMD issuing them (the T role): the pipe's 16.5 clocks
     'barrier': 0.0,
 }
-MEASURED = {              # clocks per tick, median of the middle ticks of profiles/r03h_timeline_wt16_v5_packed_phase_a.txt
-    'T (tabulator, wavefronts 0-2)': (2400 + 360, 'mfma+table 2150-2800, descriptor / barrier bookkeeping ~360'),
-    'T3 (+ phase tables)': (2400 + 1070, 'mfma+table 2400, phase tables 1070'),
-    'B (interpolator, 4 tiles)': (3250 + 120 + 105, 'phase B 2900-3520, top 110-150, end 105'),
-    'A (row maker, 4 row pairs)': (3940 + 190 + 140, 'phase A + prefetch 3770-4070, top 145-220, end'),
+MEASURED = {              # clocks per tick, median of the middle ticks of profiles/r03q_timeline_final.txt
+    'T (tabulator, wavefronts 0-2)': (2800 + 630, 'mfma+table 2790-3200, amplitudes / descriptors / barrier bookkeeping 340-650'),
+    'T3 (+ phase tables)': (3100 + 1090, 'mfma+table 3100, phase tables 1090'),
+    'B (interpolator, 4 tiles)': (3050 + 150 + 105, 'phase B 2440-3360, top 120-200, end 105'),
+    'A (row maker, 4 row pairs)': (2750 + 950 + 60, 'phase A 2500-3060, descriptor + next rows issued 770-1130 (starved at the top of the tick: the youngest wavefronts)'),
 }
 
 
@@ -119,8 +119,7 @@ def main():
   b_store = next(b for b in blocks if nb(b, 'global_store') == 3 and len(b) < 40)      # its stores (the fourth rides in the block above)
   a_main = [b for b in blocks if nb(b, 'v_exp_f32') >= 32][-1]                          # phase A, four row pairs (the rotated loop body)
   a_write = [b for b in blocks if nb(b, 'ds_write') == 8 and len(b) > 60][-1]           # the splits and plane writes
-  a_fetch = [b for b in blocks if nb(b, 'global_load') == 8 and len(b) < 60][-1]          # the top of a tick: the descriptor, the rows of the tick after
-  a_end = [b for b in blocks if nb(b, 's_barrier') == 1 and nb(b, 'v_mov_b32') >= 16][-1]  # those rows have arrived: into this tick's registers, the barrier
+  a_fetch = [b for b in blocks if nb(b, 'global_load') == 8 and len(b) < 75][-1]          # the top of a tick: the descriptor, the rows of the tick after
   t_mfma = [b for b in blocks if nb(b, 'v_mfma') == 24]                                 # two row tiles
   t_tables = max((b for b in blocks if nb(b, 'v_fma_f64') + nb(b, 'v_add_f64') + nb(b, 'v_mul_f64') >= 6 and nb(b, 'ds_read2_b32') == 0), key=len)
   loop_glue = 45          # per tick and wavefront: descriptor read / take (4 v_readfirstlane), the shifts, the dispatch on the tile count
@@ -128,11 +127,11 @@ def main():
       'T (tabulator, wavefronts 0-2)': [t_mfma[0], t_mfma[1], ['s_add_u32'] * loop_glue],
       'T3 (+ phase tables)': [t_mfma[0], t_mfma[1], t_tables, ['s_add_u32'] * loop_glue],
       'B (interpolator, 4 tiles)': [b_tiles, b_store, ['s_add_u32'] * loop_glue],
-      'A (row maker, 4 row pairs)': [a_fetch, a_main, a_write, a_end, ['s_add_u32'] * (loop_glue - 20)],
+      'A (row maker, 4 row pairs)': [a_fetch, a_main, a_write, ['s_add_u32'] * (loop_glue - 20)],
   }
   classes = list(PRICE)
   print('harm_table_kernel<6, 2, true, false> (K = 100, hop 64): instructions per tick and wavefront, by class; price = clocks as ONE wavefront')
-  print('sees them at four wavefronts per SIMD (profiles/r03a_*, r03b_*); predicted = sum; measured = its part of the tick (profiles/r03h_*)')
+  print('sees them at four wavefronts per SIMD (profiles/r03a_*, r03b_*); predicted = sum; measured = its part of the tick (profiles/r03q_*)')
   print()
   print('%-32s' % 'role' + ''.join('%9s' % c for c in classes if c != 'barrier') + '   total  predicted  measured   ratio')
   print('%-32s' % 'price (clocks / instruction)' + ''.join('%9.1f' % PRICE[c] for c in classes if c != 'barrier'))
@@ -150,10 +149,12 @@ def main():
   print()
   print('SIMD view: sum over the 16 wavefronts of predicted / 4 = %.0f clocks of issue time per tick on the 4 SIMDs = %.0f per SIMD;'
         % (simd_time, simd_time / 4))
-  print('the tick is ~4600 clocks (40.6 us / 19 ticks at ~2.15 GHz, batch 128): the SIMDs issue %.0f %% of the time, the longest role'
-        % (100 * simd_time / 4 / 4600))
-  print('(the row makers) sets the tick; what separates the two is the imbalance between roles (interpolators wait ~1000 clocks')
-  print('at the barrier, tabulators ~1700) and the two fill ticks of the 19.')
+  print('the tick is ~4300 clocks (37.7 us / 19 ticks, batch 128; 4950 with the stamps of the timeline build): the SIMDs issue %.0f %% of'
+        % (100 * simd_time / 4 / 4300))
+  print('the time.  A wavefront is not bound by its own instruction count any more (r03o: 20 % fewer row-maker instructions, 9 % fewer')
+  print('interpolator instructions: 1.7 % of the kernel): the SIMD serves its four wavefronts oldest first, the row makers (the')
+  print('youngest) get what is left and arrive last; what a role costs the kernel is its ablation (profiles/r03o_ablation_roles.txt:')
+  print('tabulators 7.6 us, interpolators 8.9, row makers 4.2 of 37.9), not its share of the instructions.')
 
 
 if __name__ == '__main__':

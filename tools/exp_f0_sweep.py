@@ -21,8 +21,13 @@ for B in batches:
   for f0c in F0S:
     f0 = ddsp.core.tf_float32(f0c + rng.standard_normal((B, F, 1)))
     synth = ddsp.synths.Harmonic(n_samples=N)
-    for _ in range(30): synth(amps, hd, f0)
-    torch.cuda.synchronize()
+    synth.kernel = os.environ.get('DDSP_SWEEP_KERNEL', 'auto')
+    # (clock settle: a box reaches its sustained clocks after tenths of a second of load - without it the first f0 of
+    # the list is measured 25 % slow, r03q)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < (0.5 if f0c == F0S[0] else 0.1):
+      for _ in range(30): synth(amps, hd, f0)
+      torch.cuda.synchronize()
     _lib.profile_begin(None, max_records=512)
     for _ in range(50): synth(amps, hd, f0)
     torch.cuda.synchronize()
