@@ -770,6 +770,13 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   const dim3 grid((unsigned)(p.n_units < max_blocks ? p.n_units : max_blocks)), block(256);
   static std::atomic<unsigned> ticket{0};
   p.sched_set = (int)(ticket.fetch_add(1u) % (unsigned)kSchedSets);
+  // A set may only be handed out again when the launch that had it last is done: launches on ONE stream are, by stream
+  // order; with more than kSchedSets streams in flight the new launch waits for the set's last user (an event per set,
+  // recorded behind every launch: ~1 us of host time on a path that is not the default one).
+  static hipEvent_t set_done[kSchedSets];
+  static std::atomic<int> set_state[kSchedSets];            // 0: never used, 1: event exists and was recorded
+  if (set_state[p.sched_set].load(std::memory_order_acquire) == 1)
+    (void)hipStreamWaitEvent(st, set_done[p.sched_set], 0);
   // STD: the flag combination of Harmonic.__call__ with default arguments, compiled in
   const bool std_flags = (flags & DDSP_HARM_SCALE_EXP_SIGMOID) && (flags & DDSP_HARM_NORMALIZE_NYQUIST) &&
                          !inputs_are_controls && !ctl_amp && !ctl_hd && (flags >> 24) == 0;
@@ -794,6 +801,11 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   else return DDSP_ERR_UNSUPPORTED;
 #undef DDSP_LAUNCH_FUSED_LPR
 #undef DDSP_LAUNCH_FUSED
+  if (set_state[p.sched_set].load(std::memory_order_acquire) == 0 &&
+      hipEventCreateWithFlags(&set_done[p.sched_set], hipEventDisableTiming) != hipSuccess)
+    return DDSP_ERR_LAUNCH;
+  if (hipEventRecord(set_done[p.sched_set], st) != hipSuccess) return DDSP_ERR_LAUNCH;
+  set_state[p.sched_set].store(1, std::memory_order_release);
   return check_launch();
 }
 // fused path: hop a multiple of 64, K a multiple of 4 (16-byte rows), caller buffers 16-byte aligned
