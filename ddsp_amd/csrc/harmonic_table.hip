@@ -135,6 +135,7 @@ struct TableArgs {
   FastDiv f_div, tpf_div;        // F; hop / 64
   float nyquist, nyq_lo, nyq_hi;
   int amp_linear;
+  int rows16;          // rows of hd (and of the controls out) are 16 bytes apart and aligned: K % 4 == 0, aligned bases
   double inv_sr, inv_2hop, hop_d, half_hm1;
   long long* dbg;      // DDSP_EXP_TABLE_TIMELINE=1: shader-clock stamps of block 0, [wavefront][tick + 2][stamp]; or null
 };
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_t = wave < 4;
   const int F = p.F, K = p.K;
-  const int K4 = K >> 2;
+  const int K4 = (K + 3) >> 2;                    // lanes of a row with a harmonic to their name (any K <= 128)
   const float kLog10 = 2.302585092994046f;       // tf.math.log(exponent), ddsp/core.py:403
   const int sub = lane >> 5, kq = lane & 31;     // phase A: 32 lanes per row, lane kq owns harmonics 4 kq + 1 .. 4 kq + 4
   const bool live = kq < K4;
@@ -628,13 +629,14 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       const int u0 = NU * (sw - 8);
       // per-lane constants: 1 / psi_hat(k), the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit:
       // always masked)
-      float ipsi[4], kf[4];
+      float ipsi[4], kf[4], nyq_u[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ipsi[u] = live ? WtPoly<W>::invpsi(4 * kq + u + 1) : 0.0f;
-        kf[u] = live ? (float)(4 * kq + u + 1) : 0.0f;
+        const bool alive = 4 * kq + u + 1 <= K;              // (K need not be a multiple of 4: the last lane's tail is dead)
+        ipsi[u] = alive ? WtPoly<W>::invpsi(min(4 * kq + u + 1, 128)) : 0.0f;
+        kf[u] = alive ? (float)(4 * kq + u + 1) : 0.0f;
+        nyq_u[u] = alive ? p.nyquist : -1.0f;
       }
-      const float nyq_l = live ? p.nyquist : -1.0f;
       // the rows of a chunk in registers: fetched at the top of the tick BEFORE the one that works on them (HBM has a whole
       // tick to answer; fetched at the end of a tick, as in r03h, every tick of the block's slowest wavefronts began
       // with the full latency: 41.0 -> 38.8 us), two sets used in turn (the tick loop is unrolled twice: no copies)
@@ -644,6 +646,10 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       // clip's F K floats are < 4 GB and F < 2^24, harm_table_ok: four vector instructions per row pair where 64-bit row
       // arithmetic took twelve)
       const unsigned kq16 = 16u * (unsigned)min(kq, K4 - 1), row_bytes = 4u * (unsigned)K;
+      // rows that are not 16-byte aligned (K % 4 != 0, or an odd base): four 4-byte loads per lane, the tail clamped
+      unsigned ku4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ku4[u] = 4u * (unsigned)min(4 * kq + u, K - 1);
       auto prefetch = [&](const WtDesc& d, Rows& r) {
         const size_t r0 = (size_t)d.b * (size_t)F;                               // (an empty descriptor: row 0 of clip 0)
         const char* __restrict__ hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
@@ -651,8 +657,14 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
           const unsigned jr = (unsigned)min(d.j0 + 2 * (u0 + i) + sub, F - 1);
-          const float4 v = *reinterpret_cast<const float4*>(hb + (__umul24(jr, row_bytes) + kq16));   // F < 2^24
-          r.x[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+          const unsigned ro = __umul24(jr, row_bytes);                                                // F < 2^24
+          if (p.rows16) {
+            const float4 v = *reinterpret_cast<const float4*>(hb + (ro + kq16));
+            r.x[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+          } else {
+            r.x[i] = (ddsp_f32x4){*reinterpret_cast<const float*>(hb + (ro + ku4[0])), *reinterpret_cast<const float*>(hb + (ro + ku4[1])),
+                                  *reinterpret_cast<const float*>(hb + (ro + ku4[2])), *reinterpret_cast<const float*>(hb + (ro + ku4[3]))};
+          }
           r.f0[i] = *reinterpret_cast<const float*>(fb + 4u * jr);
         }
       };
@@ -671,11 +683,12 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       };
       // e > 0: kept iff fl32(f0 k) < nyquist: median(e, 0, (nyquist - fl32(f0 k)) 2^100) - the scaled difference is one
       // FMA of exact products: 0 or >= 2^76 in magnitude, its sign the comparison's
-      const float kHuge = 0x1p100f, nyq_s = nyq_l * kHuge;
-      auto nyq_mask2 = [&](f32x2 e, float f0r, f32x2 kfp) -> f32x2 {
+      const float kHuge = 0x1p100f;
+      const f32x2 nyq_o = {nyq_u[0] * kHuge, nyq_u[2] * kHuge}, nyq_e = {nyq_u[1] * kHuge, nyq_u[3] * kHuge};
+      auto nyq_mask2 = [&](f32x2 e, float f0r, f32x2 kfp, f32x2 nyq_s) -> f32x2 {
         f32x2 prod;
         { _Pragma("clang fp contract(off)") prod = kfp * f0r; }
-        const f32x2 y = __builtin_elementwise_fma(prod, (f32x2){-kHuge, -kHuge}, (f32x2){nyq_s, nyq_s});
+        const f32x2 y = __builtin_elementwise_fma(prod, (f32x2){-kHuge, -kHuge}, nyq_s);
         return (f32x2){__builtin_amdgcn_fmed3f(e[0], 0.0f, y[0]), __builtin_amdgcn_fmed3f(e[1], 0.0f, y[1])};
       };
       auto phase_a = [&](const WtDesc& d, _Float16* planes, const Rows& r) {
@@ -684,8 +697,8 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         float part[NU], inv[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          xo[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][0], r.x[i][2]}), r.f0[i], kf_o);
-          xe[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][1], r.x[i][3]}), r.f0[i], kf_e);
+          xo[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][0], r.x[i][2]}), r.f0[i], kf_o, nyq_o);
+          xe[i] = nyq_mask2(exp_sigmoid2((f32x2){r.x[i][1], r.x[i][3]}), r.f0[i], kf_e, nyq_e);
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) { const f32x2 h = xo[i] + xe[i]; part[i] = h[0] + h[1]; }
@@ -712,7 +725,15 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             const int crow = d.b * F + d.j0 + arow;        // this lane's (batch * frame) row, if arow < nfr
             if (arow < nfr) {
               const f32x2 ho = xo[i] * inv[i], he = xe[i] * inv[i];
-              if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(ho[0], he[0], ho[1], he[1]);
+              if (p.rows16) {
+                if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(ho[0], he[0], ho[1], he[1]);
+              } else {
+                float* __restrict__ crow_p = ctl_hd + (size_t)crow * K + 4 * kq;
+                const float h4[4] = {ho[0], he[0], ho[1], he[1]};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  if (4 * kq + u < K) crow_p[u] = h4[u];
+              }
             }
           }
         }
@@ -891,8 +912,8 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
   if (flags & DDSP_HARM_DIRECT_SUM) return false;
   if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
   if (inputs_are_controls || (ctl_amp == nullptr) != (ctl_hd == nullptr) || (flags >> 24) != 0) return false;
-  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 4 && K <= 128 && (K % 4) == 0 && F < (1 << 24) &&
-         (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0;
+  (void)hd;
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 1 && K <= 128 && F < (1 << 24);
 }
 
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
@@ -908,6 +929,7 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
   p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
+  p.rows16 = ((K & 3) == 0 && (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0) ? 1 : 0;
   p.inv_sr = 1.0 / (double)sample_rate;
   p.inv_2hop = 0.5 / (double)p.hop;
   p.hop_d = (double)p.hop;
