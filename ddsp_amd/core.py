@@ -162,6 +162,99 @@ def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7):
   return out
 
 
+def safe_divide(numerator, denominator, eps=1e-7):
+  """core.safe_divide (ddsp/core.py:207-210): numerator / where(denominator == 0, eps, denominator).
+
+  The shapes are broadcast the way TF would; a denominator that only broadcasts along the last axis ([..., 1], what
+  normalize_harmonics passes) is read in place."""
+  numerator, denominator = tf_float32(numerator), tf_float32(denominator)
+  require_no_grad('core.safe_divide', numerator, denominator)
+  shape = torch.broadcast_shapes(numerator.shape, denominator.shape)
+  num = numerator.expand(shape).contiguous()
+  if len(shape) == 0:
+    num, den_cols, den = num.reshape(1, 1), 1, denominator.reshape(1, 1).contiguous()
+  elif denominator.dim() == len(shape) and tuple(denominator.shape[:-1]) == tuple(shape[:-1]) and denominator.shape[-1] == 1 \
+      and shape[-1] != 1:
+    den_cols, den = 1, denominator.contiguous()
+  else:
+    den_cols, den = int(shape[-1]), denominator.expand(shape).contiguous()
+  cols = int(shape[-1]) if len(shape) else 1
+  out = torch.empty(shape, dtype=torch.float32, device=num.device)
+  rc = _lib.load().ddsp_safe_divide_f32(num.data_ptr(), den.data_ptr(), out.data_ptr(), num.numel() // max(cols, 1), cols,
+                                        den_cols, float(eps), _stream())
+  _lib.check(rc, 'ddsp_safe_divide_f32')
+  return out
+
+
+def safe_log(x, eps=1e-5):
+  """core.safe_log (ddsp/core.py:213-216): log of x, non-positive entries replaced by eps first."""
+  x = tf_float32(x).contiguous()
+  require_no_grad('core.safe_log', x)
+  out = torch.empty_like(x)
+  rc = _lib.load().ddsp_safe_log_f32(x.data_ptr(), out.data_ptr(), x.numel(), float(eps), _stream())
+  _lib.check(rc, 'ddsp_safe_log_f32')
+  return out
+
+
+def get_harmonic_frequencies(frequencies, n_harmonics):
+  """core.get_harmonic_frequencies (ddsp/core.py:1028-1045): [batch, :, 1] fundamentals -> [batch, :, n_harmonics]."""
+  frequencies = tf_float32(frequencies).contiguous()
+  require_no_grad('core.get_harmonic_frequencies', frequencies)
+  if frequencies.dim() < 1 or frequencies.shape[-1] != 1:
+    raise ValueError('frequencies must be [batch_size, :, 1], got {}'.format(tuple(frequencies.shape)))
+  k = int(n_harmonics)
+  out = torch.empty(tuple(frequencies.shape[:-1]) + (k,), dtype=torch.float32, device=frequencies.device)
+  rc = _lib.load().ddsp_harmonic_frequencies_f32(frequencies.data_ptr(), out.data_ptr(), frequencies.numel(), k, _stream())
+  _lib.check(rc, 'ddsp_harmonic_frequencies_f32')
+  return out
+
+
+def remove_above_nyquist(frequency_envelopes, amplitude_envelopes, sample_rate=16000):
+  """core.remove_above_nyquist (ddsp/core.py:869-891): amplitudes of oscillators at or above sample_rate / 2 set to 0."""
+  frequency_envelopes, amplitude_envelopes = tf_float32(frequency_envelopes), tf_float32(amplitude_envelopes)
+  require_no_grad('core.remove_above_nyquist', frequency_envelopes, amplitude_envelopes)
+  shape = torch.broadcast_shapes(frequency_envelopes.shape, amplitude_envelopes.shape)
+  f = frequency_envelopes.expand(shape).contiguous()
+  a = amplitude_envelopes.expand(shape).contiguous()
+  out = torch.empty(shape, dtype=torch.float32, device=a.device)
+  rc = _lib.load().ddsp_remove_above_nyquist_f32(f.data_ptr(), a.data_ptr(), out.data_ptr(), a.numel(), int(sample_rate),
+                                                 _stream())
+  _lib.check(rc, 'ddsp_remove_above_nyquist_f32')
+  return out
+
+
+def angular_cumsum(angular_frequency, chunk_size=1000):
+  """core.angular_cumsum (ddsp/core.py:800-866): the accumulated phase in [0, 2 pi), shape [batch, time, ...].
+
+  The scan runs in fp64 revolutions on chip (sums per chunk of 256 samples, a wrapped prefix over the chunks, the
+  running phase inside each): `chunk_size` - the reference's guard against fp32 accumulation error - is accepted and has
+  nothing to control; the result is the exactly accumulated phase rounded to fp32, where the reference's fp32 chunks are
+  ~1e-4 rad off after a 4 s clip.  Axis 0 is the batch and axis 1 time, as the reference's code has it; a 1-D input is
+  taken as one clip."""
+  del chunk_size
+  w = tf_float32(angular_frequency)
+  require_no_grad('core.angular_cumsum', w)
+  if w.dim() < 1:
+    raise ValueError('angular_frequency must be [batch, time, ...], got a scalar')
+  squeeze = w.dim() == 1
+  if squeeze:
+    w = w[None]
+  shape = tuple(w.shape)
+  b, t = shape[0], shape[1]
+  c = 1
+  for d in shape[2:]:
+    c *= int(d)
+  w = w.contiguous()
+  out = torch.empty(shape, dtype=torch.float32, device=w.device)
+  if w.numel() == 0:
+    return out[0] if squeeze else out
+  lib = _lib.load()
+  ws = _default_ws.get(lib.ddsp_angular_cumsum_workspace_bytes(b, t, c), w.device)
+  rc = lib.ddsp_angular_cumsum_f32(w.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), b, t, c, _stream())
+  _lib.check(rc, 'ddsp_angular_cumsum_f32')
+  return out[0] if squeeze else out
+
+
 # --------------------------------------------------------------------------------------
 # resampling  (ddsp/core.py:573-714) - stand-alone; the synths evaluate it on the fly
 # --------------------------------------------------------------------------------------

@@ -636,6 +636,141 @@ extern "C" int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* de
   return check_launch();
 }
 
+// ---- small stand-alone pieces of ddsp/core.py that the synths only use fused: callable on their own for drop-in completeness ----
+namespace ddsp {
+namespace general {
+// core.safe_divide (ddsp/core.py:207-210): numerator [rows, C], denominator [rows, C] or [rows, 1] (den_cols = 1)
+__global__ __launch_bounds__(kThreads) void safe_divide_kernel(const float* __restrict__ num, const float* __restrict__ den,
+                                                               float* __restrict__ out, size_t n, int C, int den_cols, float eps) {
+  for (size_t i = global_thread(); i < n; i += grid_threads()) {
+    const float d = den[den_cols == 1 ? i / (size_t)C : i];
+    out[i] = num[i] / (d == 0.0f ? eps : d);
+  }
+}
+// core.safe_log (ddsp/core.py:213-216)
+__global__ __launch_bounds__(kThreads) void safe_log_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n, float eps) {
+  for (size_t i = global_thread(); i < n; i += grid_threads()) {
+    const float v = x[i];
+    out[i] = logf(v <= 0.0f ? eps : v);
+  }
+}
+// core.get_harmonic_frequencies (ddsp/core.py:1028-1045): out[r, k] = fl32(f[r] (k + 1))
+__global__ __launch_bounds__(kThreads) void harmonic_frequencies_kernel(const float* __restrict__ f, float* __restrict__ out,
+                                                                        size_t rows, int K) {
+  const size_t n = rows * (size_t)K;
+  for (size_t i = global_thread(); i < n; i += grid_threads()) {
+    const size_t r = i / (size_t)K;
+    out[i] = rn_mul(f[r], (float)((int)(i - r * (size_t)K) + 1));
+  }
+}
+// core.remove_above_nyquist (ddsp/core.py:869-891)
+__global__ __launch_bounds__(kThreads) void remove_above_nyquist_kernel(const float* __restrict__ freq, const float* __restrict__ amp,
+                                                                        float* __restrict__ out, size_t n, float nyquist) {
+  for (size_t i = global_thread(); i < n; i += grid_threads()) out[i] = freq[i] >= nyquist ? 0.0f : amp[i];
+}
+// core.angular_cumsum (ddsp/core.py:800-866) on [B, T, C]: the phase in [0, 2 pi).  fp64 revolutions, chunks of 256 samples:
+// sums per chunk, an exclusive wrapped prefix over the chunks, then the running phase inside each chunk - exact to ~1e-13
+// revolutions for any length (the reference's fp32 chunks of `chunk_size` drift by ~1e-4 rad over a 4 s clip).
+constexpr int kAngChunk = 256;
+__global__ __launch_bounds__(kThreads) void ang_chunk_sums_kernel(const float* __restrict__ w, double* __restrict__ sums, int T, int C,
+                                                                  int n_chunks) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kAngChunk, t1 = min(t0 + kAngChunk, T);
+  const float* __restrict__ wb = w + (size_t)b * T * C;
+  for (int k = threadIdx.x; k < C; k += kThreads) {
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) s += (double)wb[(size_t)t * C + k];
+    sums[((size_t)b * n_chunks + c) * C + k] = s;
+  }
+}
+__global__ __launch_bounds__(kThreads) void ang_prefix_kernel(double* __restrict__ sums, int C, int n_chunks) {
+  const int b = blockIdx.y, k = blockIdx.x * kThreads + threadIdx.x;
+  if (k >= C) return;
+  const double inv_two_pi = 0.15915494309189535;
+  double run = 0.0;                                   // revolutions, wrapped
+  for (int c = 0; c < n_chunks; ++c) {
+    double* p = sums + ((size_t)b * n_chunks + c) * C + k;
+    const double s = *p * inv_two_pi;
+    *p = run;
+    run += s;
+    run -= floor(run);
+  }
+}
+__global__ __launch_bounds__(kThreads) void ang_apply_kernel(const float* __restrict__ w, const double* __restrict__ offs,
+                                                             float* __restrict__ out, int T, int C, int n_chunks) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kAngChunk, t1 = min(t0 + kAngChunk, T);
+  const double inv_two_pi = 0.15915494309189535, two_pi = 6.283185307179586;
+  const float* __restrict__ wb = w + (size_t)b * T * C;
+  float* __restrict__ ob = out + (size_t)b * T * C;
+  for (int k = threadIdx.x; k < C; k += kThreads) {
+    double ph = offs[((size_t)b * n_chunks + c) * C + k];
+    for (int t = t0; t < t1; ++t) {
+      ph += (double)wb[(size_t)t * C + k] * inv_two_pi;
+      ph -= floor(ph);
+      ob[(size_t)t * C + k] = (float)(ph * two_pi);
+    }
+  }
+}
+}  // namespace general
+}  // namespace ddsp
+
+extern "C" int ddsp_safe_divide_f32(const float* numerator, const float* denominator, float* out, size_t rows, int C,
+                                    int den_cols, float eps, void* stream) {
+  if (!numerator || !denominator || !out) return DDSP_ERR_NULL_POINTER;
+  if (C <= 0 || (den_cols != 1 && den_cols != C)) return DDSP_ERR_BAD_SHAPE;
+  if (rows == 0) return DDSP_OK;
+  hipLaunchKernelGGL(safe_divide_kernel, dim3(grid_for(rows * (size_t)C)), dim3(kThreads), 0, (hipStream_t)stream, numerator,
+                     denominator, out, rows * (size_t)C, C, den_cols, eps);
+  return check_launch();
+}
+
+extern "C" int ddsp_safe_log_f32(const float* x, float* out, size_t n, float eps, void* stream) {
+  if (!x || !out) return DDSP_ERR_NULL_POINTER;
+  if (n == 0) return DDSP_OK;
+  hipLaunchKernelGGL(safe_log_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, x, out, n, eps);
+  return check_launch();
+}
+
+extern "C" int ddsp_harmonic_frequencies_f32(const float* frequencies, float* out, size_t rows, int n_harmonics, void* stream) {
+  if (!frequencies || !out) return DDSP_ERR_NULL_POINTER;
+  if (n_harmonics <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (rows == 0) return DDSP_OK;
+  hipLaunchKernelGGL(harmonic_frequencies_kernel, dim3(grid_for(rows * (size_t)n_harmonics)), dim3(kThreads), 0,
+                     (hipStream_t)stream, frequencies, out, rows, n_harmonics);
+  return check_launch();
+}
+
+extern "C" int ddsp_remove_above_nyquist_f32(const float* frequency_envelopes, const float* amplitude_envelopes, float* out,
+                                             size_t n, int sample_rate, void* stream) {
+  if (!frequency_envelopes || !amplitude_envelopes || !out) return DDSP_ERR_NULL_POINTER;
+  if (sample_rate <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (n == 0) return DDSP_OK;
+  hipLaunchKernelGGL(remove_above_nyquist_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                     frequency_envelopes, amplitude_envelopes, out, n, (float)(sample_rate / 2.0));
+  return check_launch();
+}
+
+extern "C" size_t ddsp_angular_cumsum_workspace_bytes(int B, int T, int C) {
+  if (B <= 0 || T <= 0 || C <= 0) return 0;
+  return (size_t)B * ((T + kAngChunk - 1) / kAngChunk) * C * sizeof(double);
+}
+
+extern "C" int ddsp_angular_cumsum_f32(const float* angular_frequency, float* out, void* workspace, size_t workspace_bytes,
+                                       int B, int T, int C, void* stream) {
+  if (!angular_frequency || !out || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || C <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_angular_cumsum_workspace_bytes(B, T, C) || ((uintptr_t)workspace & 7)) return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_chunks = (T + kAngChunk - 1) / kAngChunk;
+  double* sums = (double*)workspace;
+  hipLaunchKernelGGL(ang_chunk_sums_kernel, dim3(n_chunks, B), dim3(kThreads), 0, st, angular_frequency, sums, T, C, n_chunks);
+  hipLaunchKernelGGL(ang_prefix_kernel, dim3((C + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, sums, C, n_chunks);
+  hipLaunchKernelGGL(ang_apply_kernel, dim3(n_chunks, B), dim3(kThreads), 0, st, angular_frequency, (const double*)sums, out, T, C,
+                     n_chunks);
+  return check_launch();
+}
+
 extern "C" int ddsp_sigmoid_f32(const float* in, float* out, size_t n, void* stream) {
   if (!in || !out) return DDSP_ERR_NULL_POINTER;
   if (n == 0) return DDSP_OK;

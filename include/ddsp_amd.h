@@ -431,6 +431,30 @@ int ddsp_sigmoid_f32(const float* in, float* out, size_t n, void* stream);
 int ddsp_mix_f32(const float* signal_one, const float* signal_two, const float* mix_level, float* out,
                  size_t rows, int C, void* stream);
 
+/* Small pieces of ddsp/core.py that the synths only use fused inside their kernels, callable on their own (the reference
+ * exports them; nothing on the hot path calls these):
+ *   ddsp_safe_divide_f32           core.safe_divide (ddsp/core.py:207-210): out = numerator / where(denominator == 0, eps,
+ *                                  denominator); numerator, out [rows, C]; denominator [rows, den_cols], den_cols = C or 1;
+ *   ddsp_safe_log_f32              core.safe_log (:213-216): log(where(x <= 0, eps, x));
+ *   ddsp_harmonic_frequencies_f32  core.get_harmonic_frequencies (:1028-1045): frequencies [rows] -> out [rows, n_harmonics],
+ *                                  out[r][k] = fl32(frequencies[r] * (k + 1));
+ *   ddsp_remove_above_nyquist_f32  core.remove_above_nyquist (:869-891): out = where(frequency >= sample_rate / 2, 0,
+ *                                  amplitude) on n values (same shape);
+ *   ddsp_angular_cumsum_f32        core.angular_cumsum (:800-866): angular_frequency [B, T, C] (radians per sample) -> the
+ *                                  accumulated phase in [0, 2 pi), [B, T, C].  The scan runs in fp64 revolutions (chunk sums,
+ *                                  wrapped prefix, running phase): the reference's `chunk_size` has no counterpart - the
+ *                                  result is exact to fp32 rounding for any length, where the reference's fp32 chunks drift.
+ *                                  workspace: ddsp_angular_cumsum_workspace_bytes(B, T, C), 8-byte aligned. */
+int ddsp_safe_divide_f32(const float* numerator, const float* denominator, float* out, size_t rows, int C,
+                         int den_cols, float eps, void* stream);
+int ddsp_safe_log_f32(const float* x, float* out, size_t n, float eps, void* stream);
+int ddsp_harmonic_frequencies_f32(const float* frequencies, float* out, size_t rows, int n_harmonics, void* stream);
+int ddsp_remove_above_nyquist_f32(const float* frequency_envelopes, const float* amplitude_envelopes, float* out,
+                                  size_t n, int sample_rate, void* stream);
+size_t ddsp_angular_cumsum_workspace_bytes(int B, int T, int C);
+int ddsp_angular_cumsum_f32(const float* angular_frequency, float* out, void* workspace, size_t workspace_bytes,
+                            int B, int T, int C, void* stream);
+
 /* core.exp_sigmoid (ddsp/core.py:386-404), elementwise on n values (in may equal out). */
 int ddsp_exp_sigmoid_f32(const float* in, float* out, size_t n, float exponent,
                          float max_value, float threshold, void* stream);

@@ -285,6 +285,48 @@ def test_exp_decay_reverb_reference_tests_and_gradients(ddsp):
   parity_check(npy(td.grad), ref_d, 2e-4 * np.abs(ref_d).max())
 
 
+# ---- core.safe_divide / safe_log / get_harmonic_frequencies / remove_above_nyquist / angular_cumsum as functions --------
+def test_small_core_functions_standalone(ddsp):
+  """The pieces of ddsp/core.py (207-216, 800-891, 1028-1045) that the synths only use fused, called on their own: bit
+  equal to the fp32 restatement where the op is a single rounded operation, the scan against exact accumulation."""
+  rng = np.random.default_rng(11)
+  num = rng.standard_normal((3, 50, 7)).astype(np.float32)
+  den = rng.standard_normal((3, 50, 7)).astype(np.float32)
+  den[rng.random(den.shape) < 0.2] = 0.0
+  np.testing.assert_allclose(npy(ddsp.core.safe_divide(num, den)), O.safe_divide(num, den), rtol=3e-7, atol=0)
+  row = den[:, :, :1].copy()
+  np.testing.assert_allclose(npy(ddsp.core.safe_divide(num, row, eps=1e-3)), O.safe_divide(num, row, 1e-3), rtol=3e-7, atol=0)
+  np.testing.assert_allclose(npy(ddsp.core.safe_divide(num, np.float32(0.0))), num / np.float32(1e-7), rtol=3e-7)
+  x = rng.standard_normal((5, 33)).astype(np.float32)
+  np.testing.assert_allclose(npy(ddsp.core.safe_log(x)), O.safe_log(x), rtol=2e-6, atol=2e-7)
+  np.testing.assert_allclose(npy(ddsp.core.safe_log(x, eps=0.5)), O.safe_log(x, 0.5), rtol=2e-6, atol=2e-7)
+  f0 = np.abs(rng.standard_normal((4, 61, 1)) * 300 + 400).astype(np.float32)
+  hf = ddsp.core.get_harmonic_frequencies(f0, 23)
+  assert list(hf.shape) == [4, 61, 23]
+  np.testing.assert_array_equal(npy(hf), O.get_harmonic_frequencies(f0, 23))
+  with pytest.raises(ValueError):
+    ddsp.core.get_harmonic_frequencies(f0[:, :, 0], 5)
+  amp = rng.standard_normal((4, 61, 23)).astype(np.float32)
+  np.testing.assert_array_equal(npy(ddsp.core.remove_above_nyquist(hf, amp, sample_rate=16000)),
+                                O.remove_above_nyquist(O.get_harmonic_frequencies(f0, 23), amp, 16000))
+  edge = np.array([[[7999.9995, 8000.0, 8000.001]]], np.float32)      # the comparison is >= on fp32 values
+  np.testing.assert_array_equal(npy(ddsp.core.remove_above_nyquist(edge, np.ones_like(edge), 16000)), [[[1.0, 0.0, 0.0]]])
+  # angular_cumsum: a 4 s clip of 3 oscillators; exact accumulation in fp64, then the reference's fp32 chunks
+  t_len = 64000 if DEV == 'cuda' else 3000
+  w = (2 * np.pi * np.abs(rng.standard_normal((2, t_len, 3)) * 50 + np.array([110.0, 440.0, 3000.0])) / 16000).astype(np.float32)
+  got = npy(ddsp.core.angular_cumsum(w))
+  assert got.shape == w.shape and got.min() >= 0.0 and got.max() <= np.float32(2 * np.pi)
+  exact = np.mod(np.cumsum(w.astype(np.float64), axis=1), 2 * np.pi)
+  d = np.abs(got - exact)
+  d = np.minimum(d, 2 * np.pi - d)                                     # (either side of the wrap)
+  assert d.max() <= 1e-6
+  faithful = O.angular_cumsum(w, 1000)                                 # fp32 chunks: ~1e-4 .. 1e-3 rad of drift
+  d = np.abs(got - faithful)
+  assert np.minimum(d, 2 * np.pi - d).max() <= 5e-3
+  np.testing.assert_array_equal(npy(ddsp.core.angular_cumsum(w[0, :, 0], chunk_size=250)), got[0, :, 0])     # [time]; chunk_size has nothing to control
+  np.testing.assert_array_equal(npy(ddsp.core.angular_cumsum(w[:, :, 0])), got[:, :, 0])          # [batch, time]
+
+
 # ---- processors.Mix, synths.TensorToAudio (processors_test.py:103-114, synths.py:23-52) -----------------------------
 def test_mix_and_tensor_to_audio(ddsp):
   x1 = np.zeros((2, 100, 3), np.float32) + 1.0
