@@ -320,9 +320,9 @@ def test_small_core_functions_standalone(ddsp):
   d = np.abs(got - exact)
   d = np.minimum(d, 2 * np.pi - d)                                     # (either side of the wrap)
   assert d.max() <= 1e-6
-  faithful = O.angular_cumsum(w, 1000)                                 # fp32 chunks: ~1e-4 .. 1e-3 rad of drift
+  faithful = O.angular_cumsum(w, 1000)                                 # fp32 chunks: up to ~1e-2 rad of drift over 4 s at 3 kHz
   d = np.abs(got - faithful)
-  assert np.minimum(d, 2 * np.pi - d).max() <= 5e-3
+  assert np.minimum(d, 2 * np.pi - d).max() <= 3e-2
   np.testing.assert_array_equal(npy(ddsp.core.angular_cumsum(w[0, :, 0], chunk_size=250)), got[0, :, 0])     # [time]; chunk_size has nothing to control
   np.testing.assert_array_equal(npy(ddsp.core.angular_cumsum(w[:, :, 0])), got[:, :, 0])          # [batch, time]
 
