@@ -199,6 +199,22 @@ __device__ __forceinline__ void load_issue(float& dst, const float* src) {
   dst = *src;
 #endif
 }
+// The same from a wave-uniform base (scalar register pair) and a 32-bit byte offset per lane: no 64-bit address arithmetic.
+__device__ __forceinline__ void load_issue(ddsp_f32x4& dst, const char* base, unsigned byte_offset) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
+#else
+  const float4 v = *reinterpret_cast<const float4*>(base + byte_offset);
+  dst = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+#endif
+}
+__device__ __forceinline__ void load_issue(float& dst, const char* base, unsigned byte_offset) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
+#else
+  dst = *reinterpret_cast<const float*>(base + byte_offset);
+#endif
+}
 // every load this wavefront has issued has landed; the listed values are ordered behind the wait
 __device__ __forceinline__ void loads_landed(ddsp_f32x4& a, float& b, float& c) {
 #if defined(__AMDGCN__)

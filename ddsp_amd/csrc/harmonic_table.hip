@@ -368,7 +368,7 @@ __device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const
   });
 }
 
-template <int W, int NK, bool ONE_TILE, bool ADD>
+template <int W, int NK, bool ONE_TILE, bool ADD, bool ROWS16>
 __global__ __launch_bounds__(1024) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, TableArgs p) {
@@ -650,23 +650,42 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       unsigned ku4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) ku4[u] = 4u * (unsigned)min(4 * kq + u, K - 1);
+      // (loads ISSUED where they are written and first touched behind rows_landed() a tick later, common.h; the row format
+      // is a template parameter: as a run-time branch - plain loads, two formats - it made the compiler's wait counts at
+      // the join conservative and the tick began with part of the HBM latency again: 39.2 - 41.4 instead of 37.5 us, r03s)
       auto prefetch = [&](const WtDesc& d, Rows& r) {
         const size_t r0 = (size_t)d.b * (size_t)F;                               // (an empty descriptor: row 0 of clip 0)
-        const char* __restrict__ hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
-        const char* __restrict__ fb = reinterpret_cast<const char*>(f0_all) + r0 * 4;
+        const char* hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
+        const char* fb = reinterpret_cast<const char*>(f0_all) + r0 * 4;
+        unsigned ro[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
           const unsigned jr = (unsigned)min(d.j0 + 2 * (u0 + i) + sub, F - 1);
-          const unsigned ro = __umul24(jr, row_bytes);                                                // F < 2^24
-          if (p.rows16) {
-            const float4 v = *reinterpret_cast<const float4*>(hb + (ro + kq16));
-            r.x[i] = (ddsp_f32x4){v.x, v.y, v.z, v.w};
-          } else {
-            r.x[i] = (ddsp_f32x4){*reinterpret_cast<const float*>(hb + (ro + ku4[0])), *reinterpret_cast<const float*>(hb + (ro + ku4[1])),
-                                  *reinterpret_cast<const float*>(hb + (ro + ku4[2])), *reinterpret_cast<const float*>(hb + (ro + ku4[3]))};
-          }
-          r.f0[i] = *reinterpret_cast<const float*>(fb + 4u * jr);
+          ro[i] = __umul24(jr, row_bytes);                                                            // F < 2^24
+          load_issue(r.f0[i], fb, 4u * jr);
         }
+        if constexpr (ROWS16) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) load_issue(r.x[i], hb, ro[i] + kq16);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) {
+            float e0, e1, e2, e3;
+            load_issue(e0, hb, ro[i] + ku4[0]);
+            load_issue(e1, hb, ro[i] + ku4[1]);
+            load_issue(e2, hb, ro[i] + ku4[2]);
+            load_issue(e3, hb, ro[i] + ku4[3]);
+            r.x[i] = (ddsp_f32x4){e0, e1, e2, e3};
+          }
+        }
+      };
+      auto rows_landed = [&](Rows& r) {
+#if defined(__AMDGCN__)
+        __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3]), "+v"(r.f0[0]), "+v"(r.f0[1]),
+                         "+v"(r.f0[2]), "+v"(r.f0[3]));
+#else
+        (void)r;
+#endif
       };
       // core.exp_sigmoid (core.py:386-404), remove_above_nyquist on f0 * [1..K] (core.py:899-903, 1028-1045),
       // safe_divide by the row sum (core.py:905-907, 207-210), amplitudes * distribution (core.py:1097)
@@ -725,7 +744,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             const int crow = d.b * F + d.j0 + arow;        // this lane's (batch * frame) row, if arow < nfr
             if (arow < nfr) {
               const f32x2 ho = xo[i] * inv[i], he = xe[i] * inv[i];
-              if (p.rows16) {
+              if constexpr (ROWS16) {
                 if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(ho[0], he[0], ho[1], he[1]);
               } else {
                 float* __restrict__ crow_p = ctl_hd + (size_t)crow * K + 4 * kq;
@@ -753,10 +772,11 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         }
       };
       prefetch(dA, rows_a);
-      auto one_tick = [&](int tick, const Rows& cur, Rows& next) -> bool {
+      auto one_tick = [&](int tick, Rows& cur, Rows& next) -> bool {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
         desc_take();
+        rows_landed(cur);                          // issued a tick ago
         prefetch(dL, next);                        // the next tick's dA
         DDSP_WT_STAMP(1);
         DDSP_WT_STAMP(2);
@@ -772,6 +792,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         if (one_tick(tick, rows_a, rows_b)) break;
         if (one_tick(tick + 1, rows_b, rows_a)) break;
       }
+#if defined(__AMDGCN__)
+      __asm__ volatile("s_waitcnt vmcnt(0)");      // (nothing in flight when the wavefront leaves: tests/test_isa_guards.py reads
+#endif                                             // the instruction stream as text, past the end of this loop)
     } else {
       // =================== interpolators (S-wavefronts 0 .. 7): phase B, four tiles at a time ========================
       // tile slots s, s + 8, s + 16, s + 24 of every round of 31 (slot 7 has three), s = this wavefront's nibble of kWtSlots
@@ -960,9 +983,14 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
 #endif
   hipEvent_t ev0, ev1;
   profile_kernel_events(kHarmTable, &ev0, &ev1);
-#define DDSP_LAUNCH_TABLE_(W, NK, ONE, ADD)                                                                     \
-  hipExtLaunchKernelGGL((harm_table_kernel<W, NK, ONE, ADD>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
+#define DDSP_LAUNCH_TABLE__(W, NK, ONE, ADD, R16)                                                                 \
+  hipExtLaunchKernelGGL((harm_table_kernel<W, NK, ONE, ADD, R16>), grid, block, 0, st, ev0, ev1, 0, amplitudes, hd, f0, \
                         audio, ctl_amp, ctl_hd, add_in, p)
+#define DDSP_LAUNCH_TABLE_(W, NK, ONE, ADD)                                                                     \
+  do {                                                                                                         \
+    if (p.rows16) DDSP_LAUNCH_TABLE__(W, NK, ONE, ADD, true);                                                  \
+    else DDSP_LAUNCH_TABLE__(W, NK, ONE, ADD, false);                                                          \
+  } while (0)
 #define DDSP_LAUNCH_TABLE(W, NK)                                                                                \
   do {                                                                                                         \
     if (p.hop == 64) {                                                                                         \
@@ -979,6 +1007,7 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   else DDSP_LAUNCH_TABLE(8, 2);
 #undef DDSP_LAUNCH_TABLE
 #undef DDSP_LAUNCH_TABLE_
+#undef DDSP_LAUNCH_TABLE__
 #ifdef DDSP_WT_TIMELINE
   if (p.dbg) {
     static long long host[16 * 24 * 8];

@@ -63,6 +63,8 @@ def test_pinned_loads_are_not_touched_before_their_wait(asm):
   for name, body in kernels.items():
     lines = body.split('\n')
     in_asm, pending = False, {}            # pending: {register: line number of the load}
+    at_label = {}                          # what is pending where a forward branch lands (the scan follows the text, not the
+                                           # control flow: code behind an unconditional branch is not reached from above it)
     for n, line in enumerate(lines):
       code = line.split(';')[0].strip() if not line.strip().startswith(';;#') else line.strip()
       if code.startswith(';;#ASMSTART'):
@@ -71,7 +73,16 @@ def test_pinned_loads_are_not_touched_before_their_wait(asm):
       if code.startswith(';;#ASMEND'):
         in_asm = False
         continue
-      if not code or code.endswith(':') or code.startswith('.'):
+      if code.endswith(':') and not code.startswith(';'):
+        pending.update(at_label.pop(code[:-1], {}))
+        continue
+      if not code or code.startswith('.'):
+        continue
+      if code.startswith('s_cbranch') or code.startswith('s_branch'):
+        target = code.split()[-1]
+        at_label.setdefault(target, {}).update(pending)
+        if code.startswith('s_branch'):
+          pending = {}
         continue
       if in_asm and code.startswith('global_load'):
         dst = code.split(',')[0]
@@ -82,7 +93,7 @@ def test_pinned_loads_are_not_touched_before_their_wait(asm):
       if in_asm and code.startswith('s_waitcnt vmcnt(0)'):
         pending.clear()
         continue
-      if code.startswith('s_cbranch') or code.startswith('s_branch') or code.startswith('s_barrier'):
+      if code.startswith('s_barrier'):
         continue
       # any other instruction: must not name a pending destination register (address operands of later pinned loads
       # are covered by the same rule: they are ordinary instructions' results, never the pending registers)

@@ -111,7 +111,7 @@ def main():
                                       os.path.join(ROOT, 'ddsp_amd', 'csrc', 'harmonic_table.hip')], check=True,
                    stderr=subprocess.DEVNULL)
     asm = open(out).read()
-  m = re.search(r'^_ZN4ddsp17harm_table_kernelILi6ELi2ELb1ELb0E\w+:.*?\n(.*?)\n\s*s_endpgm', asm, re.S | re.M)
+  m = re.search(r'^_ZN4ddsp17harm_table_kernelILi6ELi2ELb1ELb0ELb1E\w+:.*?\n(.*?)\n\s*s_endpgm', asm, re.S | re.M)
   blocks = blocks_of(m.group(1))
   nb = lambda b, p: count(b, lambda o: o.startswith(p))
   # the hot blocks of a tick, by what they contain
@@ -130,7 +130,7 @@ def main():
       'A (row maker, 4 row pairs)': [a_fetch, a_main, a_write, ['s_add_u32'] * (loop_glue - 20)],
   }
   classes = list(PRICE)
-  print('harm_table_kernel<6, 2, true, false> (K = 100, hop 64): instructions per tick and wavefront, by class; price = clocks as ONE wavefront')
+  print('harm_table_kernel<6, 2, true, false, true> (K = 100, hop 64): instructions per tick and wavefront, by class; price = clocks as ONE wavefront')
   print('sees them at four wavefronts per SIMD (profiles/r03a_*, r03b_*); predicted = sum; measured = its part of the tick (profiles/r03q_*)')
   print()
   print('%-32s' % 'role' + ''.join('%9s' % c for c in classes if c != 'barrier') + '   total  predicted  measured   ratio')
