@@ -528,7 +528,6 @@ def main(argv=None):
     step()
   if not dry:
     torch.cuda.synchronize()
-  settle(step, a.settle if not dry else 0.0)
 
   # diagnostic pass (untimed, one stream so every kernel runs alone): every kernel bracketed, to
   # find the dominant one and give the isolated per-kernel times
@@ -544,6 +543,15 @@ def main(argv=None):
     torch.cuda.synchronize()
     breakdown = _lib.profile_end()
   dominant = max(breakdown, key=lambda k: breakdown[k][0] / breakdown[k][1])
+  # clock settle LAST, in the issue mode of the timed regions: the first two-stream regions after a stretch of one-stream
+  # launches (the diagnostic pass) are slow - 3.4 ms for a 1.4 ms region, then tens of regions above the steady 68-69 us per
+  # step (r03t: 74.2 vs 70.0 us as the median of 29 / 71 regions) - the runtime re-activates the second stream's queue
+  settle(step, a.settle if not dry else 0.0)
+  # ... and the same again as REGIONS (untimed): the event fork / join of a region and the synchronize between regions have a
+  # warm-up of their own (the first region takes 3.4 ms instead of 1.4, the next ~30 are 5 % slow)
+  t_settle = time.perf_counter()
+  while not dry and time.perf_counter() - t_settle < 0.5 * a.settle:
+    timed_region(step, min(a.steps, 50), overlap)
 
   # ---- timed regions: exactly K steps each, barrier + synchronize on both sides --------------------------
   e_probe, _, _ = timed_region(step, a.steps, overlap)          # untimed probe: sizes the repeat count

@@ -56,3 +56,28 @@ for steps in (5, 10, 20, 50, 200, 1000):
     host.append((t1 - t0) * 1e6 / steps)
   print(json.dumps({'plain_regions_steps': steps, 'regions': reps, 'us_per_step_median': round(float(np.median(ev)), 2),
                     'us_per_step_min': round(float(np.min(ev)), 2), 'host_launch_loop_us_per_step': round(float(np.median(host)), 2)}))
+# two free-running streams the way bench.py brackets a region: both streams start behind e0 (recorded on the base stream), the base
+# stream waits for both before e1; per region length: per-step median / min, and the same with a fixed launch-ahead of the
+# first kernels (`prime`): one Harmonic + one FilteredNoise launch ahead of e0 on their streams (untimed), so that the GPU is not idle
+# when the timed launches arrive
+s0 = torch.cuda.current_stream()
+sh, sz = torch.cuda.Stream(), torch.cuda.Stream()
+def step2():
+  torch.cuda.set_stream(sh); harm(amps, hd, f0)
+  torch.cuda.set_stream(sz); noise(mags)
+  torch.cuda.set_stream(s0)
+for steps in (5, 20, 50, 200, 1000):
+  reps = max(5, 2000 // steps)
+  ev = []
+  for r in range(reps):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s0); sh.wait_event(e0); sz.wait_event(e0)
+    for _ in range(steps): step2()
+    eh, ez = torch.cuda.Event(), torch.cuda.Event()
+    eh.record(sh); ez.record(sz); s0.wait_event(eh); s0.wait_event(ez)
+    e1.record(s0)
+    torch.cuda.synchronize()
+    ev.append(e0.elapsed_time(e1) * 1e3 / steps)
+  print(json.dumps({'two_stream_regions_steps': steps, 'regions': reps, 'us_per_step_median': round(float(np.median(ev)), 2),
+                    'us_per_step_min': round(float(np.min(ev)), 2), 'us_per_step_p90': round(float(np.percentile(ev, 90)), 2)}))
