@@ -549,9 +549,12 @@ def main(argv=None):
   settle(step, a.settle if not dry else 0.0)
   # ... and the same again as REGIONS (untimed): the event fork / join of a region and the synchronize between regions have a
   # warm-up of their own (the first region takes 3.4 ms instead of 1.4, the next ~30 are 5 % slow)
-  t_settle = time.perf_counter()
-  while not dry and time.perf_counter() - t_settle < 0.5 * a.settle:
-    timed_region(step, min(a.steps, 50), overlap)
+  # (a fixed COUNT of regions, the same on every rank: a region's bracket holds a barrier when world > 1, so a loop that
+  # ran until a rank's own clock said stop would leave the ranks with different numbers of barriers)
+  k_warm = min(a.steps, 50)
+  n_warm = 0 if a.settle <= 0 else max(3, min(300, int(5000 * a.settle / 0.5) // max(k_warm, 1)))
+  for _ in range(n_warm if not dry else 0):
+    timed_region(step, k_warm, overlap)
 
   # ---- timed regions: exactly K steps each, barrier + synchronize on both sides --------------------------
   e_probe, _, _ = timed_region(step, a.steps, overlap)          # untimed probe: sizes the repeat count
