@@ -107,6 +107,14 @@ template <> struct WtPoly<8> {
 //     Nyquist mask (v_med3_f32); phase B folds theta into [0, 1/2] with |x| and restores the sign with a xor;
 //   * processors.Add can ride in phase B (add_in): the other signal's samples are fetched at the top of a tile and
 //     added at the store.
+// Second half of round 3 (same-session A/B runs, profiles/r03o_* .. r03t_*; 41.0 -> 37.5 us): the row makers fetch their
+// rows a whole tick ahead (pinned loads, two register sets; fetched at the end of the previous tick, the block's last
+// wavefronts began every tick with the HBM latency); the frame's amplitude is made by tabulator 1 and multiplied into the
+// table sums (the planes hold the normalised distribution); phase B's tap pairs are packed as neighbours in the table row
+// (no register moves), its stores and fused-Add loads go through a scalar base, the tile slots are dealt by SIMD load;
+// any K <= 128 (rows that are not 16 bytes apart: ROWS16 = false).  What did NOT pay: fewer row-maker instructions as such
+// (the SIMD serves its wavefronts oldest first; the row makers run in what is left whatever they have to do), the phase
+// tables removed from tabulator 3 or threaded between its MFMAs, s_setprio in any arrangement.
 // Measured and dropped on the way (timelines under profiles/): twelve identical S-wavefronts (r03d: 45.4 us - a wavefront
 // that does three tiles AND a row pair is ~5000 clocks long, the T-wavefronts idle half the tick); a row pair on each
 // T-wavefront as well (r03e: their MFMA section stretches from 2600 to 4000 clocks and they become the critical
