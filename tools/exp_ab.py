@@ -16,7 +16,7 @@ if %(lib)r: _lib.LIB_PATH = %(lib)r
 import ddsp_amd as ddsp
 only = %(only)r
 res = {}
-for B in (32, 128):
+for B in ((32, 128) if only != 'loss' else ()):
   F, K, N = 1000, 100, 64000
   rng = np.random.default_rng(0)
   amps = ddsp.core.tf_float32(rng.standard_normal((B, F, 1)))
@@ -38,6 +38,22 @@ for B in (32, 128):
     torch.cuda.synchronize()
     bd = _lib.profile_end()
     res['%%s_b%%d' %% (name, B)] = round(sum(v[0] for v in bd.values()) / max(v[1] for v in bd.values()) * 1e3, 2)
+if not only or only == 'loss':
+  B, N = 32, 64000
+  rng = np.random.default_rng(1)
+  a = ddsp.core.tf_float32(rng.standard_normal((B, N)))
+  t = ddsp.core.tf_float32(rng.standard_normal((B, N)))
+  for sizes in ((2048,), (256,), (2048, 1024, 512, 256, 128, 64)):
+    loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=1.0, logmag_weight=1.0)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+      for _ in range(10): loss(t, a)
+      torch.cuda.synchronize()
+    _lib.profile_begin(None, max_records=1024)
+    for _ in range(50): loss(t, a)
+    torch.cuda.synchronize()
+    bd = _lib.profile_end()
+    res['loss_fwd_%%s' %% ('all' if len(sizes) > 1 else sizes[0])] = round(sum(v[0] for v in bd.values()) / 50 * 1e3, 1)
 print('AB ' + json.dumps(res))
 '''
 
