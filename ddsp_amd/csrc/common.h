@@ -249,4 +249,14 @@ __device__ __forceinline__ float row_pair_sum(float v) {
   return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 
+// v_permlane32_swap_b32 likewise for the two halves of the wavefront: every lane receives its half's value plus the
+// other half's.
+__device__ __forceinline__ float wave_half_sum(float v) {
+  typedef unsigned ddsp_u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned bits = __builtin_bit_cast(unsigned, v);
+  const ddsp_u32x2 r = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+
 }  // namespace ddsp

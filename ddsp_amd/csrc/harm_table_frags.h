@@ -59,4 +59,33 @@ constexpr WtFrags make_wt_frags(const WtSinSplit& t) {
   return f;
 }
 
+// 129 .. 200 harmonics (harm_table_kernel<10, 4, ..>): four k-steps per parity.  A plane row ends at k' = 104, so the
+// fourth step reads k' = 72 .. 103 and its fragment is zero where the third already went (k' < 96): k <= 208.
+constexpr int wt_wide_kstep_base(int ks) { return ks < 3 ? 32 * ks : 72; }
+struct WtFragsWide {
+  unsigned int v[4][2][2][2][4][64][4];      // as WtFrags, [k-step ks] of four
+};
+constexpr WtFragsWide make_wt_frags_wide(const WtSinSplit& t) {
+  WtFragsWide f{};
+  for (int rw = 0; rw < 4; ++rw)
+    for (int par = 0; par < 2; ++par)
+      for (int tt = 0; tt < 2; ++tt)
+        for (int ks = 0; ks < 4; ++ks)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int d = 0; d < 4; ++d) {
+              unsigned int hi2 = 0, lo2 = 0;
+              for (int h = 0; h < 2; ++h) {
+                const int kp = wt_wide_kstep_base(ks) + 8 * (lane >> 4) + 2 * d + h;
+                if (ks == 3 && kp < 96) continue;
+                const int n = 16 * (2 * rw + tt) + (lane & 15);
+                const int q = ((2 * kp + 1 + par) * (2 * n + 1)) & 1023;
+                hi2 |= (unsigned int)t.hi[q] << (16 * h);
+                lo2 |= (unsigned int)t.lo[q] << (16 * h);
+              }
+              f.v[rw][0][par][tt][ks][lane][d] = hi2;
+              f.v[rw][1][par][tt][ks][lane][d] = lo2;
+            }
+  return f;
+}
+
 }  // namespace ddsp

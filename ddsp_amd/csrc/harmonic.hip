@@ -908,7 +908,7 @@ extern "C" int ddsp_harmonic_signal_f32(const float* ctl_amp, const float* ctl_h
 // Harmonic.__call__ with processors.Add fused in (ddsp/processors.py:162-176; the node that follows the two synths in every
 // shipped DAG, gin/models/ae.gin:49-56): audio = Harmonic(...) + add_signal in one launch, one [B,N] stream written
 // where the three-kernel form moves three more.  Only where the wavetable kernel applies (ddsp_harmonic_f32's default
-// path: hop % 64 == 0, K <= 128, default flags); DDSP_ERR_UNSUPPORTED otherwise - the caller then runs
+// path: hop % 64 == 0, K <= 200, default flags); DDSP_ERR_UNSUPPORTED otherwise - the caller then runs
 // ddsp_harmonic_f32 and ddsp_add_f32.
 extern "C" int ddsp_harmonic_add_f32(const float* amplitudes, const float* hd, const float* f0_hz, const float* add_signal,
                                      float* audio, int B, int F, int K, int N, int sample_rate, unsigned flags,

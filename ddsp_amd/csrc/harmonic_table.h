@@ -7,7 +7,7 @@ namespace ddsp {
 
 // True when ddsp_harmonic_f32 can run on harm_table_kernel: raw network outputs in (exp_sigmoid +
 // Nyquist-normalised distribution, the defaults of ddsp/synths.py:59-66), the controls dict requested in full
-// or not at all, N % F == 0 with a frame size that is a multiple of 64, K % 4 == 0 and K <= 128.
+// or not at all, N % F == 0 with a frame size that is a multiple of 64, any K <= 200 (129 .. 200: ten taps, csrc/harmonic_table.hip WIDE).
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
                    int inputs_are_controls);
 

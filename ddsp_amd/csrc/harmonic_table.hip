@@ -42,17 +42,24 @@ namespace ddsp {
 
 constexpr WtSinSplit kWtSinSplit = make_wt_sin_split();
 static __device__ const WtFrags kWtFrags = make_wt_frags(kWtSinSplit);      // 64 KB of constants, fetched once per T-wavefront
+static __device__ const WtFragsWide kWtFragsWide = make_wt_frags_wide(kWtSinSplit);      // 128 KB: 129 .. 200 harmonics, streamed from L2 every tick
 
 constexpr int kWtT = 512;            // table points per revolution
 constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, kWtHalf + kWtH); the other half is its mirror image
 constexpr int kWtNQ = kWtT / 4;      // positions produced by the matrix product
-constexpr int kWtH = 4;              // halo entries on either side (>= W/2)
-constexpr int kWtTS = 268;           // table row stride in floats: 4*odd, so 16 rows' b128 writes spread over the banks
+// halo entries on either side of a table row (>= W/2, a multiple of 4) and the row stride in floats (4*odd, so 16 rows'
+// b128 writes spread over the banks), by window width: 4 and 268 up to eight taps, 8 and 276 for ten
+template <int W> struct WtGeom {
+  static constexpr int H = W <= 8 ? 4 : 8;
+  static constexpr int TS = kWtHalf + 2 * H + 4;
+};
 constexpr int kWtRowTiles = 2;       // MFMA N-tiles of 16 amplitude rows per chunk
 constexpr int kWtRows = 16 * kWtRowTiles;    // amplitude rows per chunk
 constexpr int kWtFrames = kWtRows - 1;       // frames per chunk (31): row r+1 is the "next" row of frame r
 constexpr int kWtNT = 4;             // tiles of 64 samples an S-wavefront carries through phase B together
-constexpr int kWtPS = 72;            // row stride of an amplitude plane (fp16 elements; odd / even harmonics apart): 144 B
+// row stride of an amplitude plane (fp16 elements; odd / even harmonics apart): 144 B for two k-steps (K <= 128), 208 B
+// for four (K <= 208: three plane buffers of 136 would not fit the LDS next to the tables; harm_table_frags.h)
+template <int NK> struct WtPlane { static constexpr int PS = NK <= 2 ? 72 : 104; };
 constexpr float kWtLoScale = 2048.0f; // x = hi + lo / 2048 in two fp16 numbers
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -68,18 +75,26 @@ struct ChunkTables {
 
 template <int W> struct WtPoly;
 template <> struct WtPoly<6> {
-  static constexpr int DE = kWtDegE6, DO = kWtDegO6;
+  static constexpr int DE = kWtDegE6, DO = kWtDegO6, KMAX = 128;
   static constexpr float e(int p, int d) { return kWtE6[p * (DE + 1) + d]; }
   static constexpr float o(int p, int d) { return kWtO6[p * (DO + 1) + d]; }
   __device__ static float invpsi(int k) { return kWtInvPsi6_T512[k]; }
   __device__ static float psi(int k) { return kWtPsi6_T512[k]; }
 };
 template <> struct WtPoly<8> {
-  static constexpr int DE = kWtDegE8, DO = kWtDegO8;
+  static constexpr int DE = kWtDegE8, DO = kWtDegO8, KMAX = 128;
   static constexpr float e(int p, int d) { return kWtE8[p * (DE + 1) + d]; }
   static constexpr float o(int p, int d) { return kWtO8[p * (DO + 1) + d]; }
   __device__ static float invpsi(int k) { return kWtInvPsi8_T512[k]; }
   __device__ static float psi(int k) { return kWtPsi8_T512[k]; }
+};
+
+template <> struct WtPoly<10> {      // 129 .. 200 harmonics on the same 512 points (oversampling 1.28; tools/gen_wavetable_coeffs.py)
+  static constexpr int DE = kWtDegE10, DO = kWtDegO10, KMAX = 208;
+  static constexpr float e(int p, int d) { return kWtE10[p * (DE + 1) + d]; }
+  static constexpr float o(int p, int d) { return kWtO10[p * (DO + 1) + d]; }
+  __device__ static float invpsi(int k) { return kWtInvPsi10_T512[k]; }
+  __device__ static float psi(int k) { return kWtPsi10_T512[k]; }
 };
 
 // =====================================================================================================================
@@ -266,6 +281,15 @@ __device__ __forceinline__ f32x2 wt_pk_minus(f32x2 o, f32x2 zz, f32x2 e) {
   return (f32x2){fmaf(-o[0], zz[0], e[0]), fmaf(-o[1], zz[0], e[1])};
 #endif
 }
+// the four 16-byte loads of a k-step have landed when at most N younger loads are still in flight (loads return in order)
+template <int N>
+__device__ __forceinline__ void wt_frags_landed(ddsp_f32x4& a, ddsp_f32x4& b, ddsp_f32x4& c, ddsp_f32x4& d) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+#else
+  (void)a; (void)b; (void)c; (void)d;
+#endif
+}
 template <int N, class Fn>
 __device__ __forceinline__ void wt_static_for(Fn&& f) {
   if constexpr (N > 0) {
@@ -316,7 +340,7 @@ __device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const
   // row j + 1 is 1072 bytes further: past what ds_read2_b32 reaches from row j's address (1020) - ONE second address
   // per tile, made here (left to itself the compiler makes one per read pair)
   const float* t1[kWtNT];
-  int row_stride = kWtTS;
+  int row_stride = WtGeom<W>::TS;
   DDSP_KEEP_IN_VGPR(row_stride);               // (opaque: t1 + 4 stays an immediate offset from ONE address)
 #pragma unroll
   for (int u = 0; u < NT; ++u) t1[u] = t[u] + row_stride;
@@ -380,6 +404,8 @@ template <int W, int NK, bool ONE_TILE, bool ADD, bool ROWS16>
 __global__ __launch_bounds__(1024) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
     float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, TableArgs p) {
+  constexpr int kWtH = WtGeom<W>::H, kWtTS = WtGeom<W>::TS, kWtPS = WtPlane<NK>::PS;
+  constexpr bool WIDE = NK > 2;                   // 129 .. 200 harmonics: see the tabulators and the row makers
   __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];
   __shared__ __attribute__((aligned(16))) _Float16 planes_all[3][4 * kWtRows * kWtPS];   // [hi, lo][parity][row][k']: a_k / psi_hat(k)
   __shared__ ChunkTables t_all[2];
@@ -431,7 +457,10 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
   if (is_t) {
     const int rw = wave;
     // ---- this wavefront's share of the constant factor, in MFMA A-operand layout (harm_table_frags.h) ---------------
-    f16x8 ahi[2][2][NK], alo[2][2][NK];
+    // (four k-steps, WIDE: 128 registers' worth - the share of one parity and row tile is fetched from L2 where it is
+    // used, below: 64 KB per tabulator and tick, which a frame of three or more tiles - what such shapes have - hides)
+    f16x8 ahi[2][2][WIDE ? 1 : NK], alo[2][2][WIDE ? 1 : NK];
+    if constexpr (!WIDE) {
 #pragma unroll
     for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -444,6 +473,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           ahi[par][tt][ks] = __builtin_bit_cast(f16x8, vh);
           alo[par][tt][ks] = __builtin_bit_cast(f16x8, vl);
         }
+    }
     // wavefront 3 builds the per-frame phase tables (lanes = frames 0 .. 32): f0 of the chunk's frames, issued before the
     // MFMAs of the tick and used after them; `before` = the sum of f0 over the frames of the row before the chunk, carried
     // from chunk to chunk and summed afresh (fp64: exact, so the same bits in any order) at the start of a row segment
@@ -514,6 +544,36 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             accx[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
+          if constexpr (WIDE) {
+            // this parity's sixteen fragments, issued together (pinned: left to itself the compiler hoists these loop-
+            // invariant loads out of the tick loop, into registers nobody has) and used k-step by k-step as they land
+            ddsp_f32x4 fr[NK][2][2];                          // [k-step][position tile][hi, lo]
+            const char* fbase = reinterpret_cast<const char*>(kWtFragsWide.v);
+            unsigned lane16 = 16u * (unsigned)lane;
+            DDSP_KEEP_IN_VGPR(lane16);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                  load_issue(fr[ks][tt][hl], fbase + 1024 * (((((rw * 2 + hl) * 2 + par) * 2 + tt) * 4) + ks), lane16);      // (scalar base, one lane offset)
+            wt_static_for<NK>([&](auto kk) {
+              constexpr int ks = decltype(kk)::value;
+              const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS + wt_wide_kstep_base(ks));
+              const f16x8 blo = *reinterpret_cast<const f16x8*>(bsrc + (1 * 2 + par) * kWtRows * kWtPS + wt_wide_kstep_base(ks));
+              wt_frags_landed<4 * (NK - 1 - ks)>(fr[ks][0][0], fr[ks][0][1], fr[ks][1][0], fr[ks][1][1]);
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[ks][tt][0]), bhi, acc[tt], 0, 0, 0);
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[ks][tt][0]), blo, accx[tt], 0, 0, 0);
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[ks][tt][1]), bhi, accx[tt], 0, 0, 0);
+            });
+          } else {
 #pragma unroll
           for (int ks = 0; ks < NK; ++ks) {
             const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS + 32 * ks);
@@ -528,6 +588,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             for (int tt = 0; tt < 2; ++tt)
               accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][tt][ks], bhi, accx[tt], 0, 0, 0);
           }
+          }
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) soe[par][tt] = acc[tt] * am + accx[tt] * am_lo;
         }
@@ -541,9 +602,16 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           const f32x4 sm = so - se;                         // S(T/2-1-n)   = O - E
           *reinterpret_cast<f32x4*>(trow + n0) = sp;
           *reinterpret_cast<f32x4*>(trow + (kWtHalf - 4 - n0)) = (f32x4){sm.w, sm.z, sm.y, sm.x};
+          if constexpr (kWtH == 4) {
           if (n0 == 0) {                                     // halos: S(-1-m) = -S(m), S(T/2+m) = -S(T/2-1-m)
             *reinterpret_cast<f32x4*>(trow - kWtH) = (f32x4){-sp.w, -sp.z, -sp.y, -sp.x};
             *reinterpret_cast<f32x4*>(trow + kWtHalf) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
+          }
+          } else {
+          if (n0 < kWtH) {                                   // (eight entries either side: the lanes with n0 = 0 and 4)
+            *reinterpret_cast<f32x4*>(trow - 4 - n0) = (f32x4){-sp.w, -sp.z, -sp.y, -sp.x};
+            *reinterpret_cast<f32x4*>(trow + kWtHalf + n0) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
+          }
           }
         }
        }
@@ -633,16 +701,22 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       // instructions (exp, log, exp, the sum, 1 / sum, the split), and a wavefront issues one instruction per ~8 clocks
       // only if it has independent ones to issue.  The rows come straight from HBM into registers (below).  Rows past the
       // chunk's halo row are fetched (clamped) and worked on like the others: nobody reads their planes.
+      // WIDE (129 .. 200 harmonics): all 64 lanes on ONE row, lane hq owns harmonics 4 hq + 1 .. + 4; a row maker takes rows
+      // 8 (sw - 8) .. + 7 of the chunk, four at a time in two passes per tick (such shapes have frames of several tiles:
+      // the interpolators set the length of a tick)
       constexpr int NU = 4;
       const int u0 = NU * (sw - 8);
+      const int hq = WIDE ? lane : kq;
+      const bool live_h = WIDE ? lane < K4 : live;
+      auto row_of = [&](int i, int pass) -> int { return 2 * u0 + NU * pass + i; };      // (WIDE)
       // per-lane constants: 1 / psi_hat(k), the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit:
       // always masked)
       float ipsi[4], kf[4], nyq_u[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const bool alive = 4 * kq + u + 1 <= K;              // (K need not be a multiple of 4: the last lane's tail is dead)
-        ipsi[u] = alive ? WtPoly<W>::invpsi(min(4 * kq + u + 1, 128)) : 0.0f;
-        kf[u] = alive ? (float)(4 * kq + u + 1) : 0.0f;
+        const bool alive = 4 * hq + u + 1 <= K;              // (K need not be a multiple of 4: the last lane's tail is dead)
+        ipsi[u] = alive ? WtPoly<W>::invpsi(min(4 * hq + u + 1, WtPoly<W>::KMAX)) : 0.0f;
+        kf[u] = alive ? (float)(4 * hq + u + 1) : 0.0f;
         nyq_u[u] = alive ? p.nyquist : -1.0f;
       }
       // the rows of a chunk in registers: fetched at the top of the tick BEFORE the one that works on them (HBM has a whole
@@ -653,22 +727,22 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       // (addresses: the clip's first row as wave-uniform bases in scalar registers, the rest as 32-bit byte offsets - a
       // clip's F K floats are < 4 GB and F < 2^24, harm_table_ok: four vector instructions per row pair where 64-bit row
       // arithmetic took twelve)
-      const unsigned kq16 = 16u * (unsigned)min(kq, K4 - 1), row_bytes = 4u * (unsigned)K;
+      const unsigned kq16 = 16u * (unsigned)min(hq, K4 - 1), row_bytes = 4u * (unsigned)K;
       // rows that are not 16-byte aligned (K % 4 != 0, or an odd base): four 4-byte loads per lane, the tail clamped
       unsigned ku4[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) ku4[u] = 4u * (unsigned)min(4 * kq + u, K - 1);
+      for (int u = 0; u < 4; ++u) ku4[u] = 4u * (unsigned)min(4 * hq + u, K - 1);
       // (loads ISSUED where they are written and first touched behind rows_landed() a tick later, common.h; the row format
       // is a template parameter: as a run-time branch - plain loads, two formats - it made the compiler's wait counts at
       // the join conservative and the tick began with part of the HBM latency again: 39.2 - 41.4 instead of 37.5 us, r03s)
-      auto prefetch = [&](const WtDesc& d, Rows& r) {
+      auto prefetch = [&](const WtDesc& d, Rows& r, int pass) {
         const size_t r0 = (size_t)d.b * (size_t)F;                               // (an empty descriptor: row 0 of clip 0)
         const char* hb = reinterpret_cast<const char*>(hd) + r0 * row_bytes;
         const char* fb = reinterpret_cast<const char*>(f0_all) + r0 * 4;
         unsigned ro[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          const unsigned jr = (unsigned)min(d.j0 + 2 * (u0 + i) + sub, F - 1);
+          const unsigned jr = (unsigned)min(WIDE ? d.j0 + row_of(i, pass) : d.j0 + 2 * (u0 + i) + sub, F - 1);
           ro[i] = __umul24(jr, row_bytes);                                                            // F < 2^24
           load_issue(r.f0[i], fb, 4u * jr);
         }
@@ -718,7 +792,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         const f32x2 y = __builtin_elementwise_fma(prod, (f32x2){-kHuge, -kHuge}, nyq_s);
         return (f32x2){__builtin_amdgcn_fmed3f(e[0], 0.0f, y[0]), __builtin_amdgcn_fmed3f(e[1], 0.0f, y[1])};
       };
-      auto phase_a = [&](const WtDesc& d, _Float16* planes, const Rows& r) {
+      auto phase_a = [&](const WtDesc& d, _Float16* planes, const Rows& r, int pass) {
         const int nfr = d.nfr;
         f32x2 xo[NU], xe[NU];
         float part[NU], inv[NU];
@@ -740,6 +814,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
           part[i] = row_pair_sum(part[i]);            // + the other 16 lanes of this matrix row
+          if constexpr (WIDE) part[i] = wave_half_sum(part[i]);      // + the other 32 lanes: the row is the whole wavefront
           // safe_divide: a sum of values that are 0 or >= 1e-7 is 0 (everything masked: eps instead) or >= 1e-7
           inv[i] = __builtin_amdgcn_rcpf(fmaxf(part[i], 1e-7f));
         }
@@ -748,18 +823,18 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         if (ctl_hd != nullptr) {
 #pragma unroll
           for (int i = 0; i < NU; ++i) {
-            const int arow = 2 * (u0 + i) + sub;
+            const int arow = WIDE ? row_of(i, pass) : 2 * (u0 + i) + sub;
             const int crow = d.b * F + d.j0 + arow;        // this lane's (batch * frame) row, if arow < nfr
             if (arow < nfr) {
               const f32x2 ho = xo[i] * inv[i], he = xe[i] * inv[i];
               if constexpr (ROWS16) {
-                if (live) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + kq] = make_float4(ho[0], he[0], ho[1], he[1]);
+                if (live_h) reinterpret_cast<float4*>(ctl_hd)[(size_t)crow * K4 + hq] = make_float4(ho[0], he[0], ho[1], he[1]);
               } else {
-                float* __restrict__ crow_p = ctl_hd + (size_t)crow * K + 4 * kq;
+                float* __restrict__ crow_p = ctl_hd + (size_t)crow * K + 4 * hq;
                 const float h4[4] = {ho[0], he[0], ho[1], he[1]};
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                  if (4 * kq + u < K) crow_p[u] = h4[u];
+                  if (4 * hq + u < K) crow_p[u] = h4[u];
               }
             }
           }
@@ -769,26 +844,41 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
           const f32x2 c[2] = {(xo[i] * inv[i]) * ipsi_o, (xe[i] * inv[i]) * ipsi_e};       // k odd (k' = 2 kq, 2 kq + 1), k even
-          _Float16* dst = planes + (2 * (u0 + i) + sub) * kWtPS + 2 * kq;
+          _Float16* dst = planes + (WIDE ? row_of(i, pass) : 2 * (u0 + i) + sub) * kWtPS + 2 * hq;
 #pragma unroll
           for (int par = 0; par < 2; ++par) {
             const h16x2 hi = __builtin_amdgcn_cvt_pkrtz(c[par][0], c[par][1]);
             const h16x2 lo = wt_rest_halves(c[par] * kWtLoScale, hi);
-            *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
-            *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
+            if (!WIDE || 2 * hq < kWtPS) {              // (WIDE: a plane row ends at k' = 104; dead harmonics write zeros up to there)
+              *reinterpret_cast<h16x2*>(dst + (0 * 2 + par) * kWtRows * kWtPS) = hi;
+              *reinterpret_cast<h16x2*>(dst + (1 * 2 + par) * kWtRows * kWtPS) = lo;
+            }
           }
         }
       };
-      prefetch(dA, rows_a);
+      prefetch(dA, rows_a, 0);
+      if constexpr (WIDE) prefetch(dA, rows_b, 1);
       auto one_tick = [&](int tick, Rows& cur, Rows& next) -> bool {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
         desc_take();
         rows_landed(cur);                          // issued a tick ago
-        prefetch(dL, next);                        // the next tick's dA
+        if constexpr (WIDE) {
+          // cur = the first four rows, next = the other four, both fetched during the tick before; each set is
+          // fetched again for the next chunk as soon as it has been used
+          rows_landed(next);
+          DDSP_WT_STAMP(1);
+          DDSP_WT_STAMP(2);
+          if (dA.nfr > 0) phase_a(dA, planes_all[pa], cur, 0);
+          prefetch(dL, cur, 0);
+          if (dA.nfr > 0) phase_a(dA, planes_all[pa], next, 1);
+          prefetch(dL, next, 1);
+        } else {
+        prefetch(dL, next, 0);                     // the next tick's dA
         DDSP_WT_STAMP(1);
         DDSP_WT_STAMP(2);
-        if (dA.nfr > 0) phase_a(dA, planes_all[pa], cur);
+        if (dA.nfr > 0) phase_a(dA, planes_all[pa], cur, 0);
+        }
         DDSP_WT_STAMP(3);
         __syncthreads();
         DDSP_WT_STAMP(4);
@@ -796,9 +886,14 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         { const int t3 = pb; pb = pm; pm = pa; pa = t3; }
         return tick + 1 >= 0 && dB.nfr == 0;
       };
+      if constexpr (WIDE) {
+        for (int tick = -2;; ++tick)
+          if (one_tick(tick, rows_a, rows_b)) break;
+      } else {
       for (int tick = -2;; tick += 2) {
         if (one_tick(tick, rows_a, rows_b)) break;
         if (one_tick(tick + 1, rows_b, rows_a)) break;
+      }
       }
 #if defined(__AMDGCN__)
       __asm__ volatile("s_waitcnt vmcnt(0)");      // (nothing in flight when the wavefront leaves: tests/test_isa_guards.py reads
@@ -944,7 +1039,7 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
   if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
   if (inputs_are_controls || (ctl_amp == nullptr) != (ctl_hd == nullptr) || (flags >> 24) != 0) return false;
   (void)hd;
-  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 1 && K <= 128 && F < (1 << 24);
+  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 1 && K <= 200 && F < (1 << 24);
 }
 
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
@@ -1012,7 +1107,8 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   // the 6-tap window holds its 6.3e-6 up to K = 100 (T / 2K >= 2.56); denser spectra take 8 taps
   if (K <= 64) DDSP_LAUNCH_TABLE(6, 1);
   else if (K <= 100) DDSP_LAUNCH_TABLE(6, 2);
-  else DDSP_LAUNCH_TABLE(8, 2);
+  else if (K <= 128) DDSP_LAUNCH_TABLE(8, 2);
+  else DDSP_LAUNCH_TABLE(10, 4);        // 129 .. 200 harmonics (config 5's 48 kHz shapes): ten taps on the same 512 points, <= 5.3e-6
 #undef DDSP_LAUNCH_TABLE
 #undef DDSP_LAUNCH_TABLE_
 #undef DDSP_LAUNCH_TABLE__

@@ -155,7 +155,7 @@ int ddsp_harmonic_f32(const float* amplitudes, const float* harmonic_distributio
  * in one launch - one [B,N] stream written (14.44 instead of 18.44 bytes per sample for the
  * Harmonic + FilteredNoise + Add group).  add_signal may be `audio` itself.
  * Bit-identical to ddsp_harmonic_f32 followed by ddsp_add_f32.  Returns DDSP_ERR_UNSUPPORTED where
- * the wavetable kernel does not apply (hop % 64 != 0, K > 128, non-default flags): the caller
+ * the wavetable kernel does not apply (hop % 64 != 0, K > 200, non-default flags): the caller
  * then uses the two separate entries. */
 int ddsp_harmonic_add_f32(const float* amplitudes, const float* harmonic_distribution,
                           const float* f0_hz, const float* add_signal, float* audio, int B, int F,

@@ -407,6 +407,27 @@ inline ddsp_emu_uint2v __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, 
   });
   return ddsp_emu_uint2v{o.a, o.b};
 }
+// v_permlane32_swap_b32: the upper half of the first operand changes places with the lower half of the second
+inline ddsp_emu_uint2v __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+  struct In { unsigned a, b; };
+  struct Out { unsigned a, b; };
+  const Out o = ddsp_emu::wave_op<In, Out>(32, 0, In{a, b}, [](ddsp_emu::WaveOp& op, unsigned long long live) {
+    for (int l = 0; l < 64; ++l) {
+      const In me = ddsp_emu::in_of<In>(op, l);
+      Out& out = ddsp_emu::out_of<Out>(op, l);
+      out.a = me.a;
+      out.b = me.b;
+      if (l >= 32) {                 // first operand, upper half: receives the second operand's lower half
+        const int s = l - 32;
+        out.a = ddsp_emu::is_live(live, s) ? ddsp_emu::in_of<In>(op, s).b : 0u;
+      } else {                       // second operand, lower half: receives the first operand's upper half
+        const int s = l + 32;
+        out.b = ddsp_emu::is_live(live, s) ? ddsp_emu::in_of<In>(op, s).a : 0u;
+      }
+    }
+  });
+  return ddsp_emu_uint2v{o.a, o.b};
+}
 inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
   return std::max(std::min(a, b), std::min(std::max(a, b), c));
 }

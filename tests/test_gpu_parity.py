@@ -1277,6 +1277,46 @@ def test_harmonic_counts_that_are_not_multiples_of_four(ddsp, k):
   np.testing.assert_allclose(npy(full['controls']['amplitudes']), ctl['amplitudes'], rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('k,hop,sr,base,jitter', [
+    (200, 192, 48000, 100.0, 1.0),          # config 5's shape (gin/models/vst/vst_48k.gin:16-17,102): every harmonic live
+    (200, 64, 48000, 119.0, 8.0),           # the top harmonics cross Nyquist inside frames (200 * 120 Hz = 24 kHz)
+    (199, 192, 48000, 60.0, 0.0),           # rows that are not 16 bytes apart
+    (129, 128, 16000, 40.0, 2.0),           # the smallest count on this path; 16 kHz: most harmonics above Nyquist
+    (160, 192, 48000, 440.0, 30.0),         # scattered table reads, f0 jumping from frame to frame
+])
+def test_harmonic_129_to_200_harmonics_on_the_wavetable_kernel(ddsp, k, hop, sr, base, jitter):
+  """129 .. 200 harmonics take the wavetable kernel too since round 3 (ten taps on the same 512 points, the constant
+  factor streamed from L2, rows spread over whole wavefronts: csrc/harmonic_table.hip, WIDE): signal against exact
+  arithmetic at HARM_TABLE_ATOL and within HARM_TRUTH_ATOL of the direct sum, the controls dict against the fp64 oracle,
+  the same samples whether the controls are asked for or not, a row alone = the row in its batch, processors.Add fused."""
+  b, f = 3, (45 if DEV == 'cuda' else 33)
+  n = f * hop
+  rng = np.random.default_rng(1000 + k + hop)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  hd[1, :, k // 2:] += 4.0                                    # one clip with its weight in the top harmonics (1 / psi_hat <= 27 there)
+  f0 = np.abs(base + jitter * rng.standard_normal((b, f, 1))).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  got = npy(synth(amps, hd, f0))
+  exact, knife = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges=True)
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  assert knife.mean() <= 1e-2
+  assert np.abs(got - exact)[~knife].max() <= HARM_TABLE_ATOL * scale
+  direct = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  direct.kernel = 'direct'
+  sum_ = npy(direct(amps, hd, f0))
+  assert not np.array_equal(got, sum_)                         # (two kernels)
+  assert np.abs(got - sum_)[~knife].max() <= HARM_TRUTH_ATOL * scale
+  full = synth(amps, hd, f0, return_outputs_dict=True)
+  np.testing.assert_array_equal(npy(full['signal']), got)
+  ctl = O.harmonic_get_controls(amps, hd, f0, sr, dtype=np.float64)
+  np.testing.assert_allclose(npy(full['controls']['harmonic_distribution']), ctl['harmonic_distribution'], rtol=2e-5, atol=1e-7)
+  np.testing.assert_allclose(npy(full['controls']['amplitudes']), ctl['amplitudes'], rtol=2e-5, atol=1e-7)
+  np.testing.assert_array_equal(npy(synth(amps[1:2], hd[1:2], f0[1:2])), got[1:2])
+  z = rng.standard_normal((b, n)).astype(np.float32)
+  np.testing.assert_array_equal(npy(synth.call_add(amps, hd, f0, z)), got + z)
+
+
 @pytest.mark.parametrize('seed', [1, 2, 3])
 def test_filtered_noise_random_shapes_vs_oracle(ddsp, seed):
   """Random (batch, frames, frame size 64 .. 256, ragged length, supplied or generated noise) through the default

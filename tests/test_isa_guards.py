@@ -57,13 +57,17 @@ def test_no_scratch_in_the_harmonic_table_kernels(asm):
 
 
 def test_pinned_loads_are_not_touched_before_their_wait(asm):
+  """Loads written as volatile assembly (common.h load_issue) are invisible to the compiler's wait counting: nothing may
+  name their destination registers before a wait that covers them.  Vector memory operations return in order, so
+  `s_waitcnt vmcnt(N)` - the compiler's or the kernel's own - leaves the N youngest of ALL of them in flight (the WIDE
+  tabulators take their sixteen fragments four at a time that way)."""
   kernels = _kernels(asm)
   assert kernels, 'kernels not found in the assembly'
   checked = 0
   for name, body in kernels.items():
     lines = body.split('\n')
-    in_asm, pending = False, {}            # pending: {register: line number of the load}
-    at_label = {}                          # what is pending where a forward branch lands (the scan follows the text, not the
+    in_asm, inflight = False, []           # inflight: [(line number, destination registers of a PINNED load, or an empty set)]
+    at_label = {}                          # what is in flight where a forward branch lands (the scan follows the text, not the
                                            # control flow: code behind an unconditional branch is not reached from above it)
     for n, line in enumerate(lines):
       code = line.split(';')[0].strip() if not line.strip().startswith(';;#') else line.strip()
@@ -74,30 +78,38 @@ def test_pinned_loads_are_not_touched_before_their_wait(asm):
         in_asm = False
         continue
       if code.endswith(':') and not code.startswith(';'):
-        pending.update(at_label.pop(code[:-1], {}))
+        inflight = sorted(set(inflight) | set(at_label.pop(code[:-1], [])), key=lambda e: e[0])
         continue
       if not code or code.startswith('.'):
         continue
       if code.startswith('s_cbranch') or code.startswith('s_branch'):
         target = code.split()[-1]
-        at_label.setdefault(target, {}).update(pending)
+        at_label[target] = sorted(set(at_label.get(target, [])) | set(inflight), key=lambda e: e[0])
         if code.startswith('s_branch'):
-          pending = {}
+          inflight = []
         continue
-      if in_asm and code.startswith('global_load'):
-        dst = code.split(',')[0]
-        for r in _regs(dst):
-          pending[r] = n
-        checked += 1
-        continue
-      if in_asm and code.startswith('s_waitcnt vmcnt(0)'):
-        pending.clear()
+      if code.startswith('s_waitcnt'):
+        m = re.search(r'vmcnt\((\d+)\)', code)
+        if m:
+          keep = int(m.group(1))
+          inflight = inflight[len(inflight) - keep:] if keep else []
         continue
       if code.startswith('s_barrier'):
+        continue
+      pending = {r: ln for ln, regs in inflight for r in regs}
+      is_vmem = code.startswith(('global_', 'buffer_', 'flat_', 'scratch_'))
+      if in_asm and code.startswith('global_load'):
+        dst = code.split(',')[0]
+        touched = _regs(code.split(',', 1)[1]) & set(pending)
+        assert not touched, '%s: line %d `%s` uses v%s, still in flight' % (name, n, code, sorted(touched))
+        inflight.append((n, frozenset(_regs(dst))))
+        checked += 1
         continue
       # any other instruction: must not name a pending destination register (address operands of later pinned loads
       # are covered by the same rule: they are ordinary instructions' results, never the pending registers)
       touched = _regs(code) & set(pending)
       assert not touched, '%s: line %d `%s` touches v%s, the destination of a pinned load still in flight (issued at line %d)' % (
           name, n, code, sorted(touched), min(pending[r] for r in touched))
+      if is_vmem:
+        inflight.append((n, frozenset()))
   assert checked >= 6          # the pinned loads of the T-wavefront that builds the phase tables, in every instantiation
