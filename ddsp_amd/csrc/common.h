@@ -215,6 +215,29 @@ __device__ __forceinline__ void load_issue(float& dst, const char* base, unsigne
   dst = *reinterpret_cast<const float*>(base + byte_offset);
 #endif
 }
+// The same with five wait states in front and an immediate byte offset (0 .. 4095).  A vector instruction that writes a
+// scalar register (v_readlane: how the compiler brings back a base it has spilled to a register lane; v_readfirstlane)
+// must be five wait states ahead of a vector memory instruction that reads it, and the compiler's hazard recogniser does
+// not look inside assembly statements: harm_table_kernel's instances for 129 .. 200 harmonics have that many bases
+// (profiles/r03u_*: stale bases, wrong samples that move from run to run).  tests/test_isa_guards.py checks every pinned
+// load of every instance for this.
+template <int IMM>
+__device__ __forceinline__ void load_issue_spaced(ddsp_f32x4& dst, const char* base, unsigned byte_offset) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(byte_offset), "s"(base), "n"(IMM));
+#else
+  const float4 v = *reinterpret_cast<const float4*>(base + byte_offset + IMM);
+  dst = (ddsp_f32x4){v.x, v.y, v.z, v.w};
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void load_issue_spaced(float& dst, const char* base, unsigned byte_offset) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(byte_offset), "s"(base), "n"(IMM));
+#else
+  dst = *reinterpret_cast<const float*>(base + byte_offset + IMM);
+#endif
+}
 // every load this wavefront has issued has landed; the listed values are ordered behind the wait
 __device__ __forceinline__ void loads_landed(ddsp_f32x4& a, float& b, float& c) {
 #if defined(__AMDGCN__)

@@ -63,7 +63,9 @@ constexpr WtFrags make_wt_frags(const WtSinSplit& t) {
 // fourth step reads k' = 72 .. 103 and its fragment is zero where the third already went (k' < 96): k <= 208.
 constexpr int wt_wide_kstep_base(int ks) { return ks < 3 ? 32 * ks : 72; }
 struct WtFragsWide {
-  unsigned int v[4][2][2][2][4][64][4];      // as WtFrags, [k-step ks] of four
+  // [T-wavefront rw][parity][position tile tt][part: hi / lo][k-step ks][lane][dword d]: what a tabulator fetches for one
+  // parity is one block of 16 KB - a scalar base, four lane offsets, the k-step in the load's 12-bit immediate offset
+  unsigned int v[4][2][2][2][4][64][4];
 };
 constexpr WtFragsWide make_wt_frags_wide(const WtSinSplit& t) {
   WtFragsWide f{};
@@ -82,8 +84,8 @@ constexpr WtFragsWide make_wt_frags_wide(const WtSinSplit& t) {
                 hi2 |= (unsigned int)t.hi[q] << (16 * h);
                 lo2 |= (unsigned int)t.lo[q] << (16 * h);
               }
-              f.v[rw][0][par][tt][ks][lane][d] = hi2;
-              f.v[rw][1][par][tt][ks][lane][d] = lo2;
+              f.v[rw][par][tt][0][ks][lane][d] = hi2;
+              f.v[rw][par][tt][1][ks][lane][d] = lo2;
             }
   return f;
 }

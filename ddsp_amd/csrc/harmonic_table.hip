@@ -548,16 +548,19 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             // this parity's sixteen fragments, issued together (pinned: left to itself the compiler hoists these loop-
             // invariant loads out of the tick loop, into registers nobody has) and used k-step by k-step as they land
             ddsp_f32x4 fr[NK][2][2];                          // [k-step][position tile][hi, lo]
-            const char* fbase = reinterpret_cast<const char*>(kWtFragsWide.v);
+            // (one scalar base per parity, a lane offset per position tile and part, the k-step as the immediate offset;
+            // spaced: the bases come back from spill lanes - common.h)
+            const char* fbase = reinterpret_cast<const char*>(kWtFragsWide.v) + 16384 * (rw * 2 + par);
             unsigned lane16 = 16u * (unsigned)lane;
             DDSP_KEEP_IN_VGPR(lane16);
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks)
+            wt_static_for<NK>([&](auto kk) {
+              constexpr int ks = decltype(kk)::value;
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl)
-                  load_issue(fr[ks][tt][hl], fbase + 1024 * (((((rw * 2 + hl) * 2 + par) * 2 + tt) * 4) + ks), lane16);      // (scalar base, one lane offset)
+                  load_issue_spaced<1024 * ks>(fr[ks][tt][hl], fbase, lane16 + 4096u * (unsigned)(2 * tt + hl));
+            });
             wt_static_for<NK>([&](auto kk) {
               constexpr int ks = decltype(kk)::value;
               const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS + wt_wide_kstep_base(ks));
@@ -744,19 +747,30 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         for (int i = 0; i < NU; ++i) {
           const unsigned jr = (unsigned)min(WIDE ? d.j0 + row_of(i, pass) : d.j0 + 2 * (u0 + i) + sub, F - 1);
           ro[i] = __umul24(jr, row_bytes);                                                            // F < 2^24
-          load_issue(r.f0[i], fb, 4u * jr);
+          if constexpr (WIDE) load_issue_spaced<0>(r.f0[i], fb, 4u * jr);      // (spaced: common.h)
+          else load_issue(r.f0[i], fb, 4u * jr);
         }
         if constexpr (ROWS16) {
 #pragma unroll
-          for (int i = 0; i < NU; ++i) load_issue(r.x[i], hb, ro[i] + kq16);
+          for (int i = 0; i < NU; ++i) {
+            if constexpr (WIDE) load_issue_spaced<0>(r.x[i], hb, ro[i] + kq16);
+            else load_issue(r.x[i], hb, ro[i] + kq16);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < NU; ++i) {
             float e0, e1, e2, e3;
+            if constexpr (WIDE) {
+              load_issue_spaced<0>(e0, hb, ro[i] + ku4[0]);
+              load_issue_spaced<0>(e1, hb, ro[i] + ku4[1]);
+              load_issue_spaced<0>(e2, hb, ro[i] + ku4[2]);
+              load_issue_spaced<0>(e3, hb, ro[i] + ku4[3]);
+            } else {
             load_issue(e0, hb, ro[i] + ku4[0]);
             load_issue(e1, hb, ro[i] + ku4[1]);
             load_issue(e2, hb, ro[i] + ku4[2]);
             load_issue(e3, hb, ro[i] + ku4[3]);
+            }
             r.x[i] = (ddsp_f32x4){e0, e1, e2, e3};
           }
         }

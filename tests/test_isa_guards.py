@@ -113,3 +113,47 @@ def test_pinned_loads_are_not_touched_before_their_wait(asm):
       if is_vmem:
         inflight.append((n, frozenset()))
   assert checked >= 6          # the pinned loads of the T-wavefront that builds the phase tables, in every instantiation
+
+
+def test_no_vector_written_scalar_base_right_before_a_pinned_load(asm):
+  """A vector instruction that writes a scalar register (v_readlane - how the compiler reads back a scalar it spilled
+  to a register lane -, v_readfirstlane, a compare with a scalar destination) must be five wait states ahead of a vector
+  memory instruction that reads that register.  The compiler pads its own loads; it does not look inside assembly
+  statements, so the pinned loads pad themselves where it matters (common.h load_issue_spaced).  Found on the MI355X
+  (profiles/r03u_*): the 129 .. 200-harmonic instances read fragments through stale bases."""
+  kernels = _kernels(asm)
+  assert kernels
+  loads = 0
+  for name, body in kernels.items():
+    ins, in_asm = [], False
+    for line in body.split('\n'):
+      t = line.strip()
+      if t.startswith(';;#ASMSTART'):
+        in_asm = True
+        continue
+      if t.startswith(';;#ASMEND'):
+        in_asm = False
+        continue
+      code = line.split(';')[0].strip()
+      if not code or code.startswith('.') or code.endswith(':'):
+        continue
+      ins.append((code, in_asm))
+    for i, (code, pinned) in enumerate(ins):
+      if not (pinned and code.startswith('global_load')):
+        continue
+      m = re.search(r's\[(\d+):(\d+)\]', code)
+      if not m:
+        continue                         # (a 64-bit vector address: no scalar operand)
+      loads += 1
+      base = set(range(int(m.group(1)), int(m.group(2)) + 1))
+      states = 0
+      for prev, _ in reversed(ins[max(0, i - 8):i]):
+        if states >= 5:
+          break
+        w = re.match(r'v_(?:readlane_b32|readfirstlane_b32|cmp\w*_e64|cndmask\w*|add_co\w*|addc_co\w*)\s+s\[?(\d+)(?::(\d+))?\]?', prev)
+        if w:
+          written = set(range(int(w.group(1)), int(w.group(2) or w.group(1)) + 1))
+          assert not (written & base), '%s: `%s` reads s%s %d wait state(s) after `%s` wrote it' % (name, code, sorted(base), states, prev)
+        states += int(prev.split()[1]) + 1 if prev.startswith('s_nop') else 1
+  assert loads >= 24
+

@@ -1,7 +1,7 @@
 """Per-tick timeline of harm_table_kernel's block 0 (shader clocks per role and stage), from a -DDDSP_WT_TIMELINE build
 of the library (tools/build_timeline_lib.sh -> tools/bin/libddsp_amd_timeline.so; the product library has no stamps).
 
-    python tools/exp_table_timeline.py [batch] [f0]
+    python tools/exp_table_timeline.py [batch] [f0] [frames harmonics samples sample_rate]
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,12 +12,12 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 
 import ddsp_amd as ddsp
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 f0c = float(sys.argv[2]) if len(sys.argv) > 2 else 70.0
-F, K, N = 1000, 100, 64000
+F, K, N, SR = (int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (1000, 100, 64000, 16000)
 rng = np.random.default_rng(0)
 amps = ddsp.core.tf_float32(rng.standard_normal((B, F, 1)))
 hd = ddsp.core.tf_float32(rng.standard_normal((B, F, K)))
 f0 = ddsp.core.tf_float32(f0c + rng.standard_normal((B, F, 1)))
-synth = ddsp.synths.Harmonic(n_samples=N)
+synth = ddsp.synths.Harmonic(n_samples=N, sample_rate=SR)
 devnull = os.open(os.devnull, os.O_WRONLY)
 saved = os.dup(2)
 os.dup2(devnull, 2)                      # every launch prints a timeline: keep the last one only
