@@ -19,7 +19,7 @@
 //
 // Per sample the VALU work drops from ~4 K flop-instructions to ~55 (phase, W polynomial weights, 2 W taps; packed
 // FMAs), independent of K; error vs exact arithmetic <= 6.3e-6 * sum_k a_k (W = 6, K <= 100), 6.5e-6 (W = 8,
-// K <= 128), smaller than the sine recurrence's 3.1e-5.
+// K <= 128), 5.3e-6 (W = 10, K <= 200), smaller than the sine recurrence's 3.1e-5.
 //
 // The audio-rate Nyquist mask of core.oscillator_bank (core.py:942-944) only differs from the frame-rate
 // mask of normalize_harmonics inside frames where a harmonic crosses sr/2; for those harmonics the masked
@@ -130,6 +130,15 @@ template <> struct WtPoly<10> {      // 129 .. 200 harmonics on the same 512 poi
 // any K <= 128 (rows that are not 16 bytes apart: ROWS16 = false).  What did NOT pay: fewer row-maker instructions as such
 // (the SIMD serves its wavefronts oldest first; the row makers run in what is left whatever they have to do), the phase
 // tables removed from tabulator 3 or threaded between its MFMAs, s_setprio in any arrangement.
+// 129 .. 200 harmonics (WIDE = NK > 2; BASELINE configs[4]: 48 kHz, 200 harmonics, frames of 192 samples) run here too since the end
+// of round 3 instead of on the direct sum (88 against 212 us at batch 32, profiles/r03u_*): the SAME 512 points read through ten
+// taps (oversampling 1.28; the window's transform is down at (T - K) / T just past its cut-off: <= 5.3e-6 per harmonic, 1 / psi_hat
+// up to 27 at k = 200 - tools/gen_wavetable_coeffs.py), halo 8, planes of 104 halves per row (three buffers of 136 do not fit), four
+// k-steps whose fragments - 128 registers' worth - are fetched from L2 for one parity and row tile at a time and used as they land
+// (a frame of three tiles leaves the tabulators the time), rows spread over whole wavefronts (lane = four harmonics, eight rows per
+// row maker in two passes).  Their pinned loads carry their own wait states (common.h load_issue_spaced): the first build read
+// fragments through stale scalar bases on the chip and nowhere else (profiles/r03u_inline_asm_scalar_hazard.txt).  The instances for
+// K <= 128 are instruction for instruction what they were (only prologue scheduling differs in seven of the 24).
 // Measured and dropped on the way (timelines under profiles/): twelve identical S-wavefronts (r03d: 45.4 us - a wavefront
 // that does three tiles AND a row pair is ~5000 clocks long, the T-wavefronts idle half the tick); a row pair on each
 // T-wavefront as well (r03e: their MFMA section stretches from 2600 to 4000 clocks and they become the critical

@@ -2,7 +2,7 @@
 
   configs[2]  Harmonic + FilteredNoise + losses.SpectralLoss (6 scales), batch 128
   configs[3]  ProcessorGroup Harmonic + FilteredNoise + effects.Reverb (48 000-tap IR), batch 128 per GPU (1024 over 8)
-  configs[4]  48 kHz, 200 harmonics, 10 s clips, batch 32 per GPU (256 over 8): K > 128 runs the direct-sum kernel
+  configs[4]  48 kHz, 200 harmonics, 10 s clips, batch 32 per GPU (256 over 8): the wavetable kernel (129 .. 200 harmonics: ten taps) since the end of round 3
 
     python tools/bench_configs.py
 """
@@ -54,7 +54,7 @@ a, hd, f0, mags = inputs(b, f, k)
 harm = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
 noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
 dt = timed(lambda: (harm(a, hd, f0), noise(mags)), 30)
-out.append({'config': 'configs[4] per GPU: Harmonic (200 harmonics: direct-sum kernel) + FilteredNoise, 10 s @ 48 kHz, frame size 192, batch 32 (256 over 8 GPUs)',
+out.append({'config': 'configs[4] per GPU: Harmonic (200 harmonics: wavetable kernel, ten taps) + FilteredNoise, 10 s @ 48 kHz, frame size 192, batch 32 (256 over 8 GPUs)',
             'ms_per_step': dt * 1e3, 'Msamples_per_s': b * n / dt / 1e6,
             'algorithmic_GBs': 4 * b * (f * (k + 2) + n + f * 65 + n) / dt / 1e9})
 for o in out:

@@ -34,6 +34,12 @@ echo "== rocprofv3 kernel trace, batch 128 (north-star shape, one stream)"
 for f in $(find $OUT/prof128 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_b128.csv; head -6 $f | cut -c1-200; done
 grep "^{\"metric\"" $OUT/rocprof_bench_b128.log | tail -1 > $OUT/bench_b128_under_rocprof.json
 rm -rf $OUT/prof $OUT/prof128
+echo "== configs[4] per GPU (48 kHz, 200 harmonics, 10 s, batch 32): rocprofv3 kernel trace, one stream; then BASELINE's other configurations"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof5 -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 32 --n-frames 2500 --n-harmonics 200 --n-samples 480000 --sample-rate 48000 --steps 200 --warmup 60 --streams 1 --no-cpu-baseline --no-aux --no-second-shape > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_config5.log 2>&1 )
+for f in $(find $OUT/prof5 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_config5.csv; head -4 $f | cut -c1-200; done
+grep "^{\"metric\"" $OUT/rocprof_bench_config5.log | tail -1 > $OUT/bench_config5_under_rocprof.json
+rm -rf $OUT/prof5
+timeout 600 python tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/bench_other_configs.jsonl; cut -c1-220 $OUT/bench_other_configs.jsonl
 echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 > /dev/null 2>&1; cp $OUT/pmc_traffic_b32/pmc_traffic.json $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 > /dev/null 2>&1; cp $OUT/pmc_traffic_b128/pmc_traffic.json $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
