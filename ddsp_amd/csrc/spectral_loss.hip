@@ -199,21 +199,19 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
   }
 }
 
+// One block of one FFT size: G frames of row b from frame bx * G on; nbx = blocks per row of this size.
 template <int S>
-__global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target,
-                                                             const float* __restrict__ audio,
-                                                             double* __restrict__ partial, int N,
-                                                             int n_frames, float safe_eps) {
+__device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThreads / 64], const float* __restrict__ target,
+                                              const float* __restrict__ audio, double* __restrict__ partial, int N,
+                                              int n_frames, float safe_eps, int bx, int b, int nbx) {
   // A real frame x[0..S) is transformed as the complex sequence z[n] = x[2n] + i x[2n+1] of H = S/2
   // points; X[k] = E[k] + exp(-2 pi i k / S) O[k] with E, O untangled from Z[k] and Z[H-k].  An
   // all-zero frame still gives exact zeros (nothing of another frame or signal is mixed in).
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;  // frames per block (of each signal)
   constexpr int LOG2H = __builtin_ctz(H);
-  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
-  __shared__ double red[2][kSlThreads / 64];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int f0 = blockIdx.x * G;
+  const int tid = threadIdx.x;
+  const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
   sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
@@ -258,9 +256,35 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __rest
   if (tid == 0) {
     double a0 = 0.0, a1 = 0.0;
     for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
-    double* out = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+    double* out = partial + 2 * ((size_t)b * nbx + bx);
     out[0] = a0; out[1] = a1;
   }
+}
+
+// Every FFT size of the loss in ONE launch (round 3): a size alone is 2016 blocks at batch 32 - two rounds of four blocks
+// per CU that load, transform and reduce in step, six launches one after the other, each with its own ramp and tail; as one
+// grid (the large sizes first) the blocks of different sizes and phases share the CUs.
+struct SlMulti {
+  int n;
+  int size[16], first[17], nbx[16], frames[16], offset[16];      // per size: S, first linear block, blocks per row, frames, partial offset
+};
+__global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target, const float* __restrict__ audio,
+                                                             double* __restrict__ partial, int N, SlMulti m, float safe_eps) {
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  __shared__ double red[2][kSlThreads / 64];
+  const int blk = (int)blockIdx.x;
+  int z = 0;
+  while (z + 1 < m.n && blk >= m.first[z + 1]) ++z;
+  const int local = blk - m.first[z], nbx = m.nbx[z];
+  const int b = local / nbx, bx = local - b * nbx;
+  double* dst = partial + 2 * (size_t)m.offset[z];
+#define DDSP_SL_BLOCK(SZ) case SZ: stft_l1_block<SZ>(s, red, target, audio, dst, N, m.frames[z], safe_eps, bx, b, nbx); break
+  switch (m.size[z]) {
+    DDSP_SL_BLOCK(16); DDSP_SL_BLOCK(32); DDSP_SL_BLOCK(64); DDSP_SL_BLOCK(128); DDSP_SL_BLOCK(256);
+    DDSP_SL_BLOCK(512); DDSP_SL_BLOCK(1024); DDSP_SL_BLOCK(2048); DDSP_SL_BLOCK(4096);
+    default: break;
+  }
+#undef DDSP_SL_BLOCK
 }
 
 // ---- spectral_ops.compute_mag (ddsp/spectral_ops.py:67-70) with the magnitudes written out ------------------------
@@ -517,24 +541,31 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
   SlFinishArgs fin;
   fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
   int offset = 0;
+  SlMulti m;
+  m.n = n_sizes;
+  long long total = 0;
+  // (the grid in descending order of size - the long blocks first -, whatever order the caller lists them in; the
+  // partial sums stay in the caller's order)
+  int order[16];
+  for (int z = 0; z < n_sizes; ++z) order[z] = z;
+  for (int i = 1; i < n_sizes; ++i)
+    for (int j = i; j > 0 && fft_sizes[order[j]] > fft_sizes[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  for (int z = 0; z < n_sizes; ++z) {
+    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+    fin.offset[z] = offset; fin.count[z] = B * blocks;
+    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+    offset += B * blocks;
+  }
+  for (int i = 0; i < n_sizes; ++i) {
+    const int z = order[i], S = fft_sizes[z];
+    m.size[i] = S; m.first[i] = (int)total; m.nbx[i] = sl_blocks(N, S); m.frames[i] = sl_frames(N, S); m.offset[i] = fin.offset[z];
+    total += (long long)B * m.nbx[i];
+  }
+  m.first[n_sizes] = (int)total;
+  if (total >= (1ll << 31)) return DDSP_ERR_UNSUPPORTED;
   {
     ProfileScope prof(kStftL1, st);
-    for (int z = 0; z < n_sizes; ++z) {
-      const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
-      fin.offset[z] = offset; fin.count[z] = B * blocks;
-      fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
-      const dim3 grid((unsigned)blocks, (unsigned)B);
-      double* dst = partial + 2 * (size_t)offset;
-#define DDSP_SL_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
-                                                     target_audio, audio, dst, N, frames, 1e-5f); break
-      switch (S) {
-        DDSP_SL_CASE(16); DDSP_SL_CASE(32); DDSP_SL_CASE(64); DDSP_SL_CASE(128); DDSP_SL_CASE(256);
-        DDSP_SL_CASE(512); DDSP_SL_CASE(1024); DDSP_SL_CASE(2048); DDSP_SL_CASE(4096);
-        default: return DDSP_ERR_UNSUPPORTED;
-      }
-#undef DDSP_SL_CASE
-      offset += B * blocks;
-    }
+    hipLaunchKernelGGL(stft_l1_kernel, dim3((unsigned)total), dim3(kSlThreads), 0, st, target_audio, audio, partial, N, m, 1e-5f);
   }
   hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(kSlFinishThreads), 0, st, (const double*)partial, loss, fin);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
