@@ -31,6 +31,8 @@ The JSON line also carries
   configs_1        : the same step at BASELINE.json configs[1] (batch 32 per GPU; two streams, `one_stream` beside it),
                      timed the same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
                      fractions of the HBM roofline.  (Rounds 1-2 had the two shapes the other way round.)
+  configs_4        : likewise BASELINE.json configs[4] per GPU (48 kHz, 200 harmonics, 10 s clips, batch 32): the Harmonic
+                     kernel's instances for 129 .. 200 harmonics.
   cpu_baseline     : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
                      here) timed on this host's cores (concurrent worker processes) on a bounded
                      sample of the same workload.
@@ -398,7 +400,7 @@ def main(argv=None):
   if dry:
     _lib = None
 
-    def make_step(B, seed, streams2):
+    def make_step(B, seed, streams2, a=a):
       out = (torch.zeros((B, 1)), torch.zeros((B, 1)))
 
       def step(two_streams=None):
@@ -418,7 +420,7 @@ def main(argv=None):
     stream_h, stream_z = torch.cuda.Stream(), torch.cuda.Stream()
     stream_0 = torch.cuda.current_stream()
 
-    def make_step(B, seed, streams2):
+    def make_step(B, seed, streams2, a=a):
       # ---- per-rank shard of the global batch: independent rows, no data-path collective ----
       x = make_inputs(B, a, seed=seed)
       dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
@@ -699,10 +701,53 @@ def main(argv=None):
     else:
       second = {'batch_per_gpu': BN, 'error': err or 'another rank failed to set this shape up'}
 
+  # ---- BASELINE configs[4] per GPU: 48 kHz, 200 harmonics, 10 s clips (2500 frames of 192 samples), batch 32 ---------
+  # (for the record beside the headline, when the headline is the default shape: the Harmonic kernel's instances for
+  # 129 .. 200 harmonics; same definitions as `configs_1`)
+  fifth = None
+  default_shape = (a.n_frames, a.n_harmonics, a.n_samples, a.sample_rate, a.n_bands) == (1000, 100, 64000, 16000, 65)
+  if second is not None and 'error' not in second and default_shape and not a.no_aux:
+    a5 = argparse.Namespace(**vars(a))
+    a5.n_frames, a5.n_harmonics, a5.n_samples, a5.sample_rate = 2500, 200, 480000, 48000
+    c5_steps = max(10, min(a.steps, 50))
+    err, med_n, med_1, prof_5, bd_5 = None, 0.0, 0.0, None, {}
+    try:
+      del step_n, dev_n
+      step_5, dev_5 = make_step(32, 5000 + rank, True, a5)
+      for _ in range(10):
+        step_5()
+      settle(step_5, 0.02 if not dry else 0.0)
+      if dry:
+        bd_5 = {'dry_run_step': (0.6, 3)}
+      else:
+        _lib.profile_begin(None, max_records=64)
+        for _ in range(3):
+          step_5(two_streams=False)
+        torch.cuda.synchronize()
+        bd_5 = _lib.profile_end()
+    except Exception as exc:                      # noqa: BLE001 - the headline line must survive
+      err = repr(exc)
+    failed = max_over_ranks(1.0 if err else 0.0) > 0.0
+    if not failed:
+      ev_n, _, _ = repeated_regions(step_5, c5_steps, True, 5)
+      if not dry:
+        _lib.profile_begin(list(bd_5), max_records=4 * c5_steps * 3 // max(a.event_stride, 1) + 64, stride=a.event_stride)
+      ev_1, _, _ = repeated_regions(step_5, c5_steps, False, 3)
+      if not dry:
+        prof_5 = _lib.profile_end()
+      fifth = second_block(a5, world, 32, max_over_ranks(statistics.median(ev_n)), c5_steps, prof_5, bd_5,
+                           max_over_ranks(statistics.median(ev_1)))
+      fifth['workload'] = ('BASELINE configs[4] per GPU: Harmonic (200 harmonics) + FilteredNoise, 10 s clips @ 48 kHz, '
+                           '2500 frames of 192 samples, batch 32 (256 over 8 GPUs)')
+    else:
+      fifth = {'batch_per_gpu': 32, 'error': err or 'another rank failed to set this shape up'}
+
   if rank == 0:
     result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms,
                           timing=timing, second=second, one_stream_elapsed=one_stream_elapsed,
                           roofline_timing=roofline_timing, fused_add=fused_add_elapsed)
+    if fifth:
+      result['configs_4'] = fifth
     print(json.dumps(result), flush=True)
 
   if world > 1:
