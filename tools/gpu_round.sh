@@ -24,6 +24,8 @@ print('isolated', d['kernel_breakdown_us_isolated'])
 print('fused add', d.get('fused_add'))
 c1 = d['configs_1']
 print('configs[1] B=32:', round(c1['value']), round(c1['ms_per_step'] * 1e3, 2), 'us frac', round(c1['whole_step']['frac'], 4), c1['kernel_breakdown_us'], c1.get('dominant_kernel', {}).get('frac'))
+c4 = d.get('configs_4')
+if c4: print('configs[4] B=32 48 kHz K=200:', round(c4['value']), round(c4['ms_per_step'] * 1e3, 2), 'us frac', round(c4['whole_step']['frac'], 4), c4['kernel_breakdown_us'], 'one stream', c4.get('one_stream'))
 PY
 echo "== rocprofv3 kernel trace (configs[1], batch 32, two streams)"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --batch 32 --no-cpu-baseline --no-aux --no-second-shape > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
