@@ -320,6 +320,20 @@ def test_gpus_2_without_a_launcher_starts_its_own_ranks():
   assert 'cpu_baseline' not in line and line['steps'] == 5 and line['timing']['repeats'] >= 10
 
 
+def test_default_shape_carries_configs_1_and_configs_4_two_ranks():
+  """The default (north-star) shape on two ranks, dry: the line carries `configs_1` (BASELINE configs[1], batch 32) and
+  `configs_4` (configs[4] per GPU: 48 kHz, 200 harmonics, 10 s clips, batch 32 - the 129 .. 200-harmonic instances of the
+  Harmonic kernel) with the headline's definitions; every rank walks the same collectives through both blocks."""
+  r = _run_bench('--gpus', '2', '--dry-run', '--steps', '4', '--warmup', '1', '--no-cpu-baseline')
+  assert r.returncode == 0, r.stderr[-2000:]
+  line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+  assert line['config']['batch_per_gpu'] == 128 and line['configs_1']['batch_per_gpu'] == 32
+  c4 = line['configs_4']
+  assert c4['batch_per_gpu'] == 32 and '200 harmonics' in c4['workload'] and c4['steps'] == 50
+  assert c4['whole_step']['algorithmic_bytes'] == 4 * 32 * (2500 * 202 + 480000 + 2500 * 65 + 480000)
+  assert c4['value'] == pytest.approx(2 * 32 * 480000 / (c4['ms_per_step'] * 1e-3) / 1e6) and 'one_stream' in c4
+
+
 def test_gpus_2_on_a_box_without_two_gpus_refuses_instead_of_reporting_one():
   r = _run_bench('--gpus', '2', '--steps', '5', '--warmup', '2')
   assert r.returncode != 0 and 'refusing' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
