@@ -30,18 +30,21 @@ __device__ __forceinline__ int SP(int i) { return i + ((i >> 4) << 1); }
       // 16 wavefronts per block: LDS and VALU phases of different wavefronts overlap (tools/microbench5)
 
 // ---- the H-point transforms of all frames of a block, in place in LDS -----------------------------
-// H = 2^L.  Forward = decimation in frequency: one radix-2 stage first when L is odd, then radix-4
-// stages (half the stages, barriers and twiddles of a radix-2 transform).  Bin k ends up at sl_pos(k).
-// The inverse is the algebraic inverse of those stages in reverse order, unscaled (H times the true
-// inverse).  When every stage is radix-4 and a frame's H/4 butterflies fit one wavefront (S = 128,
-// 512) the same wavefront reads and writes a frame in every stage: a wavefront-level wait replaces
-// the block barrier between stages.
+// H = 2^L.  Forward = decimation in frequency in mixed radix: radix-8 stages first, then one or two radix-4 stages
+// (3 n8 + 2 n4 = L): 17 passes over the LDS for the six sizes of the loss where radix-4 (+ a radix-2 stage for odd L)
+// took 24.  A radix-8 stage is one butterfly per thread for the 4096 points of a block; in a radix-4 stage thread t
+// takes butterflies 2 t and 2 t + 1 - so a frame belongs to the same threads in EVERY stage (frame g: threads
+// g H/8 .. (g+1) H/8 - 1), and when that range lies inside one wavefront (H <= 512) a wavefront-level wait replaces the
+// block barrier between stages.  Bin k ends up at sl_pos(k) (digit reversal in the stages' radices).
+// The inverse is the algebraic inverse of those stages in reverse order, unscaled (H times the true inverse).
 template <int H>
 struct SlPlan {
   static constexpr int L = __builtin_ctz(H);
-  static constexpr bool kOdd = (L & 1) != 0;
-  static constexpr int M = kOdd ? H / 2 : H;              // the radix-4 part
-  static constexpr bool kWaveLocal = !kOdd && (H / 4 <= 64);
+  static constexpr int N4 = (L % 3 == 0) ? 0 : ((L % 3 == 2) ? 1 : 2);       // L >= 3, or L = 2 (one radix-4 stage)
+  static constexpr int N8 = (L - 2 * N4) / 3;
+  static constexpr int M = 1 << (2 * N4);                  // the radix-4 part: what the radix-8 stages leave of a frame
+  static constexpr bool kWaveLocal = (H / 8 >= 1) && (H / 8 <= 64);
+  static_assert(3 * N8 + 2 * N4 == L, "stage plan");
 };
 
 template <int H>
@@ -57,9 +60,10 @@ __device__ __forceinline__ void sl_stage_sync() {
 template <int H>
 __device__ __forceinline__ int sl_pos(int k) {             // where bin k sits after sl_forward
   int p = 0, kk = k, m = H;
-  if (SlPlan<H>::kOdd) { p = (kk & 1) * (m / 2); kk >>= 1; m >>= 1; }
 #pragma unroll
-  for (int st = 0; st < SlPlan<H>::L / 2; ++st) { p += (kk & 3) * (m / 4); kk >>= 2; m >>= 2; }
+  for (int st = 0; st < SlPlan<H>::N8; ++st) { p += (kk & 7) * (m / 8); kk >>= 3; m >>= 3; }
+#pragma unroll
+  for (int st = 0; st < SlPlan<H>::N4; ++st) { p += (kk & 3) * (m / 4); kk >>= 2; m >>= 2; }
   return p;
 }
 
@@ -69,42 +73,90 @@ __device__ __forceinline__ float2 sl_cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 sl_cmulc(float2 a, float2 b) {        // a * conj(b)
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
+// |X| from |X|^2: v_sqrt_f32 (1 ulp).  sqrtf() is the correctly rounded expansion - a scale test, the instruction, a one-ulp
+// correction in both directions, the scaling back: sixteen instructions, four times per pair of bins (a quarter of the per-bin
+// part of the loss kernels).  The instruction flushes denormal |X|^2: a bin below 1e-19 in magnitude counts as silent.
+__device__ __forceinline__ float sl_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// log2 (v_log_f32, 1 ulp) where only differences of logarithms are summed: the block's sum is scaled by ln 2 once, in fp64.
+// __logf() is the accurate expansion - a denormal scale test, the instruction, an extended-precision product with ln 2, an
+// infinity test: twelve instructions, four times per pair of bins.  Arguments here are >= safe_eps or normal magnitudes.
+__device__ __forceinline__ float sl_log2(float x) { return __builtin_amdgcn_logf(x); }
+constexpr double kSlLn2 = 0.6931471805599453;
+__device__ __forceinline__ float2 sl_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 sl_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 sl_conj(float2 a) { return make_float2(a.x, -a.y); }
+
+// v[m] <- sum_j v[j] exp(-2 pi i j m / 8), in place, natural order
+__device__ __forceinline__ void sl_dft8(float2 (&v)[8]) {
+  const float kR = 0.70710678118654752f;
+  const float2 b0 = sl_add(v[0], v[4]), b1 = sl_add(v[1], v[5]), b2 = sl_add(v[2], v[6]), b3 = sl_add(v[3], v[7]);
+  const float2 c0 = sl_sub(v[0], v[4]), c1 = sl_sub(v[1], v[5]), c2 = sl_sub(v[2], v[6]), c3 = sl_sub(v[3], v[7]);
+  // even outputs: the 4-point transform of b
+  const float2 t0 = sl_add(b0, b2), t1 = sl_sub(b0, b2), t2 = sl_add(b1, b3), bd = sl_sub(b1, b3);
+  const float2 t3 = make_float2(bd.y, -bd.x);                            // (b1 - b3) (-i)
+  v[0] = sl_add(t0, t2); v[4] = sl_sub(t0, t2); v[2] = sl_add(t1, t3); v[6] = sl_sub(t1, t3);
+  // odd outputs: c_j w^j (w = exp(-2 pi i / 8)), then the 4-point transform
+  const float2 d1 = make_float2((c1.x + c1.y) * kR, (c1.y - c1.x) * kR);          // c1 (1 - i) / sqrt 2
+  const float2 d2 = make_float2(c2.y, -c2.x);                                     // c2 (-i)
+  const float2 d3 = make_float2((c3.y - c3.x) * kR, -(c3.x + c3.y) * kR);         // c3 (-1 - i) / sqrt 2
+  const float2 u0 = sl_add(c0, d2), u1 = sl_sub(c0, d2), u2 = sl_add(d1, d3), ud = sl_sub(d1, d3);
+  const float2 u3 = make_float2(ud.y, -ud.x);
+  v[1] = sl_add(u0, u2); v[5] = sl_sub(u0, u2); v[3] = sl_add(u1, u3); v[7] = sl_sub(u1, u3);
+}
+
+// the powers 1 .. 7 of w1 (w[0] is unused)
+__device__ __forceinline__ void sl_powers8(float2 w1, float2 (&w)[8]) {
+  w[1] = w1; w[2] = sl_cmul(w1, w1); w[3] = sl_cmul(w[2], w1); w[4] = sl_cmul(w[2], w[2]);
+  w[5] = sl_cmul(w[4], w1); w[6] = sl_cmul(w[3], w[3]); w[7] = sl_cmul(w[4], w[3]);
+}
 
 // frames g_lo .. g_lo + n_fr - 1 (H points each) of the array s
 template <int H>
 __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
   constexpr int LOG2H = SlPlan<H>::L;
-  if (SlPlan<H>::kOdd) {
-    constexpr int half = H / 2;
-    for (int t = tid; t < n_fr * half; t += kSlThreads) {
-      const int g = (t >> (LOG2H - 1)) + g_lo, pos = t & (half - 1);
-      const int i0 = (g << LOG2H) + pos;
-      const float2 a = s[SP(i0)], b = s[SP(i0 + half)];
-      const float rev = (float)pos * (1.0f / (float)H);
-      const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));   // conj of the twiddle
-      s[SP(i0)] = make_float2(a.x + b.x, a.y + b.y);
-      s[SP(i0 + half)] = sl_cmulc(make_float2(a.x - b.x, a.y - b.y), w);
+  if constexpr (SlPlan<H>::N8 > 0) {
+#pragma unroll 1
+    for (int q = H / 8; q >= SlPlan<H>::M; q >>= 3) {          // sub-length 8 q: H, H / 8, ..
+      const float inv_len = 0.125f / (float)q;
+      for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
+        const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
+        const int pos = r & (q - 1);
+        const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
+        float2 v[8], w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s[SP(i0 + j * q)];
+        const float rev = (float)pos * inv_len;
+        sl_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
+        sl_dft8(v);
+        s[SP(i0)] = v[0];
+#pragma unroll
+        for (int m = 1; m < 8; ++m) s[SP(i0 + m * q)] = sl_cmulc(v[m], w[m]);
+      }
+      sl_stage_sync<H>();
     }
-    sl_stage_sync<H>();
   }
 #pragma unroll 1
   for (int q = SlPlan<H>::M / 4; q >= 1; q >>= 2) {
     const float inv_len = 0.25f / (float)q;
-    for (int t = tid; t < n_fr * (H / 4); t += kSlThreads) {
-      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
-      const int pos = r & (q - 1);
-      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
-      const float2 a = s[SP(i0)], b = s[SP(i0 + q)], c = s[SP(i0 + 2 * q)], d = s[SP(i0 + 3 * q)];
-      const float rev = (float)pos * inv_len;
-      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
-      const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
-      const float2 t2 = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
-      const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
-      s[SP(i0)] = make_float2(t0.x + t2.x, t0.y + t2.y);
-      s[SP(i0 + q)] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
-      s[SP(i0 + 2 * q)] = sl_cmulc(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
-      s[SP(i0 + 3 * q)] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+    for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t2 + u;
+        const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+        const int pos = r & (q - 1);
+        const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+        const float2 a = s[SP(i0)], b = s[SP(i0 + q)], c = s[SP(i0 + 2 * q)], d = s[SP(i0 + 3 * q)];
+        const float rev = (float)pos * inv_len;
+        const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+        const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
+        const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
+        const float2 tb = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
+        const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
+        s[SP(i0)] = make_float2(t0.x + tb.x, t0.y + tb.y);
+        s[SP(i0 + q)] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
+        s[SP(i0 + 2 * q)] = sl_cmulc(make_float2(t0.x - tb.x, t0.y - tb.y), w2);
+        s[SP(i0 + 3 * q)] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+      }
     }
     sl_stage_sync<H>();
   }
@@ -116,37 +168,50 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
 #pragma unroll 1
   for (int q = 1; q <= SlPlan<H>::M / 4; q <<= 2) {
     const float inv_len = 0.25f / (float)q;
-    for (int t = tid; t < n_fr * (H / 4); t += kSlThreads) {
-      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
-      const int pos = r & (q - 1);
-      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
-      const float rev = (float)pos * inv_len;
-      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
-      const float2 y0 = s[SP(i0)], y1 = sl_cmul(s[SP(i0 + q)], w1), y2 = sl_cmul(s[SP(i0 + 2 * q)], w2),
-                   y3 = sl_cmul(s[SP(i0 + 3 * q)], w3);
-      const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), t2 = make_float2(y0.x - y2.x, y0.y - y2.y);
-      const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
-      const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
-      s[SP(i0)] = make_float2(t0.x + t1.x, t0.y + t1.y);
-      s[SP(i0 + 2 * q)] = make_float2(t0.x - t1.x, t0.y - t1.y);
-      s[SP(i0 + q)] = make_float2(t2.x + bd.x, t2.y + bd.y);
-      s[SP(i0 + 3 * q)] = make_float2(t2.x - bd.x, t2.y - bd.y);
+    for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t2 + u;
+        const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+        const int pos = r & (q - 1);
+        const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+        const float rev = (float)pos * inv_len;
+        const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+        const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
+        const float2 y0 = s[SP(i0)], y1 = sl_cmul(s[SP(i0 + q)], w1), y2 = sl_cmul(s[SP(i0 + 2 * q)], w2),
+                     y3 = sl_cmul(s[SP(i0 + 3 * q)], w3);
+        const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), tc = make_float2(y0.x - y2.x, y0.y - y2.y);
+        const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
+        const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
+        s[SP(i0)] = make_float2(t0.x + t1.x, t0.y + t1.y);
+        s[SP(i0 + 2 * q)] = make_float2(t0.x - t1.x, t0.y - t1.y);
+        s[SP(i0 + q)] = make_float2(tc.x + bd.x, tc.y + bd.y);
+        s[SP(i0 + 3 * q)] = make_float2(tc.x - bd.x, tc.y - bd.y);
+      }
     }
     sl_stage_sync<H>();
   }
-  if (SlPlan<H>::kOdd) {
-    constexpr int half = H / 2;
-    for (int t = tid; t < n_fr * half; t += kSlThreads) {
-      const int g = (t >> (LOG2H - 1)) + g_lo, pos = t & (half - 1);
-      const int i0 = (g << LOG2H) + pos;
-      const float rev = (float)pos * (1.0f / (float)H);
-      const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      const float2 pp = s[SP(i0)], qw = sl_cmul(s[SP(i0 + half)], w);  // undo (a+b, (a-b) conj(w))
-      s[SP(i0)] = make_float2(pp.x + qw.x, pp.y + qw.y);
-      s[SP(i0 + half)] = make_float2(pp.x - qw.x, pp.y - qw.y);
+  if constexpr (SlPlan<H>::N8 > 0) {
+#pragma unroll 1
+    for (int q = SlPlan<H>::M; q <= H / 8; q <<= 3) {
+      const float inv_len = 0.125f / (float)q;
+      for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
+        const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
+        const int pos = r & (q - 1);
+        const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
+        const float rev = (float)pos * inv_len;
+        float2 v[8], w[8];
+        sl_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
+        // undo y_m conj(w^m), then the conjugate transform: sum_m y_m exp(+2 pi i j m / 8) = conj(dft8(conj y))
+        v[0] = sl_conj(s[SP(i0)]);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) v[m] = sl_conj(sl_cmul(s[SP(i0 + m * q)], w[m]));
+        sl_dft8(v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[SP(i0 + j * q)] = sl_conj(v[j]);
+      }
+      sl_stage_sync<H>();
     }
-    sl_stage_sync<H>();
   }
 }
 
@@ -238,15 +303,15 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
         const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
         const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);      // W^k O = (c - i sn) O
         const float x1r = ex + wx, x1i = ey + wy, x2r = ex - wx, x2i = ey - wy;
-        m1[sig] = sqrtf(fmaf(x1r, x1r, x1i * x1i));                             // |X[k]|
-        m2[sig] = sqrtf(fmaf(x2r, x2r, x2i * x2i));                             // |X[S/2 - k]|
+        m1[sig] = sl_sqrt(fmaf(x1r, x1r, x1i * x1i));                             // |X[k]|
+        m2[sig] = sl_sqrt(fmaf(x2r, x2r, x2i * x2i));                             // |X[S/2 - k]|
       }
       dm += fabsf(m1[0] - m1[1]);
       // core.safe_log (core.py:213-216): non-positive -> eps
-      dl += fabsf(__logf(m1[0] <= 0.0f ? safe_eps : m1[0]) - __logf(m1[1] <= 0.0f ? safe_eps : m1[1]));
+      dl += fabsf(sl_log2(m1[0] <= 0.0f ? safe_eps : m1[0]) - sl_log2(m1[1] <= 0.0f ? safe_eps : m1[1]));
       if (2 * k != H) {                                                         // (the self-paired bin S/4 counts once)
         dm += fabsf(m2[0] - m2[1]);
-        dl += fabsf(__logf(m2[0] <= 0.0f ? safe_eps : m2[0]) - __logf(m2[1] <= 0.0f ? safe_eps : m2[1]));
+        dl += fabsf(sl_log2(m2[0] <= 0.0f ? safe_eps : m2[0]) - sl_log2(m2[1] <= 0.0f ? safe_eps : m2[1]));
       }
     }
   }
@@ -257,7 +322,7 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
     double a0 = 0.0, a1 = 0.0;
     for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
     double* out = partial + 2 * ((size_t)b * nbx + bx);
-    out[0] = a0; out[1] = a1;
+    out[0] = a0; out[1] = a1 * kSlLn2;            // (the log terms were summed in base 2)
   }
 }
 
@@ -320,7 +385,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_mag_kernel(const float* __res
         const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
         const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
         const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
-        (sig ? mag_a : mag_t)[o] = sqrtf(fmaf(xr, xr, xi * xi));
+        (sig ? mag_a : mag_t)[o] = sl_sqrt(fmaf(xr, xr, xi * xi));
       }
     }
   }
@@ -385,22 +450,22 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
     // dL/dX for one bin: coefficient * X_a / |X_a|
     auto bin_grad = [&](float2 xt, float2 xa, bool count, int bin) {
       if constexpr (COT) {
-        const float ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+        const float ma = sl_sqrt(fmaf(xa.x, xa.x, xa.y * xa.y));
         if (!(ma > 0.0f)) return make_float2(0.f, 0.f);           // |z| has gradient 0 at z = 0 (tf.abs)
-        const float coef = cot[((size_t)b * n_frames + f0 + g) * (H + 1) + bin] / ma;
+        const float coef = cot[((size_t)b * n_frames + f0 + g) * (H + 1) + bin] * __builtin_amdgcn_rcpf(ma);
         return make_float2(coef * xa.x, coef * xa.y);
       }
-      const float mt = sqrtf(fmaf(xt.x, xt.x, xt.y * xt.y)), ma = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+      const float mt = sl_sqrt(fmaf(xt.x, xt.x, xt.y * xt.y)), ma = sl_sqrt(fmaf(xa.x, xa.x, xa.y * xa.y));
       if (count) {                                              // every bin 0 .. S/2 exactly once
         dm_sum += fabsf(mt - ma);
-        dl_sum += fabsf(__logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma <= 0.0f ? safe_eps : ma));
+        dl_sum += fabsf(sl_log2(mt <= 0.0f ? safe_eps : mt) - sl_log2(ma <= 0.0f ? safe_eps : ma));
       }
       if (!(ma > 0.0f)) return make_float2(0.f, 0.f);
       const float dmag = mt - ma;
-      const float dlog = __logf(mt <= 0.0f ? safe_eps : mt) - __logf(ma);
+      const float dlog = sl_log2(mt <= 0.0f ? safe_eps : mt) - sl_log2(ma);
       const float sm = dmag > 0.0f ? 1.0f : (dmag < 0.0f ? -1.0f : 0.0f);
       const float sl = dlog > 0.0f ? 1.0f : (dlog < 0.0f ? -1.0f : 0.0f);
-      const float inv = 1.0f / ma;
+      const float inv = __builtin_amdgcn_rcpf(ma);
       const float coef = -(ms * sm + ls * sl * inv) * inv;
       return make_float2(coef * xa.x, coef * xa.y);
     };
@@ -461,7 +526,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
       double a0 = 0.0, a1 = 0.0;
       for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
       double* out = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
-      out[0] = a0; out[1] = a1;
+      out[0] = a0; out[1] = a1 * kSlLn2;            // (the log terms were summed in base 2)
     }
   }
 }
