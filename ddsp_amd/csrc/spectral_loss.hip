@@ -332,6 +332,7 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
 struct SlMulti {
   int n;
   int size[16], first[17], nbx[16], frames[16], offset[16];      // per size: S, first linear block, blocks per row, frames, partial offset
+  float mag_scale[16], log_scale[16];                            // (the gradient kernel: weight / count of the size)
 };
 __global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                              double* __restrict__ partial, int N, SlMulti m, float safe_eps) {
@@ -402,22 +403,19 @@ __global__ __launch_bounds__(kSlThreads) void stft_mag_kernel(const float* __res
 // sample: fp32 atomics, so the last bit may differ from run to run).
 // COT (the general form of the loss, csrc/spectral_terms.hip): dL/d|X_a| is read from `cot` [B, frames, S/2+1] instead
 // of being formed from the two spectra here; `target` is not looked at (the caller passes `audio` for it).
-template <int S, bool COT = false>
-__global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __restrict__ target,
-                                                                 const float* __restrict__ audio,
-                                                                 const float* __restrict__ grad_loss,
-                                                                 float* __restrict__ grad_audio, int N,
-                                                                 int n_frames, float safe_eps,
-                                                                 float mag_scale, float log_scale,
-                                                                 double* __restrict__ partial,
-                                                                 const float* __restrict__ cot) {
+// One block of one FFT size (frames bx G .. of row b; nbx = blocks per row of this size).
+template <int S, bool COT>
+__device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlThreads / 64], const float* __restrict__ target,
+                                                  const float* __restrict__ audio, const float* __restrict__ grad_loss,
+                                                  float* __restrict__ grad_audio, int N, int n_frames, float safe_eps,
+                                                  float mag_scale, float log_scale, double* __restrict__ partial,
+                                                  const float* __restrict__ cot, int bx, int b, int nbx) {
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;
   constexpr int LOG2H = __builtin_ctz(H);
   constexpr int HOP = S / 4;
-  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int f0 = blockIdx.x * G;
+  const int tid = threadIdx.x;
+  const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
   sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
@@ -505,30 +503,66 @@ __global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __
     if (n >= N) continue;
     const int gp = pidx >> LOG2HOP, ir = pidx & (HOP - 1);
     float acc = 0.0f;
+    // the window at i = ir + jj S/4: cos(x + jj pi/2) = cos x, -sin x, -cos x, sin x - one sine and one cosine for the four frames
+    const float wrev = (float)ir * (1.0f / (float)S);
+    const float hc = 0.5f * __builtin_amdgcn_cosf(wrev), hs = 0.5f * __builtin_amdgcn_sinf(wrev);
+    const float wj[4] = {0.5f - hc, 0.5f + hs, 0.5f + hc, 0.5f - hs};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int g = gp - jj, i = ir + jj * HOP;               // frame g covers the sample at its index i
       if (g >= 0 && g < G && f0 + g < n_frames) {
         const float2 u = s[SP(((g + G) << LOG2H) + (i >> 1))];
-        const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)S));
-        acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
+        acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), wj[jj], acc);
       }
     }
-    if (gp >= 3 && gp <= G - 1) grow[n] += acc;
-    else unsafeAtomicAdd(&grow[n], acc);
+    // (one fp32 atomic per sample and block, every one of them: blocks of every FFT size run side by side since the end of
+    // round 3.  Rounds 2-3 kept plain read-modify-writes for the samples a block owns among the blocks of ITS size - and
+    // were no faster for it: 190 us against 182 with atomics throughout, profiles/r03v_*)
+    unsafeAtomicAdd(&grow[n], acc);
   }
   if (partial) {                                               // block-uniform
-    __shared__ double red[2][kSlThreads / 64];
     const double sm = (double)wave_sum(dm_sum), sl = (double)wave_sum(dl_sum);
     if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sl; }
     __syncthreads();
     if (tid == 0) {
       double a0 = 0.0, a1 = 0.0;
       for (int w = 0; w < kSlThreads / 64; ++w) { a0 += red[0][w]; a1 += red[1][w]; }
-      double* out = partial + 2 * ((size_t)b * gridDim.x + blockIdx.x);
+      double* out = partial + 2 * ((size_t)b * nbx + bx);
       out[0] = a0; out[1] = a1 * kSlLn2;            // (the log terms were summed in base 2)
     }
   }
+}
+
+// Value and gradient of the 'L1' mag + logmag loss: every FFT size in one grid, as stft_l1_kernel.
+__global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __restrict__ target, const float* __restrict__ audio,
+                                                                 const float* __restrict__ grad_loss,
+                                                                 float* __restrict__ grad_audio, int N, SlMulti m,
+                                                                 float safe_eps, double* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  __shared__ double red[2][kSlThreads / 64];
+  const int blk = (int)blockIdx.x;
+  int z = 0;
+  while (z + 1 < m.n && blk >= m.first[z + 1]) ++z;
+  const int local = blk - m.first[z], nbx = m.nbx[z];
+  const int b = local / nbx, bx = local - b * nbx;
+  double* dst = partial ? partial + 2 * (size_t)m.offset[z] : nullptr;
+#define DDSP_SLB_BLOCK(SZ) case SZ: stft_l1_bwd_block<SZ, false>(s, red, target, audio, grad_loss, grad_audio, N, m.frames[z], \
+                                                                 safe_eps, m.mag_scale[z], m.log_scale[z], dst, nullptr, bx, b, nbx); break
+  switch (m.size[z]) {
+    DDSP_SLB_BLOCK(16); DDSP_SLB_BLOCK(32); DDSP_SLB_BLOCK(64); DDSP_SLB_BLOCK(128); DDSP_SLB_BLOCK(256);
+    DDSP_SLB_BLOCK(512); DDSP_SLB_BLOCK(1024); DDSP_SLB_BLOCK(2048); DDSP_SLB_BLOCK(4096);
+    default: break;
+  }
+#undef DDSP_SLB_BLOCK
+}
+
+// The general loss's gradient through one scale (COT): one launch per size - its cotangents are a buffer per size.
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_cot_bwd_kernel(const float* __restrict__ audio, float* __restrict__ grad_audio,
+                                                                  int N, int n_frames, const float* __restrict__ cot) {
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  stft_l1_bwd_block<S, true>(s, nullptr, audio, audio, nullptr, grad_audio, N, n_frames, 1e-5f, 0.0f, 0.0f, nullptr, cot,
+                             (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 struct SlFinishArgs {
@@ -575,6 +609,26 @@ __global__ __launch_bounds__(kSlFinishThreads) void spectral_loss_finish_kernel(
 static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }
 static inline int sl_blocks(int N, int S) { const int g = kSlPoints / S; return (sl_frames(N, S) + g - 1) / g; }
 static inline bool sl_size_ok(int S) { return S >= 16 && S <= kSlPoints && (S & (S - 1)) == 0; }
+// the one grid of all sizes: in descending order of size - the long blocks first -, whatever order the caller lists them
+// in (the partial sums stay in the caller's order: fin.offset)
+struct SlFinishArgs;
+template <class Fin>
+static inline bool sl_plan_grid(SlMulti& m, const Fin& fin, int B, int N, const int* fft_sizes, int n_sizes) {
+  int order[16];
+  for (int z = 0; z < n_sizes; ++z) order[z] = z;
+  for (int i = 1; i < n_sizes; ++i)
+    for (int j = i; j > 0 && fft_sizes[order[j]] > fft_sizes[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  long long total = 0;
+  m.n = n_sizes;
+  for (int i = 0; i < n_sizes; ++i) {
+    const int z = order[i], S = fft_sizes[z];
+    m.size[i] = S; m.first[i] = (int)total; m.nbx[i] = sl_blocks(N, S); m.frames[i] = sl_frames(N, S); m.offset[i] = fin.offset[z];
+    m.mag_scale[i] = 0.0f; m.log_scale[i] = 0.0f;
+    total += (long long)B * m.nbx[i];
+  }
+  m.first[n_sizes] = (int)total;
+  return total < (1ll << 31);
+}
 
 }  // namespace ddsp
 
@@ -606,31 +660,17 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
   SlFinishArgs fin;
   fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
   int offset = 0;
-  SlMulti m;
-  m.n = n_sizes;
-  long long total = 0;
-  // (the grid in descending order of size - the long blocks first -, whatever order the caller lists them in; the
-  // partial sums stay in the caller's order)
-  int order[16];
-  for (int z = 0; z < n_sizes; ++z) order[z] = z;
-  for (int i = 1; i < n_sizes; ++i)
-    for (int j = i; j > 0 && fft_sizes[order[j]] > fft_sizes[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   for (int z = 0; z < n_sizes; ++z) {
     const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
     fin.offset[z] = offset; fin.count[z] = B * blocks;
     fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
     offset += B * blocks;
   }
-  for (int i = 0; i < n_sizes; ++i) {
-    const int z = order[i], S = fft_sizes[z];
-    m.size[i] = S; m.first[i] = (int)total; m.nbx[i] = sl_blocks(N, S); m.frames[i] = sl_frames(N, S); m.offset[i] = fin.offset[z];
-    total += (long long)B * m.nbx[i];
-  }
-  m.first[n_sizes] = (int)total;
-  if (total >= (1ll << 31)) return DDSP_ERR_UNSUPPORTED;
+  SlMulti m;
+  if (!sl_plan_grid(m, fin, B, N, fft_sizes, n_sizes)) return DDSP_ERR_UNSUPPORTED;
   {
     ProfileScope prof(kStftL1, st);
-    hipLaunchKernelGGL(stft_l1_kernel, dim3((unsigned)total), dim3(kSlThreads), 0, st, target_audio, audio, partial, N, m, 1e-5f);
+    hipLaunchKernelGGL(stft_l1_kernel, dim3((unsigned)m.first[n_sizes]), dim3(kSlThreads), 0, st, target_audio, audio, partial, N, m, 1e-5f);
   }
   hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(kSlFinishThreads), 0, st, (const double*)partial, loss, fin);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
@@ -656,27 +696,23 @@ static int sl_backward_impl(const float* target_audio, const float* audio, const
   SlFinishArgs fin;
   fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
   int offset = 0;
+  for (int z = 0; z < n_sizes; ++z) {
+    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+    fin.offset[z] = offset; fin.count[z] = B * blocks;
+    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+    offset += B * blocks;
+  }
+  SlMulti m;
+  if (!sl_plan_grid(m, fin, B, N, fft_sizes, n_sizes)) return DDSP_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_sizes; ++i) {
+    const float inv_count = (float)(1.0 / ((double)B * (double)m.frames[i] * (double)(m.size[i] / 2 + 1)));
+    m.mag_scale[i] = mag_weight * inv_count;
+    m.log_scale[i] = logmag_weight * inv_count;
+  }
   {
     ProfileScope prof(kStftL1Bwd, st);
-    for (int z = 0; z < n_sizes; ++z) {
-      const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
-      const double inv_elems = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
-      const float inv_count = (float)inv_elems;
-      fin.offset[z] = offset; fin.count[z] = B * blocks; fin.inv_elems[z] = inv_elems;
-      double* dst = partial ? partial + 2 * (size_t)offset : nullptr;
-      const dim3 grid((unsigned)blocks, (unsigned)B);
-#define DDSP_SLB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
-                                                      target_audio, audio, grad_loss, grad_audio, N, frames, 1e-5f, \
-                                                      mag_weight * inv_count, logmag_weight * inv_count, dst, \
-                                                      (const float*)nullptr); break
-      switch (S) {
-        DDSP_SLB_CASE(16); DDSP_SLB_CASE(32); DDSP_SLB_CASE(64); DDSP_SLB_CASE(128); DDSP_SLB_CASE(256);
-        DDSP_SLB_CASE(512); DDSP_SLB_CASE(1024); DDSP_SLB_CASE(2048); DDSP_SLB_CASE(4096);
-        default: return DDSP_ERR_UNSUPPORTED;
-      }
-#undef DDSP_SLB_CASE
-      offset += B * blocks;
-    }
+    hipLaunchKernelGGL(stft_l1_bwd_kernel, dim3((unsigned)m.first[n_sizes]), dim3(kSlThreads), 0, st, target_audio, audio,
+                       grad_loss, grad_audio, N, m, 1e-5f, partial);
   }
   if (loss)
     hipLaunchKernelGGL(spectral_loss_finish_kernel, dim3(1), dim3(kSlFinishThreads), 0, st, (const double*)partial, loss, fin);
@@ -732,9 +768,8 @@ extern "C" int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_
   hipStream_t st = (hipStream_t)stream;
   const int S = fft_size, frames = sl_frames(N, S), blocks = sl_blocks(N, S);
   const dim3 grid((unsigned)blocks, (unsigned)B);
-#define DDSP_SMB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_l1_bwd_kernel<SZ, true>), grid, dim3(kSlThreads), 0, st, \
-                                                      audio, audio, (const float*)nullptr, grad_audio, N, frames, 1e-5f, \
-                                                      0.0f, 0.0f, (double*)nullptr, grad_mag); break
+#define DDSP_SMB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_cot_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
+                                                      audio, grad_audio, N, frames, grad_mag); break
   switch (S) {
     DDSP_SMB_CASE(16); DDSP_SMB_CASE(32); DDSP_SMB_CASE(64); DDSP_SMB_CASE(128); DDSP_SMB_CASE(256);
     DDSP_SMB_CASE(512); DDSP_SMB_CASE(1024); DDSP_SMB_CASE(2048); DDSP_SMB_CASE(4096);

@@ -54,6 +54,19 @@ if not only or only == 'loss':
     torch.cuda.synchronize()
     bd = _lib.profile_end()
     res['loss_fwd_%%s' %% ('all' if len(sizes) > 1 else sizes[0])] = round(sum(v[0] for v in bd.values()) / 50 * 1e3, 1)
+    if len(sizes) > 1:                      # value + gradient (the training path: ddsp_spectral_loss_value_and_grad_f32)
+      at = a.clone().requires_grad_(True)
+      def fb():
+        at.grad = None
+        loss(t, at).backward()
+      for _ in range(20): fb()
+      torch.cuda.synchronize()
+      _lib.profile_begin(None, max_records=2048)
+      for _ in range(50): fb()
+      torch.cuda.synchronize()
+      bd = _lib.profile_end()
+      res['loss_fwdbwd_all'] = round(sum(v[0] for v in bd.values()) / 50 * 1e3, 1)
+      res['loss_fwdbwd_kernels'] = {k: round(v[0] / 50 * 1e3, 1) for k, v in bd.items()}
 print('AB ' + json.dumps(res))
 '''
 
@@ -77,8 +90,10 @@ def main():
   import statistics
   for n in names:
     if runs[n]:
-      print(json.dumps({'variant': n, 'median_us': {k: statistics.median(r[k] for r in runs[n]) for k in runs[n][0]},
-                        'all': {k: [r[k] for r in runs[n]] for k in runs[n][0]}}))
+      num = [k for k in runs[n][0] if not isinstance(runs[n][0][k], dict)]
+      print(json.dumps({'variant': n, 'median_us': {k: statistics.median(r[k] for r in runs[n]) for k in num},
+                        'all': {k: [r[k] for r in runs[n]] for k in num},
+                        'kernels': {k: runs[n][0][k] for k in runs[n][0] if isinstance(runs[n][0][k], dict)}}))
 
 if __name__ == '__main__':
   main()
