@@ -1057,7 +1057,12 @@ __global__ __launch_bounds__(256) void noise_bwd_mags_kernel(const float* __rest
     }
     __builtin_amdgcn_s_waitcnt(0);                           // this wavefront's LDS writes (in order per wave)
     __builtin_amdgcn_wave_barrier();
-    for (int m = lane; m < 65; m += 64) {                    // magnitude bin (lane 0 also takes bin 64)
+    // bins 0 .. 63: one per lane, 33 terms each; bin 64 (even, i = 32): its 33 terms one per lane and a wavefront sum -
+    // as a second trip through the loop above it was 33 serial steps on lane 0 with 63 lanes waiting, half the kernel
+    float acc64 = (lane <= 32) ? s_tab[32 + lane * kIrRowStride] * s_eo[wave][lane] : 0.0f;
+    acc64 = wave_sum(acc64);
+    {
+      const int m = lane;
       const int i = m >> 1, odd = m & 1;
       const float* __restrict__ tab = s_tab + (odd ? 40 + i : i);
       const float* __restrict__ src = &s_eo[wave][odd ? 40 : 0];
@@ -1072,9 +1077,19 @@ __global__ __launch_bounds__(256) void noise_bwd_mags_kernel(const float* __rest
       if (p.scale) {
         const float xr = mag[at] + p.bias;
         const float y = exp_sigmoid_fast(xr, 2.302585092994046f, 2.0f, 1e-7f);
-        acc *= 2.302585092994046f * (y - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-xr)));
+        acc *= 2.302585092994046f * (y - 1e-7f) * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-xr)));
       }
       grad_mag[at] = acc;
+      if (lane == 0) {
+        const size_t at64 = (size_t)row * 65 + 64;
+        float a64 = acc64;
+        if (p.scale) {
+          const float xr = mag[at64] + p.bias;
+          const float y = exp_sigmoid_fast(xr, 2.302585092994046f, 2.0f, 1e-7f);
+          a64 *= 2.302585092994046f * (y - 1e-7f) * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-xr)));
+        }
+        grad_mag[at64] = a64;
+      }
     }
     __builtin_amdgcn_s_waitcnt(0);                           // s_eo is rewritten by the next row of this wavefront
     __builtin_amdgcn_wave_barrier();
