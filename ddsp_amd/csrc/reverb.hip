@@ -17,7 +17,7 @@
 // m-1 in its real part and block m in its imaginary part (rv_ifft_kernel): half the inverse FFTs and
 // half the multiply-adds of the plain scheme.
 //
-// The forward transform is an in-place radix-4 decimation-in-frequency FFT that leaves its bins in
+// The forward transform is an in-place radix-8 (+ one radix-2 stage) decimation-in-frequency FFT that leaves its bins in
 // digit-reversed order; the inverse undoes it stage by stage: the per-bin products do not care
 // about the order, so no reordering pass exists anywhere.  Twiddles come from
 // v_sin_f32 / v_cos_f32 on exact binary fractions of a revolution (abs. error 1.2e-7,
@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include "common.h"
 #include "profile.h"
+#include "fft_radix8.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
@@ -34,7 +35,7 @@ namespace ddsp {
 constexpr int kRvP = 4096;             // output samples per block = taps per IR partition
 constexpr int kRvN = 2 * kRvP;         // FFT size
 constexpr int kRvMaxParts = 16;        // IR partitions held in registers by the MAC kernel
-constexpr int kRvThreads = 1024;      // FFT blocks: 16 wavefronts on one 64 KB LDS array (2 radix-4 butterflies per lane per
+constexpr int kRvThreads = 1024;      // FFT blocks: 16 wavefronts on one 64 KB LDS array (one radix-8 butterfly per lane per
                                        // stage): with 4 wavefronts a stage took 1.3 us - one wavefront per SIMD cannot overlap
                                        // its own LDS and VALU phases (tools/microbench5)
 constexpr int kRvMacThreads = 256;
@@ -48,8 +49,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 
-// 8192 = 2 * 4^6: six radix-4 stages and one radix-2 stage, in place, 256 threads, one barrier per
-// stage.  Forward (decimation in frequency, kernel exp(-2 pi i nk/N)) leaves the bins in a
+// In place, 1024 threads, one barrier per stage.  Forward (decimation in frequency, kernel exp(-2 pi i nk/N)) leaves the bins in a
 // digit-reversed order; the inverse is the exact algebraic inverse of the forward pipeline - the
 // stages undone one by one in reverse order (conjugate twiddles, conjugate 4-point DFT, factor 1/N
 // left to the caller) - so it accepts that order and returns natural order, whatever the order is.
@@ -59,51 +59,36 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {          // a * co
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
 
-// All loads of a stage are issued before any arithmetic and all stores after it (the butterflies of
-// a stage touch disjoint elements, which the compiler cannot see through the LDS indices): 32 LDS
-// reads in flight per lane instead of 4 - a block of 4 wavefronts has nothing else to hide latency.
-constexpr int kRvBf = kRvN / 4 / kRvThreads;                   // radix-4 butterflies per thread per stage (8)
+// 8192 = 8^4 * 2: four radix-8 stages (one butterfly per thread: its eight loads are issued before any arithmetic and its
+// stores after it - the butterflies of a stage touch disjoint elements, which the compiler cannot see through the LDS
+// indices) and the radix-2 stage on neighbours: five passes over the LDS and five barriers where radix 4 took seven
+// (rounds 1-3; the SpectralLoss transforms went the same way: csrc/fft_radix8.h).
+constexpr int kRvPairs = kRvN / 2 / kRvThreads;                // float4 pairs per thread in the radix-2 stage (4)
+static_assert(kRvN / 8 == kRvThreads, "one radix-8 butterfly per thread");
 
 __device__ __forceinline__ void fft_forward(float2* s, int tid) {
 #pragma unroll 1
-  for (int q = kRvN / 4; q >= 2; q >>= 2) {                    // q = 2048, 512, 128, 32, 8, 2
-    const float inv_len = 0.25f / (float)q;                    // exact: powers of two
-    float2 v[kRvBf][4];
-    int idx[kRvBf];
+  for (int q = kRvN / 8; q >= 2; q >>= 3) {                    // q = 1024, 128, 16, 2
+    const float inv_len = 0.125f / (float)q;                   // exact: powers of two
+    const int pos = tid & (q - 1);
+    const int i0 = ((tid - pos) << 3) + pos;
+    float2 v[8], w[8];
 #pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-      const int t = tid + kRvThreads * u, pos = t & (q - 1);
-      idx[u] = ((t - pos) << 2) + pos;
+    for (int m = 0; m < 8; ++m) v[m] = s[RP(i0 + m * q)];
+    const float rev = (float)pos * inv_len;                    // revolutions, exact
+    fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);      // conj of the twiddles
+    fft_dft8(v);
+    s[RP(i0)] = v[0];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) v[u][m] = s[RP(idx[u] + m * q)];
-    }
-#pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-      const int pos = (tid + kRvThreads * u) & (q - 1);
-      const float rev = (float)pos * inv_len;                  // revolutions, exact
-      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));   // conj of the twiddle
-      const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-      const float2 t0 = cadd(v[u][0], v[u][2]), t1 = csub(v[u][0], v[u][2]), t2 = cadd(v[u][1], v[u][3]),
-                   bd = csub(v[u][1], v[u][3]);
-      const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
-      v[u][0] = cadd(t0, t2);
-      v[u][1] = cmulc(cadd(t1, t3), w1);
-      v[u][2] = cmulc(csub(t0, t2), w2);
-      v[u][3] = cmulc(csub(t1, t3), w3);
-    }
-#pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) s[RP(idx[u] + m * q)] = v[u][m];
-    }
+    for (int m = 1; m < 8; ++m) s[RP(i0 + m * q)] = cmulc(v[m], w[m]);
     __syncthreads();
   }
   {                                                            // radix-2, neighbours, twiddle 1
-    float4 v[2 * kRvBf];
+    float4 v[kRvPairs];
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
+    for (int u = 0; u < kRvPairs; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u)
+    for (int u = 0; u < kRvPairs; ++u)
       *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
           make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
   }
@@ -112,47 +97,30 @@ __device__ __forceinline__ void fft_forward(float2* s, int tid) {
 
 __device__ __forceinline__ void fft_inverse(float2* s, int tid) {
   {
-    float4 v[2 * kRvBf];
+    float4 v[kRvPairs];
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
+    for (int u = 0; u < kRvPairs; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
 #pragma unroll
-    for (int u = 0; u < 2 * kRvBf; ++u)
+    for (int u = 0; u < kRvPairs; ++u)
       *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
           make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
   }
   __syncthreads();
 #pragma unroll 1
-  for (int q = 2; q <= kRvN / 4; q <<= 2) {
-    const float inv_len = 0.25f / (float)q;
-    float2 v[kRvBf][4];
-    int idx[kRvBf];
+  for (int q = 2; q <= kRvN / 8; q <<= 3) {
+    const float inv_len = 0.125f / (float)q;
+    const int pos = tid & (q - 1);
+    const int i0 = ((tid - pos) << 3) + pos;
+    const float rev = (float)pos * inv_len;
+    float2 v[8], w[8];
+    fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
+    // undo y_m conj(w^m), then the conjugate transform (factor 8, part of the 1 / N left to the caller)
+    v[0] = fft_conj(s[RP(i0)]);
 #pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-      const int t = tid + kRvThreads * u, pos = t & (q - 1);
-      idx[u] = ((t - pos) << 2) + pos;
+    for (int m = 1; m < 8; ++m) v[m] = fft_conj(cmul(s[RP(i0 + m * q)], w[m]));
+    fft_dft8(v);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) v[u][m] = s[RP(idx[u] + m * q)];
-    }
-#pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-      const int pos = (tid + kRvThreads * u) & (q - 1);
-      const float rev = (float)pos * inv_len;
-      const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-      const float2 y0 = v[u][0], y1 = cmul(v[u][1], w1), y2 = cmul(v[u][2], w2), y3 = cmul(v[u][3], w3);
-      // undo y0 = t0+t2, y2 = t0-t2, y1 = t1+t3, y3 = t1-t3 (factor 2 each, part of the 1/N)
-      const float2 t0 = cadd(y0, y2), t2 = csub(y0, y2), t1 = cadd(y1, y3), t3 = csub(y1, y3);
-      const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i) = (b - d) * 2
-      v[u][0] = cadd(t0, t1);                                  // 4a
-      v[u][2] = csub(t0, t1);                                  // 4c
-      v[u][1] = cadd(t2, bd);                                  // 4b
-      v[u][3] = csub(t2, bd);                                  // 4d
-    }
-#pragma unroll
-    for (int u = 0; u < kRvBf; ++u) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) s[RP(idx[u] + m * q)] = v[u][m];
-    }
+    for (int j = 0; j < 8; ++j) s[RP(i0 + j * q)] = fft_conj(v[j]);
     __syncthreads();
   }
 }

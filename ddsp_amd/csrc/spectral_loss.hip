@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include "common.h"
 #include "profile.h"
+#include "fft_radix8.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
@@ -86,30 +87,6 @@ __device__ __forceinline__ float2 sl_add(float2 a, float2 b) { return make_float
 __device__ __forceinline__ float2 sl_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 sl_conj(float2 a) { return make_float2(a.x, -a.y); }
 
-// v[m] <- sum_j v[j] exp(-2 pi i j m / 8), in place, natural order
-__device__ __forceinline__ void sl_dft8(float2 (&v)[8]) {
-  const float kR = 0.70710678118654752f;
-  const float2 b0 = sl_add(v[0], v[4]), b1 = sl_add(v[1], v[5]), b2 = sl_add(v[2], v[6]), b3 = sl_add(v[3], v[7]);
-  const float2 c0 = sl_sub(v[0], v[4]), c1 = sl_sub(v[1], v[5]), c2 = sl_sub(v[2], v[6]), c3 = sl_sub(v[3], v[7]);
-  // even outputs: the 4-point transform of b
-  const float2 t0 = sl_add(b0, b2), t1 = sl_sub(b0, b2), t2 = sl_add(b1, b3), bd = sl_sub(b1, b3);
-  const float2 t3 = make_float2(bd.y, -bd.x);                            // (b1 - b3) (-i)
-  v[0] = sl_add(t0, t2); v[4] = sl_sub(t0, t2); v[2] = sl_add(t1, t3); v[6] = sl_sub(t1, t3);
-  // odd outputs: c_j w^j (w = exp(-2 pi i / 8)), then the 4-point transform
-  const float2 d1 = make_float2((c1.x + c1.y) * kR, (c1.y - c1.x) * kR);          // c1 (1 - i) / sqrt 2
-  const float2 d2 = make_float2(c2.y, -c2.x);                                     // c2 (-i)
-  const float2 d3 = make_float2((c3.y - c3.x) * kR, -(c3.x + c3.y) * kR);         // c3 (-1 - i) / sqrt 2
-  const float2 u0 = sl_add(c0, d2), u1 = sl_sub(c0, d2), u2 = sl_add(d1, d3), ud = sl_sub(d1, d3);
-  const float2 u3 = make_float2(ud.y, -ud.x);
-  v[1] = sl_add(u0, u2); v[5] = sl_sub(u0, u2); v[3] = sl_add(u1, u3); v[7] = sl_sub(u1, u3);
-}
-
-// the powers 1 .. 7 of w1 (w[0] is unused)
-__device__ __forceinline__ void sl_powers8(float2 w1, float2 (&w)[8]) {
-  w[1] = w1; w[2] = sl_cmul(w1, w1); w[3] = sl_cmul(w[2], w1); w[4] = sl_cmul(w[2], w[2]);
-  w[5] = sl_cmul(w[4], w1); w[6] = sl_cmul(w[3], w[3]); w[7] = sl_cmul(w[4], w[3]);
-}
-
 // frames g_lo .. g_lo + n_fr - 1 (H points each) of the array s
 template <int H>
 __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
@@ -126,8 +103,8 @@ __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_l
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = s[SP(i0 + j * q)];
         const float rev = (float)pos * inv_len;
-        sl_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
-        sl_dft8(v);
+        fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
+        fft_dft8(v);
         s[SP(i0)] = v[0];
 #pragma unroll
         for (int m = 1; m < 8; ++m) s[SP(i0 + m * q)] = sl_cmulc(v[m], w[m]);
@@ -201,12 +178,12 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
         const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
         const float rev = (float)pos * inv_len;
         float2 v[8], w[8];
-        sl_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
+        fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
         // undo y_m conj(w^m), then the conjugate transform: sum_m y_m exp(+2 pi i j m / 8) = conj(dft8(conj y))
         v[0] = sl_conj(s[SP(i0)]);
 #pragma unroll
         for (int m = 1; m < 8; ++m) v[m] = sl_conj(sl_cmul(s[SP(i0 + m * q)], w[m]));
-        sl_dft8(v);
+        fft_dft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[SP(i0 + j * q)] = sl_conj(v[j]);
       }
