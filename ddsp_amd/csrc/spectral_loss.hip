@@ -3,11 +3,12 @@
 // over [batch, frames, S/2+1] - spectral_ops.compute_mag / stft (ddsp/spectral_ops.py:34-47, 67-70),
 // tf.signal.stft semantics: frames of S samples every S/4, zero pad_end, periodic Hann, rfft(S).
 //
-// One launch per FFT size.  A block holds G = 4096/S frames of the target and the same G frames of
-// the audio in LDS, each as the S/2-point complex sequence of its even / odd samples, and runs one
-// in-place radix-2 decimation-in-frequency FFT over all of them; the real spectrum is untangled
-// from bins k and S/2-k (at their bit-reversed positions, one v_bfrev each), magnitudes are
-// compared on the fly and never touch HBM.  The two signals are NOT packed into the real and imaginary parts of one transform:
+// One grid for all FFT sizes (a block finds its size from its index; the large sizes first).  A block holds G = 4096/S
+// frames of the target and the same G frames of the audio in LDS, each as the S/2-point complex sequence of its even / odd
+// samples, and runs one in-place mixed radix-8 / radix-4 decimation-in-frequency FFT over all of them (csrc/fft_radix8.h);
+// the real spectrum is untangled from bins k and S/2-k (at their digit-reversed positions), magnitudes are compared on
+// the fly and never touch HBM.  The value + gradient kernel (stft_l1_bwd_kernel) is the same block with the gradient
+// spectrum, an inverse transform and a windowed overlap-add behind it.  The two signals are NOT packed into the real and imaginary parts of one transform:
 // rounding would leak ~1e-7 of one signal into the other, and core.safe_log treats exact zeros
 // (silent stretches of generated audio) differently from tiny values.  Per-block partial sums (fp64) go to the workspace; a one-block kernel adds them in a fixed
 // order, so the loss is deterministic.  HBM traffic: each sample is read 4 times per size (75 %
