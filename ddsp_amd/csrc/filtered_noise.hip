@@ -964,7 +964,11 @@ __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __rest
   for (int q = wave; q < nfr; q += 4) {
     const int f = f0 + q;
     for (int kc = 0; kc < p.L; kc += 128) {                // taps kc + lane and kc + 64 + lane (L = 128: one trip)
-      float acc0 = 0.0f, acc1 = 0.0f;
+      // two samples at a time on packed FMAs: (x_l, x_l+1) from two readlanes into a scalar pair, (gz[i_l + t], gz[i_l+1 + t])
+      // as the read pair brings them - the even and the odd samples' sums of a tap in the two halves of one register pair,
+      // added at the end (3 instructions per sample where 5 went)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 acc_lo = {0.0f, 0.0f}, acc_hi = {0.0f, 0.0f};
       for (int c = 0; c < p.fs; c += 64) {                 // 64 samples of the frame per chunk
         const int i = f * p.fs + c + lane;                 // this lane's sample
         float xv = 0.0f;
@@ -972,12 +976,15 @@ __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __rest
           xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1);
         const float* __restrict__ win = s_g + q * p.fs + c + kc + lane;    // + l: gz[i_l + t], t = kc + lane
 #pragma unroll
-        for (int l = 0; l < 64; ++l) {
-          const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l));
-          acc0 = fmaf(xs, win[l], acc0);
-          acc1 = fmaf(xs, win[l + 64], acc1);
+        for (int l = 0; l < 64; l += 2) {
+          const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l));
+          const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), l + 1));
+          const f32x2 xx = {x0, x1};
+          acc_lo = __builtin_elementwise_fma(xx, (f32x2){win[l], win[l + 1]}, acc_lo);
+          acc_hi = __builtin_elementwise_fma(xx, (f32x2){win[l + 64], win[l + 65]}, acc_hi);
         }
       }
+      const float acc0 = acc_lo[0] + acc_lo[1], acc1 = acc_hi[0] + acc_hi[1];
       float* __restrict__ o = dh + ((size_t)b * p.F + f) * p.L + kc;
       if (kc + lane < p.L) o[lane] = acc0;
       if (kc + 64 + lane < p.L) o[lane + 64] = acc1;
