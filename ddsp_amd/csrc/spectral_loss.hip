@@ -15,6 +15,7 @@
 // overlap), served by L2; nothing else is read or written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
 #include "fft_radix8.h"
@@ -266,33 +267,41 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
   // twiddle (X[k] = E + W^k O, X[H-k] = conj(E - W^k O)) - half the LDS reads, bit reversals and sin / cos of a loop over
   // single bins (round 3: 156 instructions per bin were 30-45 % of this kernel)
   float dm = 0.0f, dl = 0.0f;
-  for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {
-    const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);
-    if (f0 + g < n_frames) {
-      const int ia = sl_pos<H>(k), ib = sl_pos<H>((H - k) & (H - 1));
-      const float rev = (float)k * (1.0f / (float)S);
-      const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-      float m1[2], m2[2];
+  // (k = 0 .. S/4 - 1 are G S/4 pairs - 1024 per block, two full trips of the 512 threads; the self-paired bin S/4 of
+  // each frame goes in a short trip of its own: with it in the same loop - S/4 + 1 entries per frame - every size made
+  // three trips for 2.004 .. 2.125 trips' worth of pairs, a third of this part of the kernel for nothing)
+  auto pair_of_bins = [&](int g, int k, auto self_tag) {
+    constexpr bool SELF = decltype(self_tag)::value;           // k = S/4: Z[k] pairs with itself, one bin
+    const int ia = sl_pos<H>(k), ib = sl_pos<H>((H - k) & (H - 1));
+    const float rev = (float)k * (1.0f / (float)S);
+    const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+    float m1[2], m2[2];
 #pragma unroll
-      for (int sig = 0; sig < 2; ++sig) {
-        const int base = (g + sig * G) << LOG2H;
-        const float2 za = s[SP(base + ia)], zb = s[SP(base + ib)];
-        const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
-        const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
-        const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);      // W^k O = (c - i sn) O
-        const float x1r = ex + wx, x1i = ey + wy, x2r = ex - wx, x2i = ey - wy;
-        m1[sig] = sl_sqrt(fmaf(x1r, x1r, x1i * x1i));                             // |X[k]|
-        m2[sig] = sl_sqrt(fmaf(x2r, x2r, x2i * x2i));                             // |X[S/2 - k]|
-      }
-      dm += fabsf(m1[0] - m1[1]);
-      // core.safe_log (core.py:213-216): non-positive -> eps
-      dl += fabsf(sl_log2(m1[0] <= 0.0f ? safe_eps : m1[0]) - sl_log2(m1[1] <= 0.0f ? safe_eps : m1[1]));
-      if (2 * k != H) {                                                         // (the self-paired bin S/4 counts once)
-        dm += fabsf(m2[0] - m2[1]);
-        dl += fabsf(sl_log2(m2[0] <= 0.0f ? safe_eps : m2[0]) - sl_log2(m2[1] <= 0.0f ? safe_eps : m2[1]));
-      }
+    for (int sig = 0; sig < 2; ++sig) {
+      const int base = (g + sig * G) << LOG2H;
+      const float2 za = s[SP(base + ia)], zb = s[SP(base + ib)];
+      const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
+      const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
+      const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);      // W^k O = (c - i sn) O
+      const float x1r = ex + wx, x1i = ey + wy, x2r = ex - wx, x2i = ey - wy;
+      m1[sig] = sl_sqrt(fmaf(x1r, x1r, x1i * x1i));                           // |X[k]|
+      m2[sig] = sl_sqrt(fmaf(x2r, x2r, x2i * x2i));                           // |X[S/2 - k]|
     }
+    dm += fabsf(m1[0] - m1[1]);
+    // core.safe_log (core.py:213-216): non-positive -> eps
+    dl += fabsf(sl_log2(m1[0] <= 0.0f ? safe_eps : m1[0]) - sl_log2(m1[1] <= 0.0f ? safe_eps : m1[1]));
+    if (!SELF) {
+      dm += fabsf(m2[0] - m2[1]);
+      dl += fabsf(sl_log2(m2[0] <= 0.0f ? safe_eps : m2[0]) - sl_log2(m2[1] <= 0.0f ? safe_eps : m2[1]));
+    }
+  };
+  constexpr int LOG2Q = LOG2H - 1;                             // pairs per frame in the main loop: H / 2
+  for (int e = tid; e < G * (H / 2); e += kSlThreads) {
+    const int g = e >> LOG2Q, k = e & (H / 2 - 1);
+    if (f0 + g < n_frames) pair_of_bins(g, k, std::false_type{});
   }
+  for (int g = tid; g < G; g += kSlThreads)
+    if (f0 + g < n_frames) pair_of_bins(g, H / 2, std::true_type{});
   const double sm = (double)wave_sum(dm), sl = (double)wave_sum(dl);
   if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sl; }
   __syncthreads();
@@ -406,9 +415,9 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   const float up = grad_loss ? grad_loss[0] : 1.0f;
   const float ms = mag_scale * up, ls = log_scale * up;        // weight / count (per size), times dL/dloss
   float dm_sum = 0.0f, dl_sum = 0.0f;
-  for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {
-    const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);     // pair (k, H-k), k = 0 .. H/2
-    if (f0 + g >= n_frames) continue;
+  // (pairs k = 0 .. H/2 - 1 in two full trips of the block, the self-paired bin H/2 of every frame in a short trip of its
+  // own: as in stft_l1_block)
+  auto pair_grad = [&](int g, int k) {                          // pair (k, H-k)
     const int ia = sl_pos<H>(k), ib = sl_pos<H>((H - k) & (H - 1));
     const float rev = (float)k * (1.0f / (float)S);
     const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
@@ -462,7 +471,13 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
       s[SP(abase + ia)] = make_float2(ex - oy, ey + ox);            // Z'[k]   = E' + i O'
       if (2 * k != H) s[SP(abase + ib)] = make_float2(ex + oy, ox - ey);          // Z'[H-k] = conj E' + i conj O'
     }
+  };
+  for (int e = tid; e < G * (H / 2); e += kSlThreads) {
+    const int g = e >> (LOG2H - 1), k = e & (H / 2 - 1);
+    if (f0 + g < n_frames) pair_grad(g, k);
   }
+  for (int g = tid; g < G; g += kSlThreads)
+    if (f0 + g < n_frames) pair_grad(g, H / 2);
   __syncthreads();
   // ---- unscaled inverse transform of the audio frames ------------------------------------------------
   sl_inverse<H>(s, tid, G, G);
