@@ -1064,7 +1064,8 @@ def test_synth_plus_trainable_reverb_trains(ddsp):                   # solo_inst
 
 # ---- SpectralLoss backward: |ours - fp64 analytic gradient| <= 2e-4 * max|grad| + 1e-9 ------------------
 @pytest.mark.parametrize('batch,n,sizes', [(2, 3000, (2048, 1024, 512, 256, 128, 64)), (1, 777, (64, 16)),
-                                           (3, 20000, (4096, 512))])
+                                           (3, 20000, (4096, 512)),
+                                           (2, 1500, (32, 1024))])      # 32: the one transform plan without a radix-8 stage
 def test_spectral_loss_backward_vs_analytic_oracle(ddsp, batch, n, sizes):
   rng = np.random.default_rng(n)
   t = (0.3 * rng.standard_normal((batch, n))).astype(np.float32)
