@@ -89,108 +89,153 @@ __device__ __forceinline__ float2 sl_add(float2 a, float2 b) { return make_float
 __device__ __forceinline__ float2 sl_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 sl_conj(float2 a) { return make_float2(a.x, -a.y); }
 
-// frames g_lo .. g_lo + n_fr - 1 (H points each) of the array s
-template <int H>
-__device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
+// frames g_lo .. g_lo + n_fr - 1 (H points each) of the array s.  The stage with q = 1 - the last of the forward transform, the
+// first of the inverse - has unit twiddles: its instance (UNITY) neither makes nor multiplies by them.
+template <int H, bool UNITY>
+__device__ __forceinline__ void sl_fwd_stage8(float2* s, int tid, int n_fr, int g_lo, int q) {
   constexpr int LOG2H = SlPlan<H>::L;
-  if constexpr (SlPlan<H>::N8 > 0) {
-#pragma unroll 1
-    for (int q = H / 8; q >= SlPlan<H>::M; q >>= 3) {          // sub-length 8 q: H, H / 8, ..
-      const float inv_len = 0.125f / (float)q;
-      for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
-        const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
-        const int pos = r & (q - 1);
-        const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
-        float2 v[8], w[8];
+  const float inv_len = 0.125f / (float)q;
+  for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
+    const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
+    const int pos = UNITY ? 0 : (r & (q - 1));
+    const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
+    float2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = s[SP(i0 + j * q)];
-        const float rev = (float)pos * inv_len;
-        fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
-        fft_dft8(v);
-        s[SP(i0)] = v[0];
+    for (int j = 0; j < 8; ++j) v[j] = s[SP(i0 + j * q)];
+    fft_dft8(v);
+    if constexpr (UNITY) {
 #pragma unroll
-        for (int m = 1; m < 8; ++m) s[SP(i0 + m * q)] = sl_cmulc(v[m], w[m]);
-      }
-      sl_stage_sync<H>();
+      for (int m = 0; m < 8; ++m) s[SP(i0 + m * q)] = v[m];
+    } else {
+      float2 w[8];
+      const float rev = (float)pos * inv_len;
+      fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
+      s[SP(i0)] = v[0];
+#pragma unroll
+      for (int m = 1; m < 8; ++m) s[SP(i0 + m * q)] = sl_cmulc(v[m], w[m]);
     }
   }
-#pragma unroll 1
-  for (int q = SlPlan<H>::M / 4; q >= 1; q >>= 2) {
-    const float inv_len = 0.25f / (float)q;
-    for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
+  sl_stage_sync<H>();
+}
+
+template <int H, bool UNITY>
+__device__ __forceinline__ void sl_fwd_stage4(float2* s, int tid, int n_fr, int g_lo, int q) {
+  constexpr int LOG2H = SlPlan<H>::L;
+  const float inv_len = 0.25f / (float)q;
+  for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = t2 + u;
-        const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
-        const int pos = r & (q - 1);
-        const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
-        const float2 a = s[SP(i0)], b = s[SP(i0 + q)], c = s[SP(i0 + 2 * q)], d = s[SP(i0 + 3 * q)];
+    for (int u = 0; u < 2; ++u) {
+      const int t = t2 + u;
+      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+      const int pos = UNITY ? 0 : (r & (q - 1));
+      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+      const float2 a = s[SP(i0)], b = s[SP(i0 + q)], c = s[SP(i0 + 2 * q)], d = s[SP(i0 + 3 * q)];
+      const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
+      const float2 tb = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
+      const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
+      const float2 y0 = make_float2(t0.x + tb.x, t0.y + tb.y), y1 = make_float2(t1.x + t3.x, t1.y + t3.y),
+                   y2 = make_float2(t0.x - tb.x, t0.y - tb.y), y3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+      s[SP(i0)] = y0;
+      if constexpr (UNITY) {
+        s[SP(i0 + q)] = y1; s[SP(i0 + 2 * q)] = y2; s[SP(i0 + 3 * q)] = y3;
+      } else {
         const float rev = (float)pos * inv_len;
         const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
         const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
-        const float2 t0 = make_float2(a.x + c.x, a.y + c.y), t1 = make_float2(a.x - c.x, a.y - c.y);
-        const float2 tb = make_float2(b.x + d.x, b.y + d.y), bd = make_float2(b.x - d.x, b.y - d.y);
-        const float2 t3 = make_float2(bd.y, -bd.x);              // (b - d) * (-i)
-        s[SP(i0)] = make_float2(t0.x + tb.x, t0.y + tb.y);
-        s[SP(i0 + q)] = sl_cmulc(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
-        s[SP(i0 + 2 * q)] = sl_cmulc(make_float2(t0.x - tb.x, t0.y - tb.y), w2);
-        s[SP(i0 + 3 * q)] = sl_cmulc(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
+        s[SP(i0 + q)] = sl_cmulc(y1, w1);
+        s[SP(i0 + 2 * q)] = sl_cmulc(y2, w2);
+        s[SP(i0 + 3 * q)] = sl_cmulc(y3, w3);
       }
     }
-    sl_stage_sync<H>();
   }
+  sl_stage_sync<H>();
+}
+
+template <int H>
+__device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
+  typedef SlPlan<H> P;
+  if constexpr (P::N8 > 0) {
+#pragma unroll 1
+    for (int q = H / 8; q >= P::M && q > 1; q >>= 3) sl_fwd_stage8<H, false>(s, tid, n_fr, g_lo, q);      // sub-length 8 q: H, H / 8, ..
+    if constexpr (P::M == 1) sl_fwd_stage8<H, true>(s, tid, n_fr, g_lo, 1);
+  }
+  if constexpr (P::N4 > 0) {
+#pragma unroll 1
+    for (int q = P::M / 4; q > 1; q >>= 2) sl_fwd_stage4<H, false>(s, tid, n_fr, g_lo, q);
+    sl_fwd_stage4<H, true>(s, tid, n_fr, g_lo, 1);
+  }
+}
+
+template <int H, bool UNITY>
+__device__ __forceinline__ void sl_inv_stage4(float2* s, int tid, int n_fr, int g_lo, int q) {
+  constexpr int LOG2H = SlPlan<H>::L;
+  const float inv_len = 0.25f / (float)q;
+  for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t2 + u;
+      const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
+      const int pos = UNITY ? 0 : (r & (q - 1));
+      const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
+      float2 y0 = s[SP(i0)], y1 = s[SP(i0 + q)], y2 = s[SP(i0 + 2 * q)], y3 = s[SP(i0 + 3 * q)];
+      if constexpr (!UNITY) {
+        const float rev = (float)pos * inv_len;
+        const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+        const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
+        y1 = sl_cmul(y1, w1); y2 = sl_cmul(y2, w2); y3 = sl_cmul(y3, w3);
+      }
+      const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), tc = make_float2(y0.x - y2.x, y0.y - y2.y);
+      const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
+      const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
+      s[SP(i0)] = make_float2(t0.x + t1.x, t0.y + t1.y);
+      s[SP(i0 + 2 * q)] = make_float2(t0.x - t1.x, t0.y - t1.y);
+      s[SP(i0 + q)] = make_float2(tc.x + bd.x, tc.y + bd.y);
+      s[SP(i0 + 3 * q)] = make_float2(tc.x - bd.x, tc.y - bd.y);
+    }
+  }
+  sl_stage_sync<H>();
+}
+
+template <int H, bool UNITY>
+__device__ __forceinline__ void sl_inv_stage8(float2* s, int tid, int n_fr, int g_lo, int q) {
+  constexpr int LOG2H = SlPlan<H>::L;
+  const float inv_len = 0.125f / (float)q;
+  for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
+    const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
+    const int pos = UNITY ? 0 : (r & (q - 1));
+    const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
+    float2 v[8];
+    // undo y_m conj(w^m), then the conjugate transform: sum_m y_m exp(+2 pi i j m / 8) = conj(dft8(conj y))
+    if constexpr (UNITY) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = sl_conj(s[SP(i0 + m * q)]);
+    } else {
+      float2 w[8];
+      const float rev = (float)pos * inv_len;
+      fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
+      v[0] = sl_conj(s[SP(i0)]);
+#pragma unroll
+      for (int m = 1; m < 8; ++m) v[m] = sl_conj(sl_cmul(s[SP(i0 + m * q)], w[m]));
+    }
+    fft_dft8(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[SP(i0 + j * q)] = sl_conj(v[j]);
+  }
+  sl_stage_sync<H>();
 }
 
 template <int H>
 __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_lo) {
-  constexpr int LOG2H = SlPlan<H>::L;
+  typedef SlPlan<H> P;
+  if constexpr (P::N4 > 0) {
+    sl_inv_stage4<H, true>(s, tid, n_fr, g_lo, 1);
 #pragma unroll 1
-  for (int q = 1; q <= SlPlan<H>::M / 4; q <<= 2) {
-    const float inv_len = 0.25f / (float)q;
-    for (int t2 = 2 * tid; t2 < n_fr * (H / 4); t2 += 2 * kSlThreads) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = t2 + u;
-        const int g = t / (H / 4) + g_lo, r = t & (H / 4 - 1);
-        const int pos = r & (q - 1);
-        const int i0 = (g << LOG2H) + ((r - pos) << 2) + pos;
-        const float rev = (float)pos * inv_len;
-        const float2 w1 = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-        const float2 w2 = sl_cmul(w1, w1), w3 = sl_cmul(w2, w1);
-        const float2 y0 = s[SP(i0)], y1 = sl_cmul(s[SP(i0 + q)], w1), y2 = sl_cmul(s[SP(i0 + 2 * q)], w2),
-                     y3 = sl_cmul(s[SP(i0 + 3 * q)], w3);
-        const float2 t0 = make_float2(y0.x + y2.x, y0.y + y2.y), tc = make_float2(y0.x - y2.x, y0.y - y2.y);
-        const float2 t1 = make_float2(y1.x + y3.x, y1.y + y3.y), t3 = make_float2(y1.x - y3.x, y1.y - y3.y);
-        const float2 bd = make_float2(-t3.y, t3.x);              // t3 * (+i)
-        s[SP(i0)] = make_float2(t0.x + t1.x, t0.y + t1.y);
-        s[SP(i0 + 2 * q)] = make_float2(t0.x - t1.x, t0.y - t1.y);
-        s[SP(i0 + q)] = make_float2(tc.x + bd.x, tc.y + bd.y);
-        s[SP(i0 + 3 * q)] = make_float2(tc.x - bd.x, tc.y - bd.y);
-      }
-    }
-    sl_stage_sync<H>();
+    for (int q = 4; q <= P::M / 4; q <<= 2) sl_inv_stage4<H, false>(s, tid, n_fr, g_lo, q);
   }
-  if constexpr (SlPlan<H>::N8 > 0) {
+  if constexpr (P::N8 > 0) {
+    if constexpr (P::M == 1) sl_inv_stage8<H, true>(s, tid, n_fr, g_lo, 1);
 #pragma unroll 1
-    for (int q = SlPlan<H>::M; q <= H / 8; q <<= 3) {
-      const float inv_len = 0.125f / (float)q;
-      for (int t = tid; t < n_fr * (H / 8); t += kSlThreads) {
-        const int g = t / (H / 8) + g_lo, r = t & (H / 8 - 1);
-        const int pos = r & (q - 1);
-        const int i0 = (g << LOG2H) + ((r - pos) << 3) + pos;
-        const float rev = (float)pos * inv_len;
-        float2 v[8], w[8];
-        fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
-        // undo y_m conj(w^m), then the conjugate transform: sum_m y_m exp(+2 pi i j m / 8) = conj(dft8(conj y))
-        v[0] = sl_conj(s[SP(i0)]);
-#pragma unroll
-        for (int m = 1; m < 8; ++m) v[m] = sl_conj(sl_cmul(s[SP(i0 + m * q)], w[m]));
-        fft_dft8(v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[SP(i0 + j * q)] = sl_conj(v[j]);
-      }
-      sl_stage_sync<H>();
-    }
+    for (int q = (P::M == 1 ? 8 : P::M); q <= H / 8; q <<= 3) sl_inv_stage8<H, false>(s, tid, n_fr, g_lo, q);
   }
 }
 
