@@ -71,12 +71,6 @@ struct ChunkTables {
   float f0[kWtRows + 2];
   int kA[kWtRows], kN[kWtRows];
   int cross;           // any frame of the chunk with a harmonic crossing Nyquist inside it (kA < kN)
-  // the FIRST crossing harmonic kA of a frame, ready-made by the wavefront that builds these tables (lanes = frames): the two
-  // rows' amplitudes c am, the frame's end frequencies of that harmonic as top and (bot - top), psi_hat(k) and k as a float.
-  // The interpolators used to gather all of that per tile - two index reads, two f0, two amplitudes, four 2-byte plane
-  // reads, a scalar load of psi_hat - behind three waits: a frame with a crossing harmonic cost twice a frame without.
-  float4 cx[kWtRows];  // {c0 am0, c1 am1, fj k, (fj1 - fj) k}
-  float2 cy[kWtRows];  // {psi_hat(k), k}
 };
 
 template <int W> struct WtPoly;
@@ -681,21 +675,6 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             t.kA[lane] = kA;
             t.kN[lane] = kN;
           }
-          if (any != 0ull) {                                   // (wave-uniform; rows lane, lane + 1 <= 31 for a frame)
-            float4 cx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float2 cy = make_float2(0.0f, 0.0f);
-            if (crossing) {
-              const int k = kA;
-              const float kfl = (float)(k + 1);
-              const _Float16* pl = planes_all[pm] + ((k & 1) * kWtRows + lane) * kWtPS + (k >> 1);
-              const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
-              const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
-              const float top = rn_mul(fj, kfl), bot = rn_mul(fj1, kfl);
-              cx = make_float4(rn_mul(c0, amp_tab[pm][lane]), rn_mul(c1, amp_tab[pm][lane + 1]), top, rn_sub(bot, top));
-              cy = make_float2(WtPoly<W>::psi(k + 1), kfl);
-            }
-            if (lane < kWtRows) { t.cx[lane] = cx; t.cy[lane] = cy; }
-          }
           // the sum over this chunk's frames: lane 31 holds the inclusive sum of lanes 0 .. 31 (lanes >= nfr added 0)
           const long long bits31 = __builtin_bit_cast(long long, incl);
           const unsigned lo31 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits31 & 0xffffffffll), 31);
@@ -1033,18 +1012,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               const int kA = __builtin_amdgcn_readfirstlane(t.kA[q[u]]);
               const int kN = __builtin_amdgcn_readfirstlane(t.kN[q[u]]);
               if (kA < kN) {         // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
-                {                    // the first of them from the chunk tables (two broadcast reads; see ChunkTables)
-                  const float4 cx = t.cx[q[u]];
-                  const float2 cy = t.cy[q[u]];
-                  const float fk = rn_add(cx.z, rn_mul(cx.w, lerp[u]));
-                  const float ak = rn_mul(fmaf(w_next[u], cx.y, rn_mul(w_cur[u], cx.x)), cy.x);
-                  const float sv = sin_rev(fmaf(theta[u], cy.y, -rintf(theta[u] * cy.y)));     // exact fractional part of k theta
-                  if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
-                }
-                if (kA + 1 < kN) {   // more than one: the general form (an f0 that moves by several per cent within a frame)
                 const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
                 const float am0 = amp_tab[pb][q[u]], am1 = amp_tab[pb][q[u] + 1];
-                for (int k = kA + 1; k < kN; ++k) {
+                for (int k = kA; k < kN; ++k) {
                   const float kfl = (float)(k + 1);
                   const float top = fj * kfl, bot = fj1 * kfl;
                   const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp[u]));
@@ -1054,7 +1024,6 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
                   const float ak = rn_mul(fmaf(w_next[u], rn_mul(c1, am1), rn_mul(w_cur[u], rn_mul(c0, am0))), WtPoly<W>::psi(k + 1));
                   const float sv = sin_rev(fmaf(theta[u], kfl, -rintf(theta[u] * kfl)));     // exact fractional part of k theta
                   if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
-                }
                 }
               }
             }
