@@ -1,3 +1,5 @@
+# Same-session A/B of two library variants (tools/build_variant_lib.sh base / new) on the Nyquist-crossing cases of harm_table_kernel:
+# per-launch time at batch 128 for f0 centre +- jitter pairs, then the GPU tests of the Harmonic paths.  gpurun -- bash tools/exp_crossing_ab.sh
 python tools/exp_ab.py base new --rounds 3 --only harm 2>&1 | tail -2 | cut -c1-260
 for v in base new; do python - <<PY
 import os, sys, json, time
