@@ -205,12 +205,33 @@ __device__ __forceinline__ WtDesc wt_read_desc(const WtDesc* ring, int slot) {
   return d;
 }
 
-// ---- phase B on packed fp32 pairs (v_pk_fma_f32: two FMAs per issued instruction; a wavefront issues one instruction
-// per ~8 clocks whatever it is, profiles/r03b_*) ---------------------------------------------------------------------
+// ---- phase B on pairs of fp32 values: one FMA per half, spelled out ---------------------------------------------------------
+// Rounds 2-3 issued these as v_pk_fma_f32 assembly statements (two FMAs per issued instruction, op_sel / op_sel_hi routing the
+// halves) and that was the source of the run-to-run differences the round-3 bit-equality tests met once: on the MI355X a
+// wavefront running such packed FMAs back to back now and then gets ONE HALF of a result wrong in its LAST SIXTEEN LANES - a
+// window weight off in its low bits, the error of both table rows' accumulators in the same half - while a tabulator of the same
+// SIMD executes MFMAs: once in 10^6 .. 10^9 tiles for the shapes of the K <= 128 instances, in 5 - 20 % of all launches for the
+// 129 .. 200-harmonic instances (tools/stress_determinism.py reproduces it at will; with one extra vector load per tabulator and
+// tick, -DDDSP_EXP_T_DUMMY_LOADS=1, every launch of a frame-size-128 shape differs somewhere).  What it is NOT (each tested on
+// the chip, profiles/r04_packed_fma_glitch.txt): a missing wait state around the statements (s_nop 1 in front of every one: no
+// change), a result pair placed on a source pair whose halves cross (early-clobber / tied constraints: no change), the
+// v_permlane32_swap of the wide instances' row makers, a load landing in a register still in use (the same statements without
+// the packed instructions: no event in any configuration), an LDS race (theta, z, the table offset and the envelope weight of a
+// differing sample are bit-equal between the two launches; only the accumulators' halves differ).  The same arithmetic as
+// plain v_fma_f32 - below - never showed an event, in the amplified configurations either, and costs 0.7 us of 36.6 at batch
+// 128 (nothing at batch 32): -DDDSP_EXP_PACKED_PHASE_B brings the assembly statements back for whoever wants to look again.
+// The compiler's own packed instructions in the row makers (v_pk_mul / v_pk_add / v_pk_fma_f32 of phase A, a dozen per row
+// pair between transcendentals) were never hit - not in 10^4 launches in which the interpolators were hit every time.
+// tests/test_isa_guards.py keeps assembly-statement packed FMAs out of the instruction stream.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if defined(__AMDGCN__) && defined(DDSP_EXP_PACKED_PHASE_B)
+#define DDSP_WT_PK_ASM 1
+#else
+#define DDSP_WT_PK_ASM 0
+#endif
 // (e, o) <- (e, o) * z^2 + (ce, co), zz = (z, z^2)
 __device__ __forceinline__ f32x2 wt_pk_horner(f32x2 eo, f32x2 zz, f32x2 coef) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(eo), "v"(zz), "v"(coef));
   return r;
@@ -220,7 +241,7 @@ __device__ __forceinline__ f32x2 wt_pk_horner(f32x2 eo, f32x2 zz, f32x2 coef) {
 }
 // the window weights of a tap pair: (e + z o, e - z o)
 __device__ __forceinline__ f32x2 wt_pk_weights(f32x2 eo, f32x2 zz) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(eo), "v"(zz));
   return r;
@@ -229,7 +250,7 @@ __device__ __forceinline__ f32x2 wt_pk_weights(f32x2 eo, f32x2 zz) {
 #endif
 }
 __device__ __forceinline__ f32x2 wt_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
@@ -261,9 +282,9 @@ __device__ __forceinline__ int wt_floor_int(float x) {
   return (int)floorf(x);
 #endif
 }
-// (a0 b1 + c0, a1 b0 + c1): a packed FMA with the halves of b swapped
+// (a0 b1 + c0, a1 b0 + c1): the halves of b swapped
 __device__ __forceinline__ f32x2 wt_pk_fma_swap(f32x2 a, f32x2 b, f32x2 c) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
@@ -273,7 +294,7 @@ __device__ __forceinline__ f32x2 wt_pk_fma_swap(f32x2 a, f32x2 b, f32x2 c) {
 }
 // the window weights of two tap pairs at once, E = (e_a, e_b), O = (o_a, o_b): E + z O and E - z O
 __device__ __forceinline__ f32x2 wt_pk_plus(f32x2 o, f32x2 zz, f32x2 e) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(o), "v"(zz), "v"(e));
   return r;
@@ -282,7 +303,7 @@ __device__ __forceinline__ f32x2 wt_pk_plus(f32x2 o, f32x2 zz, f32x2 e) {
 #endif
 }
 __device__ __forceinline__ f32x2 wt_pk_minus(f32x2 o, f32x2 zz, f32x2 e) {
-#if defined(__AMDGCN__)
+#if DDSP_WT_PK_ASM
   f32x2 r;
   __asm__("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(o), "v"(zz), "v"(e));
   return r;
@@ -322,20 +343,26 @@ template <int W> struct WtPkCoefs {
         constexpr int s_ = decltype(ss)::value;
         constexpr float va = WtPoly<W>::e(pa, DE - s_), vb = WtPoly<W>::e(pb, DE - s_);
         e[g][s_] = (f32x2){va, vb};
-        DDSP_KEEP_IN_VGPR(e[g][s_]);          // resident: not re-made from literals at every use
+#if DDSP_WT_PK_ASM
+        DDSP_KEEP_IN_VGPR(e[g][s_]);          // resident: not re-made from literals at every use (a packed FMA takes no literal;
+#endif                                        // the plain FMAs do - v_fmaak_f32 -, and the coefficients need no registers)
       });
       wt_static_for<DO + 1>([&](auto ss) {
         constexpr int s_ = decltype(ss)::value;
         constexpr float va = WtPoly<W>::o(pa, DO - s_), vb = WtPoly<W>::o(pb, DO - s_);
         o[g][s_] = (f32x2){va, vb};
+#if DDSP_WT_PK_ASM
         DDSP_KEEP_IN_VGPR(o[g][s_]);
+#endif
       });
     });
     wt_static_for<DE + 1>([&](auto ss) {
       constexpr int s_ = decltype(ss)::value;
       constexpr float ve = WtPoly<W>::e(0, DE - s_), vo = (DE - s_) <= DO ? WtPoly<W>::o(0, (DE - s_) <= DO ? DE - s_ : 0) : 0.0f;
       m[s_] = (f32x2){ve, vo};
+#if DDSP_WT_PK_ASM
       if (MID) DDSP_KEEP_IN_VGPR(m[s_]);
+#endif
     });
   }
 };
@@ -536,6 +563,20 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         fetch_f0(dM);
       }
       if (rw == 1 && dA.nfr > 0) fetch_amp(dA);
+#if defined(DDSP_EXP_T_DUMMY_LOADS)     // experiment: vector memory loads of THIS wavefront landing while its MFMAs run
+      ddsp_f32x4 exp_dummy = {0.f, 0.f, 0.f, 0.f};
+      auto exp_dummy_issue = [&]() {
+        const float4* src = reinterpret_cast<const float4*>(&kWtFrags.v[rw][0][0][0][0][0][0]) + lane;
+#pragma unroll
+        for (int i = 0; i < DDSP_EXP_T_DUMMY_LOADS; ++i) load_issue(exp_dummy, src + 64 * i);
+      };
+#if !defined(DDSP_EXP_T_DUMMY_AFTER)
+      exp_dummy_issue();
+#endif
+#if defined(DDSP_EXP_T_DUMMY_WAIT_BEFORE)     // .. but landed before the first MFMA
+      __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(exp_dummy));
+#endif
+#endif
       // ---------------- table of chunk tick + 1: O and E on the quarter range ---------------------------------------
       if (dM.nfr > 0) {
 #pragma unroll
@@ -628,6 +669,12 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         }
        }
       }
+#if defined(DDSP_EXP_T_DUMMY_LOADS)
+#if defined(DDSP_EXP_T_DUMMY_AFTER)           // .. issued behind the last MFMA instead
+      exp_dummy_issue();
+#endif
+      __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(exp_dummy));
+#endif
       DDSP_WT_STAMP(1);
       desc_issue((tick + 3) & 7);
       // ---------------- wavefront 3: the per-frame phase tables of chunk tick + 1 ---------------------------------------
@@ -1030,6 +1077,17 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             if (ADD)
 #pragma unroll
               for (int u = 0; u < NT; ++u) out[u] += addv[u];
+#if defined(DDSP_EXP_DEBUG_DUMP)       // experiment: the per-sample intermediates, eight floats per sample
+            if (p.dbg != nullptr) {
+              float* dump = reinterpret_cast<float*>(p.dbg);
+#pragma unroll
+              for (int u = 0; u < NT; ++u) {
+                float* d8 = dump + 8 * (chunk0 + (size_t)(tile * 64 + lane) + 512u * (size_t)u);
+                d8[0] = theta[u]; d8[1] = zz[u][0]; d8[2] = acc0[u][0]; d8[3] = acc0[u][1];
+                d8[4] = acc1[u][0]; d8[5] = acc1[u][1]; d8[6] = w_next[u]; d8[7] = (float)(t0[u] - tab);
+              }
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < NT; ++u) *reinterpret_cast<float*>(out_chunk + (o32 + 2048u * (unsigned)u)) = out[u];          // N == F * hop
           };
@@ -1097,6 +1155,9 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   blocks = (p.total_frames + p.frames_per_block - 1) / p.frames_per_block;       // no empty block
   const dim3 grid((unsigned)blocks), block(1024);
   p.dbg = nullptr;
+#if defined(DDSP_EXP_DEBUG_DUMP)
+  if (const char* e = getenv("DDSP_EXP_DUMP_PTR")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 10));
+#endif
 #ifdef DDSP_WT_TIMELINE
   // DDSP_EXP_TABLE_TIMELINE=1 (a -DDDSP_WT_TIMELINE build): block 0 records shader-clock stamps per tick
   static const bool timeline = getenv("DDSP_EXP_TABLE_TIMELINE") != nullptr;

@@ -53,7 +53,11 @@ def test_no_scratch_in_the_harmonic_table_kernels(asm):
   for name in names:
     block = asm[asm.index('.name:           ' + name) - 400:asm.index('.name:           ' + name) + 400]
     m = re.search(r'\.private_segment_fixed_size:\s+(\d+)', block)
-    assert m and int(m.group(1)) == 0, '%s uses %s bytes of scratch per lane' % (name, m and m.group(1))
+    # the 129 .. 200-harmonic instances with processors.Add fused in (<10, 4, .., ADD = true, ..>) hold the other signal's four
+    # samples per lane across phase B on top of ten taps' worth of registers: three of them go to scratch since phase B runs on
+    # plain FMAs (round 4) - 12 bytes per lane and tick, nothing next to a tick of 8 us; every other instance: none
+    limit = 24 if re.search(r'harm_table_kernelILi10ELi4ELb[01]ELb1E', name) else 0
+    assert m and int(m.group(1)) <= limit, '%s uses %s bytes of scratch per lane' % (name, m and m.group(1))
 
 
 def test_pinned_loads_are_not_touched_before_their_wait(asm):
@@ -157,3 +161,22 @@ def test_no_vector_written_scalar_base_right_before_a_pinned_load(asm):
         states += int(prev.split()[1]) + 1 if prev.startswith('s_nop') else 1
   assert loads >= 24
 
+
+
+def test_no_assembly_statement_packed_fma_in_phase_b(asm):
+  """Round 4 (csrc/harmonic_table.hip, "phase B on pairs of fp32 values"; profiles/r04_packed_fma_glitch.txt): runs of v_pk_fma_f32
+  issued from assembly statements in the interpolators came back wrong in the last sixteen lanes now and then while a tabulator of
+  the same SIMD ran MFMAs.  Phase B is plain v_fma_f32 since; the statements survive behind -DDDSP_EXP_PACKED_PHASE_B for
+  experiments and must not reach the product build."""
+  kernels = _kernels(asm)
+  assert kernels
+  for name, body in kernels.items():
+    in_asm = False
+    for line in body.split('\n'):
+      t = line.strip()
+      if t.startswith(';;#ASMSTART'):
+        in_asm = True
+      elif t.startswith(';;#ASMEND'):
+        in_asm = False
+      elif in_asm:
+        assert not t.startswith('v_pk_'), '%s: `%s` inside an assembly statement' % (name, t)
