@@ -83,7 +83,7 @@ SIGNATURES = {
     'ddsp_safe_divide_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_int, c_int, ctypes.c_float, c_voidp]),
     'ddsp_safe_log_f32': (c_int, [c_f32p] * 2 + [c_size_t, ctypes.c_float, c_voidp]),
     'ddsp_harmonic_frequencies_f32': (c_int, [c_f32p] * 2 + [c_size_t, c_int, c_voidp]),
-    'ddsp_remove_above_nyquist_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_int, c_voidp]),
+    'ddsp_remove_above_nyquist_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_float, c_voidp]),
     'ddsp_angular_cumsum_workspace_bytes': (c_size_t, [c_int] * 3),
     'ddsp_angular_cumsum_f32': (c_int, [c_f32p] * 2 + [c_voidp, c_size_t] + [c_int] * 3 + [c_voidp]),
     'ddsp_profile_kernel_count': (c_int, []),

@@ -27,12 +27,23 @@ def _device():
 def tf_float32(x):
   """core.tf_float32 (ddsp/core.py:31-36): anything -> contiguous fp32 tensor in HBM."""
   if type(x) is torch.Tensor and x.is_cuda and x.dtype is torch.float32 and x.is_contiguous():
+    _check_current_device(x)
     return x                                  # the common case: nothing to do (host overhead matters)
   if isinstance(x, torch.Tensor):
     if not x.is_cuda:
       x = x.to(_device())
+    else:
+      _check_current_device(x)
     return x.to(torch.float32).contiguous()
   return torch.as_tensor(np.asarray(x, dtype=np.float32), device=_device()).contiguous()
+
+
+def _check_current_device(x):
+  """Every kernel is enqueued on the CURRENT device's current stream (one process per GPU is the model): a tensor
+  that lives on another GPU of the process would be handed to a stream of the wrong device.  Fail loudly."""
+  if x.device.index != torch._C._cuda_getDevice():
+    raise ValueError('tensor on {} but the current device is cuda:{}: ddsp_amd launches on the current device - wrap the '
+                     'call in `with torch.cuda.device({})`'.format(x.device, torch._C._cuda_getDevice(), x.device.index))
 
 
 def _stream():
@@ -77,8 +88,8 @@ class Workspace:
   """Grow-only scratch buffers in HBM, one per (device, stream): kernels enqueued on different streams never share
   scratch, and a buffer is only ever replaced by work enqueued behind its last user on the same stream (the caching
   allocator hands a freed block back to the stream it was allocated on).  A Processor instance may therefore be
-  called from several streams; each stream pays for its own scratch.  The stream is the current one of the TENSOR's
-  device; at most `kMaxStreams` buffers are kept, least recently used first out (short-lived streams do not pile up
+  called from several streams; each stream pays for its own scratch.  The stream is the current one of the tensor's
+  device, which is the current device (tf_float32 refuses tensors of another GPU: kernels launch on the current one); at most `kMaxStreams` buffers are kept, least recently used first out (short-lived streams do not pile up
   scratch, and a recycled stream handle finds a buffer that was last used on that very handle)."""
   kMaxStreams = 8
 
@@ -217,7 +228,7 @@ def remove_above_nyquist(frequency_envelopes, amplitude_envelopes, sample_rate=1
   f = frequency_envelopes.expand(shape).contiguous()
   a = amplitude_envelopes.expand(shape).contiguous()
   out = torch.empty(shape, dtype=torch.float32, device=a.device)
-  rc = _lib.load().ddsp_remove_above_nyquist_f32(f.data_ptr(), a.data_ptr(), out.data_ptr(), a.numel(), int(sample_rate),
+  rc = _lib.load().ddsp_remove_above_nyquist_f32(f.data_ptr(), a.data_ptr(), out.data_ptr(), a.numel(), float(sample_rate),
                                                  _stream())
   _lib.check(rc, 'ddsp_remove_above_nyquist_f32')
   return out

@@ -742,12 +742,12 @@ extern "C" int ddsp_harmonic_frequencies_f32(const float* frequencies, float* ou
 }
 
 extern "C" int ddsp_remove_above_nyquist_f32(const float* frequency_envelopes, const float* amplitude_envelopes, float* out,
-                                             size_t n, int sample_rate, void* stream) {
+                                             size_t n, float sample_rate, void* stream) {
   if (!frequency_envelopes || !amplitude_envelopes || !out) return DDSP_ERR_NULL_POINTER;
-  if (sample_rate <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (!(sample_rate > 0.0f)) return DDSP_ERR_BAD_SHAPE;
   if (n == 0) return DDSP_OK;
   hipLaunchKernelGGL(remove_above_nyquist_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
-                     frequency_envelopes, amplitude_envelopes, out, n, (float)(sample_rate / 2.0));
+                     frequency_envelopes, amplitude_envelopes, out, n, (float)((double)sample_rate / 2.0));
   return check_launch();
 }
 

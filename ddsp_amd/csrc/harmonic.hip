@@ -17,6 +17,7 @@
 //             the k loop; the Hann / linear interpolation weights are applied once per
 //             sample after the loop.
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <hip/hip_ext.h>
 #include "common.h"
@@ -773,10 +774,26 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   // A set may only be handed out again when the launch that had it last is done: launches on ONE stream are, by stream
   // order; with more than kSchedSets streams in flight the new launch waits for the set's last user (an event per set,
   // recorded behind every launch: ~1 us of host time on a path that is not the default one).
-  static hipEvent_t set_done[kSchedSets];
-  static std::atomic<int> set_state[kSchedSets];            // 0: never used, 1: event exists and was recorded
-  if (set_state[p.sched_set].load(std::memory_order_acquire) == 1)
-    (void)hipStreamWaitEvent(st, set_done[p.sched_set], 0);
+  // (g_sched is a __device__ array: one copy per GPU.  The events are per (device, set) as well - an event belongs to the
+  // device it was created on - and made under a lock: two host threads may launch at once.  ADVICE r3)
+  constexpr int kMaxDevices = 16;
+  struct SetEvents { hipEvent_t done[kSchedSets]; bool made[kSchedSets]; };
+  static SetEvents set_events[kMaxDevices] = {};
+  static std::mutex set_lock;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return DDSP_ERR_LAUNCH;
+  hipEvent_t set_done = nullptr;
+  {
+    std::lock_guard<std::mutex> guard(set_lock);
+    SetEvents& se = set_events[dev];
+    if (se.made[p.sched_set]) {
+      (void)hipStreamWaitEvent(st, se.done[p.sched_set], 0);      // (recorded behind the set's last launch, below)
+    } else {
+      if (hipEventCreateWithFlags(&se.done[p.sched_set], hipEventDisableTiming) != hipSuccess) return DDSP_ERR_LAUNCH;
+      se.made[p.sched_set] = true;
+    }
+    set_done = se.done[p.sched_set];
+  }
   // STD: the flag combination of Harmonic.__call__ with default arguments, compiled in
   const bool std_flags = (flags & DDSP_HARM_SCALE_EXP_SIGMOID) && (flags & DDSP_HARM_NORMALIZE_NYQUIST) &&
                          !inputs_are_controls && !ctl_amp && !ctl_hd && (flags >> 24) == 0;
@@ -801,11 +818,11 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   else return DDSP_ERR_UNSUPPORTED;
 #undef DDSP_LAUNCH_FUSED_LPR
 #undef DDSP_LAUNCH_FUSED
-  if (set_state[p.sched_set].load(std::memory_order_acquire) == 0 &&
-      hipEventCreateWithFlags(&set_done[p.sched_set], hipEventDisableTiming) != hipSuccess)
-    return DDSP_ERR_LAUNCH;
-  if (hipEventRecord(set_done[p.sched_set], st) != hipSuccess) return DDSP_ERR_LAUNCH;
-  set_state[p.sched_set].store(1, std::memory_order_release);
+  {
+    // (under the lock: the launch-to-record window of one thread must not let another thread wait on the event's OLD record)
+    std::lock_guard<std::mutex> guard(set_lock);
+    if (hipEventRecord(set_done, st) != hipSuccess) return DDSP_ERR_LAUNCH;
+  }
   return check_launch();
 }
 // fused path: hop a multiple of 64, K a multiple of 4 (16-byte rows), caller buffers 16-byte aligned

@@ -436,10 +436,17 @@ __device__ __forceinline__ void wt_taps_pk(const float* const (&t)[kWtNT], const
   });
 }
 
+// (the output pointer: restrict-qualified unless processors.Add rides in the kernel - include/ddsp_amd.h lets add_signal BE the
+// output buffer, every element read and written by the same lane, and a restrict-qualified pointer would promise the compiler
+// that no such read exists)
+typedef float* __restrict__ WtOutRestrict;
+template <bool ADD> struct WtOut { typedef WtOutRestrict type; };
+template <> struct WtOut<true> { typedef float* type; };
+
 template <int W, int NK, bool ONE_TILE, bool ADD, bool ROWS16>
 __global__ __launch_bounds__(1024) void harm_table_kernel(
     const float* __restrict__ amplitudes, const float* __restrict__ hd, const float* __restrict__ f0_all,
-    float* __restrict__ audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, TableArgs p) {
+    typename WtOut<ADD>::type audio, float* __restrict__ ctl_amp, float* __restrict__ ctl_hd, const float* add_in, TableArgs p) {
   constexpr int kWtH = WtGeom<W>::H, kWtTS = WtGeom<W>::TS, kWtPS = WtPlane<NK>::PS;
   constexpr bool WIDE = NK > 2;                   // 129 .. 200 harmonics: see the tabulators and the row makers
   __shared__ __attribute__((aligned(16))) float tab_all[2][kWtRows * kWtTS];

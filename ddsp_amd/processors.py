@@ -83,18 +83,28 @@ class ProcessorGroup(dags.DAGLayer):
           # the other signal must exist when the Harmonic node's turn comes at the Add's position: made by an earlier
           # node or an input - anything but the Harmonic itself
           if others_ok and not other.startswith(h_node.module_name + '/'):
-            plan = (ih, ia)
+            plan = (ih, ia, h, getattr(self, add_node.module_name))
       self._fused_plan = plan
-    return self._fused_plan
+    plan = self._fused_plan
+    if plan is not None:
+      # the plan names two modules: if either attribute has been re-bound since, work it out again
+      ih, ia, h, add = plan
+      if getattr(self, self._nodes[ih].module_name) is not h or getattr(self, self._nodes[ia].module_name) is not add:
+        del self._fused_plan
+        return self._fused_add_plan()
+      return ih, ia
+    return None
 
   def call(self, inputs, return_outputs_dict=False, **kwargs):
     """Convert input tensors arguments into a signal tensor (ddsp/processors.py:121-131).
 
-    When only the signal is asked for, nothing requires grad and the DAG ends Harmonic ... Add(that harmonic, another
-    signal), the Harmonic node runs at the Add's position with the Add fused into its kernel (Harmonic.call_add):
-    the same samples, one launch and two [batch, n_samples] streams less."""
-    plan = None if (return_outputs_dict or kwargs or torch.is_grad_enabled() and _any_requires_grad(inputs)) \
-        else self._fused_add_plan()
+    When only the signal is asked for and the DAG ends Harmonic ... Add(that harmonic, another signal), the Harmonic
+    node runs at the Add's position with the Add fused into its kernel (Harmonic.call_add): the same samples, one launch
+    and two [batch, n_samples] streams less.  A subclass that overrides get_controls / get_signal is never short-cut
+    (it would be bypassed), and where a gradient is wanted - an input that requires grad, or a trainable module inside the
+    DAG feeding the Add or the Harmonic - call_add itself takes the two differentiable calls."""
+    plan = None if (return_outputs_dict or kwargs or type(self) is not ProcessorGroup or
+                    torch.is_grad_enabled() and _any_requires_grad(inputs)) else self._fused_add_plan()
     if plan is not None:
       return self._call_fused_add(inputs, *plan)
     controls = self.get_controls(inputs, **kwargs)

@@ -134,12 +134,16 @@ class Harmonic(processors.Processor):
   def call_add(self, amplitudes, harmonic_distribution, f0_hz, add_signal):
     """`Add()(add_signal, self(amplitudes, harmonic_distribution, f0_hz))` (processors.py:162-176) as ONE launch where
     the wavetable kernel applies (ddsp_harmonic_add_f32: one [batch, n_samples] stream written instead of three more
-    moved), the two calls otherwise.  Bit-identical to the two calls.  Forward only: ProcessorGroup uses it when
-    nothing asks for the intermediate signals and nothing requires grad."""
+    moved), the two calls otherwise.  Bit-identical to the two calls.  The fused launch is forward only: when any of its
+    tensors requires grad the two (differentiable) calls run instead.  ProcessorGroup uses it when nothing asks for the
+    intermediate signals."""
     add_signal = core.tf_float32(add_signal)
     amps, hd, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0 = core.tf_float32(f0_hz)
-    core.require_no_grad('Harmonic.call_add (use __call__ and Add, which are differentiable)', amps, hd, f0, add_signal)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (amps, hd, f0, add_signal)):
+      # a gradient is wanted (a trainable module upstream in the DAG - a Reverb's impulse response, a decoder - while the
+      # DAG's inputs are detached): the two differentiable calls, as before the Add was fused (ADVICE r3)
+      return processors.Add()(add_signal, self.call(amplitudes, harmonic_distribution, f0_hz))
     b, f, k = core._check_harmonic_shapes(amps, hd, f0)
     n = int(self.n_samples)
     if (tuple(add_signal.shape) == (b, n) and self.kernel == 'auto' and

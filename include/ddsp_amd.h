@@ -439,7 +439,8 @@ int ddsp_mix_f32(const float* signal_one, const float* signal_two, const float* 
  *   ddsp_harmonic_frequencies_f32  core.get_harmonic_frequencies (:1028-1045): frequencies [rows] -> out [rows, n_harmonics],
  *                                  out[r][k] = fl32(frequencies[r] * (k + 1));
  *   ddsp_remove_above_nyquist_f32  core.remove_above_nyquist (:869-891): out = where(frequency >= sample_rate / 2, 0,
- *                                  amplitude) on n values (same shape);
+ *                                  amplitude) on n values (same shape); sample_rate is a float as in the reference, which
+ *                                  compares with `sample_rate / 2.0` whatever number it is handed;
  *   ddsp_angular_cumsum_f32        core.angular_cumsum (:800-866): angular_frequency [B, T, C] (radians per sample) -> the
  *                                  accumulated phase in [0, 2 pi), [B, T, C].  The scan runs in fp64 revolutions (chunk sums,
  *                                  wrapped prefix, running phase): the reference's `chunk_size` has no counterpart - the
@@ -450,7 +451,7 @@ int ddsp_safe_divide_f32(const float* numerator, const float* denominator, float
 int ddsp_safe_log_f32(const float* x, float* out, size_t n, float eps, void* stream);
 int ddsp_harmonic_frequencies_f32(const float* frequencies, float* out, size_t rows, int n_harmonics, void* stream);
 int ddsp_remove_above_nyquist_f32(const float* frequency_envelopes, const float* amplitude_envelopes, float* out,
-                                  size_t n, int sample_rate, void* stream);
+                                  size_t n, float sample_rate, void* stream);
 size_t ddsp_angular_cumsum_workspace_bytes(int B, int T, int C);
 int ddsp_angular_cumsum_f32(const float* angular_frequency, float* out, void* workspace, size_t workspace_bytes,
                             int B, int T, int C, void* stream);

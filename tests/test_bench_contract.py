@@ -48,7 +48,9 @@ def test_json_line_fields_and_roofline_arithmetic(bench, world, batch, dominant)
   launch_us = 31.0 if batch == 32 else 59.96
   prof = {dominant: (launch_us * 125 * 1e-3, 125)}
   breakdown = {'noise_fused65_kernel': (0.0247 * 3, 3), 'harm_table_kernel': (0.0204 * 3, 3)}
-  aux = {'measured_copy_GBs': 4000.0, 'f0_200_regime': {'ms_per_step': 0.03, 'steps': 200, 'value': 1.0}}
+  aux = {'measured_copy_GBs': 4000.0,
+         'f0_regimes': {'200+-1 Hz': {'ms_per_step': elapsed * 1.5, 'steps': 200, 'value': 1.0},
+                        '333+-1 Hz': {'ms_per_step': elapsed * 1.2, 'steps': 200, 'value': 1.0}}}
   r = bench.build_result(a, world, batch, elapsed, prof, breakdown, dominant, overlap=batch < 64, aux=aux,
                          alt_elapsed=0.05, gather_ms=0.4 if world > 1 else None,
                          cpu_baseline_fn=lambda args: {'value': 0.77, 'unit': 'Msamples/s', 'cores': 1,
@@ -72,9 +74,26 @@ def test_json_line_fields_and_roofline_arithmetic(bench, world, batch, dominant)
   assert roof['achieved'] == pytest.approx(per_clip * batch / (launch_us * 1e-6) / 1e9)
   assert roof['frac'] == pytest.approx(roof['achieved'] / 8000.0)
   assert roof['frac_of_measured_copy'] == pytest.approx(roof['achieved'] / 4000.0)
-  assert 0 < roof['alu_note']['frac'] < 1 and 0 < roof['alu_note']['whole_step_frac'] < 1
+  # the ALU note says what its flop count is (the reference formulation's, which the wavetable kernel does not execute:
+  # VERDICT r3, weak #6b) and carries what the kernel executes when an SQ counter pass of the shape is committed
+  note = roof['alu_note']
+  assert 'achieved_TFLOPs' not in note and 'frac' not in note
+  assert 0 < note['reference_formulation_equivalent_frac'] < 1 and 0 < note['whole_step_reference_formulation_equivalent_frac'] < 1
+  assert note['reference_formulation_equivalent_TFLOPs'] == pytest.approx(
+      note['reference_formulation_flop_per_launch'] / (launch_us * 1e-6) / 1e12)
+  assert 'executed' in note and (note['executed'] is None or note['executed']['wave_instructions_per_launch'] > 0)
   assert roof['traffic'] is None or roof['traffic'] > 0
-  assert line['f0_200_regime']['steps'] == 200 and line['other_issue_mode']['value'] > 0
+  assert line['other_issue_mode']['value'] > 0
+  # every f0 regime with its whole-step roofline fraction, the worst at the top level
+  step_bytes = 1180000 * batch
+  regimes = line['f0_regimes']
+  assert set(regimes) == {'200+-1 Hz', '333+-1 Hz', '70+-1 Hz (headline)'}
+  for r_ in regimes.values():
+    assert r_['frac'] == pytest.approx(step_bytes / (r_['ms_per_step'] * 1e-3) / 1e9 / 8000.0)
+  assert line['f0_200_regime'] == regimes['200+-1 Hz'] and line['f0_200_regime']['steps'] == 200
+  assert line['worst_regime']['regime'] == '200+-1 Hz' and line['min_regime_frac'] == pytest.approx(regimes['200+-1 Hz']['frac'])
+  assert line['min_regime_frac'] == pytest.approx(roof['whole_step']['frac'] / 1.5)
+  assert line['regime_worst_over_best_time'] == pytest.approx(1.5)
   if world == 1:
     assert line['cpu_baseline']['kind'] == 'port' and 'allgather_ms' not in line
   else:
@@ -85,7 +104,7 @@ def test_minimal_call_without_optional_blocks(bench):
   a = _args(bench, '--no-cpu-baseline')
   r = bench.build_result(a, 1, 32, 0.04, {'harm_table_kernel': (2.0, 100)}, {'harm_table_kernel': (0.06, 3)},
                          'harm_table_kernel', overlap=True)
-  assert 'cpu_baseline' not in r and 'other_issue_mode' not in r and 'f0_200_regime' not in r
+  assert 'cpu_baseline' not in r and 'other_issue_mode' not in r and 'f0_200_regime' not in r and 'min_regime_frac' not in r
   assert 'measured_copy_GBs' not in r['roofline']
   json.dumps(r)
 
@@ -176,6 +195,10 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert line['roofline']['kernel'] == 'noise_fused65_kernel'         # the larger isolated time above
   assert 'aux_error' not in line, line.get('aux_error')
   assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 10
+  assert len(line['f0_regimes']) == 5 and all(r_['frac'] > 0 for r_ in line['f0_regimes'].values())
+  assert 0 < line['min_regime_frac'] <= line['roofline']['whole_step']['frac'] and line['regime_worst_over_best_time'] >= 1.0
+  for centre in (220.0, 333.0, 500.0):
+    assert any(abs(f - centre) < 7.0 for f in calls['f0s']), centre
   assert line['cpu_baseline']['kind'] == 'port' and 'other_issue_mode' in line
   assert calls['harm'] == calls['noise'] and calls['harm'] >= 2 + 3 + 7 + 7 + 20 + 10
   assert calls['fused'] >= 7 and line['fused_add']['bytes_per_sample'] < 18.44 and line['fused_add']['value'] > 0
@@ -337,3 +360,28 @@ def test_default_shape_carries_configs_1_and_configs_4_two_ranks():
 def test_gpus_2_on_a_box_without_two_gpus_refuses_instead_of_reporting_one():
   r = _run_bench('--gpus', '2', '--steps', '5', '--warmup', '2')
   assert r.returncode != 0 and 'refusing' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_pmc_records_are_matched_on_kernel_batch_and_shape(bench, tmp_path, monkeypatch):
+  """VERDICT r3, weak #6a: `traffic` of configs[4]'s 126 MB launch was the 16 kHz batch-32 figure - the lookup was keyed on the
+  batch alone.  A PMC record is used for a launch of the same kernel at the same batch AND shape."""
+  prof = tmp_path / 'profiles'
+  prof.mkdir()
+  (prof / 'pmc_traffic.json').write_text(json.dumps({'batch': 32, 'kernels': {'harm_table_kernel': 23.5e6}}))
+  (prof / 'pmc_traffic_config5.json').write_text(json.dumps({
+      'batch': 32, 'shape': {'n_frames': 2500, 'n_harmonics': 200, 'n_samples': 480000, 'sample_rate': 48000},
+      'kernels': {'harm_table_kernel': 130e6}}))
+  (prof / 'pmc_sq_b128.json').write_text(json.dumps({
+      'batch': 128, 'source': 'stub', 'sq': {'harm_table_kernel': {'SQ_INSTS_VALU': 12e6, 'SQ_INSTS_SALU': 4e6, 'SQ_INSTS_LDS': 2e6,
+                                                                  'SQ_WAVE_CYCLES': 100e6, 'SQ_WAIT_INST_ANY': 30e6}}}))
+  monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+  a = _args(bench)
+  assert bench.load_traffic(a, 'harm_table_kernel', 32) == 23.5e6
+  assert bench.load_traffic(a, 'harm_table_kernel', 128) is None
+  a5 = _args(bench, '--n-frames', '2500', '--n-harmonics', '200', '--n-samples', '480000', '--sample-rate', '48000')
+  assert bench.load_traffic(a5, 'harm_table_kernel', 32) == 130e6
+  assert bench.load_traffic(a5, 'noise_mfma65_kernel', 32) is None
+  ex = bench.load_issue_counters(a, 'harm_table_kernel', 128, 38e-6)
+  assert ex['wave_instructions_per_launch'] == 18e6 and ex['per_simd_clock'] == pytest.approx(18e6 / (1024 * 38e-6 * 2.4e9))
+  assert ex['wave_cycles_waiting_for_an_instruction'] == pytest.approx(0.3)
+  assert bench.load_issue_counters(a5, 'harm_table_kernel', 32, 80e-6) is None

@@ -164,3 +164,59 @@ def test_config1_batch32_every_row(ddsp):
   for r in (0, 13, 22, 31):
     ref = O.filtered_noise(x['magnitudes'][r:r + 1], noise_np[r:r + 1], 0, dtype=np.float64)
     parity_check(y[r:r + 1], ref, noise_tol(ref), 'batch 32 row %d vs fp64 oracle' % r)
+
+
+@pytest.mark.parametrize('f0_centre', [200.0, 333.0])
+def test_north_star_shape_batch128_harmonic_crossing_regimes(ddsp, f0_centre):
+  """The north-star shape where the Nyquist-crossing path runs in most frames: f0 = 200 +- 1 Hz is
+  SURVEY 8(d)'s second regime (processors_test.py:40; harmonic 40 sits on 8 kHz), 333 +- 1 Hz puts harmonic 24 there and the
+  table reads on their worst bank-conflict resonance - on the 16.5-chunk schedule of batch 128.  Every row bit-equal to the row
+  run alone and inside a batch of 32; six rows against exact arithmetic outside the knife-edge samples (audio-rate mask in TF's
+  fp32 op order, ddsp/core.py:942-944)."""
+  b = 128
+  x = canonical_inputs(b, seed=int(f0_centre))
+  rng = np.random.default_rng(int(f0_centre) + 1)
+  f0 = (f0_centre + rng.standard_normal((b, 1000, 1))).astype(np.float32)
+  harm = ddsp.synths.Harmonic()
+  args = tuple(torch.as_tensor(a, device=DEV) for a in (x['amplitudes'], x['harmonic_distribution'], f0))
+  full = npy(harm(*args))
+  assert full.shape == (b, 64000) and np.isfinite(full).all()
+  _rows_equal_alone(harm, args, full, range(b))
+  for q in range(4):
+    np.testing.assert_array_equal(npy(harm(*[a[32 * q:32 * q + 32] for a in args])), full[32 * q:32 * q + 32])
+  scale = max(1.0, float(O.exp_sigmoid(x['amplitudes'].astype(np.float64), dtype=np.float64).max()))
+  for r in sorted(rng.choice(b, 6, replace=False).tolist()):
+    sl = slice(r, r + 1)
+    exact, knife = _harmonic_exact(x['amplitudes'][sl], x['harmonic_distribution'][sl], f0[sl], 64000, 16000, 'window',
+                                   with_knife_edges=True)
+    assert knife.mean() <= 2e-2
+    err = float(np.abs(full[sl] - exact)[~knife].max())
+    parity_check(np.where(knife, exact, full[sl]), exact, HARM_TABLE_ATOL * scale,
+                 'batch 128, f0 = %g +- 1 Hz, row %d vs exact arithmetic (%.2e)' % (f0_centre, r, err))
+
+
+def test_config5_batch32_every_row(ddsp):
+  """BASELINE configs[4] per GPU as bench.py runs it: batch 32 x 10 s at 48 kHz, 2500 frames of 192
+  samples, 200 harmonics (gin/models/vst/vst_48k.gin:16-17,102) - the 129 .. 200-harmonic instances on ~312 frames per block,
+  ten chunks with the fp64 phase prefix carried across row boundaries.  Every row bit-equal to the row run alone; four rows
+  against exact arithmetic."""
+  b, f, hop, k, sr = 32, 2500, 192, 200, 48000
+  n = f * hop
+  rng = np.random.default_rng(51)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = (100 + rng.standard_normal((b, f, 1))).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method='linear', use_angular_cumsum=True)
+  args = tuple(torch.as_tensor(a, device=DEV) for a in (amps, hd, f0))
+  full_t = synth(*args)
+  full = npy(full_t)
+  assert full.shape == (b, n) and np.isfinite(full).all()
+  for r in range(b):                                   # compared on the device: 61 MB per row pair otherwise
+    one = synth(*[a[r:r + 1] for a in args])
+    assert bool(torch.equal(one, full_t[r:r + 1])), 'row %d run alone differs from the row in its batch' % r
+  assert bool(torch.equal(synth(*[a[8:24] for a in args]), full_t[8:24]))
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  for r in (0, 9, 22, 31):
+    sl = slice(r, r + 1)
+    exact = _harmonic_exact(amps[sl], hd[sl], f0[sl], n, sr, 'linear')
+    parity_check(full[sl], exact, HARM_TABLE_ATOL * scale, 'config 5 at batch 32, row %d vs exact arithmetic' % r)

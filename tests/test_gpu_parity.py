@@ -1390,3 +1390,53 @@ def test_processor_group_fused_add_is_bit_identical(ddsp):
   z96 = np.random.default_rng(4).standard_normal((3, n96)).astype(np.float32)
   np.testing.assert_array_equal(npy(h96.call_add(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'], z96)),
                                 npy(h96(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'])) + z96)
+
+
+def test_processor_group_fused_add_with_a_trainable_module_inside(ddsp):
+  """ADVICE r3 (processors.py:98): the gradient may come from a module INSIDE the DAG while the DAG's inputs are detached - a
+  trainable Reverb ahead of the Add (the Add then gets a signal that requires grad), or a re-bound / subclassed group.  The
+  short-cut through Harmonic.call_add must then take the two differentiable calls, not raise: same samples as the unfused
+  group, and dL/d ir reaches the Reverb."""
+  n_frames, n = 50, 3200
+  x = canonical_inputs(2, seed=23, n_frames=n_frames)
+  features = {'amps': x['amplitudes'], 'harmonic_distribution': x['harmonic_distribution'], 'f0_hz': x['f0_hz'],
+              'magnitudes': x['magnitudes']}
+
+  def build():
+    harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+    noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, name='filtered_noise', seed=3)
+    rev = ddsp.effects.Reverb(trainable=True, reverb_length=300, name='reverb')
+    rev.build(device=torch.device(DEV))
+    rev._ir = ddsp.core.tf_float32(np.random.default_rng(5).standard_normal(300) * 0.05).requires_grad_(True)
+    add = ddsp.processors.Add(name='add')
+    dag = [(noise, ['magnitudes']), (rev, ['filtered_noise/signal']),
+           (harmonic, ['amps', 'harmonic_distribution', 'f0_hz']), (add, ['reverb/signal', 'harmonic/signal'])]
+    return ddsp.processors.ProcessorGroup(dag=dag, name='processor_group'), rev
+  g1, rev1 = build()
+  g2, rev2 = build()
+  assert g1._fused_add_plan() == (2, 3)
+  out = g1(features)                                   # inputs detached, the Reverb's impulse response requires grad
+  assert out.requires_grad
+  ref = g2(features, return_outputs_dict=True)['signal']
+  np.testing.assert_array_equal(npy(out), npy(ref))
+  w = ddsp.core.tf_float32(np.random.default_rng(6).standard_normal((2, n)))
+  out.backward(w)
+  ref.backward(w)
+  assert rev1._ir.grad is not None and float(rev1._ir.grad.abs().max()) > 0
+  np.testing.assert_array_equal(npy(rev1._ir.grad), npy(rev2._ir.grad))
+  # a module re-bound after the plan was made: worked out again, not served from the cache
+  g1.harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+  assert g1._fused_add_plan() == (2, 3)
+  # a subclass that overrides get_signal is never short-cut
+  class Halved(ddsp.processors.ProcessorGroup):
+    def get_signal(self, outputs):
+      return ddsp.processors.ProcessorGroup.get_signal(self, outputs) * 0.5
+  def dag():                                           # (modules of its own per group: a FilteredNoise counts its calls)
+    harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+    noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, name='filtered_noise', seed=3)
+    return [(harmonic, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
+            (ddsp.processors.Add(name='add'), ['filtered_noise/signal', 'harmonic/signal'])]
+  with torch.no_grad():
+    halved = npy(Halved(dag=dag())(features))
+    plain = npy(ddsp.processors.ProcessorGroup(dag=dag())(features, return_outputs_dict=True)['signal'])
+  np.testing.assert_array_equal(halved, plain * 0.5)

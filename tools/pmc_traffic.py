@@ -7,6 +7,8 @@ so read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken at face value (uncal
 import collections, csv, glob, json, os, sys
 
 root, batch = sys.argv[1], int(sys.argv[2])
+# optional: n_frames n_harmonics n_samples sample_rate of the launch (bench.py matches a record on kernel, batch AND shape)
+shape = [int(v) for v in sys.argv[3:7]]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
   with open(path) as f:
@@ -17,7 +19,8 @@ for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recur
       short = name.split('(')[0].replace('void ', '').replace('ddsp::', '').split('<')[0]
       vals[short][row['Counter_Name']].append(float(row['Counter_Value']))
 alias = {'tv_fir128_kernel': 'tv_fir_kernel', 'noise_ir65_kernel': 'noise_ir_kernel'}
-out = {'batch': batch, 'note': 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 '
+out = {'batch': batch, 'shape': dict(zip(('n_frames', 'n_harmonics', 'n_samples', 'sample_rate'), shape)) if len(shape) == 4 else {},
+       'note': 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 '
        '(gfx950 FETCH_SIZE correction x2; WRITE_SIZE uncalibrated)', 'kernels': {}, 'detail': {}}
 for k, d in vals.items():
   fetch = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1)
