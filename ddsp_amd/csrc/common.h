@@ -39,6 +39,22 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += dpp_mov0<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// minimum over the 64 lanes, result in every lane (as a wave-uniform value): the DPP steps of wave_sum_dpp with fminf; lanes a
+// step does not write keep their own value (`old` = the value itself)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_dpp(float v) {
+  v = fminf(v, dpp_keep<0xB1, 0xF>(v));     // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_keep<0x4E, 0xF>(v));     // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_keep<0x141, 0xF>(v));    // row_half_mirror
+  v = fminf(v, dpp_keep<0x140, 0xF>(v));    // row_mirror: every lane holds its 16-lane row's minimum
+  v = fminf(v, dpp_keep<0x142, 0xA>(v));    // row_bcast:15 -> rows 1, 3
+  v = fminf(v, dpp_keep<0x143, 0xC>(v));    // row_bcast:31 -> rows 2, 3: lane 63 holds the minimum of all
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov0(double v) {
   const long long b = __builtin_bit_cast(long long, v);
@@ -251,6 +267,13 @@ __device__ __forceinline__ void loads_landed(float& a) {
   __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a));
 #else
   (void)a;
+#endif
+}
+__device__ __forceinline__ void loads_landed(float& a, float& b) {
+#if defined(__AMDGCN__)
+  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b));
+#else
+  (void)a; (void)b;
 #endif
 }
 __device__ __forceinline__ void loads_landed(float& a, float& b, float& c) {

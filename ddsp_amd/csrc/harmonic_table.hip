@@ -34,18 +34,19 @@
 #include "common.h"
 #include "profile.h"
 #include "harmonic_table.h"
-#define DDSP_WT_TABLE __constant__
-#include "wavetable_coeffs.h"
+#include "wavetable_coeffs.h"      // (the window's polynomials: compile-time constants; 1 / psi_hat: host tables for the fragments)
 #include "harm_table_frags.h"
+#include <mutex>
 
 namespace ddsp {
 
-constexpr WtSinSplit kWtSinSplit = make_wt_sin_split();
-static __device__ const WtFrags kWtFrags = make_wt_frags(kWtSinSplit);      // 64 KB of constants, fetched once per T-wavefront
-static __device__ const WtFragsWide kWtFragsWide = make_wt_frags_wide(kWtSinSplit);      // 128 KB: 129 .. 200 harmonics, streamed from L2 every tick
+// the constant factors (harm_table_frags.h), filled in once per device by wt_upload_fragments() below
+static __device__ WtFragSet kWtFragSet6;      // six taps (K <= 100): table sizes 512 .. 64, 92 KB
+static __device__ WtFragSet kWtFragSet8;      // eight taps (K <= 128)
+static __device__ WtFragsWide kWtFragsWide;   // ten taps, 129 .. 200 harmonics: 128 KB, streamed from L2 every tick
 
-constexpr int kWtT = 512;            // table points per revolution
-constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, kWtHalf + kWtH); the other half is its mirror image
+constexpr int kWtT = 512;            // table points per revolution: the LARGEST table (a segment with few live harmonics takes 256, 128 or 64)
+constexpr int kWtHalf = kWtT / 2;    // the table holds p in [-kWtH, T / 2 + kWtH); the other half is its mirror image
 constexpr int kWtNQ = kWtT / 4;      // positions produced by the matrix product
 // halo entries on either side of a table row (>= W/2, a multiple of 4) and the row stride in floats (4*odd, so 16 rows'
 // b128 writes spread over the banks), by window width: 4 and 268 up to eight taps, 8 and 276 for ten
@@ -71,30 +72,34 @@ struct ChunkTables {
   float f0[kWtRows + 2];
   int kA[kWtRows], kN[kWtRows];
   int cross;           // any frame of the chunk with a harmonic crossing Nyquist inside it (kA < kN)
+  // the FIRST crossing harmonic kA of a frame, ready-made by the wavefront that builds these tables (lanes = frames): the two
+  // rows' amplitudes d am, the frame's end frequencies of that harmonic as top and (bot - top), and k as a float.  The
+  // interpolators used to gather all of that per tile - two index reads, two f0, two amplitudes, four 2-byte plane reads -
+  // behind three waits: a frame with a crossing harmonic cost twice a frame without (round 3 measured this at 6 - 9 % per
+  // launch at 200 / 250 / 333 Hz and took it out again when two bit-equality tests failed once - the packed-FMA fault of
+  // phase B, which had nothing to do with it: profiles/r04_packed_fma_glitch.txt).
+  float4 cx[kWtRows];  // {d0 am0, d1 am1, fj k, (fj1 - fj) k}
+  float ck[kWtRows];   // k
 };
 
 template <int W> struct WtPoly;
 template <> struct WtPoly<6> {
-  static constexpr int DE = kWtDegE6, DO = kWtDegO6, KMAX = 128;
+  // K512: the harmonics 512 points carry at this window's error bound (T / 2K >= 2.56 for six taps; launch_harm_table);
+  // a table of T points carries K512 T / 512
+  static constexpr int DE = kWtDegE6, DO = kWtDegO6, K512 = 100;
   static constexpr float e(int p, int d) { return kWtE6[p * (DE + 1) + d]; }
   static constexpr float o(int p, int d) { return kWtO6[p * (DO + 1) + d]; }
-  __device__ static float invpsi(int k) { return kWtInvPsi6_T512[k]; }
-  __device__ static float psi(int k) { return kWtPsi6_T512[k]; }
 };
 template <> struct WtPoly<8> {
-  static constexpr int DE = kWtDegE8, DO = kWtDegO8, KMAX = 128;
+  static constexpr int DE = kWtDegE8, DO = kWtDegO8, K512 = 128;
   static constexpr float e(int p, int d) { return kWtE8[p * (DE + 1) + d]; }
   static constexpr float o(int p, int d) { return kWtO8[p * (DO + 1) + d]; }
-  __device__ static float invpsi(int k) { return kWtInvPsi8_T512[k]; }
-  __device__ static float psi(int k) { return kWtPsi8_T512[k]; }
 };
 
 template <> struct WtPoly<10> {      // 129 .. 200 harmonics on the same 512 points (oversampling 1.28; tools/gen_wavetable_coeffs.py)
-  static constexpr int DE = kWtDegE10, DO = kWtDegO10, KMAX = 208;
+  static constexpr int DE = kWtDegE10, DO = kWtDegO10, K512 = 200;
   static constexpr float e(int p, int d) { return kWtE10[p * (DE + 1) + d]; }
   static constexpr float o(int p, int d) { return kWtO10[p * (DO + 1) + d]; }
-  __device__ static float invpsi(int k) { return kWtInvPsi10_T512[k]; }
-  __device__ static float psi(int k) { return kWtPsi10_T512[k]; }
 };
 
 // =====================================================================================================================
@@ -161,38 +166,79 @@ constexpr unsigned kWtSlots = DDSP_WT_SLOTS;     // nibble sw: the tile slot of 
                                                  // the slots that come up short (7, 6, then 5, 4) are SIMD 3's and SIMD 0's
 struct WtDesc { int b, j0, nfr, fresh; };        // a chunk: frames j0 .. j0 + nfr - 1 of row b; nfr == 0: none
 
+struct WtSizeThresholds { float t64, t128, t256; };      // wt_table_size below
+
 struct TableArgs {
   int B, F, K, N, hop;
   int total_frames, frames_per_block;
-  FastDiv f_div, tpf_div;        // F; hop / 64
+  FastDiv f_div, tpf_div, seg_div;        // F; hop / 64; kWtSegment
   float nyquist, nyq_lo, nyq_hi;
+  WtSizeThresholds size_thr;      // the table size of a segment from its smallest f0
   int amp_linear;
   int rows16;          // rows of hd (and of the controls out) are 16 bytes apart and aligned: K % 4 == 0, aligned bases
   double inv_sr, inv_2hop, hop_d, half_hm1;
   long long* dbg;      // DDSP_EXP_TABLE_TIMELINE=1: shader-clock stamps of block 0, [wavefront][tick + 2][stamp]; or null
 };
 
-struct WtWalk { int pos, end, seg_left, base, rem, b, j; };
+struct WtWalk { int pos, pos_first, end, seg_left, base, rem, b, j; };
+
+// TABLE SIZE (round 4).  The table positions of neighbouring samples are T f0 / sr entries apart; on 512 points that is 6.4 at
+// 200 Hz, 10.7 at 333 Hz, 16 at 500 Hz (16 kHz) - strides at which the 32 lanes of an LDS read meet in a handful of banks (the
+// table reads then cost 2.5 - 4 times their 70 Hz time: the kernel's f0 dependence of rounds 2-3, 37 us at 70 Hz against 60 - 74
+// at the divisors of Nyquist).  But a frame whose f0 is high has few harmonics below Nyquist, and a table of T points carries
+// K512 T / 512 of them at the same error bound (the window and its oversampling ratio T / 2K are what they were): frames are
+// therefore tabulated on T = 512, 256, 128 or 64 points by their f0, which keeps the stride between 1.3 and 5.1 entries at
+// any f0, halves (quarters, ..) the matrix product and the table writes - and makes the table reads of a 500 Hz note what they
+// are at 70 Hz.  T must be the same for the two rows of a frame, hence for runs of frames - and which frames share a T must not
+// depend on how the batch is cut into blocks and chunks, or a row run alone would differ in its bits from the row run in a
+// batch.  So: a row is cut into SEGMENTS of kWtSegment frames at fixed positions (j / kWtSegment), T is a function of the
+// segment's f0 alone (the smallest over its frames and the one behind them: wt_table_size), and the walker never lets a chunk
+// straddle a segment boundary (two chunks of 31 frames per full segment).
+#if defined(DDSP_EXP_SEGMENT)
+constexpr int kWtSegment = DDSP_EXP_SEGMENT;       // experiment: other segment lengths (a huge one: no cuts)
+#else
+constexpr int kWtSegment = 2 * kWtFrames;
+#endif
 
 // the next chunk of the block's run of frames (one wavefront, wave-uniform arithmetic)
 __device__ __forceinline__ WtDesc wt_next_chunk(WtWalk& w, const TableArgs& p) {
   WtDesc d{0, 0, 0, 0};
   if (w.pos >= w.end) return d;
-  if (w.seg_left == 0) {                      // a new row segment: cut it into equal chunks
+  if (w.seg_left == 0) {                      // a new piece of a segment: cut it into equal chunks
     uint32_t j;
-    w.b = (int)fastdiv((uint32_t)w.pos, p.f_div, j);
+    const int b = (int)fastdiv((uint32_t)w.pos, p.f_div, j);
+    d.fresh = (w.pos == w.pos_first || (int)j == 0) ? 1 : 0;      // the block's first chunk, or the first of a row: the prefix is summed afresh
+    w.b = b;
     w.j = (int)j;
-    w.seg_left = min(w.end - w.pos, p.F - w.j);
+    uint32_t in_seg;
+    (void)fastdiv(j, p.seg_div, in_seg);
+    w.seg_left = min(min(w.end - w.pos, p.F - w.j), kWtSegment - (int)in_seg);
     const int n = (w.seg_left + kWtFrames - 1) / kWtFrames;
     w.base = w.seg_left / n;
     w.rem = w.seg_left - w.base * n;
-    d.fresh = 1;
   }
   const int len = w.base + (w.rem > 0 ? 1 : 0);
   if (w.rem > 0) --w.rem;
   d.b = w.b; d.j0 = w.j; d.nfr = len;
   w.pos += len; w.j += len; w.seg_left -= len;
   return d;
+}
+
+// The table size of a segment from the smallest f0 of its frames (and of the frame behind them).  floor(nyquist / f0) bounds the
+// harmonics any of its rows has below Nyquist (core.remove_above_nyquist on f0 k, core.py:899-903); a table of T points carries
+// K512 T / 512.  As three thresholds on f0 made once per launch (wt_size_thresholds): T points suffice iff f0_min >= thr[T]
+// (-inf where K itself is small enough; a NaN or an f0 <= 0 with many harmonics compares false: 512 points).
+__device__ __forceinline__ int wt_table_size(float f0_min, const WtSizeThresholds& th) {
+  return f0_min >= th.t64 ? 64 : f0_min >= th.t128 ? 128 : f0_min >= th.t256 ? 256 : kWtT;
+}
+inline WtSizeThresholds wt_size_thresholds(int K512, int K, float nyq_hi) {
+  auto thr = [&](int T) -> float {
+    const int kmax = K512 * T / 512;                  // what T points carry (100 -> 50, 25, 12; 128 -> 64, 32, 16)
+    if (K <= kmax) return -__builtin_inff();
+    // floor(nyq_hi / f0) <= kmax  <=>  f0 > nyq_hi / (kmax + 1); a hair above it
+    return (float)((double)nyq_hi / (double)(kmax + 1) * (1.0 + 1e-6));
+  };
+  return WtSizeThresholds{thr(64), thr(128), thr(256)};
 }
 
 __device__ __forceinline__ WtDesc wt_read_desc(const WtDesc* ring, int slot) {
@@ -454,6 +500,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
   __shared__ ChunkTables t_all[2];
   __shared__ __attribute__((aligned(16))) WtDesc ring[8];
   __shared__ float amp_tab[3][kWtRows + 4];          // the frames' amplitudes (scaled), per plane buffer: tabulator 1 -> all tabulators
+  __shared__ int tsel[4];                            // the table size of chunk c in slot c & 3: tabulator 1 -> tabulators, interpolators
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,6 +522,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
   // ---- the first two chunk descriptors (the walker), then everybody reads ----------------------------------------
   WtWalk walk;
   walk.pos = (int)blockIdx.x * p.frames_per_block;
+  walk.pos_first = walk.pos;
   walk.end = min(walk.pos + p.frames_per_block, p.total_frames);
   walk.seg_left = 0; walk.base = 0; walk.rem = 0; walk.b = 0; walk.j = 0;
   if (wave == kWtWalker) {
@@ -502,21 +550,39 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
     // ---- this wavefront's share of the constant factor, in MFMA A-operand layout (harm_table_frags.h) ---------------
     // (four k-steps, WIDE: 128 registers' worth - the share of one parity and row tile is fetched from L2 where it is
     // used, below: 64 KB per tabulator and tick, which a frame of three or more tiles - what such shapes have - hides)
+    // K <= 128: the fragments of ONE table size at a time, fetched when a chunk's size differs from the last one's (16 loads
+    // for 512 points, 4 for the smaller tables: a note that stays inside one size class never fetches again)
     f16x8 ahi[2][2][WIDE ? 1 : NK], alo[2][2][WIDE ? 1 : NK];
-    if constexpr (!WIDE) {
+    int frag_T = 0;
+    auto fetch_fragments = [&](int T) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const WtFragSet& set = W == 6 ? kWtFragSet6 : kWtFragSet8;
+      // (a wave-uniform base and a 32-bit lane offset made HERE: left to itself the compiler keeps a 64-bit address per
+      // fragment alive over the whole tick loop - in scratch)
+      unsigned l16 = 16u * (unsigned)(tid & 63);
+      DDSP_KEEP_IN_VGPR(l16);
+      if (T == kWtT) {
+        const char* base = reinterpret_cast<const char*>(set.t512.v[rw]);      // [part][parity][tt][ks][lane][4]
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
+        for (int par = 0; par < 2; ++par)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+          for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 vh = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][0][par][tt][ks][lane]);
-          const u32x4 vl = *reinterpret_cast<const u32x4*>(kWtFrags.v[rw][1][par][tt][ks][lane]);
-          ahi[par][tt][ks] = __builtin_bit_cast(f16x8, vh);
-          alo[par][tt][ks] = __builtin_bit_cast(f16x8, vl);
+            for (int ks = 0; ks < (WIDE ? 1 : NK); ++ks) {
+              const unsigned off = (unsigned)(((par * 2 + tt) * 2 + ks) * 1024);
+              ahi[par][tt][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (l16 + off)));
+              alo[par][tt][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (l16 + (off + 8192u))));
+            }
+      } else if (rw < (T >> 6)) {
+        const WtFragsSmall& f = T == 256 ? set.t256 : T == 128 ? set.t128 : set.t64;
+        const char* base = reinterpret_cast<const char*>(f.v[rw]);              // [part][parity][lane][4]
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          ahi[par][0][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (l16 + 1024u * par)));
+          alo[par][0][0] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(base + (l16 + 1024u * par + 2048u)));
         }
-    }
+      }
+    };
     // wavefront 3 builds the per-frame phase tables (lanes = frames 0 .. 32): f0 of the chunk's frames, issued before the
     // MFMAs of the tick and used after them; `before` = the sum of f0 over the frames of the row before the chunk, carried
     // from chunk to chunk and summed afresh (fp64: exact, so the same bits in any order) at the start of a row segment
@@ -557,23 +623,65 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
     // wavefront 1 makes the amplitudes of chunk tick + 2 (lanes = frames 0 .. nfr: core.exp_sigmoid of the row's
     // amplitude, ddsp/synths.py:120-121): fetched at the top of a tick, scaled after its MFMAs, multiplied into the table
     // by every tabulator a tick later - the row makers' planes hold the normalised distribution only
-    float pamp = 0.0f;
+    // ... and the chunk's TABLE SIZE: the smallest f0 over the frames of the chunk's segment and the frame behind them (one load
+    // per lane: a segment has 62 frames), wt_table_size
+    // (in the registers wavefront 3 pins its f0 loads in - pf_cur, pf_next: a wavefront is one OR the other, which the register
+    // allocator cannot know; names of their own cost two registers across the MFMAs and pushed a fragment into scratch)
+    float& pamp = pf_cur;
+    float& pseg = pf_next;
+    // The size of chunk tick + 3 is made at tick `tick` (three ticks before its phase B, two before its tabulation): everybody
+    // else reads it a tick ahead of use, beside the descriptor, and carries it in a scalar register - read where it is used, the
+    // LDS round trip sat at the head of every tick of wavefronts that set the tick's length (+ 1.5 us per launch at batch 128).
+    // The very first chunk's is made together with the second's in the first tick (pf_first holds its f0: nothing else of
+    // this wavefront uses that register).
     auto fetch_amp = [&](const WtDesc& d) {
       int lane_ = lane;
       DDSP_KEEP_IN_VGPR(lane_);
       load_issue(pamp, amplitudes + (size_t)d.b * F + min(d.j0 + lane_, F - 1));
     };
+    auto fetch_segment = [&](const WtDesc& d, float& dst) {
+      int lane_ = lane;
+      DDSP_KEEP_IN_VGPR(lane_);
+      uint32_t in_seg;
+      (void)fastdiv((uint32_t)d.j0, p.seg_div, in_seg);
+      load_issue(dst, f0_all + (size_t)d.b * F + min(d.j0 - (int)in_seg + lane_, F - 1));
+    };
+    auto fragments_landed = [&]() {
+#if defined(__AMDGCN__)
+      __asm__ volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int ks = 0; ks < (WIDE ? 1 : NK); ++ks)
+            __asm__ volatile("" : "+v"(ahi[par][tt][ks]), "+v"(alo[par][tt][ks]));
+#endif
+    };
+    // 512 points are what most launches start with: fetched now, on the off chance, and landed at the end of the first tick, in
+    // which a tabulator has nothing to tabulate (fetched when the first chunk's size is known, the block's first table waits for
+    // 64 KB from L2: + 1200 clocks per launch, r04u)
+    if constexpr (!WIDE) { fetch_fragments(kWtT); frag_T = kWtT; }
+    int Tm = kWtT, Tm_ahead = kWtT;                // the table size of the chunk this tick tabulates; the next tick's, read ahead
     for (int tick = -2;; ++tick) {
       DDSP_WT_STAMP(0);
       if (rw == 3 && dM.nfr > 0) {
         if (dM.fresh) before = row_prefix(dM);
         fetch_f0(dM);
       }
-      if (rw == 1 && dA.nfr > 0) fetch_amp(dA);
+      WtDesc dN{0, 0, 0, 0};                        // chunk tick + 3 (tabulator 1 only: the others take it at the end of the tick)
+      if (rw == 1) {
+        if (dA.nfr > 0) fetch_amp(dA);
+        if constexpr (!WIDE) {
+          dN = wt_read_desc(ring, (tick + 3) & 7);
+          if (dN.nfr > 0) fetch_segment(dN, pseg);
+          if (tick == -2 && dA.nfr > 0) fetch_segment(dA, pf_first);
+        }
+      }
 #if defined(DDSP_EXP_T_DUMMY_LOADS)     // experiment: vector memory loads of THIS wavefront landing while its MFMAs run
       ddsp_f32x4 exp_dummy = {0.f, 0.f, 0.f, 0.f};
       auto exp_dummy_issue = [&]() {
-        const float4* src = reinterpret_cast<const float4*>(&kWtFrags.v[rw][0][0][0][0][0][0]) + lane;
+        const float4* src = reinterpret_cast<const float4*>(&kWtFragSet6.t512.v[rw][0][0][0][0][0][0]) + lane;
 #pragma unroll
         for (int i = 0; i < DDSP_EXP_T_DUMMY_LOADS; ++i) load_issue(exp_dummy, src + 64 * i);
       };
@@ -585,7 +693,55 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #endif
 #endif
       // ---------------- table of chunk tick + 1: O and E on the quarter range ---------------------------------------
-      if (dM.nfr > 0) {
+      if constexpr (!WIDE) {
+#if !defined(DDSP_EXP_FORCE_T512)
+        Tm_ahead = tsel[(tick + 2) & 3];           // chunk tick + 2, the next tick's: issued here, taken at the end of the tick
+        if (tick == -1) Tm = __builtin_amdgcn_readfirstlane(tsel[0]);      // (the first chunk's was made in the tick before: no tick ahead of that)
+#endif
+        if (dM.nfr > 0 && Tm != frag_T) {
+          fetch_fragments(Tm);
+          frag_T = Tm;
+          // Landed HERE, inside the branch: left to the compiler the wait sits where the fragments are first used - partial
+          // vmcnt waits in the middle of the MFMAs, executed every tick, which also wait for the pinned f0 / amplitude loads of
+          // tabulators 3 and 1 that the MFMAs are there to hide
+          fragments_landed();
+        }
+      }
+#if defined(DDSP_EXP_NO_SMALL_PATH)
+      if (false) {
+#else
+      if (dM.nfr > 0 && !WIDE && Tm != kWtT) {
+#endif
+        // ---- 256, 128 or 64 points: T / 64 position tiles - tabulator rw has tile rw or none -, one k-step -------------------
+        if (rw < (Tm >> 6)) {
+          const int half = Tm >> 1;
+#pragma unroll
+          for (int rt = 0; rt < kWtRowTiles; ++rt) {
+            const _Float16* bsrc = planes_all[pm] + (16 * rt + mi) * kWtPS + 8 * mg;
+            const float am = amp_tab[pm][16 * rt + mi], am_lo = am * (1.0f / kWtLoScale);
+            f32x4 soe[2];
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+              const f16x8 bhi = *reinterpret_cast<const f16x8*>(bsrc + (0 * 2 + par) * kWtRows * kWtPS);
+              const f16x8 blo = *reinterpret_cast<const f16x8*>(bsrc + (1 * 2 + par) * kWtRows * kWtPS);
+              const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+              const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][0][0], bhi, zero, 0, 0, 0);
+              f32x4 accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[par][0][0], blo, zero, 0, 0, 0);
+              accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[par][0][0], bhi, accx, 0, 0, 0);
+              soe[par] = acc * am + accx * am_lo;
+            }
+            float* trow = tab_all[(tick + 1) & 1] + (16 * rt + mi) * kWtTS + kWtH;
+            const int n0 = 16 * rw + 4 * mg;
+            const f32x4 sp = soe[0] + soe[1], sm = soe[0] - soe[1];     // S(n) = O + E, S(T/2-1-n) = O - E
+            *reinterpret_cast<f32x4*>(trow + n0) = sp;
+            *reinterpret_cast<f32x4*>(trow + (half - 4 - n0)) = (f32x4){sm.w, sm.z, sm.y, sm.x};
+            if (n0 == 0) {                                              // halos (four entries either side: K <= 128)
+              *reinterpret_cast<f32x4*>(trow - 4) = (f32x4){-sp.w, -sp.z, -sp.y, -sp.x};
+              *reinterpret_cast<f32x4*>(trow + half) = (f32x4){-sm.x, -sm.y, -sm.z, -sm.w};
+            }
+          }
+        }
+      } else if (dM.nfr > 0) {
 #pragma unroll
        for (int rt = 0; rt < kWtRowTiles; ++rt) {
         // B: element e of lane (j = lane & 15, g = lane >> 4): plane[part][par][row 16 rt + j][32 ks + 8 g + e]
@@ -729,6 +885,21 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             t.kA[lane] = kA;
             t.kN[lane] = kN;
           }
+          if (any != 0ull) {                                   // (wave-uniform; rows lane, lane + 1 <= 31 for a frame)
+            float4 cx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float ck = 0.0f;
+            if (crossing) {
+              const int k = kA;
+              const float kfl = (float)(k + 1);
+              const _Float16* pl = planes_all[pm] + ((k & 1) * kWtRows + lane) * kWtPS + (k >> 1);
+              const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
+              const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
+              const float top = rn_mul(fj, kfl), bot = rn_mul(fj1, kfl);
+              cx = make_float4(rn_mul(c0, amp_tab[pm][lane]), rn_mul(c1, amp_tab[pm][lane + 1]), top, rn_sub(bot, top));
+              ck = kfl;
+            }
+            if (lane < kWtRows) { t.cx[lane] = cx; t.ck[lane] = ck; }
+          }
           // the sum over this chunk's frames: lane 31 holds the inclusive sum of lanes 0 .. 31 (lanes >= nfr added 0)
           const long long bits31 = __builtin_bit_cast(long long, incl);
           const unsigned lo31 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits31 & 0xffffffffll), 31);
@@ -736,13 +907,30 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           before += __builtin_bit_cast(double, (long long)(((unsigned long long)hi31 << 32) | lo31));
         }
       }
-      if (rw == 1 && dA.nfr > 0) {
-        loads_landed(pamp);
+      if (rw == 1 && (dA.nfr > 0 || dN.nfr > 0)) {
+        loads_landed(pamp, pseg, pf_first);
         int lane_ = lane;
         DDSP_KEEP_IN_VGPR(lane_);
-        const float a = exp_sigmoid_fast(pamp, kLog10, 2.0f, 1e-7f);
-        if (lane_ <= kWtRows) amp_tab[pa][lane_] = a;
-        if (ctl_amp != nullptr && lane_ < dA.nfr) ctl_amp[(size_t)dA.b * F + dA.j0 + lane_] = a;
+        if (dA.nfr > 0) {
+          const float a = exp_sigmoid_fast(pamp, kLog10, 2.0f, 1e-7f);
+          if (lane_ <= kWtRows) amp_tab[pa][lane_] = a;
+          if (ctl_amp != nullptr && lane_ < dA.nfr) ctl_amp[(size_t)dA.b * F + dA.j0 + lane_] = a;
+        }
+        if constexpr (!WIDE) {
+#if !defined(DDSP_EXP_NO_TSEL_COMPUTE)
+          // (lanes 0 .. 62: the segment's frames and the one behind; a NaN is no minimum - fminf - and <= 0 keeps 512 points)
+          if (dN.nfr > 0) {
+            const int t_sel = wt_table_size(wave_min_dpp(lane_ <= kWtSegment ? pseg : __builtin_inff()), p.size_thr);
+            if (lane_ == 0) tsel[(tick + 3) & 3] = t_sel;
+          }
+          if (tick == -2 && dA.nfr > 0) {
+            const int t_sel = wt_table_size(wave_min_dpp(lane_ <= kWtSegment ? pf_first : __builtin_inff()), p.size_thr);
+            if (lane_ == 0) tsel[0] = t_sel;
+          }
+#else
+          if (lane_ < 4) tsel[lane_] = kWtT;
+#endif
+        }
       }
       DDSP_WT_STAMP(2);
       // ---------------- the walker: the descriptor of chunk tick + 4 ---------------------------------------------------
@@ -751,6 +939,10 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         if (lane == 0) ring[(tick + 4) & 7] = dn;
       }
       desc_take();
+      if constexpr (!WIDE) {
+        Tm = __builtin_amdgcn_readfirstlane(Tm_ahead);
+        if (tick == -2) fragments_landed();
+      }
       DDSP_WT_STAMP(3);
       __syncthreads();
       DDSP_WT_STAMP(4);
@@ -775,13 +967,11 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       const int hq = WIDE ? lane : kq;
       const bool live_h = WIDE ? lane < K4 : live;
       auto row_of = [&](int i, int pass) -> int { return 2 * u0 + NU * pass + i; };      // (WIDE)
-      // per-lane constants: 1 / psi_hat(k), the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit:
-      // always masked)
-      float ipsi[4], kf[4], nyq_u[4];
+      // per-lane constants: the harmonic numbers (dead lanes, k > K: 0 and a negative Nyquist limit: always masked)
+      float kf[4], nyq_u[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool alive = 4 * hq + u + 1 <= K;              // (K need not be a multiple of 4: the last lane's tail is dead)
-        ipsi[u] = alive ? WtPoly<W>::invpsi(min(4 * hq + u + 1, WtPoly<W>::KMAX)) : 0.0f;
         kf[u] = alive ? (float)(4 * hq + u + 1) : 0.0f;
         nyq_u[u] = alive ? p.nyquist : -1.0f;
       }
@@ -851,7 +1041,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       // (harmonics as pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 do two lanes' worth per issued instruction)
       // (harmonics as pairs of EQUAL parity - (4 kq + 1, 4 kq + 3) and (4 kq + 2, 4 kq + 4): v_pk_mul / v_pk_add /
       // v_pk_fma_f32 do two lanes' worth per issued instruction, and a pair is what one dword of a parity plane holds)
-      const f32x2 kf_o = {kf[0], kf[2]}, kf_e = {kf[1], kf[3]}, ipsi_o = {ipsi[0], ipsi[2]}, ipsi_e = {ipsi[1], ipsi[3]};
+      const f32x2 kf_o = {kf[0], kf[2]}, kf_e = {kf[1], kf[3]};
       auto exp_sigmoid2 = [&](f32x2 v) -> f32x2 {                      // exp_sigmoid_fast on a pair
         const f32x2 t = v * -1.4426950408889634f;
         const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
@@ -916,11 +1106,11 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             }
           }
         }
-        // c_k = d_k / psi_hat(k) (d = the normalised distribution) as hi + lo / 2048, two fp16 numbers each (hi rounded toward zero by
-        // v_cvt_pkrtz_f16_f32: lo takes up the rest)
+        // d_k (the normalised distribution; 1 / psi_hat(k) is in the constant factor since round 4: harm_table_frags.h) as
+        // hi + lo / 2048, two fp16 numbers each (hi rounded toward zero by v_cvt_pkrtz_f16_f32: lo takes up the rest)
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          const f32x2 c[2] = {(xo[i] * inv[i]) * ipsi_o, (xe[i] * inv[i]) * ipsi_e};       // k odd (k' = 2 kq, 2 kq + 1), k even
+          const f32x2 c[2] = {xo[i] * inv[i], xe[i] * inv[i]};       // k odd (k' = 2 kq, 2 kq + 1), k even
           _Float16* dst = planes + (WIDE ? row_of(i, pass) : 2 * (u0 + i) + sub) * kWtPS + 2 * hq;
 #pragma unroll
           for (int par = 0; par < 2; ++par) {
@@ -981,9 +1171,17 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
       WtPkCoefs<W> coef;
       coef.init();
       const int slot = (int)((kWtSlots >> (4 * sw)) & 7u);
+      // the table size of the chunk phase B works on: read a tick ahead (tabulator 1 wrote it two ticks before the chunk's
+      // phase B), taken into a scalar register at the end of the tick - read where it is used, its LDS latency was at the head
+      // of every tick of the wavefronts that set the tick's length (+ 0.7 us per launch at batch 128)
+      float Tf = (float)kWtT;
+      int t_ahead = kWtT;
       for (int tick = -2;; ++tick) {
         DDSP_WT_STAMP(0);
         desc_issue((tick + 3) & 7);
+#if !defined(DDSP_EXP_FORCE_T512)
+        if constexpr (!WIDE) t_ahead = tsel[(tick + 1) & 3];  // chunk tick + 1: the next tick's
+#endif
         DDSP_WT_STAMP(1);
         if (dB.nfr > 0) {
           // ---------------- phase B of chunk tick: tiles of 64 samples, lanes = samples ----------------------------
@@ -995,6 +1193,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           const int hop = p.hop;
           const float inv_hop = 1.0f / (float)hop;
           const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
+
           const int n_tiles = ONE_TILE ? nfr : nfr * (hop >> 6);
           const size_t chunk0 = (size_t)row0 * (size_t)hop;
           char* out_chunk = reinterpret_cast<char*>(audio + chunk0);          // (add_in may be this very buffer: no __restrict__)
@@ -1039,10 +1238,10 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               const float hm = 0.5f - theta[u];                               // S(1 - theta) = -S(theta): sign bit <=> theta > 1/2
               sgn[u] = __builtin_bit_cast(unsigned, hm) & 0x80000000u;
               const float th = 0.5f - fabsf(hm);                              // [0, 0.5]
-              const float pos = fmaf(th, (float)kWtT, -0.5f);                 // table coordinate, [-0.5, 255.5]
+              const float pos = fmaf(th, Tf, -0.5f);                          // table coordinate, [-0.5, T / 2 - 0.5]
               const float z = __builtin_amdgcn_fractf(pos) - 0.5f;            // (v_fract_f32: pos - floor(pos), below 1)
               zz[u] = (f32x2){z, z * z};
-              t0[u] = tab + q[u] * kWtTS + kWtH + wt_floor_int(pos);          // floor(pos) in [-1, 255]
+              t0[u] = tab + q[u] * kWtTS + kWtH + wt_floor_int(pos);          // floor(pos) in [-1, T / 2 - 1]
             }
             f32x2 acc0[kWtNT], acc1[kWtNT];
 #pragma unroll
@@ -1066,18 +1265,28 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               const int kA = __builtin_amdgcn_readfirstlane(t.kA[q[u]]);
               const int kN = __builtin_amdgcn_readfirstlane(t.kN[q[u]]);
               if (kA < kN) {         // harmonics crossing Nyquist inside this frame: audio-rate mask, TF's fp32 op order
-                const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
-                const float am0 = amp_tab[pb][q[u]], am1 = amp_tab[pb][q[u] + 1];
-                for (int k = kA; k < kN; ++k) {
-                  const float kfl = (float)(k + 1);
-                  const float top = fj * kfl, bot = fj1 * kfl;
-                  const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp[u]));
-                  const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
-                  const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
-                  const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
-                  const float ak = rn_mul(fmaf(w_next[u], rn_mul(c1, am1), rn_mul(w_cur[u], rn_mul(c0, am0))), WtPoly<W>::psi(k + 1));
-                  const float sv = sin_rev(fmaf(theta[u], kfl, -rintf(theta[u] * kfl)));     // exact fractional part of k theta
+                {                    // the first of them from the chunk tables (two broadcast reads; see ChunkTables)
+                  const float4 cx = t.cx[q[u]];
+                  const float ck = t.ck[q[u]];
+                  const float fk = rn_add(cx.z, rn_mul(cx.w, lerp[u]));
+                  const float ak = fmaf(w_next[u], cx.y, rn_mul(w_cur[u], cx.x));
+                  const float sv = sin_rev(fmaf(theta[u], ck, -rintf(theta[u] * ck)));     // exact fractional part of k theta
                   if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
+                }
+                if (kA + 1 < kN) {   // more than one: the general form (an f0 that moves by several per cent within a frame)
+                  const float fj = t.f0[q[u]], fj1 = t.f0[q[u] + 1];
+                  const float am0 = amp_tab[pb][q[u]], am1 = amp_tab[pb][q[u] + 1];
+                  for (int k = kA + 1; k < kN; ++k) {
+                    const float kfl = (float)(k + 1);
+                    const float top = fj * kfl, bot = fj1 * kfl;
+                    const float fk = rn_add(top, rn_mul(rn_sub(bot, top), lerp[u]));
+                    const _Float16* pl = planes + ((k & 1) * kWtRows + q[u]) * kWtPS + (k >> 1);
+                    const float c0 = fmaf((float)pl[2 * kWtRows * kWtPS], 1.0f / kWtLoScale, (float)pl[0]);
+                    const float c1 = fmaf((float)pl[2 * kWtRows * kWtPS + kWtPS], 1.0f / kWtLoScale, (float)pl[kWtPS]);
+                    const float ak = fmaf(w_next[u], rn_mul(c1, am1), rn_mul(w_cur[u], rn_mul(c0, am0)));
+                    const float sv = sin_rev(fmaf(theta[u], kfl, -rintf(theta[u] * kfl)));     // exact fractional part of k theta
+                    if (fk >= p.nyquist) out[u] = fmaf(-ak, sv, out[u]);
+                  }
                 }
               }
             }
@@ -1109,6 +1318,7 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         }
         DDSP_WT_STAMP(2);
         desc_take();
+        if constexpr (!WIDE) Tf = (float)__builtin_amdgcn_readfirstlane(t_ahead);
         DDSP_WT_STAMP(3);
         __syncthreads();
         DDSP_WT_STAMP(4);
@@ -1130,6 +1340,36 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
   return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 1 && K <= 200 && F < (1 << 24);
 }
 
+// The fragment sets of a window on the current device: made on the host once per process, copied once per device (under a
+// lock; the copy is synchronous - the one thing in this library that is, once).  0 on success.
+static int wt_upload_fragments(int W) {
+  constexpr int kMaxDevices = 16;
+  static std::mutex lock;
+  static bool done[kMaxDevices][3] = {};
+  static WtFragSet* host6 = nullptr;
+  static WtFragSet* host8 = nullptr;
+  static WtFragsWide* host10 = nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1;
+  const int slot = W == 6 ? 0 : W == 8 ? 1 : 2;
+  std::lock_guard<std::mutex> guard(lock);
+  if (done[dev][slot]) return 0;
+  hipError_t rc = hipSuccess;
+  if (W == 6) {
+    if (!host6) { host6 = new WtFragSet; wt_fill_frag_set(host6, kWtInvPsi6_T512, (int)(sizeof(kWtInvPsi6_T512) / sizeof(float))); }
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(kWtFragSet6), host6, sizeof(WtFragSet));
+  } else if (W == 8) {
+    if (!host8) { host8 = new WtFragSet; wt_fill_frag_set(host8, kWtInvPsi8_T512, (int)(sizeof(kWtInvPsi8_T512) / sizeof(float))); }
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(kWtFragSet8), host8, sizeof(WtFragSet));
+  } else {
+    if (!host10) { host10 = new WtFragsWide; wt_fill_frags_wide(host10, kWtInvPsi10_T512, (int)(sizeof(kWtInvPsi10_T512) / sizeof(float))); }
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(kWtFragsWide), host10, sizeof(WtFragsWide));
+  }
+  if (rc != hipSuccess) return 1;
+  done[dev][slot] = true;
+  return 0;
+}
+
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
                      float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
                      hipStream_t st) {
@@ -1139,9 +1379,12 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   p.total_frames = B * F;
   p.f_div = make_fastdiv((uint32_t)F);
   p.tpf_div = make_fastdiv((uint32_t)(p.hop >> 6));
+  p.seg_div = make_fastdiv((uint32_t)kWtSegment);
+  if (wt_upload_fragments(K <= 100 ? 6 : K <= 128 ? 8 : 10) != 0) return DDSP_ERR_LAUNCH;
   p.nyquist = (float)(sample_rate / 2.0);
   p.nyq_lo = p.nyquist * (1.0f - 4e-6f);
   p.nyq_hi = p.nyquist * (1.0f + 4e-6f);
+  p.size_thr = wt_size_thresholds(K <= 100 ? 100 : K <= 128 ? 128 : 200, K, p.nyq_hi);
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
   p.rows16 = ((K & 3) == 0 && (((uintptr_t)hd | (uintptr_t)ctl_hd) & 15) == 0) ? 1 : 0;
   p.inv_sr = 1.0 / (double)sample_rate;

@@ -72,6 +72,8 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define HIP_SYMBOL(x) x
+template <class T> hipError_t hipMemcpyToSymbol(T& symbol, const void* s, size_t n) { memcpy(&symbol, s, n); return hipSuccess; }
 template <class T> hipError_t hipMalloc(T** p, size_t n) { *p = (T*)calloc(n, 1); return hipSuccess; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }

@@ -1440,3 +1440,37 @@ def test_processor_group_fused_add_with_a_trainable_module_inside(ddsp):
     halved = npy(Halved(dag=dag())(features))
     plain = npy(ddsp.processors.ProcessorGroup(dag=dag())(features, return_outputs_dict=True)['signal'])
   np.testing.assert_array_equal(halved, plain * 0.5)
+
+
+@pytest.mark.parametrize('k,hop', [(100, 64), (128, 64), (60, 128), (99, 64)])
+def test_harmonic_table_sizes_follow_f0(ddsp, k, hop):
+  """Round 4 (csrc/harmonic_table.hip, "table size"): a segment of 62 frames is tabulated on 512, 256, 128 or 64 points by the
+  number of harmonics its smallest f0 leaves below Nyquist.  A clip whose f0 visits every class - steps between notes, a glide
+  from 90 Hz to 1.9 kHz, a segment with one frame of silence (f0 = 0: every harmonic "below Nyquist", 512 points) - against exact
+  arithmetic at the wavetable kernel's tolerance; and the bits of a row do not depend on how the batch is cut into blocks and
+  chunks (the sizes are a function of the row's own segments): rows alone, as sub-batches, in a batch."""
+  f, sr = 62 * 5 + 17, 16000
+  n = f * hop
+  rng = np.random.default_rng(700 + k + hop)
+  b = 5
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = np.zeros((b, f, 1), np.float32)
+  notes = [110.0, 170.0, 330.0, 700.0, 1400.0, 240.0]
+  f0[0, :, 0] = np.repeat(notes, 62)[:f] + rng.standard_normal(f)                   # a note per segment: every table size
+  f0[1, :, 0] = 90.0 * (1900.0 / 90.0) ** (np.arange(f) / (f - 1.0))                 # a glide through all of them
+  f0[2, :, 0] = 420.0 + 6.0 * np.sin(np.arange(f) * 0.14)                            # vibrato inside one class
+  f0[3, :, 0] = np.where(np.arange(f) % 97 == 40, 0.0, 650.0 + rng.standard_normal(f))     # frames of silence in a high note
+  f0[4, :, 0] = np.repeat([158.0, 155.0, 158.0, 155.0, 158.0, 155.0], 62)[:f] + 0.5 * rng.standard_normal(f)   # either side of a threshold
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  full = npy(synth(amps, hd, f0))
+  assert full.shape == (b, n) and np.isfinite(full).all()
+  exact, knife = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges=True)
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  assert knife.mean() <= 1e-2
+  for r in range(b):
+    parity_check(np.where(knife[r], exact[r], full[r]), exact[r], HARM_TABLE_ATOL * scale, 'table sizes by f0, row %d, K = %d' % (r, k))
+  for r in range(b):
+    np.testing.assert_array_equal(npy(synth(amps[r:r + 1], hd[r:r + 1], f0[r:r + 1])), full[r:r + 1], err_msg='row %d alone' % r)
+  np.testing.assert_array_equal(npy(synth(amps[1:4], hd[1:4], f0[1:4])), full[1:4])
+  np.testing.assert_array_equal(npy(synth(amps[3:], hd[3:], f0[3:])), full[3:])

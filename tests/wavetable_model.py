@@ -35,7 +35,11 @@ def harmonic_table_model(amplitudes, hd, f0_hz, n_samples, sample_rate=16000, T=
   de, do = c['kWtDegE%d' % W], c['kWtDegO%d' % W]
   ce = c['kWtE%d' % W].reshape(W // 2, de + 1)
   co = c['kWtO%d' % W].reshape(W // 2, do + 1)
-  invpsi = c['kWtInvPsi%d_T%d' % (W, T)]
+  # 1 / psi_hat depends on k / T alone: the T = 512 table read at k 512 / T (csrc/harm_table_frags.h)
+  invpsi512 = c['kWtInvPsi%d_T512' % W]
+  invpsi = np.zeros(max(K + 1, 2), F32)
+  kmax = min(K, (len(invpsi512) - 1) * T // 512)
+  invpsi[1:kmax + 1] = invpsi512[(np.arange(1, kmax + 1) * (512 // T))]
   nyq = F32(sample_rate / 2.0)
   f0 = f0_hz[..., 0].astype(F32)
   # phase A: controls (exp_sigmoid, frame-rate Nyquist mask, normalise), amp * distribution
@@ -50,8 +54,9 @@ def harmonic_table_model(amplitudes, hd, f0_hz, n_samples, sample_rate=16000, T=
   # table GEMM on the quarter range, odd and even harmonics apart
   n = np.arange(NQ)
   ang = (kk[None, :] * (2 * n[:, None] + 1)) / (2.0 * T)                 # revolutions, exact in fp32
-  sinm = np.sin(2 * np.pi * ang).astype(F32)                            # [NQ,K]
-  cdec = (rows * invpsi[1:K + 1]).astype(F32)
+  # round 4: 1 / psi_hat is part of the constant factor (the kernel's A-fragments), the rows are the plain amplitudes
+  sinm = (np.sin(2 * np.pi * ang).astype(F32).astype(np.float64) * invpsi[1:K + 1].astype(np.float64)).astype(F32)      # [NQ,K]
+  cdec = rows
   odd, even = np.arange(0, K, 2), np.arange(1, K, 2)                    # k = 1,3,.. / 2,4,..
   # both factors as two fp16 numbers, x = hi + lo / 2048; three products accumulated in fp32 (the kernel's MFMAs)
   def split(v):

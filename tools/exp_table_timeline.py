@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['DDSP_EXP_TABLE_TIMELINE'] = '1'
 import numpy as np, torch
 from ddsp_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'libddsp_amd_timeline.so')
+_lib.LIB_PATH = os.environ.get('DDSP_TIMELINE_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'libddsp_amd_timeline.so')
 import ddsp_amd as ddsp
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 f0c = float(sys.argv[2]) if len(sys.argv) > 2 else 70.0
