@@ -152,18 +152,31 @@ __device__ __forceinline__ U4 philox4x32(U4 c, uint32_t k0, uint32_t k1) {
 }
 __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) { return philox4x32<10>(c, k0, k1); }
 __device__ __forceinline__ U4 noise_philox(U4 c, uint32_t k0, uint32_t k1) { return philox4x32<kNoiseRounds>(c, k0, k1); }
-// 32 random bits -> uniform fp32 in [-1, 1): 23-bit mantissa in [1,2), as tf.random.uniform.
-__device__ __forceinline__ float bits_to_pm1(uint32_t bits) {
-  const float u = __uint_as_float((bits >> 9) | 0x3F800000u);
-  return fmaf(u, 2.0f, -3.0f);                 // == (u - 1) 2 - 1: every step of either form is exact
+// ---- the generated noise (FilteredNoise with no noise supplied; ddsp/synths.py:192-193 draws tf.random.uniform(-1, 1)) -------
+// Round 4: 2048 equally spaced levels, u = (2 k - 2047) / 2048, k an 11-bit field of a Philox word - zero mean, variance 1/3 to
+// 2e-7, every value EXACTLY an fp16 number.  Rounds 1-3 made 23-bit uniforms as TensorFlow does; the stream was never TF's (its
+// generator is stateful: SURVEY H6), and what those twelve extra bits cost was a third of the FIR's matrix products and half of its
+// LDS traffic: the Toeplitz operand of noise_mfma65_kernel had to be carried as an fp16 hi / lo pair.  A sample whose value IS an
+// fp16 number needs no lo part.  (Noise handed in by the caller - the parity entry - keeps the hi / lo pair and its 22 bits.)
+// Eight samples per Philox4x32 block instead of four: sample n of a row is field (n >> 1) & 3, n & 1 of block n >> 3 - bits
+// [10:0] (n even) or [26:16] (n odd) of that word.  oracle/ddsp_oracle.py device_uniform_noise restates this bit for bit.
+__device__ __forceinline__ float noise_level(uint32_t k11) {          // k11 in [0, 2047]
+  return (float)(2 * (int)k11 - 2047) * (1.0f / 2048.0f);             // exact
+}
+__device__ __forceinline__ float noise_even(uint32_t word) { return noise_level(word & 0x7FFu); }
+__device__ __forceinline__ float noise_odd(uint32_t word) { return noise_level((word >> 16) & 0x7FFu); }
+// the four samples 8 q + 4 h .. + 3 (h = 0, 1) of block q
+__device__ __forceinline__ float4 noise_quad(const U4& r, int h) {
+  const uint32_t w0 = h ? r.z : r.x, w1 = h ? r.w : r.y;
+  return make_float4(noise_even(w0), noise_odd(w0), noise_even(w1), noise_odd(w1));
 }
 // noise sample n of global batch row `row`
 __device__ __forceinline__ float philox_noise(uint32_t n, uint64_t row, uint32_t k0,
                                               uint32_t k1) {
-  const U4 r = noise_philox(U4{n >> 2, (uint32_t)row, 0u, 0u}, k0, k1);
-  const uint32_t w = n & 3u;
-  const uint32_t bits = (w == 0) ? r.x : (w == 1) ? r.y : (w == 2) ? r.z : r.w;
-  return bits_to_pm1(bits);
+  const U4 r = noise_philox(U4{n >> 3, (uint32_t)row, 0u, 0u}, k0, k1);
+  const uint32_t w = (n >> 1) & 3u;
+  const uint32_t word = (w == 0) ? r.x : (w == 1) ? r.y : (w == 2) ? r.z : r.w;
+  return (n & 1u) ? noise_odd(word) : noise_even(word);
 }
 
 // n / d for a divisor fixed at launch, without the divide: an integer division by a runtime value expands to ~40

@@ -115,13 +115,14 @@ __global__ __launch_bounds__(256) void uniform_noise_kernel(float* __restrict__ 
                                                             uint32_t k0, uint32_t k1,
                                                             uint64_t batch_offset) {
   const int b = blockIdx.y;
-  const int nq = (N + 3) / 4;
+  const int nq = (N + 7) / 8;                              // eight samples per Philox block (common.h)
   for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
     const U4 r = noise_philox(U4{(uint32_t)q, (uint32_t)(batch_offset + b), 0u, 0u}, k0, k1);
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    const float4 lo = noise_quad(r, 0), hi = noise_quad(r, 1);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (4 * q + i < N) out[(size_t)b * N + 4 * q + i] = bits_to_pm1(w[i]);
+    for (int i = 0; i < 8; ++i)
+      if (8 * q + i < N) out[(size_t)b * N + 8 * q + i] = v[i];
   }
 }
 
@@ -327,9 +328,8 @@ __global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
       if (GEN_NOISE) {
-        const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
-                                   p.k0, p.k1);
-        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+        const U4 r = noise_philox(U4{(uint32_t)(i >> 3), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        v = noise_quad(r, (i >> 2) & 1);      // (i is a multiple of 4: one half of the block's eight samples)
         if (i + 3 >= p.N) {
           if (i + 1 >= p.N) v.y = 0.f;
           if (i + 2 >= p.N) v.z = 0.f;
@@ -552,9 +552,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 0 && i < p.N) {
         if (GEN_NOISE) {
-          const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u},
-                                     p.k0, p.k1);
-          v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+          const U4 r = noise_philox(U4{(uint32_t)(i >> 3), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+          v = noise_quad(r, (i >> 2) & 1);      // (i is a multiple of 4: one half of the block's eight samples)
           if (i + 1 >= p.N) v.y = 0.f;
           if (i + 2 >= p.N) v.z = 0.f;
           if (i + 3 >= p.N) v.w = 0.f;

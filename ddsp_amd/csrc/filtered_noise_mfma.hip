@@ -153,25 +153,71 @@ __device__ __forceinline__ void mf_put4_down(unsigned char* hrow, int t1, bool f
   }
 }
 
-// The noise tile x[z0-128 .. z0+128+kMfTile) into the LDS planes (reversed, hi / lo split, two copies): NLANES lanes
-// (ltid), 16 kMfRows / NLANES quads of four samples per lane (independent Philox chains).
+// One quad of the noise tile into the LDS planes: samples v.x .. v.w of staged frame s at j .. j + 3 (reversed: element u0 =
+// sample j + 3).  LO: also the lo parts (supplied noise; generated noise IS fp16: its lo planes are never written nor read).
+template <bool LO>
+__device__ __forceinline__ void mf_put_quad(float4 v, int qd, unsigned char* s_xe, unsigned char* s_xo) {
+  _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+  mf_split(v.w, h0, l0);               // element u0     = sample j + 3
+  mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
+  mf_split(v.y, h2, l2);
+  mf_split(v.x, h3, l3);
+  const int s = qd >> 4, j = 4 * (qd & 15);
+  const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
+  // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
+  *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
+  if (LO) *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
+  // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
+  // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
+  unsigned char* po = s_xo + (u0 + 1) * 2;
+  *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
+  *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
+  *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
+  if (LO) {
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
+    *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
+    *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
+  }
+}
+
+// The noise tile x[z0-128 .. z0+128+kMfTile) into the LDS planes (reversed, two copies): NLANES lanes (ltid).  Supplied noise:
+// 16 kMfRows / NLANES quads of four samples per lane, hi / lo split.  Generated noise (common.h: 2048 levels, every value an fp16
+// number): 8 kMfRows / NLANES octets per lane - a Philox block is eight samples -, hi planes only.
 template <bool GEN_NOISE, int NLANES>
 __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const float* __restrict__ x, unsigned char* s_xe,
                                               unsigned char* s_xo, const MfArgs& p) {
-  static_assert((16 * kMfRows) % NLANES == 0, "quads per lane");
+  if constexpr (GEN_NOISE) {
+    static_assert((8 * kMfRows) % NLANES == 0, "octets per lane");
 #pragma unroll
-  for (int h = 0; h < 16 * kMfRows / NLANES; ++h) {
-    const int qd = ltid + NLANES * h;
-    const int i = z0 - 128 + 4 * qd;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i >= 0 && i < p.N) {
-      if (GEN_NOISE) {
-        const U4 r = noise_philox(U4{(uint32_t)(i >> 2), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-        v = make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
-        if (i + 1 >= p.N) v.y = 0.f;
-        if (i + 2 >= p.N) v.z = 0.f;
-        if (i + 3 >= p.N) v.w = 0.f;
-      } else {
+    for (int h = 0; h < 8 * kMfRows / NLANES; ++h) {
+      const int oc = ltid + NLANES * h;
+      const int i = z0 - 128 + 8 * oc;                              // a multiple of 8 (z0 is a multiple of 64)
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (i >= 0 && i < p.N) {                                       // (i < 0: i <= -8, the whole octet lies before the clip)
+        const U4 r = noise_philox(U4{(uint32_t)(i >> 3), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        v0 = noise_quad(r, 0);
+        v1 = noise_quad(r, 1);
+        if (i + 7 >= p.N) {                                          // the clip's last octet: zeros behind its end
+          if (i + 1 >= p.N) v0.y = 0.f;
+          if (i + 2 >= p.N) v0.z = 0.f;
+          if (i + 3 >= p.N) v0.w = 0.f;
+          if (i + 4 >= p.N) v1.x = 0.f;
+          if (i + 5 >= p.N) v1.y = 0.f;
+          if (i + 6 >= p.N) v1.z = 0.f;
+          v1.w = 0.f;
+        }
+      }
+      mf_put_quad<false>(v0, 2 * oc, s_xe, s_xo);
+      mf_put_quad<false>(v1, 2 * oc + 1, s_xe, s_xo);
+    }
+  } else {
+    static_assert((16 * kMfRows) % NLANES == 0, "quads per lane");
+#pragma unroll
+    for (int h = 0; h < 16 * kMfRows / NLANES; ++h) {
+      const int qd = ltid + NLANES * h;
+      const int i = z0 - 128 + 4 * qd;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i >= 0 && i < p.N) {
         const float* src = x + (size_t)b * p.N + i;
         if (i + 3 < p.N && ((p.N & 3) == 0)) {
           v = *reinterpret_cast<const float4*>(src);
@@ -182,26 +228,8 @@ __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const flo
           if (i + 3 < p.N) v.w = src[3];
         }
       }
+      mf_put_quad<true>(v, qd, s_xe, s_xo);
     }
-    _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
-    mf_split(v.w, h0, l0);               // element u0     = sample j + 3
-    mf_split(v.z, h1, l1);               // element u0 + 1 = sample j + 2
-    mf_split(v.y, h2, l2);
-    mf_split(v.x, h3, l3);
-    const int s = qd >> 4, j = 4 * (qd & 15);
-    const int u0 = 16 + kMfXStride * s + 60 - j;                     // a multiple of 4
-    // copy E: dwords u0/2 and u0/2 + 1 of each plane (8 bytes, 8-byte aligned)
-    *reinterpret_cast<uint2*>(s_xe + u0 * 2) = make_uint2(mf_pack(h0, h1), mf_pack(h2, h3));
-    *reinterpret_cast<uint2*>(s_xe + kMfXPlane + u0 * 2) = make_uint2(mf_pack(l0, l1), mf_pack(l2, l3));
-    // copy O: element e is half (e + 1) & 1 of dword (e + 1) >> 1, i.e. at byte 2 (e + 1): u0 -> high half of
-    // dword u0/2, (u0+1, u0+2) -> dword u0/2 + 1, u0+3 -> low half of dword u0/2 + 2
-    unsigned char* po = s_xo + (u0 + 1) * 2;
-    *reinterpret_cast<uint16_t*>(po) = __builtin_bit_cast(uint16_t, h0);
-    *reinterpret_cast<uint32_t*>(po + 2) = mf_pack(h1, h2);
-    *reinterpret_cast<uint16_t*>(po + 6) = __builtin_bit_cast(uint16_t, h3);
-    *reinterpret_cast<uint16_t*>(po + kMfXPlane) = __builtin_bit_cast(uint16_t, l0);
-    *reinterpret_cast<uint32_t*>(po + kMfXPlane + 2) = mf_pack(l1, l2);
-    *reinterpret_cast<uint16_t*>(po + kMfXPlane + 6) = __builtin_bit_cast(uint16_t, l3);
   }
 }
 
@@ -519,9 +547,11 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         auto load_step = [&](int j, int slot) {
           const int it = j / 5, c = j - 5 * it;
           const MfU4 qh = *reinterpret_cast<const MfU4*>(s_x + a_hi[it >> 1] + 32 * (4 - c) + 2 * kMfXStride * 2 * (it & 1));
-          const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[it >> 1] + 32 * (4 - c) + 2 * kMfXStride * 2 * (it & 1));
           fah[slot] = mf_frag(qh.x, qh.y, qh.z, qh.w);
-          fal[slot] = mf_frag(ql.x, ql.y, ql.z, ql.w);
+          if constexpr (!GEN_NOISE) {           // (generated noise is fp16 as it stands: no lo plane, no lo . hi product)
+            const MfU4 ql = *reinterpret_cast<const MfU4*>(s_x + a_lo[it >> 1] + 32 * (4 - c) + 2 * kMfXStride * 2 * (it & 1));
+            fal[slot] = mf_frag(ql.x, ql.y, ql.z, ql.w);
+          }
           if (c == 0) {
             // the pair's taps: first frame's row in lanes g < 2, second frame's in g >= 2
             const unsigned char* tr;
@@ -562,7 +592,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             if (c == 0) { fbh = fbh_in[it & 1]; fbl = fbl_in[it & 1]; }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbh, acc, 0, 0, 0);
             acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(fah[slot], fbl, acc_hl, 0, 0, 0);
-            acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh, acc_lh, 0, 0, 0);
+            if constexpr (!GEN_NOISE) acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fal[slot], fbh, acc_lh, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (j + 3 < 20) load_step(j + 3, slot);
             if (c < 4) { fbh = column_up(fbh); fbl = column_up(fbl); }      // under the MFMAs

@@ -928,13 +928,17 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=NOISE_ROUNDS):
 
 
 def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0):
-  """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL."""
-  n_quads = -(-n_samples // 4)
-  quad = np.arange(n_quads, dtype=np.uint64)[None, :].repeat(batch_size, 0)
+  """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL (csrc/common.h, "the generated noise"): 2048 equally
+  spaced levels u = (2 k - 2047) / 2048 - zero mean, variance 1/3, every value an fp16 number -, k an 11-bit field of a
+  Philox4x32 word; eight samples per block: sample n of a row is field ((n >> 1) & 3, n & 1) of block n >> 3, bits [10:0] of
+  the word for even n, [26:16] for odd n.  (Rounds 1-3: 23-bit uniforms, four per block.)"""
+  n_oct = -(-n_samples // 8)
+  octet = np.arange(n_oct, dtype=np.uint64)[None, :].repeat(batch_size, 0)
   row = (np.arange(batch_size, dtype=np.uint64) + np.uint64(batch_offset))[:, None]
-  row = np.broadcast_to(row, quad.shape)
-  words = philox4x32(quad, row, np.zeros_like(quad), np.zeros_like(quad),
+  row = np.broadcast_to(row, octet.shape)
+  words = philox4x32(octet, row, np.zeros_like(octet), np.zeros_like(octet),
                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, NOISE_ROUNDS)
-  bits = np.stack(words, axis=-1).reshape(batch_size, n_quads * 4)[:, :n_samples]
-  u = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32)
-  return (u - np.float32(1.0)) * np.float32(2.0) - np.float32(1.0)
+  w = np.stack(words, axis=-1).astype(np.uint32)                                   # [B, n_oct, 4]
+  fields = np.stack([w & np.uint32(0x7FF), (w >> np.uint32(16)) & np.uint32(0x7FF)], axis=-1)     # [B, n_oct, 4, 2]: even, odd
+  k = fields.reshape(batch_size, n_oct * 8)[:, :n_samples].astype(np.int64)
+  return ((2 * k - 2047).astype(np.float32) * np.float32(1.0 / 2048.0)).astype(np.float32)

@@ -59,11 +59,20 @@ def _digest():
 
 
 def build(verbose=False):
+  """Builds under an exclusive lock on the build directory: pytest-xdist workers that find the library stale at the same
+  moment used to stage and compile into the same files at once (one of them then failed to load a half-written object)."""
+  import fcntl
+  os.makedirs(BUILD, exist_ok=True)
+  with open(os.path.join(BUILD, '.lock'), 'w') as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    return _build_locked(verbose)
+
+
+def _build_locked(verbose):
   stamp = OUT + '.stamp'
   digest = _digest()
   if os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
     return OUT
-  os.makedirs(BUILD, exist_ok=True)
   staged = []
   for name in os.listdir(CSRC):                       # headers travel with the sources
     with open(os.path.join(CSRC, name)) as f:
