@@ -700,13 +700,13 @@ def main(argv=None):
       # (ii) f0 regimes beside the headline's 70 +- 1 Hz: SURVEY.md 8(d)'s second, "test-like" f0 = 200 + N(0,1) Hz
       # (processors_test.py:40; 39 of 100 harmonics below Nyquist, harmonic 40 ON it), a note with vibrato (220 Hz, 6 Hz deep
       # at 5.5 Hz), and 333 / 500 +- 1 Hz (Nyquist / 24 and / 16: the table reads' bank-conflict resonances, DESIGN.md
-      # section 7).  Same step, same stream mode, a fifth of the steps, three regions each
+      # section 7).  Same step, same stream mode, regions of the same K steps, three each
       x_r = make_inputs(B, a, seed=2000 + rank)
       jitter = x_r['f0_hz'] - a.f0
       tt = np.arange(a.n_frames)[None, :, None] / 250.0
       vib = 6.0 * np.sin(2 * np.pi * 5.5 * tt + np.random.default_rng(2100 + rank).uniform(0, 6.28, (B, 1, 1)))
       dev_headline = dict(dev)
-      k_r = max(a.steps // 5, 10)
+      k_r = a.steps                  # (regions as long as the headline's: a shorter region costs 2-3 us per step more, r03p)
       regimes = {}
       for name, f0 in (('200+-1 Hz', 200.0 + jitter), ('220 Hz, vibrato 6 Hz deep at 5.5 Hz', 220.0 + vib),
                        ('333+-1 Hz', 333.0 + jitter), ('500+-1 Hz', 500.0 + jitter)):

@@ -82,6 +82,21 @@ constexpr int kMfXPairs = kMfXElems / 2 + 1;                   // 2577 (copy O n
 // (odd rows) and the O lanes (even rows) of one ds_read2_b32 pass then sit in different halves of the banks
 constexpr int kMfXPlane = kMfWaves == 16 ? 10336 : 5216;
 static_assert(kMfXPlane >= kMfXPairs * 4 && kMfXPlane % 16 == 0 && (2 * kMfXPlane / 4) % 32 == 16, "noise plane layout");
+// Generated noise has no lo planes (round 4): copy O follows copy E's hi plane at kMfXOGen bytes - the same 16 (mod 32) dwords -,
+// and what the lo planes held is where the scaled magnitudes travel from the noise makers to the designers (MfHandoff).
+constexpr int kMfXOGen = kMfXPlane + 96;
+static_assert(kMfXOGen % 16 == 0 && (kMfXOGen / 4) % 32 == 16 && kMfWaves == 8, "noise plane layout, generated noise");
+template <bool GEN> struct MfX {
+  static constexpr int O = GEN ? kMfXOGen : 2 * kMfXPlane;                // byte offset of copy O's hi plane
+  static constexpr int BYTES = GEN ? kMfXOGen + kMfXPlane : 4 * kMfXPlane;
+};
+// The scaled magnitudes of a tile as the designers' MFMA B-fragments (rows 16 rg + i, bins 16 g .. + 15 split even / odd, hi / lo),
+// bin 64 and the finished tap 32 of every row: written by the noise makers a tile ahead, read by the designers.
+struct MfHandoff {
+  uint4 frag[kMfPW / 2][4][64];        // [row group][even hi, even lo, odd hi, odd lo][lane]
+  float last[kMfRows];                 // bin 64, scaled (0 for rows outside the clip)
+  float tap32[kMfRows];                // window[32] * sum over even bins of cos(pi m / 2) m (taps 32 and 96)
+};
 
 typedef _Float16 mf_f16x8 __attribute__((ext_vector_type(8)));
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
@@ -249,7 +264,9 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     const float* __restrict__ mag /*[B,F,65]*/, const float* __restrict__ x /*[B,N] or null*/,
     float* __restrict__ ctl_out /*[B,F,65] or null*/, float* __restrict__ out /*[B,N]*/, MfArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char s_taps_all[2][2 * kMfTapPlane];       // hi plane, lo plane
-  __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][4 * kMfXPlane];      // planes E hi, E lo, O hi, O lo
+  constexpr int kXO = MfX<GEN_NOISE>::O;             // copy O's hi plane (its lo plane, supplied noise only: + kMfXPlane)
+  __shared__ __attribute__((aligned(16))) unsigned char s_x_all[2][MfX<GEN_NOISE>::BYTES];      // planes E hi, [E lo,] O hi [, O lo]
+  __shared__ __attribute__((aligned(16))) std::conditional_t<GEN_NOISE, MfHandoff, uint4> s_hand[2];      // (generated noise: see the producers)
   __shared__ __attribute__((aligned(16))) float s_carry[2][kMfPW - 1][128];       // right halves handed from FIR wavefront w to w + 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,39 +293,137 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
   if (wave < kMfPW) {
     // =========================== producer wavefronts ==================================================================
     // Two kinds (round 3).  DESIGNERS (wavefronts 0 .. P/2 - 1): wavefront w turns the 16 x 65 magnitudes of rows
-    // 16 w .. + 15 into BOTH tap tiles - the magnitudes are fetched, scaled (exp_sigmoid) and split into fp16 pairs once
-    // (rounds 1-2: one wavefront per (row group, tap tile), so every row was fetched, scaled and split twice).
-    // NOISE MAKERS (wavefronts P/2 .. P - 1): the Philox noise tile, a half each.
+    // 16 w .. + 15 into BOTH tap tiles - 2 x 6 MFMAs against the constant cosine fragments, window, split, tap writes.
+    // NOISE MAKERS (wavefronts P/2 .. P - 1): the noise tile, a half each.
+    // Round 4, generated noise (HANDOFF): its noise costs a third of what it did (eight fp16 samples per Philox block, hi planes
+    // only) and the designers had become what a tick waits for (2.45 us against the FIR wavefronts' 1.7 - 2.2 and the noise makers'
+    // 0.9: profiles/r04z_*): the noise makers now also FETCH, SCALE (exp_sigmoid) and SPLIT the magnitudes - of the tile after the
+    // one the designers are working on - and hand them over as ready-made B-fragments in the LDS the noise's lo planes used to
+    // take; they write the controls and finish tap 32 (a dot product over the even bins) while they are at it.  A designer's tick is
+    // four fragment reads, the MFMAs and the tap writes.  The block's first tile has nobody a tile ahead of it: its designers scale
+    // for themselves, as every tile's do when the noise is supplied.
+    constexpr bool HANDOFF = GEN_NOISE;
     const float kLog10 = 2.302585092994046f;
     const bool designer = wave < kMfPW / 2;
-    const int rg = wave & (kMfPW / 2 - 1);           // a designer's row group
+    const int rg = wave & (kMfPW / 2 - 1);           // a designer's (and a scaling noise maker's) row group
     // zeros that stay: the zero group of the tap rows (what lanes outside the filter's support read) and the 16 elements
     // between the reversed noise frames (both copies), in both buffers
     if (designer)
       *reinterpret_cast<uint4*>(s_taps_all[lane >> 5] + (lane & 1) * kMfTapPlane + (16 * rg + ((lane >> 1) & 15)) * kMfTapRowBytes + 256) = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < 2 * (kMfRows + 1) * 16; i += 64 * kMfPW) {
       unsigned char* const s_xe = s_x_all[i >= (kMfRows + 1) * 16 ? 1 : 0];
-      unsigned char* const s_xo = s_xe + 2 * kMfXPlane;
+      unsigned char* const s_xo = s_xe + kXO;
       const int ii = i >= (kMfRows + 1) * 16 ? i - (kMfRows + 1) * 16 : i;
       const int e = 80 * (ii >> 4) + (ii & 15);                       // element index of a padding element
       // copy E: element e is half e & 1 of dword e >> 1; copy O: half (e + 1) & 1 of dword (e + 1) >> 1
       *reinterpret_cast<uint16_t*>(s_xe + e * 2) = 0;
-      *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
       *reinterpret_cast<uint16_t*>(s_xo + (e + 1) * 2) = 0;
-      *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
+      if (!GEN_NOISE) {
+        *reinterpret_cast<uint16_t*>(s_xe + kMfXPlane + e * 2) = 0;
+        *reinterpret_cast<uint16_t*>(s_xo + kMfXPlane + (e + 1) * 2) = 0;
+      }
     }
+    const int rrow = 16 * rg + mi;
+    // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
+    // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
+    MfU4f rq[4];
+    float r_last;
+    auto fetch_rows = [&](int tick_of_tile) {        // the rows of the block's tile number `tick_of_tile` (clamped to its last)
+      const int T = (int)blockIdx.x + min(max(tick_of_tile, 0), n_my - 1) * (int)gridDim.x;
+      DDSP_MF_TILE(T, b, z0, f_first, rel0);
+      (void)rel0; (void)z0;
+      const int rfr = f_first + rrow;
+      const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
+      r_last = src[64];
+    };
+    // the fetched rows of tile T scaled, masked and split: the four B-fragments, bin 64, tap 32's value; the controls written.
+    // (false: the tile's rows lie past the end of the clip - nobody reads their taps)
+    auto scale_rows = [&](int T, mf_f16x8& be_hi, mf_f16x8& be_lo, mf_f16x8& bo_hi, mf_f16x8& bo_lo, float& m_last, float& t32) -> bool {
+      DDSP_MF_TILE(T, b, z0, f_first, rel0);
+      (void)rel0;
+      // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
+      const int own_lo = (z0 == 0) ? 0 : f_first + 2;
+      uint32_t own_r;
+      const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, own_r) + 2;
+      const int rfr = f_first + rrow;
+      const bool rvalid = rfr >= 0 && rfr < p.F;
+      // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
+      if (f_first + 16 * rg > p.F + 1) return false;
+      float y[16];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
+      m_last = r_last;
+      if (p.scale & 1) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
+        m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
+      }
+      if (!rvalid) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) y[c] = 0.0f;
+        m_last = 0.0f;
+      }
+      if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
+        float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+          *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
+        if (mg == 0) dst[64] = m_last;
+      }
+      float ve[8], vo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
+      mf_split8(ve, be_hi, be_lo);
+      mf_split8(vo, bo_hi, bo_lo);
+      // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
+      const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
+      float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      t32 = kIr65.win[32] * part;
+      return true;
+    };
+    // the noise of tile tick + 1.  Supplied noise: the noise makers, a half each.  Generated noise (HANDOFF): all four producers, a
+    // quarter each - the noise makers scale the magnitudes as well now, and with the whole noise tile on top they were what a tick
+    // waited for (r05a timeline: designers 1.1 - 1.6 us, FIR 1.7 - 1.9, ticks of 2.6)
+    auto make_noise = [&](int tick) {
+      if (tick >= 0 && tick + 1 < n_my) {            // (tile 0's noise: the FIR wavefronts, idle in tick -1)
+        const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+        DDSP_MF_TILE(T, b, z0, f_first, rel0);
+        (void)rel0; (void)f_first;
+        unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
+        if constexpr (HANDOFF) mf_noise_tile<GEN_NOISE, 64 * kMfPW>(tid, b, z0, x, s_xe, s_xe + kXO, p);
+        else mf_noise_tile<GEN_NOISE, 32 * kMfPW>(tid - 32 * kMfPW, b, z0, x, s_xe, s_xe + kXO, p);
+      }
+    };
     if (!designer) {
       // ------------------------- noise makers -------------------------------------------------------------------------
+      if constexpr (HANDOFF) fetch_rows(1);          // (the block's second tile: its first is the designers' own)
 #pragma unroll 1
       for (int tick = -1; tick < n_my; ++tick) {
         if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
-        if (tick >= 0 && tick + 1 < n_my) {          // (tile 0's noise: the FIR wavefronts, idle in tick -1)
-          const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
-          DDSP_MF_TILE(T, b, z0, f_first, rel0);
-          (void)rel0; (void)f_first;
-          unsigned char* const s_xe = s_x_all[(tick + 1) & 1];
-          mf_noise_tile<GEN_NOISE, 32 * kMfPW>(tid - 32 * kMfPW, b, z0, x, s_xe, s_xe + 2 * kMfXPlane, p);
+        if constexpr (HANDOFF) {
+          // the magnitudes of tile tick + 2, for the designers' next tick
+          if (tick + 2 < n_my) {
+            const int T = (int)blockIdx.x + (tick + 2) * (int)gridDim.x;
+            MfHandoff& h = s_hand[(tick + 2) & 1];
+            mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+            float m_last, t32;
+            if (scale_rows(T, be_hi, be_lo, bo_hi, bo_lo, m_last, t32)) {
+              h.frag[rg][0][lane] = __builtin_bit_cast(uint4, be_hi);
+              h.frag[rg][1][lane] = __builtin_bit_cast(uint4, be_lo);
+              h.frag[rg][2][lane] = __builtin_bit_cast(uint4, bo_hi);
+              h.frag[rg][3][lane] = __builtin_bit_cast(uint4, bo_lo);
+              if (mg == 0) { h.last[rrow] = m_last; h.tap32[rrow] = t32; }
+            }
+          }
+          fetch_rows(tick + 3);                      // used a tick from now
         }
+        make_noise(tick);
         if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
         __syncthreads();
       }
@@ -326,65 +441,9 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             const uint4 v = *reinterpret_cast<const uint4*>(kIr65Frags.v[mt][par][hl][lane]);
             afr[mt][par][hl] = mf_frag(v.x, v.y, v.z, v.w);
           }
-      const int rrow = 16 * rg + mi;
-      // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
-      // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
-      MfU4f rq[4];
-      float r_last;
-      {
-        const int T = (int)blockIdx.x;                   // the block's first tile
-        DDSP_MF_TILE(T, b, z0, f_first, rel0);
-        (void)rel0;
-        const int rfr = f_first + rrow;
-        const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-        r_last = src[64];
-      }
-#pragma unroll 1
-      for (int tick = -1; tick < n_my; ++tick) {
-        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
-        if (tick + 1 < n_my) {
-          const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
-          DDSP_MF_TILE(T, b, z0, f_first, rel0);
-          (void)rel0;
-          unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
-          if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
-          // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
-          const int own_lo = (z0 == 0) ? 0 : f_first + 2;
-          uint32_t own_r;
-          const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, own_r) + 2;
-          const int rfr = f_first + rrow;
-          const bool rvalid = rfr >= 0 && rfr < p.F;
-          // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
-          if (f_first + 16 * rg <= p.F + 1) {
-          float y[16];
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
-          float m_last = r_last;
-          if (p.scale & 1) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) y[c] = exp_sigmoid_fast(y[c] + p.bias, kLog10, 2.0f, 1e-7f);
-            m_last = exp_sigmoid_fast(m_last + p.bias, kLog10, 2.0f, 1e-7f);
-          }
-          if (!rvalid) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) y[c] = 0.0f;
-            m_last = 0.0f;
-          }
-          if (ctl_out && rvalid && rfr >= own_lo && rfr < own_hi) {       // written by the owning tile only
-            float* __restrict__ dst = ctl_out + ((size_t)b * p.F + rfr) * 65;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-              *reinterpret_cast<MfU4f*>(dst + 16 * mg + 4 * c4) = MfU4f{y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
-            if (mg == 0) dst[64] = m_last;
-          }
-          float ve[8], vo[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { ve[e] = y[2 * e]; vo[e] = y[2 * e + 1]; }
-          mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
-          mf_split8(ve, be_hi, be_lo);
-          mf_split8(vo, bo_hi, bo_lo);
+      // the two tap tiles of this wavefront's rows from their scaled, split magnitudes
+      auto design_rows = [&](unsigned char* s_taps, const mf_f16x8& be_hi, const mf_f16x8& be_lo, const mf_f16x8& bo_hi,
+                             const mf_f16x8& bo_lo, float m_last, float t32) {
           unsigned char* __restrict__ hrow = s_taps + rrow * kMfTapRowBytes;
           const mf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -412,42 +471,52 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             mf_put4_down(hrow, 64 - n0, true, g0[0], g0[1], g0[2], g0[3]);  // n0 = 0: tap 64 once more, the same value
             mf_put4_down(hrow, 128 - n0, n0 != 0, g1[0], g1[1], g1[2], g1[3]);
           }
-          {
-            // tap 32: cos(pi m / 2) vanishes for odd bins; this lane's 8 even bins, then the row's four lanes together
-            const float* __restrict__ c32 = kIr65.c + 32 * kIrRowStride + 8 * mg;
-            float part = (mg == 0) ? m_last * kIr65.c[32 * kIrRowStride + 32] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) part = fmaf(c32[e], ve[e], part);
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            if (mg == 0) {
-              _Float16 h, l;
-              mf_split(kIr65.win[32] * part, h, l);
-              const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
-              *reinterpret_cast<uint16_t*>(hrow + 96 * 2) = hb;              // tap 96
-              *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 96 * 2) = lb;
-              *reinterpret_cast<uint16_t*>(hrow + 32 * 2) = hb;              // tap 32
-              *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
-            }
+          if (mg == 0) {                                                     // tap 32 (and its mirror image, tap 96)
+            _Float16 h, l;
+            mf_split(t32, h, l);
+            const uint16_t hb = __builtin_bit_cast(uint16_t, h), lb = __builtin_bit_cast(uint16_t, l);
+            *reinterpret_cast<uint16_t*>(hrow + 96 * 2) = hb;              // tap 96
+            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 96 * 2) = lb;
+            *reinterpret_cast<uint16_t*>(hrow + 32 * 2) = hb;              // tap 32
+            *reinterpret_cast<uint16_t*>(hrow + kMfTapPlane + 32 * 2) = lb;
           }
+      };
+      fetch_rows(0);                                 // the block's first tile
+      // one tick of a designer: tile tick + 1, its magnitudes scaled here (SCALE_HERE: the block's first tile, and every tile when the
+      // noise is supplied) or taken from the noise makers' handoff
+      auto designer_tick = [&](int tick, auto scale_here_tag) {
+        constexpr bool SCALE_HERE = decltype(scale_here_tag)::value;
+        if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 0);
+        if (tick + 1 < n_my) {
+          const int T = (int)blockIdx.x + (tick + 1) * (int)gridDim.x;
+          unsigned char* const s_taps = s_taps_all[(tick + 1) & 1];
+          if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 0);
+          if constexpr (SCALE_HERE) {
+            mf_f16x8 be_hi, be_lo, bo_hi, bo_lo;
+            float m_last = 0.0f, t32 = 0.0f;
+            if (scale_rows(T, be_hi, be_lo, bo_hi, bo_lo, m_last, t32)) design_rows(s_taps, be_hi, be_lo, bo_hi, bo_lo, m_last, t32);
+          } else if constexpr (HANDOFF) {
+            DDSP_MF_TILE(T, b, z0, f_first, rel0);
+            (void)rel0; (void)z0; (void)b;
+            if (f_first + 16 * rg <= p.F + 1) {        // (the noise maker's own test: scale_rows)
+              const MfHandoff& h = s_hand[(tick + 1) & 1];
+              design_rows(s_taps, __builtin_bit_cast(mf_f16x8, h.frag[rg][0][lane]), __builtin_bit_cast(mf_f16x8, h.frag[rg][1][lane]),
+                          __builtin_bit_cast(mf_f16x8, h.frag[rg][2][lane]), __builtin_bit_cast(mf_f16x8, h.frag[rg][3][lane]),
+                          h.last[rrow], h.tap32[rrow]);
+            }
           }
           if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 1, 1);
         }
-        // magnitudes of tile tick + 2, used a tick from now: fetched at the END of the tick, into the registers this
-        // tick's magnitudes have just left (past the block's last tile: the last one again)
-        {
-          const int T = (int)blockIdx.x + min(tick + 2, n_my - 1) * (int)gridDim.x;
-          DDSP_MF_TILE(T, b, z0, f_first, rel0);
-          (void)rel0;
-          const int rfr = f_first + rrow;
-          const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) rq[c4] = *reinterpret_cast<const MfU4f*>(src + 16 * mg + 4 * c4);
-          r_last = src[64];
-        }
+        // supplied noise: the magnitudes of tile tick + 2, used a tick from now - fetched at the END of the tick, into the
+        // registers this tick's magnitudes have just left (past the block's last tile: the last one again)
+        if (!HANDOFF) fetch_rows(tick + 2);
+        if constexpr (HANDOFF) make_noise(tick);
         if (wave == p.dbg_wave - 8) DDSP_MF_STAMP(tick, 0, 1);
         __syncthreads();
-      }
+      };
+      designer_tick(-1, std::true_type{});
+#pragma unroll 1
+      for (int tick = 0; tick < n_my; ++tick) designer_tick(tick, std::integral_constant<bool, !HANDOFF>{});
     }
   } else {
     // =========================== FIR wavefronts: pairs of frames on the matrix cores =================================
@@ -470,7 +539,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     mf_f32x4 kept = {0.f, 0.f, 0.f, 0.f};      // the incomplete left half of this wavefront's first pair (cw >= 1), last tile
     float* kept_ot = nullptr;                  // where it goes: the tile's base pointer, offset and bounds of the previous tick
     long kept_n = 0;
-    const int xsel = ((mi & 1) ? 0 : 2 * kMfXPlane) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
+    const int xsel = ((mi & 1) ? 0 : kXO) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
     const int second = mg >> 1;
     // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2 (u's parity is the lane's: 79 - i).  Step c
     // reads 32 c bytes below step 0, pair `it` 320 `it` bytes above pair 0: ONE per-lane address per plane and pair of
@@ -501,7 +570,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         const int T = (int)blockIdx.x;
         DDSP_MF_TILE(T, b, z0, f_first, rel0);
         (void)f_first; (void)rel0;
-        mf_noise_tile<GEN_NOISE, 64 * kMfPW>(tid - 64 * kMfPW, b, z0, x, s_x_all[0], s_x_all[0] + 2 * kMfXPlane, p);
+        mf_noise_tile<GEN_NOISE, 64 * kMfPW>(tid - 64 * kMfPW, b, z0, x, s_x_all[0], s_x_all[0] + kXO, p);
       }
       bool active = false;
       if (tick >= 0) {

@@ -194,7 +194,7 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
   assert line['steps'] == 7 and line['warmup'] == 2 and line['n_gpus'] == 1
   assert line['roofline']['kernel'] == 'noise_fused65_kernel'         # the larger isolated time above
   assert 'aux_error' not in line, line.get('aux_error')
-  assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 10
+  assert line['roofline']['measured_copy_GBs'] > 0 and line['f0_200_regime']['steps'] == 7
   assert len(line['f0_regimes']) == 5 and all(r_['frac'] > 0 for r_ in line['f0_regimes'].values())
   assert 0 < line['min_regime_frac'] <= line['roofline']['whole_step']['frac'] and line['regime_worst_over_best_time'] >= 1.0
   for centre in (220.0, 333.0, 500.0):
