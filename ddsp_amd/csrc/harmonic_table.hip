@@ -175,6 +175,7 @@ struct TableArgs {
   float nyquist, nyq_lo, nyq_hi;
   WtSizeThresholds size_thr;      // the table size of a segment from its smallest f0
   int amp_linear;
+  int ragged;          // hop % 64 != 0: a frame's last tile is cut short (lanes past the frame's end store nothing)
   int rows16;          // rows of hd (and of the controls out) are 16 bytes apart and aligned: K % 4 == 0, aligned bases
   double inv_sr, inv_2hop, hop_d, half_hm1;
   long long* dbg;      // DDSP_EXP_TABLE_TIMELINE=1: shader-clock stamps of block 0, [wavefront][tick + 2][stamp]; or null
@@ -1194,7 +1195,8 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           const float inv_hop = 1.0f / (float)hop;
           const bool chunk_cross = __builtin_amdgcn_readfirstlane(t.cross) != 0;      // one look per tick, not per tile
 
-          const int n_tiles = ONE_TILE ? nfr : nfr * (hop >> 6);
+          const int n_tiles = ONE_TILE ? nfr : nfr * ((hop + 63) >> 6);      // (hop % 64 != 0: the frame's last tile is cut short)
+          const bool ragged = !ONE_TILE && p.ragged != 0;
           const size_t chunk0 = (size_t)row0 * (size_t)hop;
           char* out_chunk = reinterpret_cast<char*>(audio + chunk0);          // (add_in may be this very buffer: no __restrict__)
           const char* add_chunk = ADD ? reinterpret_cast<const char*>(add_in + chunk0) : nullptr;
@@ -1224,10 +1226,19 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
             // (a tile's samples are elements 64 tile + lane of the chunk, whatever the hop: a wave-uniform base and a
             // 32-bit offset)
             const unsigned o32 = 4u * (unsigned)(tile * 64 + lane);          // bytes
+            // (frames that are not whole tiles - hop % 64 != 0, round 4: the reference's own test shapes, 640 frames of 100 samples -:
+            // a tile's samples start at q hop + 64 rem of the chunk, and the lanes past the frame's end neither load nor store)
             float addv[kWtNT];
-            if (ADD)
+            if (ADD) {
+              if (!ragged) {
 #pragma unroll
-              for (int u = 0; u < NT; ++u) addv[u] = *reinterpret_cast<const float*>(add_chunk + (o32 + 2048u * (unsigned)u));
+                for (int u = 0; u < NT; ++u) addv[u] = *reinterpret_cast<const float*>(add_chunk + (o32 + 2048u * (unsigned)u));
+              } else {
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                  addv[u] = r[u] < hop ? *reinterpret_cast<const float*>(add_chunk + 4u * (unsigned)(q[u] * hop + r[u])) : 0.0f;
+              }
+            }
             float theta[kWtNT];
             f32x2 zz[kWtNT];
             unsigned sgn[kWtNT];
@@ -1304,8 +1315,14 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
               }
             }
 #endif
+            if (!ragged) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u) *reinterpret_cast<float*>(out_chunk + (o32 + 2048u * (unsigned)u)) = out[u];          // N == F * hop
+              for (int u = 0; u < NT; ++u) *reinterpret_cast<float*>(out_chunk + (o32 + 2048u * (unsigned)u)) = out[u];          // N == F * hop
+            } else {
+#pragma unroll
+              for (int u = 0; u < NT; ++u)
+                if (r[u] < hop) *reinterpret_cast<float*>(out_chunk + 4u * (unsigned)(q[u] * hop + r[u])) = out[u];
+            }
           };
           for (int base = 0; base < n_tiles; base += kWtFrames) {
             const int left = min(n_tiles - base, kWtFrames);
@@ -1337,7 +1354,8 @@ bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, con
   if (!(flags & DDSP_HARM_SCALE_EXP_SIGMOID) || !(flags & DDSP_HARM_NORMALIZE_NYQUIST)) return false;
   if (inputs_are_controls || (ctl_amp == nullptr) != (ctl_hd == nullptr) || (flags >> 24) != 0) return false;
   (void)hd;
-  return (N % F) == 0 && ((N / F) % 64) == 0 && K >= 1 && K <= 200 && F < (1 << 24);
+  // (any frame size since round 4: frames that are not whole tiles of 64 samples run with their last tile cut short)
+  return (N % F) == 0 && K >= 1 && K <= 200 && F < (1 << 24) && (long long)(N / F) * 32 < (1ll << 29);
 }
 
 // The fragment sets of a window on the current device: made on the host once per process, copied once per device (under a
@@ -1378,7 +1396,8 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   p.B = B; p.F = F; p.K = K; p.N = N; p.hop = N / F;
   p.total_frames = B * F;
   p.f_div = make_fastdiv((uint32_t)F);
-  p.tpf_div = make_fastdiv((uint32_t)(p.hop >> 6));
+  p.tpf_div = make_fastdiv((uint32_t)((p.hop + 63) >> 6));
+  p.ragged = (p.hop & 63) != 0 ? 1 : 0;
   p.seg_div = make_fastdiv((uint32_t)kWtSegment);
   if (wt_upload_fragments(K <= 100 ? 6 : K <= 128 ? 8 : 10) != 0) return DDSP_ERR_LAUNCH;
   p.nyquist = (float)(sample_rate / 2.0);

@@ -1474,3 +1474,28 @@ def test_harmonic_table_sizes_follow_f0(ddsp, k, hop):
     np.testing.assert_array_equal(npy(synth(amps[r:r + 1], hd[r:r + 1], f0[r:r + 1])), full[r:r + 1], err_msg='row %d alone' % r)
   np.testing.assert_array_equal(npy(synth(amps[1:4], hd[1:4], f0[1:4])), full[1:4])
   np.testing.assert_array_equal(npy(synth(amps[3:], hd[3:], f0[3:])), full[3:])
+
+
+@pytest.mark.parametrize('hop,k', [(100, 100), (96, 60), (40, 30), (200, 128), (150, 160)])
+def test_harmonic_frame_sizes_that_are_not_multiples_of_64(ddsp, hop, k):
+  """Round 4: frames that are not whole tiles of 64 samples - 640 frames of 100 samples is the reference's
+  own test shape (ddsp/synths_test.py, processors_test.py:36-41) - run on the wavetable kernel with the frame's last tile cut
+  short (7 x the canonical time on the one-thread-per-sample kernels until round 3).  Against exact arithmetic; rows alone and in
+  a batch bit-equal; Harmonic with processors.Add fused in equal to the two calls."""
+  f, sr = 77, 16000
+  n = f * hop
+  rng = np.random.default_rng(900 + hop)
+  b = 3
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = np.abs(40.0 + 30.0 * rng.standard_normal((b, f, 1))).astype(np.float32)
+  for method in ('window', 'linear'):
+    synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)
+    full = npy(synth(amps, hd, f0))
+    assert full.shape == (b, n) and np.isfinite(full).all()
+    exact, knife = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=True)
+    scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+    parity_check(np.where(knife, exact, full), exact, HARM_TABLE_ATOL * scale, 'hop %d, K = %d, %s' % (hop, k, method))
+    np.testing.assert_array_equal(npy(synth(amps[1:2], hd[1:2], f0[1:2])), full[1:2])
+    z = rng.standard_normal((b, n)).astype(np.float32)
+    np.testing.assert_array_equal(npy(synth.call_add(amps, hd, f0, z)), full + z)

@@ -49,8 +49,8 @@ def noise_case(name, m, f, n, window_size=0):
 harmonic_case('Harmonic, 100 harmonics, 1000 frames of 64 (the fast path, for comparison)', 100, 1000, 64000)
 harmonic_case('Harmonic, 99 harmonics (processors_test.py): the wavetable kernel since the end of round 3', 99, 1000, 64000)
 harmonic_case('Harmonic, 100 harmonics, 250 frames of 256 samples', 100, 250, 64000)
-harmonic_case('Harmonic, 100 harmonics, 640 frames of 100 samples (hop not a multiple of 64: controls + synthesis kernels)', 100, 640, 64000)
-harmonic_case('Harmonic, 160 harmonics at 32 kHz (K > 128: direct sum)', 160, 1000, 64000, sr=32000, f0c=70.0)
+harmonic_case('Harmonic, 100 harmonics, 640 frames of 100 samples (hop not a multiple of 64: the wavetable kernel with masked tiles since round 4)', 100, 640, 64000)
+harmonic_case('Harmonic, 160 harmonics at 32 kHz (K > 128: the ten-tap wavetable instances)', 160, 1000, 64000, sr=32000, f0c=70.0)
 noise_case('FilteredNoise, 65 magnitudes, 1000 frames of 64 (the fast path, for comparison)', 65, 1000, 64000)
 noise_case('FilteredNoise, 100 magnitudes (synths_test.py): 198-tap IR, general kernels', 100, 1000, 64000)
 noise_case('FilteredNoise, 256 magnitudes: 510-tap IR, general kernels', 256, 1000, 64000)
