@@ -13,43 +13,12 @@
 #include "common.h"
 #include "noise_ir65.h"
 #include "filtered_noise_mfma.h"
+#include "filtered_noise_general.h"
+#include "noise_ir_geom.h"
 #include "profile.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
-
-// ------------------------------------------------------------------------------------
-// Geometry of core.apply_window_to_impulse_response (core.py:1477-1531).
-// ------------------------------------------------------------------------------------
-struct IrGeom {
-  int M, L0, ws, padding, half, L;
-};
-__host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
-  IrGeom g;
-  g.M = M;
-  g.L0 = 2 * (M - 1);                                     // irfft length (core.py:1559)
-  g.ws = (window_size <= 0 || window_size > g.L0) ? g.L0 : window_size;   // :1501-1503
-  g.padding = g.L0 - g.ws;
-  g.half = (g.ws + 1) / 2;                                // :1509
-  g.L = g.padding > 0 ? 2 * g.half - 1 : g.L0;            // :1520-1527
-  return g;
-}
-// causal tap index kappa -> zero-phase sample index n and Hann window index (or -1: zero)
-__device__ __forceinline__ void ir_tap_map(const IrGeom& g, int kappa, int* n, int* widx) {
-  if (g.padding > 0) {
-    // concat(ir[L0-half+2:], ir[:half+1])                         (core.py:1521-1526)
-    const int nn = (kappa < g.half - 2) ? (g.L0 - g.half + 2 + kappa) : (kappa - (g.half - 2));
-    // window_zp = concat(window[half:], zeros(padding), window[:half])   (:1510-1512)
-    int wi = -1;
-    if (nn < g.ws - g.half) wi = g.half + nn;
-    else if (nn >= g.L0 - g.half) wi = nn - (g.L0 - g.half);
-    *n = nn; *widx = wi;
-  } else {
-    // fftshift(window) * ir, then fftshift                          (:1514, 1529)
-    *n = (kappa + g.L0 / 2) % g.L0;
-    *widx = kappa;
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // kernel: controls.  ctl = exp_sigmoid(mag + bias) (synths.py:176-177) or copy.
@@ -772,6 +741,11 @@ extern "C" int ddsp_filtered_noise_controls_f32(const float* magnitudes, float* 
   return check_launch();
 }
 
+static bool general_plain_env() {
+  static const bool v = [] { const char* e = getenv("DDSP_EXP_NOISE_GENERAL"); return e && e[0] == 'p'; }();
+  return v;
+}
+
 static int launch_ir(const float* mag, float* ctl_out, float* ir, int B, int F, int M,
                      int window_size, float bias, int scale, hipStream_t st) {
   const IrGeom g = ir_geom(M, window_size);
@@ -782,9 +756,13 @@ static int launch_ir(const float* mag, float* ctl_out, float* ir, int B, int F, 
                        mag, ctl_out, ir, rows65, bias, scale);
     return check_launch();
   }
+  const long rows = (long)B * F;
+  // any other filter: one matrix product with a constant matrix (filtered_noise_general.hip); DDSP_EXP_NOISE_GENERAL=plain
+  // keeps rounds 1-3's plain kernels (the A/B of tools/bench_generic.py)
+  if (!general_plain_env() && noise_ir_gemm_ok(M, window_size))
+    return launch_noise_ir_gemm(mag, ctl_out, ir, rows, M, window_size, bias, scale, st);
   const size_t lds = (size_t)(g.L0 + M) * sizeof(float);
   if (lds > kMaxDynLds) return DDSP_ERR_UNSUPPORTED;
-  const long rows = (long)B * F;
   const unsigned grid = (unsigned)(rows < 256 * 16 ? rows : 256 * 16);
   ProfileScope prof(kNoiseIr, st);
   hipLaunchKernelGGL(noise_ir_kernel, dim3(grid), dim3(256), lds, st, mag, ctl_out, ir, rows, M,
@@ -823,6 +801,9 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
     else hipLaunchKernelGGL((tv_fir128_kernel<true>), grid, dim3(64 * kFirWaves), 0, st, x, ir, out, q);
     return check_launch();
   }
+  // any other tap count and frame size: Toeplitz products on the matrix cores (filtered_noise_general.hip)
+  if (!general_plain_env() && tv_fir_mfma_ok(B, Bir, F, L, N))
+    return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, st);
   // tile: as many outputs as keep x + taps under the LDS budget
   int tile = 1024;
   size_t lds = 0;
@@ -914,6 +895,12 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
       return check_launch();
     }
   }
+  // any other filter of up to 128 bands and 256 taps, any frame size: one launch, the taps designed tile by tile in LDS
+  // (filtered_noise_general.hip); DDSP_EXP_NOISE_GENERAL=two keeps the design and the FIR apart (the larger filters' path)
+  static const bool two_env = [] { const char* e = getenv("DDSP_EXP_NOISE_GENERAL"); return e && e[0] == 't'; }();
+  if (!general_plain_env() && !two_env && filtered_noise_general_fused_ok(B, F, M, N, window_size))
+    return launch_filtered_noise_general_fused(magnitudes, noise, audio, ctl_magnitudes, B, F, M, N, window_size, initial_bias,
+                                               scale, seed, batch_offset, st);
   float* ir = (float*)workspace;
   int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
   if (rc != DDSP_OK) return rc;

@@ -1,0 +1,28 @@
+// Internal interface of the matrix-core kernels for FilteredNoise / fft_convolve shapes the canonical kernel
+// (filtered_noise_mfma.hip: 65 bands, frames of 64 c samples) does not take - any number of bands up to 288, any window,
+// any frame size (filtered_noise_general.hip).  Used by the dispatch in filtered_noise.hip.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddsp {
+
+// IR design (core.frequency_impulse_response + apply_window_to_impulse_response, ddsp/core.py:1477-1565) as ONE matrix
+// product with a constant matrix: taps[row][kappa] = sum_m scaled_mag[row][m] C[m][kappa].
+bool noise_ir_gemm_ok(int M, int window_size);
+int launch_noise_ir_gemm(const float* mag, float* ctl_out, float* ir, long rows, int M, int window_size, float bias,
+                         int scale, hipStream_t st);
+
+// the time-varying FIR (core.fft_convolve, ddsp/core.py:1382-1473, as a time-domain sum) for any tap count up to
+// kGfMaxTaps and any frame size
+bool tv_fir_mfma_ok(int B, int Bir, int F, int L, int N);
+int launch_tv_fir_mfma(const float* x, const float* ir, float* out, int B, int Bir, int F, int L, int N, int start,
+                       uint64_t seed, uint64_t batch_offset, hipStream_t st);
+
+// FilteredNoise.__call__ in ONE launch for up to 128 bands and 256 taps: tv_fir_mfma_kernel designing its tiles' taps itself
+bool filtered_noise_general_fused_ok(int B, int F, int M, int N, int window_size);
+int launch_filtered_noise_general_fused(const float* mag, const float* x, float* out, float* ctl_out, int B, int F, int M, int N,
+                                        int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset,
+                                        hipStream_t st);
+
+}  // namespace ddsp

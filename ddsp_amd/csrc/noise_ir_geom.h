@@ -1,0 +1,41 @@
+// Geometry of the impulse response core.apply_window_to_impulse_response makes (ddsp/core.py:1477-1531): shared by the
+// general kernels (filtered_noise.hip) and the constant matrix of filtered_noise_general.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ddsp {
+
+// ------------------------------------------------------------------------------------
+// Geometry of core.apply_window_to_impulse_response (core.py:1477-1531).
+// ------------------------------------------------------------------------------------
+struct IrGeom {
+  int M, L0, ws, padding, half, L;
+};
+__host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
+  IrGeom g;
+  g.M = M;
+  g.L0 = 2 * (M - 1);                                     // irfft length (core.py:1559)
+  g.ws = (window_size <= 0 || window_size > g.L0) ? g.L0 : window_size;   // :1501-1503
+  g.padding = g.L0 - g.ws;
+  g.half = (g.ws + 1) / 2;                                // :1509
+  g.L = g.padding > 0 ? 2 * g.half - 1 : g.L0;            // :1520-1527
+  return g;
+}
+// causal tap index kappa -> zero-phase sample index n and Hann window index (or -1: zero)
+__host__ __device__ inline void ir_tap_map(const IrGeom& g, int kappa, int* n, int* widx) {
+  if (g.padding > 0) {
+    // concat(ir[L0-half+2:], ir[:half+1])                         (core.py:1521-1526)
+    const int nn = (kappa < g.half - 2) ? (g.L0 - g.half + 2 + kappa) : (kappa - (g.half - 2));
+    // window_zp = concat(window[half:], zeros(padding), window[:half])   (:1510-1512)
+    int wi = -1;
+    if (nn < g.ws - g.half) wi = g.half + nn;
+    else if (nn >= g.L0 - g.half) wi = nn - (g.L0 - g.half);
+    *n = nn; *widx = wi;
+  } else {
+    // fftshift(window) * ir, then fftshift                          (:1514, 1529)
+    *n = (kappa + g.L0 / 2) % g.L0;
+    *widx = kappa;
+  }
+}
+
+}  // namespace ddsp

@@ -1343,6 +1343,58 @@ def test_filtered_noise_random_shapes_vs_oracle(ddsp, seed):
     np.testing.assert_allclose(got, ref, rtol=0, atol=noise_tol(ref), err_msg=str(dict(fs=fs, frames=f, n=n, batch=b)))
 
 
+@pytest.mark.parametrize('m,ws,n_frames,n,batch', [
+    (100, 0, 250, 16000, 3),       # synths_test.py:43-50's 100 magnitudes: a 198-tap filter
+    (100, 257, 250, 16000, 2),     # ... under the constructor's default window: 257 is beyond 198 taps, the full window
+    (256, 0, 120, 7680, 2),        # 510 taps
+    (256, 257, 120, 7680, 2),      # ... cropped to 257 (core.py:1520-1527)
+    (65, 0, 160, 16000, 3),        # frames of 100 samples: pieces of 64 and 36
+    (40, 0, 90, 17280 - 50, 2),    # frames of 192 with a ragged end
+    (12, 0, 300, 6000, 2),         # frames of 20 samples
+    (129, 65, 64, 32768, 2),       # frames of 512
+])
+def test_filtered_noise_general_shapes_on_the_matrix_cores(ddsp, m, ws, n_frames, n, batch):
+  """filtered_noise_general.hip (noise_ir_gemm_kernel, tv_fir_mfma_kernel): any band count, window and frame size against
+  the fp64 oracle with supplied noise; generated noise against the same call with the generator's samples handed in;
+  bit equality run to run and of a row alone with the row inside the batch (the LDS adds never see three terms)."""
+  rng = np.random.default_rng(m * 7 + n_frames)
+  mags = (rng.standard_normal((batch, n_frames, m)) + 2.0).astype(np.float32)
+  noise = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=ws, seed=11)
+  got = npy(synth(mags, noise=noise))
+  ref = O.filtered_noise(mags, noise, ws, O.exp_sigmoid, dtype=np.float64)
+  assert got.shape == ref.shape
+  np.testing.assert_allclose(got, ref, rtol=0, atol=noise_tol(ref))
+  np.testing.assert_array_equal(npy(synth(mags, noise=noise)), got)
+  np.testing.assert_array_equal(npy(synth(mags[1:2], noise=noise[1:2])), got[1:2])
+  # the controls beside the audio (the IR kernel writes them on the way in)
+  full = synth(mags, noise=noise, return_outputs_dict=True)
+  np.testing.assert_array_equal(npy(full['signal']), got)
+  np.testing.assert_allclose(npy(full['controls']['magnitudes']), O.exp_sigmoid(mags.astype(np.float64) - 5.0, dtype=np.float64),
+                             rtol=2e-5, atol=1e-9)
+  # generated noise: the stream is this library's contract (oracle.device_uniform_noise restates it)
+  gen = ddsp.synths.FilteredNoise(n_samples=n, window_size=ws, seed=11)
+  z = O.device_uniform_noise(batch, n, seed=11)
+  got_gen = npy(gen(mags))
+  ref_gen = O.filtered_noise(mags, z, ws, O.exp_sigmoid, dtype=np.float64)
+  np.testing.assert_allclose(got_gen, ref_gen, rtol=0, atol=noise_tol(ref_gen))
+
+
+def test_fft_convolve_general_shapes_on_the_matrix_cores(ddsp):
+  """core.fft_convolve (ddsp/core.py:1382-1473) through tv_fir_mfma_kernel: odd tap counts, one filter for the whole batch,
+  explicit delay compensation, a single frame (a time-invariant filter), frames shorter than 16 samples."""
+  rng = np.random.default_rng(77)
+  for b, bir, f, l, n, dc in [(3, 3, 40, 97, 5000, -1), (4, 1, 25, 200, 6400, -1), (2, 2, 1, 63, 3000, 0),
+                              (2, 2, 500, 33, 4000, 5), (1, 1, 7, 3, 700, -1), (2, 2, 10, 400, 2560, -1)]:
+    audio = rng.standard_normal((b, n)).astype(np.float32)
+    ir = (rng.standard_normal((bir, f, l)) / np.sqrt(l)).astype(np.float32)
+    got = npy(ddsp.core.fft_convolve(audio, ir, delay_compensation=dc))
+    ref = O.fft_convolve(audio, ir, delay_compensation=dc, dtype=np.float64)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max(), err_msg=str((b, bir, f, l, n, dc)))
+    np.testing.assert_array_equal(npy(ddsp.core.fft_convolve(audio, ir, delay_compensation=dc)), got)
+
+
 # ---- processors.Add fused into the Harmonic kernel (ddsp/processors.py:162-176; gin/models/ae.gin:49-56) --------------
 def test_processor_group_fused_add_is_bit_identical(ddsp):
   """ProcessorGroup[Harmonic, FilteredNoise, Add] asked for the signal only runs Harmonic with the Add fused in

@@ -52,9 +52,9 @@ harmonic_case('Harmonic, 100 harmonics, 250 frames of 256 samples', 100, 250, 64
 harmonic_case('Harmonic, 100 harmonics, 640 frames of 100 samples (hop not a multiple of 64: the wavetable kernel with masked tiles since round 4)', 100, 640, 64000)
 harmonic_case('Harmonic, 160 harmonics at 32 kHz (K > 128: the ten-tap wavetable instances)', 160, 1000, 64000, sr=32000, f0c=70.0)
 noise_case('FilteredNoise, 65 magnitudes, 1000 frames of 64 (the fast path, for comparison)', 65, 1000, 64000)
-noise_case('FilteredNoise, 100 magnitudes (synths_test.py): 198-tap IR, general kernels', 100, 1000, 64000)
-noise_case('FilteredNoise, 256 magnitudes: 510-tap IR, general kernels', 256, 1000, 64000)
+noise_case('FilteredNoise, 100 magnitudes (synths_test.py): 198-tap IR - one launch, taps designed per tile in LDS (filtered_noise_general.hip)', 100, 1000, 64000)
+noise_case('FilteredNoise, 256 magnitudes: 510-tap IR - IR design as a matrix product + Toeplitz FIR on the matrix cores (two launches)', 256, 1000, 64000)
 noise_case('FilteredNoise, 65 magnitudes, window_size 257 (the constructor default: cropped window)', 65, 1000, 64000, window_size=257)
-noise_case('FilteredNoise, 65 magnitudes, 640 frames of 100 samples', 65, 640, 64000)
+noise_case('FilteredNoise, 65 magnitudes, 640 frames of 100 samples (pieces of 64 + 36: filtered_noise_general.hip)', 65, 640, 64000)
 for c in cases:
   print(json.dumps(c))
