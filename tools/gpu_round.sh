@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session for the round's evidence: parity tests, smoke, bench, rocprof kernel traces, PMC traffic, SQ counters.
 # Usage (from the build container): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -45,12 +45,18 @@ timeout 600 python tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/bench_o
 echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 > /dev/null 2>&1; cp $OUT/pmc_traffic_b32/pmc_traffic.json $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 > /dev/null 2>&1; cp $OUT/pmc_traffic_b128/pmc_traffic.json $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
+echo "== PMC: HBM traffic per launch, configs[4] per GPU (48 kHz, 200 harmonics, 2500 frames of 192, batch 32)"
+bash tools/pmc_traffic.sh $TAG/pmc_traffic_config5 32 2500 200 480000 48000 > /dev/null 2>&1; cp $OUT/pmc_traffic_config5/pmc_traffic.json $OUT/pmc_traffic_config5.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_config5.json')); print(d.get('shape'), d['kernels'])"
 echo "== PMC: SQ counters, batch 128"
-bash tools/pmc.sh $TAG/pmc_sq_b128 128 > $OUT/pmc_sq_counters_b128.log 2>&1; cp $OUT/pmc_sq_b128/summary.txt $OUT/pmc_sq_counters_b128.txt 2>/dev/null; grep -A30 "== harm_table\|== noise_mfma" $OUT/pmc_sq_counters_b128.txt | grep "==\|SQ_WAIT_ANY\|SQ_WAVE_CYCLES\|SQ_LDS_BANK\|SQ_LDS_IDX\|SQ_INSTS_VALU \|SQ_ACTIVE_INST_ANY\|SQ_WAIT_INST_ANY" | head -20
-rm -rf $OUT/pmc_traffic_b32 $OUT/pmc_traffic_b128 $OUT/pmc_sq_b128
+bash tools/pmc.sh $TAG/pmc_sq_b128 128 > $OUT/pmc_sq_counters_b128.log 2>&1; cp $OUT/pmc_sq_b128/summary.txt $OUT/pmc_sq_counters_b128.txt 2>/dev/null; python tools/pmc_summary.py $OUT/pmc_sq_b128 --json $OUT/pmc_sq_b128.json 128 1000 100 64000 16000 > /dev/null 2>&1; grep -A30 "== harm_table\|== noise_mfma" $OUT/pmc_sq_counters_b128.txt | grep "==\|SQ_WAIT_ANY\|SQ_WAVE_CYCLES\|SQ_LDS_BANK\|SQ_LDS_IDX\|SQ_INSTS_VALU \|SQ_ACTIVE_INST_ANY\|SQ_WAIT_INST_ANY" | head -20
+rm -rf $OUT/pmc_traffic_b32 $OUT/pmc_traffic_b128 $OUT/pmc_traffic_config5 $OUT/pmc_sq_b128
 echo "== next-row benches (Reverb, SpectralLoss, backward, streaming)"
 timeout 300 python tools/bench_reverb.py 32 2>&1 | tail -1 | tee $OUT/bench_reverb_b32.json | cut -c1-200
 timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json | cut -c1-200
 timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json | cut -c1-300
 timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json | cut -c1-300
+echo "== shapes behind the specialised paths (tools/bench_generic.py), batch 32 and 128"
+timeout 300 python tools/bench_generic.py 32 2>/dev/null | grep "^{" > $OUT/generic_shapes_b32.jsonl; cut -c1-200 $OUT/generic_shapes_b32.jsonl
+echo "== determinism stress: 1000 launches per case, bits compared on the device (tools/stress_determinism.py)"
+timeout 900 python tools/stress_determinism.py --iters 1000 --label $TAG --out $OUT/determinism_stress.jsonl 2>&1 | grep "SUMMARY\|MISMATCH" | cut -c1-300
 echo "== done"
