@@ -162,6 +162,10 @@ template <> struct WtPoly<10> {      // 129 .. 200 harmonics on the same 512 poi
 // wavefronts in turn, oldest first, and a tick ends when the busiest SIMD is done (r03n: the row maker next to
 // tabulator 3, whose SIMD also builds the phase tables, arrives at the barrier 900 clocks after the others).
 constexpr int kWtWalker = DDSP_WT_WALKER;        // the tabulator that walks the chunk descriptors
+#ifndef DDSP_WT_SIZER
+#define DDSP_WT_SIZER 0
+#endif
+constexpr int kWtSizer = DDSP_WT_SIZER;          // the tabulator that chooses the table sizes (wt_table_size)
 constexpr unsigned kWtSlots = DDSP_WT_SLOTS;     // nibble sw: the tile slot of interpolator sw (wavefront 4 + sw, SIMD sw % 4):
                                                  // the slots that come up short (7, 6, then 5, 4) are SIMD 3's and SIMD 0's
 struct WtDesc { int b, j0, nfr, fresh; };        // a chunk: frames j0 .. j0 + nfr - 1 of row b; nfr == 0: none
@@ -671,9 +675,9 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
         fetch_f0(dM);
       }
       WtDesc dN{0, 0, 0, 0};                        // chunk tick + 3 (tabulator 1 only: the others take it at the end of the tick)
-      if (rw == 1) {
-        if (dA.nfr > 0) fetch_amp(dA);
-        if constexpr (!WIDE) {
+      if (rw == 1 && dA.nfr > 0) fetch_amp(dA);
+      if constexpr (!WIDE) {
+        if (rw == kWtSizer) {
           dN = wt_read_desc(ring, (tick + 3) & 7);
           if (dN.nfr > 0) fetch_segment(dN, pseg);
           if (tick == -2 && dA.nfr > 0) fetch_segment(dA, pf_first);
@@ -908,15 +912,20 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
           before += __builtin_bit_cast(double, (long long)(((unsigned long long)hi31 << 32) | lo31));
         }
       }
-      if (rw == 1 && (dA.nfr > 0 || dN.nfr > 0)) {
-        loads_landed(pamp, pseg, pf_first);
+      if (rw == 1 && dA.nfr > 0) {
+        loads_landed(pamp);
         int lane_ = lane;
         DDSP_KEEP_IN_VGPR(lane_);
-        if (dA.nfr > 0) {
-          const float a = exp_sigmoid_fast(pamp, kLog10, 2.0f, 1e-7f);
-          if (lane_ <= kWtRows) amp_tab[pa][lane_] = a;
-          if (ctl_amp != nullptr && lane_ < dA.nfr) ctl_amp[(size_t)dA.b * F + dA.j0 + lane_] = a;
-        }
+        const float a = exp_sigmoid_fast(pamp, kLog10, 2.0f, 1e-7f);
+        if (lane_ <= kWtRows) amp_tab[pa][lane_] = a;
+        if (ctl_amp != nullptr && lane_ < dA.nfr) ctl_amp[(size_t)dA.b * F + dA.j0 + lane_] = a;
+      }
+      // the table sizes: the tabulator with no other side job (round 4's first version had tabulator 1 do it behind the
+      // amplitudes: its tick was the longest of the four - r04u -, and these dozen instructions cost the 70 Hz case half a microsecond)
+      if (rw == kWtSizer && (dN.nfr > 0 || (tick == -2 && dA.nfr > 0))) {
+        loads_landed(pseg, pf_first);
+        int lane_ = lane;
+        DDSP_KEEP_IN_VGPR(lane_);
         if constexpr (!WIDE) {
 #if !defined(DDSP_EXP_NO_TSEL_COMPUTE)
           // (lanes 0 .. 62: the segment's frames and the one behind; a NaN is no minimum - fminf - and <= 0 keeps 512 points)
