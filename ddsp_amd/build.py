@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'filtered_noise.hip', 'filtered_noise_mfma.hip', 'filtered_noise_general.hip', 'reverb.hip', 'spectral_loss.hip', 'spectral_terms.hip', 'general.hip', 'profile.hip']
+SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'harmonic_bwd_table.hip', 'filtered_noise.hip', 'filtered_noise_mfma.hip', 'filtered_noise_general.hip', 'reverb.hip', 'spectral_loss.hip', 'spectral_terms.hip', 'general.hip', 'profile.hip']
 OUT = os.path.join(HERE, 'lib', 'libddsp_amd.so')
 
 

@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "profile.h"
+#include "harmonic_bwd_table.h"
 #include "harmonic_table.h"
 #include "../../include/ddsp_amd.h"
 
@@ -1224,7 +1225,13 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   p.amp_linear = (flags & DDSP_HARM_AMP_LINEAR) ? 1 : 0;
   p.flags = flags; p.inputs_are_controls = inputs_are_controls;
   const double* theta0 = (const double*)workspace;
-  {
+  if (harm_bwd_table_ok(F, K, N)) {
+    // up to 128 harmonics: spread the weighted gradient onto the table grid, one product with the transposed sine matrix
+    // (harmonic_bwd_table.hip) instead of a sine per sample and harmonic
+    ProfileScope prof(kHarmBwdPq, st);
+    rc = launch_harm_bwd_table(f0_hz, theta0, grad_audio, pq, q_offset, B, F, K, N, sample_rate, p.amp_linear, st);
+    if (rc != DDSP_OK) return rc;
+  } else {
     ProfileScope prof(kHarmBwdPq, st);
     const int fb = max(1, min(8, kBwdMaxHop / p.hop));           // frames per block
     const dim3 grid((unsigned)((F + fb - 1) / fb), (unsigned)B);

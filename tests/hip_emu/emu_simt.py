@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'ddsp_amd', 'csrc')
 BUILD = os.path.join(HERE, '_build', 'simt')
 OUT = os.path.join(BUILD, 'libddsp_simt_emu.so')
-SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'filtered_noise.hip', 'filtered_noise_mfma.hip', 'filtered_noise_general.hip', 'reverb.hip', 'spectral_loss.hip', 'spectral_terms.hip', 'general.hip',
+SOURCES = ['harmonic.hip', 'harmonic_table.hip', 'harmonic_bwd_table.hip', 'filtered_noise.hip', 'filtered_noise_mfma.hip', 'filtered_noise_general.hip', 'reverb.hip', 'spectral_loss.hip', 'spectral_terms.hip', 'general.hip',
            'profile.hip']
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 

@@ -902,6 +902,40 @@ def test_harmonic_backward_vs_analytic_oracle(ddsp, batch, n_frames, k, hop, sr,
   np.testing.assert_array_equal(npy(audio), npy(synth(amps, hd, f0)))
 
 
+@pytest.mark.parametrize('batch,n_frames,k,hop,sr,f0s', [
+    (3, 40, 100, 64, 16000, (69.0, 71.0)),          # the canonical regime: all harmonics live, under one revolution per frame
+    (2, 40, 100, 64, 16000, (180.0, 420.0)),        # harmonics crossing Nyquist in most frames, up to two revolutions per tile
+    (2, 30, 128, 64, 16000, (900.0, 2500.0)),       # ten and more revolutions per tile, few live harmonics (eight taps)
+    (2, 24, 60, 192, 48000, (100.0, 130.0)),        # three tiles per frame
+    (2, 30, 100, 100, 16000, (20.0, 40.0)),         # frames of 100 samples; f0 below sr / 512 in most frames: the plain sum inside the kernel
+    (1, 20, 37, 50, 16000, (0.0, 300.0)),           # f0 = 0 and a jump across many harmonics: more than eight crossing harmonics
+])
+def test_harmonic_backward_on_the_wavetable_adjoint(ddsp, batch, n_frames, k, hop, sr, f0s):
+  """harm_bwd_table_kernel (the adjoint of the wavetable synthesis: spreading + one matrix product) against the fp64 analytic
+  gradient, in every regime that takes a different way through it; the same call twice gives the same bits."""
+  rng = np.random.default_rng(k * 31 + hop)
+  n = n_frames * hop
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
+  f0 = rng.uniform(f0s[0], f0s[1], (batch, n_frames, 1)).astype(np.float32)
+  if f0s[0] == 0.0:
+    f0[:, ::5] = 0.0
+    f0[:, 3::7] = 3000.0
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  grads = []
+  for _ in range(2):
+    ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+    th = ddsp.core.tf_float32(hd).requires_grad_(True)
+    synth(ta, th, f0).backward(ddsp.core.tf_float32(g))
+    grads.append((npy(ta.grad), npy(th.grad)))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, 'window')
+  np.testing.assert_allclose(grads[0][0], ga, rtol=0, atol=grad_tol(ga))
+  np.testing.assert_allclose(grads[0][1], gh, rtol=0, atol=grad_tol(gh))
+  np.testing.assert_array_equal(grads[0][0], grads[1][0])
+  np.testing.assert_array_equal(grads[0][1], grads[1][1])
+
+
 def test_harmonic_backward_full_size_properties(ddsp):
   rng = np.random.default_rng(12)
   b, f, k, n = 32, 1000, 100, 64000
