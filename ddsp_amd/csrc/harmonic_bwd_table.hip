@@ -163,6 +163,9 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
       c_cur = (1.0f - w_next) * gv;
       c_next = w_next * gv;
     };
+#ifdef DDSP_BT_NO_SPREAD
+    if (p.K == 12345)
+#endif
     if (!direct) {
       if (lane < 2 * kBtMaxCross) s_corr[wave][lane >> 3][lane & 7] = 0.0f;
 #pragma unroll 1
@@ -286,6 +289,9 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   __syncthreads();
 
   // ---- 3. D[harmonic][column] = sum_n A[harmonic][n] G_folded[n][column] ------------------------------------------------------------
+#ifdef DDSP_BT_NO_P3
+  if (p.K == 12345)
+#endif
   {
     const int i16 = lane & 15, g4 = lane >> 4;
     bt_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};
@@ -312,6 +318,9 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     }
   }
   __syncthreads();
+#ifdef DDSP_BT_NO_STORE
+  if (p.K == 12345)
+#endif
   if (row < p.rows && !s_k[wave][2]) {
     // wavefront w writes its own frame's two rows
 #pragma unroll
