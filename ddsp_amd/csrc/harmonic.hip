@@ -23,6 +23,7 @@
 #include "common.h"
 #include "profile.h"
 #include "harmonic_bwd_table.h"
+#include "harmonic_bwd_chain.h"
 #include "harmonic_table.h"
 #include "../../include/ddsp_amd.h"
 
@@ -1010,13 +1011,6 @@ namespace ddsp {
 
 constexpr int kBwdMaxHop = 2048;
 
-struct BwdArgs {
-  int F, K, N, hop;
-  float sample_rate, nyquist;
-  int amp_linear;
-  unsigned flags;
-  int inputs_are_controls;
-};
 
 // A block takes `fb` consecutive frames of one row (fb * hop <= kBwdMaxHop samples staged at once):
 // 32000 two-wavefront blocks of one frame each were bound by the block launch rate.
@@ -1127,66 +1121,16 @@ __global__ __launch_bounds__(256) void harm_bwd_chain_kernel(const float* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  const int F = p.F, K = p.K;
+  // dL/da[j] = P[j] + Q[j-1]; the last frame also receives Q[F-1] (row F repeats row F-1)
+  const int F = p.F;
   const int j = (int)(row % F);
-  const bool is_ctl = p.inputs_are_controls != 0;
-  const bool scale = (p.flags & DDSP_HARM_SCALE_EXP_SIGMOID) && !is_ctl;
-  const bool normalize = (p.flags & DDSP_HARM_NORMALIZE_NYQUIST) && !is_ctl;
-  const float kLog10 = 2.302585092994046f;
-  const float f0r = f0_hz[row];
-  const float amp_raw = amplitudes[row];
-  const float amp_s = scale ? exp_sigmoid(amp_raw, kLog10, 2.0f, 1e-7f) : amp_raw;
-  float x[NCHUNK], raw[NCHUNK], ga[NCHUNK];
-  bool live[NCHUNK];
-  float part = 0.0f;
-#pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) {
-    const int k = c * 64 + lane;
-    raw[c] = 0.0f; x[c] = 0.0f; ga[c] = 0.0f; live[c] = false;
-    if (k < K) {
-      const size_t at = (size_t)row * K + k;
-      raw[c] = hd[at];
-      float v = scale ? exp_sigmoid(raw[c], kLog10, 2.0f, 1e-7f) : raw[c];
-      live[c] = !(normalize && (f0r * (float)(k + 1) >= p.nyquist));
-      if (!live[c]) v = 0.0f;
-      x[c] = v;
-      // dL/da[j] = P[j] + Q[j-1]; the last frame also receives Q[F-1] (row F repeats row F-1)
-      float g = pq[at];
-      if (j > 0) g += pq[q_offset + at - K];
-      if (j == F - 1) g += pq[q_offset + at];
-      ga[c] = g;
-    }
-    part += x[c];
-  }
-  float inv = 1.0f;
-  bool den_zero = false;
-  if (!is_ctl) {
-    float den = wave_sum(part);
-    den_zero = den == 0.0f;
-    if (den_zero) den = 1e-7f;
-    inv = 1.0f / den;
-  }
-  float dot = 0.0f;                                      // sum_k ga * hd_norm = dL/d(amp_scaled)
-#pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) dot = fmaf(ga[c], x[c] * inv, dot);
-  dot = wave_sum(dot);
-  if (lane == 0)
-    grad_amp[row] = scale ? dot * kLog10 * (amp_s - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-amp_raw))) : dot;
-#pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) {
-    const int k = c * 64 + lane;
-    if (k < K) {
-      float d;
-      if (is_ctl) {
-        d = ga[c] * amp_s;
-      } else {
-        // hd_norm = x / den: d x = (d hd_norm - sum_k d hd_norm hd_norm) / den, d hd_norm = ga * amp
-        d = (live[c] && !den_zero) ? amp_s * (ga[c] - dot) * inv : 0.0f;
-        if (scale) d *= kLog10 * (x[c] - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-raw[c])));
-      }
-      grad_hd[(size_t)row * K + k] = d;
-    }
-  }
+  harm_chain_row<NCHUNK>(lane, row, j, amplitudes, hd, f0_hz, grad_amp, grad_hd, p, [&](int k) {
+    const size_t at = (size_t)row * p.K + k;
+    float g = pq[at];
+    if (j > 0) g += pq[q_offset + at - p.K];
+    if (j == F - 1) g += pq[q_offset + at];
+    return g;
+  });
 }
 
 static inline size_t bwd_pq_floats(int B, int F, int K) { return ((size_t)B * F * K + 15) & ~(size_t)15; }
@@ -1229,7 +1173,9 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
     // up to 128 harmonics: spread the weighted gradient onto the table grid, one product with the transposed sine matrix
     // (harmonic_bwd_table.hip) instead of a sine per sample and harmonic
     ProfileScope prof(kHarmBwdPq, st);
-    rc = launch_harm_bwd_table(f0_hz, theta0, grad_audio, pq, q_offset, B, F, K, N, sample_rate, p.amp_linear, st);
+    rc = launch_harm_bwd_table(f0_hz, theta0, grad_audio, pq, q_offset, B, F, K, N, sample_rate, p.amp_linear, st, amplitudes, hd,
+                               grad_amplitudes, grad_hd, flags, inputs_are_controls);
+    if (rc == 1) return check_launch();            // the chain rule ran in the same launch
     if (rc != DDSP_OK) return rc;
   } else {
     ProfileScope prof(kHarmBwdPq, st);

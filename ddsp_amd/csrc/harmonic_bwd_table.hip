@@ -41,6 +41,7 @@
 #include "harm_table_frags.h"
 #include "profile.h"
 #include "harmonic_bwd_table.h"
+#include "harmonic_bwd_chain.h"
 
 namespace ddsp {
 
@@ -68,6 +69,9 @@ struct BtArgs {
   long rows;                   // B F
   float sample_rate, nyquist;
   int amp_linear;
+  // CHAIN: the frame-rate chain rule in the same launch (harmonic_bwd_chain.h); P and Q never leave LDS
+  const float* amplitudes; const float* hd; float* grad_amp; float* grad_hd;
+  BwdArgs chain;
 };
 
 template <int W> struct BtPoly;
@@ -90,13 +94,16 @@ __device__ __forceinline__ void bt_split(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((v - (float)hi) * kBtLoScale);
 }
 
-template <int W>
+// CHAIN: groups advance by SEVEN frames - wavefront 0's frame is the one before the group's (its Q is what the group's first
+// frame adds to its P), computed here once more rather than fetched from another block
+template <int W, bool CHAIN>
 __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_table_kernel(BtArgs p) {
+  constexpr int kStep = CHAIN ? kBtFrames - 1 : kBtFrames, kBack = CHAIN ? 1 : 0;
   __shared__ __attribute__((aligned(16))) float2 s_g[kBtFrames][kBtT];            // 32 KB
   __shared__ __attribute__((aligned(16))) _Float16 s_b[2][2][16][kBtCol];         // [hi / lo][parity][column][n]: 17 KB
   __shared__ float s_corr[kBtFrames][2][kBtMaxCross];
   __shared__ int s_k[kBtFrames][4];                                               // kA, kN, direct
-  __shared__ float s_out[16][129];                                                // step 3's results: [column][harmonic]
+  __shared__ float s_out[16][132];                                                // step 3's results: [column][harmonic]
   using C = BtPoly<W>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this wavefront's share of the constant factor for step 3: fetched ONCE - blocks are persistent (a block per group of
@@ -113,16 +120,18 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   // the first tile's gradient samples of a group are requested a group ahead (a group is a chain of dependent steps with two
   // block barriers in it; the HBM latency at its head was a fifth of it)
   auto first_tile = [&](long r0) -> float {
-    const long rw = r0 + wave;
-    if (rw >= p.rows || lane >= p.hop) return 0.0f;
+    const long rw = r0 + wave - kBack;
+    if (rw < 0 || rw >= p.rows || lane >= p.hop) return 0.0f;
     return p.g[(size_t)rw * p.hop + lane];           // row (b, j): sample b N + j hop + lane = row hop + lane
   };
-  float g_next = first_tile((long)blockIdx.x * kBtFrames);
+  float g_next = first_tile((long)blockIdx.x * kStep);
 #pragma unroll 1
-  for (long row0 = (long)blockIdx.x * kBtFrames; row0 < p.rows; row0 += (long)gridDim.x * kBtFrames) {
-  const long row = row0 + wave;
+  for (long row0 = (long)blockIdx.x * kStep; row0 < p.rows; row0 += (long)gridDim.x * kStep) {
+  const long row = row0 + wave - kBack;
+  const bool row_ok = row >= 0 && row < p.rows;
   const float g_first = g_next;
-  g_next = first_tile(row0 + (long)gridDim.x * kBtFrames);
+  g_next = first_tile(row0 + (long)gridDim.x * kStep);
+  float dP0 = 0.0f, dQ0 = 0.0f, dP1 = 0.0f, dQ1 = 0.0f;         // the plain sum's results (CHAIN: into LDS behind the barrier)
 
   // ---- 1. spreading -----------------------------------------------------------------------------------------------------------
   {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   // instruction - they say so to the compiler, and to the CPU emulation of tests/hip_emu, whose lanes run one after another)
   __builtin_amdgcn_wave_barrier();
   int kA = 0, kN = 0, direct = 1;
-  if (row < p.rows) {
+  if (row_ok) {
     const int b = (int)(row / p.F), j = (int)(row - (long)b * p.F);
     const float* __restrict__ f0 = p.f0 + (size_t)b * p.F;
     const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
@@ -256,9 +265,13 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
           P1 = fmaf(cc, s1, P1); Q1 = fmaf(cn, s1, Q1);
         }
       }
-      const size_t at = (size_t)row * p.K;
-      if (k0 < p.K) { p.pq[at + k0] = P0; p.pq[p.q_offset + at + k0] = Q0; }
-      if (k1 < p.K) { p.pq[at + k1] = P1; p.pq[p.q_offset + at + k1] = Q1; }
+      if constexpr (CHAIN) {
+        dP0 = P0; dQ0 = Q0; dP1 = P1; dQ1 = Q1;
+      } else {
+        const size_t at = (size_t)row * p.K;
+        if (k0 < p.K) { p.pq[at + k0] = P0; p.pq[p.q_offset + at + k0] = Q0; }
+        if (k1 < p.K) { p.pq[at + k1] = P1; p.pq[p.q_offset + at + k1] = Q1; }
+      }
     }
   }
   if (lane == 0) { s_k[wave][0] = kA; s_k[wave][1] = kN; s_k[wave][2] = direct; }
@@ -307,21 +320,45 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     // D[row 4 g + r = harmonic k' of the tile][column i16 = 2 frame + quantity] -> rows of the P / Q workspace through LDS
     // (straight from the accumulators every lane stored 4 bytes into a cache line of its own)
     const int fr = i16 >> 1, q = i16 & 1;
-    const int fkA = s_k[fr][0], fkN = s_k[fr][1];
+    const int fkA = s_k[fr][0], fkN = s_k[fr][1], fdirect = s_k[fr][2];
+    if (!fdirect) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k0 = 2 * (16 * mt + 4 * g4 + r) + par;                 // 0-based harmonic index (harmonic k0 + 1)
-      float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kBtLoScale);
-      if (k0 >= fkN) v = 0.0f;
-      else if (k0 >= fkA) v -= s_corr[fr][q][k0 - fkA];
-      s_out[i16][k0] = v;
+      for (int r = 0; r < 4; ++r) {
+        const int k0 = 2 * (16 * mt + 4 * g4 + r) + par;                 // 0-based harmonic index (harmonic k0 + 1)
+        float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kBtLoScale);
+        if (k0 >= fkN) v = 0.0f;
+        else if (k0 >= fkA) v -= s_corr[fr][q][k0 - fkA];
+        s_out[i16][k0] = v;
+      }
+    }
+  }
+  if constexpr (CHAIN) {
+    if (row_ok && s_k[wave][2]) {          // (s_out's readers of the previous group are behind the barrier above)
+      s_out[2 * wave][lane] = dP0; s_out[2 * wave + 1][lane] = dQ0;
+      s_out[2 * wave][lane + 64] = dP1; s_out[2 * wave + 1][lane + 64] = dQ1;
     }
   }
   __syncthreads();
+  if constexpr (CHAIN) {
+    // the chain rule of frame `row` (wavefronts 1 .. 7): dL/da = P[row] + Q[row - 1] (wavefront w - 1's, same batch row) (+ Q[row]
+    // for the held last frame)
+    if (wave >= 1 && row_ok) {
+      const int j = (int)(row % p.F);
+      const float* P = s_out[2 * wave];
+      const float* Qp = s_out[2 * wave - 1];
+      const float* Qo = s_out[2 * wave + 1];
+      harm_chain_row<2>(lane, row, j, p.amplitudes, p.hd, p.f0, p.grad_amp, p.grad_hd, p.chain, [&](int k) {
+        float gsum = P[k];
+        if (j > 0) gsum += Qp[k];
+        if (j == p.F - 1) gsum += Qo[k];
+        return gsum;
+      });
+    }
+  } else
 #ifdef DDSP_BT_NO_STORE
   if (p.K == 12345)
 #endif
-  if (row < p.rows && !s_k[wave][2]) {
+  if (row_ok && !s_k[wave][2]) {
     // wavefront w writes its own frame's two rows
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -381,7 +418,13 @@ bool harm_bwd_table_ok(int F, int K, int N) {
 }
 
 int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float* grad_audio, float* pq, size_t q_offset, int B,
-                          int F, int K, int N, int sample_rate, int amp_linear, hipStream_t st) {
+                          int F, int K, int N, int sample_rate, int amp_linear, hipStream_t st, const float* amplitudes,
+                          const float* hd, float* grad_amp, float* grad_hd, unsigned flags, int inputs_are_controls) {
+  // The chain rule in the same launch (CHAIN) is correct and is NOT the default: it puts seven more dependent steps into every
+  // group's chain and recomputes a frame in eight - 60.1 us against 41.6 + 21.2 in two launches at batch 32, 215 against 135 + 66
+  // at batch 128 (profiles/r05_harm_bwd_table.txt).  DDSP_EXP_HARM_BWD=fused runs it.
+  static const bool fused = [] { const char* e = getenv("DDSP_EXP_HARM_BWD"); return e && e[0] == 'f'; }();
+  const bool chain = amplitudes != nullptr && fused;
   const int W = K <= 100 ? 6 : 8;
   const bt_u32x4* frags = bt_fragments(W);
   if (!frags) return DDSP_ERR_LAUNCH;
@@ -396,11 +439,21 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     return v;
   }();
-  const long groups = (a.rows + kBtFrames - 1) / kBtFrames;
+  a.amplitudes = amplitudes; a.hd = hd; a.grad_amp = grad_amp; a.grad_hd = grad_hd;
+  a.chain.F = F; a.chain.K = K; a.chain.N = N; a.chain.hop = a.hop;
+  a.chain.sample_rate = a.sample_rate; a.chain.nyquist = a.nyquist; a.chain.amp_linear = amp_linear;
+  a.chain.flags = flags; a.chain.inputs_are_controls = inputs_are_controls;
+  const int step = chain ? kBtFrames - 1 : kBtFrames;
+  const long groups = (a.rows + step - 1) / step;
   const dim3 grid((unsigned)std::min<long>(groups, 2L * n_cu));       // persistent: two blocks per CU (59 KB of LDS, 128 registers)
-  if (W == 6) hipLaunchKernelGGL((harm_bwd_table_kernel<6>), grid, dim3(64 * kBtFrames), 0, st, a);
-  else hipLaunchKernelGGL((harm_bwd_table_kernel<8>), grid, dim3(64 * kBtFrames), 0, st, a);
-  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+  if (chain) {
+    if (W == 6) hipLaunchKernelGGL((harm_bwd_table_kernel<6, true>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else hipLaunchKernelGGL((harm_bwd_table_kernel<8, true>), grid, dim3(64 * kBtFrames), 0, st, a);
+  } else {
+    if (W == 6) hipLaunchKernelGGL((harm_bwd_table_kernel<6, false>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else hipLaunchKernelGGL((harm_bwd_table_kernel<8, false>), grid, dim3(64 * kBtFrames), 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? (chain ? 1 : DDSP_OK) : DDSP_ERR_LAUNCH;       // 1: the chain rule is done too
 }
 
 }  // namespace ddsp
