@@ -15,10 +15,10 @@ if [ "$REV" = "WORKTREE" ]; then
 else
   git archive $REV ddsp_amd/csrc include | tar -x -C $SRC
 fi
-for f in harmonic_table harmonic_bwd_table filtered_noise_mfma filtered_noise_general spectral_loss; do
+for f in harmonic harmonic_table harmonic_bwd_table filtered_noise_mfma filtered_noise_general spectral_loss; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I$SRC/include "$@" -c $SRC/ddsp_amd/csrc/$f.hip -o tools/bin/${f}_$NAME.o &
 done
 wait
-objs=$(ls ddsp_amd/lib/obj/*.o | grep -v "harmonic_table.o\|harmonic_bwd_table.o\|filtered_noise_mfma.o\|filtered_noise_general.o\|spectral_loss.o")
-hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/bin/harmonic_table_$NAME.o tools/bin/harmonic_bwd_table_$NAME.o tools/bin/filtered_noise_mfma_$NAME.o tools/bin/filtered_noise_general_$NAME.o tools/bin/spectral_loss_$NAME.o -o tools/bin/libddsp_amd_$NAME.so
+objs=$(ls ddsp_amd/lib/obj/*.o | grep -v "/harmonic.o\|harmonic_table.o\|harmonic_bwd_table.o\|filtered_noise_mfma.o\|filtered_noise_general.o\|spectral_loss.o")
+hipcc --offload-arch=gfx950 -shared -fPIC $objs tools/bin/harmonic_$NAME.o tools/bin/harmonic_table_$NAME.o tools/bin/harmonic_bwd_table_$NAME.o tools/bin/filtered_noise_mfma_$NAME.o tools/bin/filtered_noise_general_$NAME.o tools/bin/spectral_loss_$NAME.o -o tools/bin/libddsp_amd_$NAME.so
 echo "built tools/bin/libddsp_amd_$NAME.so from $REV"
