@@ -369,8 +369,12 @@ static const GiMatrix* gi_matrix(int M, int window_size) {
           }
     if (hipMalloc((void**)&m.dev_u, fu.size() * 4) != hipSuccess || hipMalloc((void**)&m.dest, dest.size() * 4) != hipSuccess ||
         hipMemcpy(m.dev_u, fu.data(), fu.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m.dest, dest.data(), dest.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(m.dest, dest.data(), dest.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(m.dev);
+      if (m.dev_u) (void)hipFree(m.dev_u);
+      if (m.dest) (void)hipFree(m.dest);
       return nullptr;
+    }
   }
   return &cache.emplace(key, m).first->second;
 }
@@ -388,10 +392,8 @@ static void gi_launch(const float* mag, float* ctl_out, float* ir, const GiMatri
   const size_t stage = (size_t)kGiRows * (32 * KS + 4) * sizeof(float);
   if (stage > lds) lds = stage;
   const unsigned grid = (unsigned)((rows + kGiRows - 1) / kGiRows);
-  static const bool lds_set = [] {
-    return hipFuncSetAttribute((const void*)noise_ir_gemm_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
-  }();
-  (void)lds_set;
+  if (lds > 48 * 1024)      // (per launch: the attribute belongs to the current device's copy of the kernel)
+    (void)hipFuncSetAttribute((const void*)noise_ir_gemm_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipLaunchKernelGGL((noise_ir_gemm_kernel<KS>), dim3(grid), dim3(64 * kGiWaves), lds, st, mag, ctl_out, ir,
                      m->dev, rows, M, L, m->NT, bias, scale);
 }
@@ -887,10 +889,9 @@ bool tv_fir_mfma_ok(int B, int Bir, int F, int L, int N) {
 
 template <bool GEN, int NT, int KS, int NPW>
 static void gf_launch_one(const GfPlan& pl, dim3 grid, dim3 block, hipStream_t st) {
-  static const bool lds_set = [] {
-    return hipFuncSetAttribute((const void*)tv_fir_mfma_kernel<GEN, NT, KS, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, kGfLdsBudget) == hipSuccess;
-  }();
-  (void)lds_set;
+  // (per launch, not once per process: the attribute belongs to the current device's copy of the kernel)
+  if (pl.lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)tv_fir_mfma_kernel<GEN, NT, KS, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, kGfLdsBudget);
   hipLaunchKernelGGL((tv_fir_mfma_kernel<GEN, NT, KS, NPW>), grid, block, pl.lds, st, pl.a);
 }
 
