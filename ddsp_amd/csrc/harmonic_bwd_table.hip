@@ -151,9 +151,11 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
     if (fmn > 0.0f) kN = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f + 2e-6f) / fmn));
     kA = max(min(kA, kN), 0);
-    // positions at least one entry apart (and finite, and a bounded number of revolutions per tile): else the plain sum
+    // positions more than one entry apart - by a margin: the increment of the fp64 position is f(n) / sr * 512 with f between the
+    // two frames' f0, and two samples on one entry in one read-modify-write would lose one of them - (and finite, and a bounded
+    // number of revolutions per tile): else the plain sum
     const float stride_min = fmn * ((float)kBtT / p.sample_rate);
-    direct = (stride_min >= 1.0f && fmx <= 0.5f * p.sample_rate && kN - kA <= kBtMaxCross) ? 0 : 1;
+    direct = (stride_min >= 1.001f && fmx <= 0.5f * p.sample_rate && kN - kA <= kBtMaxCross) ? 0 : 1;
     const double inv_sr = 1.0 / (double)p.sample_rate, inv_2hop = 0.5 / (double)p.hop;
     const float inv_hop = 1.0f / (float)p.hop;
     const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
