@@ -124,13 +124,29 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     if (rw < 0 || rw >= p.rows || lane >= p.hop) return 0.0f;
     return p.g[(size_t)rw * p.hop + lane];           // row (b, j): sample b N + j hop + lane = row hop + lane
   };
+  // ... and so are the frame's two f0 values and its phase: everything a group's first instruction depends on
+  struct Head { float fj, fj1; double th0; };
+  auto frame_head = [&](long r0) -> Head {
+    const long rw = r0 + wave - kBack;
+    Head h{0.0f, 0.0f, 0.0};
+    if (rw >= 0 && rw < p.rows) {
+      const long jj = rw % p.F;
+      h.fj = p.f0[rw];
+      h.fj1 = p.f0[jj + 1 < p.F ? rw + 1 : rw];
+      h.th0 = p.theta0[rw];
+    }
+    return h;
+  };
   float g_next = first_tile((long)blockIdx.x * kStep);
+  Head h_next = frame_head((long)blockIdx.x * kStep);
 #pragma unroll 1
   for (long row0 = (long)blockIdx.x * kStep; row0 < p.rows; row0 += (long)gridDim.x * kStep) {
   const long row = row0 + wave - kBack;
   const bool row_ok = row >= 0 && row < p.rows;
   const float g_first = g_next;
+  const Head head = h_next;
   g_next = first_tile(row0 + (long)gridDim.x * kStep);
+  h_next = frame_head(row0 + (long)gridDim.x * kStep);
   float dP0 = 0.0f, dQ0 = 0.0f, dP1 = 0.0f, dQ1 = 0.0f;         // the plain sum's results (CHAIN: into LDS behind the barrier)
 
   // ---- 1. spreading -----------------------------------------------------------------------------------------------------------
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   if (row_ok) {
     const int b = (int)(row / p.F), j = (int)(row - (long)b * p.F);
     const float* __restrict__ f0 = p.f0 + (size_t)b * p.F;
-    const float fj = f0[j], fj1 = f0[min(j + 1, p.F - 1)];
+    const float fj = head.fj, fj1 = head.fj1;
     const float fmx = fmaxf(fj, fj1), fmn = fminf(fj, fj1);
     kA = p.K; kN = p.K;
     if (fmx > 0.0f) kA = (int)fminf((float)p.K, floorf(p.nyquist * (1.0f - 2e-6f) / fmx));
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     const double inv_sr = 1.0 / (double)p.sample_rate, inv_2hop = 0.5 / (double)p.hop;
     const float inv_hop = 1.0f / (float)p.hop;
     const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
-    const double th0 = p.theta0[(size_t)b * p.F + j];
+    const double th0 = head.th0;
     const float* __restrict__ g = p.g + (size_t)b * p.N + (size_t)j * p.hop;
     float2* const G = &s_g[wave][0];
     // per-sample values of a tile: lanes = samples
