@@ -72,6 +72,7 @@ struct BtArgs {
   // CHAIN: the frame-rate chain rule in the same launch (harmonic_bwd_chain.h); P and Q never leave LDS
   const float* amplitudes; const float* hd; float* grad_amp; float* grad_hd;
   BwdArgs chain;
+  long long* dbg;              // per-phase clock stamps of block 0 (tools/exp_bwd_timeline.py: DDSP_EXP_BT_TIMELINE = a device pointer), or null
 };
 
 template <int W> struct BtPoly;
@@ -99,6 +100,8 @@ __device__ __forceinline__ void bt_split(float v, _Float16& hi, _Float16& lo) {
 template <int W, bool CHAIN>
 __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_table_kernel(BtArgs p) {
   constexpr int kStep = CHAIN ? kBtFrames - 1 : kBtFrames, kBack = CHAIN ? 1 : 0;
+  int dbg_iter = 0;
+#define DDSP_BT_STAMP(pt) do { if (p.dbg != nullptr && blockIdx.x == 0 && lane == 0 && dbg_iter < 16) p.dbg[(dbg_iter * 8 + wave) * 8 + (pt)] = (long long)__builtin_readcyclecounter(); } while (0)
   __shared__ __attribute__((aligned(16))) float2 s_g[kBtFrames][kBtT];            // 32 KB
   __shared__ __attribute__((aligned(16))) _Float16 s_b[2][2][16][kBtCol];         // [hi / lo][parity][column][n]: 17 KB
   __shared__ float s_corr[kBtFrames][2][kBtMaxCross];
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   g_next = first_tile(row0 + (long)gridDim.x * kStep);
   h_next = frame_head(row0 + (long)gridDim.x * kStep);
   float dP0 = 0.0f, dQ0 = 0.0f, dP1 = 0.0f, dQ1 = 0.0f;         // the plain sum's results (CHAIN: into LDS behind the barrier)
+  DDSP_BT_STAMP(0);
 
   // ---- 1. spreading -----------------------------------------------------------------------------------------------------------
   {
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   }
   if (lane == 0) { s_k[wave][0] = kA; s_k[wave][1] = kN; s_k[wave][2] = direct; }
   __builtin_amdgcn_wave_barrier();
+  DDSP_BT_STAMP(1);
 
   // ---- 2. folding onto the quarter range, split, B-fragment planes: columns 2 w (P) and 2 w + 1 (Q) -----------------------------
 #ifndef DDSP_BT_NO_FOLD
@@ -317,7 +322,9 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     }
   }
 #endif
+  DDSP_BT_STAMP(2);
   __syncthreads();
+  DDSP_BT_STAMP(3);
 
   // ---- 3. D[harmonic][column] = sum_n A[harmonic][n] G_folded[n][column] ------------------------------------------------------------
 #ifdef DDSP_BT_NO_P3
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
       }
     }
   }
+  DDSP_BT_STAMP(4);
   if constexpr (CHAIN) {
     if (row_ok && s_k[wave][2]) {          // (s_out's readers of the previous group are behind the barrier above)
       s_out[2 * wave][lane] = dP0; s_out[2 * wave + 1][lane] = dQ0;
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     }
   }
   __syncthreads();
+  DDSP_BT_STAMP(5);
   if constexpr (CHAIN) {
     // the chain rule of frame `row` (wavefronts 1 .. 7): dL/da = P[row] + Q[row - 1] (wavefront w - 1's, same batch row) (+ Q[row]
     // for the held last frame)
@@ -385,7 +394,10 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
       if (lane + 64 < p.K) dst[lane + 64] = s_out[2 * wave + q][lane + 64];
     }
   }
+  DDSP_BT_STAMP(6);
+  ++dbg_iter;
   }    // the block's next group of frames
+#undef DDSP_BT_STAMP
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------
@@ -457,6 +469,7 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     return v;
   }();
+  { const char* e = getenv("DDSP_EXP_BT_TIMELINE"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
   a.amplitudes = amplitudes; a.hd = hd; a.grad_amp = grad_amp; a.grad_hd = grad_hd;
   a.chain.F = F; a.chain.K = K; a.chain.N = N; a.chain.hop = a.hop;
   a.chain.sample_rate = a.sample_rate; a.chain.nyquist = a.nyquist; a.chain.amp_linear = amp_linear;
