@@ -1414,6 +1414,32 @@ def test_filtered_noise_general_shapes_on_the_matrix_cores(ddsp, m, ws, n_frames
   np.testing.assert_allclose(got_gen, ref_gen, rtol=0, atol=noise_tol(ref_gen))
 
 
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_filtered_noise_general_random_shapes(ddsp, seed):
+  """Random band counts (3 .. 140), window sizes (full, cropped, odd), frame sizes (5 .. 400), ragged lengths, batch sizes: the
+  tile cuts of tv_fir_mfma_kernel (pieces, runs, history, the fused design for <= 128 bands, two launches above) against the
+  fp64 oracle."""
+  rng = np.random.default_rng(seed)
+  cases = 12 if DEV == 'cuda' else 3
+  for _ in range(cases):
+    m = int(rng.choice([3, 5, 17, 33, 64, 66, 100, 129, 140]))
+    l0 = 2 * (m - 1)
+    ws = int(rng.choice([0, l0 + 5, max(3, l0 // 2 + 1), max(3, (l0 // 3) | 1)]))
+    fs = int(rng.choice([5, 16, 37, 64, 100, 128, 400]))
+    f = int(rng.integers(1, 60 if DEV == 'cuda' else 12))
+    n = f * fs - int(rng.integers(0, fs))
+    if n < 1:
+      continue
+    b = int(rng.integers(1, 4))
+    mags = (rng.standard_normal((b, f, m)) + 2.0).astype(np.float32)
+    noise = rng.uniform(-1, 1, (b, n)).astype(np.float32)
+    synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=ws)
+    got = npy(synth(mags, noise=noise))
+    ref = O.filtered_noise(mags, noise, ws, O.exp_sigmoid, dtype=np.float64)
+    assert got.shape == ref.shape, dict(m=m, ws=ws, fs=fs, frames=f, n=n, batch=b)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=noise_tol(ref), err_msg=str(dict(m=m, ws=ws, fs=fs, frames=f, n=n, batch=b)))
+
+
 def test_fft_convolve_general_shapes_on_the_matrix_cores(ddsp):
   """core.fft_convolve (ddsp/core.py:1382-1473) through tv_fir_mfma_kernel: odd tap counts, one filter for the whole batch,
   explicit delay compensation, a single frame (a time-invariant filter), frames shorter than 16 samples."""
