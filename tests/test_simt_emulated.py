@@ -79,4 +79,8 @@ SLOW_UNDER_EMULATION = () if os.environ.get('DDSP_EMU_ALL') == '1' else (
     'test_harmonic_canonical_vs_truth_and_faithful[auto-200.0]',       # 4 x 6-8 s: one of the four stays
     'test_harmonic_canonical_vs_truth_and_faithful[direct-70.0]',
     'test_harmonic_canonical_vs_truth_and_faithful[direct-200.0]',
+    'test_spectral_loss_every_term_golden_and_gradient',               # 46 s (round 4: the CPU suite is run serially by the driver)
+    'test_exp_decay_reverb_reference_tests_and_gradients',             # 37 s
+    'test_filtered_noise_matrix_core_kernel_vs_oracle_and_vector_kernel[770-1-64]',      # 34 s: the two smaller cases stay
+    'test_spectral_loss_vs_fp64_oracle[3-12345]',                      # 16 s
 )
