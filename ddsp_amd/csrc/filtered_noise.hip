@@ -1113,6 +1113,10 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
       ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  // the canonical filter on frames of 64 c samples: one launch on the matrix cores (filtered_noise_general.hip)
+  if (noise_bwd_mfma_ok(B, F, M, N, window_size))
+    return launch_noise_bwd_mfma(magnitudes, noise, grad_audio, grad_magnitudes, B, F, M, N, window_size, initial_bias,
+                                 (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0, seed, batch_offset, st);
   NoiseBwdArgs p;
   p.N = N; p.F = F; p.fs = fs; p.start = start;
   p.L = g.L; p.Lpad = (g.L + 127) & ~127; p.M = M; p.window_size = window_size;

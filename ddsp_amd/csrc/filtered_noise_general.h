@@ -25,4 +25,10 @@ int launch_filtered_noise_general_fused(const float* mag, const float* x, float*
                                         int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset,
                                         hipStream_t st);
 
+// the backward of FilteredNoise.__call__ for 65 bands / full window / frames of 64, 128, 192, 256 samples in ONE launch: the tap
+// gradients as Toeplitz products, dL/d magnitudes as a product with the transposed design matrix
+bool noise_bwd_mfma_ok(int B, int F, int M, int N, int window_size);
+int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const float* grad_audio, float* grad_magnitudes, int B, int F,
+                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, hipStream_t st);
+
 }  // namespace ddsp

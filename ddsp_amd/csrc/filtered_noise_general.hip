@@ -266,6 +266,9 @@ struct GiMatrix {
   // the same column; some taps are zero), for the kernel that designs its own taps: NTu tiles of 16 columns, and where
   // each column's product goes: two tap indices per column, 0xFFFF = nowhere
   uint4* dev_u = nullptr; uint32_t* dest = nullptr; int NTu = 0;
+  // the TRANSPOSE, for the backward pass (dL/d magnitudes = dL/d taps . C^T): B[k = tap][n = band] as fragments
+  // [band tile nb][k-step of 32 taps][hi / lo][lane], KSt k-steps, NTb band tiles
+  uint4* dev_t = nullptr; int KSt = 0, NTb = 0;
 };
 
 static const GiMatrix* gi_matrix(int M, int window_size) {
@@ -375,6 +378,31 @@ static const GiMatrix* gi_matrix(int M, int window_size) {
       if (m.dest) (void)hipFree(m.dest);
       return nullptr;
     }
+  }
+  {
+    const int ld = m.NT * 16;
+    m.KSt = (g.L + 31) / 32;
+    m.NTb = (M + 15) / 16;
+    std::vector<uint32_t> ft((size_t)m.NTb * m.KSt * 2 * 64 * 4, 0u);
+    for (int nb = 0; nb < m.NTb; ++nb)
+      for (int ks = 0; ks < m.KSt; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int d = 0; d < 4; ++d) {
+            uint32_t hi2 = 0, lo2 = 0;
+            for (int h = 0; h < 2; ++h) {
+              const int t = 32 * ks + 8 * (lane >> 4) + 2 * d + h, band = 16 * nb + (lane & 15);
+              const float x = (t < g.L && band < M) ? c[(size_t)band * ld + t] : 0.0f;
+              const unsigned short hb = gi_f16_bits(x);
+              const unsigned short lb = gi_f16_bits((x - gi_f16_value(hb)) * kGfLoScale);
+              hi2 |= (uint32_t)hb << (16 * h);
+              lo2 |= (uint32_t)lb << (16 * h);
+            }
+            ft[((((size_t)nb * m.KSt + ks) * 2 + 0) * 64 + lane) * 4 + d] = hi2;
+            ft[((((size_t)nb * m.KSt + ks) * 2 + 1) * 64 + lane) * 4 + d] = lo2;
+          }
+    if (hipMalloc((void**)&m.dev_t, ft.size() * 4) != hipSuccess ||
+        hipMemcpy(m.dev_t, ft.data(), ft.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return nullptr;
   }
   return &cache.emplace(key, m).first->second;
 }
@@ -967,6 +995,242 @@ int launch_filtered_noise_general_fused(const float* mag, const float* x, float*
   a.M = M; a.scale = scale; a.bias = bias;
   a.mag_vec = ((M & 3) == 0 && ((((uintptr_t)mag) | ((uintptr_t)ctl_out)) & 15) == 0) ? 1 : 0;
   return gf_launch(pl, B, B, F, g.L, N, start, x, nullptr, out, seed, batch_offset, m->KS, st);
+}
+
+// =====================================================================================================================
+// backward of FilteredNoise.__call__ for the canonical filter (65 bands, full window: 128 taps; frames of 64 c samples)
+// =====================================================================================================================
+// dL/dh_f[t] = sum_{i in frame f} x[i] gz[i + t], gz[m] = dL/d audio[m - start]; then dL/d magnitudes = (dL/dh . C^T) exp_sigmoid'.
+// (filtered_noise.hip, "Backward pass": noise_bwd_taps_kernel + noise_bwd_mags_kernel, 28 + 23 us at batch 32 against 11 forward.)
+// The tap gradients are a correlation; with u = the frame's samples reversed it is the convolution (u * gz_window)[t + 63], and that is
+// tv_fir_mfma_kernel's algebra with the roles swapped: the NOISE piece (reversed twice: in natural order, one element into its
+// slot, so that output 64 + t is tap t) is the Toeplitz operand, the GRADIENT window is the dense one - and since a piece starts
+// at a multiple of 64 samples, the 8 gradient samples of a B-fragment are an aligned 16-byte group of ONE linear array: no tap rows.
+// Nothing is overlap-added: a frame keeps its own 8 columns of 16 taps; two frames share an MFMA tile (columns 0-7 / 8-15, each
+// with its own half of the K range).  Then a second product per 16 frames with the transposed design matrix (window and irfft
+// weights folded in), the derivative of exp_sigmoid in the epilogue.  One block = NF frames: no history, no carries.
+struct NbArgs {
+  const float* mag; const float* x; const float* g; float* grad_mag;
+  const uint4* ct;             // the transposed design matrix's fragments (gi_matrix: dev_t)
+  int N, F, M, fs, npf, start, NF;
+  int scale;
+  float bias;
+  uint32_t k0, k1;
+  uint64_t batch_offset;
+  int gz_plane;                // bytes of one part (hi or lo) of the staged gradient
+  int x_part, x_o;             // as GfArgs
+  int x_at, dh_at;             // byte offsets of the noise planes and the tap-gradient planes in LDS
+};
+constexpr int kNbDhStride = 136;               // halves per frame row of the tap gradients (128 + 8)
+
+template <bool GEN>
+__global__ __launch_bounds__(512) void noise_bwd_mfma_kernel(NbArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const s_gz = smem;                                  // hi plane, lo plane: gz[m0 + n] at half n, n < NF fs + 128; then 16 bytes of zeros
+  uint8_t* const s_x = smem + p.x_at;                          // E hi, O hi [, E lo, O lo]
+  _Float16* const s_dh = reinterpret_cast<_Float16*>(smem + p.dh_at);   // [hi / lo][NF][kNbDhStride]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 512;
+  const int b = blockIdx.y, f0 = blockIdx.x * p.NF;
+  const int m0 = f0 * p.fs;                                     // first sample of the tile
+  const int span = p.NF * p.fs + 128;
+  const int zero_at = 2 * span;                                 // byte offset (inside the hi plane's allocation) of a group of zeros
+  const int P = p.NF * p.npf;                                   // pieces of 64 samples
+
+  // the constant fragments of this wavefront's first task of the second product, requested now
+  typedef uint32_t gi_u32x4 __attribute__((ext_vector_type(4)));
+  const int RG = p.NF >> 4;                                     // row groups of 16 frames
+  const int n_tasks = RG * 5;                                   // (row group, band tile): 65 bands = 5 tiles
+  gi_u32x4 cfr[2][4][2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int task = wave + 8 * n;
+    if (task < n_tasks) {
+      const int nb = task / RG;
+      const gi_u32x4* src = reinterpret_cast<const gi_u32x4*>(p.ct) + (size_t)nb * 4 * 128 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        cfr[n][ks][0] = src[(2 * ks + 0) * 64];
+        cfr[n][ks][1] = src[(2 * ks + 1) * 64];
+      }
+    }
+  }
+
+  // ---- stage the gradient window (split) and the noise pieces -------------------------------------------------------------
+  {
+    const float* gb = p.g + (size_t)b * p.N;
+    for (int k = tid; k < (span + 8) / 8; k += nthr) {          // groups of 8; the group behind the span is the zeros
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = 8 * k + e;
+        const long a = (long)m0 + n - p.start;                  // gz[m] = g[m - start]
+        v[e] = (n < span && a >= 0 && a < p.N) ? gb[a] : 0.0f;
+      }
+      gf_f16x8 hi, lo;
+      gf_split8(v, hi, lo);
+      *reinterpret_cast<gf_f16x8*>(s_gz + 16 * k) = hi;
+      *reinterpret_cast<gf_f16x8*>(s_gz + p.gz_plane + 16 * k) = lo;
+    }
+    // the noise planes: zero, then the samples (a piece's sample i at element 31 + 96 slot + i)
+    const int n16 = ((GEN ? 1 : 2) * p.x_part) >> 4;
+    for (int k = tid; k < n16; k += nthr) reinterpret_cast<uint4*>(s_x)[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  {
+    const int x_lo = p.x_part;
+    auto place = [&](int i, float val) {                        // sample i of the row, inside the tile
+      const int rel = i - m0;
+      const int el = 31 + kGfSlot * (rel >> 6) + (rel & 63);
+      _Float16 hi, lo;
+      gf_split(val, hi, lo);
+      *reinterpret_cast<_Float16*>(s_x + 2 * el) = hi;
+      *reinterpret_cast<_Float16*>(s_x + p.x_o + 2 * (el + 1)) = hi;
+      if constexpr (!GEN) {
+        *reinterpret_cast<_Float16*>(s_x + x_lo + 2 * el) = lo;
+        *reinterpret_cast<_Float16*>(s_x + x_lo + p.x_o + 2 * (el + 1)) = lo;
+      }
+    };
+    const int i_end = min(p.N, m0 + P * 64);
+    if constexpr (GEN) {
+      for (int q = (m0 >> 3) + tid; 8 * q < i_end; q += nthr) {
+        const U4 r = noise_philox(U4{(uint32_t)q, (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
+        const float4 a = noise_quad(r, 0), c4 = noise_quad(r, 1);
+        const float v[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (8 * q + e < i_end) place(8 * q + e, v[e]);
+      }
+    } else {
+      const float* xb = p.x + (size_t)b * p.N;
+      for (int i = m0 + tid; i < i_end; i += nthr) place(i, xb[i]);
+    }
+  }
+  __syncthreads();
+
+  // ---- the tap gradients of two frames per MFMA tile -------------------------------------------------------------------------
+  const int i16 = lane & 15, g = lane >> 4;
+  {
+    const int x_copy = (i16 & 1) ? 0 : p.x_o + 2;
+    const int x_lane = 2 * (16 + 79 - (16 * (g >> 1) + i16 - 8 * (g & 1))) + x_copy;
+    const int half_col = i16 >> 3;                               // which frame of the pair this lane's column belongs to
+#pragma unroll 1
+    for (int pp = wave; pp < p.NF / 2; pp += 8) {
+      gf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int c = 0; c < p.npf; ++c) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int fr = 2 * pp + half;
+          const int slot = fr * p.npf + c;
+          const uint8_t* xa = s_x + x_lane + 2 * kGfSlot * slot;
+          const int base = fr * p.fs + 64 * c;                   // the piece's first sample relative to the tile: a multiple of 8
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) {
+            const GfU4 qh = *reinterpret_cast<const GfU4*>(xa - 64 * ks);
+            const gf_f16x8 ah = __builtin_bit_cast(gf_f16x8, qh);
+            const int q = (i16 & 7) + 4 - 2 * ks - (g >> 1);     // block of 16 gradient samples this lane's column reads
+            const int off = (half_col == half && q >= 0) ? 2 * (base + 16 * q + 8 * (g & 1)) : zero_at;
+            const gf_f16x8 bh = *reinterpret_cast<const gf_f16x8*>(s_gz + off);
+            const gf_f16x8 bl = *reinterpret_cast<const gf_f16x8*>(s_gz + p.gz_plane + off);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_x, 0, 0, 0);
+            if constexpr (!GEN) {
+              const GfU4 ql = *reinterpret_cast<const GfU4*>(xa - 64 * ks + p.x_part);
+              acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gf_f16x8, ql), bh, acc_x, 0, 0, 0);
+            }
+          }
+        }
+      }
+      // D[row 4 g + r][column]: tap 16 (column & 7) + 4 g + r of frame 2 pp + (column >> 3): four consecutive halves
+      _Float16 hi[4], lo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gf_split(acc[r] + acc_x[r] * (1.0f / kGfLoScale), hi[r], lo[r]);
+      _Float16* dst = s_dh + (2 * pp + half_col) * kNbDhStride + 16 * (i16 & 7) + 4 * g;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(gf_pack(hi[0], hi[1]), gf_pack(hi[2], hi[3]));
+      *reinterpret_cast<uint2*>(dst + p.NF * kNbDhStride) = make_uint2(gf_pack(lo[0], lo[1]), gf_pack(lo[2], lo[3]));
+    }
+  }
+  __syncthreads();
+
+  // ---- dL/d magnitudes: 16 frames x 16 bands per task ----------------------------------------------------------------------------
+  const float kLog10 = 2.302585092994046f;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int task = wave + 8 * n;
+    if (task >= n_tasks) continue;                               // (wave-uniform)
+    const int nb = task / RG, rg = task - nb * RG;
+    gf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};
+    const _Float16* arow = s_dh + (16 * rg + i16) * kNbDhStride + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const gf_f16x8 ah = *reinterpret_cast<const gf_f16x8*>(arow + 32 * ks);
+      const gf_f16x8 al = *reinterpret_cast<const gf_f16x8*>(arow + 32 * ks + p.NF * kNbDhStride);
+      const gf_f16x8 bh = __builtin_bit_cast(gf_f16x8, cfr[n][ks][0]), bl = __builtin_bit_cast(gf_f16x8, cfr[n][ks][1]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+      acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_hl, 0, 0, 0);
+      acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_lh, 0, 0, 0);
+    }
+    const int band = 16 * nb + i16;
+    if (band < p.M) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = f0 + 16 * rg + 4 * g + r;
+        if (f < p.F) {
+          const size_t at = ((size_t)b * p.F + f) * p.M + band;
+          float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kGfLoScale);
+          if (p.scale) {
+            const float xr = p.mag[at] + p.bias;
+            const float y = exp_sigmoid_fast(xr, kLog10, 2.0f, 1e-7f);
+            v *= kLog10 * (y - 1e-7f) * (1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-xr)));
+          }
+          p.grad_mag[at] = v;
+        }
+      }
+    }
+  }
+}
+
+bool noise_bwd_mfma_ok(int B, int F, int M, int N, int window_size) {
+  static const bool off = [] { const char* e = getenv("DDSP_EXP_NOISE_BWD"); return e && e[0] == 'p'; }();      // "plain": the two kernels of rounds 1-3
+  if (off || B <= 0 || B > 65535 || F <= 0 || N <= 0 || M != 65) return false;
+  const IrGeom g = ir_geom(M, window_size);
+  if (g.padding != 0) return false;
+  const int fs = (N + F - 1) / F;
+  return fs % 64 == 0 && fs <= 256 && (N + fs - 1) / fs == F && (long)N + 256 < (1L << 30);
+}
+
+int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const float* grad_audio, float* grad_magnitudes, int B, int F,
+                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, hipStream_t st) {
+  const GiMatrix* m = gi_matrix(M, window_size);
+  if (!m || m->KSt != 4 || m->NTb != 5) return DDSP_ERR_LAUNCH;
+  const IrGeom g = ir_geom(M, window_size);
+  NbArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mag = magnitudes; a.x = noise; a.g = grad_audio; a.grad_mag = grad_magnitudes; a.ct = m->dev_t;
+  a.N = N; a.F = F; a.M = M; a.fs = (N + F - 1) / F; a.npf = a.fs / 64;
+  a.start = (g.L - 1) / 2 - 1;
+  a.NF = a.npf <= 2 ? 32 : 16;                                   // at most 64 pieces per tile
+  a.scale = scale; a.bias = bias;
+  a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.batch_offset = batch_offset;
+  const int span = a.NF * a.fs + 128;
+  a.gz_plane = (2 * span + 16 + 15) & ~15;
+  const int P = a.NF * a.npf;
+  const int x_elems = 32 + kGfSlot * P + 2;
+  const int x_copy = (2 * x_elems + 15) & ~15;
+  a.x_o = x_copy;
+  while (((a.x_o / 4) % 32) != 16) a.x_o += 16;
+  a.x_part = a.x_o + x_copy;
+  a.x_at = 2 * a.gz_plane;
+  a.dh_at = a.x_at + (noise ? 2 : 1) * a.x_part;
+  const size_t lds = (size_t)a.dh_at + 2 * (size_t)a.NF * kNbDhStride * 2;
+  if (lds > (size_t)kGfLdsBudget) return DDSP_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((F + a.NF - 1) / a.NF), (unsigned)B);
+  const void* fn = noise ? (const void*)noise_bwd_mfma_kernel<false> : (const void*)noise_bwd_mfma_kernel<true>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGfLdsBudget);
+  ProfileScope prof(kNoiseBwdTaps, st);
+  if (noise) hipLaunchKernelGGL((noise_bwd_mfma_kernel<false>), grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((noise_bwd_mfma_kernel<true>), grid, dim3(512), lds, st, a);
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 
 }  // namespace ddsp

@@ -976,7 +976,9 @@ def test_harmonic_backward_full_size_properties(ddsp):
     (2, 40, 2560 - 17, True, False),    # ragged tail, noise regenerated on chip by the same Philox counters
     (1, 50, 50 * 192 - 5, True, False), # frame size 192
     (2, 30, 30 * 80, False, True),      # frame size 80 (not a multiple of 64), scale_fn=None
-    (3, 130, 130 * 64, True, False)])   # several blocks per row
+    (3, 130, 130 * 64, True, False),    # several blocks per row
+    (2, 45, 45 * 128 - 60, False, True),   # frame size 128 (two pieces per frame), noise supplied, no scale function
+    (1, 21, 21 * 256, True, False)])       # frame size 256: tiles of 16 frames
 def test_filtered_noise_backward_vs_analytic_oracle(ddsp, noise_kernel, batch, n_frames, n, scale, given_noise):
   rng = np.random.default_rng(n_frames)
   mags = (rng.standard_normal((batch, n_frames, 65)) + (4.0 if scale else 0.0)).astype(np.float32)
@@ -996,6 +998,11 @@ def test_filtered_noise_backward_vs_analytic_oracle(ddsp, noise_kernel, batch, n
   np.testing.assert_allclose(npy(tm.grad), ref, rtol=0, atol=1e-6 + 2e-5 * np.abs(ref).max())
   np.testing.assert_allclose(npy(audio), O.filtered_noise(mags, noise, 0, O.exp_sigmoid if scale else None,
                                                           dtype=np.float64), rtol=0, atol=2e-6 + 1e-5)
+  # the same gradient bit for bit from a second call (the noise regenerated from the same counters)
+  synth2 = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, scale_fn=ddsp.core.exp_sigmoid if scale else None, seed=11)
+  tm2 = ddsp.core.tf_float32(mags).requires_grad_(True)
+  (synth2(tm2, noise=noise if given_noise else None) * ddsp.core.tf_float32(g)).sum().backward()
+  np.testing.assert_array_equal(npy(tm2.grad), npy(tm.grad))
 
 
 def test_synth_backward_through_add(ddsp):
