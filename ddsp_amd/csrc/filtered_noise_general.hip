@@ -1024,7 +1024,7 @@ struct NbArgs {
 constexpr int kNbDhStride = 136;               // halves per frame row of the tap gradients (128 + 8)
 
 template <bool GEN>
-__global__ __launch_bounds__(512) void noise_bwd_mfma_kernel(NbArgs p) {
+__global__ __launch_bounds__(512, 6) void noise_bwd_mfma_kernel(NbArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const s_gz = smem;                                  // hi plane, lo plane: gz[m0 + n] at half n, n < NF fs + 128; then 16 bytes of zeros
   uint8_t* const s_x = smem + p.x_at;                          // E hi, O hi [, E lo, O lo]
@@ -1040,20 +1040,17 @@ __global__ __launch_bounds__(512) void noise_bwd_mfma_kernel(NbArgs p) {
   typedef uint32_t gi_u32x4 __attribute__((ext_vector_type(4)));
   const int RG = p.NF >> 4;                                     // row groups of 16 frames
   const int n_tasks = RG * 5;                                   // (row group, band tile): 65 bands = 5 tiles
-  gi_u32x4 cfr[2][4][2];
+  gi_u32x4 cfr[4][2];                                           // (one task's at a time: 32 registers, three blocks per CU)
+  auto fetch_task = [&](int task) {
+    const int nb = task / RG;
+    const gi_u32x4* src = reinterpret_cast<const gi_u32x4*>(p.ct) + (size_t)nb * 4 * 128 + lane;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int task = wave + 8 * n;
-    if (task < n_tasks) {
-      const int nb = task / RG;
-      const gi_u32x4* src = reinterpret_cast<const gi_u32x4*>(p.ct) + (size_t)nb * 4 * 128 + lane;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        cfr[n][ks][0] = src[(2 * ks + 0) * 64];
-        cfr[n][ks][1] = src[(2 * ks + 1) * 64];
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      cfr[ks][0] = src[(2 * ks + 0) * 64];
+      cfr[ks][1] = src[(2 * ks + 1) * 64];
     }
-  }
+  };
+  if (wave < n_tasks) fetch_task(wave);
 
   // ---- stage the gradient window (split) and the noise pieces -------------------------------------------------------------
   {
@@ -1154,10 +1151,9 @@ __global__ __launch_bounds__(512) void noise_bwd_mfma_kernel(NbArgs p) {
 
   // ---- dL/d magnitudes: 16 frames x 16 bands per task ----------------------------------------------------------------------------
   const float kLog10 = 2.302585092994046f;
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int task = wave + 8 * n;
-    if (task >= n_tasks) continue;                               // (wave-uniform)
+#pragma unroll 1
+  for (int task = wave; task < n_tasks; task += 8) {             // (wave-uniform)
+    if (task != wave) fetch_task(task);                          // (the second task of wavefronts 0, 1: its fragments only now)
     const int nb = task / RG, rg = task - nb * RG;
     gf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};
     const _Float16* arow = s_dh + (16 * rg + i16) * kNbDhStride + 8 * g;
@@ -1165,7 +1161,7 @@ __global__ __launch_bounds__(512) void noise_bwd_mfma_kernel(NbArgs p) {
     for (int ks = 0; ks < 4; ++ks) {
       const gf_f16x8 ah = *reinterpret_cast<const gf_f16x8*>(arow + 32 * ks);
       const gf_f16x8 al = *reinterpret_cast<const gf_f16x8*>(arow + 32 * ks + p.NF * kNbDhStride);
-      const gf_f16x8 bh = __builtin_bit_cast(gf_f16x8, cfr[n][ks][0]), bl = __builtin_bit_cast(gf_f16x8, cfr[n][ks][1]);
+      const gf_f16x8 bh = __builtin_bit_cast(gf_f16x8, cfr[ks][0]), bl = __builtin_bit_cast(gf_f16x8, cfr[ks][1]);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
       acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_hl, 0, 0, 0);
       acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_lh, 0, 0, 0);
