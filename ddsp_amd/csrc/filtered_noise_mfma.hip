@@ -324,6 +324,17 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       }
     }
     const int rrow = 16 * rg + mi;
+    // Frames longer than 64 samples: the tile's 32 staged frames of 64 share ceil-ish 2048 / fs tap rows - at 192 samples (BASELINE
+    // configs[4]) twelve, all in row group 0.  A row group none of whose rows any staged frame reads is neither fetched nor scaled
+    // nor designed (until round 4 it was: 130 MB of HBM traffic per launch against 82 algorithmic at that shape, pmc_traffic_config5.json).
+    // (the frames a tile owns for the controls output - scale_rows - lie among the rows its taps need or one past them)
+    auto group_unused = [&](int rel0, int z0, int f_first) -> bool {
+      if (FS64) return false;
+      uint32_t r_;
+      const int last_tap_row = (int)fastdiv((uint32_t)(rel0 + 64 * (kMfRows - 1)), p.fs_div, r_);
+      const int own_hi = (int)fastdiv((uint32_t)(z0 + kMfTile - 128), p.fs_div, r_) + 2;          // as in scale_rows
+      return 16 * rg > last_tap_row && 16 * rg >= own_hi - f_first;
+    };
     // the 16 bins of this lane's B-fragments (row = 16 rg + i, bins 16 g .. + 15) and bin 64 of that row, straight from
     // HBM; rows outside [0, F) are fetched from frame 0 and masked afterwards (unconditional loads)
     MfU4f rq[4];
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     auto fetch_rows = [&](int tick_of_tile) {        // the rows of the block's tile number `tick_of_tile` (clamped to its last)
       const int T = (int)blockIdx.x + min(max(tick_of_tile, 0), n_my - 1) * (int)gridDim.x;
       DDSP_MF_TILE(T, b, z0, f_first, rel0);
-      (void)rel0; (void)z0;
+      if (group_unused(rel0, z0, f_first)) return;     // (wave-uniform)
       const int rfr = f_first + rrow;
       const float* __restrict__ src = mag + ((size_t)b * p.F + ((rfr >= 0 && rfr < p.F) ? rfr : 0)) * 65;
 #pragma unroll
@@ -342,7 +353,6 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     // (false: the tile's rows lie past the end of the clip - nobody reads their taps)
     auto scale_rows = [&](int T, mf_f16x8& be_hi, mf_f16x8& be_lo, mf_f16x8& bo_hi, mf_f16x8& bo_lo, float& m_last, float& t32) -> bool {
       DDSP_MF_TILE(T, b, z0, f_first, rel0);
-      (void)rel0;
       // controls ownership: tile t writes frames [own_lo, own_hi) so that every frame is written once
       const int own_lo = (z0 == 0) ? 0 : f_first + 2;
       uint32_t own_r;
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
       const int rfr = f_first + rrow;
       const bool rvalid = rfr >= 0 && rfr < p.F;
       // rows past frame F + 1 are read by no FIR wavefront that stores anything (see `active` there): skipped whole
-      if (f_first + 16 * rg > p.F + 1) return false;
+      if (f_first + 16 * rg > p.F + 1 || group_unused(rel0, z0, f_first)) return false;
       float y[16];
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) { y[4 * c4] = rq[c4].x; y[4 * c4 + 1] = rq[c4].y; y[4 * c4 + 2] = rq[c4].z; y[4 * c4 + 3] = rq[c4].w; }
@@ -497,8 +507,8 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
             if (scale_rows(T, be_hi, be_lo, bo_hi, bo_lo, m_last, t32)) design_rows(s_taps, be_hi, be_lo, bo_hi, bo_lo, m_last, t32);
           } else if constexpr (HANDOFF) {
             DDSP_MF_TILE(T, b, z0, f_first, rel0);
-            (void)rel0; (void)z0; (void)b;
-            if (f_first + 16 * rg <= p.F + 1) {        // (the noise maker's own test: scale_rows)
+            (void)b;
+            if (f_first + 16 * rg <= p.F + 1 && !group_unused(rel0, z0, f_first)) {        // (the noise maker's own test: scale_rows)
               const MfHandoff& h = s_hand[(tick + 1) & 1];
               design_rows(s_taps, __builtin_bit_cast(mf_f16x8, h.frag[rg][0][lane]), __builtin_bit_cast(mf_f16x8, h.frag[rg][1][lane]),
                           __builtin_bit_cast(mf_f16x8, h.frag[rg][2][lane]), __builtin_bit_cast(mf_f16x8, h.frag[rg][3][lane]),
