@@ -101,10 +101,10 @@ class ProcessorGroup(dags.DAGLayer):
     When only the signal is asked for and the DAG ends Harmonic ... Add(that harmonic, another signal), the Harmonic
     node runs at the Add's position with the Add fused into its kernel (Harmonic.call_add): the same samples, one launch
     and two [batch, n_samples] streams less.  A subclass that overrides get_controls / get_signal is never short-cut
-    (it would be bypassed), and where a gradient is wanted - an input that requires grad, or a trainable module inside the
-    DAG feeding the Add or the Harmonic - call_add itself takes the two differentiable calls."""
-    plan = None if (return_outputs_dict or kwargs or type(self) is not ProcessorGroup or
-                    torch.is_grad_enabled() and _any_requires_grad(inputs)) else self._fused_add_plan()
+    (it would be bypassed).  Where a gradient is wanted - an input that requires grad, or a trainable module inside the DAG
+    feeding the Add or the Harmonic - call_add records the fused launch as one autograd node (round 4; round 3 fell back to
+    the two differentiable calls: ADVICE r3)."""
+    plan = None if (return_outputs_dict or kwargs or type(self) is not ProcessorGroup) else self._fused_add_plan()
     if plan is not None:
       return self._call_fused_add(inputs, *plan)
     controls = self.get_controls(inputs, **kwargs)

@@ -134,28 +134,45 @@ class Harmonic(processors.Processor):
   def call_add(self, amplitudes, harmonic_distribution, f0_hz, add_signal):
     """`Add()(add_signal, self(amplitudes, harmonic_distribution, f0_hz))` (processors.py:162-176) as ONE launch where
     the wavetable kernel applies (ddsp_harmonic_add_f32: one [batch, n_samples] stream written instead of three more
-    moved), the two calls otherwise.  Bit-identical to the two calls.  The fused launch is forward only: when any of its
-    tensors requires grad the two (differentiable) calls run instead.  ProcessorGroup uses it when nothing asks for the
-    intermediate signals."""
+    moved), the two calls otherwise.  Bit-identical to the two calls.  Differentiable (round 4): with a tensor that requires grad the
+    same launch is recorded as one torch.autograd node (_HarmonicAddFunction).  ProcessorGroup uses it when nothing asks for
+    the intermediate signals."""
     add_signal = core.tf_float32(add_signal)
     amps, hd, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0 = core.tf_float32(f0_hz)
-    if torch.is_grad_enabled() and any(t.requires_grad for t in (amps, hd, f0, add_signal)):
-      # a gradient is wanted (a trainable module upstream in the DAG - a Reverb's impulse response, a decoder - while the
-      # DAG's inputs are detached): the two differentiable calls, as before the Add was fused (ADVICE r3)
-      return processors.Add()(add_signal, self.call(amplitudes, harmonic_distribution, f0_hz))
+    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (amps, hd, f0, add_signal))
     b, f, k = core._check_harmonic_shapes(amps, hd, f0)
     n = int(self.n_samples)
     if (tuple(add_signal.shape) == (b, n) and self.kernel == 'auto' and
         core._on_closed_form_kernels(self.amp_resample_method, f, n)):
-      audio = torch.empty((b, n), dtype=torch.float32, device=amps.device)
-      rc = _lib.load().ddsp_harmonic_add_f32(amps.data_ptr(), hd.data_ptr(), f0.data_ptr(), add_signal.data_ptr(),
-                                             audio.data_ptr(), b, f, k, n, int(self.sample_rate), self._flags(fuse),
-                                             core._stream())
-      if rc != -3:                   # DDSP_ERR_UNSUPPORTED: this shape / these flags run on the other kernels
-        _lib.check(rc, 'ddsp_harmonic_add_f32')
-        return audio
+      if wants_grad:
+        # the same launch as a torch.autograd node: the Add's gradient is the identity on both operands, the Harmonic's is
+        # Harmonic's (round 4: training DAGs keep the fused launch instead of falling back to two calls and an add kernel)
+        try:
+          return _HarmonicAddFunction.apply(amps, hd, f0, add_signal, self, fuse)
+        except _FusedAddUnsupported:
+          pass
+      else:
+        audio = self._forward_add(amps, hd, f0, add_signal, fuse)
+        if audio is not None:
+          return audio
+    if wants_grad:
+      # (a shape or flag set the fused kernel does not take, with a gradient wanted: the two differentiable calls)
+      return processors.Add()(add_signal, self.call(amplitudes, harmonic_distribution, f0_hz))
     return processors._add(add_signal, self.call(amplitudes, harmonic_distribution, f0_hz))
+
+  def _forward_add(self, amps, hd, f0, add_signal, fuse):
+    """ddsp_harmonic_add_f32, or None where the wavetable kernel does not take the shape / flags."""
+    b, f, k = hd.shape
+    n = int(self.n_samples)
+    audio = torch.empty((b, n), dtype=torch.float32, device=amps.device)
+    rc = _lib.load().ddsp_harmonic_add_f32(amps.data_ptr(), hd.data_ptr(), f0.data_ptr(), add_signal.data_ptr(),
+                                           audio.data_ptr(), b, f, k, n, int(self.sample_rate), self._flags(fuse),
+                                           core._stream())
+    if rc == -3:                     # DDSP_ERR_UNSUPPORTED: this shape / these flags run on the other kernels
+      return None
+    _lib.check(rc, 'ddsp_harmonic_add_f32')
+    return audio
 
   def _flags(self, fuse):
     flags = core._harmonic_flags(fuse, self.normalize_below_nyquist, self.amp_resample_method,
@@ -226,6 +243,33 @@ class Harmonic(processors.Processor):
         _lib.HARM_AMP_LINEAR if self.amp_resample_method == 'linear' else 0, core._stream())
     _lib.check(rc, 'ddsp_harmonic_f0_grad_f32')
     return grad_f0
+
+
+class _FusedAddUnsupported(Exception):
+  """ddsp_harmonic_add_f32 does not take this shape / these flags (Harmonic.call_add falls back to the two calls)."""
+
+
+class _HarmonicAddFunction(torch.autograd.Function):
+  """torch.autograd node of Harmonic.call_add: `add_signal + Harmonic(amplitudes, harmonic_distribution, f0_hz)` in one launch."""
+
+  @staticmethod
+  def forward(ctx, amplitudes, harmonic_distribution, f0_hz, add_signal, synth, fuse):
+    audio = synth._forward_add(amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach(), add_signal.detach(), fuse)
+    if audio is None:
+      raise _FusedAddUnsupported()
+    ctx.save_for_backward(amplitudes, harmonic_distribution, f0_hz)
+    ctx.synth, ctx.fuse = synth, fuse
+    return audio
+
+  @staticmethod
+  def backward(ctx, grad_audio):
+    amplitudes, harmonic_distribution, f0_hz = (t.detach() for t in ctx.saved_tensors)
+    grad_amp = grad_hd = grad_f0 = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+      grad_amp, grad_hd = ctx.synth._backward(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
+    if ctx.needs_input_grad[2]:
+      grad_f0 = ctx.synth._backward_f0(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
+    return grad_amp, grad_hd, grad_f0, (grad_audio if ctx.needs_input_grad[3] else None), None, None
 
 
 class _HarmonicFunction(torch.autograd.Function):

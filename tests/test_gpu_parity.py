@@ -1511,6 +1511,38 @@ def test_processor_group_fused_add_is_bit_identical(ddsp):
                                 npy(h96(x['amplitudes'], x['harmonic_distribution'], x['f0_hz'])) + z96)
 
 
+def test_processor_group_fused_add_is_differentiable(ddsp):
+  """Round 4: with inputs that require grad the ae.gin group still runs Harmonic + Add as ONE launch (one autograd node,
+  _HarmonicAddFunction): same samples and the same gradients, bit for bit, as the three processors run one by one."""
+  n_frames, n = 60, 3840
+  x = canonical_inputs(2, seed=29, n_frames=n_frames)
+
+  def build():
+    harmonic = ddsp.synths.Harmonic(n_samples=n, name='harmonic')
+    noise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, name='filtered_noise', seed=5)
+    add = ddsp.processors.Add(name='add')
+    dag = [(harmonic, ['amps', 'harmonic_distribution', 'f0_hz']), (noise, ['magnitudes']),
+           (add, ['harmonic/signal', 'filtered_noise/signal'])]
+    return ddsp.processors.ProcessorGroup(dag=dag, name='processor_group')
+
+  def features():
+    t = ddsp.core.tf_float32
+    return {'amps': t(x['amplitudes']).requires_grad_(True), 'harmonic_distribution': t(x['harmonic_distribution']).requires_grad_(True),
+            'f0_hz': t(x['f0_hz']), 'magnitudes': t(x['magnitudes']).requires_grad_(True)}
+  w = ddsp.core.tf_float32(np.random.default_rng(30).standard_normal((2, n)))
+  f1, f2 = features(), features()
+  g1, g2 = build(), build()
+  out = g1(f1)                                        # the fused plan
+  assert out.requires_grad and type(out.grad_fn).__name__.startswith('_HarmonicAddFunction')
+  ref = g2(f2, return_outputs_dict=True)['signal']    # every processor on its own
+  np.testing.assert_array_equal(npy(out), npy(ref))
+  out.backward(w)
+  ref.backward(w)
+  for key in ('amps', 'harmonic_distribution', 'magnitudes'):
+    assert f1[key].grad is not None
+    np.testing.assert_array_equal(npy(f1[key].grad), npy(f2[key].grad), err_msg=key)
+
+
 def test_processor_group_fused_add_with_a_trainable_module_inside(ddsp):
   """ADVICE r3 (processors.py:98): the gradient may come from a module INSIDE the DAG while the DAG's inputs are detached - a
   trainable Reverb ahead of the Add (the Add then gets a signal that requires grad), or a re-bound / subclassed group.  The

@@ -24,9 +24,12 @@ def step(with_noise):
   # every op on the path is this library's (processors.Add, not torch's +; the upstream gradient handed to backward(),
   # not made by torch's mul / sum): what is timed beside the kernels is the autograd node's host code, nothing of torch's
   amps.grad = hd.grad = mags.grad = None
-  y = harm(amps, hd, f0)
   if with_noise:
-    y = add(y, noise(mags))
+    # Harmonic + Add as one launch and one autograd node (what ProcessorGroup does for the ae.gin DAG since round 4;
+    # DDSP_BENCH_UNFUSED_ADD=1: the three processors one by one, as rounds 1-3 timed it)
+    y = add(harm(amps, hd, f0), noise(mags)) if os.environ.get('DDSP_BENCH_UNFUSED_ADD') else harm.call_add(amps, hd, f0, noise(mags))
+  else:
+    y = harm(amps, hd, f0)
   if with_noise == 'loss':
     spec(g, y).backward()           # the whole differentiable path of ae.gin, every kernel native
   else:
