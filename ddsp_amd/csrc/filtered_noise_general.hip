@@ -3,7 +3,10 @@
 // size, any frame size - the shapes the reference's own tests use (100 bands: synths_test.py:43-50; 256: a 510-tap
 // filter; frames of 100 samples).  Rounds 1-3 ran these on two plain kernels (filtered_noise.hip: noise_ir_kernel, one
 // LDS cosine per multiply; tv_fir_kernel, two LDS reads per multiply): 22 x and 106 x the canonical shape's time at
-// batch 32 (profiles/r05c_generic_shapes_b32.txt).  Two kernels here, the taps travelling through HBM between them:
+// batch 32 (profiles/r05c_generic_shapes_b32.txt).  Here: two kernels with the taps travelling through HBM between them (any
+// shape up to 288 bands / ~1000 taps); for up to 128 bands and 256 taps the second of them designing its tiles' taps itself (one
+// launch: 100 bands 32.7 us at batch 32); and, further down, the backward pass of the canonical filter on the same algebra
+// (noise_bwd_mfma_kernel).
 //
 //   noise_ir_gemm_kernel   the IR design as ONE matrix product with a constant matrix.  frequency_impulse_response
 //       (core.py:1534-1565) is a real inverse DFT of the magnitudes, apply_window_to_impulse_response (:1477-1531)

@@ -12,7 +12,8 @@
 // product with the transposed constant sine matrix, which belongs on the matrix cores (the forward's fragments, transposed).
 // Same window, same 1 / psi_hat, same accuracy as the forward (<= 6.5e-6 sum |c| per harmonic).
 //
-// One block = 8 wavefronts = 8 consecutive frames (of the flattened [B F] rows).
+// One block = 8 wavefronts; a GROUP = 8 consecutive frames (of the flattened [B F] rows); a block walks groups blockIdx.x,
+// blockIdx.x + gridDim.x, ..
 //   1. Spreading, wavefront w = frame w, lanes = samples of a tile of 64.  A scatter in which neighbouring lanes hit overlapping
 //      entries - round 2 tried it with LDS float atomics and lost (165 us; round 4 measured why: a ds_add_f32 holds the LDS
 //      pipeline ~100 clocks).  Here no atomics and no conflicts: tap number t of lane n goes to entry floor(pos_n) + t - W/2 + 1;
@@ -24,7 +25,8 @@
 //   2. Folding: the sine matrix's symmetries (s_k(T-1-i) = -s_k(i), s_k(T/2-1-i) = +-s_k(i) for odd / even k) bring G onto the
 //      quarter range: Go / Ge for odd / even harmonics, split into fp16 hi / lo B-fragment planes, 16 columns = 8 frames x {P, Q}.
 //   3. Wavefront w = (parity w & 1, harmonic tile w >> 1): 4 k-steps x 3 v_mfma_f32_16x16x32_f16 against its constant
-//      A-fragments (32 registers, loaded once), results straight to the P / Q workspace.
+//      A-fragments (32 registers, loaded once per block: blocks are persistent), the results through LDS to whole rows of
+//      the P / Q workspace (or, DDSP_EXP_HARM_BWD=fused, into the chain rule of harmonic_bwd_chain.h without leaving LDS).
 // Harmonics that cross Nyquist inside a frame ([kA, kN): the audio-rate mask of oscillator_bank, core.py:942-944) get the masked
 // samples' contribution subtracted again, evaluated directly (one sine per sample and crossing harmonic, a wave reduction);
 // harmonics >= kN are zero.  Frames the scheme does not cover (f0 < sr / 512: positions closer than one entry; f0 <= 0 or NaN;
