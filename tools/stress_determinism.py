@@ -180,6 +180,42 @@ def main(argv=None):
     total += stress(name + '_supplied', lambda: fn(mags, noise=z), lambda: harm(amps, hd, f0), 64, subs_n)
     total += stress(name + '_generated', gen, lambda: harm(amps, hd, f0), 64, None)
 
+  # round 4's other kernels: the general FilteredNoise path (100 bands: one launch, taps designed per tile; 256 bands: two
+  # launches), and the two backward passes (gradients of a fixed upstream gradient, bits compared like the audio)
+  for name, b, m in (('noise_general_m100_b32', 32, 100), ('noise_general_m256_b8', 8, 256)):
+    if want and name not in want:
+      continue
+    amps, hd, f0, mags = controls(b, 1000, 100, 70.0, 1.0, 60 + m, m=m)
+    z = T(np.random.default_rng(61).uniform(-1, 1, (b, 64000)))
+    fn = ddsp.synths.FilteredNoise(window_size=0, seed=9)
+    harm = ddsp.synths.Harmonic()
+
+    def gen(fn=fn, mags=mags):
+      fn._calls = 0
+      return fn(mags)
+
+    def subs_g(it, b=b, fn=fn, mags=mags, z=z):
+      r = int(rng.integers(0, b))
+      return [('row %d alone, supplied noise' % r, slice(r, r + 1), lambda: fn(mags[r:r + 1], noise=z[r:r + 1]))]
+    total += stress(name + '_supplied', lambda fn=fn, mags=mags, z=z: fn(mags, noise=z), lambda: harm(amps, hd, f0), 64, subs_g)
+    total += stress(name + '_generated', gen, lambda: harm(amps, hd, f0), 64, None)
+
+  if not want or 'backward_b32' in want:
+    b = 32
+    amps, hd, f0, mags = controls(b, 1000, 100, 200.0, 1.0, 71)
+    g = T(np.random.default_rng(72).standard_normal((b, 64000)))
+    harm = ddsp.synths.Harmonic()
+    noise = ddsp.synths.FilteredNoise(window_size=0, seed=4)
+
+    def grads():
+      a_ = amps.detach().requires_grad_(True)
+      h_ = hd.detach().requires_grad_(True)
+      m_ = mags.detach().requires_grad_(True)
+      noise._calls = 0
+      (harm.call_add(a_, h_, f0, noise(m_))).backward(g)
+      return torch.cat([a_.grad.reshape(b, -1), h_.grad.reshape(b, -1), m_.grad.reshape(b, -1)], dim=1)
+    total += stress('backward_b32', grads, None, 100, None)
+
   # Harmonic with processors.Add fused in (ddsp_harmonic_add_f32) against the two calls
   if not want or 'fused_add_b128' in want:
     b = 128
