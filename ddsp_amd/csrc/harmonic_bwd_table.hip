@@ -89,6 +89,12 @@ template <> struct BtPoly<8> {
   static constexpr float o(int p, int d) { return kWtO8[p * (DO + 1) + d]; }
 };
 
+template <> struct BtPoly<10> {
+  static constexpr int DE = kWtDegE10, DO = kWtDegO10;
+  static constexpr float e(int p, int d) { return kWtE10[p * (DE + 1) + d]; }
+  static constexpr float o(int p, int d) { return kWtO10[p * (DO + 1) + d]; }
+};
+
 // entry i of a frame's G at slot i ^ (block index of 32): a permutation inside every block of 32 entries
 __device__ __forceinline__ int bt_swz(int i) { return i ^ ((i >> 5) & 15); }
 
@@ -100,7 +106,12 @@ __device__ __forceinline__ void bt_split(float v, _Float16& hi, _Float16& lo) {
 // CHAIN: groups advance by SEVEN frames - wavefront 0's frame is the one before the group's (its Q is what the group's first
 // frame adds to its P), computed here once more rather than fetched from another block
 template <int W, bool CHAIN>
-__global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_table_kernel(BtArgs p) {
+__global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_table_kernel(BtArgs p) {
+  // 129 .. 200 harmonics (W = 10: BASELINE configs[4]'s shapes): SIXTEEN wavefronts - eight of them spread a frame each as below,
+  // fourteen take a (parity, harmonic tile) of the product: seven tiles of 16 per parity, each with its 32 registers of fragments
+  constexpr int kMt = W == 10 ? 7 : 4, kMtAlloc = W == 10 ? 8 : 4;
+  constexpr int kNch = W == 10 ? 4 : 2;                         // harmonics per lane where lanes = harmonics
+  constexpr int kOutStride = W == 10 ? 212 : 132;
   constexpr int kStep = CHAIN ? kBtFrames - 1 : kBtFrames, kBack = CHAIN ? 1 : 0;
   int dbg_iter = 0;
 #define DDSP_BT_STAMP(pt) do { if (p.dbg != nullptr && blockIdx.x == 0 && lane == 0 && dbg_iter < 16) p.dbg[(dbg_iter * 8 + wave) * 8 + (pt)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -108,25 +119,27 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   __shared__ __attribute__((aligned(16))) _Float16 s_b[2][2][16][kBtCol];         // [hi / lo][parity][column][n]: 17 KB
   __shared__ float s_corr[kBtFrames][2][kBtMaxCross];
   __shared__ int s_k[kBtFrames][4];                                               // kA, kN, direct
-  __shared__ float s_out[16][132];                                                // step 3's results: [column][harmonic]
+  __shared__ float s_out[16][kOutStride];                                                // step 3's results: [column][harmonic]
   using C = BtPoly<W>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // this wavefront's share of the constant factor for step 3: fetched ONCE - blocks are persistent (a block per group of
   // eight frames fetched its 64 KB from L2 every time: 256 MB per launch at batch 32, and with the 4-byte scattered stores of
   // the first version 38 of the kernel's 45 us - r05t)
   const int par = wave & 1, mt = wave >> 1;
+  const bool has_task = mt < kMt;                               // (wave-uniform)
+  const bool has_frame = wave < kBtFrames;
   bt_u32x4 afr[4][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int part = 0; part < 2; ++part)
-      afr[ks][part] = p.frags[((((size_t)par * 4 + mt) * 4 + ks) * 2 + part) * 64 + lane];
+      afr[ks][part] = p.frags[((((size_t)par * kMtAlloc + (has_task ? mt : 0)) * 4 + ks) * 2 + part) * 64 + lane];
 
   // the first tile's gradient samples of a group are requested a group ahead (a group is a chain of dependent steps with two
   // block barriers in it; the HBM latency at its head was a fifth of it)
   auto first_tile = [&](long r0) -> float {
     const long rw = r0 + wave - kBack;
-    if (rw < 0 || rw >= p.rows || lane >= p.hop) return 0.0f;
+    if (!has_frame || rw < 0 || rw >= p.rows || lane >= p.hop) return 0.0f;
     return p.g[(size_t)rw * p.hop + lane];           // row (b, j): sample b N + j hop + lane = row hop + lane
   };
   // ... and so are the frame's two f0 values and its phase: everything a group's first instruction depends on
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
   auto frame_head = [&](long r0) -> Head {
     const long rw = r0 + wave - kBack;
     Head h{0.0f, 0.0f, 0.0};
-    if (rw >= 0 && rw < p.rows) {
+    if (has_frame && rw >= 0 && rw < p.rows) {
       const long jj = rw % p.F;
       h.fj = p.f0[rw];
       h.fj1 = p.f0[jj + 1 < p.F ? rw + 1 : rw];
@@ -147,16 +160,18 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
 #pragma unroll 1
   for (long row0 = (long)blockIdx.x * kStep; row0 < p.rows; row0 += (long)gridDim.x * kStep) {
   const long row = row0 + wave - kBack;
-  const bool row_ok = row >= 0 && row < p.rows;
+  const bool row_ok = has_frame && row >= 0 && row < p.rows;
   const float g_first = g_next;
   const Head head = h_next;
   g_next = first_tile(row0 + (long)gridDim.x * kStep);
   h_next = frame_head(row0 + (long)gridDim.x * kStep);
-  float dP0 = 0.0f, dQ0 = 0.0f, dP1 = 0.0f, dQ1 = 0.0f;         // the plain sum's results (CHAIN: into LDS behind the barrier)
+  float dP[kNch], dQ[kNch];                                      // the plain sum's results (CHAIN: into LDS behind the barrier)
+#pragma unroll
+  for (int c = 0; c < kNch; ++c) { dP[c] = 0.0f; dQ[c] = 0.0f; }
   DDSP_BT_STAMP(0);
 
   // ---- 1. spreading -----------------------------------------------------------------------------------------------------------
-  {
+  if (has_frame) {
     float4* z4 = reinterpret_cast<float4*>(&s_g[wave][0]);
     for (int k = lane; k < kBtT / 2; k += 64) z4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     const double wj = (double)fj * inv_sr, dw = ((double)fj1 - (double)fj) * inv_sr * inv_2hop;
     const double th0 = head.th0;
     const float* __restrict__ g = p.g + (size_t)b * p.N + (size_t)j * p.hop;
-    float2* const G = &s_g[wave][0];
+    float2* const G = &s_g[has_frame ? wave : 0][0];
     // per-sample values of a tile: lanes = samples
     auto sample = [&](int t0, double& cyc, float& lerp, float& c_cur, float& c_next, bool& live) {
       const int r = t0 + lane;
@@ -263,10 +278,13 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
     } else {
       // the plain sum (harm_bwd_pq_kernel's), lanes = harmonics lane and lane + 64; a tile's per-sample values come from the
       // lanes that hold them.  (A loop of its own: its accumulators then share registers with the spreading's.)
-      float P0 = 0.0f, Q0 = 0.0f, P1 = 0.0f, Q1 = 0.0f;
-      const int k0 = lane, k1 = lane + 64;
-      const float kf0 = (float)(k0 + 1), kf1 = (float)(k1 + 1);
-      const float top0 = fj * kf0, bot0 = fj1 * kf0, top1 = fj * kf1, bot1 = fj1 * kf1;
+      float Pd[kNch], Qd[kNch], kf[kNch], top[kNch], bot[kNch];
+#pragma unroll
+      for (int c = 0; c < kNch; ++c) {
+        Pd[c] = 0.0f; Qd[c] = 0.0f;
+        kf[c] = (float)(lane + 64 * c + 1);
+        top[c] = fj * kf[c]; bot[c] = fj1 * kf[c];
+      }
 #pragma unroll 1
       for (int t0 = 0; t0 < p.hop; t0 += 64) {
         double cyc;
@@ -281,30 +299,33 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
           const float cn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c_next), s_));
           const float ths = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, th), s_));
           const float lp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lerp), s_));
-          const float fk0 = rn_add(top0, rn_mul(rn_sub(bot0, top0), lp));
-          const float fk1 = rn_add(top1, rn_mul(rn_sub(bot1, top1), lp));
-          const float s0 = (fk0 >= p.nyquist || k0 >= kN) ? 0.0f : sin_rev(ths * kf0);
-          const float s1 = (fk1 >= p.nyquist || k1 >= kN) ? 0.0f : sin_rev(ths * kf1);
-          P0 = fmaf(cc, s0, P0); Q0 = fmaf(cn, s0, Q0);
-          P1 = fmaf(cc, s1, P1); Q1 = fmaf(cn, s1, Q1);
+#pragma unroll
+          for (int c = 0; c < kNch; ++c) {
+            const float fk = rn_add(top[c], rn_mul(rn_sub(bot[c], top[c]), lp));
+            const float sv = (fk >= p.nyquist || lane + 64 * c >= kN) ? 0.0f : sin_rev(ths * kf[c]);
+            Pd[c] = fmaf(cc, sv, Pd[c]);
+            Qd[c] = fmaf(cn, sv, Qd[c]);
+          }
         }
       }
       if constexpr (CHAIN) {
-        dP0 = P0; dQ0 = Q0; dP1 = P1; dQ1 = Q1;
+#pragma unroll
+        for (int c = 0; c < kNch; ++c) { dP[c] = Pd[c]; dQ[c] = Qd[c]; }
       } else {
         const size_t at = (size_t)row * p.K;
-        if (k0 < p.K) { p.pq[at + k0] = P0; p.pq[p.q_offset + at + k0] = Q0; }
-        if (k1 < p.K) { p.pq[at + k1] = P1; p.pq[p.q_offset + at + k1] = Q1; }
+#pragma unroll
+        for (int c = 0; c < kNch; ++c)
+          if (lane + 64 * c < p.K) { p.pq[at + lane + 64 * c] = Pd[c]; p.pq[p.q_offset + at + lane + 64 * c] = Qd[c]; }
       }
     }
   }
-  if (lane == 0) { s_k[wave][0] = kA; s_k[wave][1] = kN; s_k[wave][2] = direct; }
+  if (has_frame && lane == 0) { s_k[wave][0] = kA; s_k[wave][1] = kN; s_k[wave][2] = direct; }
   __builtin_amdgcn_wave_barrier();
   DDSP_BT_STAMP(1);
 
   // ---- 2. folding onto the quarter range, split, B-fragment planes: columns 2 w (P) and 2 w + 1 (Q) -----------------------------
 #ifndef DDSP_BT_NO_FOLD
-  {
+  if (has_frame) {
     const float2* G = &s_g[wave][0];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -332,7 +353,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
 #ifdef DDSP_BT_NO_P3
   if (p.K == 12345)
 #endif
-  {
+  if (has_task) {
     const int i16 = lane & 15, g4 = lane >> 4;
     bt_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_hl = {0.f, 0.f, 0.f, 0.f}, acc_lh = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -355,15 +376,15 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
         float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kBtLoScale);
         if (k0 >= fkN) v = 0.0f;
         else if (k0 >= fkA) v -= s_corr[fr][q][k0 - fkA];
-        s_out[i16][k0] = v;
+        if (k0 < kOutStride) s_out[i16][k0] = v;
       }
     }
   }
   DDSP_BT_STAMP(4);
   if constexpr (CHAIN) {
     if (row_ok && s_k[wave][2]) {          // (s_out's readers of the previous group are behind the barrier above)
-      s_out[2 * wave][lane] = dP0; s_out[2 * wave + 1][lane] = dQ0;
-      s_out[2 * wave][lane + 64] = dP1; s_out[2 * wave + 1][lane + 64] = dQ1;
+#pragma unroll
+      for (int c = 0; c < kNch; ++c) { s_out[2 * wave][lane + 64 * c] = dP[c]; s_out[2 * wave + 1][lane + 64 * c] = dQ[c]; }
     }
   }
   __syncthreads();
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
       const float* P = s_out[2 * wave];
       const float* Qp = s_out[2 * wave - 1];
       const float* Qo = s_out[2 * wave + 1];
-      harm_chain_row<2>(lane, row, j, p.amplitudes, p.hd, p.f0, p.grad_amp, p.grad_hd, p.chain, [&](int k) {
+      harm_chain_row<kNch>(lane, row, j, p.amplitudes, p.hd, p.f0, p.grad_amp, p.grad_hd, p.chain, [&](int k) {
         float gsum = P[k];
         if (j > 0) gsum += Qp[k];
         if (j == p.F - 1) gsum += Qo[k];
@@ -392,8 +413,9 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float* dst = p.pq + (q ? p.q_offset : 0) + (size_t)row * p.K;
-      if (lane < p.K) dst[lane] = s_out[2 * wave + q][lane];
-      if (lane + 64 < p.K) dst[lane + 64] = s_out[2 * wave + q][lane + 64];
+#pragma unroll
+      for (int c = 0; c < kNch; ++c)
+        if (lane + 64 * c < p.K) dst[lane + 64 * c] = s_out[2 * wave + q][lane + 64 * c];
     }
   }
   DDSP_BT_STAMP(6);
@@ -407,17 +429,19 @@ __global__ __launch_bounds__(64 * kBtFrames, DDSP_BT_MIN_WAVES) void harm_bwd_ta
 // [parity][harmonic tile of 16][k-step of 32 points][hi / lo][lane (i = k' & 15, g)][8 halves: n = 32 ks + 8 g + e]
 static const bt_u32x4* bt_fragments(int W) {
   static std::mutex mu;
-  static const bt_u32x4* cache[2][16] = {};
+  static const bt_u32x4* cache[3][16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  const int wi = W == 6 ? 0 : 1;
+  const int wi = W == 6 ? 0 : (W == 8 ? 1 : 2);
+  const int MT = W == 10 ? 8 : 4;                                // harmonic tiles of 16 per parity
   std::lock_guard<std::mutex> lock(mu);
   if (cache[wi][dev]) return cache[wi][dev];
-  const float* invpsi = W == 6 ? kWtInvPsi6_T512 : kWtInvPsi8_T512;
-  const int n_invpsi = W == 6 ? (int)(sizeof(kWtInvPsi6_T512) / sizeof(float)) : (int)(sizeof(kWtInvPsi8_T512) / sizeof(float));
-  std::vector<uint32_t> f((size_t)2 * 4 * 4 * 2 * 64 * 4, 0u);
+  const float* invpsi = W == 6 ? kWtInvPsi6_T512 : (W == 8 ? kWtInvPsi8_T512 : kWtInvPsi10_T512);
+  const int n_invpsi = W == 6 ? (int)(sizeof(kWtInvPsi6_T512) / sizeof(float))
+                     : (W == 8 ? (int)(sizeof(kWtInvPsi8_T512) / sizeof(float)) : (int)(sizeof(kWtInvPsi10_T512) / sizeof(float)));
+  std::vector<uint32_t> f((size_t)2 * MT * 4 * 2 * 64 * 4, 0u);
   for (int pa = 0; pa < 2; ++pa)
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
       for (int ks = 0; ks < 4; ++ks)
         for (int lane = 0; lane < 64; ++lane)
           for (int d = 0; d < 4; ++d) {
@@ -429,7 +453,7 @@ static const bt_u32x4* bt_fragments(int W) {
               hi2 |= (uint32_t)hb << (16 * h);
               lo2 |= (uint32_t)lb << (16 * h);
             }
-            const size_t at = ((((size_t)pa * 4 + mt) * 4 + ks) * 2) * 64 + lane;
+            const size_t at = ((((size_t)pa * MT + mt) * 4 + ks) * 2) * 64 + lane;
             f[(at + 0) * 4 + d] = hi2;
             f[(at + 64) * 4 + d] = lo2;
           }
@@ -446,7 +470,7 @@ static const bt_u32x4* bt_fragments(int W) {
 bool harm_bwd_table_ok(int F, int K, int N) {
   static const bool off = [] { const char* e = getenv("DDSP_EXP_HARM_BWD"); return e && e[0] == 'p'; }();   // "plain": the sums
   const int hop = F > 0 ? N / F : 0;
-  return !off && K >= 1 && K <= 128 && hop >= 1 && (long)F * hop == N && hop <= 4096;
+  return !off && K >= 1 && K <= 200 && hop >= 1 && (long)F * hop == N && hop <= 4096;
 }
 
 int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float* grad_audio, float* pq, size_t q_offset, int B,
@@ -457,7 +481,7 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
   // at batch 128 (profiles/r05_harm_bwd_table.txt).  DDSP_EXP_HARM_BWD=fused runs it.
   static const bool fused = [] { const char* e = getenv("DDSP_EXP_HARM_BWD"); return e && e[0] == 'f'; }();
   const bool chain = amplitudes != nullptr && fused;
-  const int W = K <= 100 ? 6 : 8;
+  const int W = K <= 100 ? 6 : (K <= 128 ? 8 : 10);
   const bt_u32x4* frags = bt_fragments(W);
   if (!frags) return DDSP_ERR_LAUNCH;
   BtArgs a;
@@ -481,10 +505,12 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
   const dim3 grid((unsigned)std::min<long>(groups, 2L * n_cu));       // persistent: two blocks per CU (59 KB of LDS, 128 registers)
   if (chain) {
     if (W == 6) hipLaunchKernelGGL((harm_bwd_table_kernel<6, true>), grid, dim3(64 * kBtFrames), 0, st, a);
-    else hipLaunchKernelGGL((harm_bwd_table_kernel<8, true>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else if (W == 8) hipLaunchKernelGGL((harm_bwd_table_kernel<8, true>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else hipLaunchKernelGGL((harm_bwd_table_kernel<10, true>), dim3(std::min<unsigned>(grid.x, (unsigned)n_cu)), dim3(1024), 0, st, a);
   } else {
     if (W == 6) hipLaunchKernelGGL((harm_bwd_table_kernel<6, false>), grid, dim3(64 * kBtFrames), 0, st, a);
-    else hipLaunchKernelGGL((harm_bwd_table_kernel<8, false>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else if (W == 8) hipLaunchKernelGGL((harm_bwd_table_kernel<8, false>), grid, dim3(64 * kBtFrames), 0, st, a);
+    else hipLaunchKernelGGL((harm_bwd_table_kernel<10, false>), dim3(std::min<unsigned>(grid.x, (unsigned)n_cu)), dim3(1024), 0, st, a);   // (one block of sixteen wavefronts per CU)
   }
   return hipGetLastError() == hipSuccess ? (chain ? 1 : DDSP_OK) : DDSP_ERR_LAUNCH;       // 1: the chain rule is done too
 }

@@ -909,6 +909,8 @@ def test_harmonic_backward_vs_analytic_oracle(ddsp, batch, n_frames, k, hop, sr,
     (2, 24, 60, 192, 48000, (100.0, 130.0)),        # three tiles per frame
     (2, 30, 100, 100, 16000, (20.0, 40.0)),         # frames of 100 samples; f0 below sr / 512 in most frames: the plain sum inside the kernel
     (1, 20, 37, 50, 16000, (0.0, 300.0)),           # f0 = 0 and a jump across many harmonics: more than eight crossing harmonics
+    (2, 20, 200, 192, 48000, (100.0, 130.0)),       # 129 .. 200 harmonics (BASELINE configs[4]'s shape): ten taps, sixteen wavefronts
+    (2, 30, 160, 64, 16000, (45.0, 60.0)),          # ... on frames of 64
 ])
 def test_harmonic_backward_on_the_wavetable_adjoint(ddsp, batch, n_frames, k, hop, sr, f0s):
   """harm_bwd_table_kernel (the adjoint of the wavetable synthesis: spreading + one matrix product) against the fp64 analytic
