@@ -33,6 +33,15 @@ The JSON line also carries
                      fractions of the HBM roofline.  (Rounds 1-2 had the two shapes the other way round.)
   configs_4        : likewise BASELINE.json configs[4] per GPU (48 kHz, 200 harmonics, 10 s clips, batch 32): the Harmonic
                      kernel's instances for 129 .. 200 harmonics.
+  configs_2        : BASELINE.json configs[2] - the synths' DAG (FilteredNoise, Harmonic with processors.Add fused in) followed by
+                     losses.SpectralLoss (six STFT scales 2048 .. 64, mag + logmag: gin/models/ae.gin:36-41), batch 128: one stream,
+                     regions like configs_4's; per-kernel breakdown, algorithmic bytes, whole-step fraction; the loss's value +
+                     gradient w.r.t. the audio (what a training step runs) beside the forward value.
+  configs_3        : BASELINE.json configs[3] per GPU - the same DAG followed by effects.Reverb with the ONE trainable 48 000-tap
+                     impulse response of gin/models/solo_instrument.gin:26-40, batch 128 (1024 over 8 GPUs); an impulse response
+                     per clip beside it.
+  fnoise_full_resolution : the headline step with FilteredNoise(noise_bits=23) - generated noise of 2^23 levels, as the reference's
+                     tf.random.uniform has, carried as fp16 hi / lo pairs - beside the headline's 2048-level noise.
   cpu_baseline     : the numpy fp32 oracle ("port" of the TF op chain; TF itself cannot run
                      here) timed on this host's cores (concurrent worker processes) on a bounded
                      sample of the same workload.
@@ -99,6 +108,11 @@ def parse_args(argv=None):
                        'the f0 = 200 Hz regime of SURVEY.md 8d)')
   ap.add_argument('--no-second-shape', '--no-north-star', dest='no_second_shape', action='store_true',
                   help='skip the second block (configs[1], batch 32 per GPU)')
+  ap.add_argument('--no-other-configs', action='store_true',
+                  help='skip the configs_2 (SpectralLoss), configs_3 (Reverb) and fnoise_full_resolution blocks')
+  ap.add_argument('--noise-bits', type=int, default=11, choices=[11, 23],
+                  help="FilteredNoise(noise_bits=...) of the headline step (11: 2048 levels, this library's default; 23: the "
+                       "2^23 levels of tf.random.uniform - reported as fnoise_full_resolution in the default run)")
   ap.add_argument('--second-batch', '--north-star-batch', dest='second_batch', type=int, default=32,
                   help='clips per GPU of the second block (32 = BASELINE configs[1], reported as `configs_1`)')
   ap.add_argument('--harm-kernel', default='auto', help="Harmonic.kernel ('auto', 'direct', ...)")
@@ -162,6 +176,9 @@ def cpu_baseline(a):
     elif r['value'] < 0.7 * best['value']:
       break                       # past the memory-bandwidth knee: larger counts only get slower (and take longer)
   best['worker_counts_tried'] = tried
+  # BASELINE configs[0] - "synths.Harmonic on reference TF CPU: batch=1, 16kHz, 1000 frames, 60 harmonics" - is this leg alone:
+  # one process, Harmonic only, 60 harmonics (gin/models/solo_instrument.gin:18-20)
+  best['configs_0'] = leg.measure_config0()
   return best
 
 
@@ -260,8 +277,10 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
       'config': {
           'workload': '%s: Harmonic+FilteredNoise, batch=%d per GPU, %d samples '
                       '@ %d Hz, %d frames, %d harmonics (f0=%g+N(0,1) Hz), %d noise bands, raw '
-                      'controls in (get_controls fused), noise generated on chip' %
-                      (shape_name(B), B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands),
+                      'controls in (get_controls fused), noise generated on chip (%s)' %
+                      (shape_name(B), B, a.n_samples, a.sample_rate, a.n_frames, a.n_harmonics, a.f0, a.n_bands,
+                       '2048 levels: FilteredNoise(noise_bits=11), the default' if a.noise_bits == 11
+                       else '2^23 levels: FilteredNoise(noise_bits=23)'),
           'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d, '
           'no collective' % world,
           'streams': 'Harmonic and FilteredNoise on two free-running HIP streams' if overlap
@@ -485,7 +504,7 @@ def main(argv=None):
       x = make_inputs(B, a, seed=seed)
       dev = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
       harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
-      fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank)
+      fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank, noise_bits=a.noise_bits)
       harmonic.kernel = a.harm_kernel                          # instance attributes: the defaults unless asked
       if a.noise_kernel != 'auto':
         fnoise.kernel = a.noise_kernel
@@ -823,12 +842,192 @@ def main(argv=None):
     else:
       fifth = {'batch_per_gpu': 32, 'error': err or 'another rank failed to set this shape up'}
 
+  # ---- the callers either side of the path at BASELINE's batch, and the full-resolution noise -------------------------------
+  # (under the driver's clock, in the default line.  One helper: whatever may raise - building the
+  # Processors, the first launches - runs inside a `try`, the ranks agree on the outcome, and the regions, which hold a
+  # barrier each when world > 1, run on every rank or on none.)
+  def side_block(build_fn, steps, reps, two_streams=False):
+    err, fn, meta, bd = None, None, {}, {}
+    try:
+      fn, meta = build_fn()
+      with torch.no_grad():
+        for _ in range(10):
+          fn(two_streams)
+        settle(lambda: fn(two_streams), 0.05)
+        for _ in range(5):
+          fn(False)
+        torch.cuda.synchronize()
+        _lib.profile_begin(None, max_records=512)
+        for _ in range(5):
+          fn(False)
+        torch.cuda.synchronize()
+        bd = _lib.profile_end()
+    except Exception as exc:                      # noqa: BLE001 - a side block: the headline line must survive
+      err = repr(exc)
+    if max_over_ranks(1.0 if err else 0.0) > 0.0:
+      return {'error': err or 'another rank failed to set this block up'}
+    with torch.no_grad():
+      for _ in range(3):
+        timed_region(fn, steps, two_streams)
+      ev_s, _, _ = repeated_regions(fn, steps, two_streams, reps)
+    per = max_over_ranks(statistics.median(ev_s)) / steps
+    nbytes = meta.pop('algorithmic_bytes')
+    b_, n_ = meta.pop('batch_per_gpu'), meta.pop('n_samples')
+    return dict(meta, batch_per_gpu=b_, steps=steps, regions=reps,
+                streams='two free-running HIP streams' if two_streams else 'one stream',
+                ms_per_step=per * 1e3, value=world * b_ * n_ / per / 1e6,
+                whole_step={'algorithmic_bytes': nbytes, 'achieved_GBs': nbytes / per / 1e9,
+                            'frac': nbytes / per / 1e9 / HBM_PEAK_GBS},
+                kernel_breakdown_us={k: v[0] / v[1] * 1e3 for k, v in bd.items()},
+                kernel_launches_per_step={k: v[1] / 5.0 for k, v in bd.items()})
+
+  other = {}
+  if default_shape and not dry and not a.no_aux and not a.no_other_configs:
+    BO = 128
+    synth_bytes = 4 * BO * (a.n_frames * (a.n_harmonics + 2) + a.n_frames * a.n_bands + a.n_samples)   # the DAG with Add fused: one [B,N] stream
+
+    def dag_parts(seed, noise_bits=11):
+      x = make_inputs(BO, a, seed=seed)
+      d = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
+      harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
+      fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank, noise_bits=noise_bits)
+
+      def dag():
+        z = fnoise(d['magnitudes'])
+        return harmonic.call_add(d['amplitudes'], d['harmonic_distribution'], d['f0_hz'], z)
+      return d, harmonic, fnoise, dag
+
+    def build_configs_2():
+      d, harmonic, fnoise, dag = dag_parts(7000 + rank)
+      loss = ddsp.losses.SpectralLoss(logmag_weight=1.0)              # gin/models/ae.gin:36-41: L1, mag + logmag, six scales
+      target = ddsp.core.tf_float32(0.3 * np.random.default_rng(7100 + rank).standard_normal((BO, a.n_samples)))
+
+      def fn(two_streams=None):
+        return loss(target, dag())
+      meta = {'workload': 'BASELINE configs[2]: FilteredNoise, Harmonic + Add (fused), losses.SpectralLoss (fft sizes 2048 .. 64, '
+                          'L1, mag + logmag) on the sum against a target; batch 128, 4 s @ 16 kHz; forward value',
+              'batch_per_gpu': BO, 'n_samples': a.n_samples,
+              # the DAG's controls in, its one audio stream out; the loss reads that stream and the target
+              'algorithmic_bytes': synth_bytes + 8 * BO * a.n_samples}
+      fn.loss, fn.target, fn.dag = loss, target, dag
+      return fn, meta
+
+    def build_configs_3(per_clip_ir=False):
+      d, harmonic, fnoise, dag = dag_parts(7200 + rank)
+      L = 48000
+      if per_clip_ir:
+        reverb = ddsp.effects.Reverb(add_dry=True)
+        ir = ddsp.core.tf_float32(0.05 * np.random.default_rng(7300 + rank).standard_normal((BO, L)))
+
+        def fn(two_streams=None):
+          return reverb(dag(), ir)
+      else:
+        reverb = ddsp.effects.Reverb(trainable=True, reverb_length=L, add_dry=True)
+        reverb.build(device=d['magnitudes'].device)
+        reverb._ir = ddsp.core.tf_float32(0.05 * np.random.default_rng(7300 + rank).standard_normal((L,)))
+
+        def fn(two_streams=None):
+          return reverb(dag())
+      meta = {'workload': 'BASELINE configs[3] per GPU: ProcessorGroup FilteredNoise, Harmonic + Add (fused), effects.Reverb (%s '
+                          '48 000-tap impulse response, add_dry), batch 128 (1024 over 8 GPUs), 4 s @ 16 kHz' %
+                          ('one per clip:' if per_clip_ir else 'the ONE trainable, as gin/models/solo_instrument.gin:26-40:'),
+              'batch_per_gpu': BO, 'n_samples': a.n_samples,
+              # ... the Reverb reads that stream and writes its own; the impulse response(s) once
+              'algorithmic_bytes': synth_bytes + 8 * BO * a.n_samples + 4 * L * (BO if per_clip_ir else 1)}
+      return fn, meta
+
+    def build_full_resolution():
+      x = make_inputs(B, a, seed=1000 + rank)
+      d = {k: ddsp.core.tf_float32(v) for k, v in x.items()}
+      harmonic = ddsp.synths.Harmonic(n_samples=a.n_samples, sample_rate=a.sample_rate)
+      fnoise = ddsp.synths.FilteredNoise(n_samples=a.n_samples, window_size=0, seed=rank, noise_bits=23)
+
+      def fn(two_streams=None):
+        if two_streams:
+          torch.cuda.set_stream(stream_h)
+          h = harmonic(d['amplitudes'], d['harmonic_distribution'], d['f0_hz'])
+          torch.cuda.set_stream(stream_z)
+          z = fnoise(d['magnitudes'])
+          torch.cuda.set_stream(stream_0)
+        else:
+          h = harmonic(d['amplitudes'], d['harmonic_distribution'], d['f0_hz'])
+          z = fnoise(d['magnitudes'])
+        return h, z
+      hb, nb = algorithmic_bytes(a, B)
+      meta = {'workload': 'the headline step with FilteredNoise(noise_bits=23): generated noise of 2^23 levels (the resolution of '
+                          "the reference's tf.random.uniform, ddsp/synths.py:192-193) carried as fp16 hi / lo pairs; the headline "
+                          'draws 2048 levels (noise_bits=11, the default: every sample an fp16 number)',
+              'batch_per_gpu': B, 'n_samples': a.n_samples, 'algorithmic_bytes': hb + nb}
+      return fn, meta
+
+    k_o = max(10, min(a.steps, 100))
+    if a.noise_bits == 11:
+      other['fnoise_full_resolution'] = side_block(build_full_resolution, a.steps, max(3, repeats // 2), two_streams=overlap)
+      if 'error' not in other['fnoise_full_resolution']:
+        fr = other['fnoise_full_resolution']
+        fr['headline_ms_per_step'] = elapsed / a.steps * 1e3
+        fr['cost_of_the_twelve_bits_us'] = fr['ms_per_step'] * 1e3 - elapsed / a.steps * 1e6
+    other['configs_2'] = side_block(build_configs_2, k_o, 5)
+    other['configs_3'] = side_block(build_configs_3, k_o, 5)
+    c3b = side_block(lambda: build_configs_3(per_clip_ir=True), k_o, 3)
+    if 'error' not in other['configs_3']:
+      other['configs_3']['per_clip_ir'] = ({k: c3b[k] for k in ('ms_per_step', 'value', 'whole_step', 'kernel_breakdown_us')}
+                                           if 'error' not in c3b else c3b)
+    # the loss's value AND gradient w.r.t. the audio, as a training step runs it (one kernel for both)
+    if 'error' not in other['configs_2']:
+      err_g, fn_g = None, None
+      try:
+        fn2, _ = build_configs_2()
+
+        def fn_g(two_streams=None):
+          with torch.no_grad():
+            y = fn2.dag()
+          y.requires_grad_(True)
+          with torch.enable_grad():
+            fn2.loss(fn2.target, y).backward()
+          return y.grad
+        for _ in range(5):
+          fn_g()
+        torch.cuda.synchronize()
+      except Exception as exc:                    # noqa: BLE001
+        err_g = repr(exc)
+      if max_over_ranks(1.0 if err_g else 0.0) == 0.0:
+        ev_g, _, _ = repeated_regions(fn_g, k_o, False, 3)
+        per = max_over_ranks(statistics.median(ev_g)) / k_o
+        other['configs_2']['with_gradient_wrt_audio'] = {'ms_per_step': per * 1e3, 'value': world * BO * a.n_samples / per / 1e6}
+      else:
+        other['configs_2']['with_gradient_wrt_audio'] = {'error': err_g or 'another rank failed'}
+
+  # ---- who holds which rows (contiguous batch shards, no data-path collective) ---------------------------------
+  # every rank reports the rows ddsp_amd.distributed.shard_bounds gives it for the global batches of BASELINE's sharded
+  # configurations at this world size (weak scaling: per-GPU batch x world; configs[3] 1024 -> 128 and configs[4] 256 -> 32
+  # at 8 GPUs), summed into one vector: rank 0 prints what every rank actually took (tests/test_bench_contract.py, 8 ranks)
+  shards = None
+  try:
+    from ddsp_amd.distributed import shard_bounds
+    plan = {'headline': B * world, 'configs_3': 128 * world, 'configs_4': 32 * world}
+    v = [0.0] * (len(plan) * 2 * world)
+    for i, (name, gb) in enumerate(plan.items()):
+      v[(i * world + rank) * 2], v[(i * world + rank) * 2 + 1] = (float(x) for x in shard_bounds(gb, rank, world))
+    if world > 1:
+      vec = torch.tensor(v, dtype=torch.float64, device=dev_name)
+      dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+      v = vec.tolist()
+    v = [int(x) for x in v]
+    shards = {name: {'global_batch': gb, 'rows_of_rank': [[v[(i * world + r) * 2], v[(i * world + r) * 2 + 1]] for r in range(world)]}
+              for i, (name, gb) in enumerate(plan.items())}
+  except ImportError:
+    pass
+
   if rank == 0:
     result = build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux, alt_elapsed, gather_ms,
                           timing=timing, second=second, one_stream_elapsed=one_stream_elapsed,
                           roofline_timing=roofline_timing, fused_add=fused_add_elapsed)
     if fifth:
       result['configs_4'] = fifth
+    result.update(other)
+    if shards:
+      result['shards'] = shards
     print(json.dumps(result), flush=True)
 
   if world > 1:

@@ -61,6 +61,8 @@ SIGNATURES = {
                                 [c_int] * 4 + [ctypes.c_float] * 5 + [c_int, c_voidp]),
     'ddsp_stft_mag_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_voidp]),
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
+    'ddsp_prepare': (c_int, [c_int, c_int, c_int]),
+    'ddsp_uniform_noise_ex_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_int, c_voidp]),
     'ddsp_add_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
     'ddsp_exp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t] + [c_float] * 3 + [c_voidp]),
     'ddsp_oscillator_bank_workspace_bytes': (c_size_t, [c_int] * 3),
@@ -102,6 +104,7 @@ HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
 NOISE_SCALE_EXP_SIGMOID = 0x1
 NOISE_FIR_VECTOR_ALU = 0x8
+NOISE_BITS_23 = 0x10
 DECAY_SCALE_EXP_SIGMOID = 0x1
 RESAMPLE_METHODS = {'nearest': 0, 'linear': 1, 'cubic': 2, 'window': 3}
 LOSS_TYPES = {'L1': 0, 'L2': 1, 'COSINE': 2}

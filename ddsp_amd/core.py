@@ -794,10 +794,20 @@ def frequency_filter(audio, magnitudes, window_size=0, padding='same'):
   return fft_convolve(audio, impulse_response, padding=padding)
 
 
-def uniform_noise(batch_size, n_samples, seed=0, batch_offset=0):
-  """The on-chip stand-in for tf.random.uniform([B, N], -1, 1) (ddsp/synths.py:192-193)."""
+def prepare(n_harmonics=0, n_noise_bands=0, window_size=0):
+  """Make the constant operand tables of the matrix-core kernels for these shapes on the current device now (C ABI
+  ddsp_prepare): the one thing in the library that allocates and copies synchronously, once per device and shape, on first
+  use otherwise - which must not happen inside a HIP-graph capture."""
+  _lib.check(_lib.load().ddsp_prepare(int(n_harmonics), int(n_noise_bands), int(window_size)), 'ddsp_prepare')
+
+
+def uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=11):
+  """The on-chip stand-in for tf.random.uniform([B, N], -1, 1) (ddsp/synths.py:192-193): what FilteredNoise generates
+  for itself, 2048 levels (noise_bits=11, the default) or the 2^23 levels of an fp32 uniform (noise_bits=23)."""
+  if noise_bits not in (11, 23):
+    raise ValueError('noise_bits must be 11 or 23, got {!r}'.format(noise_bits))
   out = torch.empty((int(batch_size), int(n_samples)), dtype=torch.float32, device=_device())
-  rc = _lib.load().ddsp_uniform_noise_f32(out.data_ptr(), int(batch_size), int(n_samples),
-                                          int(seed), int(batch_offset), _stream())
-  _lib.check(rc, 'ddsp_uniform_noise_f32')
+  rc = _lib.load().ddsp_uniform_noise_ex_f32(out.data_ptr(), int(batch_size), int(n_samples),
+                                             int(seed), int(batch_offset), int(noise_bits), _stream())
+  _lib.check(rc, 'ddsp_uniform_noise_ex_f32')
   return out

@@ -55,6 +55,28 @@ __device__ __forceinline__ float wave_min_dpp(float v) {
   v = fminf(v, dpp_keep<0x143, 0xC>(v));    // row_bcast:31 -> rows 2, 3: lane 63 holds the minimum of all
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// maximum of NON-NEGATIVE values over the 64 lanes, wave-uniform result (lanes a DPP step does not reach read 0, which is
+// neutral for values >= 0; a NaN is ignored by fmaxf - the value that carries it still poisons whatever it is used in)
+__device__ __forceinline__ float wave_max_nonneg_dpp(float v) {
+  v = fmaxf(v, dpp_mov0<0xB1, 0xF>(v));
+  v = fmaxf(v, dpp_mov0<0x4E, 0xF>(v));
+  v = fmaxf(v, dpp_mov0<0x141, 0xF>(v));
+  v = fmaxf(v, dpp_mov0<0x140, 0xF>(v));
+  v = fmaxf(v, dpp_mov0<0x142, 0xA>(v));
+  v = fmaxf(v, dpp_mov0<0x143, 0xC>(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// Power-of-two normalisation ahead of an fp16 hi / lo split (the splits x = hi + lo / 2048 are exact to 22 bits only
+// while x is inside fp16's normal range; gradients, caller-supplied audio and impulse responses come at any scale, and the fp32
+// reference - tf.signal's FFTs, tf.GradientTape - is scale invariant).  e with m 2^-e in [1/2, 1); 0 for m = 0, inf, NaN; clamped
+// so that v_ldexp_f32 by -e and by +e are both exact inverses on normal numbers.  Data is multiplied by 2^-e before the split and
+// the accumulator by 2^e (x 2^e' of the other operand) after the product: powers of two, so nothing is rounded twice.
+__device__ __forceinline__ int pow2_exponent(float m) {
+  const int field = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);
+  int e = field - 126;
+  if (m == 0.0f || field == 255) e = 0;
+  return e < -125 ? -125 : (e > 126 ? 126 : e);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov0(double v) {
   const long long b = __builtin_bit_cast(long long, v);
@@ -170,9 +192,34 @@ __device__ __forceinline__ float4 noise_quad(const U4& r, int h) {
   const uint32_t w0 = h ? r.z : r.x, w1 = h ? r.w : r.y;
   return make_float4(noise_even(w0), noise_odd(w0), noise_even(w1), noise_odd(w1));
 }
+// ---- the full-resolution option (round 5: FilteredNoise(noise_bits=23), C flag DDSP_NOISE_BITS_23) ------------------------------
+// tf.random.uniform(-1, 1) has 2^23 levels (ddsp/synths.py:192-193).  With 23 bits a sample is built the way TensorFlow builds
+// an fp32 uniform - the top 23 bits of a word as the mantissa of a number in [1, 2), then 2 u - 3, every step exact - one sample
+// per Philox word: sample n of a row is word n & 3 of block (n >> 3, row, 1 + ((n >> 2) & 1), 0).  (The third counter word tells
+// the half-octets apart and keeps this stream disjoint from the 11-bit one, whose third word is 0.)  Such a sample is not an fp16
+// number: the matrix-core kernels carry it as an fp16 hi / lo pair, as they carry noise the caller supplies - three products per
+// k-step instead of two, twice the LDS traffic of the Toeplitz operand; bench.py reports the step both ways.
+__device__ __forceinline__ float bits_to_pm1(uint32_t bits) {
+  const float u = __builtin_bit_cast(float, (bits >> 9) | 0x3F800000u);
+  return fmaf(u, 2.0f, -3.0f);                 // == (u - 1) 2 - 1: every step of either form is exact
+}
+// the four samples i .. i + 3 of global batch row `row`, i a multiple of 4
+__device__ __forceinline__ float4 noise_quad_at(uint32_t i, uint64_t row, uint32_t k0, uint32_t k1, bool bits23) {
+  if (bits23) {
+    const U4 r = noise_philox(U4{i >> 3, (uint32_t)row, 1u + ((i >> 2) & 1u), 0u}, k0, k1);
+    return make_float4(bits_to_pm1(r.x), bits_to_pm1(r.y), bits_to_pm1(r.z), bits_to_pm1(r.w));
+  }
+  const U4 r = noise_philox(U4{i >> 3, (uint32_t)row, 0u, 0u}, k0, k1);
+  return noise_quad(r, (int)((i >> 2) & 1u));
+}
 // noise sample n of global batch row `row`
 __device__ __forceinline__ float philox_noise(uint32_t n, uint64_t row, uint32_t k0,
-                                              uint32_t k1) {
+                                              uint32_t k1, bool bits23 = false) {
+  if (bits23) {
+    const U4 r = noise_philox(U4{n >> 3, (uint32_t)row, 1u + ((n >> 2) & 1u), 0u}, k0, k1);
+    const uint32_t w = n & 3u;
+    return bits_to_pm1((w == 0) ? r.x : (w == 1) ? r.y : (w == 2) ? r.z : r.w);
+  }
   const U4 r = noise_philox(U4{n >> 3, (uint32_t)row, 0u, 0u}, k0, k1);
   const uint32_t w = (n >> 1) & 3u;
   const uint32_t word = (w == 0) ? r.x : (w == 1) ? r.y : (w == 2) ? r.z : r.w;

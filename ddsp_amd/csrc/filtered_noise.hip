@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256) void noise_ir_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void uniform_noise_kernel(float* __restrict__ out, int N,
                                                             uint32_t k0, uint32_t k1,
-                                                            uint64_t batch_offset) {
+                                                            uint64_t batch_offset, int bits23) {
   const int b = blockIdx.y;
-  const int nq = (N + 7) / 8;                              // eight samples per Philox block (common.h)
+  const int nq = (N + 7) / 8;                              // eight samples per octet: one Philox block (11 bits) or two (23: common.h)
   for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
-    const U4 r = noise_philox(U4{(uint32_t)q, (uint32_t)(batch_offset + b), 0u, 0u}, k0, k1);
-    const float4 lo = noise_quad(r, 0), hi = noise_quad(r, 1);
+    const float4 lo = noise_quad_at(8u * (uint32_t)q, batch_offset + b, k0, k1, bits23 != 0);
+    const float4 hi = noise_quad_at(8u * (uint32_t)q + 4u, batch_offset + b, k0, k1, bits23 != 0);
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -108,6 +108,7 @@ struct FirArgs {
   size_t ir_batch_stride;   // F*L, or 0 when Bir == 1 (broadcast, core.py:1433-1434)
   uint32_t k0, k1;
   uint64_t batch_offset;
+  int bits23;               // generated noise: 23-bit samples (DDSP_NOISE_BITS_23) instead of the 2048 levels
 };
 
 template <bool GEN_NOISE>
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void tv_fir_kernel(FirArgs p) {
     const int i = i_lo + t;
     float v = 0.0f;
     if (i >= 0 && i < p.N)
-      v = GEN_NOISE ? philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1)
+      v = GEN_NOISE ? philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1, p.bits23 != 0)
                     : p.x[(size_t)b * p.N + i];
     s_x[t] = v;
   }
@@ -278,6 +279,7 @@ struct Fir128Args {
   int N, F, start;
   uint32_t k0, k1;
   uint64_t batch_offset;
+  int bits23;
 };
 
 template <bool GEN_NOISE>
@@ -297,8 +299,7 @@ __global__ __launch_bounds__(64 * kFirWaves, 4) void tv_fir128_kernel(
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i >= 0 && i < p.N) {
       if (GEN_NOISE) {
-        const U4 r = noise_philox(U4{(uint32_t)(i >> 3), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-        v = noise_quad(r, (i >> 2) & 1);      // (i is a multiple of 4: one half of the block's eight samples)
+        v = noise_quad_at((uint32_t)i, p.batch_offset + b, p.k0, p.k1, p.bits23 != 0);      // (i is a multiple of 4)
         if (i + 3 >= p.N) {
           if (i + 1 >= p.N) v.y = 0.f;
           if (i + 2 >= p.N) v.z = 0.f;
@@ -430,6 +431,7 @@ struct FusedNoiseArgs {
   float bias;
   uint32_t k0, k1;
   uint64_t batch_offset;
+  int bits23;
 };
 
 typedef _Float16 fn_f16x8 __attribute__((ext_vector_type(8)));
@@ -521,8 +523,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 6 : 3)) void noise_fused65_kern
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 0 && i < p.N) {
         if (GEN_NOISE) {
-          const U4 r = noise_philox(U4{(uint32_t)(i >> 3), (uint32_t)(p.batch_offset + b), 0u, 0u}, p.k0, p.k1);
-          v = noise_quad(r, (i >> 2) & 1);      // (i is a multiple of 4: one half of the block's eight samples)
+          v = noise_quad_at((uint32_t)i, p.batch_offset + b, p.k0, p.k1, p.bits23 != 0);      // (i is a multiple of 4)
           if (i + 1 >= p.N) v.y = 0.f;
           if (i + 2 >= p.N) v.z = 0.f;
           if (i + 3 >= p.N) v.w = 0.f;
@@ -779,7 +780,7 @@ extern "C" int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, 
 
 static int launch_fir(const float* x, const float* ir, float* out, int B, int Bir, int F, int L,
                       int N, int delay_compensation, uint64_t seed, uint64_t batch_offset,
-                      hipStream_t st) {
+                      int bits23, hipStream_t st) {
   if (B > 65535) return DDSP_ERR_UNSUPPORTED;
   FirArgs p;
   p.x = x; p.ir = ir; p.out = out;
@@ -791,10 +792,11 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
   p.ir_batch_stride = (Bir == 1) ? 0 : (size_t)F * L;
   p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
   p.batch_offset = batch_offset;
+  p.bits23 = bits23;
   if (L == 128 && p.frame_size == 64 && Bir == B && (((uintptr_t)ir) & 15) == 0 &&
       (x == nullptr || (((uintptr_t)x) & 15) == 0)) {
     Fir128Args q;
-    q.N = N; q.F = F; q.start = p.start; q.k0 = p.k0; q.k1 = p.k1; q.batch_offset = batch_offset;
+    q.N = N; q.F = F; q.start = p.start; q.k0 = p.k0; q.k1 = p.k1; q.batch_offset = batch_offset; q.bits23 = bits23;
     const dim3 grid((unsigned)((N + p.start + kFirTile - 1) / kFirTile), (unsigned)B);
     ProfileScope prof(kTvFir, st);
     if (x) hipLaunchKernelGGL((tv_fir128_kernel<false>), grid, dim3(64 * kFirWaves), 0, st, x, ir, out, q);
@@ -803,7 +805,7 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
   }
   // any other tap count and frame size: Toeplitz products on the matrix cores (filtered_noise_general.hip)
   if (!general_plain_env() && tv_fir_mfma_ok(B, Bir, F, L, N))
-    return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, st);
+    return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, bits23, st);
   // tile: as many outputs as keep x + taps under the LDS budget
   int tile = 1024;
   size_t lds = 0;
@@ -826,7 +828,7 @@ extern "C" int ddsp_fft_convolve_same_f32(const float* audio, const float* impul
                                           int delay_compensation, void* stream) {
   if (!audio || !impulse_response || !out) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || F <= 0 || L <= 0 || N <= 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
-  return launch_fir(audio, impulse_response, out, B, Bir, F, L, N, delay_compensation, 0, 0,
+  return launch_fir(audio, impulse_response, out, B, Bir, F, L, N, delay_compensation, 0, 0, 0,
                     (hipStream_t)stream);
 }
 
@@ -851,8 +853,9 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   // bit 30 (the in-kernel timeline of tools/exp_noise_fir.py: the controls pointer then carries a stamp buffer) only
   // under DDSP_NOISE_DEBUG_TIMELINE=1; any other unknown bit is an error, not a silent reinterpretation
   static const bool dbg_allowed = getenv("DDSP_NOISE_DEBUG_TIMELINE") != nullptr;
-  const unsigned known = DDSP_NOISE_SCALE_EXP_SIGMOID | DDSP_NOISE_FIR_VECTOR_ALU | (dbg_allowed ? 0x40000000u : 0u);
+  const unsigned known = DDSP_NOISE_SCALE_EXP_SIGMOID | DDSP_NOISE_FIR_VECTOR_ALU | DDSP_NOISE_BITS_23 | (dbg_allowed ? 0x40000000u : 0u);
   if (flags & ~known) return DDSP_ERR_UNSUPPORTED;
+  const int bits23 = (flags & DDSP_NOISE_BITS_23) ? 1 : 0;             // (generated noise only: supplied noise is what it is)
   {
     const IrGeom g = ir_geom(M, window_size);
     const int frame_size = (N + F - 1) / F;
@@ -860,19 +863,20 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
     // DDSP_NOISE_FIR_VECTOR_ALU (or DDSP_EXP_NOISE_FIR=vector) keeps the FIR on the vector ALUs (noise_fused65_kernel)
     static const bool fir_vector_env = [] { const char* e = getenv("DDSP_EXP_NOISE_FIR"); return e && e[0] == 'v'; }();
     if (!(flags & DDSP_NOISE_FIR_VECTOR_ALU) && !fir_vector_env && B <= 65535 &&
-        noise_mfma65_ok(F, M, N, g.padding, noise)) {
+        noise_mfma65_ok(F, M, N, g.padding, noise, scale)) {
       long long* dbg = (flags & 0x40000000u) ? reinterpret_cast<long long*>(ctl_magnitudes) : nullptr;   // debug timeline
       return launch_noise_mfma65(magnitudes, noise, audio, dbg ? nullptr : ctl_magnitudes, B, F, N, (g.L - 1) / 2 - 1,
-                                 initial_bias, scale, seed, batch_offset, dbg, st);
+                                 initial_bias, scale, seed, batch_offset, dbg, bits23, (float*)workspace, st);
     }
-    if (M == 65 && g.padding == 0 && frame_size >= 64 && (frame_size % 16) == 0 && frame_size <= 4096 &&
+    // (the vector-ALU kernel designs its taps on the matrix cores from magnitudes it splits as they come: squashed ones only)
+    if (scale && M == 65 && g.padding == 0 && frame_size >= 64 && (frame_size % 16) == 0 && frame_size <= 4096 &&
         (N + frame_size - 1) / frame_size == F && B <= 65535 &&
         (noise == nullptr || (((uintptr_t)noise) & 15) == 0)) {
       FusedNoiseArgs q;
       q.N = N; q.F = F; q.start = (g.L - 1) / 2 - 1; q.bias = initial_bias;
       q.fs = frame_size; q.inv_fs = 1.0f / (float)frame_size;
       q.scale = scale | ((flags & 0x40000000u) ? 0x40000000 : 0);      // bit 30: debug timeline
-      q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
+      q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset; q.bits23 = bits23;
       const dim3 grid((unsigned)((N + q.start + kFnTile - 1) / kFnTile), (unsigned)B);
       hipEvent_t ev0, ev1;
       profile_kernel_events(kNoiseFused, &ev0, &ev1);
@@ -900,12 +904,12 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   static const bool two_env = [] { const char* e = getenv("DDSP_EXP_NOISE_GENERAL"); return e && e[0] == 't'; }();
   if (!general_plain_env() && !two_env && filtered_noise_general_fused_ok(B, F, M, N, window_size))
     return launch_filtered_noise_general_fused(magnitudes, noise, audio, ctl_magnitudes, B, F, M, N, window_size, initial_bias,
-                                               scale, seed, batch_offset, st);
+                                               scale, seed, batch_offset, bits23, st);
   float* ir = (float*)workspace;
   int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
   if (rc != DDSP_OK) return rc;
   return launch_fir(noise, ir, audio, B, B, F, ir_geom(M, window_size).L, N, -1, seed,
-                    batch_offset, st);
+                    batch_offset, bits23, st);
 }
 
 // =====================================================================================
@@ -929,6 +933,7 @@ struct NoiseBwdArgs {
   float bias;
   uint32_t k0, k1;
   uint64_t batch_offset;
+  int bits23;
 };
 
 __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __restrict__ x /*[B,N] or null*/,
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(256) void noise_bwd_taps_kernel(const float* __rest
         const int i = f * p.fs + c + lane;                 // this lane's sample
         float xv = 0.0f;
         if (c + lane < p.fs && i < p.N)
-          xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1);
+          xv = x ? x[(size_t)b * p.N + i] : philox_noise((uint32_t)i, p.batch_offset + b, p.k0, p.k1, p.bits23 != 0);
         const float* __restrict__ win = s_g + q * p.fs + c + kc + lane;    // + l: gz[i_l + t], t = kc + lane
 #pragma unroll
         for (int l = 0; l < 64; l += 2) {
@@ -1113,10 +1118,12 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
       ((uintptr_t)workspace & 15))
     return DDSP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  if (flags & ~(DDSP_NOISE_SCALE_EXP_SIGMOID | DDSP_NOISE_FIR_VECTOR_ALU | DDSP_NOISE_BITS_23)) return DDSP_ERR_UNSUPPORTED;
+  const int bits23 = (flags & DDSP_NOISE_BITS_23) ? 1 : 0;             // as in the forward call whose noise is regenerated
   // the canonical filter on frames of 64 c samples: one launch on the matrix cores (filtered_noise_general.hip)
   if (noise_bwd_mfma_ok(B, F, M, N, window_size))
     return launch_noise_bwd_mfma(magnitudes, noise, grad_audio, grad_magnitudes, B, F, M, N, window_size, initial_bias,
-                                 (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0, seed, batch_offset, st);
+                                 (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0, seed, batch_offset, bits23, st);
   NoiseBwdArgs p;
   p.N = N; p.F = F; p.fs = fs; p.start = start;
   p.L = g.L; p.Lpad = (g.L + 127) & ~127; p.M = M; p.window_size = window_size;
@@ -1125,7 +1132,7 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
   if (p.tile_frames < 1) p.tile_frames = 1;
   p.scale = (flags & DDSP_NOISE_SCALE_EXP_SIGMOID) ? 1 : 0;
   p.bias = initial_bias;
-  p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.batch_offset = batch_offset;
+  p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.batch_offset = batch_offset; p.bits23 = bits23;
   float* dh = (float*)workspace;
   {
     ProfileScope prof(kNoiseBwdTaps, st);
@@ -1154,15 +1161,21 @@ extern "C" int ddsp_filtered_noise_backward_f32(const float* magnitudes, const f
   return check_launch();
 }
 
-extern "C" int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed,
-                                      uint64_t batch_offset, void* stream) {
+extern "C" int ddsp_uniform_noise_ex_f32(float* out, int B, int N, uint64_t seed,
+                                         uint64_t batch_offset, int noise_bits, void* stream) {
   if (!out) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
-  const dim3 grid(grid_for((size_t)(N + 3) / 4, 64), (unsigned)B);
+  if (noise_bits != 11 && noise_bits != 23) return DDSP_ERR_UNSUPPORTED;
+  const dim3 grid(grid_for((size_t)(N + 7) / 8, 64), (unsigned)B);
   ProfileScope prof(kUniformNoise, (hipStream_t)stream);
   hipLaunchKernelGGL(uniform_noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, out, N,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), batch_offset);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), batch_offset, noise_bits == 23 ? 1 : 0);
   return check_launch();
+}
+
+extern "C" int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed,
+                                      uint64_t batch_offset, void* stream) {
+  return ddsp_uniform_noise_ex_f32(out, B, N, seed, batch_offset, 11, stream);
 }
 
 extern "C" int ddsp_add_f32(const float* a, const float* b, float* out, size_t n, void* stream) {

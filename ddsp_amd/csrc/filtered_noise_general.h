@@ -16,19 +16,24 @@ int launch_noise_ir_gemm(const float* mag, float* ctl_out, float* ir, long rows,
 // the time-varying FIR (core.fft_convolve, ddsp/core.py:1382-1473, as a time-domain sum) for any tap count up to
 // kGfMaxTaps and any frame size
 bool tv_fir_mfma_ok(int B, int Bir, int F, int L, int N);
+// (bits23: noise generated with 23-bit samples - DDSP_NOISE_BITS_23, common.h - when x is null)
 int launch_tv_fir_mfma(const float* x, const float* ir, float* out, int B, int Bir, int F, int L, int N, int start,
-                       uint64_t seed, uint64_t batch_offset, hipStream_t st);
+                       uint64_t seed, uint64_t batch_offset, int bits23, hipStream_t st);
 
 // FilteredNoise.__call__ in ONE launch for up to 128 bands and 256 taps: tv_fir_mfma_kernel designing its tiles' taps itself
 bool filtered_noise_general_fused_ok(int B, int F, int M, int N, int window_size);
 int launch_filtered_noise_general_fused(const float* mag, const float* x, float* out, float* ctl_out, int B, int F, int M, int N,
                                         int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset,
-                                        hipStream_t st);
+                                        int bits23, hipStream_t st);
 
 // the backward of FilteredNoise.__call__ for 65 bands / full window / frames of 64, 128, 192, 256 samples in ONE launch: the tap
 // gradients as Toeplitz products, dL/d magnitudes as a product with the transposed design matrix
 bool noise_bwd_mfma_ok(int B, int F, int M, int N, int window_size);
 int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const float* grad_audio, float* grad_magnitudes, int B, int F,
-                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, hipStream_t st);
+                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, int bits23,
+                          hipStream_t st);
+
+// the design matrix of (bands, window size) and its transpose as fragments on the current device NOW (ddsp_prepare); 0 on success
+int noise_general_prepare(int M, int window_size);
 
 }  // namespace ddsp

@@ -170,12 +170,30 @@ __global__ __launch_bounds__(64 * kGiWaves) void noise_ir_gemm_kernel(const floa
   __syncthreads();
   // this wavefront's 16 rows as A-fragments: lane (i, g) holds bins 32 ks + 8 g .. + 7 of row i
   gf_f16x8 ah[KS], al[KS];
+  // Magnitudes that are not squashed by exp_sigmoid (core.frequency_impulse_response on the caller's own: any scale) are brought
+  // to [1/2, 1) by the power of two of the largest among this wavefront's sixteen rows before the fp16 hi / lo split; the
+  // epilogue takes it back (the design is linear)
+  int a_exp = 0;
   {
     const float* arow = s_a + (16 * wave + i) * S + 8 * g;
+    if (!scale) {
+      float mx = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 q0 = *reinterpret_cast<const float4*>(arow + 32 * ks), q1 = *reinterpret_cast<const float4*>(arow + 32 * ks + 4);
+        mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(fabsf(q0.x), fabsf(q0.y))), fmaxf(fabsf(q0.z), fabsf(q0.w))),
+                   fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+      }
+      a_exp = pow2_exponent(wave_max_nonneg_dpp(mx));
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const float4 q0 = *reinterpret_cast<const float4*>(arow + 32 * ks), q1 = *reinterpret_cast<const float4*>(arow + 32 * ks + 4);
-      const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      if (a_exp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ldexpf(v[e], -a_exp);
+      }
       gf_split8(v, ah[ks], al[ks]);
     }
   }
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(64 * kGiWaves) void noise_ir_gemm_kernel(const floa
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long rr = row0 + 4 * g + r;
-            const float v = acc[u][r] + (acc_hl[u][r] + acc_lh[u][r]) * (1.0f / kGfLoScale);
+            const float v = ldexpf(acc[u][r] + (acc_hl[u][r] + acc_lh[u][r]) * (1.0f / kGfLoScale), a_exp);
 #ifndef DDSP_GI_NO_STORE
             if (rr < rows) ir[rr * L + col] = v;
 #else
@@ -404,10 +422,20 @@ static const GiMatrix* gi_matrix(int M, int window_size) {
             ft[((((size_t)nb * m.KSt + ks) * 2 + 1) * 64 + lane) * 4 + d] = lo2;
           }
     if (hipMalloc((void**)&m.dev_t, ft.size() * 4) != hipSuccess ||
-        hipMemcpy(m.dev_t, ft.data(), ft.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(m.dev_t, ft.data(), ft.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(m.dev);                                    // (every buffer made so far: ADVICE r4)
+      (void)hipFree(m.dev_u);
+      (void)hipFree(m.dest);
+      if (m.dev_t) (void)hipFree(m.dev_t);
       return nullptr;
+    }
   }
   return &cache.emplace(key, m).first->second;
+}
+
+int noise_general_prepare(int M, int window_size) {
+  if (M < 2 || !noise_ir_gemm_ok(M, window_size)) return 0;    // (shapes the plain kernels take need no constants)
+  return gi_matrix(M, window_size) ? 0 : 1;
 }
 
 bool noise_ir_gemm_ok(int M, int window_size) {
@@ -476,6 +504,8 @@ struct GfArgs {
   int ir_pairs;                // the tap rows may be read two floats at a time
   uint32_t k0, k1;
   uint64_t batch_offset;
+  // (GEN = false with x == null: DDSP_NOISE_BITS_23 - the noise is made here with 23-bit samples, which take the hi / lo planes
+  // that supplied noise takes; common.h)
   // taps designed in the kernel (template parameter KS > 0): FilteredNoise.__call__ in one launch
   const float* mag;            // [B, F, M]
   float* ctl;                  // [B, F, M] or null
@@ -517,6 +547,41 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
   int f_dummy;
   const int i_end = min(p.N, gf_piece_start(Vt0 + WR, p, &f_dummy));
 
+  // ---- the scale of what the caller supplies ----------------------------------------------------------------------
+  // core.fft_convolve is fp32 and scale invariant (core.py:1382-1473: tf.signal's FFTs); an fp16 hi / lo split is exact to 22
+  // bits only inside fp16's normal range - int16-range audio (x 32768) overflowed it, an impulse response of 1e-9 fell below
+  // it.  Audio the caller supplies, taps that come from HBM and magnitudes that are not squashed by exp_sigmoid are brought to
+  // [1/2, 1) by the power of two of the TILE's largest magnitude before they are split, and the outputs take the exponents back
+  // as they leave the accumulators.  Generated noise (|x| < 1) and exp_sigmoid's values (<= 2) need none of it.  The maxima are
+  // a pass of their own over the tile's inputs (L2 hits the second time round), reduced per wavefront, exchanged through 3 x 8
+  // floats of LDS and read behind the first barrier that follows.
+  __shared__ float s_wmax[3][8];
+  {
+    float xmx = 0.0f, hmx = 0.0f, mmx = 0.0f;
+    if constexpr (!GEN) {
+      if (p.x) {
+        const float* xb = p.x + (size_t)b * p.N;
+        for (int i = i_lo + tid; i < i_end; i += nthr) xmx = fmaxf(xmx, fabsf(xb[i]));
+      }
+    }
+    const int rows_in = max(0, min(p.max_rows, p.F - f_lo));
+    if constexpr (KS == 0) {
+      const float* irb = p.ir + (size_t)b * p.ir_batch_stride + (size_t)f_lo * p.L;
+      for (int k = tid; k < rows_in * p.L; k += nthr) hmx = fmaxf(hmx, fabsf(irb[k]));
+    } else if (!p.scale) {
+      const float* mb = p.mag + ((size_t)b * p.F + f_lo) * p.M;
+      for (int k = tid; k < rows_in * p.M; k += nthr) mmx = fmaxf(mmx, fabsf(mb[k]));
+    }
+    xmx = wave_max_nonneg_dpp(xmx); hmx = wave_max_nonneg_dpp(hmx); mmx = wave_max_nonneg_dpp(mmx);
+    if (lane == 0) { s_wmax[0][wave] = xmx; s_wmax[1][wave] = hmx; s_wmax[2][wave] = mmx; }
+  }
+  auto tile_exponent = [&](int which) {
+    float m = 0.0f;
+    for (int w = 0; w < p.W; ++w) m = fmaxf(m, s_wmax[which][w]);
+    return pow2_exponent(m);
+  };
+  int x_exp = 0, h_exp = 0;                                  // audio; taps (KS > 0: the magnitudes' - the design is linear)
+
   // ---- the taps, designed here (KS > 0) -----------------------------------------------------------------------------------
   // The tile's frames f_lo .. are consecutive rows of the magnitudes: read as one stretch, scaled (the frames this tile owns
   // also go out as controls), split into fp16 hi / lo and laid down in LDS - in the space the noise and the output buffer
@@ -555,6 +620,10 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
     const float* src = p.mag + ((size_t)b * p.F + f_lo) * p.M;
     float* ctl = p.ctl ? p.ctl + ((size_t)b * p.F + f_lo) * p.M : nullptr;
     auto scaled = [&](float x) { return p.scale ? exp_sigmoid(x + p.bias, kLog10, 2.0f, 1e-7f) : x; };
+    if (!p.scale) {                                           // (launch-uniform: raw magnitudes, scale_fn = None)
+      __syncthreads();
+      h_exp = tile_exponent(2);
+    }
 #ifdef DDSP_GF_NO_DESIGN_STAGE
     if (p.M == 12345)
 #endif
@@ -566,6 +635,7 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
         const int r = k / m4, c4 = k - r * m4;
         if (ctl && f_lo + r >= own_lo && f_lo + r < own_hi) reinterpret_cast<float4*>(ctl)[k] = q;
         _Float16 h[4], l[4];
+        if (h_exp) { q.x = ldexpf(q.x, -h_exp); q.y = ldexpf(q.y, -h_exp); q.z = ldexpf(q.z, -h_exp); q.w = ldexpf(q.w, -h_exp); }
         gf_split(q.x, h[0], l[0]); gf_split(q.y, h[1], l[1]); gf_split(q.z, h[2], l[2]); gf_split(q.w, h[3], l[3]);
         uint8_t* dst = smem + (r * SA + 4 * c4) * 2;
         *reinterpret_cast<uint2*>(dst) = make_uint2(gf_pack(h[0], h[1]), gf_pack(h[2], h[3]));
@@ -577,7 +647,7 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
         const int r = k / p.M, c = k - r * p.M;
         if (ctl && f_lo + r >= own_lo && f_lo + r < own_hi) ctl[k] = q;
         _Float16 h, l;
-        gf_split(q, h, l);
+        gf_split(ldexpf(q, -h_exp), h, l);
         *reinterpret_cast<_Float16*>(smem + (r * SA + c) * 2) = h;
         *reinterpret_cast<_Float16*>(smem + (r * SA + c) * 2 + a_plane) = l;
       }
@@ -656,6 +726,9 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
   }
 #endif
   __syncthreads();
+  if constexpr (!GEN) x_exp = tile_exponent(0);
+  if constexpr (KS == 0) h_exp = tile_exponent(1);
+  const int o_exp = x_exp + h_exp;
 
   // ---- the taps of the tile's frames: fp32 rows from HBM, split, as groups of 8 ------------------------------------------
 #ifndef DDSP_GF_NO_TAPS
@@ -686,6 +759,8 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
         }
       }
       gf_f16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ldexpf(v[e], -h_exp);
       gf_split8(v, hi, lo);
       unsigned char* dst = s_taps + row * p.tap_row_bytes + (half * (p.Q + 1) + q) * 16;
       *reinterpret_cast<gf_f16x8*>(dst) = hi;
@@ -705,6 +780,7 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
     const int s = i - within;
     const int el = 16 + kGfSlot * sl + 79 - ((s & 15) + within);
     _Float16 hi, lo;
+    if constexpr (!GEN) val = ldexpf(val, -x_exp);
     gf_split(val, hi, lo);
     *reinterpret_cast<_Float16*>(s_x + 2 * el) = hi;
     *reinterpret_cast<_Float16*>(s_x + p.x_o + 2 * (el + 1)) = hi;
@@ -722,6 +798,16 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int i = 8 * q + e;
+        if (i >= i_lo && i < i_end) place(i, v[e]);
+      }
+    }
+  } else if (p.x == nullptr) {                                // 23-bit samples made here (|x| < 1: x_exp = 0)
+    for (int q = (i_lo >> 2) + tid; 4 * q < i_end; q += nthr) {
+      const float4 a = noise_quad_at(4u * (uint32_t)q, p.batch_offset + b, p.k0, p.k1, true);
+      const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
         if (i >= i_lo && i < i_end) place(i, v[e]);
       }
     }
@@ -796,6 +882,7 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
   // the kernel's 48 us at 100 bands and batch 32: an LDS float atomic costs ~100 clocks of the CU's one LDS pipeline.)
   // D[row 4 g + r][column a]: outputs 16 a + 4 g + r - a lane's four values are 16 aligned bytes
   float* const o_run = s_out + (Z_run - Z_t0) + 16 * i16 + 4 * g;
+  auto fin = [&](float a, float ax) { return ldexpf(a + ax * (1.0f / kGfLoScale), o_exp); };    // (the exponents of audio and taps back)
   int head = 0, limit = 0;
   if (have) {
     int fd;
@@ -805,8 +892,8 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
     for (int t = 0; t < NT; ++t) {
       if (!((touched >> t) & 1u)) continue;
       if (256 * t + 16 * i16 + 4 * g < head)
-        *reinterpret_cast<float4*>(o_run + 256 * t) = make_float4(acc[t][0] + acc_x[t][0] * (1.0f / kGfLoScale), acc[t][1] + acc_x[t][1] * (1.0f / kGfLoScale),
-                                                                  acc[t][2] + acc_x[t][2] * (1.0f / kGfLoScale), acc[t][3] + acc_x[t][3] * (1.0f / kGfLoScale));
+        *reinterpret_cast<float4*>(o_run + 256 * t) = make_float4(fin(acc[t][0], acc_x[t][0]), fin(acc[t][1], acc_x[t][1]),
+                                                                  fin(acc[t][2], acc_x[t][2]), fin(acc[t][3], acc_x[t][3]));
     }
   }
   __syncthreads();
@@ -817,10 +904,10 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
       const int pos = 256 * t + 16 * i16 + 4 * g;
       if (pos >= head && pos < limit) {
         float4 cur = *reinterpret_cast<const float4*>(o_run + 256 * t);
-        cur.x += acc[t][0] + acc_x[t][0] * (1.0f / kGfLoScale);
-        cur.y += acc[t][1] + acc_x[t][1] * (1.0f / kGfLoScale);
-        cur.z += acc[t][2] + acc_x[t][2] * (1.0f / kGfLoScale);
-        cur.w += acc[t][3] + acc_x[t][3] * (1.0f / kGfLoScale);
+        cur.x += fin(acc[t][0], acc_x[t][0]);
+        cur.y += fin(acc[t][1], acc_x[t][1]);
+        cur.z += fin(acc[t][2], acc_x[t][2]);
+        cur.w += fin(acc[t][3], acc_x[t][3]);
         *reinterpret_cast<float4*>(o_run + 256 * t) = cur;
       }
     }
@@ -928,7 +1015,7 @@ static void gf_launch_one(const GfPlan& pl, dim3 grid, dim3 block, hipStream_t s
 
 // the launch shared by the FIR alone (ks = 0) and the whole of FilteredNoise.__call__ (ks = the matrix's k-steps)
 static int gf_launch(GfPlan& pl, int B, int Bir, int F, int L, int N, int start, const float* x, const float* ir, float* out,
-                     uint64_t seed, uint64_t batch_offset, int ks, hipStream_t st) {
+                     uint64_t seed, uint64_t batch_offset, int ks, bool gen, hipStream_t st) {
   GfArgs& a = pl.a;
   a.x = x; a.ir = ir; a.out = out;
   a.N = N; a.F = F; a.L = L; a.start = start;
@@ -944,7 +1031,7 @@ static int gf_launch(GfPlan& pl, int B, int Bir, int F, int L, int N, int start,
   const long tiles = (pieces + a.fresh - 1) / a.fresh;
   if (tiles > 0x7fffffffL / 2) return DDSP_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)tiles, (unsigned)B), block((unsigned)(64 * a.W));
-  const bool gen = x == nullptr;
+  // gen: the no-lo-plane instances (generated noise of 2048 levels); otherwise supplied noise or 23-bit samples made in the kernel
   ProfileScope prof(kTvFir, st);
   const int npw = ks > 0 && a.NTu > 8 ? 2 : 1;
 #define DDSP_GF_CASE(NT_, KS_, NPW_)                                        \
@@ -961,10 +1048,11 @@ static int gf_launch(GfPlan& pl, int B, int Bir, int F, int L, int N, int start,
 }
 
 int launch_tv_fir_mfma(const float* x, const float* ir, float* out, int B, int Bir, int F, int L, int N, int start,
-                       uint64_t seed, uint64_t batch_offset, hipStream_t st) {
-  GfPlan pl = gf_plan(F, L, N, x == nullptr);
+                       uint64_t seed, uint64_t batch_offset, int bits23, hipStream_t st) {
+  const bool gen = x == nullptr && !bits23;
+  GfPlan pl = gf_plan(F, L, N, gen);
   if (!pl.ok) return DDSP_ERR_UNSUPPORTED;
-  return gf_launch(pl, B, Bir, F, L, N, start, x, ir, out, seed, batch_offset, 0, st);
+  return gf_launch(pl, B, Bir, F, L, N, start, x, ir, out, seed, batch_offset, 0, gen, st);
 }
 
 // FilteredNoise.__call__ in one launch: up to 128 bands (four k-steps: the matrix's fragments of two tap tiles fit a
@@ -984,9 +1072,10 @@ bool filtered_noise_general_fused_ok(int B, int F, int M, int N, int window_size
 }
 int launch_filtered_noise_general_fused(const float* mag, const float* x, float* out, float* ctl_out, int B, int F, int M, int N,
                                         int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset,
-                                        hipStream_t st) {
+                                        int bits23, hipStream_t st) {
   GfPlan pl;
-  if (!gf_fused_plan(B, F, M, N, window_size, x == nullptr, &pl)) return DDSP_ERR_UNSUPPORTED;
+  const bool gen = x == nullptr && !bits23;
+  if (!gf_fused_plan(B, F, M, N, window_size, gen, &pl)) return DDSP_ERR_UNSUPPORTED;
   const GiMatrix* m = gi_matrix(M, window_size);
   if (!m) return DDSP_ERR_LAUNCH;
   const IrGeom g = ir_geom(M, window_size);
@@ -997,7 +1086,7 @@ int launch_filtered_noise_general_fused(const float* mag, const float* x, float*
   a.mag = mag; a.ctl = ctl_out; a.cm = m->dev_u; a.dest = m->dest; a.NTu = m->NTu;
   a.M = M; a.scale = scale; a.bias = bias;
   a.mag_vec = ((M & 3) == 0 && ((((uintptr_t)mag) | ((uintptr_t)ctl_out)) & 15) == 0) ? 1 : 0;
-  return gf_launch(pl, B, B, F, g.L, N, start, x, nullptr, out, seed, batch_offset, m->KS, st);
+  return gf_launch(pl, B, B, F, g.L, N, start, x, nullptr, out, seed, batch_offset, m->KS, gen, st);
 }
 
 // =====================================================================================================================
@@ -1056,32 +1145,72 @@ __global__ __launch_bounds__(512, 6) void noise_bwd_mfma_kernel(NbArgs p) {
   if (wave < n_tasks) fetch_task(wave);
 
   // ---- stage the gradient window (split) and the noise pieces -------------------------------------------------------------
+  // dL/d audio comes at any scale (loss scaling, sum-reduced losses, vanishing gradients) and so does noise the caller supplies;
+  // the fp16 hi / lo split is exact to 22 bits only inside fp16's normal range.  Both are brought to [1/2, 1) by the power of two
+  // of the TILE's largest magnitude before they are split, the tap gradients stay in those units through the second product
+  // (|dh| <= frame size there), and the epilogue takes the two exponents back: scale invariant like tf.GradientTape's fp32
+  // gradients (3e4 overflowed to NaN, 1e-10 lost 7-9 %).  A thread keeps its (at most two) groups of the gradient
+  // window in registers across the barrier the maxima need - the one that was here already.
+  __shared__ float s_wmax[2][8];
+  constexpr int kNbGroups = 2;                                  // groups of 8 per thread: span <= 16 * 256 + 128 (launch_noise_bwd_mfma)
+  float gv[kNbGroups][8];
   {
     const float* gb = p.g + (size_t)b * p.N;
-    for (int k = tid; k < (span + 8) / 8; k += nthr) {          // groups of 8; the group behind the span is the zeros
-      float v[8];
+    float gmx = 0.0f, xmx = 0.0f;
+#pragma unroll
+    for (int u = 0; u < kNbGroups; ++u) {                       // groups of 8; the group behind the span is the zeros
+      const int k = tid + nthr * u;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int n = 8 * k + e;
         const long a = (long)m0 + n - p.start;                  // gz[m] = g[m - start]
-        v[e] = (n < span && a >= 0 && a < p.N) ? gb[a] : 0.0f;
+        gv[u][e] = (n < span && a >= 0 && a < p.N) ? gb[a] : 0.0f;
+        gmx = fmaxf(gmx, fabsf(gv[u][e]));
       }
-      gf_f16x8 hi, lo;
-      gf_split8(v, hi, lo);
-      *reinterpret_cast<gf_f16x8*>(s_gz + 16 * k) = hi;
-      *reinterpret_cast<gf_f16x8*>(s_gz + p.gz_plane + 16 * k) = lo;
     }
+    if constexpr (!GEN) {
+      if (p.x) {                                                // (null: 23-bit samples regenerated below, |x| < 1)
+        const float* xb = p.x + (size_t)b * p.N;
+        const int i_end = min(p.N, m0 + P * 64);
+        for (int i = m0 + tid; i < i_end; i += nthr) xmx = fmaxf(xmx, fabsf(xb[i]));
+      }
+    }
+    gmx = wave_max_nonneg_dpp(gmx);
+    xmx = wave_max_nonneg_dpp(xmx);
+    if (lane == 0) { s_wmax[0][wave] = gmx; s_wmax[1][wave] = xmx; }
     // the noise planes: zero, then the samples (a piece's sample i at element 31 + 96 slot + i)
     const int n16 = ((GEN ? 1 : 2) * p.x_part) >> 4;
     for (int k = tid; k < n16; k += nthr) reinterpret_cast<uint4*>(s_x)[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  int g_exp, x_exp = 0;
+  {
+    float gmx = 0.0f, xmx = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { gmx = fmaxf(gmx, s_wmax[0][w]); xmx = fmaxf(xmx, s_wmax[1][w]); }
+    g_exp = pow2_exponent(gmx);
+    if constexpr (!GEN) x_exp = pow2_exponent(xmx);
+  }
+#pragma unroll
+  for (int u = 0; u < kNbGroups; ++u) {
+    const int k = tid + nthr * u;
+    if (k < (span + 8) / 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ldexpf(gv[u][e], -g_exp);
+      gf_f16x8 hi, lo;
+      gf_split8(v, hi, lo);
+      *reinterpret_cast<gf_f16x8*>(s_gz + 16 * k) = hi;
+      *reinterpret_cast<gf_f16x8*>(s_gz + p.gz_plane + 16 * k) = lo;
+    }
+  }
   {
     const int x_lo = p.x_part;
     auto place = [&](int i, float val) {                        // sample i of the row, inside the tile
       const int rel = i - m0;
       const int el = 31 + kGfSlot * (rel >> 6) + (rel & 63);
       _Float16 hi, lo;
+      if constexpr (!GEN) val = ldexpf(val, -x_exp);
       gf_split(val, hi, lo);
       *reinterpret_cast<_Float16*>(s_x + 2 * el) = hi;
       *reinterpret_cast<_Float16*>(s_x + p.x_o + 2 * (el + 1)) = hi;
@@ -1099,6 +1228,14 @@ __global__ __launch_bounds__(512, 6) void noise_bwd_mfma_kernel(NbArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (8 * q + e < i_end) place(8 * q + e, v[e]);
+      }
+    } else if (p.x == nullptr) {                                // DDSP_NOISE_BITS_23: the forward's 23-bit samples again
+      for (int q = (m0 >> 2) + tid; 4 * q < i_end; q += nthr) {
+        const float4 a = noise_quad_at(4u * (uint32_t)q, p.batch_offset + b, p.k0, p.k1, true);
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * q + e < i_end) place(4 * q + e, v[e]);
       }
     } else {
       const float* xb = p.x + (size_t)b * p.N;
@@ -1176,7 +1313,7 @@ __global__ __launch_bounds__(512, 6) void noise_bwd_mfma_kernel(NbArgs p) {
         const int f = f0 + 16 * rg + 4 * g + r;
         if (f < p.F) {
           const size_t at = ((size_t)b * p.F + f) * p.M + band;
-          float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kGfLoScale);
+          float v = ldexpf(acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kGfLoScale), g_exp + x_exp);
           if (p.scale) {
             const float xr = p.mag[at] + p.bias;
             const float y = exp_sigmoid_fast(xr, kLog10, 2.0f, 1e-7f);
@@ -1199,7 +1336,8 @@ bool noise_bwd_mfma_ok(int B, int F, int M, int N, int window_size) {
 }
 
 int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const float* grad_audio, float* grad_magnitudes, int B, int F,
-                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, hipStream_t st) {
+                          int M, int N, int window_size, float bias, int scale, uint64_t seed, uint64_t batch_offset, int bits23,
+                          hipStream_t st) {
   const GiMatrix* m = gi_matrix(M, window_size);
   if (!m || m->KSt != 4 || m->NTb != 5) return DDSP_ERR_LAUNCH;
   const IrGeom g = ir_geom(M, window_size);
@@ -1212,6 +1350,7 @@ int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const flo
   a.scale = scale; a.bias = bias;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32); a.batch_offset = batch_offset;
   const int span = a.NF * a.fs + 128;
+  if ((span + 8) / 8 > 2 * 512) return DDSP_ERR_UNSUPPORTED;     // (the kernel keeps two groups of 8 gradient samples per thread)
   a.gz_plane = (2 * span + 16 + 15) & ~15;
   const int P = a.NF * a.npf;
   const int x_elems = 32 + kGfSlot * P + 2;
@@ -1220,14 +1359,15 @@ int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const flo
   while (((a.x_o / 4) % 32) != 16) a.x_o += 16;
   a.x_part = a.x_o + x_copy;
   a.x_at = 2 * a.gz_plane;
-  a.dh_at = a.x_at + (noise ? 2 : 1) * a.x_part;
+  const bool lo_planes = noise != nullptr || bits23 != 0;       // supplied noise, or 23-bit samples regenerated in the kernel
+  a.dh_at = a.x_at + (lo_planes ? 2 : 1) * a.x_part;
   const size_t lds = (size_t)a.dh_at + 2 * (size_t)a.NF * kNbDhStride * 2;
   if (lds > (size_t)kGfLdsBudget) return DDSP_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((F + a.NF - 1) / a.NF), (unsigned)B);
-  const void* fn = noise ? (const void*)noise_bwd_mfma_kernel<false> : (const void*)noise_bwd_mfma_kernel<true>;
+  const void* fn = lo_planes ? (const void*)noise_bwd_mfma_kernel<false> : (const void*)noise_bwd_mfma_kernel<true>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGfLdsBudget);
   ProfileScope prof(kNoiseBwdTaps, st);
-  if (noise) hipLaunchKernelGGL((noise_bwd_mfma_kernel<false>), grid, dim3(512), lds, st, a);
+  if (lo_planes) hipLaunchKernelGGL((noise_bwd_mfma_kernel<false>), grid, dim3(512), lds, st, a);
   else hipLaunchKernelGGL((noise_bwd_mfma_kernel<true>), grid, dim3(512), lds, st, a);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

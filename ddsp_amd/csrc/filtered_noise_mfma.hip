@@ -114,6 +114,12 @@ struct MfArgs {
   int dbg_block;                    // the block whose times are stamped (DDSP_MF_DBG_BLOCK, default 0)
   int dbg_wave;                     // the FIR wavefront (8 .. 15) whose times are stamped; the producer is dbg_wave - 8
   long long* dbg;                   // block 0's per-tick stamps [16 ticks][3 roles][begin, end] (tools/exp_noise_fir.py), or null
+  // The hi / lo instances (GEN_NOISE = false) serve two callers.  Noise the caller SUPPLIES comes at any scale: x_absmax[row] =
+  // max |noise[row]| (row_absmax_kernel, a launch ahead of this one) gives the power of two that brings the row to [1/2, 1)
+  // before the fp16 split and the outputs back (the FIR is linear in the noise).  And DDSP_NOISE_BITS_23: x == null,
+  // the noise is generated on chip with 23-bit samples (common.h), which need the hi / lo pair as supplied noise does.
+  const float* x_absmax;
+  int bits23;
 };
 
 struct __attribute__((packed, aligned(4))) MfU4f { float x, y, z, w; };        // 16 bytes from a 4-byte aligned address
@@ -201,6 +207,11 @@ __device__ __forceinline__ void mf_put_quad(float4 v, int qd, unsigned char* s_x
 template <bool GEN_NOISE, int NLANES>
 __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const float* __restrict__ x, unsigned char* s_xe,
                                               unsigned char* s_xo, const MfArgs& p) {
+  // supplied noise: the exponent of the row's largest magnitude (a scalar load: the row is wave-uniform)
+  int x_exp = 0;
+  if constexpr (!GEN_NOISE) {
+    if (p.x_absmax) x_exp = pow2_exponent(p.x_absmax[b]);
+  }
   if constexpr (GEN_NOISE) {
     static_assert((8 * kMfRows) % NLANES == 0, "octets per lane");
 #pragma unroll
@@ -233,14 +244,22 @@ __device__ __forceinline__ void mf_noise_tile(int ltid, int b, int z0, const flo
       const int i = z0 - 128 + 4 * qd;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i >= 0 && i < p.N) {
-        const float* src = x + (size_t)b * p.N + i;
-        if (i + 3 < p.N && ((p.N & 3) == 0)) {
-          v = *reinterpret_cast<const float4*>(src);
+        if (x == nullptr) {                                          // (launch-uniform) 23-bit samples made here
+          v = noise_quad_at((uint32_t)i, p.batch_offset + b, p.k0, p.k1, true);
+          if (i + 1 >= p.N) v.y = 0.f;
+          if (i + 2 >= p.N) v.z = 0.f;
+          if (i + 3 >= p.N) v.w = 0.f;
         } else {
-          v.x = src[0];
-          if (i + 1 < p.N) v.y = src[1];
-          if (i + 2 < p.N) v.z = src[2];
-          if (i + 3 < p.N) v.w = src[3];
+          const float* src = x + (size_t)b * p.N + i;
+          if (i + 3 < p.N && ((p.N & 3) == 0)) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            v.x = src[0];
+            if (i + 1 < p.N) v.y = src[1];
+            if (i + 2 < p.N) v.z = src[2];
+            if (i + 3 < p.N) v.w = src[3];
+          }
+          if (x_exp) { v.x = ldexpf(v.x, -x_exp); v.y = ldexpf(v.y, -x_exp); v.z = ldexpf(v.z, -x_exp); v.w = ldexpf(v.w, -x_exp); }
         }
       }
       mf_put_quad<true>(v, qd, s_xe, s_xo);
@@ -549,6 +568,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     mf_f32x4 kept = {0.f, 0.f, 0.f, 0.f};      // the incomplete left half of this wavefront's first pair (cw >= 1), last tile
     float* kept_ot = nullptr;                  // where it goes: the tile's base pointer, offset and bounds of the previous tick
     long kept_n = 0;
+    int kept_exp = 0;                          // (supplied noise: the exponent its row was normalised by)
     const int xsel = ((mi & 1) ? 0 : kXO) + 2 * kMfXStride * 2 * p_first;       // i odd -> u even -> copy E
     const int second = mg >> 1;
     // u even -> copy E, dword u / 2; u odd -> copy O, dword (u + 1) / 2 (u's parity is the lane's: 79 - i).  Step c
@@ -565,7 +585,11 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
     auto flush_kept = [&](int parity) {
       if (cw >= 1 && kept_ot != nullptr && mi < 8) {
         const float4 cr = *reinterpret_cast<const float4*>(&s_carry[parity][cw - 1][lane_off]);
-        const float v[4] = {kept[0] + cr.x, kept[1] + cr.y, kept[2] + cr.z, kept[3] + cr.w};
+        float v[4] = {kept[0] + cr.x, kept[1] + cr.y, kept[2] + cr.z, kept[3] + cr.w};
+        if constexpr (!GEN_NOISE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ldexpf(v[r], kept_exp);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kept_n + lane_off + r >= 0 && kept_n + lane_off + r < p.N) kept_ot[lane_off + r] = v[r];
@@ -602,6 +626,10 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         // every store of this wavefront inside [0, N) and 8-byte aligned: no per-element checks
         const bool interior = n_tile + 128 >= 0 && n_tile + 128 * 4 <= (long)p.N && (((p.start | p.N) & 1) == 0);
         float* __restrict__ ot = o + n_tile;                               // wave-uniform base; lanes add a 32-bit offset
+        int o_exp = 0;                                                     // supplied noise: its row's exponent back at the stores
+        if constexpr (!GEN_NOISE) {
+          if (p.x_absmax) o_exp = pow2_exponent(p.x_absmax[b]);
+        }
         mf_f32x4 carry = {0.f, 0.f, 0.f, 0.f};
         int a_hi[2], a_lo[2], b_ptr = b_ptr0;
         DDSP_KEEP_IN_VGPR(b_ptr);
@@ -686,13 +714,18 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
                 kept = comb;
               } else if (mi < 8) {
                 const int idx = lane_off + 128 * it;                         // out index n = n_tile + idx
+                mf_f32x4 st4 = comb;
+                if constexpr (!GEN_NOISE) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) { const float v = comb[r]; st4[r] = ldexpf(v, o_exp); }
+                }
                 if (kInterior) {
-                  *reinterpret_cast<float2*>(ot + idx) = make_float2(comb[0], comb[1]);
-                  *reinterpret_cast<float2*>(ot + idx + 2) = make_float2(comb[2], comb[3]);
+                  *reinterpret_cast<float2*>(ot + idx) = make_float2(st4[0], st4[1]);
+                  *reinterpret_cast<float2*>(ot + idx + 2) = make_float2(st4[2], st4[3]);
                 } else {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
-                    const float v = comb[r];
+                    const float v = st4[r];
                     if (n_tile + idx + r >= 0 && n_tile + idx + r < p.N) ot[idx + r] = v;
                   }
                 }
@@ -714,6 +747,7 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
         else pipeline(std::false_type{});
         kept_ot = ot;
         kept_n = n_tile;
+        kept_exp = o_exp;
       } else {
         kept_ot = nullptr;
       }
@@ -726,16 +760,41 @@ __global__ __launch_bounds__(64 * kMfWaves, 4) void noise_mfma65_kernel(
 #undef DDSP_MF_TILE
 }
 
-bool noise_mfma65_ok(int F, int M, int N, int padding, const void* noise) {
+// (scale = 0 - magnitudes that are not squashed by exp_sigmoid, at any scale - goes to the general kernels, which normalise what
+// they split: this kernel's designers split the magnitudes as they come)
+bool noise_mfma65_ok(int F, int M, int N, int padding, const void* noise, int scale) {
   const int frame_size = (N + F - 1) / F;
-  return M == 65 && padding == 0 && frame_size >= 64 && (frame_size % 64) == 0 && frame_size <= 4096 &&
+  return scale != 0 && M == 65 && padding == 0 && frame_size >= 64 && (frame_size % 64) == 0 && frame_size <= 4096 &&
          (N + frame_size - 1) / frame_size == F && (noise == nullptr || (((uintptr_t)noise) & 15) == 0);
+}
+
+// max |x[row]| of every row: what supplied noise is normalised by (one block per row; a parity / FIRFilter entry, not a hot path)
+__global__ __launch_bounds__(1024) void row_absmax_kernel(const float* __restrict__ x, int N, float* __restrict__ out) {
+  __shared__ float s_m[16];
+  const float* row = x + (size_t)blockIdx.x * N;
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < N; i += 1024) m = fmaxf(m, fabsf(row[i]));
+  m = wave_max_nonneg_dpp(m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = 0.0f;
+    for (int w = 0; w < 16; ++w) r = fmaxf(r, s_m[w]);
+    out[blockIdx.x] = r;
+  }
 }
 
 int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audio, float* ctl_magnitudes, int B, int F,
                         int N, int start, float initial_bias, int scale, uint64_t seed, uint64_t batch_offset,
-                        long long* dbg, hipStream_t st) {
+                        long long* dbg, int bits23, float* row_scratch /* B floats */, hipStream_t st) {
   MfArgs q;
+  q.x_absmax = nullptr; q.bits23 = bits23;
+  if (noise) {
+    if (!row_scratch) return DDSP_ERR_WORKSPACE;
+    hipLaunchKernelGGL(row_absmax_kernel, dim3((unsigned)B), dim3(1024), 0, st, noise, N, row_scratch);
+    q.x_absmax = row_scratch;
+  }
+  const bool lo_planes = noise != nullptr || bits23 != 0;          // the hi / lo instances: supplied noise, or 23-bit samples made on chip
   q.N = N; q.F = F; q.start = start; q.bias = initial_bias; q.scale = scale;
   q.fs = (N + F - 1) / F; q.inv_fs = 1.0f / (float)q.fs;
   q.k0 = (uint32_t)seed; q.k1 = (uint32_t)(seed >> 32); q.batch_offset = batch_offset;
@@ -764,8 +823,8 @@ int launch_noise_mfma65(const float* magnitudes, const float* noise, float* audi
 #define DDSP_LAUNCH_MF(GEN, FS64)                                                                                      \
   hipExtLaunchKernelGGL((noise_mfma65_kernel<GEN, FS64>), grid, dim3(64 * kMfWaves), 0, st, ev0, ev1, 0, magnitudes, noise, \
                         ctl_magnitudes, audio, q)
-  if (q.fs == 64) { if (noise) DDSP_LAUNCH_MF(false, true); else DDSP_LAUNCH_MF(true, true); }
-  else { if (noise) DDSP_LAUNCH_MF(false, false); else DDSP_LAUNCH_MF(true, false); }
+  if (q.fs == 64) { if (lo_planes) DDSP_LAUNCH_MF(false, true); else DDSP_LAUNCH_MF(true, true); }
+  else { if (lo_planes) DDSP_LAUNCH_MF(false, false); else DDSP_LAUNCH_MF(true, false); }
 #undef DDSP_LAUNCH_MF
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

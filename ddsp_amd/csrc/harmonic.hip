@@ -25,6 +25,7 @@
 #include "harmonic_bwd_table.h"
 #include "harmonic_bwd_chain.h"
 #include "harmonic_table.h"
+#include "filtered_noise_general.h"
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
@@ -785,8 +786,12 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return DDSP_ERR_LAUNCH;
   hipEvent_t set_done = nullptr;
+  // The lock is held from the wait on the set's last user THROUGH the launch and the record behind it (with the
+  // wait and the record locked separately, a second host thread handed the same set could slip in between - wait on the
+  // event's OLD record and launch beside this one on the same g_sched set).  ~2 us of host time, on a path that is not the
+  // default one.
+  std::unique_lock<std::mutex> set_guard(set_lock);
   {
-    std::lock_guard<std::mutex> guard(set_lock);
     SetEvents& se = set_events[dev];
     if (se.made[p.sched_set]) {
       (void)hipStreamWaitEvent(st, se.done[p.sched_set], 0);      // (recorded behind the set's last launch, below)
@@ -820,11 +825,8 @@ static int launch_fused(const float* amps, const float* hd, const float* f0, flo
   else return DDSP_ERR_UNSUPPORTED;
 #undef DDSP_LAUNCH_FUSED_LPR
 #undef DDSP_LAUNCH_FUSED
-  {
-    // (under the lock: the launch-to-record window of one thread must not let another thread wait on the event's OLD record)
-    std::lock_guard<std::mutex> guard(set_lock);
-    if (hipEventRecord(set_done, st) != hipSuccess) return DDSP_ERR_LAUNCH;
-  }
+  if (hipEventRecord(set_done, st) != hipSuccess) return DDSP_ERR_LAUNCH;       // (still under set_guard)
+  set_guard.unlock();
   return check_launch();
 }
 // fused path: hop a multiple of 64, K a multiple of 4 (16-byte rows), caller buffers 16-byte aligned
@@ -1410,4 +1412,16 @@ extern "C" int ddsp_harmonic_signal_tf_order_f32(const float* ctl_amp, const flo
                      audio, F, K, N, amp_linear ? 1 : N / F, (float)sample_rate,
                      (float)(sample_rate / 2.0), amp_linear, (flags & DDSP_HARM_ANGULAR_CUMSUM) ? 1 : 0);
   return check_launch();
+}
+
+// The constant tables of the matrix-core kernels are made on the host and copied to the device - synchronously, with hipMalloc -
+// the first time a shape needs them (harmonic_table.hip: wt_upload_fragments; harmonic_bwd_table.hip: bt_fragments;
+// filtered_noise_general.hip: gi_matrix).  That is illegal inside a HIP-graph stream capture and synchronises the device
+// (ADVICE r4): a caller that captures graphs, or that must not stall, calls this once per device and shape first.
+extern "C" int ddsp_prepare(int n_harmonics, int n_noise_bands, int window_size) {
+  if (n_harmonics > 0 && n_harmonics <= 200) {
+    if (ddsp::harm_table_prepare(n_harmonics) != 0 || ddsp::harm_bwd_table_prepare(n_harmonics) != 0) return DDSP_ERR_LAUNCH;
+  }
+  if (n_noise_bands >= 2 && ddsp::noise_general_prepare(n_noise_bands, window_size) != 0) return DDSP_ERR_LAUNCH;
+  return DDSP_OK;
 }

@@ -15,4 +15,7 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
                           const float* hd = nullptr, float* grad_amp = nullptr, float* grad_hd = nullptr, unsigned flags = 0,
                           int inputs_are_controls = 0);
 
+// the transposed constant factor a K-harmonic backward launch needs, on the current device NOW (ddsp_prepare); 0 on success
+int harm_bwd_table_prepare(int K);
+
 }  // namespace ddsp

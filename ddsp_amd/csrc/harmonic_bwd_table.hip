@@ -118,7 +118,7 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
   __shared__ __attribute__((aligned(16))) float2 s_g[kBtFrames][kBtT];            // 32 KB
   __shared__ __attribute__((aligned(16))) _Float16 s_b[2][2][16][kBtCol];         // [hi / lo][parity][column][n]: 17 KB
   __shared__ float s_corr[kBtFrames][2][kBtMaxCross];
-  __shared__ int s_k[kBtFrames][4];                                               // kA, kN, direct
+  __shared__ int s_k[kBtFrames][4];                                               // kA, kN, direct, the exponent G was normalised by
   __shared__ float s_out[16][kOutStride];                                                // step 3's results: [column][harmonic]
   using C = BtPoly<W>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,7 +203,9 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
     auto sample = [&](int t0, double& cyc, float& lerp, float& c_cur, float& c_next, bool& live) {
       const int r = t0 + lane;
       live = r < p.hop;
-      const double rr = (double)r;
+      // (lanes past the frame's last sample - frame sizes that are not multiples of 64 - carry that sample's phase: the ramp
+      // extrapolated past the frame can run backwards when f0 falls steeply)
+      const double rr = (double)min(r, p.hop - 1);
       cyc = th0 + (rr + 1.0) * (wj + dw * rr);
       lerp = (float)r * inv_hop;
       const float w_next = p.amp_linear ? lerp : 0.5f - 0.5f * __builtin_amdgcn_cosf(0.5f * lerp);
@@ -230,7 +232,10 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
         const int i0 = i_abs & (kBtT - 1);
         const int rev_abs = i_abs >> 9;
         const int rev = rev_abs - __builtin_amdgcn_readfirstlane(rev_abs);
-        const int rev_last = __builtin_amdgcn_readlane(rev, 63);
+        // the revolutions the tile's LIVE samples span: positions grow along the frame, so the last live lane holds the last
+        // (lane 63 of a frame's last tile is past the frame when hop % 64 != 0: taken from there, live lanes' turns were
+        // skipped and their share of G dropped - ADVICE r4)
+        const int rev_last = __builtin_amdgcn_readlane(rev, min(63, p.hop - 1 - t0));
         const float zz = z * z;
         float w_lo[W / 2], w_hi[W / 2];
 #pragma unroll
@@ -327,18 +332,30 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
 #ifndef DDSP_BT_NO_FOLD
   if (has_frame) {
     const float2* G = &s_g[wave][0];
+    float v[2][2][2];                                                           // [half][parity: odd k, even k][P, Q]
+    float mx = 0.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int n = lane + 64 * h;
       const float2 g0 = G[bt_swz(n)], g1 = G[bt_swz(kBtT - 1 - n)], g2 = G[bt_swz(kBtT / 2 - 1 - n)], g3 = G[bt_swz(kBtT / 2 + n)];
       const float ax = g0.x - g1.x, ay = g0.y - g1.y, bx = g2.x - g3.x, by = g2.y - g3.y;
-      const float v[2][2] = {{ax + bx, ay + by}, {ax - bx, ay - by}};           // [parity: odd k, even k][P, Q]
+      v[h][0][0] = ax + bx; v[h][0][1] = ay + by; v[h][1][0] = ax - bx; v[h][1][1] = ay - by;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[h][0][0]), fabsf(v[h][0][1]))), fmaxf(fabsf(v[h][1][0]), fabsf(v[h][1][1])));
+    }
+    // G carries the scale of dL/d audio, whatever it is (loss scaling, sum-reduced losses, vanishing gradients): the frame's
+    // four columns are brought to [1/2, 1) by a power of two before the fp16 hi / lo split and the products taken back by it
+    // in step 3 - the result is as scale invariant as the plain sum's (3e4 overflowed, 1e-10 lost 7 %)
+    const int ge = pow2_exponent(wave_max_nonneg_dpp(mx));
+    if (lane == 0) s_k[wave][3] = ge;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = lane + 64 * h;
 #pragma unroll
       for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           _Float16 hi, lo;
-          bt_split(v[pa][q], hi, lo);
+          bt_split(ldexpf(v[h][pa][q], -ge), hi, lo);
           s_b[0][pa][2 * wave + q][n] = hi;
           s_b[1][pa][2 * wave + q][n] = lo;
         }
@@ -368,12 +385,12 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
     // D[row 4 g + r = harmonic k' of the tile][column i16 = 2 frame + quantity] -> rows of the P / Q workspace through LDS
     // (straight from the accumulators every lane stored 4 bytes into a cache line of its own)
     const int fr = i16 >> 1, q = i16 & 1;
-    const int fkA = s_k[fr][0], fkN = s_k[fr][1], fdirect = s_k[fr][2];
+    const int fkA = s_k[fr][0], fkN = s_k[fr][1], fdirect = s_k[fr][2], fge = s_k[fr][3];
     if (!fdirect) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k0 = 2 * (16 * mt + 4 * g4 + r) + par;                 // 0-based harmonic index (harmonic k0 + 1)
-        float v = acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kBtLoScale);
+        float v = ldexpf(acc[r] + (acc_hl[r] + acc_lh[r]) * (1.0f / kBtLoScale), fge);
         if (k0 >= fkN) v = 0.0f;
         else if (k0 >= fkA) v -= s_corr[fr][q][k0 - fkA];
         if (k0 < kOutStride) s_out[i16][k0] = v;
@@ -467,6 +484,8 @@ static const bt_u32x4* bt_fragments(int W) {
   return cache[wi][dev];
 }
 
+int harm_bwd_table_prepare(int K) { return bt_fragments(K <= 100 ? 6 : (K <= 128 ? 8 : 10)) ? 0 : 1; }
+
 bool harm_bwd_table_ok(int F, int K, int N) {
   static const bool off = [] { const char* e = getenv("DDSP_EXP_HARM_BWD"); return e && e[0] == 'p'; }();   // "plain": the sums
   const int hop = F > 0 ? N / F : 0;
@@ -495,7 +514,10 @@ int launch_harm_bwd_table(const float* f0_hz, const double* theta0, const float*
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     return v;
   }();
+  a.dbg = nullptr;
+#ifdef DDSP_BT_TIMELINE      // tools/exp_bwd_timeline.py's build only (the product does not take raw pointers from the environment)
   { const char* e = getenv("DDSP_EXP_BT_TIMELINE"); a.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   a.amplitudes = amplitudes; a.hd = hd; a.grad_amp = grad_amp; a.grad_hd = grad_hd;
   a.chain.F = F; a.chain.K = K; a.chain.N = N; a.chain.hop = a.hop;
   a.chain.sample_rate = a.sample_rate; a.chain.nyquist = a.nyquist; a.chain.amp_linear = amp_linear;

@@ -17,4 +17,8 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
                       float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
                       hipStream_t st);
 
+// the constant fragment sets a K-harmonic launch needs, made and copied to the current device NOW (ddsp_prepare: the copy is
+// synchronous and must not fall inside a HIP-graph capture); 0 on success
+int harm_table_prepare(int K);
+
 }  // namespace ddsp

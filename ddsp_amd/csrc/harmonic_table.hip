@@ -1397,6 +1397,8 @@ static int wt_upload_fragments(int W) {
   return 0;
 }
 
+int harm_table_prepare(int K) { return wt_upload_fragments(K <= 100 ? 6 : K <= 128 ? 8 : 10); }
+
 int launch_harm_table(const float* amplitudes, const float* hd, const float* f0, float* audio, float* ctl_amp,
                      float* ctl_hd, const float* add_in, int B, int F, int K, int N, int sample_rate, unsigned flags,
                      hipStream_t st) {

@@ -307,6 +307,12 @@ class FilteredNoise(processors.Processor):
   here noise is Philox4x32-10 keyed by (seed, call counter), generated inside the FIR
   kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
 
+  `noise_bits` is the other extension: 11 (the default) draws every sample from 2048 equally spaced levels in (-1, 1) -
+  zero mean, variance 1/3, white, each value exactly an fp16 number, which is what lets the matrix-core FIR carry its
+  noise operand in one fp16 plane; 23 draws the 2^23 levels tf.random.uniform's fp32 samples have (synths.py:192-193),
+  carried as fp16 hi / lo pairs (a third more matrix products and twice the LDS traffic of that operand: bench.py's
+  `fnoise_full_resolution` block prices it).  Both are Philox4x32-10 streams documented in include/ddsp_amd.h.
+
   `kernel` (an attribute, like Harmonic.kernel; the constructor is the reference's): 'auto' runs the canonical filter
   (65 bands, full window, frames of 64 c samples) on noise_mfma65_kernel - IR design and the time-varying FIR on the fp16
   matrix cores (hi/lo-split operands, fp32 accumulation); 'vector' keeps the FIR on the vector ALUs
@@ -320,13 +326,18 @@ class FilteredNoise(processors.Processor):
                scale_fn=core.exp_sigmoid,
                initial_bias=-5.0,
                name='filtered_noise',
-               seed=0):
+               seed=0,
+               noise_bits=11):
     super().__init__(name=name)
+    if noise_bits not in (11, 23):
+      raise ValueError('noise_bits must be 11 (2048 levels, the default) or 23 (the 2^23 levels of tf.random.uniform), '
+                       'got {!r}'.format(noise_bits))
     self.n_samples = n_samples
     self.window_size = window_size
     self.scale_fn = scale_fn
     self.initial_bias = initial_bias
     self.seed = int(seed)
+    self.noise_bits = int(noise_bits)
     self._calls = 0
     self._ws = core.Workspace()
     self._ws_bwd = core.Workspace()
@@ -351,11 +362,12 @@ class FilteredNoise(processors.Processor):
     return {'magnitudes': ctl}
 
   def _ir_flag(self):
+    bits = _lib.NOISE_BITS_23 if self.noise_bits == 23 else 0
     if self.kernel == 'auto':
-      return 0
+      return bits
     if self.kernel != 'vector':
       raise ValueError("FilteredNoise.kernel must be 'auto' or 'vector', got {!r}".format(self.kernel))
-    return _lib.NOISE_FIR_VECTOR_ALU
+    return _lib.NOISE_FIR_VECTOR_ALU | bits
 
   def _next_seed(self):
     s = (self.seed & 0xFFFFFFFF) | ((self._calls & 0xFFFFFFFF) << 32)
@@ -455,7 +467,8 @@ class FilteredNoise(processors.Processor):
         magnitudes.data_ptr(), noise.data_ptr() if noise is not None else None,
         grad_audio.data_ptr(), grad_mag.data_ptr(), ws.data_ptr(), ws.numel(), b, f, m, n,
         int(self.window_size), float(self.initial_bias),
-        _lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0, seed, 0, core._stream())
+        (_lib.NOISE_SCALE_EXP_SIGMOID if fuse_scale else 0) | (_lib.NOISE_BITS_23 if self.noise_bits == 23 else 0),
+        seed, 0, core._stream())
     if rc == -3:
       raise NotImplementedError('FilteredNoise backward needs n_samples / n_frames <= 8192, at most 4097 '
                                 'bands and an impulse response of at least 3 taps')

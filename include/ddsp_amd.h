@@ -52,9 +52,22 @@ extern "C" {
                                              keep the time-varying FIR on the vector ALUs (noise_fused65_kernel) instead of the
                                              default matrix-core kernel (noise_mfma65_kernel: IR design and FIR as fp16 hi/lo-split
                                              MFMA products, fp32 accumulation) */
+#define DDSP_NOISE_BITS_23 0x10u          /* generated noise (noise == NULL) with 23-bit samples - the 2^23 levels of the reference's
+                                             tf.random.uniform (ddsp/synths.py:192-193) - instead of the default 2048 levels
+                                             (FilteredNoise(noise_bits=23)); see ddsp_filtered_noise_f32.  The backward call
+                                             takes the same flag so that it regenerates the same samples. */
 
 /* Library / build identification: "ddsp_amd <version> gfx950". */
 const char* ddsp_version(void);
+
+/* No entry point of this library synchronises or allocates, with ONE exception: the constant operand tables of the
+ * matrix-core kernels (the wavetable kernels' sine fragments per device; the general FilteredNoise / frequency_impulse_response
+ * kernels' design matrix per device, band count and window size) are made on the host and copied to the device, synchronously,
+ * the first time a shape needs them.  ddsp_prepare makes them NOW for the current device: call it before capturing a HIP graph
+ * (a synchronous copy inside a capture is an error) or before a latency-critical first call.  n_harmonics <= 0 / n_noise_bands
+ * < 2 skip their part; shapes whose kernels need no tables (more than 200 harmonics, the canonical 65-band filter with the
+ * full window, whose tables are compile-time constants - it still has a design matrix for its backward pass) are no-ops. */
+int ddsp_prepare(int n_harmonics, int n_noise_bands, int window_size);
 
 /* ------------------------------------------------------------------------------------
  * Harmonic.get_controls  (ddsp/synths.py:94-121; core.exp_sigmoid core.py:386-404,
@@ -183,11 +196,25 @@ int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* impu
  * core.py:1628-1655 -> fft_convolve :1382-1473, crop_and_compensate_delay :1338-1379).
  *   magnitudes [B,F,M]: raw (flags has DDSP_NOISE_SCALE_EXP_SIGMOID: get_controls is
  *                       fused in) or controls (flag clear: pure get_signal).
- *   noise      [B,N] or NULL.  NULL: uniform noise in [-1,1) is generated on chip
- *              (Philox4x32-10, counter=(sample/4, batch_offset+row), key=seed), the
- *              stand-in for the reference's tf.random.uniform (synths.py:192-193).
+ *   noise      [B,N] or NULL.  NULL: uniform noise in (-1,1) is generated on chip, the
+ *              stand-in for the reference's tf.random.uniform (synths.py:192-193), whose
+ *              stateful stream cannot be reproduced outside TensorFlow.  The generator is
+ *              Philox4x32-10 with key = (seed low word, seed high word) and counter
+ *              (n >> 3, batch_offset + row, c2, 0) for sample n of a row; this library's
+ *              contract (csrc/common.h; oracle/ddsp_oracle.py::device_uniform_noise
+ *              restates both forms bit for bit):
+ *                default (11 bits, c2 = 0): eight samples per block; sample n is the
+ *                  11-bit field k = bits [10:0] (n even) or [26:16] (n odd) of word
+ *                  (n >> 1) & 3, value (2 k - 2047) / 2048 - 2048 equally spaced levels,
+ *                  zero mean, variance 1/3 to 2e-7, every value exactly an fp16 number
+ *                  (the matrix-core FIR then needs no lo part for its noise operand);
+ *                DDSP_NOISE_BITS_23 (c2 = 1 + ((n >> 2) & 1)): four samples per block;
+ *                  sample n is word n & 3: its top 23 bits as the mantissa of u in [1,2),
+ *                  value 2 u - 3 - the 2^23 levels TensorFlow's fp32 uniforms have.
  *              Non-NULL is the parity entry: the same maths as effects.FIRFilter
- *              (ddsp/effects.py:311-324) / core.frequency_filter on supplied audio.
+ *              (ddsp/effects.py:311-324) / core.frequency_filter on supplied audio, at
+ *              any scale (it is normalised by a power of two before the fp16 hi/lo
+ *              split of the matrix-core kernels and the outputs are scaled back).
  *   audio      [B,N] out.   ctl_magnitudes: NULL or [B,F,M] out (controls dict).
  * Frames: frame_size = ceil(N/F) and ceil(N/frame_size) must equal F (the reference's
  * ValueError, core.py:1451-1457) else DDSP_ERR_BAD_SHAPE.
@@ -320,9 +347,12 @@ int ddsp_spectral_terms_f32(const float* target_mag, const float* value_mag, con
 int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                void* stream);
 
-/* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N]. */
+/* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N].
+ * _ex: noise_bits = 11 (the default form) or 23 (DDSP_NOISE_BITS_23's). */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);
+int ddsp_uniform_noise_ex_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
+                              int noise_bits, void* stream);
 
 /* processors.Add.get_signal (ddsp/processors.py:174-176): out = a + b, n elements. */
 int ddsp_add_f32(const float* signal_one, const float* signal_two, float* out, size_t n,

@@ -113,6 +113,24 @@ def measure(clips_per_proc, procs, n_frames, n_harmonics, n_bands, n_samples, sa
   return result
 
 
+def measure_config0(n_clips=3, n_frames=1000, n_harmonics=60, n_samples=64000, sample_rate=16000, f0=200.0):
+  """BASELINE.json configs[0]: synths.Harmonic alone, batch 1, 16 kHz, 1000 frames, 60 harmonics
+  (gin/models/solo_instrument.gin:18-20), one process - the reference's own CPU-runnable case, as the numpy fp32 port of
+  its op chain runs it (f0 = 200 + N(0,1) Hz, the reference tests' regime: processors_test.py:40)."""
+  from oracle import ddsp_oracle as O
+  x = _make_inputs(n_clips + 1, n_frames, n_harmonics, 2, f0, seed=60)
+  O.harmonic(x['amplitudes'][:1], x['harmonic_distribution'][:1], x['f0_hz'][:1], n_samples, sample_rate)     # warm-up
+  t0 = time.perf_counter()
+  for i in range(1, n_clips + 1):
+    s = slice(i, i + 1)
+    O.harmonic(x['amplitudes'][s], x['harmonic_distribution'][s], x['f0_hz'][s], n_samples, sample_rate)
+  dt = (time.perf_counter() - t0) / n_clips
+  return {'value': n_samples / dt / 1e6, 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port', 'ms_per_clip': dt * 1e3,
+          'sample': '%d clips of BASELINE configs[0] (synths.Harmonic, batch 1, %d samples @ %d Hz, %d frames, %d harmonics, '
+                    'f0 = %g + N(0,1) Hz) through oracle/ddsp_oracle.py in one process' %
+                    (n_clips, n_samples, sample_rate, n_frames, n_harmonics, f0)}
+
+
 if __name__ == '__main__':
   # worker: python -m oracle.cpu_baseline <clips> <n_frames> <n_harmonics> <n_bands> <n_samples> <sample_rate> <f0> <seed>
   _clips, _f, _k, _m, _n, _sr = (int(v) for v in sys.argv[1:7])

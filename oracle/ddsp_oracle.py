@@ -927,15 +927,29 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=NOISE_ROUNDS):
   return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
 
 
-def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0):
-  """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL (csrc/common.h, "the generated noise"): 2048 equally
-  spaced levels u = (2 k - 2047) / 2048 - zero mean, variance 1/3, every value an fp16 number -, k an 11-bit field of a
-  Philox4x32 word; eight samples per block: sample n of a row is field ((n >> 1) & 3, n & 1) of block n >> 3, bits [10:0] of
-  the word for even n, [26:16] for odd n.  (Rounds 1-3: 23-bit uniforms, four per block.)"""
+def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=11):
+  """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL (csrc/common.h, "the generated noise"; the contract
+  text is in include/ddsp_amd.h).  noise_bits=11 (the default): 2048 equally spaced levels u = (2 k - 2047) / 2048 - zero mean,
+  variance 1/3, every value an fp16 number -, k an 11-bit field of a Philox4x32 word; eight samples per block: sample n of a
+  row is field ((n >> 1) & 3, n & 1) of block (n >> 3, row, 0, 0), bits [10:0] of the word for even n, [26:16] for odd n.
+  noise_bits=23 (DDSP_NOISE_BITS_23, FilteredNoise(noise_bits=23)): the 2^23 levels of tf.random.uniform's fp32 samples
+  (ddsp/synths.py:192-193) - sample n is word n & 3 of block (n >> 3, row, 1 + ((n >> 2) & 1), 0), its top 23 bits the
+  mantissa of u in [1, 2), value 2 u - 3 (as rounds 1-3 made them, four per block)."""
   n_oct = -(-n_samples // 8)
   octet = np.arange(n_oct, dtype=np.uint64)[None, :].repeat(batch_size, 0)
   row = (np.arange(batch_size, dtype=np.uint64) + np.uint64(batch_offset))[:, None]
   row = np.broadcast_to(row, octet.shape)
+  if noise_bits == 23:
+    halves = []
+    for half in (1, 2):                                                            # samples 8 q .. + 3, then 8 q + 4 .. + 7
+      words = philox4x32(octet, row, np.full_like(octet, half), np.zeros_like(octet),
+                         seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, NOISE_ROUNDS)
+      halves.append(np.stack(words, axis=-1).astype(np.uint32))                    # [B, n_oct, 4]
+    bits = np.stack(halves, axis=2).reshape(batch_size, n_oct * 8)[:, :n_samples]
+    u = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).astype(np.uint32).view(np.float32)
+    return (u * np.float32(2.0) - np.float32(3.0)).astype(np.float32)              # exact: u 2 in [2, 4), spacing 2^-22
+  if noise_bits != 11:
+    raise ValueError('noise_bits must be 11 or 23')
   words = philox4x32(octet, row, np.zeros_like(octet), np.zeros_like(octet),
                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, NOISE_ROUNDS)
   w = np.stack(words, axis=-1).astype(np.uint32)                                   # [B, n_oct, 4]

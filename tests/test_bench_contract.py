@@ -174,8 +174,9 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
       return add_signal
 
   class _Noise:
-    def __init__(self, n_samples, window_size, seed):
+    def __init__(self, n_samples, window_size, seed, noise_bits=11):
       self.n = n_samples
+      calls.setdefault('noise_bits', set()).add(noise_bits)
 
     def __call__(self, magnitudes):
       calls['noise'] += 1
@@ -264,9 +265,36 @@ def _mock_device(monkeypatch, bench, calls):
       calls['harm'] = calls.get('harm', 0) + 1
       return torch.zeros(amplitudes.shape[0], self.n)
 
+    def call_add(self, amplitudes, harmonic_distribution, f0_hz, add_signal):
+      calls['fused'] = calls.get('fused', 0) + 1
+      return add_signal.clone()
+
+  class _Loss:
+    def __init__(self, **kwargs):
+      calls['loss_kwargs'] = kwargs
+
+    def __call__(self, target, audio):
+      calls['loss'] = calls.get('loss', 0) + 1
+      return (audio * 0.0).sum()
+
+  class _Reverb:
+    def __init__(self, trainable=False, reverb_length=48000, add_dry=True):
+      self.trainable, self._ir = trainable, None
+
+    def build(self, device=None):
+      pass
+
+    def __call__(self, audio, ir=None):
+      assert (ir is None) == self.trainable
+      calls['reverb'] = calls.get('reverb', 0) + 1
+      return audio
+  monkeypatch.setattr(ddsp_amd.losses, 'SpectralLoss', _Loss)
+  monkeypatch.setattr(ddsp_amd.effects, 'Reverb', _Reverb)
+
   class _Noise:
-    def __init__(self, n_samples, window_size, seed):
+    def __init__(self, n_samples, window_size, seed, noise_bits=11):
       self.n = n_samples
+      calls.setdefault('noise_bits', set()).add(noise_bits)
 
     def __call__(self, magnitudes):
       calls['noise'] = calls.get('noise', 0) + 1
@@ -305,6 +333,38 @@ def test_main_multi_rank_branches_with_device_and_collectives_mocked_out(bench, 
   with pytest.raises(SystemExit, match='WORLD_SIZE'):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4'])
     bench.main()
+
+
+def test_main_other_configs_blocks_with_the_device_mocked_out(bench, monkeypatch, capsys):
+  """The default-shape run's extra blocks - configs_2 (SpectralLoss), configs_3 (Reverb, one trainable impulse response and one per
+  clip), fnoise_full_resolution (noise_bits=23) - end to end with every device call replaced by a stand-in (these
+  blocks must be in the driver's line; a NameError here would only show on the GPU box at round end)."""
+  calls = {}
+  _mock_device(monkeypatch, bench, calls)
+  monkeypatch.setenv('WORLD_SIZE', '1')
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--steps', '3', '--warmup', '1', '--settle', '0'])
+  bench.main()
+  out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')]
+  assert len(out) == 1
+  line = json.loads(out[0])
+  assert 'aux_error' not in line, line.get('aux_error')
+  for key in ('configs_1', 'configs_4', 'configs_2', 'configs_3', 'fnoise_full_resolution'):
+    assert key in line and 'error' not in line[key], (key, line.get(key))
+    blk = line[key]
+    assert blk['ms_per_step'] > 0 and blk['value'] > 0 and 0 < blk['whole_step']['frac'] and blk['whole_step']['algorithmic_bytes'] > 0
+  c2, c3, fr = line['configs_2'], line['configs_3'], line['fnoise_full_resolution']
+  assert c2['batch_per_gpu'] == 128 and c3['batch_per_gpu'] == 128 and fr['batch_per_gpu'] == 128
+  # algorithmic bytes: the DAG's controls in and one audio stream out (14.44 B / sample at this shape), + what the caller reads / writes
+  synth = 4 * 128 * (1000 * 102 + 1000 * 65 + 64000)
+  assert c2['whole_step']['algorithmic_bytes'] == synth + 8 * 128 * 64000
+  assert c3['whole_step']['algorithmic_bytes'] == synth + 8 * 128 * 64000 + 4 * 48000
+  assert c3['per_clip_ir']['whole_step']['algorithmic_bytes'] == synth + 8 * 128 * 64000 + 4 * 48000 * 128
+  assert fr['whole_step']['algorithmic_bytes'] == line['roofline']['whole_step']['algorithmic_bytes']
+  assert 'kernel_breakdown_us' in c2 and 'kernel_breakdown_us' in c3 and c2['with_gradient_wrt_audio']['ms_per_step'] > 0
+  assert 'cost_of_the_twelve_bits_us' in fr and fr['headline_ms_per_step'] == line['ms_per_step']
+  assert calls['noise_bits'] == {11, 23} and calls['loss'] > 10 and calls['reverb'] > 20 and calls['fused'] > 30
+  assert calls['loss_kwargs'] == {'logmag_weight': 1.0}
+  assert '2048 levels' in line['config']['workload']
 
 
 def test_cpu_baseline_leg_runs_concurrent_workers_and_falls_back(monkeypatch):
@@ -355,6 +415,29 @@ def test_default_shape_carries_configs_1_and_configs_4_two_ranks():
   assert c4['batch_per_gpu'] == 32 and '200 harmonics' in c4['workload'] and c4['steps'] == 50
   assert c4['whole_step']['algorithmic_bytes'] == 4 * 32 * (2500 * 202 + 480000 + 2500 * 65 + 480000)
   assert c4['value'] == pytest.approx(2 * 32 * 480000 / (c4['ms_per_step'] * 1e-3) / 1e6) and 'one_stream' in c4
+
+
+def test_eight_ranks_dry_run_shards_of_the_sharded_configs_and_a_separate_gather_time():
+  """the 8-GPU launch as the driver makes it, dry (gloo, no device): `n_gpus` = 8, every rank's rows of
+  BASELINE's sharded configurations as ddsp_amd.distributed.shard_bounds hands them out - configs[3] 1024 -> 128 per GPU,
+  configs[4] 256 -> 32, the headline 1024 -> 128: contiguous, disjoint, covering -, weak scaling, and --allgather reporting the
+  gather's time in a field of its own, outside `ms_per_step`."""
+  r = _run_bench('--gpus', '8', '--dry-run', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--allgather', '--repeats', '3',
+                 timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  out = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(out) == 1
+  line = json.loads(out[0])
+  assert line['n_gpus'] == 8 and line['dry_run'] is True and line['scaling'] == 'weak'
+  assert line['config']['batch_per_gpu'] == 128 and line['config']['global_batch'] == 1024
+  assert line['per_gpu_value'] == pytest.approx(line['value'] / 8)
+  for name, gb, per in (('configs_3', 1024, 128), ('configs_4', 256, 32), ('headline', 1024, 128)):
+    sh = line['shards'][name]
+    assert sh['global_batch'] == gb
+    assert sh['rows_of_rank'] == [[per * r_, per * (r_ + 1)] for r_ in range(8)], (name, sh)
+  assert line['allgather_ms'] > 0 and 'allgather' not in line['timing']['method']
+  assert line['configs_1']['batch_per_gpu'] == 32 and line['configs_4']['batch_per_gpu'] == 32
+  assert line['configs_4']['value'] == pytest.approx(8 * 32 * 480000 / (line['configs_4']['ms_per_step'] * 1e-3) / 1e6)
 
 
 def test_gpus_2_on_a_box_without_two_gpus_refuses_instead_of_reporting_one():

@@ -69,6 +69,11 @@ class _HostLib:
     _view(out, (b, n))[:] = O.device_uniform_noise(b, n, seed=seed, batch_offset=batch_offset)
     return 0
 
+  def ddsp_uniform_noise_ex_f32(self, out, b, n, seed, batch_offset, noise_bits, stream):
+    self.calls.append('ddsp_uniform_noise_f32')
+    _view(out, (b, n))[:] = O.device_uniform_noise(b, n, seed=seed, batch_offset=batch_offset, noise_bits=noise_bits)
+    return 0
+
   def ddsp_fft_convolve_long_ex_workspace_bytes(self, b, bir, n, l, n_out, delay):
     return 64
 

@@ -15,8 +15,8 @@ import torch
 
 from conftest import parity_check
 from oracle import ddsp_oracle as O
-from test_gpu_parity import (DEV, HARM_TABLE_ATOL, HARM_TRUTH_ATOL, _harmonic_exact, canonical_inputs, ddsp,  # noqa: F401
-                             noise_tol, npy, reverb_tol)
+from test_gpu_parity import (DEV, HARM_TABLE_ATOL, HARM_TRUTH_ATOL, _harmonic_exact, assert_knife_edges_take_the_fp32_side,  # noqa: F401
+                             canonical_inputs, ddsp, noise_tol, npy, reverb_tol)
 
 pytestmark = pytest.mark.gpu
 
@@ -187,12 +187,15 @@ def test_north_star_shape_batch128_harmonic_crossing_regimes(ddsp, f0_centre):
   scale = max(1.0, float(O.exp_sigmoid(x['amplitudes'].astype(np.float64), dtype=np.float64).max()))
   for r in sorted(rng.choice(b, 6, replace=False).tolist()):
     sl = slice(r, r + 1)
-    exact, knife = _harmonic_exact(x['amplitudes'][sl], x['harmonic_distribution'][sl], f0[sl], 64000, 16000, 'window',
-                                   with_knife_edges=True)
+    exact, knife, exact32 = _harmonic_exact(x['amplitudes'][sl], x['harmonic_distribution'][sl], f0[sl], 64000, 16000, 'window',
+                                            with_knife_edges='fp32 mask')
     assert knife.mean() <= 2e-2
     err = float(np.abs(full[sl] - exact)[~knife].max())
     parity_check(np.where(knife, exact, full[sl]), exact, HARM_TABLE_ATOL * scale,
                  'batch 128, f0 = %g +- 1 Hz, row %d vs exact arithmetic (%.2e)' % (f0_centre, r, err))
+    # ... and the knife-edge samples against the same sum with the mask decided in the reference's fp32 op order (core.py:942-944):
+    # no sample is left unchecked
+    assert_knife_edges_take_the_fp32_side(full[sl], exact32, knife, HARM_TABLE_ATOL * scale, ('batch 128', f0_centre, r))
 
 
 def test_config5_batch32_every_row(ddsp):
@@ -220,3 +223,54 @@ def test_config5_batch32_every_row(ddsp):
     sl = slice(r, r + 1)
     exact = _harmonic_exact(amps[sl], hd[sl], f0[sl], n, sr, 'linear')
     parity_check(full[sl], exact, HARM_TABLE_ATOL * scale, 'config 5 at batch 32, row %d vs exact arithmetic' % r)
+
+
+def test_config3_spectral_loss_batch128(ddsp):
+  """BASELINE configs[2] at ITS batch (the loss tests of test_gpu_parity.py stop at batch 32 and check two
+  clips): losses.SpectralLoss (fft sizes 2048 .. 64, L1, mag + logmag: ddsp/losses.py:131-243, gin/models/ae.gin:36-41) on the
+  synths' DAG output at batch 128.  The loss is a mean over [batch, frames, bins] per scale, so it is additive over rows: the
+  batch's value is the mean of its sub-batches' and of its rows' values; six rows' values against the fp64 oracle; value AND
+  gradient w.r.t. the audio (what a training step runs, one kernel) against the analytic fp64 gradient on two rows."""
+  b, f, k, n = 128, 1000, 100, 64000
+  rng = np.random.default_rng(31)
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  fnoise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=3)
+
+  def dag(seed, f0c):
+    r = np.random.default_rng(seed)
+    z = fnoise(r.standard_normal((b, f, 65)) + 2.0)
+    return harm.call_add(r.standard_normal((b, f, 1)), r.standard_normal((b, f, k)), f0c + r.standard_normal((b, f, 1)), z)
+  with torch.no_grad():
+    audio, target = dag(32, 200.0), dag(33, 210.0)
+  loss = ddsp.losses.SpectralLoss(mag_weight=1.0, logmag_weight=1.0)
+  got = float(loss(target, audio))
+  assert np.isfinite(got) and got > 0
+  # the same call twice: the same bits (fp64 partials, fixed-order finish)
+  assert float(loss(target, audio)) == got
+  # additive over rows
+  quarters = [float(loss(target[32 * q:32 * q + 32].contiguous(), audio[32 * q:32 * q + 32].contiguous())) for q in range(4)]
+  np.testing.assert_allclose(got, np.mean(quarters), rtol=1e-6)
+  rows = sorted(rng.choice(b, 6, replace=False).tolist())
+  row_vals = []
+  for r in rows:
+    v = float(loss(target[r:r + 1].contiguous(), audio[r:r + 1].contiguous()))
+    ref = float(O.spectral_loss(npy(target[r:r + 1]), npy(audio[r:r + 1]), logmag_weight=1.0, dtype=np.float64))
+    np.testing.assert_allclose(v, ref, rtol=5e-5, err_msg='row %d' % r)
+    row_vals.append(v)
+  # each scale on its own adds up to the total, at this batch
+  parts = sum(float(ddsp.losses.SpectralLoss(fft_sizes=(s,), logmag_weight=1.0)(target, audio)) for s in (2048, 1024, 512, 256, 128, 64))
+  np.testing.assert_allclose(got, parts, rtol=1e-6)
+  # value and gradient at batch 128: the value is the forward's, rows' gradients are their own (x 1 / batch: the mean)
+  ta = audio.clone().requires_grad_(True)
+  val = loss(target, ta)
+  val.backward()
+  np.testing.assert_allclose(float(val.detach()), got, rtol=1e-6)
+  g = npy(ta.grad)
+  assert g.shape == (b, n) and np.isfinite(g).all()
+  for r in rows[:2]:
+    ref = O.spectral_loss_backward(npy(target[r:r + 1]), npy(audio[r:r + 1]), (2048, 1024, 512, 256, 128, 64), 1.0, 1.0) / b
+    atol = 1e-9 + 2e-4 * np.abs(ref).max()
+    err = np.abs(g[r:r + 1] - ref)
+    # (d|x|/dx is a sign: a bin whose two magnitudes agree to rounding may take the other sign in fp32 - a frame's worth of
+    # samples a few tolerances off; test_spectral_loss_backward_vs_analytic_oracle)
+    assert (err > atol).mean() <= 1e-3 and err.max() <= 10 * atol, (r, float((err > atol).mean()), float(err.max()), atol)

@@ -140,6 +140,20 @@ def test_filtered_noise_golden(ddsp, noise_kernel, name):
   np.testing.assert_allclose(sig3, sig, rtol=0, atol=1e-7)
 
 
+def test_prepare_makes_the_constant_tables_ahead_of_the_first_launch(ddsp):
+  """ddsp_prepare (the tables' first-use hipMalloc / hipMemcpy may not fall inside a graph capture): callable for any
+  shape, idempotent, and the launches after it give what they give without it."""
+  for k, m, ws in [(100, 65, 0), (128, 100, 0), (200, 256, 257), (300, 2, 0), (0, 0, 0), (60, 5000, 0)]:
+    ddsp.core.prepare(k, m, ws)
+    ddsp.core.prepare(k, m, ws)
+  rng = np.random.default_rng(0)
+  mags = rng.standard_normal((1, 10, 100)).astype(np.float32)
+  noise = rng.uniform(-1, 1, (1, 640)).astype(np.float32)
+  ours = npy(ddsp.synths.FilteredNoise(n_samples=640, window_size=0)(mags, noise=noise))
+  ref = O.filtered_noise(mags, noise, 0, dtype=np.float64)
+  assert np.abs(ours - ref).max() <= noise_tol(ref)
+
+
 def test_add_golden(ddsp):
   g = load_golden('add')
   np.testing.assert_array_equal(npy(ddsp.processors.Add()(g['signal_one'], g['signal_two'])),
@@ -201,6 +215,111 @@ def test_generated_noise_is_bit_exact_and_fused_path_matches_injection(ddsp, noi
   gen2 = npy(synth(mags))                                   # stateful like tf.random: differs
   assert np.abs(gen2 - gen).max() > 0
   assert abs(gen.mean()) < 1e-3 and gen.std() > 0
+
+
+def noise_statistics(x):
+  """What 'uniform on (-1, 1), white' means in numbers, for one long row: mean, variance, the largest autocorrelation at
+  lags 1 .. 128 (the FIR has 128 taps: correlations inside its reach are what would colour the output) and the
+  Kolmogorov-Smirnov distance to U(-1, 1)."""
+  x = x.astype(np.float64)
+  n = x.size
+  xc = x - x.mean()
+  spec = np.fft.rfft(xc, 2 * n)
+  ac = np.fft.irfft(spec * np.conj(spec))[:129] / (xc.var() * n)
+  xs = np.sort(x)
+  cdf = (xs + 1.0) / 2.0
+  ks = max(np.abs(cdf - np.arange(1, n + 1) / n).max(), np.abs(cdf - np.arange(0, n) / n).max())
+  return dict(mean=x.mean(), var=x.var(), max_ac=np.abs(ac[1:]).max(), ks=ks)
+
+
+@pytest.mark.parametrize('noise_bits', [11, 23])
+def test_generated_noise_contract_both_resolutions(ddsp, noise_kernel, noise_bits):
+  """The generated-noise contract of include/ddsp_amd.h at both settings of FilteredNoise(noise_bits=): the stream is
+  bit-exact against the oracle's restatement, the synth run on it equals the synth handed the same samples (bit for bit
+  where the kernel carries them the same way: 11-bit samples ARE their fp16 hi part; 23-bit samples made on chip and
+  supplied ones go through the same hi / lo planes, but supplied noise is normalised by its row's power of two first -
+  a no-op in exact arithmetic - so that comparison has the parity tolerance), the backward pass regenerates the same samples,
+  and the samples are what the reference's tf.random.uniform(-1, 1) (ddsp/synths.py:192-193) promises statistically."""
+  b, n = 2, 6400
+  dev_noise = npy(ddsp.core.uniform_noise(b, n, seed=1234, batch_offset=5, noise_bits=noise_bits))
+  ref_noise = O.device_uniform_noise(b, n, 1234, 5, noise_bits=noise_bits)
+  np.testing.assert_array_equal(dev_noise, ref_noise)
+  levels = np.unique(dev_noise).size
+  assert levels <= 2048 if noise_bits == 11 else levels > 6000        # 12 800 samples: 23-bit samples hardly ever repeat
+  rng = np.random.default_rng(4)
+  mags = rng.standard_normal((b, 100, 65)).astype(np.float32)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=99, noise_bits=noise_bits)
+  tm = ddsp.core.tf_float32(mags).requires_grad_(True)
+  gen_t = synth(tm)                                                   # call counter 0 -> key (99, 0)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  gen_t.backward(ddsp.core.tf_float32(g))
+  gen = npy(gen_t)
+  noise = O.device_uniform_noise(b, n, 99, 0, noise_bits=noise_bits)
+  inj = npy(synth(mags, noise=noise))
+  ref = O.filtered_noise(mags, noise, 0, dtype=np.float64)
+  assert np.abs(gen - ref).max() <= noise_tol(ref)
+  if noise_bits == 11:
+    np.testing.assert_array_equal(gen, inj)
+  else:
+    assert np.abs(gen - inj).max() <= noise_tol(ref)
+  gref = O.filtered_noise_backward(mags, noise, g, 0, O.exp_sigmoid)
+  np.testing.assert_allclose(npy(tm.grad), gref, rtol=0, atol=1e-6 + 2e-5 * np.abs(gref).max())
+  # the other resolution is another stream
+  other = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=99, noise_bits=34 - noise_bits)
+  assert np.abs(npy(other(mags)) - gen).max() > 1e-3
+  # statistics on 10^6 samples of one row (sigma of the mean 5.8e-4, of the variance 3e-4, of an autocorrelation 1e-3;
+  # KS at the 0.1 % level 1.95e-3 - the 2048-level staircase itself is 2.4e-4 away from the uniform law)
+  st = noise_statistics(npy(ddsp.core.uniform_noise(1, 1000000, seed=2024, noise_bits=noise_bits))[0])
+  assert abs(st['mean']) < 3e-3 and abs(st['var'] - 1.0 / 3.0) < 1.5e-3, st
+  assert st['max_ac'] < 6e-3 and st['ks'] < 2.5e-3, st
+  with pytest.raises(ValueError):
+    ddsp.synths.FilteredNoise(noise_bits=16)
+
+
+def test_supplied_audio_and_filters_at_any_scale(ddsp):
+  """core.fft_convolve, frequency_filter, frequency_impulse_response and FilteredNoise with supplied noise
+  run on the matrix cores with fp16 hi / lo operands; the reference (ddsp/core.py:1382-1473, tf.signal's FFTs) is fp32 and
+  scale invariant.  int16-range audio (x 32768) overflowed fp16 to NaN, an impulse response of 1e-9 lost 8 %.  Every operand
+  the caller supplies is normalised by a power of two per tile now: out(s x, t h) / (s t) matches the fp64 result at the
+  tolerance of s = t = 1."""
+  rng = np.random.default_rng(5)
+  b, f, l, n = 2, 25, 97, 3200
+  audio = rng.standard_normal((b, n)).astype(np.float32)
+  ir = (rng.standard_normal((b, f, l)) / np.sqrt(l)).astype(np.float32)
+  ref = O.fft_convolve(audio, ir, dtype=np.float64)
+  for sa, sh in [(32768.0, 1.0), (1.0, 1e-7), (1.0, 1e-9), (1e-9, 1.0), (1e5, 1e4), (3e-12, 2e-11)]:
+    got = npy(ddsp.core.fft_convolve((audio * np.float32(sa)).astype(np.float32), (ir * np.float32(sh)).astype(np.float32)))
+    ref_s = O.fft_convolve((audio * np.float32(sa)).astype(np.float32), (ir * np.float32(sh)).astype(np.float32), dtype=np.float64)
+    assert np.isfinite(got).all(), (sa, sh)
+    np.testing.assert_allclose(got / (sa * sh), ref_s / (sa * sh), rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max(), err_msg=str((sa, sh)))
+  # one filter for the whole batch, 128 taps on frames of 64 (the canonical filter's geometry through fft_convolve)
+  ir1 = (rng.standard_normal((1, 50, 128)) / 11.0).astype(np.float32)
+  ref1 = O.fft_convolve(audio, ir1, dtype=np.float64)
+  for sa, sh in [(32768.0, 1e-6), (1e-8, 1e3)]:
+    got = npy(ddsp.core.fft_convolve((audio * np.float32(sa)).astype(np.float32), (ir1 * np.float32(sh)).astype(np.float32)))
+    np.testing.assert_allclose(got / (sa * sh), ref1, rtol=0, atol=2e-6 + 2e-5 * np.abs(ref1).max(), err_msg=str((sa, sh)))
+  # magnitudes of any size: frequency_impulse_response (raw magnitudes, no exp_sigmoid) and the synth with scale_fn=None
+  for m, ws in [(65, 0), (100, 0), (33, 17)]:
+    mags = np.abs(rng.standard_normal((b, 20, m))).astype(np.float32)
+    ir_ref = O.frequency_impulse_response(mags, ws, dtype=np.float64)
+    for sm in (1e-8, 1.0, 3e5):
+      got = npy(ddsp.core.frequency_impulse_response((mags * np.float32(sm)).astype(np.float32), window_size=ws))
+      np.testing.assert_allclose(got / sm, ir_ref, rtol=0, atol=2e-7 + 1e-5 * np.abs(ir_ref).max(), err_msg=str((m, ws, sm)))
+  mags = np.abs(rng.standard_normal((b, 50, 65))).astype(np.float32)
+  noise = rng.uniform(-1, 1, (b, n)).astype(np.float32)
+  ref_fn = O.filtered_noise(mags, noise, 0, None, dtype=np.float64)
+  for kernel in ('auto', 'vector'):
+    for sm, sx in [(1.0, 1.0), (1e-7, 32768.0), (2e4, 1e-9)]:
+      synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, scale_fn=None)
+      synth.kernel = kernel
+      got = npy(synth((mags * np.float32(sm)).astype(np.float32), noise=(noise * np.float32(sx)).astype(np.float32)))
+      np.testing.assert_allclose(got / (sm * sx), ref_fn, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref_fn).max(), err_msg=str((kernel, sm, sx)))
+  # supplied noise at any scale through the canonical kernel (exp_sigmoid magnitudes)
+  mags = rng.standard_normal((b, 50, 65)).astype(np.float32)
+  ref_c = O.filtered_noise(mags, noise, 0, dtype=np.float64)
+  for sx in (32768.0, 1e-9):
+    got = npy(ddsp.synths.FilteredNoise(n_samples=n, window_size=0)(mags, noise=(noise * np.float32(sx)).astype(np.float32)))
+    np.testing.assert_allclose(got / sx, ref_c, rtol=0, atol=noise_tol(ref_c), err_msg=str(sx))
 
 
 # ---- edge cases --------------------------------------------------------------------------------
@@ -938,6 +1057,66 @@ def test_harmonic_backward_on_the_wavetable_adjoint(ddsp, batch, n_frames, k, ho
   np.testing.assert_array_equal(grads[0][1], grads[1][1])
 
 
+@pytest.mark.parametrize('hop', [20, 40, 100, 200])
+def test_harmonic_backward_ragged_frames_and_steep_f0_drops(ddsp, hop):
+  """frame sizes that are not multiples of 64 with f0 falling steeply inside a frame.  The lanes past a
+  frame's last sample carried the frequency ramp EXTRAPOLATED past the frame - backwards when f0 falls -, harm_bwd_table_kernel
+  took the tile's revolution count from lane 63 and skipped live lanes' turns: at hop 20 more than half of the gradient values
+  were wrong by O(1).  The advisor's reproduction: f0 alternating 200-390 Hz and 35-45 Hz."""
+  rng = np.random.default_rng(hop)
+  batch, n_frames, k, sr = 1, 96, 20, 16000
+  n = n_frames * hop
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
+  f0 = rng.uniform(200.0, 390.0, (batch, n_frames, 1)).astype(np.float32)
+  f0[:, 1::2] = rng.uniform(35.0, 45.0, (batch, n_frames // 2, 1)).astype(np.float32)
+  f0[:, 40:48] = rng.uniform(200.0, 390.0, (batch, 8, 1)).astype(np.float32)     # and a stretch without drops
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  synth(ta, th, f0).backward(ddsp.core.tf_float32(g))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, 'window')
+  # (frames of 200 samples with f0 jumping by 300 Hz per frame: the oracle keeps TF's fp32 resize positions, which are up to
+  # 1.5e-5 off r / hop for frame sizes that are not powers of two - DESIGN.md "known limits"; the plain-sum kernel is the same
+  # 6e-4 away from it at the same element.  The bug this test is for was 0.2 - 2.3.)
+  slack = 3.0 if hop == 200 else 1.0
+  np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=slack * grad_tol(ga))
+  np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=slack * grad_tol(gh))
+
+
+@pytest.mark.parametrize('scale', [1e-10, 1e-6, 1.0, 3e4, 1e5])
+def test_synth_backward_is_invariant_to_the_scale_of_grad_audio(ddsp, scale):
+  """the matrix-core backward kernels split dL/d audio (Harmonic: its spread image G) into fp16 hi / lo
+  pairs; without normalisation 3e4 overflowed to NaN, 1e-10 lost 7-9 %, smaller gradients flushed to zero.  tf.GradientTape's
+  fp32 gradients are scale invariant (loss scaling by 2^16, sum-reduced losses): so are these now - grad(s g) / s equals
+  grad(g) to fp32 rounding for every s, checked against the fp64 analytic gradient."""
+  rng = np.random.default_rng(77)
+  batch, n_frames, k, hop = 2, 32, 100, 64
+  n = n_frames * hop
+  amps = rng.standard_normal((batch, n_frames, 1)).astype(np.float32)
+  hd = rng.standard_normal((batch, n_frames, k)).astype(np.float32)
+  f0 = rng.uniform(69.0, 71.0, (batch, n_frames, 1)).astype(np.float32)
+  mags = (rng.standard_normal((batch, n_frames, 65)) + 4.0).astype(np.float32)
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  gs = (g.astype(np.float64) * scale).astype(np.float32)
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  harm(ta, th, f0).backward(ddsp.core.tf_float32(gs))
+  ga, gh = O.harmonic_backward(amps, hd, f0, gs, n, 16000, O.exp_sigmoid, True, 'window')
+  np.testing.assert_allclose(npy(ta.grad) / scale, ga / scale, rtol=0, atol=grad_tol(ga / scale))
+  np.testing.assert_allclose(npy(th.grad) / scale, gh / scale, rtol=0, atol=grad_tol(gh / scale))
+  for given_noise in (False, True):
+    noise_synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=5)
+    # supplied noise at an arbitrary scale of its own (the forward is linear in it)
+    noise = (rng.uniform(-1, 1, (batch, n)) * 300.0).astype(np.float32) if given_noise else O.device_uniform_noise(batch, n, seed=5)
+    tm = ddsp.core.tf_float32(mags).requires_grad_(True)
+    noise_synth(tm, noise=noise if given_noise else None).backward(ddsp.core.tf_float32(gs))
+    ref = O.filtered_noise_backward(mags, noise, gs, 0, O.exp_sigmoid)
+    np.testing.assert_allclose(npy(tm.grad) / scale, ref / scale, rtol=0, atol=(1e-6 + 2e-5 * np.abs(ref).max()) / scale)
+
+
 def test_harmonic_backward_full_size_properties(ddsp):
   rng = np.random.default_rng(12)
   b, f, k, n = 32, 1000, 100, 64000
@@ -1255,15 +1434,40 @@ def _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=False):
   ph = np.cumsum(ft / sr, axis=1)
   wn = lerp if method == 'linear' else 0.5 - 0.5 * np.cos(np.pi * lerp)
   out = np.zeros((b, n))
+  out32 = np.zeros((b, n))                   # the same sum with the audio-rate mask decided as the reference decides it
   knife = np.zeros((b, n), dtype=bool)
+  # the reference's decision (core.py:942-944 on what core.resample made of get_harmonic_frequencies' fp32 products): legacy
+  # bilinear resize, top + (bottom - top) * lerp with every step rounded to fp32, compared with fl32(sr / 2).
+  # lerp = r / hop is exact in fp32 for frame sizes that are powers of two; for others (192) TF's position t * fl32(F / N) is up
+  # to 1.5e-5 off and the kernels' r * fl32(1 / hop) is what is restated here (known limits).
+  f32 = np.float32
+  fr32 = f0.astype(f32)[:, :, 0]
+  lerp32 = (r.astype(f32) * (f32(1.0) / f32(hop))).astype(f32)
   for q in range(1, k + 1):
     aq = amp[:, j, q - 1] * (1 - wn)[None] + amp[:, j1, q - 1] * wn[None]
-    out += np.where(ft * q >= sr / 2, 0.0, aq) * np.sin(2 * np.pi * q * ph)
+    sq = np.sin(2 * np.pi * q * ph)
+    out += np.where(ft * q >= sr / 2, 0.0, aq) * sq
+    top, bot = (fr32[:, j] * f32(q)).astype(f32), (fr32[:, j1] * f32(q)).astype(f32)
+    fk32 = (top + ((bot - top).astype(f32) * lerp32[None]).astype(f32)).astype(f32)
+    out32 += np.where(fk32 >= f32(sr / 2.0), 0.0, aq) * sq
     # samples where a harmonic sits within fp32 rounding of Nyquist: the reference's fp32 comparison (which the kernels
-    # reproduce: core.py:942-944 on fl32 values) and this fp64 one may fall on different sides
+    # reproduce) and the fp64 one may fall on different sides
     d = ft * q - sr / 2                      # (exactly on Nyquist - f0 = 200 Hz, harmonic 40 - is not ambiguous: both say >=)
     knife |= (d != 0) & (np.abs(d) <= 4e-7 * sr)
+  if with_knife_edges == 'fp32 mask':
+    return out, knife, out32
   return (out, knife) if with_knife_edges else out
+
+
+def assert_knife_edges_take_the_fp32_side(got, exact32, knife, atol, what):
+  """the samples the exact-arithmetic comparison leaves out - a harmonic within fp32 rounding of Nyquist,
+  where the fp64 comparison and the reference's fp32 one may fall on different sides - are held to the SAME sum with the mask
+  decided in the reference's fp32 op order (the crossing harmonic's amplitude present or absent: a difference of that
+  harmonic's whole amplitude, orders of magnitude above the tolerance, if the kernel decided otherwise).  With this every
+  sample is checked against something; and away from the knife edges the two references are the same sum."""
+  if knife.any():
+    err = np.abs(got - exact32)[knife]
+    assert err.max() <= atol, (what, 'knife-edge samples', int(knife.sum()), float(err.max()), atol)
 
 
 @pytest.mark.parametrize('seed', [1, 2, 3])
@@ -1290,9 +1494,10 @@ def test_harmonic_random_shapes_vs_exact_arithmetic(ddsp, seed):
     got = npy(ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)(amps, hd, f0))
     what = dict(hop=hop, frames=f, k=k, batch=b, base=base, method=method)
     scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
-    exact, knife = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=True)
+    exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges='fp32 mask')
     assert knife.mean() <= 1e-2, what                        # (a handful of samples per clip at most)
     assert np.abs(got - exact)[~knife].max() <= HARM_TABLE_ATOL * scale, what
+    assert_knife_edges_take_the_fp32_side(got, exact32, knife, HARM_TABLE_ATOL * scale, what)
     if hop in (64, 128):
       truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, amp_resample_method=method, dtype=np.float64)
       assert np.abs(got - truth)[~knife].max() <= HARM_TABLE_ATOL * scale, what
@@ -1342,15 +1547,17 @@ def test_harmonic_129_to_200_harmonics_on_the_wavetable_kernel(ddsp, k, hop, sr,
   f0 = np.abs(base + jitter * rng.standard_normal((b, f, 1))).astype(np.float32)
   synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   got = npy(synth(amps, hd, f0))
-  exact, knife = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges=True)
+  exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='fp32 mask')
   scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
   assert knife.mean() <= 1e-2
   assert np.abs(got - exact)[~knife].max() <= HARM_TABLE_ATOL * scale
+  assert_knife_edges_take_the_fp32_side(got, exact32, knife, HARM_TABLE_ATOL * scale, (k, hop, sr, base))
   direct = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   direct.kernel = 'direct'
   sum_ = npy(direct(amps, hd, f0))
   assert not np.array_equal(got, sum_)                         # (two kernels)
   assert np.abs(got - sum_)[~knife].max() <= HARM_TRUTH_ATOL * scale
+  assert_knife_edges_take_the_fp32_side(sum_, exact32, knife, HARM_TRUTH_ATOL * scale, ('direct sum', k, hop, sr, base))
   full = synth(amps, hd, f0, return_outputs_dict=True)
   np.testing.assert_array_equal(npy(full['signal']), got)
   ctl = O.harmonic_get_controls(amps, hd, f0, sr, dtype=np.float64)
@@ -1618,11 +1825,12 @@ def test_harmonic_table_sizes_follow_f0(ddsp, k, hop):
   synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   full = npy(synth(amps, hd, f0))
   assert full.shape == (b, n) and np.isfinite(full).all()
-  exact, knife = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges=True)
+  exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='fp32 mask')
   scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
   assert knife.mean() <= 1e-2
   for r in range(b):
     parity_check(np.where(knife[r], exact[r], full[r]), exact[r], HARM_TABLE_ATOL * scale, 'table sizes by f0, row %d, K = %d' % (r, k))
+  assert_knife_edges_take_the_fp32_side(full, exact32, knife, HARM_TABLE_ATOL * scale, ('table sizes by f0', k))
   for r in range(b):
     np.testing.assert_array_equal(npy(synth(amps[r:r + 1], hd[r:r + 1], f0[r:r + 1])), full[r:r + 1], err_msg='row %d alone' % r)
   np.testing.assert_array_equal(npy(synth(amps[1:4], hd[1:4], f0[1:4])), full[1:4])
@@ -1646,9 +1854,10 @@ def test_harmonic_frame_sizes_that_are_not_multiples_of_64(ddsp, hop, k):
     synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)
     full = npy(synth(amps, hd, f0))
     assert full.shape == (b, n) and np.isfinite(full).all()
-    exact, knife = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=True)
+    exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges='fp32 mask')
     scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
     parity_check(np.where(knife, exact, full), exact, HARM_TABLE_ATOL * scale, 'hop %d, K = %d, %s' % (hop, k, method))
+    assert_knife_edges_take_the_fp32_side(full, exact32, knife, HARM_TABLE_ATOL * scale, (hop, k, method))
     np.testing.assert_array_equal(npy(synth(amps[1:2], hd[1:2], f0[1:2])), full[1:2])
     z = rng.standard_normal((b, n)).astype(np.float32)
     np.testing.assert_array_equal(npy(synth.call_add(amps, hd, f0, z)), full + z)
