@@ -17,6 +17,15 @@
 // m-1 in its real part and block m in its imaginary part (rv_ifft_kernel): half the inverse FFTs and
 // half the multiply-adds of the plain scheme.
 //
+// Round 5, one impulse response for the whole batch (the trainable Reverb of the shipped configurations: effects.py:62-80,
+// gin/models/solo_instrument.gin:26-40): two ROWS ride in one complex transform instead of two blocks of one row,
+// Z_j = X_j(row a) + i X_j(row b); Z_j H = Y_j(a) + i Y_j(b) for every j because H is the spectrum of a real response both rows
+// share.  Every block is then transformed ONCE (above, each is the imaginary part of one spectrum and the real part of the
+// next), the multiply-add pass reads half the spectra, and the audio's blocks and the impulse response's partitions are one
+// launch (the partitions' launch ahead of the audio's was 15 - 19 us of latency at any batch size): 126 -> 100 us at batch 128,
+// 50 -> 44 at batch 32 (profiles/r05_reverb_row_pairs_and_the_fused_experiment.txt, which also has the form that keeps every
+// spectrum on chip - bin classes with the ring of spectra in registers - built, measured at 99 us and taken out again).
+//
 // The forward transform is an in-place radix-8 (+ one radix-2 stage) decimation-in-frequency FFT that leaves its bins in
 // digit-reversed order; the inverse undoes it stage by stage: the per-bin products do not care
 // about the order, so no reordering pass exists anywhere.  Twiddles come from
@@ -25,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "common.h"
 #include "profile.h"
 #include "fft_radix8.h"
@@ -129,26 +139,35 @@ struct RvArgs {
   int N, L, n_out, nb, np, delay;      // n_out: samples written per row (out[n] = y[n + delay], n < n_out)
   unsigned flags;
   int ir_batch;                         // 1: one IR for every batch row
+  // ROW PAIRS (round 5; one impulse response for the whole batch, the trainable Reverb of the shipped configurations): two ROWS
+  // ride in one complex transform - Z_j = X_j(row a) + i X_j(row b), block j of both - instead of two blocks of one row.  Z H is
+  // then Y_j(a) + i Y_j(b) for EVERY j because H is the spectrum of a real response both rows share: half the forward
+  // transforms (each block is transformed once, not as the real part of one spectrum and the imaginary part of the next) and
+  // half the spectra written and read by the multiply-add pass.  B: rows (an odd batch's last pair holds one).
+  int pairs, B;
 };
 
-// blockIdx.x = block / partition, blockIdx.y = batch row.  IS_IR: the rows are IR partitions.
+// One block = one 8192-point forward transform: block / partition j of row (pair / impulse response) b, `stride` spectra per row.
+// IS_IR: the rows are IR partitions.
 template <bool IS_IR>
-__global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restrict__ src,
-                                                            float2* __restrict__ spec, RvArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float2 s[];
-  const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
+__device__ __forceinline__ void rv_fft_block(float2* s, const float* __restrict__ src, float2* __restrict__ spec, const RvArgs& p,
+                                             int j, int b, int stride) {
+  const int tid = threadIdx.x;
   const int len = IS_IR ? p.L : p.N;
-  const float* __restrict__ row = src + (size_t)b * len;
+  const bool pair_mode = !IS_IR && p.pairs > 0;
+  const float* __restrict__ row = src + (size_t)(pair_mode ? 2 * b : b) * len;
+  const float* __restrict__ row_im = (pair_mode && 2 * b + 1 < p.B) ? row + len : nullptr;    // (pair mode: the second row, or none)
   // IR partition: taps jP .. (j+1)P-1 then P zeros (imaginary part 0);
   // x spectrum m = j: real part samples (m-2)P .. mP-1 (block m-1), imaginary part (m-1)P .. (m+1)P-1 (block m)
-  const int base = IS_IR ? j * kRvP : (j - 2) * kRvP;
+  // pair mode: real and imaginary part are block j (samples (j-1)P .. (j+1)P-1) of the pair's two rows
+  const int base = IS_IR ? j * kRvP : (pair_mode ? (j - 1) * kRvP : (j - 2) * kRvP);
   const int live = IS_IR ? kRvP : kRvN;
   // DDSP_CONV_REVERSE_AUDIO / _IR: logical sample g is stored at len-1-g (correlations for the backward pass)
   const bool rev = (p.flags & (IS_IR ? DDSP_CONV_REVERSE_IR : DDSP_CONV_REVERSE_AUDIO)) != 0;
   const bool vec = !rev && ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-  auto load4 = [&](int g) {
+  auto load4 = [&](const float* __restrict__ row, int g) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g + 3 >= 0 && g < len) {
+    if (row != nullptr && g + 3 >= 0 && g < len) {
       if (rev) {
         if (g >= 0 && g < len) v.x = row[len - 1 - g];
         if (g + 1 >= 0 && g + 1 < len) v.y = row[len - 2 - g];
@@ -169,22 +188,40 @@ __global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restr
     const int i = 4 * i4, g = base + i;
     float4 re = make_float4(0.f, 0.f, 0.f, 0.f), im = re;
     if (i < live) {
-      re = load4(g);
+      re = load4(row, g);
       // effects.Reverb._mask_dry_ir (effects.py:50-60): tap 0 carries the dry signal -> 0
       if (IS_IR && g == 0 && (p.flags & DDSP_CONV_MASK_TAP0)) re.x = 0.0f;
-      if (!IS_IR) im = load4(g + kRvP);
+      if (!IS_IR) im = pair_mode ? load4(row_im, g) : load4(row, g + kRvP);
     }
     *reinterpret_cast<float4*>(&s[RP(4 * i4)]) = make_float4(re.x, im.x, re.y, im.y);
     *reinterpret_cast<float4*>(&s[RP(4 * i4 + 2)]) = make_float4(re.z, im.z, re.w, im.w);
   }
   __syncthreads();
   fft_forward(s, tid);
-  float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)b * gridDim.x + j) * kRvN);
+  float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)b * stride + j) * kRvN);
   for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) dst[i2] = *reinterpret_cast<const float4*>(&s[RP(2 * i2)]);
 }
 
+// The audio's blocks and the impulse responses' partitions in ONE launch (round 5): grid (max(nb, np), rows + Bir) - rows
+// blockIdx.y < rows are audio rows (row pairs), the rest impulse responses.  As two launches the second waited for the first's
+// twelve blocks: one 8192-point transform of latency (15 - 19 us at any batch size, profiles/r05e) ahead of every call.
+__global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restrict__ audio, const float* __restrict__ ir,
+                                                            float2* __restrict__ xspec, float2* __restrict__ hspec, RvArgs p,
+                                                            int rows) {
+  extern __shared__ __attribute__((aligned(16))) float2 s[];
+  const int j = blockIdx.x, b = blockIdx.y;
+  if (b < rows) {
+    if (j < p.nb) rv_fft_block<false>(s, audio, xspec, p, j, b, p.nb);
+  } else {
+    if (j < p.np) rv_fft_block<true>(s, ir, hspec, p, j, b - rows, p.np);
+  }
+}
+
 // One thread per pair of bins (16-byte accesses).  The IR spectra of all partitions sit in
-// registers, the Z spectra slide through a register window, W_m replaces Z_m (odd m) in memory.
+// registers, the Z spectra slide through a register window, W_m replaces Z_m (odd m; every m for row pairs) in memory.
+// (Round 5 measured the spectra requested three blocks ahead of their use - the loop is a load, its wait and the products, sixteen
+// times -: 35.6 -> 42.1 us at batch 128, twelve more registers at three wavefronts per SIMD cost more than the waits;
+// profiles/r05f_reverb_three_ways.txt.)
 __global__ __launch_bounds__(kRvMacThreads) void rv_mac_kernel(float4* __restrict__ xspec,
                                                             const float4* __restrict__ hspec, RvArgs p) {
   const int idx = blockIdx.x * kRvMacThreads + threadIdx.x;      // < kRvN / 2
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(kRvMacThreads) void rv_mac_kernel(float4* __restric
 #pragma unroll
     for (int q = kRvMaxParts - 1; q > 0; --q) w[q] = w[q - 1];
     w[0] = xb[(size_t)j * (kRvN / 2)];
-    if ((j & 1) == 0) continue;                                // W_m only for odd m (blocks m-1 and m)
+    if (p.pairs == 0 && (j & 1) == 0) continue;                // W_m only for odd m (blocks m-1 and m); row pairs: every m
     float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < kRvMaxParts; ++q) {
@@ -220,8 +257,10 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
                                                              float* __restrict__ out, RvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float2 s[];
   const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
-  // spectrum m = 2j+1 holds output blocks 2j (real part) and 2j+1 (imaginary part)
-  const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + 2 * j + 1) * kRvN);
+  const bool pair_mode = p.pairs > 0;
+  // spectrum m = 2j+1 holds output blocks 2j (real part) and 2j+1 (imaginary part); row pairs: spectrum j holds output block j
+  // of the pair's first row (real part) and of its second (imaginary part)
+  const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + (pair_mode ? j : 2 * j + 1)) * kRvN);
   for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) *reinterpret_cast<float4*>(&s[RP(2 * i2)]) = srcv[i2];
   __syncthreads();
   fft_inverse(s, tid);
@@ -229,6 +268,19 @@ __global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __res
   const float scale = 1.0f / (float)kRvN;
   const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;           // only with n_out == N (checked by the host)
   const bool rev_a = (p.flags & DDSP_CONV_REVERSE_AUDIO) != 0, rev_o = (p.flags & DDSP_CONV_REVERSE_OUT) != 0;
+  if (pair_mode) {
+    const int b0 = 2 * b;
+    const bool two = b0 + 1 < p.B;
+    for (int i = tid; i < kRvP; i += kRvThreads) {
+      const float2 y = s[RP(kRvP + i)];
+      const int n = j * kRvP + i - p.delay;
+      if (n < 0 || n >= p.n_out) continue;
+      const int no = rev_o ? p.n_out - 1 - n : n, na = rev_a ? p.N - 1 - n : n;
+      out[(size_t)b0 * p.n_out + no] = fmaf(y.x, scale, dry ? audio[(size_t)b0 * p.N + na] : 0.0f);
+      if (two) out[(size_t)(b0 + 1) * p.n_out + no] = fmaf(y.y, scale, dry ? audio[(size_t)(b0 + 1) * p.N + na] : 0.0f);
+    }
+    return;
+  }
   const float* __restrict__ arow = audio + (size_t)b * p.N;
   float* __restrict__ orow = out + (size_t)b * p.n_out;
   for (int i = tid; i < kRvP; i += kRvThreads) {
@@ -274,31 +326,35 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   RvArgs p;
   p.N = N; p.L = L; p.n_out = n_out; p.nb = rv_blocks(n_out, delay); p.np = rv_parts(L); p.delay = delay;
   p.flags = flags; p.ir_batch = Bir;
+  // row pairs: one impulse response for at least two rows - the trainable Reverb of the shipped configurations, effects.py:62-80
+  // (DDSP_EXP_REVERB=single keeps the one-row form for the A/B)
+  static const bool single_env = [] { const char* e = getenv("DDSP_EXP_REVERB"); return e && e[0] == 's'; }();
+  const bool pair_mode = Bir == 1 && B >= 2 && !single_env;
+  p.pairs = pair_mode ? (B + 1) / 2 : 0; p.B = B;
+  if (pair_mode) p.nb = (n_out + delay + kRvP - 1) / kRvP;          // (no rounding up to even: a spectrum is one block)
+  const int rows_z = pair_mode ? p.pairs : B;
   float2* xspec = (float2*)workspace;
-  float2* hspec = xspec + (size_t)B * p.nb * kRvN;
+  float2* hspec = xspec + (size_t)rows_z * p.nb * kRvN;
   const size_t lds = (size_t)kRvStore * sizeof(float2);
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
-    (void)hipFuncSetAttribute((const void*)rv_fft_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
+    (void)hipFuncSetAttribute((const void*)rv_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
     (void)hipFuncSetAttribute((const void*)rv_ifft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
     return true;
   }();
   (void)attr_set;
   {
     ProfileScope prof(kReverbFft, st);
-    hipLaunchKernelGGL((rv_fft_kernel<true>), dim3((unsigned)p.np, (unsigned)Bir), dim3(kRvThreads), lds, st,
-                       impulse_response, hspec, p);
-    hipLaunchKernelGGL((rv_fft_kernel<false>), dim3((unsigned)p.nb, (unsigned)B), dim3(kRvThreads), lds, st,
-                       audio, xspec, p);
+    hipLaunchKernelGGL(rv_fft_kernel, dim3((unsigned)(p.nb > p.np ? p.nb : p.np), (unsigned)(rows_z + Bir)), dim3(kRvThreads), lds, st,
+                       audio, impulse_response, xspec, hspec, p, rows_z);
   }
   {
     ProfileScope prof(kReverbMac, st);
-    hipLaunchKernelGGL(rv_mac_kernel, dim3(kRvN / 2 / kRvMacThreads, (unsigned)B), dim3(kRvMacThreads), 0, st,
+    hipLaunchKernelGGL(rv_mac_kernel, dim3(kRvN / 2 / kRvMacThreads, (unsigned)rows_z), dim3(kRvMacThreads), 0, st,
                        (float4*)xspec, (const float4*)hspec, p);
   }
   {
     ProfileScope prof(kReverbIfft, st);
-    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)p.nb / 2, (unsigned)B), dim3(kRvThreads), lds, st,
+    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)(pair_mode ? p.nb : p.nb / 2), (unsigned)rows_z), dim3(kRvThreads), lds, st,
                        (const float2*)xspec, audio, out, p);
   }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
