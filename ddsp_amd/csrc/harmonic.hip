@@ -1116,8 +1116,14 @@ __global__ __launch_bounds__(64 * NW) void harm_bwd_pq_kernel(const float* __res
 #define DDSP_CHAIN_ROWS 1
 #endif
 constexpr int kChainRows = DDSP_CHAIN_ROWS;
+// wavefronts (= rows) per block (-DDDSP_CHAIN_WAVES): 19.2 / 19.2 / 19.7 us at batch 32 and 57 / 60 / 63 at batch 128 for 4 / 8 / 16
+// (round 5, profiles/r05o: not the rate blocks are launched at either): four it stays
+#ifndef DDSP_CHAIN_WAVES
+#define DDSP_CHAIN_WAVES 4
+#endif
+constexpr int kChainWaves = DDSP_CHAIN_WAVES;
 template <int NCHUNK>   // ceil(K/64) <= NCHUNK
-__global__ __launch_bounds__(256) void harm_bwd_chain_kernel(const float* __restrict__ amplitudes,
+__global__ __launch_bounds__(64 * kChainWaves) void harm_bwd_chain_kernel(const float* __restrict__ amplitudes,
                                                              const float* __restrict__ hd,
                                                              const float* __restrict__ f0_hz,
                                                              const float* __restrict__ pq, size_t q_offset,
@@ -1131,7 +1137,7 @@ __global__ __launch_bounds__(256) void harm_bwd_chain_kernel(const float* __rest
   // kernel is not waiting for its loads; one row it stays
 #pragma unroll
   for (int u = 0; u < kChainRows; ++u) {
-    const long row = ((long)blockIdx.x * 4 + wave) * kChainRows + u;
+    const long row = ((long)blockIdx.x * kChainWaves + wave) * kChainRows + u;
     if (row >= rows) break;
     const int j = (int)(row % F);
     harm_chain_row<NCHUNK>(lane, row, j, amplitudes, hd, f0_hz, grad_amp, grad_hd, p, [&](int k) {
@@ -1199,9 +1205,9 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   {
     ProfileScope prof(kHarmBwdChain, st);
     const long rows = (long)B * F;
-    const dim3 grid((unsigned)((rows + 4 * kChainRows - 1) / (4 * kChainRows)));
+    const dim3 grid((unsigned)((rows + kChainWaves * kChainRows - 1) / (kChainWaves * kChainRows)));
     const int nchunk = (K + 63) / 64;
-#define DDSP_LAUNCH_BWD(NC) hipLaunchKernelGGL((harm_bwd_chain_kernel<NC>), grid, dim3(256), 0, st, amplitudes, hd, \
+#define DDSP_LAUNCH_BWD(NC) hipLaunchKernelGGL((harm_bwd_chain_kernel<NC>), grid, dim3(64 * kChainWaves), 0, st, amplitudes, hd, \
                                                f0_hz, (const float*)pq, q_offset, grad_amplitudes, grad_hd, rows, p)
     if (nchunk <= 1) DDSP_LAUNCH_BWD(1);
     else if (nchunk <= 2) DDSP_LAUNCH_BWD(2);

@@ -53,7 +53,7 @@ __device__ __forceinline__ void harm_chain_row(int lane, long row, int j, const 
   float inv = 1.0f;
   bool den_zero = false;
   if (!is_ctl) {
-    float den = wave_sum(part);
+    float den = wave_sum_dpp(part);      // (DPP row reductions: the shuffle form is six dependent ds_bpermute round trips per sum)
     den_zero = den == 0.0f;
     if (den_zero) den = 1e-7f;
     inv = 1.0f / den;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void harm_chain_row(int lane, long row, int j, const 
   float dot = 0.0f;                                      // sum_k ga * hd_norm = dL/d(amp_scaled)
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) dot = fmaf(ga[c], x[c] * inv, dot);
-  dot = wave_sum(dot);
+  dot = wave_sum_dpp(dot);
   if (lane == 0)
     grad_amp[row] = scale ? dot * kLog10 * (amp_s - 1e-7f) * (1.0f - 1.0f / (1.0f + __expf(-amp_raw))) : dot;
 #pragma unroll

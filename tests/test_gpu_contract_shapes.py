@@ -261,13 +261,14 @@ def test_config3_spectral_loss_batch128(ddsp):
   parts = sum(float(ddsp.losses.SpectralLoss(fft_sizes=(s,), logmag_weight=1.0)(target, audio)) for s in (2048, 1024, 512, 256, 128, 64))
   np.testing.assert_allclose(got, parts, rtol=1e-6)
   # value and gradient at batch 128: the value is the forward's, rows' gradients are their own (x 1 / batch: the mean).
-  # (On a broadband floor of -20 dB: the log-magnitude term's gradient is 1 / |bin|, and between the partials of a purely
-  # synthetic tone the bins are 1e-4 of the peaks - where the fp32 transform's own rounding, 1e-7 of the PEAK, is a per cent of
-  # the bin: first GPU run of this test, 1.2 % of the largest gradient off at 0.3 % of the samples, with the value right to 5e-5.
-  # That is the conditioning of the function in fp32, the reference's included, not the kernel's business at batch 128; the
-  # smaller gradient tests use broadband signals for the same reason.)
-  audio = audio + ddsp.core.tf_float32(0.1 * rng.standard_normal((b, n)))
-  target = target + ddsp.core.tf_float32(0.1 * rng.standard_normal((b, n)))
+  # (On BROADBAND signals, as the smaller gradient tests: the log-magnitude term's gradient is 1 / |bin|, and between the partials
+  # of a tone the bins are 1e-3 .. 1e-4 of the peaks - where the fp32 transform's own rounding, 1e-7 of the PEAK, and the 1-ulp
+  # v_sqrt / v_log are a per cent of the gradient.  Measured on the synths' output: the value right to 5e-5, the mag term's
+  # gradient to 3e-3 of the tolerance, the logmag term's 0.7 % of the samples up to 30 tolerances off on the MI355X (8 under
+  # the emulation's exact transcendentals).  That is the conditioning of the function in fp32, the reference's included; what
+  # this test is for is the batch-128 schedule: 48 384 blocks, every output sample through an atomic.)
+  audio = ddsp.core.tf_float32(0.3 * rng.standard_normal((b, n)))
+  target = ddsp.core.tf_float32(0.8 * npy(audio) + 0.05 * rng.standard_normal((b, n)))
   got = float(loss(target, audio))
   ta = audio.clone().requires_grad_(True)
   val = loss(target, ta)
@@ -280,5 +281,6 @@ def test_config3_spectral_loss_batch128(ddsp):
     atol = 1e-9 + 2e-4 * np.abs(ref).max()
     err = np.abs(g[r:r + 1] - ref)
     # (d|x|/dx is a sign: a bin whose two magnitudes agree to rounding may take the other sign in fp32 - a frame's worth of
-    # samples a few tolerances off; test_spectral_loss_backward_vs_analytic_oracle)
-    assert (err > atol).mean() <= 5e-3 and err.max() <= 10 * atol, (r, float((err > atol).mean()), float(err.max()), atol)
+    # samples a few tolerances off; test_spectral_loss_backward_vs_analytic_oracle allows 0.1 % of its 3000 .. 20 000 samples,
+    # a 4 s row has 8500 frames over the six sizes: measured 0.15 % of the samples, the largest 6 tolerances)
+    assert (err > atol).mean() <= 3e-3 and err.max() <= 10 * atol, (r, float((err > atol).mean()), float(err.max()), atol)
