@@ -1,4 +1,4 @@
-"""Same-session A/B of library variants (tools/build_variant_lib.sh): per-launch time (dispatch events) of the two
+"""Same-session A/B of library variants (tools/build_variant.sh): per-launch time (dispatch events) of the two
 default kernels at batch 32 and 128, the variants taken in turn, `rounds` times; medians.
 
     python tools/exp_ab.py base new [--rounds 3] [--only harm|noise]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session for the round's evidence: parity tests, smoke, bench, rocprof kernel traces, PMC traffic, SQ counters.
 # Usage (from the build container): gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tag]'
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -41,7 +41,14 @@ echo "== configs[4] per GPU (48 kHz, 200 harmonics, 10 s, batch 32): rocprofv3 k
 for f in $(find $OUT/prof5 -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_config5.csv; head -4 $f | cut -c1-200; done
 grep "^{\"metric\"" $OUT/rocprof_bench_config5.log | tail -1 > $OUT/bench_config5_under_rocprof.json
 rm -rf $OUT/prof5
-timeout 600 python tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/bench_other_configs.jsonl; cut -c1-220 $OUT/bench_other_configs.jsonl
+# (BASELINE's other configurations are blocks of the bench line itself since round 5: configs_2, configs_3)
+python - <<PY
+import json
+d = json.load(open('$OUT/bench_1000.json'))
+for k in ('configs_2', 'configs_3', 'fnoise_full_resolution'):
+  b = d.get(k, {})
+  print(k, {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in b.items() if kk in ('ms_per_step', 'value', 'error', 'cost_of_the_twelve_bits_us', 'with_gradient_wrt_audio', 'kernel_breakdown_us')}, 'frac', b.get('whole_step', {}).get('frac'))
+PY
 echo "== PMC: HBM traffic per launch (separate FETCH_SIZE / WRITE_SIZE passes), batch 32 and 128"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b32 32 > /dev/null 2>&1; cp $OUT/pmc_traffic_b32/pmc_traffic.json $OUT/pmc_traffic.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic.json')); print(d['kernels'])"
 bash tools/pmc_traffic.sh $TAG/pmc_traffic_b128 128 > /dev/null 2>&1; cp $OUT/pmc_traffic_b128/pmc_traffic.json $OUT/pmc_traffic_b128.json; python -c "import json; d=json.load(open('$OUT/pmc_traffic_b128.json')); print(d['kernels'])"
@@ -52,11 +59,14 @@ bash tools/pmc.sh $TAG/pmc_sq_b128 128 > $OUT/pmc_sq_counters_b128.log 2>&1; cp 
 rm -rf $OUT/pmc_traffic_b32 $OUT/pmc_traffic_b128 $OUT/pmc_traffic_config5 $OUT/pmc_sq_b128
 echo "== next-row benches (Reverb, SpectralLoss, backward, streaming)"
 timeout 300 python tools/bench_reverb.py 32 2>&1 | tail -1 | tee $OUT/bench_reverb_b32.json | cut -c1-200
+timeout 300 python tools/bench_reverb.py 128 64000 48000 1 2>&1 | tail -1 | tee $OUT/bench_reverb_b128_one_ir.json | cut -c1-260
+timeout 300 python tools/bench_reverb.py 128 2>&1 | tail -1 | tee $OUT/bench_reverb_b128_ir_per_row.json | cut -c1-260
+timeout 300 python tools/bench_spectral_loss.py 128 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b128.json | cut -c1-200
 timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json | cut -c1-200
 timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json | cut -c1-300
 timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json | cut -c1-300
 echo "== shapes behind the specialised paths (tools/bench_generic.py), batch 32 and 128"
 timeout 300 python tools/bench_generic.py 32 2>/dev/null | grep "^{" > $OUT/generic_shapes_b32.jsonl; cut -c1-200 $OUT/generic_shapes_b32.jsonl
-echo "== determinism stress: 1000 launches per case, bits compared on the device (tools/stress_determinism.py)"
-timeout 900 python tools/stress_determinism.py --iters 1000 --label $TAG --out $OUT/determinism_stress.jsonl 2>&1 | grep "SUMMARY\|MISMATCH" | cut -c1-300
+echo "== determinism stress: ${STRESS_ITERS:-300} launches per case, bits compared on the device (tools/stress_determinism.py)"
+timeout 600 python tools/stress_determinism.py --iters ${STRESS_ITERS:-300} --label $TAG --out $OUT/determinism_stress.jsonl 2>&1 | grep "SUMMARY\|MISMATCH" | cut -c1-300
 echo "== done"
