@@ -780,7 +780,7 @@ extern "C" int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, 
 
 static int launch_fir(const float* x, const float* ir, float* out, int B, int Bir, int F, int L,
                       int N, int delay_compensation, uint64_t seed, uint64_t batch_offset,
-                      int bits23, hipStream_t st) {
+                      int bits23, int taps_bounded, hipStream_t st) {
   if (B > 65535) return DDSP_ERR_UNSUPPORTED;
   FirArgs p;
   p.x = x; p.ir = ir; p.out = out;
@@ -805,7 +805,7 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
   }
   // any other tap count and frame size: Toeplitz products on the matrix cores (filtered_noise_general.hip)
   if (!general_plain_env() && tv_fir_mfma_ok(B, Bir, F, L, N))
-    return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, bits23, st);
+    return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, bits23, taps_bounded, st);
   // tile: as many outputs as keep x + taps under the LDS budget
   int tile = 1024;
   size_t lds = 0;
@@ -828,7 +828,7 @@ extern "C" int ddsp_fft_convolve_same_f32(const float* audio, const float* impul
                                           int delay_compensation, void* stream) {
   if (!audio || !impulse_response || !out) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || F <= 0 || L <= 0 || N <= 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
-  return launch_fir(audio, impulse_response, out, B, Bir, F, L, N, delay_compensation, 0, 0, 0,
+  return launch_fir(audio, impulse_response, out, B, Bir, F, L, N, delay_compensation, 0, 0, 0, 0,
                     (hipStream_t)stream);
 }
 
@@ -909,7 +909,7 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
   if (rc != DDSP_OK) return rc;
   return launch_fir(noise, ir, audio, B, B, F, ir_geom(M, window_size).L, N, -1, seed,
-                    batch_offset, bits23, st);
+                    batch_offset, bits23, scale, st);             // (scale: the taps were designed from squashed magnitudes)
 }
 
 // =====================================================================================

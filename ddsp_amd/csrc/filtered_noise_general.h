@@ -16,9 +16,10 @@ int launch_noise_ir_gemm(const float* mag, float* ctl_out, float* ir, long rows,
 // the time-varying FIR (core.fft_convolve, ddsp/core.py:1382-1473, as a time-domain sum) for any tap count up to
 // kGfMaxTaps and any frame size
 bool tv_fir_mfma_ok(int B, int Bir, int F, int L, int N);
-// (bits23: noise generated with 23-bit samples - DDSP_NOISE_BITS_23, common.h - when x is null)
+// (bits23: noise generated with 23-bit samples - DDSP_NOISE_BITS_23, common.h - when x is null; taps_bounded: the taps are this
+// library's own design of exp_sigmoid magnitudes and need no normalisation ahead of the fp16 split)
 int launch_tv_fir_mfma(const float* x, const float* ir, float* out, int B, int Bir, int F, int L, int N, int start,
-                       uint64_t seed, uint64_t batch_offset, int bits23, hipStream_t st);
+                       uint64_t seed, uint64_t batch_offset, int bits23, int taps_bounded, hipStream_t st);
 
 // FilteredNoise.__call__ in ONE launch for up to 128 bands and 256 taps: tv_fir_mfma_kernel designing its tiles' taps itself
 bool filtered_noise_general_fused_ok(int B, int F, int M, int N, int window_size);

@@ -504,6 +504,8 @@ struct GfArgs {
   int ir_pairs;                // the tap rows may be read two floats at a time
   uint32_t k0, k1;
   uint64_t batch_offset;
+  int taps_bounded;            // KS = 0: the taps in HBM are this library's own design of exp_sigmoid magnitudes (<= 2 in sum): no
+                               // normalisation pass (it read every tap row a second time: 139 -> 223 us at 256 bands, r05_final)
   // (GEN = false with x == null: DDSP_NOISE_BITS_23 - the noise is made here with 23-bit samples, which take the hi / lo planes
   // that supplied noise takes; common.h)
   // taps designed in the kernel (template parameter KS > 0): FilteredNoise.__call__ in one launch
@@ -566,8 +568,10 @@ __global__ __launch_bounds__(512, (NT == 4 && NPW == 1) ? 6 : 1) void tv_fir_mfm
     }
     const int rows_in = max(0, min(p.max_rows, p.F - f_lo));
     if constexpr (KS == 0) {
-      const float* irb = p.ir + (size_t)b * p.ir_batch_stride + (size_t)f_lo * p.L;
-      for (int k = tid; k < rows_in * p.L; k += nthr) hmx = fmaxf(hmx, fabsf(irb[k]));
+      if (!p.taps_bounded) {
+        const float* irb = p.ir + (size_t)b * p.ir_batch_stride + (size_t)f_lo * p.L;
+        for (int k = tid; k < rows_in * p.L; k += nthr) hmx = fmaxf(hmx, fabsf(irb[k]));
+      }
     } else if (!p.scale) {
       const float* mb = p.mag + ((size_t)b * p.F + f_lo) * p.M;
       for (int k = tid; k < rows_in * p.M; k += nthr) mmx = fmaxf(mmx, fabsf(mb[k]));
@@ -1048,10 +1052,11 @@ static int gf_launch(GfPlan& pl, int B, int Bir, int F, int L, int N, int start,
 }
 
 int launch_tv_fir_mfma(const float* x, const float* ir, float* out, int B, int Bir, int F, int L, int N, int start,
-                       uint64_t seed, uint64_t batch_offset, int bits23, hipStream_t st) {
+                       uint64_t seed, uint64_t batch_offset, int bits23, int taps_bounded, hipStream_t st) {
   const bool gen = x == nullptr && !bits23;
   GfPlan pl = gf_plan(F, L, N, gen);
   if (!pl.ok) return DDSP_ERR_UNSUPPORTED;
+  pl.a.taps_bounded = taps_bounded;
   return gf_launch(pl, B, Bir, F, L, N, start, x, ir, out, seed, batch_offset, 0, gen, st);
 }
 
