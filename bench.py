@@ -27,7 +27,7 @@ reported beside it (`timing`).
 The JSON line also carries
   roofline         : dominant kernel, algorithmic bytes per launch / its mean duration measured
                      with HIP events on the launch stream during the timed regions (ddsp_profile_*),
-                     against the 8 TB/s HBM peak (the path is in fact ALU-bound; see DESIGN.md).
+                     against the 8 TB/s HBM peak (the path is in fact ALU-bound; see DESIGN.md section 4).
   configs_1        : the same step at BASELINE.json configs[1] (batch 32 per GPU; two streams, `one_stream` beside it),
                      timed the same way right after the headline: ms_per_step, value, whole-step and dominant-kernel
                      fractions of the HBM roofline.  (Rounds 1-2 had the two shapes the other way round.)
@@ -229,7 +229,7 @@ def load_issue_counters(a, dominant, batch, avg_launch_s):
       out = {'source': rec.get('source', 'profiles/pmc_sq_*.json'), 'wave_instructions_per_launch': total,
              'by_class': insts, 'per_simd_clock': total / simd_clocks,
              'note': 'a SIMD issues at most one instruction per clock; with four busy wavefronts one per 2.15 (plain fp32) to '
-                     '3.3 (fp64, conversions, DPP, packed) to 5.5 clocks (transcendental), DESIGN.md section 4'}
+                     '3.3 (fp64, conversions, DPP, packed) to 5.5 clocks (transcendental), HISTORY.md section 4'}
       if c.get('SQ_WAVE_CYCLES') and c.get('SQ_WAIT_INST_ANY') is not None:
         out['wave_cycles_waiting_for_an_instruction'] = c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']
       if c.get('SQ_LDS_IDX_ACTIVE') and c.get('SQ_LDS_BANK_CONFLICT') is not None:
@@ -333,7 +333,7 @@ def build_result(a, world, B, elapsed, prof, breakdown, dominant, overlap, aux=N
     result['roofline']['measured_copy_GBs'] = aux['measured_copy_GBs']
     result['roofline']['frac_of_measured_copy'] = roof['achieved'] / aux['measured_copy_GBs']
   if 'f0_regimes' in aux:
-    # SURVEY.md 8(d) names two f0 regimes; the wavetable kernel's time depends on f0 in others too, so the
+    # SURVEY.md 8(d) names two f0 regimes; the wavetable kernel's time depends on f0 in others too (HISTORY.md section 7), so the
     # line carries a small sweep - the same step, the same issue mode - with the whole-step roofline fraction of each, the
     # worst of them at the top level
     regimes = {}
@@ -718,7 +718,7 @@ def main(argv=None):
       del src, dst
       # (ii) f0 regimes beside the headline's 70 +- 1 Hz: SURVEY.md 8(d)'s second, "test-like" f0 = 200 + N(0,1) Hz
       # (processors_test.py:40; 39 of 100 harmonics below Nyquist, harmonic 40 ON it), a note with vibrato (220 Hz, 6 Hz deep
-      # at 5.5 Hz), and 333 / 500 +- 1 Hz (Nyquist / 24 and / 16: the table reads' bank-conflict resonances, DESIGN.md
+      # at 5.5 Hz), and 333 / 500 +- 1 Hz (Nyquist / 24 and / 16: the table reads' bank-conflict resonances, HISTORY.md
       # section 7).  Same step, same stream mode, regions of the same K steps, three each
       x_r = make_inputs(B, a, seed=2000 + rank)
       jitter = x_r['f0_hz'] - a.f0
