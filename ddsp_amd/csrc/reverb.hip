@@ -23,7 +23,7 @@
 // share.  Every block is then transformed ONCE (above, each is the imaginary part of one spectrum and the real part of the
 // next), the multiply-add pass reads half the spectra, and the audio's blocks and the impulse response's partitions are one
 // launch (the partitions' launch ahead of the audio's was 15 - 19 us of latency at any batch size): 126 -> 100 us at batch 128,
-// 50 -> 44 at batch 32 (profiles/r05_reverb_row_pairs_and_the_fused_experiment.txt, which also has the form that keeps every
+// 50 -> 44 at batch 32; with the transform blocks persistent and the multiply-add pass at four wavefronts per SIMD: 91 us (profiles/r05_reverb_row_pairs_and_the_fused_experiment.txt, which also has the form that keeps every
 // spectrum on chip - bin classes with the ring of spectra in registers - built, measured at 99 us and taken out again).
 //
 // The forward transform is an in-place radix-8 (+ one radix-2 stage) decimation-in-frequency FFT that leaves its bins in
@@ -71,69 +71,13 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {          // a * co
 
 // 8192 = 8^4 * 2: four radix-8 stages (one butterfly per thread: its eight loads are issued before any arithmetic and its
 // stores after it - the butterflies of a stage touch disjoint elements, which the compiler cannot see through the LDS
-// indices) and the radix-2 stage on neighbours: five passes over the LDS and five barriers where radix 4 took seven
-// (rounds 1-3; the SpectralLoss transforms went the same way: csrc/fft_radix8.h).
+// indices) and the radix-2 stage on neighbours: five passes and five barriers where radix 4 took seven (rounds 1-3; the
+// SpectralLoss transforms went the same way: csrc/fft_radix8.h).  Forward (decimation in frequency, kernel exp(-2 pi i nk/N))
+// leaves the bins in a digit-reversed order; the inverse is the exact algebraic inverse of the forward pipeline - the stages
+// undone one by one in reverse order (conjugate twiddles, conjugate 8-point DFT, factor 1/N applied at the output) - so it
+// accepts that order and returns natural order.  Both live inside the two loop kernels below.
 constexpr int kRvPairs = kRvN / 2 / kRvThreads;                // float4 pairs per thread in the radix-2 stage (4)
 static_assert(kRvN / 8 == kRvThreads, "one radix-8 butterfly per thread");
-
-__device__ __forceinline__ void fft_forward(float2* s, int tid) {
-#pragma unroll 1
-  for (int q = kRvN / 8; q >= 2; q >>= 3) {                    // q = 1024, 128, 16, 2
-    const float inv_len = 0.125f / (float)q;                   // exact: powers of two
-    const int pos = tid & (q - 1);
-    const int i0 = ((tid - pos) << 3) + pos;
-    float2 v[8], w[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = s[RP(i0 + m * q)];
-    const float rev = (float)pos * inv_len;                    // revolutions, exact
-    fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);      // conj of the twiddles
-    fft_dft8(v);
-    s[RP(i0)] = v[0];
-#pragma unroll
-    for (int m = 1; m < 8; ++m) s[RP(i0 + m * q)] = cmulc(v[m], w[m]);
-    __syncthreads();
-  }
-  {                                                            // radix-2, neighbours, twiddle 1
-    float4 v[kRvPairs];
-#pragma unroll
-    for (int u = 0; u < kRvPairs; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
-#pragma unroll
-    for (int u = 0; u < kRvPairs; ++u)
-      *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
-          make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void fft_inverse(float2* s, int tid) {
-  {
-    float4 v[kRvPairs];
-#pragma unroll
-    for (int u = 0; u < kRvPairs; ++u) v[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (tid + kRvThreads * u))]);
-#pragma unroll
-    for (int u = 0; u < kRvPairs; ++u)
-      *reinterpret_cast<float4*>(&s[RP(2 * (tid + kRvThreads * u))]) =
-          make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int q = 2; q <= kRvN / 8; q <<= 3) {
-    const float inv_len = 0.125f / (float)q;
-    const int pos = tid & (q - 1);
-    const int i0 = ((tid - pos) << 3) + pos;
-    const float rev = (float)pos * inv_len;
-    float2 v[8], w[8];
-    fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);
-    // undo y_m conj(w^m), then the conjugate transform (factor 8, part of the 1 / N left to the caller)
-    v[0] = fft_conj(s[RP(i0)]);
-#pragma unroll
-    for (int m = 1; m < 8; ++m) v[m] = fft_conj(cmul(s[RP(i0 + m * q)], w[m]));
-    fft_dft8(v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[RP(i0 + j * q)] = fft_conj(v[j]);
-    __syncthreads();
-  }
-}
 
 struct RvArgs {
   int N, L, n_out, nb, np, delay;      // n_out: samples written per row (out[n] = y[n + delay], n < n_out)
@@ -146,76 +90,6 @@ struct RvArgs {
   // half the spectra written and read by the multiply-add pass.  B: rows (an odd batch's last pair holds one).
   int pairs, B;
 };
-
-// One block = one 8192-point forward transform: block / partition j of row (pair / impulse response) b, `stride` spectra per row.
-// IS_IR: the rows are IR partitions.
-template <bool IS_IR>
-__device__ __forceinline__ void rv_fft_block(float2* s, const float* __restrict__ src, float2* __restrict__ spec, const RvArgs& p,
-                                             int j, int b, int stride) {
-  const int tid = threadIdx.x;
-  const int len = IS_IR ? p.L : p.N;
-  const bool pair_mode = !IS_IR && p.pairs > 0;
-  const float* __restrict__ row = src + (size_t)(pair_mode ? 2 * b : b) * len;
-  const float* __restrict__ row_im = (pair_mode && 2 * b + 1 < p.B) ? row + len : nullptr;    // (pair mode: the second row, or none)
-  // IR partition: taps jP .. (j+1)P-1 then P zeros (imaginary part 0);
-  // x spectrum m = j: real part samples (m-2)P .. mP-1 (block m-1), imaginary part (m-1)P .. (m+1)P-1 (block m)
-  // pair mode: real and imaginary part are block j (samples (j-1)P .. (j+1)P-1) of the pair's two rows
-  const int base = IS_IR ? j * kRvP : (pair_mode ? (j - 1) * kRvP : (j - 2) * kRvP);
-  const int live = IS_IR ? kRvP : kRvN;
-  // DDSP_CONV_REVERSE_AUDIO / _IR: logical sample g is stored at len-1-g (correlations for the backward pass)
-  const bool rev = (p.flags & (IS_IR ? DDSP_CONV_REVERSE_IR : DDSP_CONV_REVERSE_AUDIO)) != 0;
-  const bool vec = !rev && ((len & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-  auto load4 = [&](const float* __restrict__ row, int g) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row != nullptr && g + 3 >= 0 && g < len) {
-      if (rev) {
-        if (g >= 0 && g < len) v.x = row[len - 1 - g];
-        if (g + 1 >= 0 && g + 1 < len) v.y = row[len - 2 - g];
-        if (g + 2 >= 0 && g + 2 < len) v.z = row[len - 3 - g];
-        if (g + 3 >= 0 && g + 3 < len) v.w = row[len - 4 - g];
-      } else if (vec && g >= 0 && g + 3 < len) {
-        v = *reinterpret_cast<const float4*>(row + g);
-      } else {
-        if (g >= 0 && g < len) v.x = row[g];
-        if (g + 1 >= 0 && g + 1 < len) v.y = row[g + 1];
-        if (g + 2 >= 0 && g + 2 < len) v.z = row[g + 2];
-        if (g + 3 >= 0 && g + 3 < len) v.w = row[g + 3];
-      }
-    }
-    return v;
-  };
-  for (int i4 = tid; i4 < kRvN / 4; i4 += kRvThreads) {
-    const int i = 4 * i4, g = base + i;
-    float4 re = make_float4(0.f, 0.f, 0.f, 0.f), im = re;
-    if (i < live) {
-      re = load4(row, g);
-      // effects.Reverb._mask_dry_ir (effects.py:50-60): tap 0 carries the dry signal -> 0
-      if (IS_IR && g == 0 && (p.flags & DDSP_CONV_MASK_TAP0)) re.x = 0.0f;
-      if (!IS_IR) im = pair_mode ? load4(row_im, g) : load4(row, g + kRvP);
-    }
-    *reinterpret_cast<float4*>(&s[RP(4 * i4)]) = make_float4(re.x, im.x, re.y, im.y);
-    *reinterpret_cast<float4*>(&s[RP(4 * i4 + 2)]) = make_float4(re.z, im.z, re.w, im.w);
-  }
-  __syncthreads();
-  fft_forward(s, tid);
-  float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)b * stride + j) * kRvN);
-  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) dst[i2] = *reinterpret_cast<const float4*>(&s[RP(2 * i2)]);
-}
-
-// The audio's blocks and the impulse responses' partitions in ONE launch (round 5): grid (max(nb, np), rows + Bir) - rows
-// blockIdx.y < rows are audio rows (row pairs), the rest impulse responses.  As two launches the second waited for the first's
-// twelve blocks: one 8192-point transform of latency (15 - 19 us at any batch size, profiles/r05e) ahead of every call.
-__global__ __launch_bounds__(kRvThreads) void rv_fft_kernel(const float* __restrict__ audio, const float* __restrict__ ir,
-                                                            float2* __restrict__ xspec, float2* __restrict__ hspec, RvArgs p,
-                                                            int rows) {
-  extern __shared__ __attribute__((aligned(16))) float2 s[];
-  const int j = blockIdx.x, b = blockIdx.y;
-  if (b < rows) {
-    if (j < p.nb) rv_fft_block<false>(s, audio, xspec, p, j, b, p.nb);
-  } else {
-    if (j < p.np) rv_fft_block<true>(s, ir, hspec, p, j, b - rows, p.np);
-  }
-}
 
 // One thread per pair of bins (16-byte accesses).  The IR spectra of all partitions sit in
 // registers, the Z spectra slide through a register window, W_m replaces Z_m (odd m; every m for row pairs) in memory.
@@ -252,44 +126,261 @@ __global__ __launch_bounds__(kRvMacThreads) void rv_mac_kernel(float4* __restric
   }
 }
 
-__global__ __launch_bounds__(kRvThreads) void rv_ifft_kernel(const float2* __restrict__ yspec,
-                                                             const float* __restrict__ audio,
-                                                             float* __restrict__ out, RvArgs p) {
+// ---- the transform kernels: persistent blocks ---------------------------------------------------------------------------------
+// A block LOOPS over transforms (two blocks of 16 wavefronts per CU, 64 registers) and requests the next one's input before it
+// starts on the current one.  The first pass of the forward transform (q = 1024: elements tid + 1024 m) works on those
+// registers and the last (radix 2 on neighbours) goes straight from LDS to the spectrum in memory: 8 instead of 12 passes over
+// the LDS array per transform; the inverse likewise (radix 2 on the way in, the last radix-8 pass straight to the output rows:
+// only its outputs 4 .. 7 - the second half of the block, what overlap-save keeps - become samples).  The audio's blocks and
+// the impulse responses' partitions are items of one launch (as two launches the second waited for the first's twelve blocks:
+// 15 - 19 us at any batch size, profiles/r05e).  Until late in round 5 a block was ONE transform - load, five passes, store,
+// both blocks of a CU in the same phase at the same time -: 34.9 / 33.5 us per launch at batch 128 against 30.4 / 32.0 now
+// (profiles/r05q_reverb_persistent_ab.txt); what is left is the sum of LDS time and ALU time of the passes, which overlap
+// poorly behind their barriers.  The index t the addresses and twiddles are made from is laundered once per transform
+// (DDSP_KEEP_IN_VGPR): they are functions of the thread index alone, and the compiler otherwise makes them ahead of the loop,
+// keeps sixty registers of them alive, spills, and waits for the prefetch at every reload.
+struct RvItem { int j, b, ir; };
+__device__ __forceinline__ RvItem rv_item(int w, int n_ir, const RvArgs& p) {
+  RvItem it;
+  if (w < n_ir) { it.ir = 1; it.b = w / p.np; it.j = w - it.b * p.np; }
+  else { const int a = w - n_ir; it.ir = 0; it.b = a / p.nb; it.j = a - it.b * p.nb; }
+  return it;
+}
+
+// elements tid + 1024 m (m = 0 .. 7) of the transform's input: one path for the three kinds of
+// input - an IR partition (P taps, then zeros; no imaginary part), two blocks of one row (the imaginary part is the row one
+// block later), block j of a pair of rows
+__device__ __forceinline__ void rv_fetch(float2 (&v)[8], const float* __restrict__ audio, const float* __restrict__ ir,
+                                         const RvArgs& p, RvItem it, int tid) {
+  const bool is_ir = it.ir != 0;
+  const int len = is_ir ? p.L : p.N;
+  const bool pair_mode = !is_ir && p.pairs > 0;
+  const float* __restrict__ row = (is_ir ? ir : audio) + (size_t)(pair_mode ? 2 * it.b : it.b) * len;
+  const float* __restrict__ row_im = is_ir ? nullptr : (pair_mode ? (2 * it.b + 1 < p.B ? row + len : nullptr) : row);
+  const int base = is_ir ? it.j * kRvP : (pair_mode ? (it.j - 1) * kRvP : (it.j - 2) * kRvP);
+  const int shift_im = pair_mode ? 0 : kRvP;
+  const int hi = is_ir ? min(len, base + kRvP) : len;            // (a partition ends after P taps)
+  const bool rev = (p.flags & (is_ir ? DDSP_CONV_REVERSE_IR : DDSP_CONV_REVERSE_AUDIO)) != 0;
+  // effects.Reverb._mask_dry_ir (effects.py:50-60): tap 0 carries the dry signal -> 0
+  const int lo = (is_ir && (p.flags & DDSP_CONV_MASK_TAP0)) ? 1 : 0;
+  const int g0 = base + tid;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int g = g0 + kRvThreads * m, gi = g + shift_im;
+    float re = 0.0f, im = 0.0f;
+    if (g >= lo && g < hi) re = row[rev ? len - 1 - g : g];
+    if (row_im != nullptr && gi >= 0 && gi < hi) im = row_im[rev ? len - 1 - gi : gi];
+    v[m] = make_float2(re, im);
+  }
+}
+
+__global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __restrict__ audio, const float* __restrict__ ir,
+                                                                 float2* __restrict__ xspec, float2* __restrict__ hspec, RvArgs p,
+                                                                 int n_ir, int n_items) {
   extern __shared__ __attribute__((aligned(16))) float2 s[];
-  const int tid = threadIdx.x, j = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  int w = blockIdx.x;
+  float2 nv[8];
+  if (w < n_items) rv_fetch(nv, audio, ir, p, rv_item(w, n_ir, p), tid);
+  bool first = true;
+  while (w < n_items) {
+    const RvItem it = rv_item(w, n_ir, p);
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = nv[m];
+    w += gridDim.x;
+    if (w < n_items) rv_fetch(nv, audio, ir, p, rv_item(w, n_ir, p), tid);
+    if (!first) __syncthreads();                 // the previous transform's last pass has read the array
+    first = false;
+    int t = tid;
+    DDSP_KEEP_IN_VGPR(t);                        // (twiddles are functions of the thread index: left alone the compiler makes them once,
+                                                 //  ahead of the loop, and keeps 14 + 42 registers of them alive through it)
+    {                                            // q = 1024: pos = tid, i0 = tid
+      float2 tw[8];
+      const float rev = (float)t * (0.125f / (float)(kRvN / 8));
+      fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), tw);
+      fft_dft8(v);
+      s[RP(t)] = v[0];
+#pragma unroll
+      for (int m = 1; m < 8; ++m) s[RP(t + m * (kRvN / 8))] = cmulc(v[m], tw[m]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = kRvN / 64; q >= 2; q >>= 3) {   // q = 128, 16, 2
+      const float inv_len = 0.125f / (float)q;
+      const int pos = t & (q - 1);
+      const int i0 = ((t - pos) << 3) + pos;
+      float2 x[8], tw[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) x[m] = s[RP(i0 + m * q)];
+      const float rev = (float)pos * inv_len;
+      fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), tw);
+      fft_dft8(x);
+      s[RP(i0)] = x[0];
+#pragma unroll
+      for (int m = 1; m < 8; ++m) s[RP(i0 + m * q)] = cmulc(x[m], tw[m]);
+      __syncthreads();
+    }
+    float2* __restrict__ spec = it.ir ? hspec : xspec;
+    float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)it.b * (it.ir ? p.np : p.nb) + it.j) * kRvN);
+    float4 y[kRvPairs];
+#pragma unroll
+    for (int u = 0; u < kRvPairs; ++u) y[u] = *reinterpret_cast<const float4*>(&s[RP(2 * (t + kRvThreads * u))]);
+#pragma unroll
+    for (int u = 0; u < kRvPairs; ++u)            // radix 2 on neighbours, twiddle 1
+      dst[t + kRvThreads * u] = make_float4(y[u].x + y[u].z, y[u].y + y[u].w, y[u].x - y[u].z, y[u].y - y[u].w);
+  }
+}
+
+__global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __restrict__ yspec, const float* __restrict__ audio,
+                                                                  float* __restrict__ out, RvArgs p, int nbo, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) float2 s[];
+  const int tid = threadIdx.x;
   const bool pair_mode = p.pairs > 0;
-  // spectrum m = 2j+1 holds output blocks 2j (real part) and 2j+1 (imaginary part); row pairs: spectrum j holds output block j
-  // of the pair's first row (real part) and of its second (imaginary part)
-  const float4* __restrict__ srcv = reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + (pair_mode ? j : 2 * j + 1)) * kRvN);
-  for (int i2 = tid; i2 < kRvN / 2; i2 += kRvThreads) *reinterpret_cast<float4*>(&s[RP(2 * i2)]) = srcv[i2];
-  __syncthreads();
-  fft_inverse(s, tid);
-  // overlap-save: the last P samples of the block are y[jP .. (j+1)P); out[n] = y[n + delay]
   const float scale = 1.0f / (float)kRvN;
   const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;           // only with n_out == N (checked by the host)
   const bool rev_a = (p.flags & DDSP_CONV_REVERSE_AUDIO) != 0, rev_o = (p.flags & DDSP_CONV_REVERSE_OUT) != 0;
-  if (pair_mode) {
-    const int b0 = 2 * b;
-    const bool two = b0 + 1 < p.B;
-    for (int i = tid; i < kRvP; i += kRvThreads) {
-      const float2 y = s[RP(kRvP + i)];
-      const int n = j * kRvP + i - p.delay;
-      if (n < 0 || n >= p.n_out) continue;
-      const int no = rev_o ? p.n_out - 1 - n : n, na = rev_a ? p.N - 1 - n : n;
-      out[(size_t)b0 * p.n_out + no] = fmaf(y.x, scale, dry ? audio[(size_t)b0 * p.N + na] : 0.0f);
-      if (two) out[(size_t)(b0 + 1) * p.n_out + no] = fmaf(y.y, scale, dry ? audio[(size_t)(b0 + 1) * p.N + na] : 0.0f);
-    }
-    return;
+  auto spectrum = [&](int w) {
+    const int b = w / nbo, j = w - b * nbo;
+    return reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + (pair_mode ? j : 2 * j + 1)) * kRvN);
+  };
+  int w = blockIdx.x;
+  float4 nv[kRvPairs];
+  if (w < n_items) {
+    const float4* __restrict__ src = spectrum(w);
+#pragma unroll
+    for (int u = 0; u < kRvPairs; ++u) nv[u] = src[tid + kRvThreads * u];
   }
-  const float* __restrict__ arow = audio + (size_t)b * p.N;
-  float* __restrict__ orow = out + (size_t)b * p.n_out;
-  for (int i = tid; i < kRvP; i += kRvThreads) {
-    const float2 y = s[RP(kRvP + i)];
-    const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
-    if (n0 >= 0 && n0 < p.n_out)
-      orow[rev_o ? p.n_out - 1 - n0 : n0] = fmaf(y.x, scale, dry ? arow[rev_a ? p.N - 1 - n0 : n0] : 0.0f);
-    if (n1 >= 0 && n1 < p.n_out)
-      orow[rev_o ? p.n_out - 1 - n1 : n1] = fmaf(y.y, scale, dry ? arow[rev_a ? p.N - 1 - n1 : n1] : 0.0f);
+  bool first = true;
+  while (w < n_items) {
+    const int b = w / nbo, j = w - b * nbo;
+    float4 v[kRvPairs];
+#pragma unroll
+    for (int u = 0; u < kRvPairs; ++u) v[u] = nv[u];
+    w += gridDim.x;
+    if (w < n_items) {
+      const float4* __restrict__ src = spectrum(w);
+#pragma unroll
+      for (int u = 0; u < kRvPairs; ++u) nv[u] = src[tid + kRvThreads * u];
+    }
+    if (!first) __syncthreads();
+    first = false;
+    int t = tid;
+    DDSP_KEEP_IN_VGPR(t);                         // (as in rv_fft_kernel)
+#pragma unroll
+    for (int u = 0; u < kRvPairs; ++u)            // radix 2 on neighbours on the way in
+      *reinterpret_cast<float4*>(&s[RP(2 * (t + kRvThreads * u))]) =
+          make_float4(v[u].x + v[u].z, v[u].y + v[u].w, v[u].x - v[u].z, v[u].y - v[u].w);
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 2; q <= kRvN / 64; q <<= 3) {   // q = 2, 16, 128
+      const float inv_len = 0.125f / (float)q;
+      const int pos = t & (q - 1);
+      const int i0 = ((t - pos) << 3) + pos;
+      const float rev = (float)pos * inv_len;
+      float2 x[8], tw[8];
+      fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), tw);
+      x[0] = fft_conj(s[RP(i0)]);
+#pragma unroll
+      for (int m = 1; m < 8; ++m) x[m] = fft_conj(cmul(s[RP(i0 + m * q)], tw[m]));
+      fft_dft8(x);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) s[RP(i0 + m * q)] = fft_conj(x[m]);
+      __syncthreads();
+    }
+    // q = 1024 (pos = i0 = tid): outputs 4 .. 7 are elements P + tid + 1024 (jj - 4) - the samples overlap-save keeps
+    {
+      float2 x[8];
+      {
+        float2 tw[8];
+        const float rev = (float)t * (0.125f / (float)(kRvN / 8));
+        fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), tw);
+        x[0] = fft_conj(s[RP(t)]);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) x[m] = fft_conj(cmul(s[RP(t + m * (kRvN / 8))], tw[m]));
+      }
+      // the dry signal, requested behind the twiddle products (their registers are free) and ahead of the butterfly
+      float d0[4], d1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t + kRvThreads * r;
+        d0[r] = d1[r] = 0.0f;
+        if (!dry) continue;
+        if (pair_mode) {
+          const int n = j * kRvP + i - p.delay;
+          if (n >= 0 && n < p.n_out) {
+            const int na = rev_a ? p.N - 1 - n : n;
+            d0[r] = audio[(size_t)(2 * b) * p.N + na];
+            if (2 * b + 1 < p.B) d1[r] = audio[(size_t)(2 * b + 1) * p.N + na];
+          }
+        } else {
+          const float* __restrict__ arow = audio + (size_t)b * p.N;
+          const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
+          if (n0 >= 0 && n0 < p.n_out) d0[r] = arow[rev_a ? p.N - 1 - n0 : n0];
+          if (n1 >= 0 && n1 < p.n_out) d1[r] = arow[rev_a ? p.N - 1 - n1 : n1];
+        }
+      }
+      fft_dft8(x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t + kRvThreads * r;
+        const float2 y = fft_conj(x[4 + r]);
+        if (pair_mode) {
+          const int n = j * kRvP + i - p.delay;
+          if (n < 0 || n >= p.n_out) continue;
+          const int no = rev_o ? p.n_out - 1 - n : n;
+          out[(size_t)(2 * b) * p.n_out + no] = fmaf(y.x, scale, d0[r]);
+          if (2 * b + 1 < p.B) out[(size_t)(2 * b + 1) * p.n_out + no] = fmaf(y.y, scale, d1[r]);
+        } else {
+          float* __restrict__ orow = out + (size_t)b * p.n_out;
+          const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
+          if (n0 >= 0 && n0 < p.n_out) orow[rev_o ? p.n_out - 1 - n0 : n0] = fmaf(y.x, scale, d0[r]);
+          if (n1 >= 0 && n1 < p.n_out) orow[rev_o ? p.n_out - 1 - n1 : n1] = fmaf(y.y, scale, d1[r]);
+        }
+      }
+    }
+  }
+}
+
+// The multiply-add pass with the partition count a template parameter: the window of spectra rotates through its registers
+// by unrolling instead of by moves, the next two spectra are requested ahead of the products, and twelve partitions (48 000
+// taps) take 110 registers instead of 138 - four wavefronts per SIMD, so that batch 128's 4096 wavefronts are resident at once
+// (at three per SIMD a quarter of them ran as a second round).
+template <int NP>
+__global__ __launch_bounds__(kRvMacThreads) void rv_mac_np_kernel(float4* __restrict__ xspec, const float4* __restrict__ hspec,
+                                                                  RvArgs p) {
+  const int idx = blockIdx.x * kRvMacThreads + threadIdx.x;      // < kRvN / 2
+  const int b = blockIdx.y;
+  const float4* __restrict__ hb = hspec + (size_t)(p.ir_batch == 1 ? 0 : b) * p.np * (kRvN / 2) + idx;
+  float4* __restrict__ xb = xspec + (size_t)b * p.nb * (kRvN / 2) + idx;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 h[NP], w[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    h[q] = (q < p.np) ? hb[(size_t)q * (kRvN / 2)] : zero;
+    w[q] = zero;
+  }
+  float4 n1 = xb[0], n2 = p.nb > 1 ? xb[(size_t)(kRvN / 2)] : zero;
+  for (int j0 = 0; j0 < p.nb; j0 += NP) {
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      const int j = j0 + r;
+      if (j < p.nb) {                                            // wave-uniform
+        w[r] = n1; n1 = n2;
+        if (j + 2 < p.nb) n2 = xb[(size_t)(j + 2) * (kRvN / 2)];
+        if (p.pairs != 0 || (j & 1) != 0) {                      // W_m only for odd m (blocks m-1 and m); row pairs: every m
+          float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {                         // slot (r - q) mod NP holds spectrum j - q (zeros before the first)
+            const float4 x = w[(r - q + NP) % NP];
+            const float2 a0 = cmul(make_float2(x.x, x.y), make_float2(h[q].x, h[q].y));
+            const float2 a1 = cmul(make_float2(x.z, x.w), make_float2(h[q].z, h[q].w));
+            y0.x += a0.x; y0.y += a0.y; y1.x += a1.x; y1.y += a1.y;
+          }
+          xb[(size_t)j * (kRvN / 2)] = make_float4(y0.x, y0.y, y1.x, y1.y);
+        }
+      }
+    }
   }
 }
 
@@ -336,26 +427,37 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   float2* xspec = (float2*)workspace;
   float2* hspec = xspec + (size_t)rows_z * p.nb * kRvN;
   const size_t lds = (size_t)kRvStore * sizeof(float2);
-  static const bool attr_set = [] {
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  static const bool attr2_set = [] {
     (void)hipFuncSetAttribute((const void*)rv_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
     (void)hipFuncSetAttribute((const void*)rv_ifft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRvStore * sizeof(float2)));
     return true;
   }();
-  (void)attr_set;
+  (void)attr2_set;
+  const int nbo = pair_mode ? p.nb : p.nb / 2;
   {
     ProfileScope prof(kReverbFft, st);
-    hipLaunchKernelGGL(rv_fft_kernel, dim3((unsigned)(p.nb > p.np ? p.nb : p.np), (unsigned)(rows_z + Bir)), dim3(kRvThreads), lds, st,
-                       audio, impulse_response, xspec, hspec, p, rows_z);
+    const int n_ir = Bir * p.np, n_items = n_ir + rows_z * p.nb;
+    hipLaunchKernelGGL(rv_fft_kernel, dim3((unsigned)(n_items < 2 * n_cu ? n_items : 2 * n_cu)), dim3(kRvThreads), lds, st,
+                       audio, impulse_response, xspec, hspec, p, n_ir, n_items);
   }
   {
     ProfileScope prof(kReverbMac, st);
-    hipLaunchKernelGGL(rv_mac_kernel, dim3(kRvN / 2 / kRvMacThreads, (unsigned)rows_z), dim3(kRvMacThreads), 0, st,
-                       (float4*)xspec, (const float4*)hspec, p);
+    const dim3 grid(kRvN / 2 / kRvMacThreads, (unsigned)rows_z), block(kRvMacThreads);
+    if (p.np <= 4) hipLaunchKernelGGL(rv_mac_np_kernel<4>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
+    else if (p.np <= 8) hipLaunchKernelGGL(rv_mac_np_kernel<8>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
+    else if (p.np <= 12) hipLaunchKernelGGL(rv_mac_np_kernel<12>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
+    else hipLaunchKernelGGL(rv_mac_kernel, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);      // (13 .. 16 partitions: the window of sixteen by moves, 138 registers)
   }
   {
     ProfileScope prof(kReverbIfft, st);
-    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)(pair_mode ? p.nb : p.nb / 2), (unsigned)rows_z), dim3(kRvThreads), lds, st,
-                       (const float2*)xspec, audio, out, p);
+    const int n_items = rows_z * nbo;
+    hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)(n_items < 2 * n_cu ? n_items : 2 * n_cu)), dim3(kRvThreads), lds, st,
+                       (const float2*)xspec, audio, out, p, nbo, n_items);
   }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
