@@ -151,12 +151,17 @@ __device__ __forceinline__ void sl_fwd_stage4(float2* s, int tid, int n_fr, int 
   sl_stage_sync<H>();
 }
 
+// kSlFusedFirst<H>: the first stage of the forward transform is a radix-8 stage with twiddles (every H >= 32), which
+// sl_load_stage1 runs on the samples as they arrive from memory; sl_forward<H, true> is the rest of the transform.
 template <int H>
+constexpr bool kSlFusedFirst = SlPlan<H>::N8 > 0 && (H / 8 > 1) && (H / 8 >= SlPlan<H>::M);
+
+template <int H, bool SKIP_FIRST = false>
 __device__ __forceinline__ void sl_forward(float2* s, int tid, int n_fr, int g_lo) {
   typedef SlPlan<H> P;
   if constexpr (P::N8 > 0) {
 #pragma unroll 1
-    for (int q = H / 8; q >= P::M && q > 1; q >>= 3) sl_fwd_stage8<H, false>(s, tid, n_fr, g_lo, q);      // sub-length 8 q: H, H / 8, ..
+    for (int q = SKIP_FIRST ? H / 64 : H / 8; q >= P::M && q > 1; q >>= 3) sl_fwd_stage8<H, false>(s, tid, n_fr, g_lo, q);      // sub-length 8 q: H, H / 8, ..
     if constexpr (P::M == 1) sl_fwd_stage8<H, true>(s, tid, n_fr, g_lo, 1);
   }
   if constexpr (P::N4 > 0) {
@@ -288,6 +293,86 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
   }
 }
 
+// Frames -> first radix-8 stage -> LDS (late round 5).  The first stage of the forward transform (q = H / 8) takes the
+// elements r + j H / 8 (j = 0 .. 7) of a frame - with 2 G frames of H points and 512 threads exactly one butterfly per thread -
+// so a thread can fetch those eight sample pairs itself, window them and write the stage's OUTPUT: the array is neither
+// written by a load pass nor read back by the first stage (8 of a thread's 8 + 8 stages ds_write_b64, the expensive half of
+// the LDS traffic - a 64-bit store occupies the store path for six cycles, a load the array for two), and one block barrier
+// goes.  The window at those elements is cos(a + j / 8 turn): one sine and one cosine per sample parity give all sixteen
+// values.  Frames past the end and samples past N are zeros, as in sl_load_frames.
+template <int S>
+__device__ __forceinline__ void sl_load_stage1(float2* s, const float* __restrict__ trow, const float* __restrict__ arow, int tid,
+                                               int f0, int n_frames, int N) {
+  constexpr int H = S / 2, G = kSlPoints / 2 / H, LOG2H = __builtin_ctz(H), HOP = S / 4, Q = H / 8;
+  static_assert(2 * G * Q == kSlThreads, "one butterfly of the first stage per thread");
+  const int g2 = tid / Q, r = tid & (Q - 1);
+  const int g = g2 >= G ? g2 - G : g2;
+  const float* __restrict__ row = g2 >= G ? arow : trow;
+  const bool vec = ((N & 1) == 0) && (((reinterpret_cast<uintptr_t>(trow) | reinterpret_cast<uintptr_t>(arow)) & 7) == 0);
+  const int n0 = (f0 + g) * HOP + 2 * r;
+  const bool live = f0 + g < n_frames;
+  float2 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + j * (S / 8);
+    v[j] = make_float2(0.f, 0.f);
+    if (live && n < N) {
+      if (vec) {
+        v[j] = *reinterpret_cast<const float2*>(row + n);
+      } else {
+        v[j].x = row[n];
+        if (n + 1 < N) v[j].y = row[n + 1];
+      }
+    }
+  }
+  // w[i] = 0.5 - 0.5 cos(2 pi i / S) at i = 2 r + j S / 8 (+ 1): cos(a + j pi / 4)
+  const float kR = 0.70710678118654752f;
+  const float a0 = (float)(2 * r) * (1.0f / (float)S), a1 = (float)(2 * r + 1) * (1.0f / (float)S);
+  const float c0 = 0.5f * __builtin_amdgcn_cosf(a0), s0 = 0.5f * __builtin_amdgcn_sinf(a0);
+  const float c1 = 0.5f * __builtin_amdgcn_cosf(a1), s1 = 0.5f * __builtin_amdgcn_sinf(a1);
+  const float d0 = (c0 - s0) * kR, e0 = (c0 + s0) * kR, d1 = (c1 - s1) * kR, e1 = (c1 + s1) * kR;
+  const float hc0[8] = {c0, d0, -s0, -e0, -c0, -d0, s0, e0};            // 0.5 cos(a0 + j pi / 4)
+  const float hc1[8] = {c1, d1, -s1, -e1, -c1, -d1, s1, e1};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = make_float2(v[j].x * (0.5f - hc0[j]), v[j].y * (0.5f - hc1[j]));
+  fft_dft8(v);
+  float2 w[8];
+  const float rev = (float)r * (0.125f / (float)Q);
+  fft_powers8(make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)), w);   // conj of the twiddles
+  const int i0 = (g2 << LOG2H) + r;
+  s[SP(i0)] = v[0];
+#pragma unroll
+  for (int m = 1; m < 8; ++m) s[SP(i0 + m * Q)] = sl_cmulc(v[m], w[m]);
+  sl_stage_sync<H>();
+}
+
+// frames of both signals, windowed and transformed (bin k at sl_pos<H>(k))
+template <int S>
+__device__ __forceinline__ void sl_frames_to_spectra(float2* s, const float* __restrict__ trow, const float* __restrict__ arow,
+                                                     int tid, int f0, int n_frames, int N) {
+  constexpr int H = S / 2, G = kSlPoints / 2 / H;
+  // (DDSP_SL_NO_*: parts of the kernels compiled out for the time accounting of tools/exp_loss_ablation.sh - wrong results)
+#if defined(DDSP_SL_NO_LOAD) || defined(DDSP_SL_NO_FFT) || defined(DDSP_SL_UNFUSED)
+#ifndef DDSP_SL_NO_LOAD
+  sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
+#endif
+  __syncthreads();
+#ifndef DDSP_SL_NO_FFT
+  sl_forward<H>(s, tid, 2 * G, 0);
+#endif
+#else
+  if constexpr (kSlFusedFirst<H>) {
+    sl_load_stage1<S>(s, trow, arow, tid, f0, n_frames, N);
+    sl_forward<H, true>(s, tid, 2 * G, 0);
+  } else {
+    sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
+    __syncthreads();
+    sl_forward<H>(s, tid, 2 * G, 0);
+  }
+#endif
+  if (SlPlan<H>::kWaveLocal) __syncthreads();                  // the bins of a frame are read by other wavefronts
+}
+
 // One block of one FFT size: G frames of row b from frame bx * G on; nbx = blocks per row of this size.
 template <int S>
 __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThreads / 64], const float* __restrict__ target,
@@ -303,15 +388,7 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-  // (DDSP_SL_NO_*: parts of the kernels compiled out for the time accounting of tools/exp_loss_ablation.sh - wrong results)
-#ifndef DDSP_SL_NO_LOAD
-  sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
-#endif
-  __syncthreads();
-#ifndef DDSP_SL_NO_FFT
-  sl_forward<H>(s, tid, 2 * G, 0);
-#endif
-  if (SlPlan<H>::kWaveLocal) __syncthreads();                  // the bins of a frame are read by other wavefronts
+  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N);
   // ---- untangle, magnitudes of bins 0 .. S/2, L1 terms ---------------------------------------------
   // per PAIR of bins (k, S/2 - k), k = 0 .. S/4: the two share the packed bins Z[k] and Z[H-k], their positions and the
   // twiddle (X[k] = E + W^k O, X[H-k] = conj(E - W^k O)) - half the LDS reads, bit reversals and sin / cos of a loop over
@@ -374,7 +451,7 @@ struct SlMulti {
   int size[16], first[17], nbx[16], frames[16], offset[16];      // per size: S, first linear block, blocks per row, frames, partial offset
   float mag_scale[16], log_scale[16];                            // (the gradient kernel: weight / count of the size)
 };
-__global__ __launch_bounds__(kSlThreads) void stft_l1_kernel(const float* __restrict__ target, const float* __restrict__ audio,
+__global__ __launch_bounds__(kSlThreads, 8) void stft_l1_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                              double* __restrict__ partial, int N, SlMulti m, float safe_eps) {
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   __shared__ double red[2][kSlThreads / 64];
@@ -408,10 +485,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_mag_kernel(const float* __res
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int f0 = blockIdx.x * G;
-  sl_load_frames<S>(s, target + (size_t)b * N, audio + (size_t)b * N, tid, f0, n_frames, N);
-  __syncthreads();
-  sl_forward<H>(s, tid, 2 * G, 0);
-  if (SlPlan<H>::kWaveLocal) __syncthreads();
+  sl_frames_to_spectra<S>(s, target + (size_t)b * N, audio + (size_t)b * N, tid, f0, n_frames, N);
   for (int e = tid; e < G * (H + 1); e += kSlThreads) {
     const int g = e / (H + 1), k = e - g * (H + 1);
     if (f0 + g < n_frames) {
@@ -458,14 +532,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-#ifndef DDSP_SL_NO_LOAD
-  sl_load_frames<S>(s, trow, arow, tid, f0, n_frames, N);
-#endif
-  __syncthreads();
-#ifndef DDSP_SL_NO_FFT
-  sl_forward<H>(s, tid, 2 * G, 0);
-#endif
-  if (SlPlan<H>::kWaveLocal) __syncthreads();
+  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N);
   // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
   // grad_loss == nullptr: the fused loss + gradient call - dL/dloss = 1 and the block's L1 sums go to
   // `partial` exactly as stft_l1_kernel writes them (the frame spectra are computed once for both)
@@ -596,7 +663,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
 }
 
 // Value and gradient of the 'L1' mag + logmag loss: every FFT size in one grid, as stft_l1_kernel.
-__global__ __launch_bounds__(kSlThreads) void stft_l1_bwd_kernel(const float* __restrict__ target, const float* __restrict__ audio,
+__global__ __launch_bounds__(kSlThreads, 8) void stft_l1_bwd_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                                  const float* __restrict__ grad_loss,
                                                                  float* __restrict__ grad_audio, int N, SlMulti m,
                                                                  float safe_eps, double* __restrict__ partial) {
