@@ -462,7 +462,7 @@ int launch_noise_ir_gemm(const float* mag, float* ctl_out, float* ir, long rows,
   const GiMatrix* m = gi_matrix(M, window_size);
   if (!m) return DDSP_ERR_LAUNCH;
   const int L = ir_geom(M, window_size).L;
-  ProfileScope prof(kNoiseIr, st);
+  ProfileScope prof(kNoiseIrGemm, st);
   switch (m->KS) {
     case 1: gi_launch<1>(mag, ctl_out, ir, m, rows, M, L, bias, scale, st); break;
     case 2: gi_launch<2>(mag, ctl_out, ir, m, rows, M, L, bias, scale, st); break;
@@ -1036,7 +1036,7 @@ static int gf_launch(GfPlan& pl, int B, int Bir, int F, int L, int N, int start,
   if (tiles > 0x7fffffffL / 2) return DDSP_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)tiles, (unsigned)B), block((unsigned)(64 * a.W));
   // gen: the no-lo-plane instances (generated noise of 2048 levels); otherwise supplied noise or 23-bit samples made in the kernel
-  ProfileScope prof(kTvFir, st);
+  ProfileScope prof(kTvFirMfma, st);
   const int npw = ks > 0 && a.NTu > 8 ? 2 : 1;
 #define DDSP_GF_CASE(NT_, KS_, NPW_)                                        \
   if (pl.NT == NT_ && ks == KS_ && npw == NPW_) {                           \
@@ -1371,7 +1371,7 @@ int launch_noise_bwd_mfma(const float* magnitudes, const float* noise, const flo
   const dim3 grid((unsigned)((F + a.NF - 1) / a.NF), (unsigned)B);
   const void* fn = lo_planes ? (const void*)noise_bwd_mfma_kernel<false> : (const void*)noise_bwd_mfma_kernel<true>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGfLdsBudget);
-  ProfileScope prof(kNoiseBwdTaps, st);
+  ProfileScope prof(kNoiseBwdMfma, st);
   if (lo_planes) hipLaunchKernelGGL((noise_bwd_mfma_kernel<false>), grid, dim3(512), lds, st, a);
   else hipLaunchKernelGGL((noise_bwd_mfma_kernel<true>), grid, dim3(512), lds, st, a);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;

@@ -1189,7 +1189,7 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   if (harm_bwd_table_ok(F, K, N)) {
     // up to 128 harmonics: spread the weighted gradient onto the table grid, one product with the transposed sine matrix
     // (harmonic_bwd_table.hip) instead of a sine per sample and harmonic
-    ProfileScope prof(kHarmBwdPq, st);
+    ProfileScope prof(kHarmBwdTable, st);
     rc = launch_harm_bwd_table(f0_hz, theta0, grad_audio, pq, q_offset, B, F, K, N, sample_rate, p.amp_linear, st, amplitudes, hd,
                                grad_amplitudes, grad_hd, flags, inputs_are_controls);
     if (rc == 1) return check_launch();            // the chain rule ran in the same launch

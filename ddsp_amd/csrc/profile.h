@@ -28,6 +28,10 @@ enum KernelId {
   kStftL1Bwd,
   kHarmTable,
   kNoiseMfma,
+  kHarmBwdTable,
+  kNoiseBwdMfma,
+  kTvFirMfma,
+  kNoiseIrGemm,
   kNumKernels
 };
 

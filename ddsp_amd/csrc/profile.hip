@@ -19,7 +19,8 @@ const char* const kNames[kNumKernels] = {
     "harm_fused_kernel", "noise_fused65_kernel", "rv_fft_kernel", "rv_mac_kernel",
     "rv_ifft_kernel", "stft_l1_kernel", "harm_bwd_pq_kernel", "harm_bwd_chain_kernel",
     "noise_bwd_taps_kernel", "noise_bwd_mags_kernel", "stft_l1_bwd_kernel", "harm_table_kernel",
-    "noise_mfma65_kernel"};
+    "noise_mfma65_kernel", "harm_bwd_table_kernel", "noise_bwd_mfma_kernel", "tv_fir_mfma_kernel", "noise_ir_gemm_kernel"};
+static_assert(kNumKernels <= 32, "the selection mask is 32 bits");
 }  // namespace
 
 void profile_record(int kernel_id, hipStream_t st, bool start) {
