@@ -114,6 +114,64 @@ __global__ __launch_bounds__(kThreads) void resample_ex_kernel(const float* __re
   }
 }
 
+// The adjoint of resample_ex_kernel (what tf.GradientTape forms through core.resample, trainers.py:162-171): resampling is
+// linear in its input, grad_in[j] = sum_t W[t][j] grad_out[t].  One thread per (frame j, channel c) GATHERS: it walks the output
+// samples whose interpolation can touch frame j (a conservative range: j +- 2 frames' worth and one sample more), recomputes each
+// one's taps and weights exactly as the forward kernel does - same fp32 positions, same clamped indices - and adds the weights
+// that land on j.  No atomics, a fixed order of additions: deterministic.
+__global__ __launch_bounds__(kThreads) void resample_ex_backward_kernel(const float* __restrict__ gout,
+                                                                        float* __restrict__ gin, ResampleArgs p) {
+  const int b = blockIdx.y;
+  const size_t total = (size_t)p.F * p.C;
+  const float* __restrict__ gb = gout + (size_t)b * p.N * p.C;
+  float* __restrict__ ib = gin + (size_t)b * total;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const int j = (int)(i / p.C), c = (int)(i - (size_t)j * p.C);
+    float acc = 0.0f;
+    if (p.method == DDSP_RESAMPLE_WINDOW) {
+      const int t_lo = max((j - 1) * p.hop, 0);
+      const int t_hi = (int)min((long)(j + 1) * p.hop, (long)p.N);
+      for (int t = t_lo; t < t_hi; ++t) {
+        const int jj = t / p.hop, r = t - jj * p.hop;
+        const int hi = min(jj + 1, p.F - 1);
+        const float w = 0.5f - 0.5f * cospif((float)r / (float)p.hop);
+        const float g = gb[(size_t)t * p.C + c];
+        if (jj == j) acc = fmaf(g, 1.0f - w, acc);
+        if (hi == j) acc = fmaf(g, w, acc);
+      }
+    } else {
+      long t_lo = (long)floorf((float)(j - 2) / p.scale) - 1, t_hi = (long)ceilf((float)(j + 2) / p.scale) + 1;
+      if (j == 0 || t_lo < 0) t_lo = 0;
+      if (j == p.F - 1 || t_hi > p.N - 1) t_hi = p.N - 1;
+      for (long t = t_lo; t <= t_hi; ++t) {
+        const float pos = rn_mul((float)t, p.scale);
+        const float g = gb[(size_t)t * p.C + c];
+        if (p.method == DDSP_RESAMPLE_NEAREST) {
+          const int src = min((int)(p.align_corners ? roundf(pos) : floorf(pos)), p.F - 1);
+          if (src == j) acc += g;
+        } else if (p.method == DDSP_RESAMPLE_LINEAR) {
+          const float lo = floorf(pos);
+          const int lo_i = min(max((int)lo, 0), p.F - 1), hi_i = min((int)ceilf(pos), p.F - 1);
+          const float frac = rn_sub(pos, lo);
+          if (lo_i == j) acc = fmaf(g, 1.0f - frac, acc);
+          if (hi_i == j) acc = fmaf(g, frac, acc);
+        } else {                                          // DDSP_RESAMPLE_CUBIC
+          const float lo = floorf(pos);
+          const int src = (int)lo;
+          const int offset = (int)lrintf(rn_mul(rn_sub(pos, lo), 1024.0f));
+          const int i0 = min(max(src - 1, 0), p.F - 1), i1 = min(max(src, 0), p.F - 1);
+          const int i2 = min(max(src + 1, 0), p.F - 1), i3 = min(max(src + 2, 0), p.F - 1);
+          if (i0 == j) acc = fmaf(g, cubic_far(offset), acc);
+          if (i1 == j) acc = fmaf(g, cubic_near(offset), acc);
+          if (i2 == j) acc = fmaf(g, cubic_near(1024 - offset), acc);
+          if (i3 == j) acc = fmaf(g, cubic_far(1024 - offset), acc);
+        }
+      }
+    }
+    ib[i] = acc;
+  }
+}
+
 // =====================================================================================
 // core.fft_convolve (ddsp/core.py:1382-1473) as the direct time-varying FIR it equals:
 //   z[m] = sum_i x[i] h_{frame(i)}[m - i]   (framed FFT products, overlap-added)
@@ -500,6 +558,25 @@ extern "C" int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, in
   p.scale = (p.align_corners && N > 1) ? (float)(F - 1) / (float)(N - 1) : (float)F / (float)N;
   const dim3 grid(grid_for((size_t)N * C, 2048), (unsigned)B);
   hipLaunchKernelGGL(resample_ex_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, out, p);
+  return check_launch();
+}
+
+extern "C" int ddsp_resample_ex_backward_f32(const float* grad_out, float* grad_in, int B, int F, int N, int C, int method,
+                                             int add_endpoint, void* stream) {
+  if (!grad_out || !grad_in) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || N <= 0 || C <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (method < DDSP_RESAMPLE_NEAREST || method > DDSP_RESAMPLE_WINDOW) return DDSP_ERR_BAD_SHAPE;
+  ResampleArgs p;
+  p.F = F; p.N = N; p.C = C; p.method = method; p.align_corners = add_endpoint ? 0 : 1;
+  p.hop = 1;
+  if (method == DDSP_RESAMPLE_WINDOW) {
+    const int n_intervals = add_endpoint ? F : F - 1;
+    if (n_intervals <= 0 || n_intervals + 1 >= N || N % n_intervals != 0) return DDSP_ERR_BAD_SHAPE;
+    p.hop = N / n_intervals;
+  }
+  p.scale = (p.align_corners && N > 1) ? (float)(F - 1) / (float)(N - 1) : (float)F / (float)N;
+  const dim3 grid(grid_for((size_t)F * C, 2048), (unsigned)B);
+  hipLaunchKernelGGL(resample_ex_backward_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, grad_in, p);
   return check_launch();
 }
 

@@ -1150,6 +1150,20 @@ __global__ __launch_bounds__(64 * kChainWaves) void harm_bwd_chain_kernel(const 
   }
 }
 
+// The frame-rate chain rule on its own: dL/d (amplitudes * harmonic_distribution)[B,F,K] handed in (the materialised chain's
+// backward pass forms it with the adjoint of core.resample), dL/d amplitudes and dL/d harmonic_distribution out.
+template <int NCHUNK>
+__global__ __launch_bounds__(256) void harm_controls_bwd_kernel(const float* __restrict__ amplitudes, const float* __restrict__ hd,
+                                                                const float* __restrict__ f0_hz, const float* __restrict__ gha,
+                                                                float* __restrict__ grad_amp, float* __restrict__ grad_hd,
+                                                                long rows, BwdArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  harm_chain_row<NCHUNK>(lane, row, (int)(row % p.F), amplitudes, hd, f0_hz, grad_amp, grad_hd, p,
+                         [&](int k) { return gha[(size_t)row * p.K + k]; });
+}
+
 static inline size_t bwd_pq_floats(int B, int F, int K) { return ((size_t)B * F * K + 15) & ~(size_t)15; }
 
 }  // namespace ddsp
@@ -1217,6 +1231,33 @@ extern "C" int ddsp_harmonic_backward_f32(const float* amplitudes, const float* 
   return check_launch();
 }
 
+// The backward pass of Harmonic.get_controls + the product amplitudes * harmonic_distribution of core.harmonic_synthesis
+// (synths.py:94-121, core.py:1097) on its own: grad_harmonic_amplitudes [B,F,K] = dL/d (amplitudes * distribution) in.
+extern "C" int ddsp_harmonic_controls_backward_f32(const float* amplitudes, const float* hd, const float* f0_hz,
+                                                   const float* grad_harmonic_amplitudes, float* grad_amplitudes,
+                                                   float* grad_hd, int B, int F, int K, int sample_rate, unsigned flags,
+                                                   int inputs_are_controls, void* stream) {
+  if (!amplitudes || !hd || !f0_hz || !grad_harmonic_amplitudes || !grad_amplitudes || !grad_hd) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || K <= 0 || sample_rate <= 0) return DDSP_ERR_BAD_SHAPE;
+  if (K > 512) return DDSP_ERR_UNSUPPORTED;
+  BwdArgs p;
+  p.F = F; p.K = K; p.N = 0; p.hop = 0;
+  p.sample_rate = (float)sample_rate; p.nyquist = (float)(sample_rate / 2.0);
+  p.amp_linear = 0; p.flags = flags; p.inputs_are_controls = inputs_are_controls;
+  const long rows = (long)B * F;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (K + 63) / 64;
+#define DDSP_LAUNCH_CB(NC) hipLaunchKernelGGL((harm_controls_bwd_kernel<NC>), grid, dim3(256), 0, st, amplitudes, hd, f0_hz, \
+                                              grad_harmonic_amplitudes, grad_amplitudes, grad_hd, rows, p)
+  if (nchunk <= 1) DDSP_LAUNCH_CB(1);
+  else if (nchunk <= 2) DDSP_LAUNCH_CB(2);
+  else if (nchunk <= 4) DDSP_LAUNCH_CB(4);
+  else DDSP_LAUNCH_CB(8);
+#undef DDSP_LAUNCH_CB
+  return check_launch();
+}
+
 // =====================================================================================
 // Stand-alone core.oscillator_bank (ddsp/core.py:912-962) on materialised audio-rate envelopes
 // [B,N,K] (what synths.Sinusoidal and direct callers use).  The Harmonic path never calls this:
@@ -1264,13 +1305,15 @@ __global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict_
                                                         const double* __restrict__ offs,
                                                         float* __restrict__ out, int N, int K,
                                                         int n_chunks, double inv_sr, float nyquist,
-                                                        int sum_sinusoids) {
+                                                        int sum_sinusoids, int amp_per_sample) {
   __shared__ float s_acc[kOscChunk];
   const int c = blockIdx.x, b = blockIdx.y;
   const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
   const int tid = threadIdx.x, lane = tid & 63;
   const float* __restrict__ fb = freq + (size_t)b * N * K;
-  const float* __restrict__ ab = amp + (size_t)b * N * K;
+  // amp_per_sample: one amplitude per sample, [B,N] - the backward pass hands dL/d audio in here and reads
+  // dL/d amplitude_envelopes = dL/d audio[n] mask sin(phase) out of the [B,N,K] output (ddsp_oscillator_bank_grad_amplitudes_f32)
+  const float* __restrict__ ab = amp + (amp_per_sample ? (size_t)b * N : (size_t)b * N * K);
   for (int i = tid; i < kOscChunk; i += 256) s_acc[i] = 0.0f;
   __syncthreads();
   for (int k0 = 0; k0 < K; k0 += 256) {               // every thread takes the trip: full waves for DPP
@@ -1283,7 +1326,7 @@ __global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict_
         const float f = fb[(size_t)t * K + k];
         ph += (double)f * inv_sr;                     // inclusive cumsum (core.py:955)
         ph -= floor(ph);
-        const float a = (f >= nyquist) ? 0.0f : ab[(size_t)t * K + k];   // remove_above_nyquist
+        const float a = (f >= nyquist) ? 0.0f : (amp_per_sample ? ab[t] : ab[(size_t)t * K + k]);   // remove_above_nyquist
         v = a * sin_rev((float)ph);
         if (!sum_sinusoids) out[((size_t)b * N + t) * K + k] = v;
       }
@@ -1323,7 +1366,30 @@ extern "C" int ddsp_oscillator_bank_f32(const float* frequency_envelopes,
                      n_chunks, inv_sr);
   hipLaunchKernelGGL(osc_apply_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes,
                      amplitude_envelopes, sums, out, N, K, n_chunks, inv_sr,
-                     (float)(sample_rate / 2.0), sum_sinusoids);
+                     (float)(sample_rate / 2.0), sum_sinusoids, 0);
+  return check_launch();
+}
+
+// dL/d amplitude_envelopes [B,N,K] of core.oscillator_bank (core.py:912-962) given dL/d audio [B,N]: the output is linear in
+// the amplitudes, d audio[n] / d A[n,k] = mask(f[n,k] < Nyquist) sin(phase[n,k]) - the forward's own passes with dL/d audio as
+// a per-sample amplitude and nothing summed.  (What tf.GradientTape forms for the materialised chain of harmonic_synthesis:
+// 'nearest' / 'cubic' envelopes, n_samples that is not a multiple of n_frames.)  Workspace: ddsp_oscillator_bank_workspace_bytes.
+extern "C" int ddsp_oscillator_bank_grad_amplitudes_f32(const float* frequency_envelopes, const float* grad_audio,
+                                                        float* grad_amplitude_envelopes, void* workspace,
+                                                        size_t workspace_bytes, int B, int N, int K, int sample_rate,
+                                                        void* stream) {
+  if (!frequency_envelopes || !grad_audio || !grad_amplitude_envelopes || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || K <= 0 || sample_rate <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  if (workspace_bytes < ddsp_oscillator_bank_workspace_bytes(B, N, K) || ((uintptr_t)workspace & 7))
+    return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_chunks = (N + kOscChunk - 1) / kOscChunk;
+  const double inv_sr = 1.0 / (double)sample_rate;
+  double* sums = (double*)workspace;
+  hipLaunchKernelGGL(osc_chunk_sums_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes, sums, N, K, n_chunks);
+  hipLaunchKernelGGL(osc_chunk_prefix_kernel, dim3((K + 255) / 256, B), dim3(256), 0, st, sums, K, n_chunks, inv_sr);
+  hipLaunchKernelGGL(osc_apply_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes, grad_audio, sums,
+                     grad_amplitude_envelopes, N, K, n_chunks, inv_sr, (float)(sample_rate / 2.0), 0, 1);
   return check_launch();
 }
 

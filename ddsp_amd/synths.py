@@ -116,9 +116,18 @@ class Harmonic(processors.Processor):
       # 'nearest' / 'cubic' envelopes, or n_samples not a multiple of n_frames: the reference's own two
       # steps, get_signal following its chain of materialised envelopes (core.harmonic_synthesis)
       if needs_grad:
-        raise NotImplementedError(
-            "the backward pass of Harmonic covers amp_resample_method 'window' / 'linear' with n_samples a "
-            'multiple of n_frames')
+        if self.scale_fn is not None and self.scale_fn is not core.exp_sigmoid:
+          raise NotImplementedError('the backward pass of Harmonic covers scale_fn=core.exp_sigmoid and scale_fn=None')
+        if f0_hz.requires_grad:
+          raise NotImplementedError(
+              "dL/d f0_hz is formed for amp_resample_method 'window' / 'linear' with n_samples a multiple of n_frames; "
+              'the materialised chain gives dL/d amplitudes and dL/d harmonic_distribution')
+        # the same two steps as one torch.autograd node whose backward pass is the chain's adjoint, op for op
+        # (round 5: oscillator_bank's gradient w.r.t. its amplitude envelopes, the adjoint of core.resample, get_controls)
+        audio, ctl_amp, ctl_hd = _HarmonicMaterialisedFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse)
+        if not return_outputs_dict:
+          return audio
+        return dict(signal=audio, controls={'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz})
       controls = self.get_controls(raw_amplitudes, raw_harmonic_distribution, f0_hz)
       signal = self.get_signal(**controls)
       return dict(signal=signal, controls=controls) if return_outputs_dict else signal
@@ -221,6 +230,56 @@ class Harmonic(processors.Processor):
     return grad_amp, grad_hd
 
 
+  def _controls(self, amplitudes, harmonic_distribution, f0_hz, fuse):
+    """get_controls on tensors that went through _prescale already (one launch)."""
+    b, f, k = harmonic_distribution.shape
+    ctl_amp = torch.empty_like(amplitudes)
+    ctl_hd = torch.empty_like(harmonic_distribution)
+    rc = _lib.load().ddsp_harmonic_controls_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(), ctl_amp.data_ptr(),
+        ctl_hd.data_ptr(), b, f, k, int(self.sample_rate),
+        core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False), core._stream())
+    _lib.check(rc, 'ddsp_harmonic_controls_f32')
+    return {'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz}
+
+  def _backward_materialised(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
+    """(dL/d amplitudes, dL/d harmonic_distribution) through the chain of materialised envelopes (core.py:1080-1111)."""
+    b, f, k = harmonic_distribution.shape
+    n = int(self.n_samples)
+    lib = _lib.load()
+    dev = amplitudes.device
+    grad_audio = core.tf_float32(grad_audio)
+    # the frequency envelopes the forward pass ran on: f0 [1 .. K], resampled 'linear' (core.py:1086-1090, 1101)
+    harmonic_frequencies = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+    harmonic_amplitudes = torch.empty((b, f, k), dtype=torch.float32, device=dev)      # (made alongside; not used)
+    ctl = self._controls(amplitudes, harmonic_distribution, f0_hz, fuse)
+    rc = lib.ddsp_harmonic_envelopes_f32(ctl['amplitudes'].data_ptr(), ctl['harmonic_distribution'].data_ptr(),
+                                         f0_hz.data_ptr(), None, harmonic_frequencies.data_ptr(),
+                                         harmonic_amplitudes.data_ptr(), b, f, k, core._stream())
+    _lib.check(rc, 'ddsp_harmonic_envelopes_f32')
+    del harmonic_amplitudes
+    frequency_envelopes = core.resample(harmonic_frequencies, n)
+    grad_env = torch.empty((b, n, k), dtype=torch.float32, device=dev)
+    ws = self._ws_bwd.get(lib.ddsp_oscillator_bank_workspace_bytes(b, n, k), dev)
+    rc = lib.ddsp_oscillator_bank_grad_amplitudes_f32(frequency_envelopes.data_ptr(), grad_audio.data_ptr(),
+                                                      grad_env.data_ptr(), ws.data_ptr(), ws.numel(), b, n, k,
+                                                      int(self.sample_rate), core._stream())
+    _lib.check(rc, 'ddsp_oscillator_bank_grad_amplitudes_f32')
+    del frequency_envelopes
+    grad_ha = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+    rc = lib.ddsp_resample_ex_backward_f32(grad_env.data_ptr(), grad_ha.data_ptr(), b, f, n, k,
+                                           _lib.RESAMPLE_METHODS[self.amp_resample_method], 1, core._stream())
+    _lib.check(rc, 'ddsp_resample_ex_backward_f32')
+    del grad_env
+    grad_amp = torch.empty_like(amplitudes)
+    grad_hd = torch.empty_like(harmonic_distribution)
+    rc = lib.ddsp_harmonic_controls_backward_f32(
+        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(), grad_ha.data_ptr(),
+        grad_amp.data_ptr(), grad_hd.data_ptr(), b, f, k, int(self.sample_rate),
+        core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False), 0, core._stream())
+    _lib.check(rc, 'ddsp_harmonic_controls_backward_f32')
+    return grad_amp, grad_hd
+
   def _backward_f0(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
     """dL/d f0_hz [B,F,1]: the controls once more (one small launch), then ddsp_harmonic_f0_grad_f32."""
     b, f, k = harmonic_distribution.shape
@@ -243,6 +302,31 @@ class Harmonic(processors.Processor):
         _lib.HARM_AMP_LINEAR if self.amp_resample_method == 'linear' else 0, core._stream())
     _lib.check(rc, 'ddsp_harmonic_f0_grad_f32')
     return grad_f0
+
+
+class _HarmonicMaterialisedFunction(torch.autograd.Function):
+  """torch.autograd node of Harmonic.__call__ on the reference's own chain of materialised envelopes ('nearest' / 'cubic'
+  amplitude envelopes, n_samples that is not a multiple of n_frames; ddsp/core.py:1080-1111).  Forward: get_controls, then
+  core.harmonic_synthesis.  Backward, the chain's adjoint op for op, every op a C-ABI call:
+      dL/d amplitude_envelopes [B,N,K] = dL/d audio mask sin(phase)          ddsp_oscillator_bank_grad_amplitudes_f32
+      dL/d (amplitudes distribution) [B,F,K] = resample^T of it              ddsp_resample_ex_backward_f32
+      dL/d amplitudes, dL/d harmonic_distribution through get_controls      ddsp_harmonic_controls_backward_f32"""
+
+  @staticmethod
+  def forward(ctx, amplitudes, harmonic_distribution, f0_hz, synth, fuse):
+    ctx.save_for_backward(amplitudes, harmonic_distribution, f0_hz)
+    ctx.synth, ctx.fuse = synth, fuse
+    with torch.no_grad():
+      controls = synth._controls(amplitudes.detach(), harmonic_distribution.detach(), f0_hz.detach(), fuse)
+      signal = synth.get_signal(**controls)
+    ctx.mark_non_differentiable(controls['amplitudes'], controls['harmonic_distribution'])
+    return signal, controls['amplitudes'], controls['harmonic_distribution']
+
+  @staticmethod
+  def backward(ctx, grad_audio, _grad_ctl_amp, _grad_ctl_hd):
+    amplitudes, harmonic_distribution, f0_hz = (t.detach() for t in ctx.saved_tensors)
+    grad_amp, grad_hd = ctx.synth._backward_materialised(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
+    return grad_amp, grad_hd, None, None, None
 
 
 class _FusedAddUnsupported(Exception):

@@ -126,6 +126,15 @@ int ddsp_harmonic_backward_f32(const float* amplitudes, const float* harmonic_di
                                float* grad_harmonic_distribution, void* workspace,
                                size_t workspace_bytes, int B, int F, int K, int N, int sample_rate,
                                unsigned flags, int inputs_are_controls, void* stream);
+/* The frame-rate half of that backward pass on its own: dL/d (amplitudes * harmonic_distribution) [B,F,K] in
+ * (core.harmonic_synthesis' product, ddsp/core.py:1097), through Harmonic.get_controls (exp_sigmoid, the frame-rate Nyquist
+ * mask, safe_divide by the sum: ddsp/synths.py:94-121) to dL/d amplitudes [B,F,1] and dL/d harmonic_distribution [B,F,K].
+ * With ddsp_oscillator_bank_grad_amplitudes_f32 and ddsp_resample_ex_backward_f32 the backward pass of the materialised
+ * chain ('nearest' / 'cubic' envelopes, n_samples that is not a multiple of n_frames).  K <= 512. */
+int ddsp_harmonic_controls_backward_f32(const float* amplitudes, const float* harmonic_distribution, const float* f0_hz,
+                                        const float* grad_harmonic_amplitudes, float* grad_amplitudes,
+                                        float* grad_harmonic_distribution, int B, int F, int K, int sample_rate,
+                                        unsigned flags, int inputs_are_controls, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * core.streaming_harmonic_synthesis (ddsp/core.py:1114-1164) with harmonic_oscillator_bank
@@ -366,6 +375,11 @@ size_t ddsp_oscillator_bank_workspace_bytes(int B, int N, int K);
 int ddsp_oscillator_bank_f32(const float* frequency_envelopes, const float* amplitude_envelopes,
                              float* out, void* workspace, size_t workspace_bytes, int B, int N,
                              int K, int sample_rate, int sum_sinusoids, void* stream);
+/* dL/d amplitude_envelopes [B,N,K] of ddsp_oscillator_bank_f32 given dL/d audio [B,N]: grad_audio[n] where the frequency is
+ * below Nyquist, times sin(phase[n,k]) (the output is linear in the amplitudes).  Workspace as the forward's. */
+int ddsp_oscillator_bank_grad_amplitudes_f32(const float* frequency_envelopes, const float* grad_audio,
+                                             float* grad_amplitude_envelopes, void* workspace, size_t workspace_bytes,
+                                             int B, int N, int K, int sample_rate, void* stream);
 
 /* core.resample (ddsp/core.py:573-642) for [B,F,C] -> [B,N,C], add_endpoint=True:
  *   window == 0: method='linear' (tf.compat.v1.image.resize BILINEAR, align_corners=False);
@@ -388,6 +402,11 @@ int ddsp_resample_f32(const float* x, float* out, int B, int F, int N, int C, in
 #define DDSP_RESAMPLE_WINDOW 3
 int ddsp_resample_ex_f32(const float* x, float* out, int B, int F, int N, int C, int method,
                          int add_endpoint, void* stream);
+/* Its adjoint - what tf.GradientTape forms through core.resample (ddsp/training/trainers.py:162-171): grad_out [B,N,C] ->
+ * grad_in [B,F,C], grad_in[j] = sum_t W[t][j] grad_out[t] with the forward's own fp32 positions, clamped indices and
+ * weights; gathered per frame (no atomics: deterministic).  (csrc/general.hip) */
+int ddsp_resample_ex_backward_f32(const float* grad_out, float* grad_in, int B, int F, int N, int C, int method,
+                                  int add_endpoint, void* stream);
 
 /* core.fft_convolve (ddsp/core.py:1382-1473) with any crop (crop_and_compensate_delay :1338-1379):
  *     out[b][n] = z[b][n + start],  n < n_out,   z[m] = sum_i audio[i] * ir[frame(i)][m - i]

@@ -178,9 +178,79 @@ def test_harmonic_processor_with_cubic_and_nearest_envelopes(ddsp):    # synths.
   chain = npy(ddsp.core._harmonic_synthesis_materialised(ctl['f0_hz'], ctl['amplitudes'], None,
                                                          ctl['harmonic_distribution'], 1600, 16000, 'linear', False))
   parity_check(chain, fused, 2e-4 * 2.0)
-  a = torch.tensor(g['amplitudes'], device=DEV, requires_grad=True)
-  with pytest.raises(NotImplementedError, match='backward'):
-    synth(a, g['harmonic_distribution'], g['f0_hz'])
+  # dL/d f0_hz through the materialised chain is the one gradient that is not formed
+  f0g = torch.tensor(g['f0_hz'], device=DEV, requires_grad=True)
+  with pytest.raises(NotImplementedError, match='f0_hz'):
+    synth(g['amplitudes'], g['harmonic_distribution'], f0g)
+
+
+# ---- the backward pass through the chain of materialised envelopes (round 5) --------------------------------------------------
+@pytest.mark.parametrize('method,b,f,k,n,sr,f_lo,f_hi,scale,normalize', [
+    ('cubic', 2, 12, 8, 768, 16000, 100.0, 400.0, True, True),
+    ('nearest', 2, 10, 20, 640, 16000, 300.0, 1200.0, True, True),       # harmonics cross Nyquist inside frames
+    ('linear', 2, 9, 12, 1000, 16000, 150.0, 500.0, True, True),         # n_samples not a multiple of n_frames
+    ('cubic', 1, 7, 100, 500, 16000, 60.0, 75.0, True, True),            # ragged AND cubic, 100 harmonics (two lane chunks)
+    ('nearest', 2, 16, 5, 1024, 8000, 60.0, 90.0, False, False),         # scale_fn=None, no Nyquist normalisation
+    ('cubic', 1, 6, 300, 384, 16000, 20.0, 26.0, True, True),            # 300 harmonics: five lane chunks
+])
+def test_harmonic_backward_through_the_materialised_chain(ddsp, method, b, f, k, n, sr, f_lo, f_hi, scale, normalize):
+  """What tf.GradientTape (ddsp/training/trainers.py:162-171) forms through Harmonic.__call__ when its amplitude envelopes
+  are 'nearest' / 'cubic' or n_samples is not a multiple of n_frames - the reference's chain of materialised envelopes
+  (ddsp/core.py:1080-1111, 573-642, 912-962): dL/d amplitudes and dL/d harmonic_distribution against the analytic fp64
+  gradient (oracle/: the resampling matrix from the identity, itself checked against finite differences on the CPU)."""
+  rng = np.random.default_rng(f * 100 + k)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  if not scale:
+    amps, hd = np.abs(amps) + 0.1, np.abs(hd) + 0.05
+  f0 = rng.uniform(f_lo, f_hi, (b, f, 1)).astype(np.float32)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, scale_fn=ddsp.core.exp_sigmoid if scale else None,
+                               normalize_below_nyquist=normalize, amp_resample_method=method)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  out = synth(ta, th, f0, return_outputs_dict=True)
+  audio = out['signal']
+  assert audio.requires_grad and not out['controls']['amplitudes'].requires_grad
+  (audio * ddsp.core.tf_float32(g)).sum().backward()
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid if scale else None, normalize, method)
+  np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=1e-6 + 2e-4 * np.abs(ga).max())
+  np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=1e-6 + 2e-4 * np.abs(gh).max())
+  # the forward value and the controls are the unrecorded call's, to the bit; the backward is deterministic (gathers, no atomics)
+  plain = synth(amps, hd, f0, return_outputs_dict=True)
+  np.testing.assert_array_equal(npy(audio), npy(plain['signal']))
+  np.testing.assert_array_equal(npy(out['controls']['harmonic_distribution']), npy(plain['controls']['harmonic_distribution']))
+  ta2 = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th2 = ddsp.core.tf_float32(hd).requires_grad_(True)
+  (synth(ta2, th2, f0) * ddsp.core.tf_float32(g)).sum().backward()
+  np.testing.assert_array_equal(npy(ta2.grad), npy(ta.grad))
+  np.testing.assert_array_equal(npy(th2.grad), npy(th.grad))
+
+
+@pytest.mark.parametrize('method', ['nearest', 'linear', 'cubic', 'window'])
+@pytest.mark.parametrize('add_endpoint', [True, False])
+@pytest.mark.parametrize('f,n,c', [(9, 640, 3), (12, 96, 5), (30, 7, 2)])
+def test_resample_adjoint_is_the_transpose(ddsp, method, add_endpoint, f, n, c):
+  """ddsp_resample_ex_backward_f32 against the transpose of the forward call's own matrix (the forward applied to the
+  identity): <R x, y> = <x, R^T y> to fp32 rounding, up- and down-sampling, every method and both end conventions."""
+  if method == 'window':                       # upsampling only, n_samples a multiple of the number of intervals
+    if n < f:
+      pytest.skip("'window' only upsamples")
+    n = (f if add_endpoint else f - 1) * max(2, n // f)
+  from ddsp_amd import _lib
+  lib = _lib.load()
+  rng = np.random.default_rng(f * n + c)
+  eye = np.zeros((f, f, 1), np.float32)
+  eye[np.arange(f), np.arange(f), 0] = 1.0
+  r = npy(ddsp.core.resample(eye, n, method=method, add_endpoint=add_endpoint))[:, :, 0].T        # [n, f]
+  y = rng.standard_normal((2, n, c)).astype(np.float32)
+  ty = ddsp.core.tf_float32(y)
+  gx = torch.empty((2, f, c), dtype=torch.float32, device=ty.device)
+  rc = lib.ddsp_resample_ex_backward_f32(ty.data_ptr(), gx.data_ptr(), 2, f, n, c, _lib.RESAMPLE_METHODS[method],
+                                         1 if add_endpoint else 0, ddsp.core._stream())
+  assert rc == 0
+  ref = np.einsum('nf,bnc->bfc', r.astype(np.float64), y.astype(np.float64))
+  np.testing.assert_allclose(npy(gx), ref, rtol=0, atol=1e-6 + 2e-6 * np.abs(ref).max())
 
 
 # ---- dL/d f0_hz ---------------------------------------------------------------------------------------------

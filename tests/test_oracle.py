@@ -262,11 +262,14 @@ def test_streaming_synthesis_matches_reference_source(name):
 
 
 # ---- backward pass of Harmonic: analytic fp64 vs finite differences ----
-@pytest.mark.parametrize('method,scale,normalize', [('window', True, True), ('linear', True, True),
-                                                     ('window', False, False)])
-def test_harmonic_backward_matches_finite_differences(method, scale, normalize):
+@pytest.mark.parametrize('method,scale,normalize,n', [('window', True, True, 40), ('linear', True, True, 40),
+                                                       ('window', False, False, 40),
+                                                       # the materialised chain's argument space (round 5): other envelopes, ragged lengths
+                                                       ('cubic', True, True, 40), ('nearest', True, True, 40),
+                                                       ('linear', True, True, 43), ('cubic', False, False, 37)])
+def test_harmonic_backward_matches_finite_differences(method, scale, normalize, n):
   rng = np.random.default_rng(3)
-  b, f, k, n, sr = 1, 5, 6, 40, 16000
+  b, f, k, sr = 1, 5, 6, 16000
   amps = rng.standard_normal((b, f, 1))
   hd = rng.standard_normal((b, f, k))
   if not scale:
