@@ -1306,15 +1306,16 @@ __global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict_
                                                         float* __restrict__ out, int N, int K,
                                                         int n_chunks, double inv_sr, float nyquist,
                                                         int sum_sinusoids, int amp_per_sample) {
-  __shared__ float s_acc[kOscChunk];
-  const int c = blockIdx.x, b = blockIdx.y;
+  __shared__ float s_acc[4][kOscChunk];               // one row of partial sums per wavefront, added in a fixed order at the end
+  const int c = blockIdx.x, b = blockIdx.y;             // (an LDS atomic per wavefront and sample made the sum's last bit depend on
+                                                        //  which wavefront came first: found by a bit-equality test in round 5)
   const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* __restrict__ fb = freq + (size_t)b * N * K;
   // amp_per_sample: one amplitude per sample, [B,N] - the backward pass hands dL/d audio in here and reads
   // dL/d amplitude_envelopes = dL/d audio[n] mask sin(phase) out of the [B,N,K] output (ddsp_oscillator_bank_grad_amplitudes_f32)
   const float* __restrict__ ab = amp + (amp_per_sample ? (size_t)b * N : (size_t)b * N * K);
-  for (int i = tid; i < kOscChunk; i += 256) s_acc[i] = 0.0f;
+  for (int i = tid; i < 4 * kOscChunk; i += 256) (&s_acc[0][0])[i] = 0.0f;
   __syncthreads();
   for (int k0 = 0; k0 < K; k0 += 256) {               // every thread takes the trip: full waves for DPP
     const int k = k0 + tid;
@@ -1332,13 +1333,13 @@ __global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict_
       }
       if (sum_sinusoids) {
         const float s = wave_sum_dpp(v);
-        if (lane == 0) atomicAdd(&s_acc[t - t0], s);
+        if (lane == 0) s_acc[wave][t - t0] += s;        // this wavefront's row: no other writer
       }
     }
   }
   if (sum_sinusoids) {
     __syncthreads();
-    for (int i = tid; i < t1 - t0; i += 256) out[(size_t)b * N + t0 + i] = s_acc[i];
+    for (int i = tid; i < t1 - t0; i += 256) out[(size_t)b * N + t0 + i] = ((s_acc[0][i] + s_acc[1][i]) + s_acc[2][i]) + s_acc[3][i];
   }
 }
 }  // namespace ddsp
