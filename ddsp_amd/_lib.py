@@ -69,6 +69,7 @@ SIGNATURES = {
     'ddsp_oscillator_bank_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 5 + [c_voidp]),
     'ddsp_resample_f32': (c_int, [c_f32p] * 2 + [c_int] * 5 + [c_voidp]),
     'ddsp_resample_ex_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
+    'ddsp_sum_rows_f32': (c_int, [c_f32p] * 2 + [c_int] * 3 + [c_voidp]),
     'ddsp_resample_ex_backward_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
     'ddsp_oscillator_bank_grad_amplitudes_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 4 + [c_voidp]),
     'ddsp_harmonic_controls_backward_f32': (c_int, [c_f32p] * 6 + [c_int] * 4 + [c_uint, c_int, c_voidp]),
@@ -116,6 +117,7 @@ CONV_MASK_TAP0 = 0x2
 CONV_REVERSE_AUDIO = 0x4
 CONV_REVERSE_IR = 0x8
 CONV_REVERSE_OUT = 0x10
+CONV_ZERO_OUT0 = 0x20
 
 ERR_UNSUPPORTED = -3
 ERRORS = {-1: 'DDSP_ERR_NULL_POINTER', -2: 'DDSP_ERR_BAD_SHAPE', -3: 'DDSP_ERR_UNSUPPORTED',

@@ -738,7 +738,7 @@ LONG_IR_TAPS = 1024       # single-frame IRs longer than this take the FFT path
 
 def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0=False,
                       workspace=None, n_out=None, reverse_audio=False, reverse_ir=False,
-                      reverse_out=False):
+                      reverse_out=False, zero_out0=False):
   """out[b, n] = sum_k ir[b, k] audio[b, n + delay - k] (+ audio[b, n]) for one IR per row.
 
   The single-frame case of core.fft_convolve (ddsp/core.py:1428-1430, padding='same',
@@ -766,7 +766,7 @@ def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0
   out = torch.empty((b, n_out), dtype=torch.float32, device=audio.device)
   flags = ((_lib.CONV_ADD_DRY if add_dry else 0) | (_lib.CONV_MASK_TAP0 if mask_tap0 else 0) |
            (_lib.CONV_REVERSE_AUDIO if reverse_audio else 0) | (_lib.CONV_REVERSE_IR if reverse_ir else 0) |
-           (_lib.CONV_REVERSE_OUT if reverse_out else 0))
+           (_lib.CONV_REVERSE_OUT if reverse_out else 0) | (_lib.CONV_ZERO_OUT0 if zero_out0 else 0))
   rc = lib.ddsp_fft_convolve_long_ex_f32(audio.data_ptr(), impulse_response.data_ptr(), out.data_ptr(),
                                          ws.data_ptr(), ws.numel(), b, b_ir, n, l, n_out, int(delay),
                                          flags, _stream())

@@ -89,6 +89,9 @@ struct RvArgs {
   // transforms (each block is transformed once, not as the real part of one spectrum and the imaginary part of the next) and
   // half the spectra written and read by the multiply-add pass.  B: rows (an odd batch's last pair holds one).
   int pairs, B;
+  // the first output spectrum any kept sample lies in (delay > 0: the correlations of the backward pass keep samples from
+  // `delay` on - dL/d ir starts N - 1 samples into the convolution, half of its blocks are never looked at)
+  int m_first;
 };
 
 // One thread per pair of bins (16-byte accesses).  The IR spectra of all partitions sit in
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kRvMacThreads) void rv_mac_kernel(float4* __restric
 #pragma unroll
     for (int q = kRvMaxParts - 1; q > 0; --q) w[q] = w[q - 1];
     w[0] = xb[(size_t)j * (kRvN / 2)];
-    if (p.pairs == 0 && (j & 1) == 0) continue;                // W_m only for odd m (blocks m-1 and m); row pairs: every m
+    if ((p.pairs == 0 && (j & 1) == 0) || j < p.m_first) continue;      // W_m only for odd m (blocks m-1 and m); row pairs: every m; none below the first kept sample
     float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < kRvMaxParts; ++q) {
@@ -233,15 +236,17 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __restrict__ yspec, const float* __restrict__ audio,
-                                                                  float* __restrict__ out, RvArgs p, int nbo, int n_items) {
+                                                                  float* __restrict__ out, RvArgs p, int nbo, int j0, int n_items) {
   extern __shared__ __attribute__((aligned(16))) float2 s[];
   const int tid = threadIdx.x;
   const bool pair_mode = p.pairs > 0;
   const float scale = 1.0f / (float)kRvN;
   const bool dry = (p.flags & DDSP_CONV_ADD_DRY) != 0;           // only with n_out == N (checked by the host)
   const bool rev_a = (p.flags & DDSP_CONV_REVERSE_AUDIO) != 0, rev_o = (p.flags & DDSP_CONV_REVERSE_OUT) != 0;
+  const bool zero0 = (p.flags & DDSP_CONV_ZERO_OUT0) != 0;
+  // items: (row, j) for j0 <= j < j0 + nbo - the spectra that hold kept samples
   auto spectrum = [&](int w) {
-    const int b = w / nbo, j = w - b * nbo;
+    const int b = w / nbo, j = j0 + (w - b * nbo);
     return reinterpret_cast<const float4*>(yspec + ((size_t)b * p.nb + (pair_mode ? j : 2 * j + 1)) * kRvN);
   };
   int w = blockIdx.x;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
   }
   bool first = true;
   while (w < n_items) {
-    const int b = w / nbo, j = w - b * nbo;
+    const int b = w / nbo, j = j0 + (w - b * nbo);
     float4 v[kRvPairs];
 #pragma unroll
     for (int u = 0; u < kRvPairs; ++u) v[u] = nv[u];
@@ -329,13 +334,14 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
           const int n = j * kRvP + i - p.delay;
           if (n < 0 || n >= p.n_out) continue;
           const int no = rev_o ? p.n_out - 1 - n : n;
-          out[(size_t)(2 * b) * p.n_out + no] = fmaf(y.x, scale, d0[r]);
-          if (2 * b + 1 < p.B) out[(size_t)(2 * b + 1) * p.n_out + no] = fmaf(y.y, scale, d1[r]);
+          const bool z = zero0 && n == 0;
+          out[(size_t)(2 * b) * p.n_out + no] = z ? 0.0f : fmaf(y.x, scale, d0[r]);
+          if (2 * b + 1 < p.B) out[(size_t)(2 * b + 1) * p.n_out + no] = z ? 0.0f : fmaf(y.y, scale, d1[r]);
         } else {
           float* __restrict__ orow = out + (size_t)b * p.n_out;
           const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
-          if (n0 >= 0 && n0 < p.n_out) orow[rev_o ? p.n_out - 1 - n0 : n0] = fmaf(y.x, scale, d0[r]);
-          if (n1 >= 0 && n1 < p.n_out) orow[rev_o ? p.n_out - 1 - n1 : n1] = fmaf(y.y, scale, d1[r]);
+          if (n0 >= 0 && n0 < p.n_out) orow[rev_o ? p.n_out - 1 - n0 : n0] = (zero0 && n0 == 0) ? 0.0f : fmaf(y.x, scale, d0[r]);
+          if (n1 >= 0 && n1 < p.n_out) orow[rev_o ? p.n_out - 1 - n1 : n1] = (zero0 && n1 == 0) ? 0.0f : fmaf(y.y, scale, d1[r]);
         }
       }
     }
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(kRvMacThreads) void rv_mac_np_kernel(float4* __rest
       if (j < p.nb) {                                            // wave-uniform
         w[r] = n1; n1 = n2;
         if (j + 2 < p.nb) n2 = xb[(size_t)(j + 2) * (kRvN / 2)];
-        if (p.pairs != 0 || (j & 1) != 0) {                      // W_m only for odd m (blocks m-1 and m); row pairs: every m
+        if ((p.pairs != 0 || (j & 1) != 0) && j >= p.m_first) {  // W_m only for odd m (blocks m-1 and m); row pairs: every m; none below the first kept sample
           float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
 #pragma unroll
           for (int q = 0; q < NP; ++q) {                         // slot (r - q) mod NP holds spectrum j - q (zeros before the first)
@@ -438,7 +444,10 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
     return true;
   }();
   (void)attr2_set;
-  const int nbo = pair_mode ? p.nb : p.nb / 2;
+  const int q0 = delay / kRvP;                                          // the first block with a kept sample
+  const int j0 = pair_mode ? q0 : q0 / 2;                               // ... and the inverse transform it comes out of
+  p.m_first = pair_mode ? q0 : 2 * j0 + 1;
+  const int nbo = (pair_mode ? p.nb : p.nb / 2) - j0;
   {
     ProfileScope prof(kReverbFft, st);
     const int n_ir = Bir * p.np, n_items = n_ir + rows_z * p.nb;
@@ -457,8 +466,29 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
     ProfileScope prof(kReverbIfft, st);
     const int n_items = rows_z * nbo;
     hipLaunchKernelGGL(rv_ifft_kernel, dim3((unsigned)(n_items < 2 * n_cu ? n_items : 2 * n_cu)), dim3(kRvThreads), lds, st,
-                       (const float2*)xspec, audio, out, p, nbo, n_items);
+                       (const float2*)xspec, audio, out, p, nbo, j0, n_items);
   }
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+// dL/d ir of a Reverb whose ONE impulse response serves the whole batch (the trainable Reverb: effects.py:62-80): the rows'
+// correlations [B, L] added up in a fixed order (row 0 first), tap 0 - the masked dry tap, effects.py:50-60 - set to zero.
+namespace ddsp {
+__global__ __launch_bounds__(256) void rv_sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int L,
+                                                          int zero_tap0) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  float acc = 0.0f;
+  for (int b = 0; b < B; ++b) acc += x[(size_t)b * L + l];
+  out[l] = (zero_tap0 && l == 0) ? 0.0f : acc;
+}
+}  // namespace ddsp
+
+extern "C" int ddsp_sum_rows_f32(const float* x, float* out, int B, int L, int zero_first, void* stream) {
+  if (!x || !out) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || L <= 0) return DDSP_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(ddsp::rv_sum_rows_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, L,
+                     zero_first);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 

@@ -92,11 +92,15 @@ class Reverb(processors.Processor):
       grad_audio = core.fft_convolve_long(g, ir2d, delay=0, add_dry=self._add_dry, mask_tap0=True,
                                           workspace=self._ws, reverse_audio=True, reverse_out=True)
     if need_ir:          # dL/d ir[k] = conv(g, reverse(audio))[N-1+k]; the masked tap gets none
-      grad_ir = core.fft_convolve_long(g, audio, delay=n - 1, n_out=l, reverse_ir=True,
+      # (the masked dry tap gets no gradient: logical output 0 written as zero)
+      grad_ir = core.fft_convolve_long(g, audio, delay=n - 1, n_out=l, reverse_ir=True, zero_out0=True,
                                        workspace=self._ws_bwd)
-      grad_ir[:, 0] = 0.0
       if ir2d.shape[0] == 1 and audio.shape[0] > 1:
-        grad_ir = grad_ir.sum(dim=0, keepdim=True)       # one tiled IR collects the batch (plumbing)
+        # one IR for the whole batch collects the rows' gradients, in a fixed order (ddsp_sum_rows_f32)
+        summed = torch.empty((1, l), dtype=torch.float32, device=grad_ir.device)
+        _lib.check(_lib.load().ddsp_sum_rows_f32(grad_ir.data_ptr(), summed.data_ptr(), grad_ir.shape[0], l, 0, core._stream()),
+                   'ddsp_sum_rows_f32')
+        grad_ir = summed
     return grad_audio, grad_ir
 
 

@@ -276,6 +276,7 @@ int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response
 #define DDSP_CONV_REVERSE_AUDIO 4u   /* _ex only: logical audio sample g is stored at N-1-g   */
 #define DDSP_CONV_REVERSE_IR 8u      /* _ex only: logical tap k is stored at L-1-k            */
 #define DDSP_CONV_REVERSE_OUT 16u    /* _ex only: logical output n is written to n_out-1-n    */
+#define DDSP_CONV_ZERO_OUT0 32u      /* _ex only: logical output 0 is written as 0 (dL/d ir: the masked dry tap has no gradient) */
 size_t ddsp_fft_convolve_long_workspace_bytes(int B, int Bir, int N, int L, int delay);
 int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response, float* out,
                                void* workspace, size_t workspace_bytes, int B, int Bir, int N,
@@ -291,6 +292,9 @@ size_t ddsp_fft_convolve_long_ex_workspace_bytes(int B, int Bir, int N, int L, i
 int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* impulse_response, float* out,
                                   void* workspace, size_t workspace_bytes, int B, int Bir, int N,
                                   int L, int n_out, int delay, unsigned flags, void* stream);
+/* out[l] = sum_b x[b][l] (row 0 first: a fixed order), out[0] = 0 when zero_first: what collects dL/d ir of a Reverb whose one
+ * impulse response serves the whole batch (ddsp/effects.py:62-80; the dry tap is masked, :50-60) from the rows' correlations. */
+int ddsp_sum_rows_f32(const float* x, float* out, int B, int L, int zero_first, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * losses.SpectralLoss.call, forward pass (ddsp/losses.py:189-243), loss_type 'L1', magnitude and
