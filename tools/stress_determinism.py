@@ -230,6 +230,56 @@ def main(argv=None):
       return [('fused Add vs Harmonic then +', slice(0, b), lambda: two_calls)]
     total += stress('fused_add_b128', lambda: harm.call_add(amps, hd, f0, other), lambda: noise(mags), 64, subs_a)
 
+  # round 5: effects.Reverb on persistent transform blocks (a block loops over transforms: the LDS array is reused behind a
+  # barrier) - one IR for the batch (row pairs) and an IR per row; its backward pass (the two correlations, the shared IR's
+  # gradient collected in a fixed order); rows alone against the rows of the batch
+  for name, b, bir in (('reverb_b128_one_ir', 128, 1), ('reverb_b32_ir_per_row', 32, 32), ('reverb_b7_one_ir_odd', 7, 1)):
+    if want and name not in want:
+      continue
+    r5 = np.random.default_rng(80 + b)
+    audio = T(r5.standard_normal((b, 64000)))
+    ir = T(r5.standard_normal((bir, 48000)) * np.exp(-np.arange(48000) / 9600.0))
+    amps, hd, f0, mags = controls(32, 1000, 100, 70.0, 1.0, 81)
+    rev = ddsp.effects.Reverb(add_dry=True)
+    harm = ddsp.synths.Harmonic()
+
+    def subs_r(it, b=b, bir=bir, audio=audio, ir=ir, rev=rev):
+      r = int(rng.integers(0, b))
+      return [('row %d alone' % r, slice(r, r + 1), lambda: rev(audio[r:r + 1], ir[r:r + 1] if bir > 1 else ir))]
+    # (a row alone is compared where the batch runs the same arithmetic: with ONE impulse response two rows share a complex
+    #  transform, a row alone does not - equal to rounding, tests/test_gpu_parity.py, not to the bit)
+    total += stress(name, lambda audio=audio, ir=ir, rev=rev: rev(audio, ir), lambda: harm(amps, hd, f0), 4096,
+                    subs_r if bir > 1 else None)
+  if not want or 'reverb_backward_b16_one_ir' in want:
+    b = 16
+    r5 = np.random.default_rng(85)
+    audio = T(r5.standard_normal((b, 64000)))
+    ir = T(r5.standard_normal((1, 48000)) * np.exp(-np.arange(48000) / 9600.0))
+    g = T(r5.standard_normal((b, 64000)))
+    rev = ddsp.effects.Reverb(add_dry=True)
+
+    def rgrads():
+      a_ = audio.detach().requires_grad_(True)
+      i_ = ir.detach().requires_grad_(True)
+      rev(a_, i_).backward(g)
+      return torch.cat([a_.grad, i_.grad.reshape(1, -1).expand(b, -1)[:, :48000]], dim=1)
+    total += stress('reverb_backward_b16_one_ir', rgrads, None, 4096, None)
+  # the backward pass through the chain of materialised envelopes (gathers, no atomics), and the stand-alone oscillator bank
+  # with more than 64 sinusoids (its per-wavefront sums in a fixed order since round 5)
+  if not want or 'harmonic_materialised_backward' in want:
+    b, f, k, n = 4, 50, 100, 3300
+    amps, hd, f0, mags = controls(b, f, k, 90.0, 2.0, 91)
+    g = T(np.random.default_rng(92).standard_normal((b, n)))
+    harm = ddsp.synths.Harmonic(n_samples=n, amp_resample_method='cubic')
+
+    def mgrads():
+      a_ = amps.detach().requires_grad_(True)
+      h_ = hd.detach().requires_grad_(True)
+      y = harm(a_, h_, f0)
+      y.backward(g)
+      return torch.cat([y.detach(), a_.grad.reshape(b, -1), h_.grad.reshape(b, -1)], dim=1)
+    total += stress('harmonic_materialised_backward', mgrads, None, 66, None)
+
   summary = {'cases_run': sum(1 for r in log if 'iters' in r), 'label': args.label, 'lib': _lib.LIB_PATH, 'iters': args.iters, 'launches_with_a_difference': total,
              'device': torch.cuda.get_device_name(0)}
   print('SUMMARY ' + json.dumps(summary), flush=True)
