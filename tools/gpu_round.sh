@@ -65,6 +65,12 @@ timeout 300 python tools/bench_spectral_loss.py 128 2>&1 | tail -1 | tee $OUT/be
 timeout 300 python tools/bench_spectral_loss.py 32 2>&1 | tail -1 | tee $OUT/bench_spectral_loss_b32.json | cut -c1-200
 timeout 300 python tools/bench_backward.py 32 2>&1 | tail -1 | tee $OUT/bench_backward_b32.json | cut -c1-300
 timeout 300 python tools/bench_streaming.py 2>&1 | tail -1 | tee $OUT/bench_streaming.json | cut -c1-300
+echo "== rocprofv3 kernel trace of the Reverb and SpectralLoss benches at batch 128 (BASELINE configs[3] / configs[2]'s own kernels)"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/profrv -o trace -- python $GRAFT_REPO_ROOT/tools/bench_reverb.py 128 64000 48000 1 > /dev/null 2>&1 )
+for f in $(find $OUT/profrv -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_reverb_b128_one_ir.csv; head -5 $f | cut -c1-160; done
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/profsl -o trace -- python $GRAFT_REPO_ROOT/tools/bench_spectral_loss.py 128 > /dev/null 2>&1 )
+for f in $(find $OUT/profsl -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_spectral_loss_b128.csv; head -5 $f | cut -c1-160; done
+rm -rf $OUT/profrv $OUT/profsl
 echo "== shapes behind the specialised paths (tools/bench_generic.py), batch 32 and 128"
 timeout 300 python tools/bench_generic.py 32 2>/dev/null | grep "^{" > $OUT/generic_shapes_b32.jsonl; cut -c1-200 $OUT/generic_shapes_b32.jsonl
 echo "== determinism stress: ${STRESS_ITERS:-300} launches per case, bits compared on the device (tools/stress_determinism.py)"
