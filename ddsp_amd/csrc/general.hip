@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void resample_ex_backward_kernel(const fl
     if (p.method == DDSP_RESAMPLE_WINDOW) {
       const int t_lo = max((j - 1) * p.hop, 0);
       const int t_hi = (int)min((long)(j + 1) * p.hop, (long)p.N);
+#pragma unroll 4
       for (int t = t_lo; t < t_hi; ++t) {
         const int jj = t / p.hop, r = t - jj * p.hop;
         const int hi = min(jj + 1, p.F - 1);
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(kThreads) void resample_ex_backward_kernel(const fl
       long t_lo = (long)floorf((float)(j - 2) / p.scale) - 1, t_hi = (long)ceilf((float)(j + 2) / p.scale) + 1;
       if (j == 0 || t_lo < 0) t_lo = 0;
       if (j == p.F - 1 || t_hi > p.N - 1) t_hi = p.N - 1;
+#pragma unroll 4
       for (long t = t_lo; t <= t_hi; ++t) {
         const float pos = rn_mul((float)t, p.scale);
         const float g = gb[(size_t)t * p.C + c];

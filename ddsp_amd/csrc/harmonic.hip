@@ -1140,13 +1140,15 @@ __global__ __launch_bounds__(64 * kChainWaves) void harm_bwd_chain_kernel(const 
     const long row = ((long)blockIdx.x * kChainWaves + wave) * kChainRows + u;
     if (row >= rows) break;
     const int j = (int)(row % F);
+    // (no branch around the loads and no arithmetic between them - harm_chain_row issues every load of the row, then waits
+    //  once: frame 0 reads its own Q and weighs it 0; the last frame's extra term re-reads an address the row has just read
+    //  unless the row IS the last frame)
+    const size_t q_back = j > 0 ? (size_t)p.K : 0, x_back = j == F - 1 ? 0 : q_back;
+    const float q_keep = j > 0 ? 1.0f : 0.0f, x_keep = j == F - 1 ? 1.0f : 0.0f;
     harm_chain_row<NCHUNK>(lane, row, j, amplitudes, hd, f0_hz, grad_amp, grad_hd, p, [&](int k) {
       const size_t at = (size_t)row * p.K + k;
-      float g = pq[at];
-      if (j > 0) g += pq[q_offset + at - p.K];
-      if (j == F - 1) g += pq[q_offset + at];
-      return g;
-    });
+      return ChainPq{pq[at], pq[q_offset + at - q_back], pq[q_offset + at - x_back]};
+    }, [&](ChainPq v) { return fmaf(v.x, x_keep, fmaf(v.q, q_keep, v.p)); });
   }
 }
 
@@ -1161,7 +1163,7 @@ __global__ __launch_bounds__(256) void harm_controls_bwd_kernel(const float* __r
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
   harm_chain_row<NCHUNK>(lane, row, (int)(row % p.F), amplitudes, hd, f0_hz, grad_amp, grad_hd, p,
-                         [&](int k) { return gha[(size_t)row * p.K + k]; });
+                         [&](int k) { return gha[(size_t)row * p.K + k]; }, [](float v) { return v; });
 }
 
 static inline size_t bwd_pq_floats(int B, int F, int K) { return ((size_t)B * F * K + 15) & ~(size_t)15; }

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
         if (j > 0) gsum += Qp[k];
         if (j == p.F - 1) gsum += Qo[k];
         return gsum;
-      });
+      }, [](float v) { return v; });
     }
   } else
 #ifdef DDSP_BT_NO_STORE

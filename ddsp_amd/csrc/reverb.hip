@@ -479,7 +479,13 @@ __global__ __launch_bounds__(256) void rv_sum_rows_kernel(const float* __restric
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= L) return;
   float acc = 0.0f;
-  for (int b = 0; b < B; ++b) acc += x[(size_t)b * L + l];
+  for (int b0 = 0; b0 < B; b0 += 8) {            // eight rows requested together, added in row order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? x[(size_t)(b0 + u) * L + l] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
   out[l] = (zero_tap0 && l == 0) ? 0.0f : acc;
 }
 }  // namespace ddsp

@@ -714,9 +714,19 @@ __global__ __launch_bounds__(kSlFinishThreads) void spectral_loss_finish_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int z = 0; z < p.n_sizes; ++z) {
     double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < p.count[z]; i += kSlFinishThreads) {
-      const double2 v = *reinterpret_cast<const double2*>(partial + 2 * (size_t)(p.offset[z] + i));
-      a0 += v.x; a1 += v.y;
+    // eight partial pairs per thread requested before the first is added (one at a time the loop was a chain of memory round
+    // trips: 18.6 us at batch 128, a fifteenth of the loss's forward pass, for adding up 0.8 MB - round 5)
+    const int cnt = p.count[z];
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(partial) + p.offset[z];
+    for (int base = 0; base < cnt; base += 8 * kSlFinishThreads) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + (int)threadIdx.x + kSlFinishThreads * u;
+        v[u] = i < cnt ? src[i] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a0 += v[u].x; a1 += v[u].y; }
     }
     a0 = wave_sum_dpp(a0);
     a1 = wave_sum_dpp(a1);
