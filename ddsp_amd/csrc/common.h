@@ -100,8 +100,10 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 // byte offsets that every unrolled iteration reuses with an immediate added; without it each use recomputes base + plane).
 #if defined(__AMDGCN__)
 #define DDSP_KEEP_IN_VGPR(v) __asm__ volatile("" : "+v"(v))
+#define DDSP_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0): every vector memory operation issued so far */
 #else
 #define DDSP_KEEP_IN_VGPR(v) ((void)0)
+#define DDSP_WAIT_VMCNT0() ((void)0)
 #endif
 
 // ---- individually rounded fp32 steps ---------------------------------------------------------

@@ -185,6 +185,10 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __re
   int w = blockIdx.x;
   float2 nv[8];
   if (w < n_items) rv_fetch(nv, audio, ir, p, rv_item(w, n_ir, p), tid);
+  // (the first input waited for HERE, once: left to the loop's head, where the first entry and the loop's own back edge meet,
+  //  the wait becomes "everything outstanding" - and behind the back edge that is the four stores just issued, a store's
+  //  round trip per transform; with it the loop waits at its foot for the loads alone: vmcnt(4))
+  DDSP_WAIT_VMCNT0();
   bool first = true;
   while (w < n_items) {
     const RvItem it = rv_item(w, n_ir, p);
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
 #pragma unroll
     for (int u = 0; u < kRvPairs; ++u) nv[u] = src[tid + kRvThreads * u];
   }
+  DDSP_WAIT_VMCNT0();                             // (as in rv_fft_kernel)
   bool first = true;
   while (w < n_items) {
     const int b = w / nbo, j = j0 + (w - b * nbo);
@@ -304,25 +309,32 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
 #pragma unroll
         for (int m = 1; m < 8; ++m) x[m] = fft_conj(cmul(s[RP(t + m * (kRvN / 8))], tw[m]));
       }
-      // the dry signal, requested behind the twiddle products (their registers are free) and ahead of the butterfly
+      // the dry signal, requested behind the twiddle products (their registers are free) and ahead of the butterfly - at
+      // CLAMPED indices, no test around a load (a test per load is a wait per load: eight round trips one after the other);
+      // samples that are not written are not used either
       float d0[4], d1[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = t + kRvThreads * r;
-        d0[r] = d1[r] = 0.0f;
-        if (!dry) continue;
+      for (int r = 0; r < 4; ++r) d0[r] = d1[r] = 0.0f;
+      if (dry) {                                  // (uniform)
+        const int hi = p.N - 1;
         if (pair_mode) {
-          const int n = j * kRvP + i - p.delay;
-          if (n >= 0 && n < p.n_out) {
-            const int na = rev_a ? p.N - 1 - n : n;
-            d0[r] = audio[(size_t)(2 * b) * p.N + na];
-            if (2 * b + 1 < p.B) d1[r] = audio[(size_t)(2 * b + 1) * p.N + na];
+          const float* __restrict__ a0 = audio + (size_t)(2 * b) * p.N;
+          const float* __restrict__ a1 = audio + (size_t)min(2 * b + 1, p.B - 1) * p.N;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = j * kRvP + (t + kRvThreads * r) - p.delay;
+            const int na = min(max(rev_a ? p.N - 1 - n : n, 0), hi);
+            d0[r] = a0[na];
+            d1[r] = a1[na];
           }
         } else {
           const float* __restrict__ arow = audio + (size_t)b * p.N;
-          const int n0 = 2 * j * kRvP + i - p.delay, n1 = n0 + kRvP;
-          if (n0 >= 0 && n0 < p.n_out) d0[r] = arow[rev_a ? p.N - 1 - n0 : n0];
-          if (n1 >= 0 && n1 < p.n_out) d1[r] = arow[rev_a ? p.N - 1 - n1 : n1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n0 = 2 * j * kRvP + (t + kRvThreads * r) - p.delay, n1 = n0 + kRvP;
+            d0[r] = arow[min(max(rev_a ? p.N - 1 - n0 : n0, 0), hi)];
+            d1[r] = arow[min(max(rev_a ? p.N - 1 - n1 : n1, 0), hi)];
+          }
         }
       }
       fft_dft8(x);
@@ -349,42 +361,76 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
 }
 
 // The multiply-add pass with the partition count a template parameter: the window of spectra rotates through its registers
-// by unrolling instead of by moves, the next two spectra are requested ahead of the products, and twelve partitions (48 000
-// taps) take 110 registers instead of 138 - four wavefronts per SIMD, so that batch 128's 4096 wavefronts are resident at once
-// (at three per SIMD a quarter of them ran as a second round).
+// by unrolling instead of by moves, and twelve partitions (48 000 taps) take under 128 registers - four wavefronts per SIMD, so
+// that batch 128's 4096 wavefronts are resident at once (at three per SIMD a quarter of them ran as a second round).
+// FULL passes of NP spectra are STRAIGHT-LINE code: loads with clamped indices, no test around a load, a product or a store.
+// With a test per spectrum (the first form of this kernel) every iteration began with `s_waitcnt vmcnt(0)` - at a join of
+// control flow the compiler waits for everything outstanding, and on gfx9 that includes the STORE of the iteration before:
+// sixteen store round trips one after the other were most of the kernel's 30 us.  In straight-line code the waits count
+// exactly (the spectrum requested two iterations ago, not the store behind it).  What does not fill a pass runs in the
+// tested form.  ODD_ONLY: two blocks of one row per spectrum - W_m for odd m only.
 template <int NP>
+__device__ __forceinline__ float4 rv_window_product(const float4 (&w)[NP], const float4 (&h)[NP], int r) {
+  float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {                                   // slot (r - q) mod NP holds spectrum j - q (zeros before the first)
+    const float4 x = w[(r - q + NP) % NP];
+    const float2 a0 = cmul(make_float2(x.x, x.y), make_float2(h[q].x, h[q].y));
+    const float2 a1 = cmul(make_float2(x.z, x.w), make_float2(h[q].z, h[q].w));
+    y0.x += a0.x; y0.y += a0.y; y1.x += a1.x; y1.y += a1.y;
+  }
+  return make_float4(y0.x, y0.y, y1.x, y1.y);
+}
+
+// a 16-byte access at a wave-uniform base plus a 32-bit byte offset of the thread's own: the base stays in scalar registers
+__device__ __forceinline__ float4 rv_ld16(const float4* base, unsigned off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ void rv_st16(float4* base, unsigned off, float4 v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + off) = v;
+}
+
+template <int NP, bool ODD_ONLY>
 __global__ __launch_bounds__(kRvMacThreads) void rv_mac_np_kernel(float4* __restrict__ xspec, const float4* __restrict__ hspec,
                                                                   RvArgs p) {
-  const int idx = blockIdx.x * kRvMacThreads + threadIdx.x;      // < kRvN / 2
+  // every address is a wave-uniform base (scalar registers: row, spectrum) plus this thread's bin pair: no address registers
+  // per spectrum (twelve of them made ahead of the unrolled loop were 24 registers - three wavefronts per SIMD instead of four)
+  const unsigned off = (blockIdx.x * kRvMacThreads + threadIdx.x) * 16u;      // bin pair < kRvN / 2, in bytes
   const int b = blockIdx.y;
-  const float4* __restrict__ hb = hspec + (size_t)(p.ir_batch == 1 ? 0 : b) * p.np * (kRvN / 2) + idx;
-  float4* __restrict__ xb = xspec + (size_t)b * p.nb * (kRvN / 2) + idx;
+  const float4* __restrict__ hrow = hspec + (size_t)(p.ir_batch == 1 ? 0 : b) * p.np * (kRvN / 2);
+  float4* __restrict__ xrow = xspec + (size_t)b * p.nb * (kRvN / 2);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 h[NP], w[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    h[q] = (q < p.np) ? hb[(size_t)q * (kRvN / 2)] : zero;
+    h[q] = (q < p.np) ? rv_ld16(hrow + (size_t)q * (kRvN / 2), off) : zero;
     w[q] = zero;
   }
-  float4 n1 = xb[0], n2 = p.nb > 1 ? xb[(size_t)(kRvN / 2)] : zero;
-  for (int j0 = 0; j0 < p.nb; j0 += NP) {
+  const int last = p.nb - 1;
+  float4 n1 = rv_ld16(xrow, off), n2 = rv_ld16(xrow + (size_t)min(1, last) * (kRvN / 2), off);
+  int j0 = 0;
+  // full passes with every spectrum kept (the forward pass: m_first = 0): straight-line code.  The spectrum two ahead is read
+  // without a test - past a row's last spectrum lies the next row's first, past the last row's the impulse response's spectra
+  // (at least two of them: np >= 2).
+  if (p.m_first == 0 && p.np >= 2) {
+    for (; j0 + NP <= p.nb; j0 += NP) {
+      float4* __restrict__ pass = xrow + (size_t)j0 * (kRvN / 2);
+#pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        w[r] = n1; n1 = n2; n2 = rv_ld16(pass + (size_t)(r + 2) * (kRvN / 2), off);
+        if (!ODD_ONLY || (r & 1) != 0)                            // (NP is even: the parity of j0 + r is r's)
+          rv_st16(pass + (size_t)r * (kRvN / 2), off, rv_window_product<NP>(w, h, r));
+      }
+    }
+  }
+  // what does not fill a pass, and the correlations of the backward pass (spectra below the first kept sample only fill the window)
+  for (; j0 < p.nb; j0 += NP) {
 #pragma unroll
     for (int r = 0; r < NP; ++r) {
       const int j = j0 + r;
       if (j < p.nb) {                                            // wave-uniform
-        w[r] = n1; n1 = n2;
-        if (j + 2 < p.nb) n2 = xb[(size_t)(j + 2) * (kRvN / 2)];
-        if ((p.pairs != 0 || (j & 1) != 0) && j >= p.m_first) {  // W_m only for odd m (blocks m-1 and m); row pairs: every m; none below the first kept sample
-          float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int q = 0; q < NP; ++q) {                         // slot (r - q) mod NP holds spectrum j - q (zeros before the first)
-            const float4 x = w[(r - q + NP) % NP];
-            const float2 a0 = cmul(make_float2(x.x, x.y), make_float2(h[q].x, h[q].y));
-            const float2 a1 = cmul(make_float2(x.z, x.w), make_float2(h[q].z, h[q].w));
-            y0.x += a0.x; y0.y += a0.y; y1.x += a1.x; y1.y += a1.y;
-          }
-          xb[(size_t)j * (kRvN / 2)] = make_float4(y0.x, y0.y, y1.x, y1.y);
-        }
+        w[r] = n1; n1 = n2; n2 = rv_ld16(xrow + (size_t)min(j + 2, last) * (kRvN / 2), off);
+        if ((!ODD_ONLY || (j & 1) != 0) && j >= p.m_first) rv_st16(xrow + (size_t)j * (kRvN / 2), off, rv_window_product<NP>(w, h, r));
       }
     }
   }
@@ -457,10 +503,16 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   {
     ProfileScope prof(kReverbMac, st);
     const dim3 grid(kRvN / 2 / kRvMacThreads, (unsigned)rows_z), block(kRvMacThreads);
-    if (p.np <= 4) hipLaunchKernelGGL(rv_mac_np_kernel<4>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
-    else if (p.np <= 8) hipLaunchKernelGGL(rv_mac_np_kernel<8>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
-    else if (p.np <= 12) hipLaunchKernelGGL(rv_mac_np_kernel<12>, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
+#define DDSP_RV_MAC(NP_)                                                                                                     \
+  do {                                                                                                                       \
+    if (pair_mode) hipLaunchKernelGGL((rv_mac_np_kernel<NP_, false>), grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p); \
+    else hipLaunchKernelGGL((rv_mac_np_kernel<NP_, true>), grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);      \
+  } while (0)
+    if (p.np <= 4) DDSP_RV_MAC(4);
+    else if (p.np <= 8) DDSP_RV_MAC(8);
+    else if (p.np <= 12) DDSP_RV_MAC(12);
     else hipLaunchKernelGGL(rv_mac_kernel, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);      // (13 .. 16 partitions: the window of sixteen by moves, 138 registers)
+#undef DDSP_RV_MAC
   }
   {
     ProfileScope prof(kReverbIfft, st);
