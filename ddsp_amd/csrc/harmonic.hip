@@ -80,9 +80,26 @@ __global__ __launch_bounds__(256) void harm_controls_kernel(
     const int jb = threadIdx.x * per, je = min(jb + per, F);
     const double hop_d = (double)p.hop;
     double local = 0.0;
-    for (int j = jb; j < je; ++j) {
-      const double fa = (double)f0[j], fb = (double)f0[min(j + 1, F - 1)];
-      local += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+    // a thread's frames (and the one behind them) requested together where they fit eight registers - up to 2048 frames per
+    // row; taken one at a time the scan was a chain of memory round trips, most of this launch's 6 us
+    constexpr int kCache = 8;
+    float fc[kCache + 1];
+    const bool cached = per <= kCache;
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u <= kCache; ++u) fc[u] = f0[min(jb + u, F - 1)];
+#pragma unroll
+      for (int u = 0; u < kCache; ++u) {
+        if (jb + u < je) {
+          const double fa = (double)fc[u], fb = (double)fc[u + 1];
+          local += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+        }
+      }
+    } else {
+      for (int j = jb; j < je; ++j) {
+        const double fa = (double)f0[j], fb = (double)f0[min(j + 1, F - 1)];
+        local += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+      }
     }
     double incl = local;                       // inclusive scan across the wavefront
 #pragma unroll
@@ -98,11 +115,23 @@ __global__ __launch_bounds__(256) void harm_controls_kernel(
     const double inv_sr = 1.0 / (double)p.sample_rate;
     const double kTwoPi = 6.283185307179586;
     const double init_rev = p.initial_phase ? (double)p.initial_phase[b] / kTwoPi : 0.0;
-    for (int j = jb; j < je; ++j) {
-      const double cyc = run * inv_sr + init_rev;
-      theta0[(size_t)b * F + j] = cyc - floor(cyc);
-      const double fa = (double)f0[j], fb = (double)f0[min(j + 1, F - 1)];
-      run += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < kCache; ++u) {
+        if (jb + u < je) {
+          const double cyc = run * inv_sr + init_rev;
+          theta0[(size_t)b * F + jb + u] = cyc - floor(cyc);
+          const double fa = (double)fc[u], fb = (double)fc[u + 1];
+          run += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+        }
+      }
+    } else {
+      for (int j = jb; j < je; ++j) {
+        const double cyc = run * inv_sr + init_rev;
+        theta0[(size_t)b * F + j] = cyc - floor(cyc);
+        const double fa = (double)f0[j], fb = (double)f0[min(j + 1, F - 1)];
+        run += hop_d * fa + (fb - fa) * (hop_d - 1.0) * 0.5;
+      }
     }
     // harmonic_oscillator_bank's final_phase (core.py:1008-1012, angular cumsum):
     // (sum of all omega mod 2 pi) + initial_phase - the fundamental's phase at the last sample
