@@ -101,9 +101,11 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 #if defined(__AMDGCN__)
 #define DDSP_KEEP_IN_VGPR(v) __asm__ volatile("" : "+v"(v))
 #define DDSP_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0): every vector memory operation issued so far */
+#define DDSP_WAVE_LDS_SYNC() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); } while (0)   /* s_waitcnt lgkmcnt(0): this wavefront's LDS operations have landed (a wavefront's own LDS traffic is in order: no block barrier needed where producer and consumer are lanes of one wavefront) */
 #else
 #define DDSP_KEEP_IN_VGPR(v) ((void)0)
 #define DDSP_WAIT_VMCNT0() ((void)0)
+#define DDSP_WAVE_LDS_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 // ---- individually rounded fp32 steps ---------------------------------------------------------

@@ -226,7 +226,9 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __re
       s[RP(i0)] = x[0];
 #pragma unroll
       for (int m = 1; m < 8; ++m) s[RP(i0 + m * q)] = cmulc(x[m], tw[m]);
-      __syncthreads();
+      // behind the q = 16 pass the next one (q = 2) reads what the SAME sixteen lanes wrote - a 128-point group belongs to
+      // lanes 16 k .. 16 k + 15 in both - : the wavefront's own LDS order is enough, no block barrier
+      if (q == 16) DDSP_WAVE_LDS_SYNC(); else __syncthreads();
     }
     float2* __restrict__ spec = it.ir ? hspec : xspec;
     float4* __restrict__ dst = reinterpret_cast<float4*>(spec + ((size_t)it.b * (it.ir ? p.np : p.nb) + it.j) * kRvN);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_ifft_kernel(const float2* __
       fft_dft8(x);
 #pragma unroll
       for (int m = 0; m < 8; ++m) s[RP(i0 + m * q)] = fft_conj(x[m]);
-      __syncthreads();
+      if (q == 2) DDSP_WAVE_LDS_SYNC(); else __syncthreads();      // (q = 2 -> q = 16: the same sixteen lanes, as in rv_fft_kernel)
     }
     // q = 1024 (pos = i0 = tid): outputs 4 .. 7 are elements P + tid + 1024 (jj - 4) - the samples overlap-save keeps
     {
