@@ -72,6 +72,8 @@ SIGNATURES = {
     'ddsp_sum_rows_f32': (c_int, [c_f32p] * 2 + [c_int] * 3 + [c_voidp]),
     'ddsp_resample_ex_backward_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
     'ddsp_oscillator_bank_grad_amplitudes_f32': (c_int, [c_f32p] * 3 + [c_voidp, c_size_t] + [c_int] * 4 + [c_voidp]),
+    'ddsp_oscillator_bank_grad_frequencies_f32': (c_int, [c_f32p] * 4 + [c_voidp, c_size_t] + [c_int] * 4 + [c_voidp]),
+    'ddsp_harmonic_frequencies_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_voidp]),
     'ddsp_harmonic_controls_backward_f32': (c_int, [c_f32p] * 6 + [c_int] * 4 + [c_uint, c_int, c_voidp]),
     'ddsp_fft_convolve_f32': (c_int, [c_f32p] * 3 + [c_int] * 7 + [c_voidp]),
     'ddsp_harmonic_envelopes_f32': (c_int, [c_f32p] * 6 + [c_int] * 3 + [c_voidp]),

@@ -229,6 +229,21 @@ __global__ __launch_bounds__(kThreads) void harmonic_envelopes_kernel(
   }
 }
 
+// The adjoint of harmonic_frequencies = f0 [1..K] (1 + shifts) with respect to f0: dL/d f0[row] = sum_k dL/d hf[row,k] (k+1) (1 + shift)
+__global__ __launch_bounds__(kThreads) void harmonic_frequencies_backward_kernel(const float* __restrict__ ghf /*[R,K]*/,
+                                                                                 const float* __restrict__ shifts /*[R,K] or null*/,
+                                                                                 float* __restrict__ gf0 /*[R]*/, size_t rows, int K) {
+  for (size_t row = global_thread(); row < rows; row += grid_threads()) {
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      float w = (float)(k + 1);
+      if (shifts != nullptr) w *= 1.0f + shifts[row * K + k];
+      acc += (double)ghf[row * K + k] * (double)w;
+    }
+    gf0[row] = (float)acc;
+  }
+}
+
 // out[i] = x[i] * scale[0]: the upstream scalar of a loss's backward pass applied to the stored dL/d audio (the chain
 // rule through a scalar; what tf.GradientTape does implicitly, ddsp/training/trainers.py:162-171)
 __global__ __launch_bounds__(kThreads) void scale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -608,6 +623,16 @@ extern "C" int ddsp_harmonic_envelopes_f32(const float* amplitudes, const float*
   hipLaunchKernelGGL(harmonic_envelopes_kernel, dim3(grid_for(rows * K)), dim3(kThreads), 0,
                      (hipStream_t)stream, amplitudes, harmonic_distribution, f0_hz, harmonic_shifts,
                      harmonic_frequencies, harmonic_amplitudes, rows, K);
+  return check_launch();
+}
+
+extern "C" int ddsp_harmonic_frequencies_backward_f32(const float* grad_harmonic_frequencies, const float* harmonic_shifts,
+                                                      float* grad_f0_hz, int B, int F, int K, void* stream) {
+  if (!grad_harmonic_frequencies || !grad_f0_hz) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || F <= 0 || K <= 0) return DDSP_ERR_BAD_SHAPE;
+  const size_t rows = (size_t)B * F;
+  hipLaunchKernelGGL(harmonic_frequencies_backward_kernel, dim3(grid_for(rows)), dim3(kThreads), 0, (hipStream_t)stream,
+                     grad_harmonic_frequencies, harmonic_shifts, grad_f0_hz, rows, K);
   return check_launch();
 }
 

@@ -1373,6 +1373,64 @@ __global__ __launch_bounds__(256) void osc_apply_kernel(const float* __restrict_
     for (int i = tid; i < t1 - t0; i += 256) out[(size_t)b * N + t0 + i] = ((s_acc[0][i] + s_acc[1][i]) + s_acc[2][i]) + s_acc[3][i];
   }
 }
+// dL/d frequency_envelopes of oscillator_bank: phase[n] = (2 pi / sr) sum_{t <= n} f[t] (core.py:950-955), so
+//   dL/d f[t,k] = (2 pi / sr) sum_{n >= t} c[n,k],   c[n,k] = dL/d audio[n] A[n,k] mask[n,k] cos(phase[n,k])
+// (the mask - tf.where - passes no gradient).  Pass 1 walks a chunk forwards like osc_apply_kernel, leaves c in `out` and the
+// chunk's sum of c (fp64) in `csum`; osc_chunk_suffix_kernel turns the chunk sums into the sums over all LATER chunks; pass 2
+// walks a chunk backwards and replaces c by its inclusive suffix sum.
+__global__ __launch_bounds__(256) void osc_grad_freq_c_kernel(const float* __restrict__ freq, const float* __restrict__ amp,
+                                                              const float* __restrict__ g, const double* __restrict__ offs,
+                                                              float* __restrict__ out, double* __restrict__ csum, int N, int K,
+                                                              int n_chunks, double inv_sr, float nyquist) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
+  const float* __restrict__ fb = freq + (size_t)b * N * K;
+  const float* __restrict__ ab = amp + (size_t)b * N * K;
+  const float* __restrict__ gb = g + (size_t)b * N;
+  float* __restrict__ ob = out + (size_t)b * N * K;
+  const float two_pi_over_sr = (float)(6.283185307179586 * inv_sr);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    double ph = offs[((size_t)b * n_chunks + c) * K + k];
+    double sum = 0.0;
+    for (int t = t0; t < t1; ++t) {
+      const float f = fb[(size_t)t * K + k];
+      ph += (double)f * inv_sr;
+      ph -= floor(ph);
+      const float a = (f >= nyquist) ? 0.0f : ab[(size_t)t * K + k];
+      const float cv = gb[t] * a * __builtin_amdgcn_cosf((float)ph) * two_pi_over_sr;
+      ob[(size_t)t * K + k] = cv;
+      sum += (double)cv;
+    }
+    csum[((size_t)b * n_chunks + c) * K + k] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void osc_chunk_suffix_kernel(double* __restrict__ csum, int K, int n_chunks) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double run = 0.0;                                   // the sum over the chunks behind this one
+  for (int c = n_chunks - 1; c >= 0; --c) {
+    double* p = csum + ((size_t)b * n_chunks + c) * K + k;
+    const double s = *p;
+    *p = run;
+    run += s;
+  }
+}
+
+__global__ __launch_bounds__(256) void osc_grad_freq_suffix_kernel(float* __restrict__ out, const double* __restrict__ csuf, int N,
+                                                                   int K, int n_chunks) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t0 = c * kOscChunk, t1 = min(t0 + kOscChunk, N);
+  float* __restrict__ ob = out + (size_t)b * N * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    double run = csuf[((size_t)b * n_chunks + c) * K + k];
+    for (int t = t1 - 1; t >= t0; --t) {
+      run += (double)ob[(size_t)t * K + k];
+      ob[(size_t)t * K + k] = (float)run;
+    }
+  }
+}
 }  // namespace ddsp
 
 extern "C" size_t ddsp_oscillator_bank_workspace_bytes(int B, int N, int K) {
@@ -1422,6 +1480,29 @@ extern "C" int ddsp_oscillator_bank_grad_amplitudes_f32(const float* frequency_e
   hipLaunchKernelGGL(osc_chunk_prefix_kernel, dim3((K + 255) / 256, B), dim3(256), 0, st, sums, K, n_chunks, inv_sr);
   hipLaunchKernelGGL(osc_apply_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes, grad_audio, sums,
                      grad_amplitude_envelopes, N, K, n_chunks, inv_sr, (float)(sample_rate / 2.0), 0, 1);
+  return check_launch();
+}
+
+// dL/d frequency_envelopes [B,N,K] of ddsp_oscillator_bank_f32 (kernels above).  Workspace: TWICE ddsp_oscillator_bank_workspace_bytes.
+extern "C" int ddsp_oscillator_bank_grad_frequencies_f32(const float* frequency_envelopes, const float* amplitude_envelopes,
+                                                         const float* grad_audio, float* grad_frequency_envelopes,
+                                                         void* workspace, size_t workspace_bytes, int B, int N, int K,
+                                                         int sample_rate, void* stream) {
+  if (!frequency_envelopes || !amplitude_envelopes || !grad_audio || !grad_frequency_envelopes || !workspace) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || K <= 0 || sample_rate <= 0 || B > 65535) return DDSP_ERR_BAD_SHAPE;
+  const size_t half = ddsp_oscillator_bank_workspace_bytes(B, N, K);
+  if (workspace_bytes < 2 * half || ((uintptr_t)workspace & 7)) return DDSP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_chunks = (N + kOscChunk - 1) / kOscChunk;
+  const double inv_sr = 1.0 / (double)sample_rate;
+  double* sums = (double*)workspace;
+  double* csum = (double*)((char*)workspace + half);
+  hipLaunchKernelGGL(osc_chunk_sums_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes, sums, N, K, n_chunks);
+  hipLaunchKernelGGL(osc_chunk_prefix_kernel, dim3((K + 255) / 256, B), dim3(256), 0, st, sums, K, n_chunks, inv_sr);
+  hipLaunchKernelGGL(osc_grad_freq_c_kernel, dim3(n_chunks, B), dim3(256), 0, st, frequency_envelopes, amplitude_envelopes,
+                     grad_audio, sums, grad_frequency_envelopes, csum, N, K, n_chunks, inv_sr, (float)(sample_rate / 2.0));
+  hipLaunchKernelGGL(osc_chunk_suffix_kernel, dim3((K + 255) / 256, B), dim3(256), 0, st, csum, K, n_chunks);
+  hipLaunchKernelGGL(osc_grad_freq_suffix_kernel, dim3(n_chunks, B), dim3(256), 0, st, grad_frequency_envelopes, csum, N, K, n_chunks);
   return check_launch();
 }
 

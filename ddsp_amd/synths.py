@@ -118,10 +118,6 @@ class Harmonic(processors.Processor):
       if needs_grad:
         if self.scale_fn is not None and self.scale_fn is not core.exp_sigmoid:
           raise NotImplementedError('the backward pass of Harmonic covers scale_fn=core.exp_sigmoid and scale_fn=None')
-        if f0_hz.requires_grad:
-          raise NotImplementedError(
-              "dL/d f0_hz is formed for amp_resample_method 'window' / 'linear' with n_samples a multiple of n_frames; "
-              'the materialised chain gives dL/d amplitudes and dL/d harmonic_distribution')
         # the same two steps as one torch.autograd node whose backward pass is the chain's adjoint, op for op
         # (round 5: oscillator_bank's gradient w.r.t. its amplitude envelopes, the adjoint of core.resample, get_controls)
         audio, ctl_amp, ctl_hd = _HarmonicMaterialisedFunction.apply(amplitudes, harmonic_distribution, f0_hz, self, fuse)
@@ -242,43 +238,64 @@ class Harmonic(processors.Processor):
     _lib.check(rc, 'ddsp_harmonic_controls_f32')
     return {'amplitudes': ctl_amp, 'harmonic_distribution': ctl_hd, 'f0_hz': f0_hz}
 
-  def _backward_materialised(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
-    """(dL/d amplitudes, dL/d harmonic_distribution) through the chain of materialised envelopes (core.py:1080-1111)."""
+  def _backward_materialised(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio, want_controls=True,
+                             want_f0=False):
+    """(dL/d amplitudes, dL/d harmonic_distribution, dL/d f0_hz) through the chain of materialised envelopes
+    (core.py:1080-1111), the chain's adjoint op for op; the ones not asked for are None."""
     b, f, k = harmonic_distribution.shape
     n = int(self.n_samples)
     lib = _lib.load()
     dev = amplitudes.device
     grad_audio = core.tf_float32(grad_audio)
-    # the frequency envelopes the forward pass ran on: f0 [1 .. K], resampled 'linear' (core.py:1086-1090, 1101)
+    # the envelopes the forward pass ran on: f0 [1 .. K] resampled 'linear', amplitudes * distribution resampled by the method
     harmonic_frequencies = torch.empty((b, f, k), dtype=torch.float32, device=dev)
-    harmonic_amplitudes = torch.empty((b, f, k), dtype=torch.float32, device=dev)      # (made alongside; not used)
+    harmonic_amplitudes = torch.empty((b, f, k), dtype=torch.float32, device=dev)
     ctl = self._controls(amplitudes, harmonic_distribution, f0_hz, fuse)
     rc = lib.ddsp_harmonic_envelopes_f32(ctl['amplitudes'].data_ptr(), ctl['harmonic_distribution'].data_ptr(),
                                          f0_hz.data_ptr(), None, harmonic_frequencies.data_ptr(),
                                          harmonic_amplitudes.data_ptr(), b, f, k, core._stream())
     _lib.check(rc, 'ddsp_harmonic_envelopes_f32')
-    del harmonic_amplitudes
     frequency_envelopes = core.resample(harmonic_frequencies, n)
-    grad_env = torch.empty((b, n, k), dtype=torch.float32, device=dev)
-    ws = self._ws_bwd.get(lib.ddsp_oscillator_bank_workspace_bytes(b, n, k), dev)
-    rc = lib.ddsp_oscillator_bank_grad_amplitudes_f32(frequency_envelopes.data_ptr(), grad_audio.data_ptr(),
-                                                      grad_env.data_ptr(), ws.data_ptr(), ws.numel(), b, n, k,
-                                                      int(self.sample_rate), core._stream())
-    _lib.check(rc, 'ddsp_oscillator_bank_grad_amplitudes_f32')
-    del frequency_envelopes
-    grad_ha = torch.empty((b, f, k), dtype=torch.float32, device=dev)
-    rc = lib.ddsp_resample_ex_backward_f32(grad_env.data_ptr(), grad_ha.data_ptr(), b, f, n, k,
-                                           _lib.RESAMPLE_METHODS[self.amp_resample_method], 1, core._stream())
-    _lib.check(rc, 'ddsp_resample_ex_backward_f32')
-    del grad_env
-    grad_amp = torch.empty_like(amplitudes)
-    grad_hd = torch.empty_like(harmonic_distribution)
-    rc = lib.ddsp_harmonic_controls_backward_f32(
-        amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(), grad_ha.data_ptr(),
-        grad_amp.data_ptr(), grad_hd.data_ptr(), b, f, k, int(self.sample_rate),
-        core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False), 0, core._stream())
-    _lib.check(rc, 'ddsp_harmonic_controls_backward_f32')
-    return grad_amp, grad_hd
+    half = lib.ddsp_oscillator_bank_workspace_bytes(b, n, k)
+    ws = self._ws_bwd.get(2 * half, dev)
+    grad_amp = grad_hd = grad_f0 = None
+    if want_controls:
+      grad_env = torch.empty((b, n, k), dtype=torch.float32, device=dev)
+      rc = lib.ddsp_oscillator_bank_grad_amplitudes_f32(frequency_envelopes.data_ptr(), grad_audio.data_ptr(),
+                                                        grad_env.data_ptr(), ws.data_ptr(), ws.numel(), b, n, k,
+                                                        int(self.sample_rate), core._stream())
+      _lib.check(rc, 'ddsp_oscillator_bank_grad_amplitudes_f32')
+      grad_ha = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+      rc = lib.ddsp_resample_ex_backward_f32(grad_env.data_ptr(), grad_ha.data_ptr(), b, f, n, k,
+                                             _lib.RESAMPLE_METHODS[self.amp_resample_method], 1, core._stream())
+      _lib.check(rc, 'ddsp_resample_ex_backward_f32')
+      del grad_env
+      grad_amp = torch.empty_like(amplitudes)
+      grad_hd = torch.empty_like(harmonic_distribution)
+      rc = lib.ddsp_harmonic_controls_backward_f32(
+          amplitudes.data_ptr(), harmonic_distribution.data_ptr(), f0_hz.data_ptr(), grad_ha.data_ptr(),
+          grad_amp.data_ptr(), grad_hd.data_ptr(), b, f, k, int(self.sample_rate),
+          core._harmonic_flags(fuse, self.normalize_below_nyquist, 'window', False), 0, core._stream())
+      _lib.check(rc, 'ddsp_harmonic_controls_backward_f32')
+    if want_f0:
+      # dL/d frequency envelopes (a suffix sum over time of dL/d audio A mask cos(phase)), the adjoint of the 'linear'
+      # resample, the sum over harmonics weighted [1 .. K]; the frame-rate mask of get_controls (tf.where) passes none
+      amplitude_envelopes = core.resample(harmonic_amplitudes, n, method=self.amp_resample_method)
+      grad_fenv = torch.empty((b, n, k), dtype=torch.float32, device=dev)
+      rc = lib.ddsp_oscillator_bank_grad_frequencies_f32(
+          frequency_envelopes.data_ptr(), amplitude_envelopes.data_ptr(), grad_audio.data_ptr(), grad_fenv.data_ptr(),
+          ws.data_ptr(), ws.numel(), b, n, k, int(self.sample_rate), core._stream())
+      _lib.check(rc, 'ddsp_oscillator_bank_grad_frequencies_f32')
+      del amplitude_envelopes
+      grad_hf = torch.empty((b, f, k), dtype=torch.float32, device=dev)
+      rc = lib.ddsp_resample_ex_backward_f32(grad_fenv.data_ptr(), grad_hf.data_ptr(), b, f, n, k,
+                                             _lib.RESAMPLE_METHODS['linear'], 1, core._stream())
+      _lib.check(rc, 'ddsp_resample_ex_backward_f32')
+      del grad_fenv
+      grad_f0 = torch.empty_like(f0_hz)
+      rc = lib.ddsp_harmonic_frequencies_backward_f32(grad_hf.data_ptr(), None, grad_f0.data_ptr(), b, f, k, core._stream())
+      _lib.check(rc, 'ddsp_harmonic_frequencies_backward_f32')
+    return grad_amp, grad_hd, grad_f0
 
   def _backward_f0(self, amplitudes, harmonic_distribution, f0_hz, fuse, grad_audio):
     """dL/d f0_hz [B,F,1]: the controls once more (one small launch), then ddsp_harmonic_f0_grad_f32."""
@@ -310,7 +327,9 @@ class _HarmonicMaterialisedFunction(torch.autograd.Function):
   core.harmonic_synthesis.  Backward, the chain's adjoint op for op, every op a C-ABI call:
       dL/d amplitude_envelopes [B,N,K] = dL/d audio mask sin(phase)          ddsp_oscillator_bank_grad_amplitudes_f32
       dL/d (amplitudes distribution) [B,F,K] = resample^T of it              ddsp_resample_ex_backward_f32
-      dL/d amplitudes, dL/d harmonic_distribution through get_controls      ddsp_harmonic_controls_backward_f32"""
+      dL/d amplitudes, dL/d harmonic_distribution through get_controls      ddsp_harmonic_controls_backward_f32
+      dL/d frequency_envelopes [B,N,K] (a suffix sum over time)              ddsp_oscillator_bank_grad_frequencies_f32
+      dL/d f0_hz = sum_k k resample^T of it                                  ddsp_harmonic_frequencies_backward_f32"""
 
   @staticmethod
   def forward(ctx, amplitudes, harmonic_distribution, f0_hz, synth, fuse):
@@ -325,8 +344,10 @@ class _HarmonicMaterialisedFunction(torch.autograd.Function):
   @staticmethod
   def backward(ctx, grad_audio, _grad_ctl_amp, _grad_ctl_hd):
     amplitudes, harmonic_distribution, f0_hz = (t.detach() for t in ctx.saved_tensors)
-    grad_amp, grad_hd = ctx.synth._backward_materialised(amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio)
-    return grad_amp, grad_hd, None, None, None
+    grad_amp, grad_hd, grad_f0 = ctx.synth._backward_materialised(
+        amplitudes, harmonic_distribution, f0_hz, ctx.fuse, grad_audio,
+        ctx.needs_input_grad[0] or ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+    return grad_amp, grad_hd, grad_f0, None, None
 
 
 class _FusedAddUnsupported(Exception):

@@ -384,6 +384,16 @@ int ddsp_oscillator_bank_f32(const float* frequency_envelopes, const float* ampl
 int ddsp_oscillator_bank_grad_amplitudes_f32(const float* frequency_envelopes, const float* grad_audio,
                                              float* grad_amplitude_envelopes, void* workspace, size_t workspace_bytes,
                                              int B, int N, int K, int sample_rate, void* stream);
+/* dL/d frequency_envelopes [B,N,K]: phase[n] = (2 pi / sr) sum_{t <= n} f[t] (ddsp/core.py:950-955), so
+ * dL/d f[t,k] = (2 pi / sr) sum_{n >= t} grad_audio[n] A[n,k] mask[n,k] cos(phase[n,k]) (the Nyquist mask, tf.where, passes none).
+ * Workspace: TWICE ddsp_oscillator_bank_workspace_bytes. */
+int ddsp_oscillator_bank_grad_frequencies_f32(const float* frequency_envelopes, const float* amplitude_envelopes,
+                                              const float* grad_audio, float* grad_frequency_envelopes, void* workspace,
+                                              size_t workspace_bytes, int B, int N, int K, int sample_rate, void* stream);
+/* dL/d f0_hz [B,F,1] from dL/d harmonic_frequencies [B,F,K] (= f0 [1..K] (1 + harmonic_shifts), ddsp/core.py:1086-1090;
+ * harmonic_shifts may be NULL). */
+int ddsp_harmonic_frequencies_backward_f32(const float* grad_harmonic_frequencies, const float* harmonic_shifts,
+                                           float* grad_f0_hz, int B, int F, int K, void* stream);
 
 /* core.resample (ddsp/core.py:573-642) for [B,F,C] -> [B,N,C], add_endpoint=True:
  *   window == 0: method='linear' (tf.compat.v1.image.resize BILINEAR, align_corners=False);

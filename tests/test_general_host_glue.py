@@ -93,7 +93,17 @@ class _HostLib:
       y = np.concatenate([np.convolve(a[row], h[row]), np.zeros(delay + n_out)])[delay:delay + n_out]
       if flags & _lib.CONV_ADD_DRY:
         y = y + a[row]
+      if flags & _lib.CONV_ZERO_OUT0:
+        y[0] = 0.0
       o[row] = y[::-1] if flags & _lib.CONV_REVERSE_OUT else y
+    return 0
+
+  def ddsp_sum_rows_f32(self, x, out, b, l, zero_first, stream):
+    self.calls.append('ddsp_sum_rows_f32')
+    v = _view(x, (b, l)).astype(np.float64).sum(axis=0)
+    if zero_first:
+      v[0] = 0.0
+    _view(out, (1, l))[:] = v
     return 0
 
   def ddsp_resample_f32(self, x, out, b, f, n, c, window, stream):
@@ -189,9 +199,6 @@ def test_harmonic_processor_glue_cubic_envelope(host):
   np.testing.assert_allclose(npy(out['controls']['harmonic_distribution']), g['ctl_harmonic_distribution'],
                              rtol=2e-5, atol=1e-9)
   np.testing.assert_allclose(npy(out['signal']), g['signal'], rtol=0, atol=2e-3)
-  f0g = torch.tensor(g['f0_hz'], requires_grad=True)
-  with pytest.raises(NotImplementedError, match='f0_hz'):           # the one gradient the materialised chain does not form
-    synth(g['amplitudes'], g['harmonic_distribution'], f0g)
 
 
 def test_harmonic_f0_gradient_glue(host):

@@ -178,10 +178,7 @@ def test_harmonic_processor_with_cubic_and_nearest_envelopes(ddsp):    # synths.
   chain = npy(ddsp.core._harmonic_synthesis_materialised(ctl['f0_hz'], ctl['amplitudes'], None,
                                                          ctl['harmonic_distribution'], 1600, 16000, 'linear', False))
   parity_check(chain, fused, 2e-4 * 2.0)
-  # dL/d f0_hz through the materialised chain is the one gradient that is not formed
-  f0g = torch.tensor(g['f0_hz'], device=DEV, requires_grad=True)
-  with pytest.raises(NotImplementedError, match='f0_hz'):
-    synth(g['amplitudes'], g['harmonic_distribution'], f0g)
+  # (every gradient flows through the materialised chain too: test_harmonic_backward_through_the_materialised_chain)
 
 
 # ---- the backward pass through the chain of materialised envelopes (round 5) --------------------------------------------------
@@ -213,9 +210,13 @@ def test_harmonic_backward_through_the_materialised_chain(ddsp, method, b, f, k,
   audio = out['signal']
   assert audio.requires_grad and not out['controls']['amplitudes'].requires_grad
   (audio * ddsp.core.tf_float32(g)).sum().backward()
-  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid if scale else None, normalize, method)
+  ga, gh, gf = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid if scale else None, normalize, method, with_f0=True)
   np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=1e-6 + 2e-4 * np.abs(ga).max())
   np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=1e-6 + 2e-4 * np.abs(gh).max())
+  # dL/d f0_hz: the same chain through the frequency envelopes (a suffix sum over time: fp32 sines of fp64 phases, fp64 sums)
+  tf0 = ddsp.core.tf_float32(f0).requires_grad_(True)
+  (synth(amps, hd, tf0) * ddsp.core.tf_float32(g)).sum().backward()
+  np.testing.assert_allclose(npy(tf0.grad), gf, rtol=0, atol=1e-6 + 5e-4 * np.abs(gf).max())
   # the forward value and the controls are the unrecorded call's, to the bit; the backward is deterministic (gathers, no atomics)
   plain = synth(amps, hd, f0, return_outputs_dict=True)
   np.testing.assert_array_equal(npy(audio), npy(plain['signal']))
