@@ -23,8 +23,11 @@
 // share.  Every block is then transformed ONCE (above, each is the imaginary part of one spectrum and the real part of the
 // next), the multiply-add pass reads half the spectra, and the audio's blocks and the impulse response's partitions are one
 // launch (the partitions' launch ahead of the audio's was 15 - 19 us of latency at any batch size): 126 -> 100 us at batch 128,
-// 50 -> 44 at batch 32; with the transform blocks persistent and the multiply-add pass at four wavefronts per SIMD: 91 us (profiles/r05_reverb_row_pairs_and_the_fused_experiment.txt, which also has the form that keeps every
-// spectrum on chip - bin classes with the ring of spectra in registers - built, measured at 99 us and taken out again).
+// 50 -> 44 at batch 32 (profiles/r05_reverb_row_pairs_and_the_fused_experiment.txt, which also has the form that keeps every
+// spectrum on chip - bin classes with the ring of spectra in registers - built, measured at 99 us and taken out again).  Later in
+// the round: the transform blocks persistent (they fetch the next input ahead, first / last pass fused with load / store: 91 us),
+// and no loop waits for its own stores any more (the multiply-add pass's full passes are straight-line code, the dry signal
+// is fetched at clamped indices: 80 - 85 us of kernels; profiles/r05q_*, r05u_*, r05v_*).
 //
 // The forward transform is an in-place radix-8 (+ one radix-2 stage) decimation-in-frequency FFT that leaves its bins in
 // digit-reversed order; the inverse undoes it stage by stage: the per-bin products do not care
