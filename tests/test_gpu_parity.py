@@ -742,7 +742,8 @@ def test_reverb_golden(ddsp, name):
     (1, 4096, 4096, 1, True),          # exactly one block / one partition
     (2, 4097, 4097, 2, False),         # one sample past the block / partition edge
     (2, 1000, 65536, 2, True),         # the longest supported IR, much longer than the audio
-    (1, 20001, 5, 1, False)])          # a tiny IR, ragged length (scalar load path)
+    (1, 20001, 5, 1, False),           # a tiny IR, ragged length (scalar load path)
+    (2, 40000, 30000, 2, True)])       # 8 partitions, 10 spectra per row: the multiply-add pass's straight-line passes of eight
 def test_reverb_vs_fp64_convolution(ddsp, batch, n, l, ir_batch, add_dry):
   import scipy.signal
   rng = np.random.default_rng(n + l)
@@ -766,7 +767,8 @@ def test_reverb_vs_fp64_convolution(ddsp, batch, n, l, ir_batch, add_dry):
     (5, 9000, 20000),         # 5 partitions (ring of eight), an odd batch: the last row pair holds one row
     (4, 30001, 48000),        # 12 partitions - the default reverb_length -, a length that is not a multiple of four
     (3, 5000, 65536),         # 16 partitions: the longest supported response (one row pair per block)
-    (2, 64000, 12289)])       # one tap past three partitions
+    (2, 64000, 12289),        # one tap past three partitions
+    (3, 40000, 30000)])       # 8 partitions, 10 spectra: a straight-line pass of eight, then the tested form for two
 def test_reverb_one_impulse_response_for_the_batch_row_pairs(ddsp, batch, n, l):
   """Round 5: one impulse response for the whole batch - the trainable Reverb of the shipped configurations
   (ddsp/effects.py:62-80, gin/models/solo_instrument.gin:26-40) - runs with two ROWS per complex transform
