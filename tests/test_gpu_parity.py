@@ -154,6 +154,51 @@ def test_prepare_makes_the_constant_tables_ahead_of_the_first_launch(ddsp):
   assert np.abs(ours - ref).max() <= noise_tol(ref)
 
 
+def test_synth_step_replays_from_a_captured_hip_graph(ddsp):
+  """The C ABI neither allocates nor synchronises once ddsp_prepare has run, so a caller may capture its launches into a HIP
+  graph and replay them (the way a serving loop amortises its launches): Harmonic + FilteredNoise + Add and the SpectralLoss
+  captured with torch.cuda.CUDAGraph (plumbing: streams and capture are torch's), replayed on NEW inputs written into the
+  captured buffers, against the eager calls - the same bits (supplied noise: the generated stream's call counter is a launch
+  argument, a captured launch would replay one counter)."""
+  if not torch.cuda.is_available():
+    pytest.skip('needs the GPU')
+  b, f, k, m, n = 4, 100, 100, 65, 6400
+  ddsp.core.prepare(k, m, 0)
+  rng = np.random.default_rng(123)
+  T = ddsp.core.tf_float32
+
+  def fresh():
+    return (T(rng.standard_normal((b, f, 1))), T(rng.standard_normal((b, f, k))), T(200.0 + rng.standard_normal((b, f, 1))),
+            T(rng.standard_normal((b, f, m))), T(rng.uniform(-1, 1, (b, n))), T(rng.standard_normal((b, n))))
+  amps, hd, f0, mags, noise, target = fresh()
+  harm = ddsp.synths.Harmonic(n_samples=n)
+  fnoise = ddsp.synths.FilteredNoise(n_samples=n, window_size=0)
+  loss = ddsp.losses.SpectralLoss(fft_sizes=(512, 256, 64), logmag_weight=1.0)
+
+  def step():
+    audio = harm.call_add(amps, hd, f0, fnoise(mags, noise=noise))
+    return audio, loss(target, audio)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):                     # warm-up on the capture stream: workspaces are per stream, made here
+    for _ in range(3):
+      step()
+  torch.cuda.current_stream().wait_stream(side)
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=side):
+    g_audio, g_loss = step()
+  for _ in range(3):
+    new = fresh()
+    for dst, src in zip((amps, hd, f0, mags, noise, target), new):
+      dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    e_audio, e_loss = step()
+    np.testing.assert_array_equal(npy(g_audio), npy(e_audio))
+    assert float(g_loss) == float(e_loss)
+
+
 def test_add_golden(ddsp):
   g = load_golden('add')
   np.testing.assert_array_equal(npy(ddsp.processors.Add()(g['signal_one'], g['signal_two'])),
