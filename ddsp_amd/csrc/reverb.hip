@@ -44,6 +44,8 @@
 #include "../../include/ddsp_amd.h"
 
 namespace ddsp {
+constexpr unsigned DDSP_CONV_EXP_PLAIN_ORDER = 1u << 30;      // internal: rv_fft_kernel deals its items in block order
+
 
 constexpr int kRvP = 4096;             // output samples per block = taps per IR partition
 constexpr int kRvN = 2 * kRvP;         // FFT size
@@ -185,7 +187,27 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __re
                                                                  int n_ir, int n_items) {
   extern __shared__ __attribute__((aligned(16))) float2 s[];
   const int tid = threadIdx.x;
-  int w = blockIdx.x;
+  // Which items a block takes: consecutive blocks of one row share half their input (overlap-save: block j is the row's samples
+  // (j - 1) P .. (j + 1) P), and block i of the grid runs on XCD i % 8, each with an L2 of its own - dealt out in the order of
+  // the block index the two readers of a sample sat on different XCDs and the L2s fetched the audio twice (FETCH_SIZE 63 MB
+  // a launch at batch 128 against 33 MB of input, profiles/r05v_*).  Of every ROUND of gridDim.x items (the last one: of what
+  // is left, so that every XCD keeps its share of it) an XCD therefore takes a contiguous eighth, its blocks in order.
+  // (A permutation of the items within a round: which block computes a spectrum is all that changes.)
+  // Measured (profiles/r05z_reverb_xcd_item_order.txt): with one impulse response for the batch (row pairs: the audio's blocks
+  // are all but twelve of the items) 30.9 -> 29.9 us a launch at batch 128; with an impulse response per row - a third of the
+  // items are partitions, which read half as much and overlap with nothing - an XCD's share of a round is all partitions or all
+  // audio and the launch is 0.8 us slower at batch 32, no faster at 128: those keep the block order.
+  const bool xcd_order = (gridDim.x & 7) == 0 && p.pairs > 0 && !(p.flags & DDSP_CONV_EXP_PLAIN_ORDER);
+  int round_base = 0;
+  auto item_of_round = [&]() -> int {              // this block's item of the round that starts at round_base, or n_items
+    if (!xcd_order) return round_base + (int)blockIdx.x < n_items ? round_base + (int)blockIdx.x : n_items;
+    const int size = min((int)gridDim.x, n_items - round_base);
+    if (size <= 0) return n_items;
+    const int x = (int)(blockIdx.x & 7), i = (int)(blockIdx.x >> 3);
+    const int lo = (x * size) >> 3, hi = ((x + 1) * size) >> 3;
+    return lo + i < hi ? round_base + lo + i : n_items;
+  };
+  int w = item_of_round();
   float2 nv[8];
   if (w < n_items) rv_fetch(nv, audio, ir, p, rv_item(w, n_ir, p), tid);
   // (the first input waited for HERE, once: left to the loop's head, where the first entry and the loop's own back edge meet,
@@ -198,7 +220,8 @@ __global__ __launch_bounds__(kRvThreads, 8) void rv_fft_kernel(const float* __re
     float2 v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = nv[m];
-    w += gridDim.x;
+    round_base += (int)gridDim.x;
+    w = item_of_round();
     if (w < n_items) rv_fetch(nv, audio, ir, p, rv_item(w, n_ir, p), tid);
     if (!first) __syncthreads();                 // the previous transform's last pass has read the array
     first = false;
@@ -474,6 +497,8 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   RvArgs p;
   p.N = N; p.L = L; p.n_out = n_out; p.nb = rv_blocks(n_out, delay); p.np = rv_parts(L); p.delay = delay;
   p.flags = flags; p.ir_batch = Bir;
+  static const bool plain_order = getenv("DDSP_EXP_RV_PLAIN_ORDER") != nullptr;     // (A/B of the item order, tools/exp_xcd_order.sh)
+  if (plain_order) p.flags |= DDSP_CONV_EXP_PLAIN_ORDER;
   // row pairs: one impulse response for at least two rows - the trainable Reverb of the shipped configurations, effects.py:62-80
   // (DDSP_EXP_REVERB=single keeps the one-row form for the A/B)
   static const bool single_env = [] { const char* e = getenv("DDSP_EXP_REVERB"); return e && e[0] == 's'; }();

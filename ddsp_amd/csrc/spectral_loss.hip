@@ -15,6 +15,7 @@
 // overlap), served by L2; nothing else is read or written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "profile.h"
@@ -450,16 +451,45 @@ struct SlMulti {
   int n;
   int size[16], first[17], nbx[16], frames[16], offset[16];      // per size: S, first linear block, blocks per row, frames, partial offset
   float mag_scale[16], log_scale[16];                            // (the gradient kernel: weight / count of the size)
+  int units;                                                     // > 0: the XCD-aware block order below (B * nbx units of n blocks)
+  FastDiv n_div, nbx_div;                                        // n; nbx (the same for every size)
 };
+// WHICH block does what (late round 5).  Block bx of EVERY size starts at sample 1024 bx of its row (G frames of hop S / 4)
+// and reads 1024 + 3 S / 4 samples of both signals from there: the n blocks (one per size) of a UNIT (row, bx) read the same
+// 2 x 10 KB, and neighbouring units overlap by up to 1536 samples.  In the order "every block of size 2048, then every block
+// of size 1024, .." a sample's 24 readers are spread over the whole launch and over the eight XCDs (block i runs on XCD
+// i % 8, each with an L2 of its own: MI355X_MICROARCH.md, "Workgroup dispatch"): the L2s fetched 4.4 - 8.7 times the two
+// signals' bytes through the fabric (profiles/r05g_*: FETCH_SIZE 286 MB a launch at batch 128 against 65.5 MB of input).
+// Here XCD x = block % 8 owns a CONTIGUOUS eighth of the units and walks it in order, the n sizes of a unit side by side:
+// what a block reads was read by its neighbours on the same L2 moments before.  Only the order of the blocks changes -
+// a block's work and the slot its partial sums go to are the same, so the loss keeps its bits.
+__device__ __forceinline__ bool sl_where(const SlMulti& m, int blk, int& z, int& b, int& bx) {
+  if (m.units > 0) {
+    const int x = blk & 7, q = blk >> 3;
+    uint32_t rz, rbx;
+    const int u = (int)fastdiv((uint32_t)q, m.n_div, rz);
+    z = (int)rz;
+    const int lo = (int)(((long long)x * m.units) >> 3), hi = (int)(((long long)(x + 1) * m.units) >> 3);
+    const int unit = lo + u;
+    if (unit >= hi) return false;
+    b = (int)fastdiv((uint32_t)unit, m.nbx_div, rbx);
+    bx = (int)rbx;
+    return true;
+  }
+  z = 0;
+  while (z + 1 < m.n && blk >= m.first[z + 1]) ++z;
+  const int local = blk - m.first[z], nbx = m.nbx[z];
+  b = local / nbx;
+  bx = local - b * nbx;
+  return true;
+}
 __global__ __launch_bounds__(kSlThreads, 8) void stft_l1_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                              double* __restrict__ partial, int N, SlMulti m, float safe_eps) {
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   __shared__ double red[2][kSlThreads / 64];
-  const int blk = (int)blockIdx.x;
-  int z = 0;
-  while (z + 1 < m.n && blk >= m.first[z + 1]) ++z;
-  const int local = blk - m.first[z], nbx = m.nbx[z];
-  const int b = local / nbx, bx = local - b * nbx;
+  int z, b, bx;
+  if (!sl_where(m, (int)blockIdx.x, z, b, bx)) return;
+  const int nbx = m.nbx[z];
   double* dst = partial + 2 * (size_t)m.offset[z];
 #define DDSP_SL_BLOCK(SZ) case SZ: stft_l1_block<SZ>(s, red, target, audio, dst, N, m.frames[z], safe_eps, bx, b, nbx); break
   switch (m.size[z]) {
@@ -669,11 +699,9 @@ __global__ __launch_bounds__(kSlThreads, 8) void stft_l1_bwd_kernel(const float*
                                                                  float safe_eps, double* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   __shared__ double red[2][kSlThreads / 64];
-  const int blk = (int)blockIdx.x;
-  int z = 0;
-  while (z + 1 < m.n && blk >= m.first[z + 1]) ++z;
-  const int local = blk - m.first[z], nbx = m.nbx[z];
-  const int b = local / nbx, bx = local - b * nbx;
+  int z, b, bx;
+  if (!sl_where(m, (int)blockIdx.x, z, b, bx)) return;
+  const int nbx = m.nbx[z];
   double* dst = partial ? partial + 2 * (size_t)m.offset[z] : nullptr;
 #define DDSP_SLB_BLOCK(SZ) case SZ: stft_l1_bwd_block<SZ, false>(s, red, target, audio, grad_loss, grad_audio, N, m.frames[z], \
                                                                  safe_eps, m.mag_scale[z], m.log_scale[z], dst, nullptr, bx, b, nbx); break
@@ -766,6 +794,21 @@ static inline bool sl_plan_grid(SlMulti& m, const Fin& fin, int B, int N, const 
     total += (long long)B * m.nbx[i];
   }
   m.first[n_sizes] = (int)total;
+  // the XCD-aware order (sl_where): every size has ceil(N / 1024) blocks per row - G frames of hop S / 4 are 1024 samples
+  m.units = 0;
+  bool same = true;
+  for (int i = 1; i < n_sizes; ++i) same = same && m.nbx[i] == m.nbx[0];
+  static const bool plain_order = getenv("DDSP_EXP_SL_PLAIN_ORDER") != nullptr;
+  if (same && !plain_order) {
+    const long long units = (long long)B * m.nbx[0];
+    const long long grid = 8ll * n_sizes * ((units + 7) / 8);
+    if (units < (1ll << 28) && grid < (1ll << 31)) {
+      m.units = (int)units;
+      m.n_div = make_fastdiv((uint32_t)n_sizes);
+      m.nbx_div = make_fastdiv((uint32_t)m.nbx[0]);
+      m.first[n_sizes] = (int)grid;                 // (the launches' grid size)
+    }
+  }
   return total < (1ll << 31);
 }
 

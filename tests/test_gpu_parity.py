@@ -972,7 +972,8 @@ def test_spectral_loss_every_term_golden_and_gradient(ddsp):
     ddsp.losses.SpectralLoss(loss_type='L3')(t, a)
 
 
-@pytest.mark.parametrize('batch,n', [(2, 64000), (3, 12345), (1, 100)])
+# (9, 5000), (17, 1030): 45 and 34 units of (row, 1024 samples) - not multiples of the eight XCDs the block order deals them to (sl_where)
+@pytest.mark.parametrize('batch,n', [(2, 64000), (3, 12345), (1, 100), (9, 5000), (17, 1030)])
 def test_spectral_loss_vs_fp64_oracle(ddsp, batch, n):
   rng = np.random.default_rng(n)
   t = (0.3 * rng.standard_normal((batch, n))).astype(np.float32)
