@@ -778,9 +778,29 @@ extern "C" int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, 
   return launch_ir(ctl_magnitudes, nullptr, ir, B, F, M, window_size, 0.0f, 0, (hipStream_t)stream);
 }
 
+// the plain tiled kernel's tile: as many outputs as keep x + taps under the LDS budget; < 64: none does
+static int fir_plain_tile(int L, int frame_size, size_t& lds) {
+  int tile = 1024;
+  for (; tile >= 64; tile /= 2) {
+    const int nfr = (tile + L - 1) / frame_size + 2;
+    lds = ((size_t)((tile + L - 1 + 3) & ~3) + (size_t)nfr * L) * sizeof(float);
+    if (lds <= kMaxDynLds) break;
+  }
+  return tile;
+}
+// ... in which case launch_fir needs the noise in memory (FilteredNoise with generated noise: a scratch row per clip)
+static bool fir_needs_noise_in_memory(int B, int F, int L, int N) {
+  if (F <= 0 || N <= 0 || L <= 0) return false;
+  const int frame_size = (N + F - 1) / F;
+  if (L == 128 && frame_size == 64) return false;
+  if (!general_plain_env() && tv_fir_mfma_ok(B, B, F, L, N)) return false;
+  size_t lds = 0;
+  return fir_plain_tile(L, frame_size, lds) < 64;
+}
+
 static int launch_fir(const float* x, const float* ir, float* out, int B, int Bir, int F, int L,
                       int N, int delay_compensation, uint64_t seed, uint64_t batch_offset,
-                      int bits23, int taps_bounded, hipStream_t st) {
+                      int bits23, int taps_bounded, hipStream_t st, float* x_scratch = nullptr) {
   if (B > 65535) return DDSP_ERR_UNSUPPORTED;
   FirArgs p;
   p.x = x; p.ir = ir; p.out = out;
@@ -807,14 +827,20 @@ static int launch_fir(const float* x, const float* ir, float* out, int B, int Bi
   if (!general_plain_env() && tv_fir_mfma_ok(B, Bir, F, L, N))
     return launch_tv_fir_mfma(x, ir, out, B, Bir, F, L, N, p.start, seed, batch_offset, bits23, taps_bounded, st);
   // tile: as many outputs as keep x + taps under the LDS budget
-  int tile = 1024;
   size_t lds = 0;
-  for (; tile >= 64; tile /= 2) {
-    const int nfr = (tile + L - 1) / p.frame_size + 2;
-    lds = ((size_t)((tile + L - 1 + 3) & ~3) + (size_t)nfr * L) * sizeof(float);
-    if (lds <= kMaxDynLds) break;
+  const int tile = fir_plain_tile(L, p.frame_size, lds);
+  if (tile < 64) {
+    // filters that reach across so many frames that not even 64 outputs' taps fit the LDS (510 taps on frames of 5 samples: 116
+    // tap rows per tile) - found by tools/fuzz_parity.py, the reference takes any shape: the plain sum of csrc/general.hip, which
+    // reads its taps from memory.  It wants the noise in memory: the caller's, or generated into `x_scratch` first.
+    if (!x) {
+      if (!x_scratch) return DDSP_ERR_UNSUPPORTED;
+      const int rc = ddsp_uniform_noise_ex_f32(x_scratch, B, N, seed, batch_offset, bits23 ? 23 : 11, st);
+      if (rc != DDSP_OK) return rc;
+      x = x_scratch;
+    }
+    return ddsp_fft_convolve_f32(x, ir, out, B, Bir, F, L, N, N, p.start, st);
   }
-  if (tile < 64) return DDSP_ERR_UNSUPPORTED;                 // very long IRs (Reverb): not v1
   p.tile = tile;
   const dim3 grid((unsigned)((N + tile - 1) / tile), (unsigned)B), block(256);
   ProfileScope prof(kTvFir, st);
@@ -833,9 +859,12 @@ extern "C" int ddsp_fft_convolve_same_f32(const float* audio, const float* impul
 }
 
 extern "C" size_t ddsp_filtered_noise_workspace_bytes(int B, int F, int M, int N, int window_size) {
-  (void)N;
   if (B <= 0 || F <= 0 || M < 2) return 0;
-  return (size_t)B * F * (size_t)ir_geom(M, window_size).L * sizeof(float);
+  const int L = ir_geom(M, window_size).L;
+  size_t bytes = (size_t)B * F * (size_t)L * sizeof(float);
+  if (N > 0 && fir_needs_noise_in_memory(B, F, L, N))                   // (launch_fir: generated noise for the plain sum)
+    bytes = ((bytes + 15) & ~(size_t)15) + (size_t)B * N * sizeof(float);
+  return bytes;
 }
 
 extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* audio,
@@ -908,8 +937,12 @@ extern "C" int ddsp_filtered_noise_f32(const float* magnitudes, const float* noi
   float* ir = (float*)workspace;
   int rc = launch_ir(magnitudes, ctl_magnitudes, ir, B, F, M, window_size, initial_bias, scale, st);
   if (rc != DDSP_OK) return rc;
-  return launch_fir(noise, ir, audio, B, B, F, ir_geom(M, window_size).L, N, -1, seed,
-                    batch_offset, bits23, scale, st);             // (scale: the taps were designed from squashed magnitudes)
+  const int L = ir_geom(M, window_size).L;
+  float* x_scratch = nullptr;
+  if (!noise && fir_needs_noise_in_memory(B, F, L, N))
+    x_scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((((size_t)B * F * L * sizeof(float)) + 15) & ~(size_t)15));
+  return launch_fir(noise, ir, audio, B, B, F, L, N, -1, seed,
+                    batch_offset, bits23, scale, st, x_scratch);  // (scale: the taps were designed from squashed magnitudes)
 }
 
 // =====================================================================================

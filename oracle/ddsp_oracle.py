@@ -107,7 +107,9 @@ def resize_nearest_legacy(x, n_out, align_corners=False):
   source = min(floor(pos), F-1), or min(round(pos), F-1) with align_corners (roundf: half away from 0)."""
   n_in = x.shape[1]
   pos = _legacy_resize_positions(n_in, n_out, align_corners)
-  src = np.floor(pos + np.float32(0.5)) if align_corners else np.floor(pos)
+  # roundf(pos): half away from zero.  In fp64: pos + 0.5 is exact there - in fp32 the sum itself rounds (0.49999997 + 0.5 -> 1.0)
+  # and floor() lands one frame too far (found by tools/fuzz_parity.py against the kernel's roundf: frames = 2, n = 111)
+  src = np.floor(pos.astype(np.float64) + 0.5) if align_corners else np.floor(pos)
   return x[:, np.minimum(src.astype(np.int64), n_in - 1), :]
 
 

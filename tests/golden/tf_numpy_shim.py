@@ -193,7 +193,7 @@ def _nearest_rows(x, out_size, align_corners):
   src = np.empty(out_size, np.int64)
   for o in range(out_size):
     pos = np.float32(o) * scale
-    r = np.floor(pos + np.float32(0.5)) if align_corners else np.floor(pos)   # roundf: half away from zero, pos >= 0
+    r = np.floor(pos.astype(np.float64) + 0.5) if align_corners else np.floor(pos)   # roundf: half away from zero, pos >= 0 (the sum in fp64: exact)
     src[o] = min(int(r), in_size - 1)
   return x[:, src]
 

@@ -1695,6 +1695,8 @@ def test_filtered_noise_random_shapes_vs_oracle(ddsp, seed):
     (40, 0, 90, 17280 - 50, 2),    # frames of 192 with a ragged end
     (12, 0, 300, 6000, 2),         # frames of 20 samples
     (129, 65, 64, 32768, 2),       # frames of 512
+    (256, 0, 65, 324, 3),          # 510 taps on frames of 5 samples: 116 tap rows per 64 outputs - no tiled kernel holds them; the
+    (129, 257, 10, 50, 4),         # plain sum of csrc/general.hip takes over (tools/fuzz_parity.py found these returning UNSUPPORTED)
 ])
 def test_filtered_noise_general_shapes_on_the_matrix_cores(ddsp, m, ws, n_frames, n, batch):
   """filtered_noise_general.hip (noise_ir_gemm_kernel, tv_fir_mfma_kernel): any band count, window and frame size against

@@ -516,3 +516,16 @@ def test_spectral_loss_every_term_matches_reference_source():
   x = np.arange(24, dtype=np.float32).reshape(1, 4, 6) ** 2
   np.testing.assert_array_equal(O.diff(x, 1), x[:, 1:] - x[:, :-1])
   np.testing.assert_array_equal(O.diff(x, 2), x[:, :, 1:] - x[:, :, :-1])
+
+
+def test_nearest_resize_rounds_like_roundf_not_like_a_rounded_sum():
+  """tf.compat.v1.image.resize(NEAREST, align_corners=True) takes roundf(out * scale) (resize_nearest_neighbor_op.cc).  With two
+  frames and 111 samples the position of sample 55 is 55 * fp32(1 / 110) = 0.49999997: roundf gives frame 0; floor(pos + 0.5) in
+  fp32 - the sum rounds to 1.0 - gave frame 1 (the restatement until round 5; tools/fuzz_parity.py found the kernel, which calls
+  roundf, and this oracle one whole frame apart)."""
+  pos = O._legacy_resize_positions(2, 111, True)
+  assert pos[55] < np.float32(0.5) and np.float32(pos[55] + np.float32(0.5)) == np.float32(1.0)
+  x = np.array([[[1.0], [2.0]]], np.float32)
+  out = O.resize_nearest_legacy(x, 111, True)[0, :, 0]
+  np.testing.assert_array_equal(out[:56], 1.0)
+  np.testing.assert_array_equal(out[56:], 2.0)
