@@ -227,6 +227,11 @@ int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* impu
  *   audio      [B,N] out.   ctl_magnitudes: NULL or [B,F,M] out (controls dict).
  * Frames: frame_size = ceil(N/F) and ceil(N/frame_size) must equal F (the reference's
  * ValueError, core.py:1451-1457) else DDSP_ERR_BAD_SHAPE.
+ * Workspace: the taps [B,F,L] for the shapes that design them in a launch of their own,
+ * plus - for filters that reach across more frames than a tiled kernel holds (510 taps
+ * on frames of 5 samples: the plain sum of ddsp_fft_convolve_f32 takes those) - a row of
+ * generated noise per clip; always ask ddsp_filtered_noise_workspace_bytes() with the
+ * call's own (B, F, M, N, window_size).
  */
 size_t ddsp_filtered_noise_workspace_bytes(int B, int F, int M, int N, int window_size);
 int ddsp_filtered_noise_f32(const float* magnitudes, const float* noise, float* audio,
