@@ -166,10 +166,10 @@ def case_noise(rng):
 
 
 def case_noise_bwd(rng):
-  m = int(rng.choice([5, 33, 65, 65, 65, 100, 129]))
+  m = int(rng.choice([5, 33, 65, 65, 65, 100, 129, 200, 256]))
   l0 = 2 * (m - 1)
   ws = int(rng.choice([0, 0, 257, max(3, l0 // 2 + 1)]))
-  fs = int(rng.choice([16, 64, 64, 80, 100, 128, 192, 256]))
+  fs = int(rng.choice([5, 16, 64, 64, 80, 100, 128, 192, 256]))
   f = int(rng.integers(1, 60))
   n = f * fs - int(rng.integers(0, fs))
   b = int(rng.integers(1, 4))
@@ -309,7 +309,7 @@ def case_resample(rng):
   up = int(rng.integers(1, 200))
   if method == 'window':
     n = (f if add_endpoint else max(f - 1, 1)) * up                 # (core.py:687: divisible by the number of hops)
-    if n < f or (not add_endpoint and f < 2):
+    if n <= f or (not add_endpoint and f < 2):
       return None, 0.0
   else:
     n = int(rng.integers(f, f * 200 + 1))
@@ -323,8 +323,72 @@ def case_resample(rng):
   return what, err / tol
 
 
+def case_harmonic_chain(rng):
+  """The materialised chain (csrc/general.hip): 'nearest' / 'cubic' / 'linear' envelopes, lengths that are not multiples of the
+  frame count - forward against the fp64 oracle, backward against its analytic gradient (moderate f0 motion: TF's fp32 resize
+  positions, see case_harmonic_bwd)."""
+  f = int(rng.integers(2, 40))
+  k = int(rng.choice([1, 7, 20, 60, 100]))
+  b = int(rng.integers(1, 3))
+  sr = int(rng.choice([16000, 48000]))
+  method = str(rng.choice(['nearest', 'cubic', 'linear']))
+  n = int(rng.integers(f, f * 120))
+  if b * n * k > 1.5e6:
+    n = max(f, int(1.5e6 / (b * k)))
+  base = float(rng.choice([70.0, 110.0, 220.0, 440.0]))
+  f0 = np.abs(base * (1.0 + 0.01 * rng.standard_normal((b, f, 1)))).astype(np.float32)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  what = note(dict(frames=f, n=n, k=k, batch=b, sr=sr, method=method, base=base))
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  audio = synth(ta, th, f0)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, amp_resample_method=method, dtype=np.float64)
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  # (TF's fp32 positions against the kernels' - both restate the legacy resize; a cubic envelope may overshoot its frames)
+  atol = 4 * P.HARM_TRUTH_ATOL * scale * (2.0 if method == 'cubic' else 1.0)
+  e = np.abs(npy(audio.detach()) - truth)
+  # knife edges: the sample at which a harmonic's interpolated frequency passes Nyquist is masked by an fp32 comparison in the
+  # kernels (as in the reference) and by an fp64 one in this oracle - at most a sample or two per row may take the other side
+  # (replayed: exactly one sample, off by that harmonic's amplitude); those carry no cotangent below
+  knife = e > atol
+  assert knife.sum(axis=1).max() <= 3, ('materialised chain forward', float(e.max()), atol, int(knife.sum()))
+  err = float(e[~knife].max())
+  g[knife] = 0.0
+  audio.backward(ddsp.core.tf_float32(g))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, method)
+  tol_a, tol_h = 3 * (1e-5 + 2e-4 * np.abs(ga).max()), 3 * (1e-5 + 2e-4 * np.abs(gh).max())
+  ea, eh = float(np.abs(npy(ta.grad) - ga).max()), float(np.abs(npy(th.grad) - gh).max())
+  assert ea <= tol_a and eh <= tol_h, ('materialised chain backward', ea, tol_a, eh, tol_h)
+  return what, max(err / atol, ea / tol_a, eh / tol_h)
+
+
+def case_oscillator_bank(rng):
+  b, n, k = int(rng.integers(1, 3)), int(rng.integers(1, 3000)), int(rng.choice([1, 2, 17, 64, 65, 100, 200]))
+  sr = int(rng.choice([8000, 16000, 48000]))
+  f = (rng.uniform(20.0, sr * 0.55, (b, 1, k)) * (1.0 + 0.001 * rng.standard_normal((b, n, 1)))).astype(np.float32)
+  a = rng.standard_normal((b, n, k)).astype(np.float32)
+  sum_s = bool(rng.integers(0, 2))
+  what = note(dict(batch=b, n=n, sinusoids=k, sr=sr, sum_sinusoids=sum_s))
+  got = npy(ddsp.core.oscillator_bank(f, a, sample_rate=sr, sum_sinusoids=sum_s))
+  # (the reference masks in fp32: the oracle in fp32 op order decides the mask, fp64 carries the phases)
+  mask = (f >= np.float32(sr / 2.0))
+  a64 = np.where(mask, 0.0, a.astype(np.float64))
+  ph = np.cumsum(f.astype(np.float64) * (2.0 * np.pi / sr), axis=1)
+  ref = a64 * np.sin(ph)
+  if sum_s:
+    ref = ref.sum(-1)
+  tol = 6e-5 * max(1.0, float(np.abs(a).sum(-1).max()) if sum_s else float(np.abs(a).max()))
+  err = float(np.abs(got - ref).max())
+  assert got.shape == ref.shape and err <= tol, ('oscillator_bank', err, tol)
+  return what, err / tol
+
+
 CASES = dict(harmonic=case_harmonic, harmonic_bwd=case_harmonic_bwd, noise=case_noise, noise_bwd=case_noise_bwd,
-             reverb=case_reverb, loss=case_loss, fft_convolve=case_fft_convolve, resample=case_resample)
+             reverb=case_reverb, loss=case_loss, fft_convolve=case_fft_convolve, resample=case_resample,
+             harmonic_chain=case_harmonic_chain, oscillator_bank=case_oscillator_bank)
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
