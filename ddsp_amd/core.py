@@ -599,12 +599,24 @@ def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=
   frequencies, amplitudes = tf_float32(frequencies), tf_float32(amplitudes)
   flags = _lib.HARM_AMP_LINEAR if amp_resample_method == 'linear' else 0
   require_no_grad('core.streaming_harmonic_synthesis', frequencies, amplitudes, harmonic_distribution, initial_phase)
+  n = int(n_samples)
+  if harmonic_distribution is None and amplitudes.dim() == 3 and amplitudes.shape[-1] != 1:
+    # amplitudes given PER HARMONIC [batch, n_frames, n_harmonics] and no distribution: the reference then takes them as the
+    # harmonic amplitudes themselves (core.py:1150-1151, `harmonic_amplitudes = amplitudes` - its docstring says [.., 1], its code
+    # takes any last axis; tools/fuzz_parity.py found this entry raising): the chain on materialised envelopes
+    if frequencies.dim() != 3 or frequencies.shape[-1] != 1 or frequencies.shape[:2] != amplitudes.shape[:2]:
+      raise ValueError('frequencies must have shape [{}, {}, 1], got {}'.format(amplitudes.shape[0], amplitudes.shape[1],
+                                                                               tuple(frequencies.shape)))
+    _check_amp_method(amp_resample_method, int(amplitudes.shape[1]), n)
+    frequency_envelope = resample(frequencies, n)
+    amplitude_envelopes = resample(amplitudes.contiguous(), n, method=amp_resample_method)
+    return harmonic_oscillator_bank(frequency_envelope, amplitude_envelopes, initial_phase, sample_rate=sample_rate,
+                                    workspace=workspace)
   if harmonic_distribution is None:
     harmonic_distribution = torch.ones_like(amplitudes)
     flags |= _lib.HARM_INPUTS_ARE_AMPLITUDES
   harmonic_distribution = tf_float32(harmonic_distribution)
   b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
-  n = int(n_samples)
   _check_amp_method(amp_resample_method, f, n)
   if amp_resample_method not in ('linear', 'window') or n % f:
     # the closed-form kernel knows the two envelopes the shipped configs use on whole frames; everything else follows

@@ -1076,6 +1076,28 @@ def test_streaming_chunks_are_phase_continuous(ddsp):               # inference.
   assert np.abs(got).max() > 0.2
 
 
+@pytest.mark.parametrize('method,n', [('linear', 320), ('window', 320), ('nearest', 333), ('cubic', 250)])
+def test_streaming_synthesis_with_per_harmonic_amplitudes_and_no_distribution(ddsp, method, n):
+  """core.streaming_harmonic_synthesis(frequencies, amplitudes [batch, n_frames, n_harmonics]) without a distribution: the
+  reference takes the amplitudes as the harmonic amplitudes themselves (`harmonic_amplitudes = amplitudes`, core.py:1150-1151 -
+  its docstring says [.., 1], its code takes any last axis).  This entry raised until tools/fuzz_parity.py drew the case."""
+  rng = np.random.default_rng(n)
+  b, f, k, sr = 2, 5, 20, 16000
+  f0 = rng.uniform(80.0, 500.0, (b, f, 1)).astype(np.float32)
+  amps = rng.uniform(0.0, 1.0, (b, f, k)).astype(np.float32)
+  phase = rng.uniform(0.0, 6.0, (b, 1, 1)).astype(np.float32)
+  got, final = ddsp.core.streaming_harmonic_synthesis(f0, amps, None, initial_phase=phase, n_samples=n, sample_rate=sr,
+                                                      amp_resample_method=method)
+  ref, ref_final = O.streaming_harmonic_synthesis(f0, amps, None, initial_phase=phase, n_samples=n, sample_rate=sr,
+                                                  amp_resample_method=method, dtype=np.float64)
+  assert tuple(got.shape) == (b, n) and tuple(final.shape) == (b, 1, 1)
+  np.testing.assert_allclose(npy(got), ref, rtol=0, atol=3e-4 * max(1.0, np.abs(ref).max()))
+  d = np.abs(((npy(final).astype(np.float64) - ref_final + np.pi) % (2 * np.pi)) - np.pi)
+  assert d.max() <= 2e-4
+  with pytest.raises(ValueError, match='frequencies must have shape'):
+    ddsp.core.streaming_harmonic_synthesis(f0[:, :3], amps, None, n_samples=n, sample_rate=sr, amp_resample_method=method)
+
+
 # ---- backward pass of Harmonic (SURVEY section 8f rank 3) ----------------------------------------
 # GRAD  |ours - fp64 analytic gradient| <= 2e-4 * max|ref| + 1e-6   (fp32 sines, fp32 accumulation
 #       over one frame; the analytic oracle is itself checked against finite differences on CPU)

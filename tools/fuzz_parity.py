@@ -386,9 +386,42 @@ def case_oscillator_bank(rng):
   return what, err / tol
 
 
+def case_streaming(rng):
+  """core.streaming_harmonic_synthesis over several calls with the phase carried (the VST path, core.py:1114-1164)."""
+  b, f = int(rng.integers(1, 3)), int(rng.integers(2, 6))
+  k = int(rng.choice([1, 20, 60, 100]))
+  n = int(rng.choice([64, 320, 512, 1000, int(rng.integers(f, 1500))]))
+  sr = int(rng.choice([16000, 48000]))
+  method = str(rng.choice(['linear', 'linear', 'window', 'nearest', 'cubic']))
+  if method == 'window':
+    n = f * int(rng.integers(2, 300))                          # (core.py:687: divisible by the number of frames)
+  calls = int(rng.integers(1, 5))
+  with_hd = bool(rng.integers(0, 4))
+  what = note(dict(batch=b, frames=f, k=k, n=n, sr=sr, method=method, calls=calls, with_distribution=with_hd))
+  phase = np.zeros((b, 1, 1), np.float32); phase64 = np.zeros((b, 1, 1))
+  worst = 0.0
+  for _ in range(calls):
+    f0 = rng.uniform(60.0, 600.0, (b, f, 1)).astype(np.float32)
+    amps = rng.uniform(0.1, 1.0, (b, f, 1 if with_hd else k)).astype(np.float32)
+    hd = rng.uniform(0.0, 1.0, (b, f, k)).astype(np.float32) if with_hd else None
+    got, phase = ddsp.core.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase, n_samples=n, sample_rate=sr,
+                                                        amp_resample_method=method)
+    ref, phase64 = O.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase64, n_samples=n, sample_rate=sr,
+                                                  amp_resample_method=method, dtype=np.float64)
+    # (the carried phase goes through fp32 between calls: tests/test_gpu_parity.py allows 2e-3 over 40 calls)
+    tol = 3e-4 * max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(npy(got) - ref).max())
+    assert err <= tol, ('streaming synthesis', err, tol)
+    dphi = np.abs(((npy(phase).astype(np.float64) - phase64 + np.pi) % (2 * np.pi)) - np.pi).max()
+    assert dphi <= 2e-4, ('carried phase', float(dphi))
+    worst = max(worst, err / tol)
+    phase = npy(phase); 
+  return what, worst
+
+
 CASES = dict(harmonic=case_harmonic, harmonic_bwd=case_harmonic_bwd, noise=case_noise, noise_bwd=case_noise_bwd,
              reverb=case_reverb, loss=case_loss, fft_convolve=case_fft_convolve, resample=case_resample,
-             harmonic_chain=case_harmonic_chain, oscillator_bank=case_oscillator_bank)
+             harmonic_chain=case_harmonic_chain, oscillator_bank=case_oscillator_bank, streaming=case_streaming)
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
