@@ -11,6 +11,7 @@ namespace ddsp {
 struct IrGeom {
   int M, L0, ws, padding, half, L;
 };
+__host__ __device__ inline int ir_first_len(int half) { return half > 2 ? half - 2 : 0; }       // len(ir[L0 - half + 2:])
 __host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
   IrGeom g;
   g.M = M;
@@ -18,14 +19,18 @@ __host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
   g.ws = (window_size <= 0 || window_size > g.L0) ? g.L0 : window_size;   // :1501-1503
   g.padding = g.L0 - g.ws;
   g.half = (g.ws + 1) / 2;                                // :1509
-  g.L = g.padding > 0 ? 2 * g.half - 1 : g.L0;            // :1520-1527
+  // concat(ir[L0 - half + 2:], ir[:half + 1]) (:1520-1527): half - 2 taps and half + 1 taps - but a window of one or two samples
+  // (half = 1) starts its first slice at L0 + 1, past the end: python gives an EMPTY slice there, not one of -1 elements, and
+  // the filter has two taps (found by tools/fuzz_api_vs_reference.py: the mirror said one)
+  g.L = g.padding > 0 ? ir_first_len(g.half) + g.half + 1 : g.L0;
   return g;
 }
 // causal tap index kappa -> zero-phase sample index n and Hann window index (or -1: zero)
 __host__ __device__ inline void ir_tap_map(const IrGeom& g, int kappa, int* n, int* widx) {
   if (g.padding > 0) {
     // concat(ir[L0-half+2:], ir[:half+1])                         (core.py:1521-1526)
-    const int nn = (kappa < g.half - 2) ? (g.L0 - g.half + 2 + kappa) : (kappa - (g.half - 2));
+    const int first = ir_first_len(g.half);
+    const int nn = (kappa < first) ? (g.L0 - g.half + 2 + kappa) : (kappa - first);
     // window_zp = concat(window[half:], zeros(padding), window[:half])   (:1510-1512)
     int wi = -1;
     if (nn < g.ws - g.half) wi = g.half + nn;

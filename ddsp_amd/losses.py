@@ -57,8 +57,11 @@ class SpectralLoss(Loss):
   def call(self, target_audio, audio, weights=None):
     """Scalar loss (0-dim tensor in HBM) between two batches of audio [batch, n_samples(, 1)]."""
     if self.loss_type.upper() not in ('L1', 'L2', 'COSINE'):
-      raise ValueError('Loss type ({}), must be '
-                       '"L1", "L2", or "COSINE"'.format(self.loss_type.upper()))
+      # losses.mean_difference (losses.py:102-128) raises when it is CALLED: a loss whose every weight is zero never calls it
+      if max(self.mag_weight, self.delta_time_weight, self.delta_freq_weight, self.cumsum_freq_weight, self.logmag_weight) > 0:
+        raise ValueError('Loss type ({}), must be '
+                         '"L1", "L2", or "COSINE"'.format(self.loss_type.upper()))
+      return torch.zeros((), dtype=torch.float32, device=core._device())
     if self.loudness_weight > 0:
       raise NotImplementedError('SpectralLoss.loudness_weight needs spectral_ops.compute_loudness (librosa A-weighting), '
                                 'which is outside the MI355X path')
@@ -139,6 +142,12 @@ class SpectralLoss(Loss):
         rc = lib.ddsp_stft_mag_backward_f32(audio.data_ptr(), cot.data_ptr(), grad_audio.data_ptr(), b, n, size,
                                             core._stream())
         _lib.check(rc, 'ddsp_stft_mag_backward_f32')
+    if (self.delta_time_weight > 0 and self.loss_type.upper() in ('L1', 'L2') and
+        any(-(-n // (int(size) // 4)) < 2 for size in self.fft_sizes)):
+      # a clip of ONE frame at some size: the reference's delta-time term is the mean of an empty difference - NaN
+      # (tf.reduce_mean over no elements, losses.py:102-128, 213-216), and so is the loss it returns.  ('COSINE' goes through
+      # tf.compat.v1.losses.cosine_distance, whose weighted mean divides safely: 0 for no elements - what the kernel adds.)
+      loss.fill_(float('nan'))
     return loss, grad_audio
 
   def _sizes(self):

@@ -972,6 +972,26 @@ def test_spectral_loss_every_term_golden_and_gradient(ddsp):
     ddsp.losses.SpectralLoss(loss_type='L3')(t, a)
 
 
+def test_spectral_loss_degenerate_arguments_follow_the_reference(ddsp):
+  """What tools/fuzz_api_vs_reference.py found the mirror doing differently from the reference's own code:
+  a loss type that does not exist raises when losses.mean_difference is CALLED (losses.py:102-128) - a loss whose every weight
+  is zero never calls it and returns 0; a delta-time term over ONE frame is tf.reduce_mean of no elements, NaN ('L1' / 'L2'),
+  or cosine_distance's safe mean, 0 ('COSINE')."""
+  rng = np.random.default_rng(5)
+  t = (0.3 * rng.standard_normal((2, 64))).astype(np.float32)
+  a = (0.8 * t + 0.05 * rng.standard_normal((2, 64))).astype(np.float32)
+  assert float(ddsp.losses.SpectralLoss(loss_type='L3', mag_weight=0.0)(t, a)) == 0.0
+  with pytest.raises(ValueError, match='Loss type'):
+    ddsp.losses.SpectralLoss(loss_type='L3', mag_weight=0.0, delta_freq_weight=1.0)(t, a)
+  one_frame = dict(fft_sizes=(256, 64), mag_weight=1.0, delta_time_weight=1.0)          # 64 samples: one frame of size 256
+  assert np.isnan(float(ddsp.losses.SpectralLoss(loss_type='L1', **one_frame)(t, a)))
+  assert np.isnan(float(ddsp.losses.SpectralLoss(loss_type='L2', **one_frame)(t, a)))
+  cos = float(ddsp.losses.SpectralLoss(loss_type='COSINE', **one_frame)(t, a))
+  ref = float(O.spectral_loss(t, a, (64,), loss_type='COSINE', mag_weight=1.0, delta_time_weight=1.0, dtype=np.float64)) + \
+      float(O.spectral_loss(t, a, (256,), loss_type='COSINE', mag_weight=1.0, dtype=np.float64))
+  np.testing.assert_allclose(cos, ref, rtol=5e-5)
+
+
 # (9, 5000), (17, 1030): 45 and 34 units of (row, 1024 samples) - not multiples of the eight XCDs the block order deals them to (sl_where)
 @pytest.mark.parametrize('batch,n', [(2, 64000), (3, 12345), (1, 100), (9, 5000), (17, 1030)])
 def test_spectral_loss_vs_fp64_oracle(ddsp, batch, n):

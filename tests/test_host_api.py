@@ -261,3 +261,17 @@ def test_crop_processor():                                         # processors.
       P.Crop(frame_size=4, crop_location='middle')(x)
   finally:
     P.core = old
+
+
+def test_fir_size_matches_the_reference_crop_for_every_small_window():
+  """ddsp_fir_size (host arithmetic, no GPU): the taps apply_window_to_impulse_response leaves (ddsp/core.py:1477-1531) for every
+  window size up to the filter's own - including windows of ONE or TWO samples, whose first slice `ir[L0 - half + 2:]` starts past
+  the end and is empty in python: two taps, not one (tools/fuzz_api_vs_reference.py found the mirror's geometry one short)."""
+  import numpy as np
+  from oracle import ddsp_oracle as O
+  lib = _lib.load()
+  for m in (3, 5, 9, 17, 65):
+    mags = np.ones((1, 1, m), np.float32)
+    for ws in list(range(0, 2 * (m - 1) + 3)) + [257]:
+      taps = O.frequency_impulse_response(mags, window_size=ws, dtype=np.float32).shape[-1]
+      assert lib.ddsp_fir_size(m, ws) == taps, (m, ws, lib.ddsp_fir_size(m, ws), taps)
