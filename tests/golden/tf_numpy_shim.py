@@ -262,7 +262,11 @@ def image_resize_v1(images, size, method=ResizeMethod.BILINEAR, align_corners=Fa
 
 
 # --- keras Layer ------------------------------------------------------------------
-class Layer:
+class Module:
+  pass
+
+
+class Layer(Module):                                          # (a keras Layer IS a tf.Module: dags.is_module, ddsp/dags.py:40)
   def __init__(self, name=None, trainable=False, **kwargs):
     self._name = name
     self.trainable = trainable
@@ -277,10 +281,6 @@ class Layer:
 
   def __call__(self, *args, **kwargs):
     return self.call(*args, **kwargs)
-
-
-class Module:
-  pass
 
 
 def _identity_decorator(*dargs, **dkwargs):
@@ -308,6 +308,7 @@ def build_tf_module():
   tf.complex = complex_
   tf.sin = _wrap(np.sin)
   tf.abs = _wrap(np.abs)
+  tf.sqrt = _wrap(np.sqrt)                                   # (processors.Mix: processors.py:225-226)
   tf.exp = _wrap(np.exp)
   tf.concat = lambda values, axis: _t(np.concatenate([_np(v) for v in values], axis=axis))
   tf.zeros_like = _wrap(np.zeros_like)

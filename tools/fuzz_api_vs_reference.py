@@ -279,9 +279,92 @@ def case_spectral_loss(rng):
   return what, compare(what, ref, got, 5e-5)
 
 
+def case_processors(rng):
+  which = str(rng.choice(['mix', 'crop', 'fir_filter', 'group']))
+  what = dict(case='processors', which=which)
+  if which == 'mix':
+    b, n, f = int(rng.integers(1, 3)), int(rng.integers(8, 300)), int(rng.integers(1, 8))
+    # ([batch, n, 1] signals: the reference's docstring says "2-D or 3-D", its broadcast against the [batch, n, 1] mix level
+    #  only works for 3-D - the mirror takes both)
+    n2 = n if maybe(rng, 0.8) else n + 1
+    x, y = rng.standard_normal((b, n, 1)).astype(np.float32), rng.standard_normal((b, n2, 1)).astype(np.float32)
+    lvl = rng.standard_normal((b, f, 1)).astype(np.float32)
+    what.update(b=b, n=n, n2=n2, f=f)
+    return what, compare(what, lambda: Rproc.Mix()(x, y, lvl), lambda: M.processors.Mix()(x, y, lvl), 2e-6)
+  if which == 'crop':
+    b, n = int(rng.integers(1, 3)), int(rng.integers(8, 300))
+    fs = int(rng.integers(1, 40)); loc = str(rng.choice(['front', 'center', 'back', 'middle']))
+    x = rng.standard_normal((b, n)).astype(np.float32)
+    what.update(b=b, n=n, frame_size=fs, crop_location=loc)
+    return what, compare(what, lambda: Rproc.Crop(fs, loc)(x), lambda: M.processors.Crop(fs, loc)(x), 0.0)
+  if which == 'fir_filter':
+    b, f, m = int(rng.integers(1, 3)), int(rng.integers(1, 8)), int(rng.choice([5, 17, 65]))
+    fs = int(rng.choice([16, 64])); n = f * fs
+    ws = int(rng.choice([0, 257, 9]))
+    x = rng.standard_normal((b, n)).astype(np.float32); mags = rng.standard_normal((b, f, m)).astype(np.float32)
+    what.update(b=b, f=f, m=m, n=n, ws=ws)
+    return what, compare(what, lambda: Reffects.FIRFilter(window_size=ws)(x, mags), lambda: M.effects.FIRFilter(window_size=ws)(x, mags), 2e-5)
+  # a ProcessorGroup: two Harmonic synths (different pitch ranges) summed, then cropped - every node deterministic
+  b, f, k, hop = int(rng.integers(1, 3)), int(rng.integers(2, 8)), int(rng.choice([4, 16])), 16
+  n = f * hop
+  feats = dict(a1=rng.standard_normal((b, f, 1)).astype(np.float32), h1=rng.standard_normal((b, f, k)).astype(np.float32),
+               f1=rng.uniform(100, 400, (b, f, 1)).astype(np.float32), a2=rng.standard_normal((b, f, 1)).astype(np.float32),
+               h2=rng.standard_normal((b, f, k)).astype(np.float32), f2=rng.uniform(400, 900, (b, f, 1)).astype(np.float32))
+  def dag(P, S):
+    return [(S.Harmonic(n_samples=n, name='low'), ['a1', 'h1', 'f1']), (S.Harmonic(n_samples=n, name='high'), ['a2', 'h2', 'f2']),
+            (P.Add(name='add'), ['low/signal', 'high/signal']), (P.Crop(8, 'front', name='crop'), ['add/signal'])]
+  as_dict = maybe(rng)
+  what.update(b=b, f=f, k=k, as_dict=as_dict)
+  def flat(out):
+    if not as_dict:
+      return out
+    # processors.py:124-134: {'signal': the last node's signal, 'controls': the DAG's outputs (per node: controls and signal)}
+    return {key: out['controls'][key]['signal'] for key in ('low', 'high', 'add', 'crop')} | {'signal': out['signal']}
+  return what, compare(what, lambda: flat(Rproc.ProcessorGroup(dag=dag(Rproc, Rsynths))(feats, return_outputs_dict=as_dict)),
+                       lambda: flat(M.processors.ProcessorGroup(dag=dag(M.processors, M.synths))(feats, return_outputs_dict=as_dict)), 2e-3)
+
+
+def case_synthesis(rng):
+  which = str(rng.choice(['harmonic_synthesis', 'oscillator_bank', 'harmonic_oscillator_bank', 'streaming']))
+  what = dict(case='synthesis', which=which)
+  b, f, k = int(rng.integers(1, 3)), int(rng.integers(2, 8)), int(rng.choice([1, 6, 20]))
+  sr = int(rng.choice([16000, 48000]))
+  if which == 'harmonic_synthesis':
+    hop = int(rng.choice([16, 50])); method = str(rng.choice(['window', 'linear', 'nearest', 'cubic']))
+    n = f * hop if method == 'window' or maybe(rng) else int(rng.integers(f, f * hop))
+    fr = rng.uniform(80, 900, (b, f, 1)).astype(np.float32); am = rng.uniform(0.1, 1, (b, f, 1)).astype(np.float32)
+    shifts = (0.01 * rng.standard_normal((b, f, k))).astype(np.float32) if maybe(rng, 0.4) else None
+    hd = rng.uniform(0, 1, (b, f, k)).astype(np.float32) if maybe(rng, 0.7) else None
+    kw = dict(harmonic_shifts=shifts, harmonic_distribution=hd, n_samples=n, sample_rate=sr, amp_resample_method=method,
+              use_angular_cumsum=maybe(rng, 0.3))
+    what.update(b=b, f=f, k=k, n=n, method=method, shifts=shifts is not None, distribution=hd is not None)
+    return what, compare(what, lambda: Rcore.harmonic_synthesis(fr, am, **kw), lambda: M.core.harmonic_synthesis(fr, am, **kw), 4e-3)
+  n = int(rng.integers(1, 600))
+  if which == 'oscillator_bank':
+    fr = rng.uniform(0, sr * 0.6, (b, n, k)).astype(np.float32); am = rng.standard_normal((b, n, k)).astype(np.float32)
+    kw = dict(sample_rate=sr, sum_sinusoids=maybe(rng), use_angular_cumsum=maybe(rng, 0.3))
+    what.update(b=b, n=n, k=k, **kw)
+    return what, compare(what, lambda: Rcore.oscillator_bank(fr, am, **kw), lambda: M.core.oscillator_bank(fr, am, **kw), 2e-3)
+  phase = rng.uniform(0, 6.0, (b, 1, 1)).astype(np.float32) if maybe(rng) else None
+  def wrapped(out):                                           # (audio, final_phase): the phase modulo a revolution
+    return out[0], np.mod(npy(out[1]) + 1e-4, 2 * np.pi)
+  if which == 'harmonic_oscillator_bank':
+    fr = rng.uniform(50, 500, (b, n, 1)).astype(np.float32); am = rng.uniform(0, 1, (b, n, k)).astype(np.float32)
+    kw = dict(initial_phase=phase, sample_rate=sr, use_angular_cumsum=maybe(rng, 0.7))
+    what.update(b=b, n=n, k=k, angular=kw['use_angular_cumsum'], phase=phase is not None)
+    return what, compare(what, lambda: wrapped(Rcore.harmonic_oscillator_bank(fr, am, **kw)), lambda: wrapped(M.core.harmonic_oscillator_bank(fr, am, **kw)), 2e-3)
+  method = str(rng.choice(['linear', 'window', 'nearest']))
+  n = f * int(rng.integers(2, 60)) if method == 'window' else n + f
+  fr = rng.uniform(80, 500, (b, f, 1)).astype(np.float32); am = rng.uniform(0.1, 1, (b, f, 1)).astype(np.float32)
+  hd = rng.uniform(0, 1, (b, f, k)).astype(np.float32) if maybe(rng, 0.7) else None
+  kw = dict(harmonic_distribution=hd, initial_phase=phase, n_samples=n, sample_rate=sr, amp_resample_method=method)
+  what.update(b=b, f=f, k=k, n=n, method=method, distribution=hd is not None, phase=phase is not None)
+  return what, compare(what, lambda: wrapped(Rcore.streaming_harmonic_synthesis(fr, am, **kw)), lambda: wrapped(M.core.streaming_harmonic_synthesis(fr, am, **kw)), 2e-3)
+
+
 CASES = dict(harmonic=case_harmonic, filtered_noise=case_filtered_noise, resample=case_resample,
              upsample_with_windows=case_upsample_with_windows, fft_convolve=case_fft_convolve, reverb=case_reverb,
-             small_core=case_small_core, spectral_loss=case_spectral_loss)
+             small_core=case_small_core, spectral_loss=case_spectral_loss, processors=case_processors, synthesis=case_synthesis)
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
