@@ -783,7 +783,8 @@ def fft_convolve_long(audio, impulse_response, delay=0, add_dry=False, mask_tap0
                                          ws.data_ptr(), ws.numel(), b, b_ir, n, l, n_out, int(delay),
                                          flags, _stream())
   if rc == -3:
-    raise NotImplementedError('the FFT convolution holds at most 65536 taps per row, got {}'.format(l))
+    raise NotImplementedError('the FFT convolution holds fewer than 2**28 taps per row and at most 65535 rows, got {} taps, '
+                              '{} rows'.format(l, b))
   _lib.check(rc, 'ddsp_fft_convolve_long_ex_f32')
   return out
 

@@ -464,6 +464,33 @@ __global__ __launch_bounds__(kRvMacThreads) void rv_mac_np_kernel(float4* __rest
   }
 }
 
+// More than sixteen partitions (impulse responses beyond 65 536 taps: gin/models/vst/vst_48k.gin's 72 000-tap FilteredNoiseReverb,
+// the dL/d ir correlation of any clip longer than that): no register window holds them.  W_j = sum_q Z_{j-q} H_q reads spectra
+// with indices <= j only, so IN PLACE still works if j runs DOWNWARDS - everything at or below j is untouched when W_j is formed.
+// Every term is fetched from memory (np reads per output where the windowed kernels make one: a bin slice of a row's spectra is
+// np x 16 bytes x nb per thread, re-read from L2); the plain form of the same sum, for the shapes the fast kernels do not take.
+template <bool ODD_ONLY>
+__global__ __launch_bounds__(kRvMacThreads) void rv_mac_desc_kernel(float4* __restrict__ xspec, const float4* __restrict__ hspec,
+                                                                    RvArgs p) {
+  const unsigned off = (blockIdx.x * kRvMacThreads + threadIdx.x) * 16u;
+  const int b = blockIdx.y;
+  const float4* __restrict__ hrow = hspec + (size_t)(p.ir_batch == 1 ? 0 : b) * p.np * (kRvN / 2);
+  float4* __restrict__ xrow = xspec + (size_t)b * p.nb * (kRvN / 2);
+  for (int j = p.nb - 1; j >= max(p.m_first, 0); --j) {
+    if (ODD_ONLY && (j & 1) == 0) continue;
+    float2 y0 = make_float2(0.f, 0.f), y1 = make_float2(0.f, 0.f);
+    const int nq = min(p.np, j + 1);
+    for (int q = 0; q < nq; ++q) {                                 // the same order of additions as rv_window_product: q upwards
+      const float4 x = rv_ld16(xrow + (size_t)(j - q) * (kRvN / 2), off);
+      const float4 h = rv_ld16(hrow + (size_t)q * (kRvN / 2), off);
+      const float2 a0 = cmul(make_float2(x.x, x.y), make_float2(h.x, h.y));
+      const float2 a1 = cmul(make_float2(x.z, x.w), make_float2(h.z, h.w));
+      y0.x += a0.x; y0.y += a0.y; y1.x += a1.x; y1.y += a1.y;
+    }
+    rv_st16(xrow + (size_t)j * (kRvN / 2), off, make_float4(y0.x, y0.y, y1.x, y1.y));
+  }
+}
+
 // number of Z spectra: two output blocks each, so the block count rounded up to even
 static inline int rv_blocks(int N, int delay) { return (((N + delay + kRvP - 1) / kRvP) + 1) & ~1; }
 static inline int rv_parts(int L) { return (L + kRvP - 1) / kRvP; }
@@ -489,7 +516,7 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
   if (!audio || !impulse_response || !out || !workspace) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || L <= 0 || n_out <= 0 || delay < 0 || (Bir != B && Bir != 1)) return DDSP_ERR_BAD_SHAPE;
   if ((flags & DDSP_CONV_ADD_DRY) && n_out != N) return DDSP_ERR_BAD_SHAPE;
-  if (B > 65535 || rv_parts(L) > kRvMaxParts) return DDSP_ERR_UNSUPPORTED;
+  if (B > 65535 || (long)L >= (1L << 28)) return DDSP_ERR_UNSUPPORTED;             // (any number of partitions: rv_mac_desc_kernel beyond sixteen)
   if (workspace_bytes < ddsp_fft_convolve_long_ex_workspace_bytes(B, Bir, N, L, n_out, delay) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15))
     return DDSP_ERR_WORKSPACE;
@@ -541,7 +568,9 @@ extern "C" int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* im
     if (p.np <= 4) DDSP_RV_MAC(4);
     else if (p.np <= 8) DDSP_RV_MAC(8);
     else if (p.np <= 12) DDSP_RV_MAC(12);
-    else hipLaunchKernelGGL(rv_mac_kernel, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);      // (13 .. 16 partitions: the window of sixteen by moves, 138 registers)
+    else if (p.np <= kRvMaxParts) hipLaunchKernelGGL(rv_mac_kernel, grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);      // (13 .. 16 partitions: the window of sixteen by moves, 138 registers)
+    else if (pair_mode) hipLaunchKernelGGL((rv_mac_desc_kernel<false>), grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
+    else hipLaunchKernelGGL((rv_mac_desc_kernel<true>), grid, block, 0, st, (float4*)xspec, (const float4*)hspec, p);
 #undef DDSP_RV_MAC
   }
   {

@@ -273,7 +273,8 @@ int ddsp_fft_convolve_same_f32(const float* audio, const float* impulse_response
  * (Reverb passes delay_compensation=0).  ir [Bir,L], Bir == B or 1 (tiled over the batch,
  * effects.py:62-69 / core.py:1433-1434).  DDSP_CONV_MASK_TAP0 zeroes tap 0 as
  * Reverb._mask_dry_ir does (effects.py:50-60).  Evaluated as a partitioned overlap-save FFT
- * convolution with LDS-resident 8192-point FFTs; L <= 65536 else DDSP_ERR_UNSUPPORTED.
+ * convolution with LDS-resident 8192-point FFTs; any L < 2^28 (up to 16 partitions of 4096 taps stay in a
+ * register window of the multiply-add pass; beyond - vst_48k.gin's 72 000 taps - a plain pass re-reads them).
  * workspace: ddsp_fft_convolve_long_workspace_bytes(...) bytes, 16-byte aligned.
  */
 #define DDSP_CONV_ADD_DRY 1u
@@ -292,7 +293,7 @@ int ddsp_fft_convolve_long_f32(const float* audio, const float* impulse_response
  *   dL/d audio = reverse( conv(reverse(g), ir)[0:N] )           (REVERSE_AUDIO | REVERSE_OUT)
  *   dL/d ir[k] = conv(g, reverse(audio))[N-1+k], k < L          (REVERSE_IR on the audio passed as "ir",
  *                                                                 n_out = L, delay = N-1)
- * The "impulse response" of a call may be up to 65536 samples long.  ADD_DRY needs n_out == N. */
+ * The "impulse response" of a call may be any length below 2^28.  ADD_DRY needs n_out == N. */
 size_t ddsp_fft_convolve_long_ex_workspace_bytes(int B, int Bir, int N, int L, int n_out, int delay);
 int ddsp_fft_convolve_long_ex_f32(const float* audio, const float* impulse_response, float* out,
                                   void* workspace, size_t workspace_bytes, int B, int Bir, int N,

@@ -786,7 +786,7 @@ def test_reverb_golden(ddsp, name):
     (3, 64000, 48000, 1, False),       # a trainable Reverb's single IR
     (1, 4096, 4096, 1, True),          # exactly one block / one partition
     (2, 4097, 4097, 2, False),         # one sample past the block / partition edge
-    (2, 1000, 65536, 2, True),         # the longest supported IR, much longer than the audio
+    (2, 1000, 65536, 2, True),         # 16 partitions (the register window's limit), much longer than the audio
     (1, 20001, 5, 1, False),           # a tiny IR, ragged length (scalar load path)
     (2, 40000, 30000, 2, True)])       # 8 partitions, 10 spectra per row: the multiply-add pass's straight-line passes of eight
 def test_reverb_vs_fp64_convolution(ddsp, batch, n, l, ir_batch, add_dry):
@@ -811,7 +811,7 @@ def test_reverb_vs_fp64_convolution(ddsp, batch, n, l, ir_batch, add_dry):
     (2, 20000, 13000),        # 4 partitions of 4096 taps: a ring of four
     (5, 9000, 20000),         # 5 partitions (ring of eight), an odd batch: the last row pair holds one row
     (4, 30001, 48000),        # 12 partitions - the default reverb_length -, a length that is not a multiple of four
-    (3, 5000, 65536),         # 16 partitions: the longest supported response (one row pair per block)
+    (3, 5000, 65536),         # 16 partitions: the longest response of the windowed kernels (one row pair per block)
     (2, 64000, 12289),        # one tap past three partitions
     (3, 40000, 30000)])       # 8 partitions, 10 spectra: a straight-line pass of eight, then the tested form for two
 def test_reverb_one_impulse_response_for_the_batch_row_pairs(ddsp, batch, n, l):
@@ -850,6 +850,40 @@ def test_reverb_one_impulse_response_for_the_batch_row_pairs(ddsp, batch, n, l):
   got = npy(ddsp.core.fft_convolve_long(audio, ir, delay=delay, n_out=n_out))
   full = np.stack([scipy.signal.fftconvolve(audio[b].astype(np.float64), ir[0].astype(np.float64)) for b in range(batch)])
   np.testing.assert_allclose(got, full[:, delay:delay + n_out], rtol=0, atol=reverb_tol(full))
+
+
+@pytest.mark.parametrize('batch,n,l,ir_batch,backward', [
+    (2, 3000, 72000, 1, False),      # gin/models/vst/vst_48k.gin:88: a 72 000-tap reverb - 18 partitions, one IR for the batch (row pairs)
+    (2, 5000, 70000, 2, False),      # ... an IR per row (two blocks of a row per spectrum: W_m for odd m)
+    (3, 70000, 600, 1, True),        # dL/d ir of a clip of 70 000 samples: the AUDIO is the 18-partition operand of the correlation
+])
+def test_reverb_beyond_sixteen_partitions(ddsp, batch, n, l, ir_batch, backward):
+  """Impulse responses of more than 65 536 taps (effects.FilteredNoiseReverb of vst_48k.gin has 72 000) and the backward pass of
+  clips longer than that raised NotImplementedError until the end of round 5: the multiply-add pass kept its partitions in a
+  register window of sixteen.  rv_mac_desc_kernel forms W_j in place from j = last downwards, any number of partitions."""
+  import scipy.signal
+  rng = np.random.default_rng(l)
+  x = rng.standard_normal((batch, n)).astype(np.float32)
+  h = (rng.standard_normal((ir_batch, l)) * np.exp(-np.arange(l) / (0.3 * l))).astype(np.float32)
+  hm = h.astype(np.float64).copy(); hm[:, 0] = 0.0
+  ref = np.stack([scipy.signal.fftconvolve(x[i].astype(np.float64), hm[i % ir_batch])[:n] for i in range(batch)]) + x
+  rev = ddsp.effects.Reverb(add_dry=True)
+  if not backward:
+    np.testing.assert_allclose(npy(rev(x, h)), ref, rtol=0, atol=reverb_tol(ref))
+    return
+  g = rng.standard_normal((batch, n)).astype(np.float32)
+  tx = ddsp.core.tf_float32(x).requires_grad_(True)
+  th = ddsp.core.tf_float32(h).requires_grad_(True)
+  out = rev(tx, th)
+  out.backward(ddsp.core.tf_float32(g))
+  np.testing.assert_allclose(npy(out), ref, rtol=0, atol=reverb_tol(ref))
+  dx = np.stack([scipy.signal.fftconvolve(g[i].astype(np.float64)[::-1], hm[i % ir_batch])[:n][::-1] for i in range(batch)]) + g
+  dh = np.stack([scipy.signal.fftconvolve(g[i].astype(np.float64), x[i].astype(np.float64)[::-1])[n - 1:n - 1 + l] for i in range(batch)])
+  dh[:, 0] = 0.0
+  if ir_batch == 1:
+    dh = dh.sum(0, keepdims=True)
+  np.testing.assert_allclose(npy(tx.grad), dx, rtol=0, atol=reverb_tol(dx))
+  np.testing.assert_allclose(npy(th.grad).reshape(dh.shape), dh, rtol=0, atol=1e-6 + 1e-5 * max(np.abs(dh).max(), np.sqrt(n)))
 
 
 def test_reverb_properties_full_size_batch32(ddsp):
