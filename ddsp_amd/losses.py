@@ -112,7 +112,8 @@ class SpectralLoss(Loss):
     for z, size in enumerate(self.fft_sizes):
       size = int(size)
       if size < 16 or size > 4096 or size & (size - 1):
-        raise ValueError('fft_sizes must be powers of two in [16, 4096], got {}'.format(tuple(self.fft_sizes)))
+        raise ValueError('fft_sizes must be powers of two in [16, 4096] on the MI355X path (vst_48k.gin\'s 3 * 2**k sizes '
+                         'need a radix-3 pass that is not built), got {}'.format(tuple(self.fft_sizes)))
       frames, bins = -(-n // (size // 4)), size // 2 + 1
       wb = wf = wk = 0
       if weights is not None:
