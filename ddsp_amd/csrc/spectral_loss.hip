@@ -722,6 +722,142 @@ __global__ __launch_bounds__(kSlThreads) void stft_cot_bwd_kernel(const float* _
                              (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
+// =====================================================================================================================
+// Frame sizes 3 * 2^k (gin/models/vst/vst_48k.gin:56 asks for 6144, 3072, .. 192).  spectral_ops.stft (spectral_ops.py:34-47)
+// calls tf.signal.stft with fft_length=None: frames of F samples every F / 4, a periodic Hann window of F points - and an FFT of
+// the ENCLOSING POWER OF TWO S = 4 F / 3, the frame zero-padded to it: S / 2 + 1 bins.  So no radix-3 pass is needed; what
+// differs from the kernels above is the frame (length, hop, window) under the same power-of-two transform.  Plain kernels for
+// the general form of the loss (ddsp_stft_mag_f32 / ddsp_stft_mag_backward_f32 + csrc/spectral_terms.hip): one signal per
+// block (the largest size - 6144 samples under an 8192-point transform - fills a block's 4096 complex points with ONE frame),
+// a load pass of its own, every output sample through an atomic.
+// =====================================================================================================================
+// frames [f0, f0 + n_fr) of `row`, F = 3 S / 4 samples each, hop F / 4, windowed, zero-padded to S: element e of frame g is the
+// sample pair (2 e, 2 e + 1)
+template <int S>
+__device__ __forceinline__ void tq_load_frames(float2* s, const float* __restrict__ row, int tid, int f0, int n_fr,
+                                               int n_frames, int N) {
+  constexpr int H = S / 2, LOG2H = __builtin_ctz(H), F = 3 * S / 4, HOP = F / 4;
+  for (int it = tid; it < n_fr * H; it += kSlThreads) {
+    const int g = it >> LOG2H, e = it & (H - 1);
+    float x0 = 0.0f, x1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+    if (f0 + g < n_frames && 2 * e < F) {                        // (F is even: a pair is inside the frame or outside)
+      const long i = (long)(f0 + g) * HOP + 2 * e;
+      if (i < N) x0 = row[i];
+      if (i + 1 < N) x1 = row[i + 1];
+      // tf.signal.hann_window(F), periodic: 0.5 - 0.5 cos(2 pi i / F)
+      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e) * (1.0f / (float)F));
+      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e + 1) * (1.0f / (float)F));
+    }
+    s[SP(it)] = make_float2(x0 * w0, x1 * w1);
+  }
+}
+
+// |STFT| of ONE signal (blockIdx.z: 0 target, 1 audio): [B, frames, S / 2 + 1]
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_tq_mag_kernel(const float* __restrict__ target, const float* __restrict__ audio,
+                                                                 float* __restrict__ mag_t, float* __restrict__ mag_a, int N,
+                                                                 int n_frames) {
+  constexpr int H = S / 2, G = kSlPoints / H;
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * G;
+  const float* __restrict__ row = (blockIdx.z ? audio : target) + (size_t)b * N;
+  float* __restrict__ mag = blockIdx.z ? mag_a : mag_t;
+  tq_load_frames<S>(s, row, tid, f0, G, n_frames, N);
+  __syncthreads();
+  sl_forward<H>(s, tid, G, 0);
+  __syncthreads();
+  for (int e = tid; e < G * (H + 1); e += kSlThreads) {
+    const int g = e / (H + 1), k = e - g * (H + 1);
+    if (f0 + g >= n_frames) continue;
+    const int ia = sl_pos<H>(k & (H - 1)), ib = sl_pos<H>((H - k) & (H - 1));
+    const float rev = (float)k * (1.0f / (float)S);
+    const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+    const float2 za = s[SP(g * H + ia)], zb = s[SP(g * H + ib)];
+    const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
+    const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
+    const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
+    mag[((size_t)b * n_frames + f0 + g) * (H + 1) + k] = sl_sqrt(fmaf(xr, xr, xi * xi));
+  }
+}
+
+// dL/d audio from dL/d |STFT(audio)| (`cot` [B, frames, S / 2 + 1]); stft_l1_bwd_block's arithmetic on frames of 3 S / 4 samples
+template <int S>
+__global__ __launch_bounds__(kSlThreads) void stft_tq_cot_bwd_kernel(const float* __restrict__ audio, float* __restrict__ grad_audio,
+                                                                     int N, int n_frames, const float* __restrict__ cot) {
+  constexpr int H = S / 2, G = kSlPoints / H, F = 3 * S / 4, HOP = F / 4;
+  __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int f0 = blockIdx.x * G;
+  tq_load_frames<S>(s, audio + (size_t)b * N, tid, f0, G, n_frames, N);
+  __syncthreads();
+  sl_forward<H>(s, tid, G, 0);
+  __syncthreads();
+  for (int e = tid; e < G * (H / 2 + 1); e += kSlThreads) {      // pairs of bins (k, H - k), k = 0 .. H / 2
+    const int g = e / (H / 2 + 1), k = e - g * (H / 2 + 1);
+    if (f0 + g >= n_frames) continue;
+    const int pa = g * H + sl_pos<H>(k), pb = g * H + sl_pos<H>((H - k) & (H - 1));
+    const float rev = (float)k * (1.0f / (float)S);
+    const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+    const float2 za = s[SP(pa)], zb = s[SP(pb)];
+    const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);
+    const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);
+    const float wx = fmaf(ox, c, oy * sn), wy = fmaf(oy, c, -ox * sn);       // W^k O
+    const float2 x1 = make_float2(ex + wx, ey + wy);                          // X[k]   = E + W^k O
+    const float2 x2 = make_float2(ex - wx, -(ey - wy));                       // X[H-k] = conj(E - W^k O)
+    const float* __restrict__ crow = cot + ((size_t)b * n_frames + f0 + g) * (H + 1);
+    auto bin_grad = [&](float2 xa, int bin) {                                 // dL/dX: cot * X / |X| (0 at X = 0: tf.abs)
+      const float ma = sl_sqrt(fmaf(xa.x, xa.x, xa.y * xa.y));
+      if (!(ma > 0.0f)) return make_float2(0.f, 0.f);
+      const float coef = crow[bin] * __builtin_amdgcn_rcpf(ma);
+      return make_float2(coef * xa.x, coef * xa.y);
+    };
+    float2 c1 = bin_grad(x1, k), c2 = bin_grad(x2, H - k);
+    if (k == 0) {                                               // bins 0 and S/2: real, C = Re G
+      const float e0 = 0.5f * (c1.x + c2.x), o0 = 0.5f * (c1.x - c2.x);
+      s[SP(pa)] = make_float2(e0, o0);
+    } else {
+      if (2 * k == H) c2 = c1;                                  // the self-paired bin S/4
+      c1 = make_float2(0.5f * c1.x, 0.5f * c1.y);
+      c2 = make_float2(0.5f * c2.x, 0.5f * c2.y);
+      const float gx = 0.5f * (c1.x + c2.x), gy = 0.5f * (c1.y - c2.y);
+      const float dx = 0.5f * (c1.x - c2.x), dy = 0.5f * (c1.y + c2.y);
+      const float qx = fmaf(dx, c, -dy * sn), qy = fmaf(dx, sn, dy * c);      // D * (c + i sn)
+      s[SP(pa)] = make_float2(gx - qy, gy + qx);
+      if (2 * k != H) s[SP(pb)] = make_float2(gx + qy, qx - gy);
+    }
+  }
+  __syncthreads();
+  sl_inverse<H>(s, tid, G, 0);
+  __syncthreads();
+  // window and overlap-add: g_x[2 e] = 2 Re U[e], g_x[2 e + 1] = 2 Im U[e] for the frame's first F samples (the zero padding
+  // has no gradient); a sample meets up to four of the block's frames (hop F / 4)
+  float* __restrict__ grow = grad_audio + (size_t)b * N;
+  for (int pidx = tid; pidx < (G + 3) * HOP; pidx += kSlThreads) {
+    const long n = (long)f0 * HOP + pidx;
+    if (n >= N) continue;
+    const int gp = pidx / HOP, ir = pidx - gp * HOP;
+    float acc = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int g = gp - jj, i = ir + jj * HOP;                 // frame g covers the sample at its index i < F
+      if (g >= 0 && g < G && f0 + g < n_frames) {
+        const float2 u = s[SP(g * H + (i >> 1))];
+        const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)F));
+        acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
+      }
+    }
+    unsafeAtomicAdd(&grow[n], acc);
+  }
+}
+
+// a frame size 3 * 2^k in [48, 6144] -> its FFT length 2^(k+2), or 0
+static inline int sl_tq_fft_size(int F) {
+  if (F < 48 || F > 6144 || F % 3 != 0) return 0;
+  const int p = F / 3;
+  return (p & (p - 1)) == 0 ? 4 * p : 0;
+}
+
 struct SlFinishArgs {
   int n_sizes;
   int offset[16];          // first partial pair of each size
@@ -927,8 +1063,22 @@ extern "C" int ddsp_stft_mag_f32(const float* target_audio, const float* audio, 
                                  int N, int fft_size, void* stream) {
   if (!target_audio || !audio || !target_mag || !mag) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0) return DDSP_ERR_BAD_SHAPE;
-  if (!sl_size_ok(fft_size) || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  if (B > 65535) return DDSP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (const int S3 = sl_tq_fft_size(fft_size)) {                // frames of 3 * 2^k samples under a transform of 2^(k+2)
+    const int frames3 = sl_frames(N, fft_size), g3 = 2 * kSlPoints / S3;       // (sl_frames: ceil(N / (F / 4)))
+    const dim3 grid3((unsigned)((frames3 + g3 - 1) / g3), (unsigned)B, 2u);
+#define DDSP_SM3_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_mag_kernel<SZ>), grid3, dim3(kSlThreads), 0, st, \
+                                                      target_audio, audio, target_mag, mag, N, frames3); break
+    switch (S3) {
+      DDSP_SM3_CASE(64); DDSP_SM3_CASE(128); DDSP_SM3_CASE(256); DDSP_SM3_CASE(512); DDSP_SM3_CASE(1024);
+      DDSP_SM3_CASE(2048); DDSP_SM3_CASE(4096); DDSP_SM3_CASE(8192);
+      default: return DDSP_ERR_UNSUPPORTED;
+    }
+#undef DDSP_SM3_CASE
+    return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+  }
+  if (!sl_size_ok(fft_size)) return DDSP_ERR_UNSUPPORTED;
   const int S = fft_size, frames = sl_frames(N, S), blocks = sl_blocks(N, S);
   const dim3 grid((unsigned)blocks, (unsigned)B);
 #define DDSP_SM_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_mag_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \
@@ -946,8 +1096,22 @@ extern "C" int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_
                                           int fft_size, void* stream) {
   if (!audio || !grad_mag || !grad_audio) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0) return DDSP_ERR_BAD_SHAPE;
-  if (!sl_size_ok(fft_size) || B > 65535) return DDSP_ERR_UNSUPPORTED;
+  if (B > 65535) return DDSP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (const int S3 = sl_tq_fft_size(fft_size)) {
+    const int frames3 = sl_frames(N, fft_size), g3 = 2 * kSlPoints / S3;
+    const dim3 grid3((unsigned)((frames3 + g3 - 1) / g3), (unsigned)B);
+#define DDSP_SMB3_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_cot_bwd_kernel<SZ>), grid3, dim3(kSlThreads), 0, st, \
+                                                       audio, grad_audio, N, frames3, grad_mag); break
+    switch (S3) {
+      DDSP_SMB3_CASE(64); DDSP_SMB3_CASE(128); DDSP_SMB3_CASE(256); DDSP_SMB3_CASE(512); DDSP_SMB3_CASE(1024);
+      DDSP_SMB3_CASE(2048); DDSP_SMB3_CASE(4096); DDSP_SMB3_CASE(8192);
+      default: return DDSP_ERR_UNSUPPORTED;
+    }
+#undef DDSP_SMB3_CASE
+    return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+  }
+  if (!sl_size_ok(fft_size)) return DDSP_ERR_UNSUPPORTED;
   const int S = fft_size, frames = sl_frames(N, S), blocks = sl_blocks(N, S);
   const dim3 grid((unsigned)blocks, (unsigned)B);
 #define DDSP_SMB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_cot_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, \

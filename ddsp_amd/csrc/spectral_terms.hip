@@ -20,7 +20,7 @@ namespace ddsp {
 
 constexpr int kStTerms = 5;            // mag, delta_time, delta_freq, cumsum_freq, logmag
 constexpr int kStRowsPerBlock = 4;     // one wavefront per row
-constexpr int kStMaxBins = 2049;       // fft size <= 4096
+constexpr int kStMaxBins = 4097;       // fft size <= 8192 (frames of 6144 samples: vst_48k.gin)
 
 struct SpecTermArgs {
   int B, FR, NB;
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(64 * kStRowsPerBlock) void spec_terms_grad_kernel(c
                                                                              const float* __restrict__ wts,
                                                                              const double* __restrict__ coef,
                                                                              float* __restrict__ cot, SpecTermArgs p) {
-  __shared__ float s_g[kStRowsPerBlock][kStMaxBins + 63];
+  extern __shared__ __attribute__((aligned(16))) float s_g_all[];           // [kStRowsPerBlock][NB + 63]: sized by the launch
+  float* const s_g_row = s_g_all + (size_t)(threadIdx.x >> 6) * (p.NB + 63);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long rows = (long)p.B * p.FR;
   const long row_raw = (long)blockIdx.x * kStRowsPerBlock + wv;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * kStRowsPerBlock) void spec_terms_grad_kernel(c
       const float ct = st_scan_up(t, lane) + carry_t, cv = st_scan_up(v, lane) + carry_v;
       carry_t = __shfl(ct, 63);
       carry_v = __shfl(cv, 63);
-      s_g[wv][k] = in ? st_g(lt, ct, cv, st_weight(wts, p, b, f, k), w_row) : 0.0f;
+      s_g_row[k] = in ? st_g(lt, ct, cv, st_weight(wts, p, b, f, k), w_row) : 0.0f;
     }
   }
   __syncthreads();
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * kStRowsPerBlock) void spec_terms_grad_kernel(c
     const bool in = k < p.NB;
     float g_total = 0.0f;
     if (c_cs != 0.0f) {
-      const float sfx = st_scan_down(in ? s_g[wv][k] : 0.0f, lane) + carry_s;       // sum over k' >= k
+      const float sfx = st_scan_down(in ? s_g_row[k] : 0.0f, lane) + carry_s;       // sum over k' >= k
       carry_s = __shfl(sfx, 0);
       g_total = c_cs * sfx;
     }
@@ -272,8 +273,12 @@ extern "C" int ddsp_spectral_terms_f32(const float* target_mag, const float* val
   hipLaunchKernelGGL(spec_terms_kernel, dim3(blocks), dim3(64 * kStRowsPerBlock), 0, st, target_mag, value_mag, weights, partial, p);
   hipLaunchKernelGGL(spec_terms_finish_kernel, dim3(1), dim3(1024), 0, st, (const double*)partial, loss_accumulator, coef, loss, p,
                      first ? 1 : 0);
-  if (grad_value_mag)
-    hipLaunchKernelGGL(spec_terms_grad_kernel, dim3(blocks), dim3(64 * kStRowsPerBlock), 0, st, target_mag, value_mag, weights,
+  if (grad_value_mag) {
+    const size_t lds = (size_t)kStRowsPerBlock * (bins + 63) * sizeof(float);
+    if (lds > 48 * 1024)      // (per launch: the attribute belongs to the current device's copy of the kernel)
+      (void)hipFuncSetAttribute((const void*)spec_terms_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024);
+    hipLaunchKernelGGL(spec_terms_grad_kernel, dim3(blocks), dim3(64 * kStRowsPerBlock), lds, st, target_mag, value_mag, weights,
                        (const double*)coef, grad_value_mag, p);
+  }
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

@@ -74,7 +74,8 @@ class SpectralLoss(Loss):
       raise ValueError('target_audio and audio must both be [batch, n_samples], got {} and {}'.format(
           tuple(target_audio.shape), tuple(audio.shape)))
     general = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
-               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0)
+               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or
+               any(int(v) & (int(v) - 1) for v in self.fft_sizes))         # frames of 3 * 2**k samples (vst_48k.gin): the plain kernels
     if general:
       weights = self._weights_tensor(weights, audio.device)
       if torch.is_grad_enabled() and audio.requires_grad:
@@ -111,10 +112,13 @@ class SpectralLoss(Loss):
       return loss, grad_audio
     for z, size in enumerate(self.fft_sizes):
       size = int(size)
-      if size < 16 or size > 4096 or size & (size - 1):
-        raise ValueError('fft_sizes must be powers of two in [16, 4096] on the MI355X path (vst_48k.gin\'s 3 * 2**k sizes '
-                         'need a radix-3 pass that is not built), got {}'.format(tuple(self.fft_sizes)))
-      frames, bins = -(-n // (size // 4)), size // 2 + 1
+      pow2 = 16 <= size <= 4096 and not size & (size - 1)
+      tri = 48 <= size <= 6144 and size % 3 == 0 and not (size // 3) & (size // 3 - 1)
+      if not (pow2 or tri):
+        raise ValueError('fft_sizes must be powers of two in [16, 4096] or 3 * 2**k in [48, 6144] (vst_48k.gin) on the MI355X '
+                         'path, got {}'.format(tuple(self.fft_sizes)))
+      # spectral_ops.stft (spectral_ops.py:40-45): tf.signal.stft with fft_length=None transforms the ENCLOSING power of two
+      frames, bins = -(-n // (size // 4)), (size if pow2 else 4 * size // 3) // 2 + 1
       wb = wf = wk = 0
       if weights is not None:
         wb, wf, wk = (int(v) for v in weights.shape)

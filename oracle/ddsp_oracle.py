@@ -877,9 +877,12 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
       coef = coef - logmag_weight * np.sign(safe_log(mt) - safe_log(ma)) * np.where(
           ma > 0.0, 1.0 / np.where(ma > 0.0, ma, 1.0), 0.0)
     g_bins = (coef / count) * np.where(ma > 0.0, za / np.where(ma > 0.0, ma, 1.0), 0.0)
-    full = np.zeros(za.shape[:-1] + (size,), complex)
-    full[..., :size // 2 + 1] = g_bins
-    g_frames = np.real(np.fft.ifft(full, axis=-1) * size) * hann_window_periodic(size, np.float64)
+    # (the transform has the enclosing power of two as its length - stft() above -: the frame's gradient is the first `size`
+    #  samples of the adjoint, the zero padding has none)
+    fft_length = 2 * (za.shape[-1] - 1)
+    full = np.zeros(za.shape[:-1] + (fft_length,), complex)
+    full[..., :fft_length // 2 + 1] = g_bins
+    g_frames = np.real(np.fft.ifft(full, axis=-1) * fft_length)[..., :size] * hann_window_periodic(size, np.float64)
     n_frames = g_frames.shape[1]
     padded = np.zeros((b, (n_frames - 1) * hop + size))
     for f in range(n_frames):

@@ -1006,6 +1006,38 @@ def test_spectral_loss_every_term_golden_and_gradient(ddsp):
     ddsp.losses.SpectralLoss(loss_type='L3')(t, a)
 
 
+@pytest.mark.parametrize('batch,n,sizes,kw', [
+    (2, 1000, (48, 96), dict(mag_weight=1.0, logmag_weight=1.0)),
+    (1, 9000, (1536, 3072, 192), dict(mag_weight=1.0, logmag_weight=0.5)),
+    (2, 13000, (6144, 384, 256), dict(mag_weight=1.0, logmag_weight=1.0)),                 # the largest: one frame per block; mixed with 2^k
+    (2, 3000, (768, 192), dict(loss_type='L2', mag_weight=1.0, delta_time_weight=1.0, delta_freq_weight=1.0, cumsum_freq_weight=1.0)),
+    (2, 3000, (384,), dict(loss_type='COSINE', mag_weight=1.0, logmag_weight=1.0)),
+])
+def test_spectral_loss_with_frames_of_three_times_a_power_of_two(ddsp, batch, n, sizes, kw):
+  """gin/models/vst/vst_48k.gin:56: fft_sizes = [6144, 3072, 1536, 768, 384, 192].  spectral_ops.stft (spectral_ops.py:34-47) hands
+  tf.signal.stft fft_length=None: frames of F samples every F / 4 under a Hann window of F points, zero-padded to the enclosing
+  power of two - 2 F / 3 + 1 bins.  stft_tq_mag_kernel / stft_tq_cot_bwd_kernel (the loss's general form); value against the
+  fp64 oracle, the 'L1' gradient against its analytic one (distribution check: sign flips, see the 2^k test below)."""
+  rng = np.random.default_rng(n)
+  t = (0.3 * rng.standard_normal((batch, n))).astype(np.float32)
+  a = (0.8 * t + 0.05 * rng.standard_normal((batch, n))).astype(np.float32)
+  loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, **kw)
+  ta = ddsp.core.tf_float32(a).requires_grad_(True)
+  val = loss(t, ta)
+  val.backward()
+  ref = float(O.spectral_loss(t, a, sizes, dtype=np.float64, **kw))
+  np.testing.assert_allclose(float(val.detach()), ref, rtol=5e-5)
+  np.testing.assert_allclose(float(loss(t, a)), ref, rtol=5e-5)
+  assert bool(torch.isfinite(ta.grad).all()) and float(ta.grad.abs().max()) > 0
+  if kw.get('loss_type', 'L1') == 'L1':
+    gref = O.spectral_loss_backward(t, a, sizes, kw['mag_weight'], kw['logmag_weight'])
+    err = np.abs(npy(ta.grad) - gref)
+    atol = 1e-9 + 2e-4 * np.abs(gref).max()
+    assert np.median(err) <= 0.2 * atol and np.quantile(err, 0.9) <= atol, (float(np.median(err)), float(np.quantile(err, 0.9)), atol)
+  with pytest.raises(ValueError, match='fft_sizes'):
+    ddsp.losses.SpectralLoss(fft_sizes=(100,))(t, a)
+
+
 def test_spectral_loss_degenerate_arguments_follow_the_reference(ddsp):
   """What tools/fuzz_api_vs_reference.py found the mirror doing differently from the reference's own code:
   a loss type that does not exist raises when losses.mean_difference is CALLED (losses.py:102-128) - a loss whose every weight

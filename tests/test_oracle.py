@@ -345,6 +345,23 @@ def test_spectral_loss_backward_matches_finite_differences():
     np.testing.assert_allclose(g[idx], fd, rtol=1e-4, atol=1e-9)
 
 
+def test_spectral_loss_backward_with_frames_that_are_not_powers_of_two():
+  """gin/models/vst/vst_48k.gin:56 asks for frames of 6144, 3072, .. 192 samples: tf.signal.stft (fft_length=None) transforms the
+  ENCLOSING power of two - 3 * 2^k samples zero-padded to 2^(k+2), 2^(k+1) + 1 bins.  The gradient restatement took the frame
+  size for the transform's length until round 5 (it had only ever met powers of two); against central differences."""
+  rng = np.random.default_rng(3)
+  t = 0.3 * rng.standard_normal((2, 400))
+  a = t * 0.8 + 0.05 * rng.standard_normal((2, 400))
+  assert O.stft(a, 48).shape == (2, -(-400 // 12), 33) and O.stft(a, 192).shape[-1] == 129
+  kw = dict(fft_sizes=(192, 48, 64), mag_weight=1.0, logmag_weight=0.7)
+  g = O.spectral_loss_backward(t, a, **kw)
+  eps = 1e-6
+  for idx in [(0, 0), (0, 201), (1, 399), (1, 47), (0, 350)]:
+    d = np.zeros_like(a); d[idx] = eps
+    fd = (O.spectral_loss(t, a + d, dtype=np.float64, **kw) - O.spectral_loss(t, a - d, dtype=np.float64, **kw)) / (2 * eps)
+    np.testing.assert_allclose(g[idx], fd, rtol=1e-4, atol=1e-9)
+
+
 @pytest.mark.parametrize('method', ['window', 'linear'])
 def test_harmonic_backward_f0_matches_finite_differences(method):
   rng = np.random.default_rng(13)

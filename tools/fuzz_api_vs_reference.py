@@ -263,7 +263,7 @@ def case_small_core(rng):
 
 def case_spectral_loss(rng):
   b, n = int(rng.integers(1, 3)), int(rng.choice([64, 500, 1500]))
-  sizes = tuple(int(s) for s in rng.permutation([1024, 512, 256, 128, 64])[:int(rng.integers(1, 4))])
+  sizes = tuple(int(s) for s in rng.permutation([1024, 512, 256, 128, 64, 768, 384, 192, 96, 48])[:int(rng.integers(1, 4))])
   kw = dict(fft_sizes=sizes, loss_type=str(rng.choice(['L1', 'L1', 'L2', 'COSINE', 'L3'])),
             mag_weight=float(rng.choice([1.0, 0.0])), logmag_weight=float(rng.choice([0.0, 1.0])),
             delta_time_weight=float(rng.choice([0.0, 0.0, 1.0])), delta_freq_weight=float(rng.choice([0.0, 0.0, 1.0])),

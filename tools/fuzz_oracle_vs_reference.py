@@ -154,7 +154,7 @@ def case_reverb(rng):
 
 def case_loss(rng):
   b, n = int(rng.integers(1, 4)), int(rng.choice([64, 500, 3000, int(rng.integers(64, 5000))]))
-  all_sizes = [2048, 1024, 512, 256, 128, 64]
+  all_sizes = [2048, 1024, 512, 256, 128, 64, 1536, 768, 384, 192, 96, 48]     # (3 * 2**k: vst_48k.gin's kind)
   sizes = tuple(int(s) for s in rng.permutation(all_sizes)[:int(rng.integers(1, 5))])
   kw = dict(mag_weight=float(rng.choice([1.0, 0.0, 0.5])), logmag_weight=float(rng.choice([1.0, 0.0, 0.5])),
             delta_time_weight=float(rng.choice([0.0, 0.0, 1.0])), delta_freq_weight=float(rng.choice([0.0, 0.0, 1.0])),

@@ -237,7 +237,7 @@ def case_reverb(rng):
 def case_loss(rng):
   b = int(rng.integers(1, 10))
   n = int(rng.choice([17, 64, 100, 1023, 1024, 1025, 3000, 12345, 20000, int(rng.integers(16, 30000))]))
-  all_sizes = [4096, 2048, 1024, 512, 256, 128, 64, 32, 16]
+  all_sizes = [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 6144, 3072, 1536, 768, 384, 192, 96, 48]   # (3 * 2**k: vst_48k.gin's kind)
   sizes = tuple(int(s) for s in rng.permutation(all_sizes)[:int(rng.integers(1, 7))])
   mw, lw = float(rng.choice([1.0, 0.0, 0.5])), float(rng.choice([1.0, 0.0, 0.5]))
   if mw == 0.0 and lw == 0.0:
