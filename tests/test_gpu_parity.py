@@ -1599,6 +1599,39 @@ def test_vst_dag_with_trainable_filtered_noise_reverb_trains(ddsp):   # gin/mode
     assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
 
 
+def test_vst_48k_configuration_full_size(ddsp):                     # gin/models/vst/vst_48k.gin:14-17, 50-112
+  """The one shipped configuration beyond the others' limits until the end of round 5: 48 kHz, clips of 192 960 samples on 201
+  frames (hop 960), 'linear' envelopes with the angular cumsum, a trainable FilteredNoiseReverb of 72 000 taps (18 partitions of
+  the FFT convolution) and a SpectralLoss on frames of 6144 .. 192 samples (3 * 2^k: the enclosing power-of-two transforms).
+  Forward through the DAG, the loss against the fp64 oracle on the audio the DAG made, gradients to every trainable input."""
+  rng = np.random.default_rng(48)
+  b, f, k, m, n, sr = 2, 201, 60, 65, 192960, 48000
+  feats = {'amps': ddsp.core.tf_float32(rng.standard_normal((b, f, 1))).requires_grad_(True),
+           'harmonic_distribution': ddsp.core.tf_float32(rng.standard_normal((b, f, k))).requires_grad_(True),
+           'f0_hz': ddsp.core.tf_float32(220 + 2 * rng.standard_normal((b, f, 1))),
+           'noise_magnitudes': ddsp.core.tf_float32(rng.standard_normal((b, f, m))).requires_grad_(True)}
+  rev = ddsp.effects.FilteredNoiseReverb(trainable=True, reverb_length=72000, n_frames=500, n_filter_banks=32,
+                                         initial_bias=-4.0, name='reverb')
+  rev.build(device=torch.device(DEV))
+  rev._magnitudes.requires_grad_(True)
+  dag = [(ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method='linear', use_angular_cumsum=True),
+          ['amps', 'harmonic_distribution', 'f0_hz']),
+         (ddsp.synths.FilteredNoise(n_samples=n, window_size=0), ['noise_magnitudes']),
+         (ddsp.processors.Add(), ['filtered_noise/signal', 'harmonic/signal']),
+         (rev, ['add/signal']),
+         (ddsp.processors.Crop(frame_size=960, crop_location='back'), ['reverb/signal'])]
+  audio = ddsp.processors.ProcessorGroup(dag=dag)(feats)
+  assert tuple(audio.shape) == (b, n - 960) and audio.requires_grad and bool(torch.isfinite(audio).all())
+  target = ddsp.core.tf_float32(0.1 * rng.standard_normal((b, n - 960)))
+  sizes = (6144, 3072, 1536, 768, 384, 192)
+  loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, loss_type='L1', mag_weight=1.0, logmag_weight=1.0)(target, audio.contiguous())
+  ref = float(O.spectral_loss(npy(target), npy(audio.detach()), sizes, mag_weight=1.0, logmag_weight=1.0, dtype=np.float64))
+  np.testing.assert_allclose(float(loss.detach()), ref, rtol=5e-5)
+  loss.backward()
+  for t in (feats['amps'], feats['harmonic_distribution'], feats['noise_magnitudes'], rev._magnitudes):
+    assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+
+
 def test_spectral_loss_fused_and_separate_gradient_entries_agree(ddsp):
   rng = np.random.default_rng(44)
   t = ddsp.core.tf_float32(0.3 * rng.standard_normal((2, 5000)))

@@ -66,6 +66,7 @@ for _module in (P, G):
       globals()[_name] = getattr(_module, _name)
 
 SLOW_UNDER_EMULATION = () if os.environ.get('DDSP_EMU_ALL') == '1' else (
+    'test_vst_48k_configuration_full_size',                            # minutes: 2 x 192 960 samples through every kernel
     'test_spectral_loss_on_the_synth_output_batch32',                  # 293 s
     'test_harmonic_backward_full_size_properties',                     # 210 s
     'test_full_size_properties_batch32',                               # 49 + 33 s
