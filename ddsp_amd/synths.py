@@ -112,7 +112,15 @@ class Harmonic(processors.Processor):
     core._check_amp_method(self.amp_resample_method, f, int(self.n_samples))
     needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or harmonic_distribution.requires_grad or
                                               f0_hz.requires_grad)
-    if not core._on_closed_form_kernels(self.amp_resample_method, f, int(self.n_samples)):
+    if k > 512:
+      raise NotImplementedError('the MI355X path holds at most 512 harmonics per frame, got {}'.format(k))
+    closed_form = core._on_closed_form_kernels(self.amp_resample_method, f, int(self.n_samples))
+    if needs_grad and closed_form and (k > 256 or int(self.n_samples) // f > 2048):
+      # the closed-form BACKWARD kernels take up to 256 harmonics and frames of up to 2048 samples (csrc/harmonic.hip); beyond
+      # (300 harmonics at 48 kHz: found raising by a probe after tools/fuzz_parity.py) the chain of materialised envelopes
+      # and its adjoint, which take any shape the forward takes
+      closed_form = False
+    if not closed_form:
       # 'nearest' / 'cubic' envelopes, or n_samples not a multiple of n_frames: the reference's own two
       # steps, get_signal following its chain of materialised envelopes (core.harmonic_synthesis)
       if needs_grad:

@@ -1258,6 +1258,35 @@ def test_harmonic_backward_on_the_wavetable_adjoint(ddsp, batch, n_frames, k, ho
   np.testing.assert_array_equal(grads[0][1], grads[1][1])
 
 
+@pytest.mark.parametrize('k,hop,sr', [(300, 64, 48000), (257, 100, 16000), (512, 64, 48000)])
+def test_harmonic_more_than_256_harmonics_forward_and_backward(ddsp, k, hop, sr):
+  """257 .. 512 harmonics (300 live ones need 48 kHz and an f0 below 80 Hz): the forward runs the plain closed-form kernels, the
+  backward - whose closed-form kernels stop at 256 - the chain of materialised envelopes and its adjoint (it raised
+  DDSP_ERR_UNSUPPORTED until a probe at the end of round 5); more than 512 is refused by name."""
+  rng = np.random.default_rng(k)
+  b, f = 1, 5
+  n = f * hop
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  f0 = rng.uniform(30.0, 45.0, (b, f, 1)).astype(np.float32)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, dtype=np.float64)
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  assert np.abs(npy(synth(amps, hd, f0)) - truth).max() <= HARM_TRUTH_ATOL * scale
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  out = synth(ta, th, f0)
+  out.backward(ddsp.core.tf_float32(g))
+  assert np.abs(npy(out.detach()) - truth).max() <= 4 * HARM_TRUTH_ATOL * scale
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, 'window')
+  slack = 1.0 if hop == 64 else 3.0
+  np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=slack * grad_tol(ga))
+  np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=slack * grad_tol(gh))
+  with pytest.raises(NotImplementedError, match='512 harmonics'):
+    ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)(amps, np.zeros((b, f, 513), np.float32), f0)
+
+
 @pytest.mark.parametrize('hop', [20, 40, 100, 200])
 def test_harmonic_backward_ragged_frames_and_steep_f0_drops(ddsp, hop):
   """frame sizes that are not multiples of 64 with f0 falling steeply inside a frame.  The lanes past a
