@@ -60,6 +60,10 @@ SIGNATURES = {
     'ddsp_spectral_terms_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_f32p, c_voidp, c_f32p, c_voidp, c_size_t] +
                                 [c_int] * 4 + [ctypes.c_float] * 5 + [c_int, c_voidp]),
     'ddsp_stft_mag_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [c_voidp]),
+    'ddsp_stft_frames_mag_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
+    'ddsp_stft_frames_mag_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
+    'ddsp_loudness_from_mag_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [ctypes.c_float] * 2 + [c_voidp]),
+    'ddsp_loudness_from_mag_backward_f32': (c_int, [c_f32p] * 4 + [c_int] * 3 + [ctypes.c_float] * 2 + [c_voidp]),
     'ddsp_uniform_noise_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_voidp]),
     'ddsp_prepare': (c_int, [c_int, c_int, c_int]),
     'ddsp_uniform_noise_ex_f32': (c_int, [c_f32p, c_int, c_int, c_u64, c_u64, c_int, c_voidp]),

@@ -453,6 +453,16 @@ def _harmonic_flags(scale, normalize, amp_resample_method, use_angular_cumsum):
   return flags
 
 
+def _broadcast_batch(*tensors):
+  """[1, frames, channels] inputs beside [batch, ..] ones: the reference's elementwise products broadcast them over the batch
+  (its own test does: ddsp/core_test.py:549-590 passes shifts and a distribution of batch 1 with frequencies of batch 2).
+  None passes through; anything else is left for the shape checks."""
+  batches = [int(t.shape[0]) for t in tensors if t is not None and t.dim() == 3]
+  b = max(batches) if batches else 1
+  return tuple(t.expand(b, -1, -1).contiguous() if t is not None and t.dim() == 3 and t.shape[0] == 1 and b > 1 else t
+               for t in tensors)
+
+
 def _check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz):
   if harmonic_distribution.dim() != 3:
     raise ValueError('harmonic_distribution must be [batch, n_frames, n_harmonics], got {}'
@@ -483,6 +493,10 @@ def harmonic_synthesis(frequencies, amplitudes, harmonic_shifts=None,
     harmonic_shifts = tf_float32(harmonic_shifts)
   require_no_grad('core.harmonic_synthesis (Harmonic.__call__ is the differentiable entry)', frequencies, amplitudes,
                   harmonic_shifts, harmonic_distribution)
+  if harmonic_distribution is not None:
+    harmonic_distribution = tf_float32(harmonic_distribution)
+  frequencies, amplitudes, harmonic_shifts, harmonic_distribution = _broadcast_batch(frequencies, amplitudes, harmonic_shifts,
+                                                                                     harmonic_distribution)
   if harmonic_distribution is None:
     if harmonic_shifts is not None:                          # n_harmonics from the shifts (core.py:1082-1084)
       return _harmonic_synthesis_materialised(frequencies, amplitudes, harmonic_shifts, None, int(n_samples),
@@ -616,6 +630,7 @@ def streaming_harmonic_synthesis(frequencies, amplitudes, harmonic_distribution=
     harmonic_distribution = torch.ones_like(amplitudes)
     flags |= _lib.HARM_INPUTS_ARE_AMPLITUDES
   harmonic_distribution = tf_float32(harmonic_distribution)
+  frequencies, amplitudes, harmonic_distribution = _broadcast_batch(frequencies, amplitudes, harmonic_distribution)
   b, f, k = _check_harmonic_shapes(amplitudes, harmonic_distribution, frequencies)
   _check_amp_method(amp_resample_method, f, n)
   if amp_resample_method not in ('linear', 'window') or n % f:

@@ -731,22 +731,26 @@ __global__ __launch_bounds__(kSlThreads) void stft_cot_bwd_kernel(const float* _
 // block (the largest size - 6144 samples under an 8192-point transform - fills a block's 4096 complex points with ONE frame),
 // a load pass of its own, every output sample through an atomic.
 // =====================================================================================================================
-// frames [f0, f0 + n_fr) of `row`, F = 3 S / 4 samples each, hop F / 4, windowed, zero-padded to S: element e of frame g is the
-// sample pair (2 e, 2 e + 1)
+// A frame geometry under a transform of S points: frames of F <= S samples (F even) every `hop`, the first starting `pad_left`
+// samples BEFORE sample 0 (spectral_ops.pad 'center': F / 2), a periodic Hann window of F points, zeros up to S and outside the row.
+//   vst_48k.gin's loss frames: F = 3 S / 4, hop F / 4, pad_left 0;  compute_loudness: F = S = 2048, hop 64, pad_left 1024.
+struct SlFrameGeom { int F, hop, pad_left; float inv_F; };
+
+// frames [f0, f0 + n_fr) of `row`: element e of frame g is the sample pair (2 e, 2 e + 1)
 template <int S>
 __device__ __forceinline__ void tq_load_frames(float2* s, const float* __restrict__ row, int tid, int f0, int n_fr,
-                                               int n_frames, int N) {
-  constexpr int H = S / 2, LOG2H = __builtin_ctz(H), F = 3 * S / 4, HOP = F / 4;
+                                               int n_frames, int N, SlFrameGeom fg) {
+  constexpr int H = S / 2, LOG2H = __builtin_ctz(H);
   for (int it = tid; it < n_fr * H; it += kSlThreads) {
     const int g = it >> LOG2H, e = it & (H - 1);
     float x0 = 0.0f, x1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
-    if (f0 + g < n_frames && 2 * e < F) {                        // (F is even: a pair is inside the frame or outside)
-      const long i = (long)(f0 + g) * HOP + 2 * e;
-      if (i < N) x0 = row[i];
-      if (i + 1 < N) x1 = row[i + 1];
+    if (f0 + g < n_frames && 2 * e < fg.F) {                     // (F is even: a pair is inside the frame or outside)
+      const long i = (long)(f0 + g) * fg.hop - fg.pad_left + 2 * e;
+      if (i >= 0 && i < N) x0 = row[i];
+      if (i + 1 >= 0 && i + 1 < N) x1 = row[i + 1];
       // tf.signal.hann_window(F), periodic: 0.5 - 0.5 cos(2 pi i / F)
-      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e) * (1.0f / (float)F));
-      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e + 1) * (1.0f / (float)F));
+      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e) * fg.inv_F);
+      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e + 1) * fg.inv_F);
     }
     s[SP(it)] = make_float2(x0 * w0, x1 * w1);
   }
@@ -756,14 +760,14 @@ __device__ __forceinline__ void tq_load_frames(float2* s, const float* __restric
 template <int S>
 __global__ __launch_bounds__(kSlThreads) void stft_tq_mag_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                                  float* __restrict__ mag_t, float* __restrict__ mag_a, int N,
-                                                                 int n_frames) {
+                                                                 int n_frames, SlFrameGeom fg) {
   constexpr int H = S / 2, G = kSlPoints / H;
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int f0 = blockIdx.x * G;
   const float* __restrict__ row = (blockIdx.z ? audio : target) + (size_t)b * N;
   float* __restrict__ mag = blockIdx.z ? mag_a : mag_t;
-  tq_load_frames<S>(s, row, tid, f0, G, n_frames, N);
+  tq_load_frames<S>(s, row, tid, f0, G, n_frames, N, fg);
   __syncthreads();
   sl_forward<H>(s, tid, G, 0);
   __syncthreads();
@@ -784,12 +788,13 @@ __global__ __launch_bounds__(kSlThreads) void stft_tq_mag_kernel(const float* __
 // dL/d audio from dL/d |STFT(audio)| (`cot` [B, frames, S / 2 + 1]); stft_l1_bwd_block's arithmetic on frames of 3 S / 4 samples
 template <int S>
 __global__ __launch_bounds__(kSlThreads) void stft_tq_cot_bwd_kernel(const float* __restrict__ audio, float* __restrict__ grad_audio,
-                                                                     int N, int n_frames, const float* __restrict__ cot) {
-  constexpr int H = S / 2, G = kSlPoints / H, F = 3 * S / 4, HOP = F / 4;
+                                                                     int N, int n_frames, const float* __restrict__ cot,
+                                                                     SlFrameGeom fg) {
+  constexpr int H = S / 2, G = kSlPoints / H;
   __shared__ __attribute__((aligned(16))) float2 s[kSlStore];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int f0 = blockIdx.x * G;
-  tq_load_frames<S>(s, audio + (size_t)b * N, tid, f0, G, n_frames, N);
+  tq_load_frames<S>(s, audio + (size_t)b * N, tid, f0, G, n_frames, N, fg);
   __syncthreads();
   sl_forward<H>(s, tid, G, 0);
   __syncthreads();
@@ -831,24 +836,60 @@ __global__ __launch_bounds__(kSlThreads) void stft_tq_cot_bwd_kernel(const float
   sl_inverse<H>(s, tid, G, 0);
   __syncthreads();
   // window and overlap-add: g_x[2 e] = 2 Re U[e], g_x[2 e + 1] = 2 Im U[e] for the frame's first F samples (the zero padding
-  // has no gradient); a sample meets up to four of the block's frames (hop F / 4)
+  // has no gradient); position p of the block's stretch (sample f0 hop - pad_left + p) lies in frames g with 0 <= p - g hop < F
   float* __restrict__ grow = grad_audio + (size_t)b * N;
-  for (int pidx = tid; pidx < (G + 3) * HOP; pidx += kSlThreads) {
-    const long n = (long)f0 * HOP + pidx;
-    if (n >= N) continue;
-    const int gp = pidx / HOP, ir = pidx - gp * HOP;
+  const int span = (G - 1) * fg.hop + fg.F;
+  for (int p = tid; p < span; p += kSlThreads) {
+    const long n = (long)f0 * fg.hop - fg.pad_left + p;
+    if (n < 0 || n >= N) continue;
+    const int g_hi = min(G - 1, p / fg.hop);
+    const int g_lo = p < fg.F ? 0 : (p - fg.F) / fg.hop + 1;
     float acc = 0.0f;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int g = gp - jj, i = ir + jj * HOP;                 // frame g covers the sample at its index i < F
-      if (g >= 0 && g < G && f0 + g < n_frames) {
-        const float2 u = s[SP(g * H + (i >> 1))];
-        const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * (1.0f / (float)F));
-        acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
-      }
+    for (int g = g_lo; g <= g_hi; ++g) {
+      if (f0 + g >= n_frames) break;
+      const int i = p - g * fg.hop;                              // < F
+      const float2 u = s[SP(g * H + (i >> 1))];
+      const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * fg.inv_F);
+      acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
     }
     unsafeAtomicAdd(&grow[n], acc);
   }
+}
+
+// ---- spectral_ops.compute_loudness (ddsp/spectral_ops.py:253-324) from the magnitudes of its STFT -----------------------------
+// loudness[b, f] = max(10 log10(max(pmin, mean_k w_k |X_k|^2)) - ref_db, -range_db),  pmin = 10^(-range_db / 10)
+// (core.power_to_db, core.py:253-267; w = 10^(A_weighting / 10), a constant table the caller supplies).  One wavefront per frame.
+struct LoudArgs { int rows, bins; float pmin, range_db, ref_db; };
+
+__global__ __launch_bounds__(256) void loudness_from_mag_kernel(const float* __restrict__ mag, const float* __restrict__ wt,
+                                                                float* __restrict__ loud, LoudArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const float* __restrict__ m = mag + row * p.bins;
+  float acc = 0.0f;
+  for (int k = lane; k < p.bins; k += 64) acc = fmaf(wt[k] * m[k], m[k], acc);
+  const float power = wave_sum(acc) / (float)p.bins;
+  const float db = 10.0f * (__logf(fmaxf(p.pmin, power)) * 0.4342944819032518f) - p.ref_db;
+  if (lane == 0) loud[row] = fmaxf(db, -p.range_db);
+}
+
+// grad_mag[b, f, k] = dL/d loudness[b, f] * d loudness / d |X_k|: 10 / (ln 10 P) * 2 w_k |X_k| / bins, nothing where a max() clips
+__global__ __launch_bounds__(256) void loudness_from_mag_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ wt,
+                                                                    const float* __restrict__ grad_loud,
+                                                                    float* __restrict__ grad_mag, LoudArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const float* __restrict__ m = mag + row * p.bins;
+  float acc = 0.0f;
+  for (int k = lane; k < p.bins; k += 64) acc = fmaf(wt[k] * m[k], m[k], acc);
+  const float power = wave_sum(acc) / (float)p.bins;
+  const float db = 10.0f * (__logf(fmaxf(p.pmin, power)) * 0.4342944819032518f) - p.ref_db;
+  const bool live = power > p.pmin && db > -p.range_db;
+  const float gp = live ? grad_loud[row] * (10.0f * 0.4342944819032518f) / power * (2.0f / (float)p.bins) : 0.0f;
+  float* __restrict__ gm = grad_mag + row * p.bins;
+  for (int k = lane; k < p.bins; k += 64) gm[k] = gp * wt[k] * m[k];
 }
 
 // a frame size 3 * 2^k in [48, 6144] -> its FFT length 2^(k+2), or 0
@@ -1067,9 +1108,10 @@ extern "C" int ddsp_stft_mag_f32(const float* target_audio, const float* audio, 
   hipStream_t st = (hipStream_t)stream;
   if (const int S3 = sl_tq_fft_size(fft_size)) {                // frames of 3 * 2^k samples under a transform of 2^(k+2)
     const int frames3 = sl_frames(N, fft_size), g3 = 2 * kSlPoints / S3;       // (sl_frames: ceil(N / (F / 4)))
+    const SlFrameGeom fg3 = {fft_size, fft_size / 4, 0, 1.0f / (float)fft_size};
     const dim3 grid3((unsigned)((frames3 + g3 - 1) / g3), (unsigned)B, 2u);
 #define DDSP_SM3_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_mag_kernel<SZ>), grid3, dim3(kSlThreads), 0, st, \
-                                                      target_audio, audio, target_mag, mag, N, frames3); break
+                                                      target_audio, audio, target_mag, mag, N, frames3, fg3); break
     switch (S3) {
       DDSP_SM3_CASE(64); DDSP_SM3_CASE(128); DDSP_SM3_CASE(256); DDSP_SM3_CASE(512); DDSP_SM3_CASE(1024);
       DDSP_SM3_CASE(2048); DDSP_SM3_CASE(4096); DDSP_SM3_CASE(8192);
@@ -1100,9 +1142,10 @@ extern "C" int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_
   hipStream_t st = (hipStream_t)stream;
   if (const int S3 = sl_tq_fft_size(fft_size)) {
     const int frames3 = sl_frames(N, fft_size), g3 = 2 * kSlPoints / S3;
+    const SlFrameGeom fg3 = {fft_size, fft_size / 4, 0, 1.0f / (float)fft_size};
     const dim3 grid3((unsigned)((frames3 + g3 - 1) / g3), (unsigned)B);
 #define DDSP_SMB3_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_cot_bwd_kernel<SZ>), grid3, dim3(kSlThreads), 0, st, \
-                                                       audio, grad_audio, N, frames3, grad_mag); break
+                                                       audio, grad_audio, N, frames3, grad_mag, fg3); break
     switch (S3) {
       DDSP_SMB3_CASE(64); DDSP_SMB3_CASE(128); DDSP_SMB3_CASE(256); DDSP_SMB3_CASE(512); DDSP_SMB3_CASE(1024);
       DDSP_SMB3_CASE(2048); DDSP_SMB3_CASE(4096); DDSP_SMB3_CASE(8192);
@@ -1122,5 +1165,74 @@ extern "C" int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_
     default: return DDSP_ERR_UNSUPPORTED;
   }
 #undef DDSP_SMB_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+// ---- |STFT| under a frame geometry of the caller's (spectral_ops.compute_loudness: frames of n_fft = 2048 every sr / 250 = 64
+// samples, centred: spectral_ops.py:289-300) - one signal, [B, n_frames, fft_size / 2 + 1] - and its adjoint ------------------------
+static int sl_frames_geometry_ok(int B, int N, int fft_size, int hop, int pad_left, int n_frames) {
+  if (B <= 0 || N <= 0 || n_frames <= 0 || hop <= 0 || pad_left < 0) return DDSP_ERR_BAD_SHAPE;
+  if (B > 65535 || fft_size < 64 || fft_size > 8192 || (fft_size & (fft_size - 1))) return DDSP_ERR_UNSUPPORTED;
+  return DDSP_OK;
+}
+
+extern "C" int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left,
+                                        int n_frames, void* stream) {
+  if (!audio || !mag) return DDSP_ERR_NULL_POINTER;
+  if (const int rc = sl_frames_geometry_ok(B, N, fft_size, hop, pad_left, n_frames)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = 2 * kSlPoints / fft_size;
+  const SlFrameGeom fg = {fft_size, hop, pad_left, 1.0f / (float)fft_size};
+  const dim3 grid((unsigned)((n_frames + g - 1) / g), (unsigned)B, 1u);
+#define DDSP_SFM_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_mag_kernel<SZ>), grid, dim3(kSlThreads), 0, st, audio, audio, mag, \
+                                                      mag, N, n_frames, fg); break
+  switch (fft_size) {
+    DDSP_SFM_CASE(64); DDSP_SFM_CASE(128); DDSP_SFM_CASE(256); DDSP_SFM_CASE(512); DDSP_SFM_CASE(1024);
+    DDSP_SFM_CASE(2048); DDSP_SFM_CASE(4096); DDSP_SFM_CASE(8192);
+    default: return DDSP_ERR_UNSUPPORTED;
+  }
+#undef DDSP_SFM_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_stft_frames_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N,
+                                                 int fft_size, int hop, int pad_left, int n_frames, void* stream) {
+  if (!audio || !grad_mag || !grad_audio) return DDSP_ERR_NULL_POINTER;
+  if (const int rc = sl_frames_geometry_ok(B, N, fft_size, hop, pad_left, n_frames)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = 2 * kSlPoints / fft_size;
+  const SlFrameGeom fg = {fft_size, hop, pad_left, 1.0f / (float)fft_size};
+  const dim3 grid((unsigned)((n_frames + g - 1) / g), (unsigned)B);
+#define DDSP_SFB_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_cot_bwd_kernel<SZ>), grid, dim3(kSlThreads), 0, st, audio, \
+                                                      grad_audio, N, n_frames, grad_mag, fg); break
+  switch (fft_size) {
+    DDSP_SFB_CASE(64); DDSP_SFB_CASE(128); DDSP_SFB_CASE(256); DDSP_SFB_CASE(512); DDSP_SFB_CASE(1024);
+    DDSP_SFB_CASE(2048); DDSP_SFB_CASE(4096); DDSP_SFB_CASE(8192);
+    default: return DDSP_ERR_UNSUPPORTED;
+  }
+#undef DDSP_SFB_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_loudness_from_mag_f32(const float* mag, const float* weighting, float* loudness, int B, int n_frames,
+                                          int bins, float range_db, float ref_db, void* stream) {
+  if (!mag || !weighting || !loudness) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || n_frames <= 0 || bins <= 0) return DDSP_ERR_BAD_SHAPE;
+  LoudArgs p;
+  p.rows = B * n_frames; p.bins = bins; p.pmin = powf(10.0f, -range_db / 10.0f); p.range_db = range_db; p.ref_db = ref_db;
+  hipLaunchKernelGGL(loudness_from_mag_kernel, dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mag,
+                     weighting, loudness, p);
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_loudness_from_mag_backward_f32(const float* mag, const float* weighting, const float* grad_loudness,
+                                                   float* grad_mag, int B, int n_frames, int bins, float range_db, float ref_db,
+                                                   void* stream) {
+  if (!mag || !weighting || !grad_loudness || !grad_mag) return DDSP_ERR_NULL_POINTER;
+  if (B <= 0 || n_frames <= 0 || bins <= 0) return DDSP_ERR_BAD_SHAPE;
+  LoudArgs p;
+  p.rows = B * n_frames; p.bins = bins; p.pmin = powf(10.0f, -range_db / 10.0f); p.range_db = range_db; p.ref_db = ref_db;
+  hipLaunchKernelGGL(loudness_from_mag_bwd_kernel, dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mag,
+                     weighting, grad_loudness, grad_mag, p);
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }

@@ -17,6 +17,8 @@ tf_float32 = core.tf_float32
 class Reverb(processors.Processor):
   """Convolutional (FIR) reverb (ddsp/effects.py:27-117)."""
 
+  _variable_names = ('_ir',)
+
   def __init__(self, trainable=False, reverb_length=48000, add_dry=True, name='reverb'):
     """Takes neural network outputs directly as the impulse response.
 
@@ -132,6 +134,8 @@ class ExpDecayReverb(Reverb):
   (seed, call counter).  `get_controls(..., noise=...)` is the parity entry with a supplied burst.
   """
 
+  _variable_names = ('_gain', '_decay')
+
   def __init__(self, trainable=False, reverb_length=48000, scale_fn=core.exp_sigmoid, add_dry=True,
                name='exp_decay_reverb', seed=0):
     super().__init__(name=name, add_dry=add_dry, trainable=trainable)
@@ -233,6 +237,8 @@ class FilteredNoiseReverb(Reverb):
 
   `seed` is this package's extension (FilteredNoise draws Philox noise keyed by it).
   """
+
+  _variable_names = ('_magnitudes',)
 
   def __init__(self, trainable=False, reverb_length=48000, window_size=257, n_frames=1000,
                n_filter_banks=16, scale_fn=core.exp_sigmoid, initial_bias=-3.0, add_dry=True,

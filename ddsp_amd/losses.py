@@ -9,6 +9,7 @@ The call is a torch.autograd node: the gradient reaches `audio` (not `target_aud
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from ddsp_amd import _lib
@@ -58,13 +59,11 @@ class SpectralLoss(Loss):
     """Scalar loss (0-dim tensor in HBM) between two batches of audio [batch, n_samples(, 1)]."""
     if self.loss_type.upper() not in ('L1', 'L2', 'COSINE'):
       # losses.mean_difference (losses.py:102-128) raises when it is CALLED: a loss whose every weight is zero never calls it
-      if max(self.mag_weight, self.delta_time_weight, self.delta_freq_weight, self.cumsum_freq_weight, self.logmag_weight) > 0:
+      if max(self.mag_weight, self.delta_time_weight, self.delta_freq_weight, self.cumsum_freq_weight, self.logmag_weight,
+             self.loudness_weight) > 0:
         raise ValueError('Loss type ({}), must be '
                          '"L1", "L2", or "COSINE"'.format(self.loss_type.upper()))
       return torch.zeros((), dtype=torch.float32, device=core._device())
-    if self.loudness_weight > 0:
-      raise NotImplementedError('SpectralLoss.loudness_weight needs spectral_ops.compute_loudness (librosa A-weighting), '
-                                'which is outside the MI355X path')
     target_audio, audio = core.tf_float32(target_audio), core.tf_float32(audio)
     if target_audio.dim() == 3:
       target_audio = target_audio[..., 0].contiguous()
@@ -74,7 +73,7 @@ class SpectralLoss(Loss):
       raise ValueError('target_audio and audio must both be [batch, n_samples], got {} and {}'.format(
           tuple(target_audio.shape), tuple(audio.shape)))
     general = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
-               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or
+               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or self.loudness_weight > 0 or
                any(int(v) & (int(v) - 1) for v in self.fft_sizes))         # frames of 3 * 2**k samples (vst_48k.gin): the plain kernels
     if general:
       weights = self._weights_tensor(weights, audio.device)
@@ -107,7 +106,7 @@ class SpectralLoss(Loss):
     loss = torch.empty((), dtype=torch.float32, device=dev)
     acc = torch.empty((), dtype=torch.float64, device=dev)
     grad_audio = torch.zeros_like(audio) if want_grad else None
-    if not self.fft_sizes:
+    if not self.fft_sizes and not self.loudness_weight > 0:
       loss.zero_()
       return loss, grad_audio
     for z, size in enumerate(self.fft_sizes):
@@ -147,6 +146,8 @@ class SpectralLoss(Loss):
         rc = lib.ddsp_stft_mag_backward_f32(audio.data_ptr(), cot.data_ptr(), grad_audio.data_ptr(), b, n, size,
                                             core._stream())
         _lib.check(rc, 'ddsp_stft_mag_backward_f32')
+    if self.loudness_weight > 0:
+      self._loudness_term(target_audio, audio, weights, loss, acc, grad_audio, first=not self.fft_sizes)
     if (self.delta_time_weight > 0 and self.loss_type.upper() in ('L1', 'L2') and
         any(-(-n // (int(size) // 4)) < 2 for size in self.fft_sizes)):
       # a clip of ONE frame at some size: the reference's delta-time term is the mean of an empty difference - NaN
@@ -154,6 +155,75 @@ class SpectralLoss(Loss):
       # tf.compat.v1.losses.cosine_distance, whose weighted mean divides safely: 0 for no elements - what the kernel adds.)
       loss.fill_(float('nan'))
     return loss, grad_audio
+
+  # spectral_ops.compute_loudness as SpectralLoss calls it (losses.py:238-242: n_fft = 2048, everything else the defaults of
+  # spectral_ops.py:253-260: 16 kHz, 250 frames a second, 80 dB of range, reference 0 dB, centre padding)
+  LOUDNESS_N_FFT, LOUDNESS_SAMPLE_RATE, LOUDNESS_FRAME_RATE, LOUDNESS_RANGE_DB, LOUDNESS_REF_DB = 2048, 16000, 250, 80.0, 0.0
+  _a_weighting = {}
+
+  @classmethod
+  def _loudness_weighting(cls, device):
+    """10 ** (A_weighting / 10) at the bins of the 2048-point transform: the A-curve librosa publishes (IEC 61672; clipped at
+    -80 dB, f = 0), a constant table made once per device in double precision - host arithmetic, as every constant table of
+    this library (oracle/ddsp_oracle.py::a_weighting_db restates the same formula for the tests)."""
+    key = str(device)
+    if key not in cls._a_weighting:
+      n_fft, sr = cls.LOUDNESS_N_FFT, cls.LOUDNESS_SAMPLE_RATE
+      f_sq = (np.arange(n_fft // 2 + 1, dtype=np.float64) * (sr / n_fft)) ** 2
+      c = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+      with np.errstate(divide='ignore'):
+        db = 2.0 + 20.0 * (np.log10(c[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + c[0]) - np.log10(f_sq + c[1])
+                           - 0.5 * np.log10(f_sq + c[2]) - 0.5 * np.log10(f_sq + c[3]))
+      w = 10.0 ** (np.maximum(-80.0, db) / 10.0)
+      cls._a_weighting[key] = torch.as_tensor(w.astype(np.float32), device=device)
+    return cls._a_weighting[key]
+
+  def _loudness_term(self, target_audio, audio, weights, loss, acc, grad_audio, first):
+    """loss += loudness_weight * mean_difference(compute_loudness(target), compute_loudness(audio)) (losses.py:238-242) and, if
+    grad_audio is given, its gradient: |STFT| under compute_loudness's frames (ddsp_stft_frames_mag_f32), the A-weighted mean power
+    in dB per frame (ddsp_loudness_from_mag_f32), the difference term on [batch, 1, frames] (ddsp_spectral_terms_f32), and back."""
+    b, n = audio.shape
+    lib = _lib.load()
+    dev = audio.device
+    n_fft = self.LOUDNESS_N_FFT
+    hop = self.LOUDNESS_SAMPLE_RATE // self.LOUDNESS_FRAME_RATE
+    frames, bins = 1 + n // hop, n_fft // 2 + 1
+    wt = self._loudness_weighting(dev)
+    loud, mags = [], []
+    for x in (target_audio, audio):
+      mag = torch.empty((b, frames, bins), dtype=torch.float32, device=dev)
+      _lib.check(lib.ddsp_stft_frames_mag_f32(x.data_ptr(), mag.data_ptr(), b, n, n_fft, hop, n_fft // 2, frames, core._stream()),
+                 'ddsp_stft_frames_mag_f32')
+      ld = torch.empty((b, 1, frames), dtype=torch.float32, device=dev)
+      _lib.check(lib.ddsp_loudness_from_mag_f32(mag.data_ptr(), wt.data_ptr(), ld.data_ptr(), b, frames, bins,
+                                                self.LOUDNESS_RANGE_DB, self.LOUDNESS_REF_DB, core._stream()),
+                 'ddsp_loudness_from_mag_f32')
+      loud.append(ld); mags.append(mag)
+    wb = wf = wk = 0
+    if weights is not None:
+      # (`weights` multiplies the [batch, frames] difference in the reference: a [batch, frames, 1]-shaped mask reads as
+      #  [batch, 1, frames] here only if it is broadcast along what it does not have - kept to masks of one value per clip)
+      wb, wf, wk = (int(v) for v in weights.shape)
+      if wf != 1 or wk != 1:
+        raise ValueError('with loudness_weight > 0 the weights mask must be one value per clip ([batch, 1, 1]), got {}'.format(
+            tuple(weights.shape)))
+    want_grad = grad_audio is not None
+    cot = torch.empty_like(loud[1]) if want_grad else None
+    ws = self._ws.get(core.cached_workspace_bytes('ddsp_spectral_terms_workspace_bytes', b, 1), dev)
+    rc = lib.ddsp_spectral_terms_f32(
+        loud[0].data_ptr(), loud[1].data_ptr(), weights.data_ptr() if weights is not None else None, wb, wf, wk,
+        cot.data_ptr() if want_grad else None, acc.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(), b, 1, frames,
+        _lib.LOSS_TYPES[self.loss_type.upper()], float(self.loudness_weight), 0.0, 0.0, 0.0, 0.0, 1 if first else 0,
+        core._stream())
+    _lib.check(rc, 'ddsp_spectral_terms_f32')
+    if want_grad:
+      grad_mag = mags[0]                                         # (the target's magnitudes are done with: their buffer)
+      _lib.check(lib.ddsp_loudness_from_mag_backward_f32(mags[1].data_ptr(), wt.data_ptr(), cot.data_ptr(), grad_mag.data_ptr(),
+                                                         b, frames, bins, self.LOUDNESS_RANGE_DB, self.LOUDNESS_REF_DB,
+                                                         core._stream()), 'ddsp_loudness_from_mag_backward_f32')
+      _lib.check(lib.ddsp_stft_frames_mag_backward_f32(audio.data_ptr(), grad_mag.data_ptr(), grad_audio.data_ptr(), b, n, n_fft,
+                                                       hop, n_fft // 2, frames, core._stream()),
+                 'ddsp_stft_frames_mag_backward_f32')
 
   def _sizes(self):
     return (ctypes.c_int * len(self.fft_sizes))(*[int(v) for v in self.fft_sizes])

@@ -39,6 +39,23 @@ class Processor:
   def get_signal(self, *args, **kwargs):
     raise NotImplementedError
 
+  # The keras Layer's variable lists (what the reference's own tests look at: effects_test.py:40-45 - a trainable Reverb owns its
+  # impulse response, nothing is ever non-trainable).  The tensors a processor creates in build() live in the attributes named
+  # in `_variable_names` (effects.Reverb: '_ir'; ExpDecayReverb: '_gain', '_decay'; FilteredNoiseReverb: '_magnitudes').
+  _variable_names = ()
+
+  @property
+  def variables(self):
+    return [v for v in (getattr(self, name, None) for name in self._variable_names) if v is not None]
+
+  @property
+  def trainable_variables(self):
+    return self.variables if self.trainable else []
+
+  @property
+  def non_trainable_variables(self):
+    return []
+
 
 class ProcessorGroup(dags.DAGLayer):
   """String Processor() objects together into a processor_group (ddsp/processors.py:79-158).

@@ -71,6 +71,7 @@ class Harmonic(processors.Processor):
     """Network outputs -> {'amplitudes', 'harmonic_distribution', 'f0_hz'} (synths.py:94-121)."""
     amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0_hz = core.tf_float32(f0_hz)
+    amplitudes, harmonic_distribution, f0_hz = core._broadcast_batch(amplitudes, harmonic_distribution, f0_hz)
     b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
     core.require_no_grad('Harmonic.get_controls (use __call__, which is differentiable)', amplitudes,
                          harmonic_distribution, f0_hz)
@@ -108,6 +109,7 @@ class Harmonic(processors.Processor):
     raw_amplitudes, raw_harmonic_distribution = amplitudes, harmonic_distribution
     amplitudes, harmonic_distribution, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0_hz = core.tf_float32(f0_hz)
+    amplitudes, harmonic_distribution, f0_hz = core._broadcast_batch(amplitudes, harmonic_distribution, f0_hz)
     b, f, k = core._check_harmonic_shapes(amplitudes, harmonic_distribution, f0_hz)
     core._check_amp_method(self.amp_resample_method, f, int(self.n_samples))
     needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or harmonic_distribution.requires_grad or
@@ -153,6 +155,7 @@ class Harmonic(processors.Processor):
     add_signal = core.tf_float32(add_signal)
     amps, hd, fuse = self._prescale(amplitudes, harmonic_distribution)
     f0 = core.tf_float32(f0_hz)
+    amps, hd, f0 = core._broadcast_batch(amps, hd, f0)
     wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (amps, hd, f0, add_signal))
     b, f, k = core._check_harmonic_shapes(amps, hd, f0)
     n = int(self.n_samples)

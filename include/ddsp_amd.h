@@ -365,6 +365,26 @@ int ddsp_spectral_terms_f32(const float* target_mag, const float* value_mag, con
                             float cumsum_freq_weight, float logmag_weight, int first, void* stream);
 int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                void* stream);
+/* fft_size of the two calls above: a power of two in [16, 4096], or a frame of 3 * 2^k samples in [48, 6144]
+ * (gin/models/vst/vst_48k.gin:56) - tf.signal.stft then transforms the enclosing power of two, the frame zero-padded:
+ * bins = (4 fft_size / 3) / 2 + 1.
+ *
+ * The loudness term of SpectralLoss (ddsp/losses.py:238-242 -> spectral_ops.compute_loudness, spectral_ops.py:253-324), in the
+ * same materialised form.  ddsp_stft_frames_mag_f32: |STFT| of ONE signal under the caller's frame geometry - frames of
+ * fft_size samples (a power of two in [64, 8192]) every `hop`, the first starting pad_left samples before sample 0 (zeros
+ * outside the row; compute_loudness: fft_size 2048, hop sample_rate / 250, pad_left 1024, n_frames 1 + N / hop), periodic Hann
+ * -> mag [B, n_frames, fft_size/2+1]; ..._backward: grad_audio += its adjoint applied to grad_mag.
+ * ddsp_loudness_from_mag_f32: loudness [B, n_frames] = max(10 log10(max(pmin, mean_k weighting[k] mag[k]^2)) - ref_db, -range_db),
+ * pmin = 10^(-range_db/10) (core.power_to_db, core.py:253-267); `weighting` [bins] = 10^(A_weighting/10), made by the caller
+ * (librosa's published A-curve: oracle/ddsp_oracle.py::a_weighting_db).  ..._backward: grad_mag [B, n_frames, bins]. */
+int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left, int n_frames,
+                             void* stream);
+int ddsp_stft_frames_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
+                                      int hop, int pad_left, int n_frames, void* stream);
+int ddsp_loudness_from_mag_f32(const float* mag, const float* weighting, float* loudness, int B, int n_frames, int bins,
+                               float range_db, float ref_db, void* stream);
+int ddsp_loudness_from_mag_backward_f32(const float* mag, const float* weighting, const float* grad_loudness, float* grad_mag,
+                                        int B, int n_frames, int bins, float range_db, float ref_db, void* stream);
 
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N].
  * _ex: noise_bits = 11 (the default form) or 23 (DDSP_NOISE_BITS_23's). */

@@ -830,10 +830,77 @@ def diff(x, axis=-1):
   return np.moveaxis(x[1:] - x[:-1], 0, axis)
 
 
+def a_weighting_db(sample_rate=16000, n_fft=2048):
+  """librosa.A_weighting(librosa.fft_frequencies(sr, n_fft)) as spectral_ops.compute_loudness calls them (spectral_ops.py:307-308).
+  librosa is a third-party dependency of the reference (setup.py: 'librosa', unpinned; not under /root/reference): its published
+  formula (librosa/core/convert.py, unchanged 0.8 .. 0.10) - the IEC 61672 A-curve in dB, clipped at min_db = -80 (f = 0)."""
+  f_sq = np.fft.rfftfreq(n=n_fft, d=1.0 / sample_rate) ** 2.0
+  c = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+  with np.errstate(divide='ignore'):
+    w = 2.0 + 20.0 * (np.log10(c[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + c[0]) - np.log10(f_sq + c[1])
+                      - 0.5 * np.log10(f_sq + c[2]) - 0.5 * np.log10(f_sq + c[3]))
+  return np.maximum(-80.0, w)
+
+
+def _loudness_frames(audio, n_fft, hop):
+  """pad(audio, 'center') (spectral_ops.py:171-218) + tf.signal.frame(pad_end=False): frames of n_fft every hop, the first
+  centred on sample 0 -> [B, 1 + N // hop, n_fft]."""
+  b, n = audio.shape
+  padded = np.pad(audio, [(0, 0), (n_fft // 2, n_fft // 2)])
+  n_frames = 1 + (padded.shape[1] - n_fft) // hop
+  idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+  return padded[:, idx]
+
+
+def compute_loudness(audio, sample_rate=16000, frame_rate=250, n_fft=2048, range_db=80.0, ref_db=0.0, dtype=np.float32):
+  """spectral_ops.compute_loudness(use_tf=True, padding='center') (spectral_ops.py:253-324): A-weighted mean power per frame in
+  dB, floored at -range_db -> [B, 1 + N // hop]."""
+  audio = as_float(audio, dtype)
+  if audio.ndim == 3:
+    audio = audio[..., 0]
+  hop = sample_rate // frame_rate
+  frames = _loudness_frames(audio, n_fft, hop)
+  s = np.fft.rfft(frames * hann_window_periodic(n_fft, dtype), n_fft)
+  power = (np.abs(s).astype(dtype)) ** 2
+  weighting = (10.0 ** (a_weighting_db(sample_rate, n_fft) / 10.0)).astype(dtype)
+  avg_power = np.mean(power * weighting, axis=-1, dtype=dtype)
+  pmin = dtype(10.0 ** -(range_db / 10.0))                        # core.power_to_db (core.py:253-267)
+  db = dtype(10.0) * (np.log(np.maximum(pmin, avg_power)) / dtype(np.log(10.0))).astype(dtype)
+  return np.maximum(db - dtype(ref_db), dtype(-range_db)).astype(dtype)
+
+
+def compute_loudness_backward(audio, grad_loudness, sample_rate=16000, frame_rate=250, n_fft=2048, range_db=80.0):
+  """dL/d audio of compute_loudness given dL/d loudness [B, frames] (fp64): through max(., -range) and max(pmin, .) (no
+  gradient where either clips), the weighted mean power, |rfft|^2, the window, the frames' overlap-add and the centre padding."""
+  a = as_float(audio, np.float64)
+  b, n = a.shape
+  hop = sample_rate // frame_rate
+  frames = _loudness_frames(a, n_fft, hop)
+  win = hann_window_periodic(n_fft, np.float64)
+  s = np.fft.rfft(frames * win, n_fft)
+  weighting = 10.0 ** (a_weighting_db(sample_rate, n_fft) / 10.0)
+  bins = s.shape[-1]
+  avg_power = np.mean(np.abs(s) ** 2 * weighting, axis=-1)
+  pmin = 10.0 ** -(range_db / 10.0)
+  db = 10.0 * np.log10(np.maximum(pmin, avg_power))
+  live = (avg_power > pmin) & (db > -range_db)
+  g_p = np.where(live, np.asarray(grad_loudness, np.float64) * 10.0 / (np.log(10.0) * np.where(live, avg_power, 1.0)), 0.0)
+  # d|X_k|^2 / dx_i = 2 Re(X_k exp(+2 pi i k i / n)): the sum over the rfft's bins is the real part of an inverse transform of
+  # the half spectrum (no doubling of the inner bins: each |X_k|^2 of the mean is one term)
+  g_s = (g_p[..., None] * weighting / bins) * 2.0 * s
+  full = np.zeros(s.shape[:-1] + (n_fft,), complex)
+  full[..., :bins] = g_s
+  g_frames = np.real(np.fft.ifft(full, axis=-1) * n_fft) * win
+  padded = np.zeros((b, n + n_fft))
+  for f in range(g_frames.shape[1]):
+    padded[:, f * hop:f * hop + n_fft] += g_frames[:, f]
+  return padded[:, n_fft // 2:n_fft // 2 + n]
+
+
 def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type='L1',
                   mag_weight=1.0, logmag_weight=0.0, dtype=np.float32, delta_time_weight=0.0, delta_freq_weight=0.0,
-                  cumsum_freq_weight=0.0, weights=None):
-  """losses.SpectralLoss.call (losses.py:189-243), every term but the loudness one."""
+                  cumsum_freq_weight=0.0, weights=None, loudness_weight=0.0):
+  """losses.SpectralLoss.call (losses.py:189-243), every term (the loudness one: compute_loudness above, n_fft = 2048)."""
   loss = dtype(0.0)
   if weights is not None:
     weights = np.asarray(weights, dtype)
@@ -852,6 +919,9 @@ def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64)
     if logmag_weight > 0:
       loss += dtype(logmag_weight) * mean_difference(safe_log(target_mag), safe_log(value_mag),
                                                      loss_type, weights)
+  if loudness_weight > 0:                                          # losses.py:238-242
+    loss += dtype(loudness_weight) * mean_difference(compute_loudness(target_audio, n_fft=2048, dtype=dtype),
+                                                     compute_loudness(audio, n_fft=2048, dtype=dtype), loss_type, weights)
   return loss
 
 

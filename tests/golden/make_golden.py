@@ -167,6 +167,16 @@ def main():
       l2_delta_time_only=a(losses.SpectralLoss(fft_sizes=(256,), loss_type='L2', mag_weight=0.0, delta_time_weight=1.0)(tgt, aud)),
       l1_cumsum_only=a(losses.SpectralLoss(fft_sizes=(2048, 64), mag_weight=0.0, cumsum_freq_weight=1.0)(tgt, aud)))
 
+  # (round 5) the loudness term (losses.py:238-242 -> spectral_ops.compute_loudness with n_fft = 2048; librosa's two functions
+  # restated in the stand-in): alone, with the other terms, every loss type; the loudness curve itself
+  cases['spectral_loss_loudness'] = dict(
+      target_audio=tgt, audio=aud,
+      loudness_audio=a(spectral_ops.compute_loudness(aud, n_fft=2048, use_tf=True)).astype(np.float32),
+      l1_only=a(losses.SpectralLoss(mag_weight=0.0, loudness_weight=1.0)(tgt, aud)),
+      l2_only=a(losses.SpectralLoss(loss_type='L2', mag_weight=0.0, loudness_weight=1.0)(tgt, aud)),
+      cosine_only=a(losses.SpectralLoss(loss_type='COSINE', mag_weight=0.0, loudness_weight=1.0)(tgt, aud)),
+      l1_all=a(losses.SpectralLoss(loudness_weight=0.5, **all_terms)(tgt, aud)))
+
   # --- core.streaming_harmonic_synthesis: the VST model's call (2 frames -> one hop, carried phase) ---
   rng = np.random.default_rng(51)
   def streaming_case(batch, n_frames, n_harm, n_samples, sr, method, with_hd=True, f_lo=200.0, f_hi=900.0):

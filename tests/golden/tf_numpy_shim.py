@@ -283,6 +283,19 @@ class Layer(Module):                                          # (a keras Layer I
     return self.call(*args, **kwargs)
 
 
+def librosa_fft_frequencies(sr=22050, n_fft=2048):
+  return np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+
+
+def librosa_a_weighting(frequencies, min_db=-80.0):
+  f_sq = np.asanyarray(frequencies) ** 2.0
+  const = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+  with np.errstate(divide='ignore'):
+    weights = 2.0 + 20.0 * (np.log10(const[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + const[0]) - np.log10(f_sq + const[1])
+                            - 0.5 * np.log10(f_sq + const[2]) - 0.5 * np.log10(f_sq + const[3]))
+  return weights if min_db is None else np.maximum(min_db, weights)
+
+
 def _identity_decorator(*dargs, **dkwargs):
   """gin.register / gin.configurable: bare or parameterised, both become no-ops."""
   if len(dargs) == 1 and callable(dargs[0]) and not dkwargs:
@@ -389,6 +402,14 @@ def install(reference_root='/root/reference'):
     stub = types.ModuleType(name)
     stub.distributions = types.SimpleNamespace(HiddenMarkovModel=object)
     sys.modules[name] = stub
+  # librosa (setup.py: 'librosa', unpinned; not under /root/reference): the two functions spectral_ops.compute_loudness calls
+  # (spectral_ops.py:307-308), restated from librosa's published source (librosa/core/convert.py, 0.8 .. 0.10: unchanged):
+  #   fft_frequencies(sr, n_fft) = linspace(0, sr / 2, 1 + n_fft // 2)                       (np.fft.rfftfreq)
+  #   A_weighting(f, min_db=-80) = max(min_db, 2.0 + 20 (log10(c0) + 2 log10(f^2) - log10(f^2 + c0) - log10(f^2 + c1)
+  #                                              - 0.5 log10(f^2 + c2) - 0.5 log10(f^2 + c3))),
+  #   c = [12194.217, 20.598997, 107.65265, 737.86223]^2          (IEC 61672 A-curve; f = 0 -> -inf -> min_db)
+  sys.modules['librosa'].fft_frequencies = librosa_fft_frequencies
+  sys.modules['librosa'].A_weighting = librosa_a_weighting
 
   pkg = types.ModuleType('ddsp')
   pkg.__path__ = [reference_root + '/ddsp']      # namespace only: __init__.py not run

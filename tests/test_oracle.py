@@ -546,3 +546,27 @@ def test_nearest_resize_rounds_like_roundf_not_like_a_rounded_sum():
   out = O.resize_nearest_legacy(x, 111, True)[0, :, 0]
   np.testing.assert_array_equal(out[:56], 1.0)
   np.testing.assert_array_equal(out[56:], 2.0)
+
+
+def test_loudness_matches_the_reference_source_and_its_gradient_finite_differences():
+  """spectral_ops.compute_loudness as SpectralLoss calls it (n_fft = 2048): the restatement against the golden vectors (the
+  reference's own source with librosa's fft_frequencies / A_weighting restated from its published formula), the analytic
+  gradient against central differences - through the dB floor too (a silent stretch)."""
+  g = load_golden('spectral_loss_loudness')
+  t, a = g['target_audio'], g['audio']
+  np.testing.assert_allclose(O.compute_loudness(a, dtype=np.float32), g['loudness_audio'], rtol=0, atol=2e-4)
+  assert O.compute_loudness(a).shape == (2, 1 + 3000 // 64)
+  for key, kw in (('l1_only', dict(mag_weight=0.0, loudness_weight=1.0)), ('l2_only', dict(loss_type='L2', mag_weight=0.0, loudness_weight=1.0)),
+                  ('cosine_only', dict(loss_type='COSINE', mag_weight=0.0, loudness_weight=1.0))):
+    np.testing.assert_allclose(float(O.spectral_loss(t, a, dtype=np.float32, **kw)), float(np.ravel(g[key])[0]), rtol=2e-5)
+  w = O.a_weighting_db(16000, 2048)
+  assert w.shape == (1025,) and w[0] == -80.0 and abs(w[128] - 0.0) < 0.01                     # 0 dB at 1 kHz (bin 128 of 2048 at 16 kHz)
+  rng = np.random.default_rng(1)
+  a64 = a.astype(np.float64)
+  gl = rng.standard_normal(O.compute_loudness(a64, dtype=np.float64).shape)
+  gb = O.compute_loudness_backward(a64, gl)
+  eps = 1e-6
+  for idx in [(0, 5), (1, 700), (0, 2500), (1, 2999), (1, 1400)]:
+    d = np.zeros_like(a64); d[idx] = eps
+    fd = ((O.compute_loudness(a64 + d, dtype=np.float64) - O.compute_loudness(a64 - d, dtype=np.float64)) * gl).sum() / (2 * eps)
+    np.testing.assert_allclose(gb[idx], fd, rtol=1e-4, atol=1e-9)

@@ -17,6 +17,7 @@ import torch
 
 import test_gpu_parity as P
 import test_gpu_parity_general as G
+import test_gpu_reference_tests as R
 from ddsp_amd import _lib, core
 from tests.hip_emu import emu_simt
 
@@ -28,17 +29,17 @@ def ddsp():
   if not os.path.exists(emu_simt.CLANG):
     pytest.skip('the SIMT emulation builds with the ROCm clang++ (%s), which this machine does not have' % emu_simt.CLANG)
   lib = emu_simt.load()
-  saved = (_lib.load, core._device, core._stream, dict(core._ws_bytes_cache), P.DEV, G.DEV)
+  saved = (_lib.load, core._device, core._stream, dict(core._ws_bytes_cache), P.DEV, G.DEV, R.DEV)
   _lib.load = lambda: lib
   core._device = lambda: torch.device('cpu')
   core._stream = lambda: None
   core._ws_bytes_cache.clear()
-  P.DEV = G.DEV = 'cpu'
+  P.DEV = G.DEV = R.DEV = 'cpu'
   yield ddsp_amd
   _lib.load, core._device, core._stream = saved[0], saved[1], saved[2]
   core._ws_bytes_cache.clear()
   core._ws_bytes_cache.update(saved[3])
-  P.DEV, G.DEV = saved[4], saved[5]
+  P.DEV, G.DEV, R.DEV = saved[4], saved[5], saved[6]
 
 
 @pytest.fixture(params=['auto', 'direct'])
@@ -60,12 +61,15 @@ def noise_kernel(request, ddsp):
 # Every test function of the two GPU modules is re-exported under its own name (so its parametrisation comes
 # along); the cases below are left to the GPU run - minutes each under the emulation (clips of 4 s at batch 32).
 # DDSP_EMU_ALL=1 runs them too (about 17 minutes in all; every one of them passes).
-for _module in (P, G):
+for _module in (P, G, R):
   for _name in dir(_module):
     if _name.startswith('test_') and callable(getattr(_module, _name)):
       globals()[_name] = getattr(_module, _name)
 
 SLOW_UNDER_EMULATION = () if os.environ.get('DDSP_EMU_ALL') == '1' else (
+    'test_processors_group_dag_construction',                          # 4 x 64 000 samples, 256 bands, a 48 000-tap reverb
+    'test_synths_filtered_noise_output_shape',                         # 26 s: 16 000 frames of one sample on the plain sum
+    'test_synths_harmonic_output_shape',
     'test_vst_48k_configuration_full_size',                            # minutes: 2 x 192 960 samples through every kernel
     'test_spectral_loss_on_the_synth_output_batch32',                  # 293 s
     'test_harmonic_backward_full_size_properties',                     # 210 s

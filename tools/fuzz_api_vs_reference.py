@@ -162,8 +162,8 @@ def case_resample(rng):
   shape = {1: (f,), 2: (2, f), 3: (2, f, int(rng.integers(1, 5))), 4: (2, f, 3, 2)}[rank]
   method = str(rng.choice(['nearest', 'linear', 'cubic', 'window', 'quadratic']))
   add_endpoint = maybe(rng)
-  n = int(rng.choice([f * int(rng.integers(1, 40)), int(rng.integers(1, f * 40 + 1)), max(1, f - 1)]))
-  x = rng.standard_normal(shape).astype(np.float32)
+  n = int(rng.choice([f * int(rng.integers(1, 40)), int(rng.integers(1, f * 40 + 1)), max(1, f - 1), int(rng.integers(1, f + 1))]))   # (down too:
+  x = rng.standard_normal(shape).astype(np.float32)                                                       #  core_test.py:268-290)
   what = dict(case='resample', shape=shape, n=n, method=method, add_endpoint=add_endpoint)
   return what, compare(what, lambda: Rcore.resample(x, n, method=method, add_endpoint=add_endpoint),
                        lambda: M.core.resample(x, n, method=method, add_endpoint=add_endpoint), 2e-5)
@@ -267,7 +267,7 @@ def case_spectral_loss(rng):
   kw = dict(fft_sizes=sizes, loss_type=str(rng.choice(['L1', 'L1', 'L2', 'COSINE', 'L3'])),
             mag_weight=float(rng.choice([1.0, 0.0])), logmag_weight=float(rng.choice([0.0, 1.0])),
             delta_time_weight=float(rng.choice([0.0, 0.0, 1.0])), delta_freq_weight=float(rng.choice([0.0, 0.0, 1.0])),
-            cumsum_freq_weight=float(rng.choice([0.0, 0.0, 1.0])))
+            cumsum_freq_weight=float(rng.choice([0.0, 0.0, 1.0])), loudness_weight=float(rng.choice([0.0, 0.0, 0.5])))
   t = (0.3 * rng.standard_normal((b, n))).astype(np.float32)
   x = (0.8 * t + 0.05 * rng.standard_normal((b, n))).astype(np.float32)
   what = dict(case='spectral_loss', b=b, n=n, **kw)

@@ -45,7 +45,7 @@ def case_resample(rng):
       return None
     n = hops * int(rng.integers(2, 80))
   else:
-    n = int(rng.integers(f, f * 100 + 1))
+    n = int(rng.integers(f, f * 100 + 1)) if rng.random() < 0.8 else int(rng.integers(1, f + 1))      # (downsampling too: core_test.py:268-290)
   x = rng.standard_normal((b, f, c)).astype(np.float32)
   what = dict(case='resample', b=b, f=f, c=c, n=n, method=method, add_endpoint=add_endpoint)
   ref = a(core.resample(x, n, method=method, add_endpoint=add_endpoint))
@@ -158,7 +158,7 @@ def case_loss(rng):
   sizes = tuple(int(s) for s in rng.permutation(all_sizes)[:int(rng.integers(1, 5))])
   kw = dict(mag_weight=float(rng.choice([1.0, 0.0, 0.5])), logmag_weight=float(rng.choice([1.0, 0.0, 0.5])),
             delta_time_weight=float(rng.choice([0.0, 0.0, 1.0])), delta_freq_weight=float(rng.choice([0.0, 0.0, 1.0])),
-            cumsum_freq_weight=float(rng.choice([0.0, 0.0, 1.0])))
+            cumsum_freq_weight=float(rng.choice([0.0, 0.0, 1.0])), loudness_weight=float(rng.choice([0.0, 0.0, 1.0])))
   loss_type = str(rng.choice(['L1', 'L1', 'L2', 'COSINE']))
   t = (0.3 * rng.standard_normal((b, n))).astype(np.float32)
   x = (0.8 * t + 0.05 * rng.standard_normal((b, n))).astype(np.float32)
