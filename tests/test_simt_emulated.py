@@ -70,6 +70,10 @@ SLOW_UNDER_EMULATION = () if os.environ.get('DDSP_EMU_ALL') == '1' else (
     'test_processors_group_dag_construction',                          # 4 x 64 000 samples, 256 bands, a 48 000-tap reverb
     'test_synths_filtered_noise_output_shape',                         # 26 s: 16 000 frames of one sample on the plain sum
     'test_synths_harmonic_output_shape',
+    # the reference's own accuracy tests at its own sizes (batch 16 x 4000 x 1 .. 2 x 32 000 x 5 on the stand-alone oscillator bank,
+    # one thread per sample and sinusoid under the emulation): 28 - 55 s each, on the GPU milliseconds
+    'test_core_oscillator_bank_is_accurate', 'test_core_harmonic_synthesis_multiple_harmonics', 'test_core_silent_above_nyquist',
+    'test_core_oscillator_bank_shape_is_correct',
     'test_vst_48k_configuration_full_size',                            # minutes: 2 x 192 960 samples through every kernel
     'test_spectral_loss_on_the_synth_output_batch32',                  # 293 s
     'test_harmonic_backward_full_size_properties',                     # 210 s
