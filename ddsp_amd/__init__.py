@@ -10,5 +10,6 @@ from ddsp_amd import effects
 from ddsp_amd import losses
 from ddsp_amd import processors
 from ddsp_amd import synths
+from ddsp_amd import spectral_ops
 
 __version__ = '0.1.0'

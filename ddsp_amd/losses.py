@@ -16,6 +16,19 @@ from ddsp_amd import _lib
 from ddsp_amd import core
 
 
+def a_weighting_linear(sample_rate, n_fft):
+  """10 ** (A_weighting / 10) at the bins of an n_fft-point transform: the A-curve librosa publishes (IEC 61672; clipped at -80 dB,
+  f = 0) - what spectral_ops.compute_loudness multiplies the power by (spectral_ops.py:307-312).  A constant table made on the
+  host in double precision, as every constant table of this library (oracle/ddsp_oracle.py::a_weighting_db restates the same
+  formula for the tests)."""
+  f_sq = (np.arange(n_fft // 2 + 1, dtype=np.float64) * (sample_rate / n_fft)) ** 2
+  c = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+  with np.errstate(divide='ignore'):
+    db = 2.0 + 20.0 * (np.log10(c[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + c[0]) - np.log10(f_sq + c[1])
+                       - 0.5 * np.log10(f_sq + c[2]) - 0.5 * np.log10(f_sq + c[3]))
+  return (10.0 ** (np.maximum(-80.0, db) / 10.0)).astype(np.float32)
+
+
 class Loss:
   """Base class. Duck typing: losses just must implement get_losses_dict() (losses.py:41-48)."""
 
@@ -163,19 +176,9 @@ class SpectralLoss(Loss):
 
   @classmethod
   def _loudness_weighting(cls, device):
-    """10 ** (A_weighting / 10) at the bins of the 2048-point transform: the A-curve librosa publishes (IEC 61672; clipped at
-    -80 dB, f = 0), a constant table made once per device in double precision - host arithmetic, as every constant table of
-    this library (oracle/ddsp_oracle.py::a_weighting_db restates the same formula for the tests)."""
     key = str(device)
     if key not in cls._a_weighting:
-      n_fft, sr = cls.LOUDNESS_N_FFT, cls.LOUDNESS_SAMPLE_RATE
-      f_sq = (np.arange(n_fft // 2 + 1, dtype=np.float64) * (sr / n_fft)) ** 2
-      c = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
-      with np.errstate(divide='ignore'):
-        db = 2.0 + 20.0 * (np.log10(c[0]) + 2 * np.log10(f_sq) - np.log10(f_sq + c[0]) - np.log10(f_sq + c[1])
-                           - 0.5 * np.log10(f_sq + c[2]) - 0.5 * np.log10(f_sq + c[3]))
-      w = 10.0 ** (np.maximum(-80.0, db) / 10.0)
-      cls._a_weighting[key] = torch.as_tensor(w.astype(np.float32), device=device)
+      cls._a_weighting[key] = torch.as_tensor(a_weighting_linear(cls.LOUDNESS_SAMPLE_RATE, cls.LOUDNESS_N_FFT), device=device)
     return cls._a_weighting[key]
 
   def _loudness_term(self, target_audio, audio, weights, loss, acc, grad_audio, first):

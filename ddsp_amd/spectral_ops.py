@@ -1,0 +1,123 @@
+"""Mirror of the spectral functions SpectralLoss is built from (ddsp/spectral_ops.py): compute_mag / compute_logmag
+(:67-70, 95-97), compute_loudness (:253-324), get_framed_lengths (:130-168) - the rows SURVEY.md section 8(f2) names.
+
+Forward only (the differentiable entry is losses.SpectralLoss); magnitudes come from the plain STFT kernels under a frame
+geometry given at run time (ddsp_stft_frames_mag_f32: csrc/spectral_loss.hip), so any `overlap` whose hop is a whole number of
+samples and both settings of `pad_end` run; `stft` itself - the complex spectrogram - is not offered (nothing on the path keeps
+phases), nor are the mel / MFCC / pitch functions (out of scope)."""
+import numpy as np
+import torch
+
+from ddsp_amd import _lib
+from ddsp_amd import core
+from ddsp_amd import losses
+
+DB_RANGE = 80.0
+
+
+def _audio_2d(audio):
+  audio = core.tf_float32(audio)
+  core.require_no_grad('spectral_ops (losses.SpectralLoss is the differentiable entry)', audio)
+  if audio.dim() == 3:
+    audio = audio[..., 0]
+  squeeze = audio.dim() == 1
+  if squeeze:
+    audio = audio[None, :]
+  if audio.dim() != 2:
+    raise ValueError('audio must be [batch, n_samples], [batch, n_samples, 1] or [n_samples], got {}'.format(tuple(audio.shape)))
+  return audio.contiguous(), squeeze
+
+
+def _frames_mag(audio, frame_size, hop, pad_left, n_frames):
+  """|tf.signal.stft| under a frame geometry: frames of frame_size samples every hop, the first pad_left samples before sample 0,
+  the enclosing power of two transformed (fft_length=None, spectral_ops.py:40-45)."""
+  b, n = audio.shape
+  fft_size = 1 << max(int(frame_size) - 1, 1).bit_length()
+  if fft_size != frame_size and 3 * fft_size != 4 * frame_size:
+    raise NotImplementedError('frame sizes are powers of two or 3 * 2**k on the MI355X path, got {}'.format(frame_size))
+  if fft_size != frame_size and (hop * 4 != frame_size or pad_left != 0):
+    raise NotImplementedError('frames of 3 * 2**k samples run at overlap 0.75 without padding in front')
+  if n_frames <= 0:
+    return torch.empty((b, 0, fft_size // 2 + 1), dtype=torch.float32, device=audio.device)
+  mag = torch.empty((b, n_frames, fft_size // 2 + 1), dtype=torch.float32, device=audio.device)
+  lib = _lib.load()
+  if fft_size == frame_size:
+    rc = lib.ddsp_stft_frames_mag_f32(audio.data_ptr(), mag.data_ptr(), b, n, fft_size, int(hop), int(pad_left), int(n_frames),
+                                      core._stream())
+    _lib.check(rc, 'ddsp_stft_frames_mag_f32')
+  else:                                                        # 3 * 2**k: the loss's own entry (one signal twice)
+    other = torch.empty_like(mag)
+    _lib.check(lib.ddsp_stft_mag_f32(audio.data_ptr(), audio.data_ptr(), other.data_ptr(), mag.data_ptr(), b, n, int(frame_size),
+                                     core._stream()), 'ddsp_stft_mag_f32')
+  return mag
+
+
+def get_framed_lengths(input_length, frame_size, hop_size, padding='center'):
+  """(n_frames, padded_length) of a strided framing (spectral_ops.py:130-168)."""
+  def get_n_frames(length):
+    return int(np.floor((length - frame_size) // hop_size)) + 1
+  if padding == 'valid':
+    padded_length = input_length
+    n_frames = get_n_frames(input_length)
+  elif padding == 'center':
+    padded_length = input_length + frame_size
+    n_frames = get_n_frames(padded_length)
+  elif padding == 'same':
+    n_frames = int(np.ceil(input_length / hop_size))
+    padded_length = (n_frames - 1) * hop_size + frame_size
+  else:
+    raise ValueError('`padding` must be one of [\'center\', \'same\', \'valid\'], received ({}).'.format(padding))
+  return n_frames, padded_length
+
+
+def compute_mag(audio, size=2048, overlap=0.75, pad_end=True):
+  """|STFT| [batch, n_frames, bins] (spectral_ops.py:67-70): frames of `size` every size * (1 - overlap) samples under a periodic
+  Hann window; pad_end: zero-padded frames up to the last sample (tf.signal.frame)."""
+  audio, squeeze = _audio_2d(audio)
+  n = audio.shape[1]
+  hop = int(size * (1.0 - overlap))
+  if hop <= 0:
+    raise ValueError('overlap {} leaves no hop for frames of {}'.format(overlap, size))
+  n_frames = -(-n // hop) if pad_end else (1 + (n - size) // hop if n >= size else 0)
+  mag = _frames_mag(audio, int(size), hop, 0, n_frames)
+  return mag[0] if squeeze else mag
+
+
+def compute_logmag(audio, size=2048, overlap=0.75, pad_end=True):
+  """core.safe_log of compute_mag (spectral_ops.py:95-97)."""
+  return core.safe_log(compute_mag(audio, size, overlap, pad_end))
+
+
+def compute_loudness(audio, sample_rate=16000, frame_rate=250, n_fft=512, range_db=DB_RANGE, ref_db=0.0, use_tf=True,
+                     padding='center'):
+  """Perceptual loudness in dB [batch, n_frames] (spectral_ops.py:253-324): A-weighted mean power per frame of n_fft samples every
+  sample_rate // frame_rate, floored at -range_db.  `use_tf` is accepted and ignored (one implementation)."""
+  del use_tf
+  audio, squeeze = _audio_2d(audio)
+  b, n = audio.shape
+  hop = sample_rate // frame_rate
+  if padding not in ('center', 'same', 'valid'):
+    raise ValueError('`padding` must be one of [\'center\', \'same\', \'valid\'], received ({}).'.format(padding))
+  if padding != 'valid' and hop > n_fft:
+    raise ValueError('During padding, frame_size ({}) must be greater than hop_size ({}).'.format(n_fft, hop))
+  n_frames, _ = get_framed_lengths(n, n_fft, hop, padding)
+  pad_left = n_fft // 2 if padding == 'center' else 0
+  mag = _frames_mag(audio, int(n_fft), hop, pad_left, max(n_frames, 0))
+  frames, bins = mag.shape[1], mag.shape[2]
+  loud = torch.empty((b, frames), dtype=torch.float32, device=audio.device)
+  if frames:
+    wt = _a_weighting(sample_rate, n_fft, audio.device)
+    _lib.check(_lib.load().ddsp_loudness_from_mag_f32(mag.data_ptr(), wt.data_ptr(), loud.data_ptr(), b, frames, bins,
+                                                      float(range_db), float(ref_db), core._stream()),
+               'ddsp_loudness_from_mag_f32')
+  return loud[0] if squeeze else loud
+
+
+_weighting_cache = {}
+
+
+def _a_weighting(sample_rate, n_fft, device):
+  key = (int(sample_rate), int(n_fft), str(device))
+  if key not in _weighting_cache:
+    _weighting_cache[key] = torch.as_tensor(losses.a_weighting_linear(sample_rate, n_fft), device=device)
+  return _weighting_cache[key]

@@ -363,3 +363,41 @@ def test_losses_spectral_loss_output_shape(ddsp):                            # l
   target_audio = np.ones((3, 8000), np.float32)
   loss = loss_obj(input_audio, target_audio)
   assert list(loss.shape) == [] and bool(torch.isfinite(loss))
+
+
+# ---- ddsp/spectral_ops_test.py: the loudness cases (the others test pitch / RMS / numpy twins: out of scope) ----------------------
+def _np_sinusoid(frequency, amp, sample_rate, audio_len_sec):               # spectral_ops_test.py: gen_np_sinusoid
+  x = np.linspace(0, audio_len_sec, int(audio_len_sec * sample_rate))
+  return amp * np.sin(2 * np.pi * frequency * x)
+
+
+@pytest.mark.parametrize('sample_rate,audio_len_sec', [(16000, .21), (24000, .21), (44100, .21), (16000, .4), (24000, .4), (44100, .4)])
+def test_spectral_ops_compute_loudness(ddsp, sample_rate, audio_len_sec):    # spectral_ops_test.py:176-197
+  frame_rate, frame_size, padding = 250, 512, 'center'
+  audio_sin = _np_sinusoid(440.0, 0.75, sample_rate, audio_len_sec)
+  expected_len, _ = ddsp.spectral_ops.get_framed_lengths(audio_sin.shape[-1], frame_size, int(sample_rate // frame_rate), padding)
+  loudness = npy(ddsp.spectral_ops.compute_loudness(audio_sin, sample_rate, frame_rate, frame_size, padding=padding))
+  assert len(loudness) == expected_len and np.all(np.isfinite(loudness))
+  ref = O.compute_loudness(audio_sin[None, :], sample_rate, frame_rate, frame_size, dtype=np.float64)[0]
+  np.testing.assert_allclose(loudness, ref, rtol=0, atol=2e-3)               # dB
+
+
+@pytest.mark.parametrize('padding', ['same', 'valid', 'center'])
+def test_spectral_ops_compute_loudness_padding(ddsp, padding):               # spectral_ops_test.py:199-216
+  sample_rate, frame_rate, frame_size = 16000, 250, 512
+  audio_sin = _np_sinusoid(440.0, 0.75, sample_rate, 0.21)
+  expected_len, _ = ddsp.spectral_ops.get_framed_lengths(audio_sin.shape[-1], frame_size, int(sample_rate // frame_rate), padding)
+  loudness = npy(ddsp.spectral_ops.compute_loudness(audio_sin, sample_rate, frame_rate, frame_size, padding=padding))
+  assert len(loudness) == expected_len and np.all(np.isfinite(loudness))
+
+
+def test_spectral_ops_compute_mag_matches_the_oracle(ddsp):                  # spectral_ops.py:67-70, 95-97
+  rng = np.random.default_rng(3)
+  x = (0.3 * rng.standard_normal((2, 3000))).astype(np.float32)
+  for kw in (dict(size=2048), dict(size=256, overlap=0.5), dict(size=64, pad_end=False), dict(size=192), dict(size=512, overlap=0.875)):
+    ref = O.compute_mag(x, kw['size'], kw.get('overlap', 0.75), kw.get('pad_end', True), dtype=np.float64)
+    got = npy(ddsp.spectral_ops.compute_mag(x, **kw))
+    assert got.shape == ref.shape, kw
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(1.0, float(ref.max())), err_msg=str(kw))
+  np.testing.assert_allclose(npy(ddsp.spectral_ops.compute_logmag(x, 256)), O.safe_log(O.compute_mag(x, 256, dtype=np.float64)),
+                             rtol=0, atol=2e-3)

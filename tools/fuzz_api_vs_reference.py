@@ -362,9 +362,31 @@ def case_synthesis(rng):
   return what, compare(what, lambda: wrapped(Rcore.streaming_harmonic_synthesis(fr, am, **kw)), lambda: wrapped(M.core.streaming_harmonic_synthesis(fr, am, **kw)), 2e-3)
 
 
+def case_spectral_ops(rng):
+  from ddsp import spectral_ops as RS
+  b, n = int(rng.integers(1, 3)), int(rng.integers(100, 5000))
+  x = (0.3 * rng.standard_normal((b, n))).astype(np.float32)
+  if maybe(rng):
+    size = int(rng.choice([64, 256, 512, 2048, 192, 768])); pow2 = not size & (size - 1)
+    overlap = float(rng.choice([0.75, 0.5, 0.875])) if pow2 else 0.75
+    pad_end = maybe(rng, 0.7) if pow2 else True
+    what = dict(case='spectral_ops', fn='compute_mag', b=b, n=n, size=size, overlap=overlap, pad_end=pad_end)
+    if not pad_end and n < size:
+      return what, 'skipped (no frame fits)'
+    return what, compare(what, lambda: RS.compute_mag(x, size, overlap, pad_end), lambda: M.spectral_ops.compute_mag(x, size, overlap, pad_end), 3e-6)
+  kw = dict(sample_rate=int(rng.choice([16000, 24000, 44100])), frame_rate=int(rng.choice([250, 100, 50])),
+            n_fft=int(rng.choice([512, 1024, 2048])), range_db=float(rng.choice([80.0, 120.0])), ref_db=float(rng.choice([0.0, 20.7])),
+            padding=str(rng.choice(['center', 'same', 'valid', 'bogus'])))
+  what = dict(case='spectral_ops', fn='compute_loudness', b=b, n=n, **kw)
+  if kw['padding'] == 'valid' and n < kw['n_fft']:
+    return what, 'skipped (no frame fits)'
+  return what, compare(what, lambda: RS.compute_loudness(x, **kw), lambda: M.spectral_ops.compute_loudness(x, **kw), 1e-4)     # (dB: 0.012 at -120)
+
+
 CASES = dict(harmonic=case_harmonic, filtered_noise=case_filtered_noise, resample=case_resample,
              upsample_with_windows=case_upsample_with_windows, fft_convolve=case_fft_convolve, reverb=case_reverb,
-             small_core=case_small_core, spectral_loss=case_spectral_loss, processors=case_processors, synthesis=case_synthesis)
+             small_core=case_small_core, spectral_loss=case_spectral_loss, processors=case_processors, synthesis=case_synthesis,
+             spectral_ops=case_spectral_ops)
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
