@@ -696,6 +696,25 @@ def frequency_impulse_response(magnitudes, window_size=0):
   return ir[:, 0, :] if squeeze else ir
 
 
+def apply_window_to_impulse_response(impulse_response, window_size=0, causal=False):
+  """core.apply_window_to_impulse_response (ddsp/core.py:1477-1531): Hann-window a series of zero-phase (`causal`: causal)
+  impulse responses [..., ir_size] and return them causal, cropped to the window when it is shorter."""
+  impulse_response = tf_float32(impulse_response)
+  require_no_grad('core.apply_window_to_impulse_response', impulse_response)
+  if impulse_response.dim() < 1 or impulse_response.shape[-1] < 1:
+    raise ValueError('impulse_response must be [..., ir_size], got {}'.format(tuple(impulse_response.shape)))
+  l0 = int(impulse_response.shape[-1])
+  lib = _lib.load()
+  l = lib.ddsp_window_impulse_response_size(l0, int(window_size))
+  flat = impulse_response.reshape(-1, l0).contiguous()
+  out = torch.empty((flat.shape[0], l), dtype=torch.float32, device=flat.device)
+  if flat.shape[0]:
+    rc = lib.ddsp_apply_window_to_impulse_response_f32(flat.data_ptr(), out.data_ptr(), flat.shape[0], l0, int(window_size),
+                                                       1 if causal else 0, _stream())
+    _lib.check(rc, 'ddsp_apply_window_to_impulse_response_f32')
+  return out.reshape(tuple(impulse_response.shape[:-1]) + (l,))
+
+
 def _crop_range(audio_size, n_ir_frames, ir_size, padding, delay_compensation):
   """(start as requested, first kept index, number of kept samples) of the slice
   crop_and_compensate_delay (ddsp/core.py:1338-1379) takes from the overlap-added FFT frames of

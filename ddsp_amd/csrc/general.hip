@@ -597,6 +597,56 @@ extern "C" int ddsp_resample_ex_backward_f32(const float* grad_out, float* grad_
   return check_launch();
 }
 
+// =====================================================================================
+// core.apply_window_to_impulse_response (ddsp/core.py:1477-1531) on its own, for any impulse-response length (the fused IR
+// designs of FilteredNoise know it for irfft outputs only): zero-phase (or causal -> fftshift first) responses [rows, L0] ->
+// Hann-windowed, causal, cropped responses [rows, L].  Index arithmetic of the reference's concat / fftshift calls, one
+// element per thread.
+// =====================================================================================
+struct WinIrArgs { long rows; int L0, L, ws, padding, half, first_len, causal; };
+
+__global__ __launch_bounds__(kThreads) void window_ir_kernel(const float* __restrict__ ir, float* __restrict__ out, WinIrArgs p) {
+  const size_t total = (size_t)p.rows * p.L;
+  for (size_t i = global_thread(); i < total; i += grid_threads()) {
+    const long row = (long)(i / p.L);
+    const int kappa = (int)(i - (size_t)row * p.L);
+    int j;                                                       // index into the windowed zero-phase response
+    if (p.padding > 0) j = kappa < p.first_len ? p.L0 - p.half + 2 + kappa : kappa - p.first_len;      // concat(w[L0-half+2:], w[:half+1])
+    else j = (kappa - p.L0 / 2 + p.L0) % p.L0;                                                       // fftshift
+    int wi;                                                      // window index at j, or -1 (the zero padding)
+    if (p.padding > 0) wi = j < p.ws - p.half ? p.half + j : (j >= p.L0 - p.half ? j - (p.L0 - p.half) : -1);
+    else wi = (j - p.ws / 2 + p.ws) % p.ws;                                                           // fftshift(window)
+    const int src = p.causal ? (j - p.L0 / 2 + p.L0) % p.L0 : j;                                      // causal input: fftshift first
+    const float w = wi < 0 ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)wi / (float)p.ws);
+    out[i] = w * ir[(size_t)row * p.L0 + src];
+  }
+}
+
+extern "C" int ddsp_window_impulse_response_size(int L0, int window_size) {
+  if (L0 <= 0) return DDSP_ERR_BAD_SHAPE;
+  const int ws = (window_size <= 0 || window_size > L0) ? L0 : window_size;
+  if (ws == L0) return L0;
+  const int half = (ws + 1) / 2;
+  const int first_len = L0 - (L0 - half + 2) > 0 ? L0 - (L0 - half + 2) : 0;
+  return first_len + (half + 1 < L0 ? half + 1 : L0);
+}
+
+extern "C" int ddsp_apply_window_to_impulse_response_f32(const float* impulse_response, float* out, long rows, int L0,
+                                                         int window_size, int causal, void* stream) {
+  if (!impulse_response || !out) return DDSP_ERR_NULL_POINTER;
+  if (rows <= 0 || L0 <= 0) return DDSP_ERR_BAD_SHAPE;
+  WinIrArgs p;
+  p.rows = rows; p.L0 = L0; p.causal = causal ? 1 : 0;
+  p.ws = (window_size <= 0 || window_size > L0) ? L0 : window_size;
+  p.padding = L0 - p.ws;
+  p.half = (p.ws + 1) / 2;
+  p.first_len = p.half > 2 ? p.half - 2 : 0;
+  p.L = ddsp_window_impulse_response_size(L0, window_size);
+  hipLaunchKernelGGL(window_ir_kernel, dim3(grid_for((size_t)rows * p.L)), dim3(kThreads), 0, (hipStream_t)stream,
+                     impulse_response, out, p);
+  return check_launch();
+}
+
 extern "C" int ddsp_fft_convolve_f32(const float* audio, const float* impulse_response, float* out, int B,
                                      int Bir, int F, int L, int N, int n_out, int start, void* stream) {
   if (!audio || !impulse_response || !out) return DDSP_ERR_NULL_POINTER;

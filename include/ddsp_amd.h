@@ -197,6 +197,11 @@ int ddsp_filtered_noise_controls_f32(const float* magnitudes, float* ctl_magnitu
  * windowed FIR taps [B,F,L].  ddsp_fir_size() gives L for (M, window_size).
  */
 int ddsp_fir_size(int M, int window_size);
+/* core.apply_window_to_impulse_response (core.py:1477-1531) on its own, any response length: [rows, L0] zero-phase (causal != 0:
+ * causal) responses -> [rows, ddsp_window_impulse_response_size(L0, window_size)] windowed causal ones. */
+int ddsp_window_impulse_response_size(int L0, int window_size);
+int ddsp_apply_window_to_impulse_response_f32(const float* impulse_response, float* out, long rows, int L0, int window_size,
+                                              int causal, void* stream);
 int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* impulse_response,
                                         int B, int F, int M, int window_size, void* stream);
 

@@ -492,3 +492,23 @@ def test_filtered_noise_with_fewer_than_three_bands_crops_like_the_reference(dds
   # three bands: a 4-tap filter, the ordinary path
   mags = rng.standard_normal((2, 10, 3)).astype(np.float32)
   assert tuple(ddsp.synths.FilteredNoise(n_samples=640, window_size=0)(mags).shape) == (2, 640)
+
+
+def test_apply_window_to_impulse_response_standalone(ddsp):       # core.py:1477-1531 on its own
+  """Any response length and window, zero-phase or causal input: the index arithmetic of the reference's concat / fftshift calls
+  against the oracle's restatement of them (itself compared with the reference's source on 400 random draws by
+  tools/fuzz_api_vs_reference.py) - including windows of one and two samples and odd lengths."""
+  rng = np.random.default_rng(12)
+  for l0, ws, causal, shape in ((128, 0, False, (2, 5, 128)), (128, 65, False, (2, 5, 128)), (198, 257, True, (3, 198)),
+                                (64, 16, False, (1, 64)), (33, 7, True, (2, 2, 33)), (10, 2, False, (4, 10)), (10, 1, True, (4, 10)),
+                                (7, 5, False, (2, 7)), (2048, 257, False, (2, 3, 2048))):
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = O.apply_window_to_impulse_response(x, ws, causal, dtype=np.float64)
+    got = npy(ddsp.core.apply_window_to_impulse_response(x, ws, causal))
+    assert got.shape == ref.shape, (l0, ws, causal)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=str((l0, ws, causal)))
+  # frequency_impulse_response is irfft + this function
+  mags = np.abs(rng.standard_normal((2, 4, 65))).astype(np.float32)
+  zero_phase = np.fft.irfft(mags.astype(np.float64)).astype(np.float32)
+  np.testing.assert_allclose(npy(ddsp.core.apply_window_to_impulse_response(zero_phase, 33)),
+                             npy(ddsp.core.frequency_impulse_response(mags, 33)), rtol=0, atol=2e-6)

@@ -215,8 +215,13 @@ def case_reverb(rng):
 
 def case_small_core(rng):
   which = str(rng.choice(['exp_sigmoid', 'safe_divide', 'safe_log', 'get_harmonic_frequencies', 'remove_above_nyquist',
-                          'normalize_harmonics', 'get_fft_size', 'crop', 'angular_cumsum', 'add']))
+                          'normalize_harmonics', 'get_fft_size', 'crop', 'angular_cumsum', 'add', 'apply_window']))
   what = dict(case='small_core', fn=which)
+  if which == 'apply_window':
+    l0 = int(rng.integers(1, 300)); ws = int(rng.choice([0, 1, 2, 3, l0, l0 + 3, max(1, l0 // 2), int(rng.integers(1, 320))])); causal = maybe(rng)
+    x = rng.standard_normal((2, 3, l0) if maybe(rng) else (4, l0)).astype(np.float32)
+    what.update(l0=l0, ws=ws, causal=causal)
+    return what, compare(what, lambda: Rcore.apply_window_to_impulse_response(x, ws, causal), lambda: M.core.apply_window_to_impulse_response(x, ws, causal), 2e-6)
   if which == 'exp_sigmoid':
     x = (10.0 * rng.standard_normal((2, 7, 3))).astype(np.float32)
     kw = dict(exponent=float(rng.choice([10.0, 2.0])), max_value=float(rng.choice([2.0, 1.0])), threshold=float(rng.choice([1e-7, 1e-3])))
