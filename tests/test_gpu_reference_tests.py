@@ -401,3 +401,16 @@ def test_spectral_ops_compute_mag_matches_the_oracle(ddsp):                  # s
     np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(1.0, float(ref.max())), err_msg=str(kw))
   np.testing.assert_allclose(npy(ddsp.spectral_ops.compute_logmag(x, 256)), O.safe_log(O.compute_mag(x, 256, dtype=np.float64)),
                              rtol=0, atol=2e-3)
+
+
+def test_losses_loss_group_dag(ddsp):                                        # losses_test.py: LossGroupTest (its CREPE loss: out of scope)
+  nn_outputs = {'audio': np.ones((3, 8000), np.float32), 'audio_synth': np.ones((3, 8000), np.float32),
+                'magnitudes': np.ones((3, 200, 2), np.float32), 'f0_hz': 200 + np.ones((3, 200, 1), np.float32)}
+  second = ddsp.losses.SpectralLoss(fft_sizes=(256, 64), logmag_weight=1.0, name='spectral_loss_small')
+  loss_group = ddsp.losses.LossGroup(dag=[(ddsp.losses.SpectralLoss(), ['audio', 'audio_synth']), (second, ['audio', 'audio_synth'])])
+  assert loss_group.loss_names == ['spectral_loss', 'spectral_loss_small'] and len(loss_group.losses) == 2
+  loss_outputs = loss_group(nn_outputs)
+  assert isinstance(loss_outputs, dict) and list(loss_outputs) == ['spectral_loss', 'spectral_loss_small']
+  for name in loss_outputs:
+    assert isinstance(loss_outputs[name], torch.Tensor) and float(loss_outputs[name]) == 0.0
+  assert list(loss_group.get_losses_dict(nn_outputs)) == list(loss_outputs)
