@@ -2157,3 +2157,31 @@ def test_harmonic_frame_sizes_that_are_not_multiples_of_64(ddsp, hop, k):
     np.testing.assert_array_equal(npy(synth(amps[1:2], hd[1:2], f0[1:2])), full[1:2])
     z = rng.standard_normal((b, n)).astype(np.float32)
     np.testing.assert_array_equal(npy(synth.call_add(amps, hd, f0, z)), full + z)
+
+
+def test_frame_rate_nyquist_mask_takes_the_reference_fp32_side(ddsp, harm_kernel):
+  """f0 = fp32(8000 / 75) = 106.666664 Hz at 16 kHz: harmonic 75 is 7999.9998 Hz in exact arithmetic - below Nyquist - and 8000.0
+  in the fp32 product the reference forms (get_harmonic_frequencies, remove_above_nyquist: core.py:1028-1045, 869-891): masked,
+  and normalize_harmonics (core.py:894-907) then divides the distribution by the sum of the OTHER harmonics.  The kernels take
+  the reference's side, for the whole clip (tools/fuzz_parity.py met this as a 'failure' of its fp64 checker: an f0 sweep whose
+  steps land on 8000 / k).  With equal weight on harmonics 10 and 75: harmonic 10 at amplitude 1, where exact arithmetic keeps
+  both alive and gives it 1/2."""
+  f0_value = np.float32(8000.0 / 75.0)
+  assert np.float32(f0_value * np.float32(75.0)) == np.float32(8000.0) and float(f0_value) * 75.0 < 8000.0
+  b, f, k, hop = 1, 8, 100, 64
+  n = f * hop
+  amps = np.ones((b, f, 1), np.float32)
+  hd = np.zeros((b, f, k), np.float32); hd[:, :, 9] = 1.0; hd[:, :, 74] = 1.0
+  f0 = np.full((b, f, 1), f0_value, np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=16000, scale_fn=None)
+  full = synth(amps, hd, f0, return_outputs_dict=True)
+  out = npy(full['signal'])
+  t = np.arange(1, n + 1) / 16000.0
+  fp32_side = np.sin(2 * np.pi * 10 * float(f0_value) * t)[None]           # harmonic 10 alone, the whole amplitude
+  np.testing.assert_allclose(out, fp32_side, rtol=0, atol=HARM_TRUTH_ATOL)
+  ctl = npy(full['controls']['harmonic_distribution'])
+  assert np.all(ctl[..., 9] == 1.0) and np.all(ctl[..., 74] == 0.0)
+  faithful = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=16000, scale_fn=None, dtype=np.float32)
+  np.testing.assert_allclose(out, faithful, rtol=0, atol=HARM_FAITHFUL_ATOL)      # the reference's own fp32 chain agrees
+  exact = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=16000, scale_fn=None, dtype=np.float64)
+  assert np.abs(out - exact).max() > 0.4                      # ... fp64 hears harmonic 10 at half the amplitude
