@@ -51,6 +51,9 @@ harmonic_case('Harmonic, 99 harmonics (processors_test.py): the wavetable kernel
 harmonic_case('Harmonic, 100 harmonics, 250 frames of 256 samples', 100, 250, 64000)
 harmonic_case('Harmonic, 100 harmonics, 640 frames of 100 samples (hop not a multiple of 64: the wavetable kernel with masked tiles since round 4)', 100, 640, 64000)
 harmonic_case('Harmonic, 160 harmonics at 32 kHz (K > 128: the ten-tap wavetable instances)', 160, 1000, 64000, sr=32000, f0c=70.0)
+harmonic_case('Harmonic, 200 harmonics at 48 kHz (the last band count of the wavetable kernel)', 200, 1000, 64000, sr=48000, f0c=70.0)
+harmonic_case('Harmonic, 256 harmonics at 48 kHz (201 … 256: the direct sum, harm_fused_kernel)', 256, 1000, 64000, sr=48000, f0c=70.0)
+harmonic_case('Harmonic, 400 harmonics at 48 kHz, f0 = 50 Hz (257 … 512: the plain kernels, envelopes through HBM)', 400, 1000, 64000, sr=48000, f0c=50.0)
 noise_case('FilteredNoise, 65 magnitudes, 1000 frames of 64 (the fast path, for comparison)', 65, 1000, 64000)
 noise_case('FilteredNoise, 100 magnitudes (synths_test.py): 198-tap IR - one launch, taps designed per tile in LDS (filtered_noise_general.hip)', 100, 1000, 64000)
 noise_case('FilteredNoise, 256 magnitudes: 510-tap IR - IR design as a matrix product + Toeplitz FIR on the matrix cores (two launches)', 256, 1000, 64000)
