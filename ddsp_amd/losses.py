@@ -3,8 +3,9 @@
 SURVEY.md section 8(f) rank 2.  What `gin/models/ae.gin:36-41` uses - loss_type 'L1' with the magnitude and
 log-magnitude terms - runs fused kernels whose spectra never leave LDS (csrc/spectral_loss.hip).  The rest of the
 reference's argument space - delta_time / delta_freq / cumsum_freq terms, 'L2' and 'COSINE', the `weights` mask -
-runs on spectrograms materialised in HBM, one FFT size at a time (csrc/spectral_terms.hip).  `loudness_weight` needs
-spectral_ops.compute_loudness (A-weighting through librosa: out of scope) and raises.
+runs on spectrograms materialised in HBM, one FFT size at a time (csrc/spectral_terms.hip); the loudness term
+(spectral_ops.compute_loudness, spectral_ops.py:253-324) likewise, under its own frame geometry.  `mean_difference` is the
+reference's public function on the same kernels.
 The call is a torch.autograd node: the gradient reaches `audio` (not `target_audio`, as a training step needs it).
 """
 import ctypes
@@ -66,6 +67,112 @@ class LossGroup(dags.DAGLayer):
 
   def get_losses_dict(self, outputs, **kwargs):
     return self(outputs, **kwargs)
+
+
+_MD_MAX_LAST = 4097                    # kStMaxBins of csrc/spectral_terms.hip: the longest row a block of the term kernels holds
+_md_ws = core.Workspace()
+
+
+def _md_view(shape):
+  """Any shape -> the [batch, rows, last axis] view the term kernels take (the last axis is what 'COSINE' reduces)."""
+  shape = tuple(int(v) for v in shape)
+  if len(shape) == 0:
+    return 1, 1, 1
+  if len(shape) == 1:
+    return 1, 1, shape[0]
+  rows = 1
+  for v in shape[1:-1]:
+    rows *= v
+  return shape[0], rows, shape[-1]
+
+
+def _md_raw(target, value, loss_type, weights, want_grad):
+  """One call of ddsp_spectral_terms_f32 with the magnitude term alone: (loss, d loss / d value or None)."""
+  dev = value.device
+  loss = torch.empty((), dtype=torch.float32, device=dev)
+  if value.numel() == 0:
+    # tf.reduce_mean over no elements is NaN; cosine_distance's weighted mean divides safely: 0 (losses.py:118-124)
+    loss.fill_(0.0 if loss_type == 'COSINE' else float('nan'))
+    return loss, (torch.zeros_like(value) if want_grad else None)
+  b, f, k = _md_view(value.shape)
+  w = None
+  if weights is not None:
+    w = core.tf_float32(weights if isinstance(weights, torch.Tensor) else torch.as_tensor(weights, dtype=torch.float32))
+    core.require_no_grad('mean_difference weights', w)
+    if w.numel() == 1:
+      w = w.reshape(1, 1, 1).contiguous()
+    else:
+      # `difference * weights` ('L1' / 'L2') or weights against [..., 1] ('COSINE'): materialised at the shape it multiplies
+      full = tuple(value.shape[:-1]) + (1,) if loss_type == 'COSINE' else tuple(value.shape)
+      if w.dim() > len(full):
+        raise ValueError('weights of shape {} do not broadcast against {}'.format(tuple(w.shape), full))
+      try:
+        w = w.expand(full).contiguous()
+      except RuntimeError:
+        raise ValueError('weights of shape {} do not broadcast against {}'.format(tuple(w.shape), full))
+      w = w.reshape(b, f, 1 if loss_type == 'COSINE' else k)
+  if k > _MD_MAX_LAST:
+    if loss_type == 'COSINE':
+      raise NotImplementedError('mean_difference(COSINE) along an axis of more than {} elements is not built on the MI355X '
+                                'path (got {})'.format(_MD_MAX_LAST, k))
+    # 'L1' / 'L2' are means over every element: any factorisation of the element count serves (the mask, materialised, with it)
+    total = b * f * k
+    cols = next(c for c in range(4096, 0, -1) if total % c == 0)
+    b, f, k = 1, total // cols, cols
+    if w is not None and w.numel() != 1:
+      w = w.reshape(b, f, k)
+  acc = torch.empty((), dtype=torch.float64, device=dev)
+  grad = torch.empty_like(value) if want_grad else None
+  ws = _md_ws.get(core.cached_workspace_bytes('ddsp_spectral_terms_workspace_bytes', b, f), dev)
+  wb, wf, wk = (int(v) for v in w.shape) if w is not None else (0, 0, 0)
+  rc = _lib.load().ddsp_spectral_terms_f32(
+      target.data_ptr(), value.data_ptr(), w.data_ptr() if w is not None else None, wb, wf, wk,
+      grad.data_ptr() if want_grad else None, acc.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(), b, f, k,
+      _lib.LOSS_TYPES[loss_type], 1.0, 0.0, 0.0, 0.0, 0.0, 1, core._stream())
+  _lib.check(rc, 'ddsp_spectral_terms_f32')
+  return loss, grad
+
+
+class _MeanDifferenceFunction(torch.autograd.Function):
+  """torch.autograd node of mean_difference.  Every loss type is symmetric in its two arguments, so d / d target is d / d value
+  of the call with the arguments exchanged."""
+
+  @staticmethod
+  def forward(ctx, target, value, loss_type, weights):
+    loss, grad_value = _md_raw(target, value, loss_type, weights, ctx.needs_input_grad[1])
+    grad_target = _md_raw(value, target, loss_type, weights, True)[1] if ctx.needs_input_grad[0] else None
+    ctx.has = (grad_target is not None, grad_value is not None)
+    ctx.save_for_backward(*[g for g in (grad_target, grad_value) if g is not None])
+    return loss
+
+  @staticmethod
+  def backward(ctx, grad_loss):
+    saved = list(ctx.saved_tensors)
+    grad_target = _scale(saved.pop(0), grad_loss) if ctx.has[0] else None
+    grad_value = _scale(saved.pop(0), grad_loss) if ctx.has[1] else None
+    return grad_target, grad_value, None, None
+
+
+def mean_difference(target, value, loss_type='L1', weights=None):
+  """Common loss functions (ddsp/losses.py:102-128): the mean of |difference * weights| ('L1') or difference**2 * weights ('L2'),
+  or tf.losses.cosine_distance along the last axis ('COSINE') - on the kernels SpectralLoss's general form runs its terms on
+  (ddsp_spectral_terms_f32: fixed-order fp64 sums), differentiable in `target` and `value`.
+
+  Raises:
+    ValueError: If loss_type is not an allowed value.
+  """
+  loss_type = loss_type.upper()
+  if loss_type not in _lib.LOSS_TYPES:
+    raise ValueError('Loss type ({}), must be '
+                     '"L1", "L2", or "COSINE"'.format(loss_type))
+  target, value = core.tf_float32(target), core.tf_float32(value)
+  if target.shape != value.shape:
+    core.require_no_grad('mean_difference of tensors that broadcast against each other', target, value)
+    target, value = torch.broadcast_tensors(target, value)
+  target, value = target.contiguous(), value.contiguous()
+  if torch.is_grad_enabled() and (target.requires_grad or value.requires_grad):
+    return _MeanDifferenceFunction.apply(target, value, loss_type, weights)
+  return _md_raw(target, value, loss_type, weights, False)[0]
 
 
 class SpectralLoss(Loss):

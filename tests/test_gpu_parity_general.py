@@ -512,3 +512,61 @@ def test_apply_window_to_impulse_response_standalone(ddsp):       # core.py:1477
   zero_phase = np.fft.irfft(mags.astype(np.float64)).astype(np.float32)
   np.testing.assert_allclose(npy(ddsp.core.apply_window_to_impulse_response(zero_phase, 33)),
                              npy(ddsp.core.frequency_impulse_response(mags, 33)), rtol=0, atol=2e-6)
+
+
+def test_mean_difference_public_function(ddsp):                      # losses.py:102-128, on its own
+  """The reference's public loss helper on tensors of any rank, with and without a mask, against the oracle's restatement in
+  fp64 - value (2e-6 relative: fixed-order fp64 sums of fp32 terms) and the gradients with respect to BOTH arguments
+  (closed forms: -/+ sign(d w) w / n, -/+ 2 d w / n, - other * w / count of non-zero weights)."""
+  rng = np.random.default_rng(21)
+  md = ddsp.losses.mean_difference
+  with pytest.raises(ValueError, match='must be "L1", "L2", or "COSINE"'):
+    md(np.zeros((2, 3), np.float32), np.zeros((2, 3), np.float32), loss_type='L3')
+  cases = [((7,), None), ((3, 5), None), ((2, 6, 9), None), ((2, 3, 4, 5), None), ((2, 6, 9), 0.25), ((2, 6, 9), (2, 6, 9)),
+           ((2, 6, 9), (2, 1, 1)), ((2, 6, 9), (6, 1)), ((2, 3, 4, 5), (3, 1, 1)), ((3, 5000), None), ((2, 3, 4099), (2, 3, 1))]
+  if DEV == 'cpu':                  # (the emulation spends 25 s on the two long rows: one of them, shorter)
+    cases = cases[:-2] + [((1, 4100), None)]
+  for shape, wshape in cases:
+    t = rng.standard_normal(shape).astype(np.float32)
+    v = rng.standard_normal(shape).astype(np.float32)
+    for loss_type in ('L1', 'l2', 'COSINE'):
+      if loss_type == 'COSINE' and shape[-1] > 4097:
+        with pytest.raises(NotImplementedError):
+          md(t, v, loss_type=loss_type)
+        continue
+      w = wshape
+      if isinstance(wshape, tuple):
+        if loss_type == 'COSINE':
+          if wshape[-1] != 1 and wshape != (2, 6, 9):
+            continue
+          w = np.abs(rng.standard_normal(wshape[:-1] + (1,))).astype(np.float32)
+          w.flat[0] = 0.0                                               # (a zero weight leaves the count of the mean)
+        else:
+          w = rng.standard_normal(wshape).astype(np.float32)            # (negative weights too: |difference * weights|)
+      ref = float(O.mean_difference(t.astype(np.float64), v.astype(np.float64), loss_type,
+                                    None if w is None else np.asarray(w, np.float64)))
+      tt = torch.tensor(t, device=DEV, requires_grad=True)
+      vv = torch.tensor(v, device=DEV, requires_grad=True)
+      wt = None if w is None else (w if isinstance(w, float) else torch.tensor(w, device=DEV))
+      loss = md(tt, vv, loss_type=loss_type, weights=wt)
+      assert loss.shape == ()
+      assert abs(float(loss.detach()) - ref) <= 2e-6 * max(1.0, abs(ref)), (shape, wshape, loss_type, float(loss.detach()), ref)
+      assert float(md(t, v, loss_type=loss_type, weights=wt)) == float(loss.detach())            # numpy in, no graph: the same bits
+      (3.0 * loss).backward()
+      d = t.astype(np.float64) - v
+      wf = np.broadcast_to(np.asarray(1.0 if w is None else w, np.float64), d.shape if loss_type != 'COSINE' else d.shape[:-1] + (1,))
+      if loss_type == 'L1':
+        gt = np.sign(d * wf) * wf / d.size
+        gv = -gt
+      elif loss_type == 'l2':
+        gt = 2.0 * d * wf / d.size
+        gv = -gt
+      else:
+        present = max(np.count_nonzero(wf), 1)
+        gt, gv = -v * wf / present, -t * wf / present
+      for got, want, what in ((tt.grad, gt, 'target'), (vv.grad, gv, 'value')):
+        np.testing.assert_allclose(npy(got), 3.0 * want, rtol=0, atol=3e-6 * max(1e-30, float(np.abs(want).max())) * 3.0 + 1e-12,
+                                   err_msg=str((shape, wshape, loss_type, what)))
+  # no elements: tf.reduce_mean gives NaN, cosine_distance's safe mean 0
+  empty = np.zeros((2, 0, 4), np.float32)
+  assert np.isnan(float(md(empty, empty))) and float(md(empty, empty, 'COSINE')) == 0.0

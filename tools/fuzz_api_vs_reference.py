@@ -390,10 +390,33 @@ def case_spectral_ops(rng):
   return what, compare(what, lambda: RS.compute_loudness(x, **kw), lambda: M.spectral_ops.compute_loudness(x, **kw), 1e-4)     # (dB: 0.012 at -120)
 
 
+def case_mean_difference(rng):
+  from ddsp import losses as RL
+  rank = int(rng.integers(1, 5))
+  shape = tuple(int(rng.integers(1, 7)) for _ in range(rank))
+  t = rng.standard_normal(shape).astype(np.float32)
+  v = rng.standard_normal(shape).astype(np.float32)
+  loss_type = str(rng.choice(['L1', 'L2', 'COSINE', 'l1', 'cosine', 'L3']))
+  kind = str(rng.choice(['none', 'scalar', 'full', 'rows', 'lead']))
+  if kind == 'none':
+    w = None
+  elif kind == 'scalar':
+    w = float(rng.uniform(0.0, 2.0))
+  else:
+    wshape = {'full': shape, 'rows': shape[:-1] + (1,), 'lead': (shape[0],) + (1,) * (rank - 1)}[kind]
+    if loss_type.upper() == 'COSINE':
+      wshape = wshape[:-1] + (1,)                  # (cosine_distance's weights go against [..., 1])
+    w = rng.standard_normal(wshape).astype(np.float32)
+    if maybe(rng, 0.3):
+      w.flat[0] = 0.0
+  what = dict(case='mean_difference', shape=shape, loss_type=loss_type, weights=kind)
+  return what, compare(what, lambda: RL.mean_difference(t, v, loss_type, w), lambda: M.losses.mean_difference(t, v, loss_type, w), 3e-6)
+
+
 CASES = dict(harmonic=case_harmonic, filtered_noise=case_filtered_noise, resample=case_resample,
              upsample_with_windows=case_upsample_with_windows, fft_convolve=case_fft_convolve, reverb=case_reverb,
              small_core=case_small_core, spectral_loss=case_spectral_loss, processors=case_processors, synthesis=case_synthesis,
-             spectral_ops=case_spectral_ops)
+             spectral_ops=case_spectral_ops, mean_difference=case_mean_difference)
 
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
