@@ -756,8 +756,8 @@ __device__ __forceinline__ void tq_load_frames(float2* s, const float* __restric
   }
 }
 
-// |STFT| of ONE signal (blockIdx.z: 0 target, 1 audio): [B, frames, S / 2 + 1]
-template <int S>
+// |STFT| of ONE signal (blockIdx.z: 0 target, 1 audio): [B, frames, S / 2 + 1]; CPLX: the spectrum itself, (re, im) pairs
+template <int S, bool CPLX = false>
 __global__ __launch_bounds__(kSlThreads) void stft_tq_mag_kernel(const float* __restrict__ target, const float* __restrict__ audio,
                                                                  float* __restrict__ mag_t, float* __restrict__ mag_a, int N,
                                                                  int n_frames, SlFrameGeom fg) {
@@ -781,7 +781,9 @@ __global__ __launch_bounds__(kSlThreads) void stft_tq_mag_kernel(const float* __
     const float ex = 0.5f * (za.x + zb.x), ey = 0.5f * (za.y - zb.y);       // E = (Za + conj Zb) / 2
     const float ox = 0.5f * (za.y + zb.y), oy = -0.5f * (za.x - zb.x);      // O = (Za - conj Zb) / 2i
     const float xr = ex + fmaf(ox, c, oy * sn), xi = ey + fmaf(oy, c, -ox * sn);   // E + (c - i sn) O
-    mag[((size_t)b * n_frames + f0 + g) * (H + 1) + k] = sl_sqrt(fmaf(xr, xr, xi * xi));
+    const size_t at = ((size_t)b * n_frames + f0 + g) * (H + 1) + k;
+    if (CPLX) reinterpret_cast<float2*>(mag)[at] = make_float2(xr, xi);
+    else mag[at] = sl_sqrt(fmaf(xr, xr, xi * xi));
   }
 }
 
@@ -1192,6 +1194,26 @@ extern "C" int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, i
     default: return DDSP_ERR_UNSUPPORTED;
   }
 #undef DDSP_SFM_CASE
+  return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_stft_frames_f32(const float* audio, float* spectrum, int B, int N, int fft_size, int frame_size, int hop,
+                                    int pad_left, int n_frames, void* stream) {
+  if (!audio || !spectrum) return DDSP_ERR_NULL_POINTER;
+  if (const int rc = sl_frames_geometry_ok(B, N, fft_size, hop, pad_left, n_frames)) return rc;
+  if (frame_size < 2 || frame_size > fft_size || (frame_size & 1)) return DDSP_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = 2 * kSlPoints / fft_size;
+  const SlFrameGeom fg = {frame_size, hop, pad_left, 1.0f / (float)frame_size};
+  const dim3 grid((unsigned)((n_frames + g - 1) / g), (unsigned)B, 1u);
+#define DDSP_SFC_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_mag_kernel<SZ, true>), grid, dim3(kSlThreads), 0, st, audio, audio, \
+                                                      spectrum, spectrum, N, n_frames, fg); break
+  switch (fft_size) {
+    DDSP_SFC_CASE(64); DDSP_SFC_CASE(128); DDSP_SFC_CASE(256); DDSP_SFC_CASE(512); DDSP_SFC_CASE(1024);
+    DDSP_SFC_CASE(2048); DDSP_SFC_CASE(4096); DDSP_SFC_CASE(8192);
+    default: return DDSP_ERR_UNSUPPORTED;
+  }
+#undef DDSP_SFC_CASE
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
 }
 

@@ -70,6 +70,29 @@ def get_framed_lengths(input_length, frame_size, hop_size, padding='center'):
   return n_frames, padded_length
 
 
+def stft(audio, frame_size=2048, overlap=0.75, pad_end=True):
+  """The complex spectrogram [batch, n_frames, bins] (complex64) of spectral_ops.stft (spectral_ops.py:34-47): tf.signal.stft with
+  fft_length=None - frames of frame_size samples every int(frame_size * (1 - overlap)) under a periodic Hann window, zero-padded
+  to the enclosing power of two.  Forward only (losses.SpectralLoss is the differentiable entry)."""
+  audio, squeeze = _audio_2d(audio)
+  b, n = audio.shape
+  frame_size = int(frame_size)
+  hop = int(frame_size * (1.0 - overlap))
+  if hop <= 0:
+    raise ValueError('overlap {} leaves no hop for frames of {}'.format(overlap, frame_size))
+  fft_size = 1 << max(frame_size - 1, 1).bit_length()
+  if frame_size & 1 or not 64 <= fft_size <= 8192:
+    raise NotImplementedError('stft on the MI355X path: even frame sizes in [34, 8192], got {}'.format(frame_size))
+  n_frames = -(-n // hop) if pad_end else (1 + (n - frame_size) // hop if n >= frame_size else 0)
+  spectrum = torch.empty((b, max(n_frames, 0), fft_size // 2 + 1, 2), dtype=torch.float32, device=audio.device)
+  if n_frames > 0:
+    rc = _lib.load().ddsp_stft_frames_f32(audio.data_ptr(), spectrum.data_ptr(), b, n, fft_size, frame_size, hop, 0, n_frames,
+                                          core._stream())
+    _lib.check(rc, 'ddsp_stft_frames_f32')
+  spectrum = torch.view_as_complex(spectrum)
+  return spectrum[0] if squeeze else spectrum
+
+
 def compute_mag(audio, size=2048, overlap=0.75, pad_end=True):
   """|STFT| [batch, n_frames, bins] (spectral_ops.py:67-70): frames of `size` every size * (1 - overlap) samples under a periodic
   Hann window; pad_end: zero-padded frames up to the last sample (tf.signal.frame)."""

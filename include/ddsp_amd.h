@@ -384,6 +384,11 @@ int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float*
  * (librosa's published A-curve: oracle/ddsp_oracle.py::a_weighting_db).  ..._backward: grad_mag [B, n_frames, bins]. */
 int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left, int n_frames,
                              void* stream);
+/* spectral_ops.stft (ddsp/spectral_ops.py:34-47: tf.signal.stft, fft_length=None) - the complex spectrum itself under the same
+ * geometry: frames of frame_size samples (even, <= fft_size; periodic Hann of frame_size) zero-padded to fft_size, a power of two
+ * in [64, 8192].  spectrum: [B, n_frames, fft_size/2 + 1] pairs (re, im), fp32.  Forward only. */
+int ddsp_stft_frames_f32(const float* audio, float* spectrum, int B, int N, int fft_size, int frame_size, int hop, int pad_left,
+                         int n_frames, void* stream);
 int ddsp_stft_frames_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                       int hop, int pad_left, int n_frames, void* stream);
 int ddsp_loudness_from_mag_f32(const float* mag, const float* weighting, float* loudness, int B, int n_frames, int bins,

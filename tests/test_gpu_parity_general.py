@@ -570,3 +570,30 @@ def test_mean_difference_public_function(ddsp):                      # losses.py
   # no elements: tf.reduce_mean gives NaN, cosine_distance's safe mean 0
   empty = np.zeros((2, 0, 4), np.float32)
   assert np.isnan(float(md(empty, empty))) and float(md(empty, empty, 'COSINE')) == 0.0
+
+
+def test_stft_complex_spectrogram(ddsp):                             # spectral_ops.py:34-47 (`stft`)
+  """The spectrum itself - real and imaginary parts, so the transform's sign and the bin order are pinned, not only |.| -
+  against the oracle's restatement of tf.signal.stft in fp64: powers of two, frames the enclosing power of two pads (3 * 2^k
+  and any even size), both pad_end settings, three overlaps, a trailing channel axis, one clip without a batch axis."""
+  rng = np.random.default_rng(33)
+  for n, size, overlap, pad_end in ((1000, 64, 0.75, True), (4000, 512, 0.75, True), (4000, 512, 0.5, False), (5000, 2048, 0.875, True),
+                                    (3000, 192, 0.75, True), (3000, 100, 0.5, True), (9000, 6144, 0.75, True), (700, 1024, 0.75, False)):
+    x = (0.5 * rng.standard_normal((2, n))).astype(np.float32)
+    ref = O.stft(x, size, overlap, pad_end, dtype=np.float64) if (pad_end or n >= size) else None
+    got = ddsp.spectral_ops.stft(x, size, overlap, pad_end)
+    assert got.dtype == torch.complex64
+    if ref is None:
+      assert tuple(got.shape) == (2, 0, (1 << (size - 1).bit_length()) // 2 + 1)
+      continue
+    got = npy(got)
+    assert got.shape == ref.shape, (n, size, overlap, pad_end)
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 3e-6 * scale, (n, size, overlap, pad_end, np.abs(got - ref).max(), scale)
+    np.testing.assert_allclose(np.abs(got), npy(ddsp.spectral_ops.compute_mag(x, size, overlap, pad_end)), rtol=0,
+                               atol=3e-6 * scale) if size in (64, 512, 2048, 1024, 192, 6144) else None
+  x = (0.5 * rng.standard_normal((2, 1500, 1))).astype(np.float32)
+  np.testing.assert_array_equal(npy(ddsp.spectral_ops.stft(x, 256)), npy(ddsp.spectral_ops.stft(x[..., 0], 256)))
+  np.testing.assert_array_equal(npy(ddsp.spectral_ops.stft(x[0, :, 0], 256)), npy(ddsp.spectral_ops.stft(x[..., 0], 256))[0])
+  with pytest.raises(NotImplementedError):
+    ddsp.spectral_ops.stft(x, 255)

@@ -381,6 +381,14 @@ def case_spectral_ops(rng):
     if not pad_end and n < size:
       return what, 'skipped (no frame fits)'
     return what, compare(what, lambda: RS.compute_mag(x, size, overlap, pad_end), lambda: M.spectral_ops.compute_mag(x, size, overlap, pad_end), 3e-6)
+  if maybe(rng, 0.4):
+    size = int(rng.choice([64, 100, 256, 512, 2048, 192, 768, 1000]))
+    overlap, pad_end = float(rng.choice([0.75, 0.5, 0.875])), maybe(rng, 0.7)
+    what = dict(case='spectral_ops', fn='stft', b=b, n=n, size=size, overlap=overlap, pad_end=pad_end)
+    if not pad_end and n < size:
+      return what, 'skipped (no frame fits)'
+    as_pairs = lambda z: np.stack([np.real(npy(z)), np.imag(npy(z))], -1)
+    return what, compare(what, lambda: as_pairs(RS.stft(x, size, overlap, pad_end)), lambda: as_pairs(M.spectral_ops.stft(x, size, overlap, pad_end)), 3e-6)
   kw = dict(sample_rate=int(rng.choice([16000, 24000, 44100])), frame_rate=int(rng.choice([250, 100, 50])),
             n_fft=int(rng.choice([512, 1024, 2048])), range_db=float(rng.choice([80.0, 120.0])), ref_db=float(rng.choice([0.0, 20.7])),
             padding=str(rng.choice(['center', 'same', 'valid', 'bogus'])))
