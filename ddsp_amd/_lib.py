@@ -64,6 +64,7 @@ SIGNATURES = {
     'ddsp_apply_window_to_impulse_response_f32': (c_int, [c_f32p, c_f32p, ctypes.c_long, c_int, c_int, c_int, c_voidp]),
     'ddsp_stft_frames_mag_f32': (c_int, [c_f32p] * 2 + [c_int] * 6 + [c_voidp]),
     'ddsp_stft_frames_f32': (c_int, [c_f32p] * 2 + [c_int] * 7 + [c_voidp]),
+    'ddsp_stft_frames_mag_ex_f32': (c_int, [c_f32p] * 2 + [c_int] * 7 + [c_voidp]),
     'ddsp_stft_frames_mag_backward_f32': (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_voidp]),
     'ddsp_loudness_from_mag_f32': (c_int, [c_f32p] * 3 + [c_int] * 3 + [ctypes.c_float] * 2 + [c_voidp]),
     'ddsp_loudness_from_mag_backward_f32': (c_int, [c_f32p] * 4 + [c_int] * 3 + [ctypes.c_float] * 2 + [c_voidp]),

@@ -1178,13 +1178,14 @@ static int sl_frames_geometry_ok(int B, int N, int fft_size, int hop, int pad_le
   return DDSP_OK;
 }
 
-extern "C" int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left,
-                                        int n_frames, void* stream) {
+static int sl_frames_mag(const float* audio, float* mag, int B, int N, int fft_size, int frame_size, int hop, int pad_left,
+                         int n_frames, void* stream) {
   if (!audio || !mag) return DDSP_ERR_NULL_POINTER;
   if (const int rc = sl_frames_geometry_ok(B, N, fft_size, hop, pad_left, n_frames)) return rc;
+  if (frame_size < 2 || frame_size > fft_size || (frame_size & 1)) return DDSP_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int g = 2 * kSlPoints / fft_size;
-  const SlFrameGeom fg = {fft_size, hop, pad_left, 1.0f / (float)fft_size};
+  const SlFrameGeom fg = {frame_size, hop, pad_left, 1.0f / (float)frame_size};
   const dim3 grid((unsigned)((n_frames + g - 1) / g), (unsigned)B, 1u);
 #define DDSP_SFM_CASE(SZ) case SZ: hipLaunchKernelGGL((stft_tq_mag_kernel<SZ>), grid, dim3(kSlThreads), 0, st, audio, audio, mag, \
                                                       mag, N, n_frames, fg); break
@@ -1195,6 +1196,16 @@ extern "C" int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, i
   }
 #undef DDSP_SFM_CASE
   return hipGetLastError() == hipSuccess ? DDSP_OK : DDSP_ERR_LAUNCH;
+}
+
+extern "C" int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left,
+                                        int n_frames, void* stream) {
+  return sl_frames_mag(audio, mag, B, N, fft_size, fft_size, hop, pad_left, n_frames, stream);
+}
+// frames shorter than the transform (any even frame_size <= fft_size, zero-padded: tf.signal.stft with fft_length=None)
+extern "C" int ddsp_stft_frames_mag_ex_f32(const float* audio, float* mag, int B, int N, int fft_size, int frame_size, int hop,
+                                           int pad_left, int n_frames, void* stream) {
+  return sl_frames_mag(audio, mag, B, N, fft_size, frame_size, hop, pad_left, n_frames, stream);
 }
 
 extern "C" int ddsp_stft_frames_f32(const float* audio, float* spectrum, int B, int N, int fft_size, int frame_size, int hop,

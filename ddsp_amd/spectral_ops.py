@@ -33,22 +33,15 @@ def _frames_mag(audio, frame_size, hop, pad_left, n_frames):
   the enclosing power of two transformed (fft_length=None, spectral_ops.py:40-45)."""
   b, n = audio.shape
   fft_size = 1 << max(int(frame_size) - 1, 1).bit_length()
-  if fft_size != frame_size and 3 * fft_size != 4 * frame_size:
-    raise NotImplementedError('frame sizes are powers of two or 3 * 2**k on the MI355X path, got {}'.format(frame_size))
-  if fft_size != frame_size and (hop * 4 != frame_size or pad_left != 0):
-    raise NotImplementedError('frames of 3 * 2**k samples run at overlap 0.75 without padding in front')
+  if frame_size & 1 or not 64 <= fft_size <= 8192:
+    raise NotImplementedError('frame sizes on the MI355X path: even, in [34, 8192], got {}'.format(frame_size))
   if n_frames <= 0:
     return torch.empty((b, 0, fft_size // 2 + 1), dtype=torch.float32, device=audio.device)
   mag = torch.empty((b, n_frames, fft_size // 2 + 1), dtype=torch.float32, device=audio.device)
   lib = _lib.load()
-  if fft_size == frame_size:
-    rc = lib.ddsp_stft_frames_mag_f32(audio.data_ptr(), mag.data_ptr(), b, n, fft_size, int(hop), int(pad_left), int(n_frames),
-                                      core._stream())
-    _lib.check(rc, 'ddsp_stft_frames_mag_f32')
-  else:                                                        # 3 * 2**k: the loss's own entry (one signal twice)
-    other = torch.empty_like(mag)
-    _lib.check(lib.ddsp_stft_mag_f32(audio.data_ptr(), audio.data_ptr(), other.data_ptr(), mag.data_ptr(), b, n, int(frame_size),
-                                     core._stream()), 'ddsp_stft_mag_f32')
+  rc = lib.ddsp_stft_frames_mag_ex_f32(audio.data_ptr(), mag.data_ptr(), b, n, fft_size, int(frame_size), int(hop), int(pad_left),
+                                       int(n_frames), core._stream())
+  _lib.check(rc, 'ddsp_stft_frames_mag_ex_f32')
   return mag
 
 

@@ -389,6 +389,10 @@ int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int f
  * in [64, 8192].  spectrum: [B, n_frames, fft_size/2 + 1] pairs (re, im), fp32.  Forward only. */
 int ddsp_stft_frames_f32(const float* audio, float* spectrum, int B, int N, int fft_size, int frame_size, int hop, int pad_left,
                          int n_frames, void* stream);
+/* ddsp_stft_frames_mag_f32 for frames shorter than the transform (spectral_ops.compute_mag at any even size: frame_size samples
+ * under a periodic Hann of frame_size, zero-padded to fft_size).  Forward only. */
+int ddsp_stft_frames_mag_ex_f32(const float* audio, float* mag, int B, int N, int fft_size, int frame_size, int hop, int pad_left,
+                                int n_frames, void* stream);
 int ddsp_stft_frames_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                       int hop, int pad_left, int n_frames, void* stream);
 int ddsp_loudness_from_mag_f32(const float* mag, const float* weighting, float* loudness, int B, int n_frames, int bins,

@@ -591,7 +591,7 @@ def test_stft_complex_spectrogram(ddsp):                             # spectral_
     scale = float(np.abs(ref).max())
     assert np.abs(got - ref).max() <= 3e-6 * scale, (n, size, overlap, pad_end, np.abs(got - ref).max(), scale)
     np.testing.assert_allclose(np.abs(got), npy(ddsp.spectral_ops.compute_mag(x, size, overlap, pad_end)), rtol=0,
-                               atol=3e-6 * scale) if size in (64, 512, 2048, 1024, 192, 6144) else None
+                               atol=3e-6 * scale)                     # compute_mag: the same frames, any even size
   x = (0.5 * rng.standard_normal((2, 1500, 1))).astype(np.float32)
   np.testing.assert_array_equal(npy(ddsp.spectral_ops.stft(x, 256)), npy(ddsp.spectral_ops.stft(x[..., 0], 256)))
   np.testing.assert_array_equal(npy(ddsp.spectral_ops.stft(x[0, :, 0], 256)), npy(ddsp.spectral_ops.stft(x[..., 0], 256))[0])
