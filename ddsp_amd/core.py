@@ -848,9 +848,9 @@ def prepare(n_harmonics=0, n_noise_bands=0, window_size=0):
   _lib.check(_lib.load().ddsp_prepare(int(n_harmonics), int(n_noise_bands), int(window_size)), 'ddsp_prepare')
 
 
-def uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=11):
+def uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=23):
   """The on-chip stand-in for tf.random.uniform([B, N], -1, 1) (ddsp/synths.py:192-193): what FilteredNoise generates
-  for itself, 2048 levels (noise_bits=11, the default) or the 2^23 levels of an fp32 uniform (noise_bits=23)."""
+  for itself: the 2^23 levels of an fp32 uniform (noise_bits=23, the default) or 2048 levels (noise_bits=11)."""
   if noise_bits not in (11, 23):
     raise ValueError('noise_bits must be 11 or 23, got {!r}'.format(noise_bits))
   out = torch.empty((int(batch_size), int(n_samples)), dtype=torch.float32, device=_device())

@@ -423,11 +423,12 @@ class FilteredNoise(processors.Processor):
   here noise is Philox4x32-10 keyed by (seed, call counter), generated inside the FIR
   kernel.  `get_signal(magnitudes, noise=...)` is the parity entry with supplied noise.
 
-  `noise_bits` is the other extension: 11 (the default) draws every sample from 2048 equally spaced levels in (-1, 1) -
-  zero mean, variance 1/3, white, each value exactly an fp16 number, which is what lets the matrix-core FIR carry its
-  noise operand in one fp16 plane; 23 draws the 2^23 levels tf.random.uniform's fp32 samples have (synths.py:192-193),
-  carried as fp16 hi / lo pairs (a third more matrix products and twice the LDS traffic of that operand: bench.py's
-  `fnoise_full_resolution` block prices it).  Both are Philox4x32-10 streams documented in include/ddsp_amd.h.
+  `noise_bits` is the other extension: 23 (the default since round 6) draws the 2^23 levels tf.random.uniform's fp32
+  samples have (synths.py:192-193), carried through the matrix-core FIR as fp16 hi / lo pairs; 11 draws every sample
+  from 2048 equally spaced levels in (-1, 1) - zero mean, variance 1/3, white, each value exactly an fp16 number, which
+  lets the FIR carry its noise operand in one fp16 plane (a third fewer matrix products and half the LDS traffic of
+  that operand: bench.py's `fnoise_11_bit_levels` block prices it).  Both are Philox4x32-10 streams documented in
+  include/ddsp_amd.h.
 
   `kernel` (an attribute, like Harmonic.kernel; the constructor is the reference's): 'auto' runs the canonical filter
   (65 bands, full window, frames of 64 c samples) on noise_mfma65_kernel - IR design and the time-varying FIR on the fp16
@@ -443,10 +444,10 @@ class FilteredNoise(processors.Processor):
                initial_bias=-5.0,
                name='filtered_noise',
                seed=0,
-               noise_bits=11):
+               noise_bits=23):
     super().__init__(name=name)
     if noise_bits not in (11, 23):
-      raise ValueError('noise_bits must be 11 (2048 levels, the default) or 23 (the 2^23 levels of tf.random.uniform), '
+      raise ValueError('noise_bits must be 23 (the 2^23 levels of tf.random.uniform, the default) or 11 (2048 levels), '
                        'got {!r}'.format(noise_bits))
     self.n_samples = n_samples
     self.window_size = window_size

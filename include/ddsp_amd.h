@@ -53,8 +53,9 @@ extern "C" {
                                              default matrix-core kernel (noise_mfma65_kernel: IR design and FIR as fp16 hi/lo-split
                                              MFMA products, fp32 accumulation) */
 #define DDSP_NOISE_BITS_23 0x10u          /* generated noise (noise == NULL) with 23-bit samples - the 2^23 levels of the reference's
-                                             tf.random.uniform (ddsp/synths.py:192-193) - instead of the default 2048 levels
-                                             (FilteredNoise(noise_bits=23)); see ddsp_filtered_noise_f32.  The backward call
+                                             tf.random.uniform (ddsp/synths.py:192-193) - instead of 2048 levels.  The Python mirror
+                                             sets it by default since round 6 (FilteredNoise(noise_bits=23) is the class default;
+                                             noise_bits=11 clears it); see ddsp_filtered_noise_f32.  The backward call
                                              takes the same flag so that it regenerates the same samples. */
 
 /* Library / build identification: "ddsp_amd <version> gfx950". */
@@ -217,12 +218,12 @@ int ddsp_frequency_impulse_response_f32(const float* ctl_magnitudes, float* impu
  *              (n >> 3, batch_offset + row, c2, 0) for sample n of a row; this library's
  *              contract (csrc/common.h; oracle/ddsp_oracle.py::device_uniform_noise
  *              restates both forms bit for bit):
- *                default (11 bits, c2 = 0): eight samples per block; sample n is the
+ *                flag clear (11 bits, c2 = 0; FilteredNoise(noise_bits=11)): eight samples per block; sample n is the
  *                  11-bit field k = bits [10:0] (n even) or [26:16] (n odd) of word
  *                  (n >> 1) & 3, value (2 k - 2047) / 2048 - 2048 equally spaced levels,
  *                  zero mean, variance 1/3 to 2e-7, every value exactly an fp16 number
  *                  (the matrix-core FIR then needs no lo part for its noise operand);
- *                DDSP_NOISE_BITS_23 (c2 = 1 + ((n >> 2) & 1)): four samples per block;
+ *                DDSP_NOISE_BITS_23 (c2 = 1 + ((n >> 2) & 1); what FilteredNoise() asks for by default): four samples per block;
  *                  sample n is word n & 3: its top 23 bits as the mantissa of u in [1,2),
  *                  value 2 u - 3 - the 2^23 levels TensorFlow's fp32 uniforms have.
  *              Non-NULL is the parity entry: the same maths as effects.FIRFilter
@@ -401,7 +402,8 @@ int ddsp_loudness_from_mag_backward_f32(const float* mag, const float* weighting
                                         int B, int n_frames, int bins, float range_db, float ref_db, void* stream);
 
 /* Uniform noise exactly as ddsp_filtered_noise_f32 generates it (noise==NULL). out [B,N].
- * _ex: noise_bits = 11 (the default form) or 23 (DDSP_NOISE_BITS_23's). */
+ * _ex: noise_bits = 11 (the flag-clear form, what ddsp_uniform_noise_f32 makes) or 23 (DDSP_NOISE_BITS_23's: the Python
+ * mirror's default). */
 int ddsp_uniform_noise_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,
                            void* stream);
 int ddsp_uniform_noise_ex_f32(float* out, int B, int N, uint64_t seed, uint64_t batch_offset,

@@ -1002,12 +1002,12 @@ def philox4x32(c0, c1, c2, c3, k0, k1, rounds=NOISE_ROUNDS):
   return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
 
 
-def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=11):
+def device_uniform_noise(batch_size, n_samples, seed=0, batch_offset=0, noise_bits=23):
   """The noise `ddsp_filtered_noise_f32` generates on chip when noise==NULL (csrc/common.h, "the generated noise"; the contract
-  text is in include/ddsp_amd.h).  noise_bits=11 (the default): 2048 equally spaced levels u = (2 k - 2047) / 2048 - zero mean,
+  text is in include/ddsp_amd.h).  noise_bits=11 (FilteredNoise(noise_bits=11); the C entry points' form without DDSP_NOISE_BITS_23): 2048 equally spaced levels u = (2 k - 2047) / 2048 - zero mean,
   variance 1/3, every value an fp16 number -, k an 11-bit field of a Philox4x32 word; eight samples per block: sample n of a
   row is field ((n >> 1) & 3, n & 1) of block (n >> 3, row, 0, 0), bits [10:0] of the word for even n, [26:16] for odd n.
-  noise_bits=23 (DDSP_NOISE_BITS_23, FilteredNoise(noise_bits=23)): the 2^23 levels of tf.random.uniform's fp32 samples
+  noise_bits=23 (the default, as FilteredNoise's since round 6; DDSP_NOISE_BITS_23): the 2^23 levels of tf.random.uniform's fp32 samples
   (ddsp/synths.py:192-193) - sample n is word n & 3 of block (n >> 3, row, 1 + ((n >> 2) & 1), 0), its top 23 bits the
   mantissa of u in [1, 2), value 2 u - 3 (as rounds 1-3 made them, four per block)."""
   n_oct = -(-n_samples // 8)

@@ -174,7 +174,7 @@ def test_main_control_flow_with_the_gpu_mocked_out(bench, monkeypatch, capsys):
       return add_signal
 
   class _Noise:
-    def __init__(self, n_samples, window_size, seed, noise_bits=11):
+    def __init__(self, n_samples, window_size, seed, noise_bits=23):
       self.n = n_samples
       calls.setdefault('noise_bits', set()).add(noise_bits)
 
@@ -292,7 +292,7 @@ def _mock_device(monkeypatch, bench, calls):
   monkeypatch.setattr(ddsp_amd.effects, 'Reverb', _Reverb)
 
   class _Noise:
-    def __init__(self, n_samples, window_size, seed, noise_bits=11):
+    def __init__(self, n_samples, window_size, seed, noise_bits=23):
       self.n = n_samples
       calls.setdefault('noise_bits', set()).add(noise_bits)
 
@@ -337,7 +337,7 @@ def test_main_multi_rank_branches_with_device_and_collectives_mocked_out(bench, 
 
 def test_main_other_configs_blocks_with_the_device_mocked_out(bench, monkeypatch, capsys):
   """The default-shape run's extra blocks - configs_2 (SpectralLoss), configs_3 (Reverb, one trainable impulse response and one per
-  clip), fnoise_full_resolution (noise_bits=23) - end to end with every device call replaced by a stand-in (these
+  clip), fnoise_11_bit_levels (noise_bits=11 beside the 23-bit headline) - end to end with every device call replaced by a stand-in (these
   blocks must be in the driver's line; a NameError here would only show on the GPU box at round end)."""
   calls = {}
   _mock_device(monkeypatch, bench, calls)
@@ -348,11 +348,11 @@ def test_main_other_configs_blocks_with_the_device_mocked_out(bench, monkeypatch
   assert len(out) == 1
   line = json.loads(out[0])
   assert 'aux_error' not in line, line.get('aux_error')
-  for key in ('configs_1', 'configs_4', 'configs_2', 'configs_3', 'fnoise_full_resolution'):
+  for key in ('configs_1', 'configs_4', 'configs_2', 'configs_3', 'fnoise_11_bit_levels'):
     assert key in line and 'error' not in line[key], (key, line.get(key))
     blk = line[key]
     assert blk['ms_per_step'] > 0 and blk['value'] > 0 and 0 < blk['whole_step']['frac'] and blk['whole_step']['algorithmic_bytes'] > 0
-  c2, c3, fr = line['configs_2'], line['configs_3'], line['fnoise_full_resolution']
+  c2, c3, fr = line['configs_2'], line['configs_3'], line['fnoise_11_bit_levels']
   assert c2['batch_per_gpu'] == 128 and c3['batch_per_gpu'] == 128 and fr['batch_per_gpu'] == 128
   # algorithmic bytes: the DAG's controls in and one audio stream out (14.44 B / sample at this shape), + what the caller reads / writes
   synth = 4 * 128 * (1000 * 102 + 1000 * 65 + 64000)
@@ -364,7 +364,7 @@ def test_main_other_configs_blocks_with_the_device_mocked_out(bench, monkeypatch
   assert 'cost_of_the_twelve_bits_us' in fr and fr['headline_ms_per_step'] == line['ms_per_step']
   assert calls['noise_bits'] == {11, 23} and calls['loss'] > 10 and calls['reverb'] > 20 and calls['fused'] > 30
   assert calls['loss_kwargs'] == {'logmag_weight': 1.0}
-  assert '2048 levels' in line['config']['workload']
+  assert '2^23 levels' in line['config']['workload'] and 'noise_bits=23' in line['config']['workload']
 
 
 def test_cpu_baseline_leg_runs_concurrent_workers_and_falls_back(monkeypatch):

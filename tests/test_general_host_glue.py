@@ -66,7 +66,7 @@ class _HostLib:
 
   def ddsp_uniform_noise_f32(self, out, b, n, seed, batch_offset, stream):
     self.calls.append('ddsp_uniform_noise_f32')
-    _view(out, (b, n))[:] = O.device_uniform_noise(b, n, seed=seed, batch_offset=batch_offset)
+    _view(out, (b, n))[:] = O.device_uniform_noise(b, n, seed=seed, batch_offset=batch_offset, noise_bits=11)
     return 0
 
   def ddsp_uniform_noise_ex_f32(self, out, b, n, seed, batch_offset, noise_bits, stream):

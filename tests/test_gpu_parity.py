@@ -253,9 +253,12 @@ def test_generated_noise_is_bit_exact_and_fused_path_matches_injection(ddsp, noi
   dev_noise = npy(ddsp.core.uniform_noise(b, n, seed=1234, batch_offset=5))
   np.testing.assert_array_equal(dev_noise, O.device_uniform_noise(b, n, 1234, 5))
   mags = np.random.default_rng(4).standard_normal((b, 100, 65)).astype(np.float32)
-  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=99)
+  assert ddsp.synths.FilteredNoise().noise_bits == 23       # the reference's resolution is the default
+  # (2048-level noise is carried in ONE fp16 plane whether generated or supplied: same bits; 23-bit samples: within the parity
+  # tolerance, test_generated_noise_contract_both_resolutions)
+  synth = ddsp.synths.FilteredNoise(n_samples=n, window_size=0, seed=99, noise_bits=11)
   gen = npy(synth(mags))                                    # call counter 0 -> key (99, 0)
-  inj = npy(synth(mags, noise=O.device_uniform_noise(b, n, 99, 0)))
+  inj = npy(synth(mags, noise=O.device_uniform_noise(b, n, 99, 0, noise_bits=11)))
   np.testing.assert_array_equal(gen, inj)
   gen2 = npy(synth(mags))                                   # stateful like tf.random: differs
   assert np.abs(gen2 - gen).max() > 0
