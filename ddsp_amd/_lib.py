@@ -116,7 +116,6 @@ HARM_AMP_LINEAR = 0x4
 HARM_ANGULAR_CUMSUM = 0x8
 HARM_INPUTS_ARE_AMPLITUDES = 0x20
 HARM_DIRECT_SUM = 0x40
-HARM_TABLE_ONE_BLOCK = 0x80
 NOISE_SCALE_EXP_SIGMOID = 0x1
 NOISE_FIR_VECTOR_ALU = 0x8
 NOISE_BITS_23 = 0x10

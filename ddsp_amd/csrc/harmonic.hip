@@ -983,7 +983,7 @@ extern "C" int ddsp_harmonic_f32(const float* amplitudes, const float* hd, const
   hipStream_t st = (hipStream_t)stream;
   if (harm_table_ok(F, K, N, hd, ctl_amp, ctl_hd, flags, /*inputs_are_controls=*/0))
     return launch_harm_table(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, nullptr, B, F, K, N, sample_rate, flags, st);
-  flags &= ~(DDSP_HARM_DIRECT_SUM | DDSP_HARM_TABLE_ONE_BLOCK);
+  flags &= ~DDSP_HARM_DIRECT_SUM;
   if (fused_ok(F, K, N, hd, ctl_hd))
     return launch_fused(amplitudes, hd, f0_hz, audio, ctl_amp, ctl_hd, workspace, B, F, K, N,
                         sample_rate, flags, /*inputs_are_controls=*/0, st);

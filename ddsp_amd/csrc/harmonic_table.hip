@@ -1357,8 +1357,6 @@ __global__ __launch_bounds__(1024) void harm_table_kernel(
 #undef DDSP_WT_STAMP
 }
 
-#include "harmonic_table4.h"     // harm_wt4_kernel: the same arithmetic as four independent blocks of four wavefronts per CU (round 6)
-
 bool harm_table_ok(int F, int K, int N, const void* hd, const void* ctl_amp, const void* ctl_hd, unsigned flags,
                    int inputs_are_controls) {
   if (flags & DDSP_HARM_DIRECT_SUM) return false;
@@ -1423,10 +1421,6 @@ int launch_harm_table(const float* amplitudes, const float* hd, const float* f0,
   p.inv_2hop = 0.5 / (double)p.hop;
   p.hop_d = (double)p.hop;
   p.half_hm1 = ((double)p.hop - 1.0) * 0.5;
-  // K <= 128: four independent blocks of four wavefronts per CU (harmonic_table4.h; round 6) unless the caller asks for the
-  // sixteen-wavefront kernel of rounds 3-5 (DDSP_HARM_TABLE_ONE_BLOCK: Harmonic.kernel = 'table16', kept for A/B measurements)
-  if (K <= 128 && !(flags & DDSP_HARM_TABLE_ONE_BLOCK))
-    return launch_harm_wt4(amplitudes, hd, f0, audio, ctl_amp, ctl_hd, add_in, p, st);
   // persistent grid: one block of 16 wavefronts per CU, each with a contiguous run of frames
   static const int n_cu = [] {
     int dev = 0, v = 0;

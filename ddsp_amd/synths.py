@@ -31,9 +31,8 @@ class Harmonic(processors.Processor):
 
   `kernel` (an attribute, not a constructor argument - the constructor is the reference's) selects how
   __call__ sums the harmonics where both kernels apply: 'auto' tabulates each frame's waveform on the
-  matrix cores and interpolates it per sample (harm_wt4_kernel: four independent blocks of four wavefronts per CU;
-  'table16' runs the same arithmetic on the sixteen-wavefront harm_table_kernel of rounds 3-5), 'direct' evaluates every
-  harmonic at every sample (harm_fused_kernel).  Same result within the parity tolerance.
+  matrix cores and interpolates it per sample (harm_table_kernel), 'direct' evaluates every harmonic at
+  every sample (harm_fused_kernel).  Same result within the parity tolerance.
   """
   kernel = 'auto'
 
@@ -196,10 +195,8 @@ class Harmonic(processors.Processor):
                                  self.use_angular_cumsum)
     if self.kernel == 'direct':
       flags |= _lib.HARM_DIRECT_SUM
-    elif self.kernel == 'table16':
-      flags |= _lib.HARM_TABLE_ONE_BLOCK
     elif self.kernel != 'auto':
-      raise ValueError("Harmonic.kernel must be 'auto', 'table16' or 'direct', got {!r}".format(self.kernel))
+      raise ValueError("Harmonic.kernel must be 'auto' or 'direct', got {!r}".format(self.kernel))
     return flags
 
   def _forward(self, amplitudes, harmonic_distribution, f0_hz, fuse, return_outputs_dict=False):

@@ -45,10 +45,6 @@ extern "C" {
 #define DDSP_HARM_INPUTS_ARE_AMPLITUDES 0x20u   /* streaming entry: harmonic_distribution=None (core.py:1149-1150) */
 #define DDSP_HARM_DIRECT_SUM 0x40u        /* ddsp_harmonic_f32: sum the harmonics sample by sample (sine recurrence on the
                                              vector ALUs) even where the matrix-core wavetable kernel applies */
-#define DDSP_HARM_TABLE_ONE_BLOCK 0x80u   /* ddsp_harmonic_f32 / ddsp_harmonic_add_f32, K <= 128: run the wavetable synthesis as ONE
-                                             block of sixteen wavefronts per CU (harm_table_kernel, rounds 3-5) instead of four
-                                             independent blocks of four (harm_wt4_kernel, the default since round 6); the same
-                                             arithmetic - kept for A/B measurements */
 
 /* ---- flags for the FilteredNoise entry points (ddsp/synths.py:153-163) ------------ */
 #define DDSP_NOISE_SCALE_EXP_SIGMOID 0x1u /* scale_fn=core.exp_sigmoid on (mag + initial_bias) */

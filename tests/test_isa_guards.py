@@ -42,13 +42,13 @@ def asm(tmp_path_factory):
 def _kernels(asm_text):
   """{mangled name: body text} of the harm_wt16 / harm_table kernels."""
   found = {}
-  for m in re.finditer(r'^(_ZN4ddsp\d+harm_(?:wt16|wt4|table)_kernel\w+):.*?\n(.*?)\n\s*s_endpgm', asm_text, re.S | re.M):
+  for m in re.finditer(r'^(_ZN4ddsp\d+harm_(?:wt16|table)_kernel\w+):.*?\n(.*?)\n\s*s_endpgm', asm_text, re.S | re.M):
     found[m.group(1)] = m.group(2)
   return found
 
 
 def test_no_scratch_in_the_harmonic_table_kernels(asm):
-  names = re.findall(r'\.name:\s+(_ZN4ddsp\d+harm_(?:wt16|wt4|table)_kernel\w+)', asm)
+  names = re.findall(r'\.name:\s+(_ZN4ddsp\d+harm_(?:wt16|table)_kernel\w+)', asm)
   assert len(names) >= 6
   for name in names:
     block = asm[asm.index('.name:           ' + name) - 400:asm.index('.name:           ' + name) + 400]
