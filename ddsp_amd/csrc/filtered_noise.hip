@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void noise_ir_kernel(const float* __restrict__
         idx += n;
         if (idx >= g.L0) idx -= g.L0;
       }
-      // periodic Hann (tf.signal.hann_window): 0.5 - 0.5 cos(2 pi i / ws)
-      const float w = (widx < 0) ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)g.ws);
+      // tf.signal.hann_window: 0.5 - 0.5 cos(2 pi i / n), n = ws for even ws, ws - 1 for odd ws; [1.0] for ws = 1 (noise_ir_geom.h)
+      const float w = (widx < 0) ? 0.0f : (g.ws == 1 ? 1.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)hann_denominator(g.ws)));
       ir[row * g.L + kappa] = w * (acc * inv_L0);
     }
   }

@@ -312,8 +312,10 @@ static const GiMatrix* gi_matrix(int M, int window_size) {
     int n, widx;
     ir_tap_map(g, kappa, &n, &widx);
     // (angles folded into the first half turn, so that mirror columns come out bit for bit equal)
-    const int wfold = widx < 0 ? 0 : (widx <= g.ws - widx ? widx : g.ws - widx);
-    const double w = widx < 0 ? 0.0 : 0.5 - 0.5 * cos(two_pi * (double)wfold / (double)g.ws);     // periodic Hann (tf.signal.hann_window)
+    // tf.signal.hann_window: the denominator is ws for even ws, ws - 1 for odd ws; one sample: [1.0] (noise_ir_geom.h)
+    const int wden = hann_denominator(g.ws);
+    const int wfold = widx < 0 ? 0 : (widx <= wden - widx ? widx : wden - widx);
+    const double w = widx < 0 ? 0.0 : (g.ws == 1 ? 1.0 : 0.5 - 0.5 * cos(two_pi * (double)wfold / (double)wden));
     for (int b = 0; b < M; ++b) {
       long long ph = ((long long)b * n) % g.L0;
       if (ph > g.L0 - ph) ph = g.L0 - ph;

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ddsp_amd.h"
+#include "noise_ir_geom.h"      // hann_denominator: tf.signal.hann_window's denominator
 
 namespace ddsp {
 namespace general {
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(kThreads) void window_ir_kernel(const float* __rest
     if (p.padding > 0) wi = j < p.ws - p.half ? p.half + j : (j >= p.L0 - p.half ? j - (p.L0 - p.half) : -1);
     else wi = (j - p.ws / 2 + p.ws) % p.ws;                                                           // fftshift(window)
     const int src = p.causal ? (j - p.L0 / 2 + p.L0) % p.L0 : j;                                      // causal input: fftshift first
-    const float w = wi < 0 ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)wi / (float)p.ws);
+    // tf.signal.hann_window(ws): denominator ws for even ws, ws - 1 for odd ws; a window of one sample is [1.0] (noise_ir_geom.h)
+    const float w = wi < 0 ? 0.0f : (p.ws == 1 ? 1.0f : 0.5f - 0.5f * cospif(2.0f * (float)wi / (float)ddsp::hann_denominator(p.ws)));
     out[i] = w * ir[(size_t)row * p.L0 + src];
   }
 }

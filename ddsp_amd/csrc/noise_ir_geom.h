@@ -25,6 +25,14 @@ __host__ __device__ inline IrGeom ir_geom(int M, int window_size) {
   g.L = g.padding > 0 ? ir_first_len(g.half) + g.half + 1 : g.L0;
   return g;
 }
+// tf.signal.hann_window(ws) as TensorFlow computes it (tensorflow/python/ops/signal/window_ops.py, _raised_cosine_window, called
+// with periodic=True by core.py:1505): w[i] = 0.5 - 0.5 cos(2 pi i / n), n = window_length + periodic * even - 1 with
+// even = 1 - window_length % 2.  "Periodic" therefore holds for EVEN lengths only (n = ws); an ODD length - the constructor's
+// default window_size=257 wherever the response is longer than that - gets the SYMMETRIC window, n = ws - 1; a window of one
+// sample is [1.0].  (Rounds 1-5 divided by ws whatever its parity: the oracle and the TF stand-in shared that reading, so no
+// test could see it; found in round 6 while fixing ADVICE r5's one-sample window.  TensorFlow is not installable in this image: tests/golden/make_golden_tf.py
+// regenerates the fixtures under real TF for whoever has it.)
+__host__ __device__ inline int hann_denominator(int ws) { return (ws & 1) ? ws - 1 : ws; }      // (0 for ws = 1: the caller's case)
 // causal tap index kappa -> zero-phase sample index n and Hann window index (or -1: zero)
 __host__ __device__ inline void ir_tap_map(const IrGeom& g, int kappa, int* n, int* widx) {
   if (g.padding > 0) {

@@ -116,6 +116,12 @@ def compute_loudness(audio, sample_rate=16000, frame_rate=250, n_fft=512, range_
     raise ValueError('`padding` must be one of [\'center\', \'same\', \'valid\'], received ({}).'.format(padding))
   if padding != 'valid' and hop > n_fft:
     raise ValueError('During padding, frame_size ({}) must be greater than hop_size ({}).'.format(n_fft, hop))
+  if n_fft < 2 or n_fft & (n_fft - 1):
+    # tf.signal.stft transforms the enclosing power of two (fft_size // 2 + 1 bins) while the A-weighting curve has n_fft // 2 + 1
+    # entries (spectral_ops.py:296-311): the reference's `power_db + a_weighting` fails to broadcast for any other n_fft.  (ADVICE
+    # r5: this used to read the curve past its end on the device.)
+    raise ValueError('compute_loudness: n_fft must be a power of two (the A-weighting curve has n_fft // 2 + 1 entries, the '
+                     'spectrogram {} bins), got {}'.format((1 << max(int(n_fft) - 1, 1).bit_length()) // 2 + 1, n_fft))
   n_frames, _ = get_framed_lengths(n, n_fft, hop, padding)
   pad_left = n_fft // 2 if padding == 'center' else 0
   mag = _frames_mag(audio, int(n_fft), hop, pad_left, max(n_frames, 0))

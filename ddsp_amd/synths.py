@@ -257,6 +257,16 @@ class Harmonic(processors.Processor):
     n = int(self.n_samples)
     lib = _lib.load()
     dev = amplitudes.device
+    # This chain holds up to four [batch, n_samples, n_harmonics] fp32 envelopes at once (the reference materialises the same
+    # tensors): 300 harmonics x 10 s at 48 kHz x batch 32 is 18 GB each.  Refuse with the arithmetic spelled out instead of
+    # dying in the allocator half way through a backward pass.
+    envelope_bytes = 4 * b * n * k
+    free_bytes = torch.cuda.mem_get_info(dev)[0] if dev.type == 'cuda' else None
+    if free_bytes is not None and 4 * envelope_bytes > free_bytes:
+      raise MemoryError('Harmonic backward on the materialised-envelope chain (amp_resample_method={!r}, {} harmonics, frames of {} '
+                        'samples) needs four [batch={}, n_samples={}, n_harmonics={}] fp32 envelopes = {:.1f} GB; {:.1f} GB are free on '
+                        '{}: split the batch'.format(self.amp_resample_method, k, n // max(f, 1), b, n, k, 4 * envelope_bytes / 1e9,
+                                                     free_bytes / 1e9, dev))
     grad_audio = core.tf_float32(grad_audio)
     # the envelopes the forward pass ran on: f0 [1 .. K] resampled 'linear', amplitudes * distribution resampled by the method
     harmonic_frequencies = torch.empty((b, f, k), dtype=torch.float32, device=dev)

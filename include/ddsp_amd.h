@@ -379,8 +379,12 @@ int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float*
  * same materialised form.  ddsp_stft_frames_mag_f32: |STFT| of ONE signal under the caller's frame geometry - frames of
  * fft_size samples (a power of two in [64, 8192]) every `hop`, the first starting pad_left samples before sample 0 (zeros
  * outside the row; compute_loudness: fft_size 2048, hop sample_rate / 250, pad_left 1024, n_frames 1 + N / hop), periodic Hann
- * -> mag [B, n_frames, fft_size/2+1]; ..._backward: grad_audio += its adjoint applied to grad_mag.
- * ddsp_loudness_from_mag_f32: loudness [B, n_frames] = max(10 log10(max(pmin, mean_k weighting[k] mag[k]^2)) - ref_db, -range_db),
+ * -> mag [B, n_frames, fft_size/2+1]; ..._backward: grad_audio += its adjoint applied to grad_mag (overlapping frames are
+ * added with fp32 atomics: the LAST BITS of this gradient - and of ddsp_stft_mag_backward_f32's for frames of 3 * 2^k samples,
+ * and of ddsp_spectral_loss_backward_f32's - depend on the order the frames arrive in; every FORWARD entry point, and the synths'
+ * backward passes, are bit-reproducible run to run).
+ * ddsp_loudness_from_mag_f32 (weighting: `bins` entries, caller-checked - the Python mirror refuses an n_fft whose spectrogram has
+ * another bin count): loudness [B, n_frames] = max(10 log10(max(pmin, mean_k weighting[k] mag[k]^2)) - ref_db, -range_db),
  * pmin = 10^(-range_db/10) (core.power_to_db, core.py:253-267); `weighting` [bins] = 10^(A_weighting/10), made by the caller
  * (librosa's published A-curve: oracle/ddsp_oracle.py::a_weighting_db).  ..._backward: grad_mag [B, n_frames, bins]. */
 int ddsp_stft_frames_mag_f32(const float* audio, float* mag, int B, int N, int fft_size, int hop, int pad_left, int n_frames,

@@ -104,8 +104,14 @@ def sigmoid(x):
 
 # --- tf.signal ----------------------------------------------------------------
 def hann_window(n, periodic=True, dtype=np.float32):
-  i = np.arange(int(n), dtype=np.float64)
-  d = n if periodic else n - 1
+  """tf.signal.hann_window (tensorflow/python/ops/signal/window_ops.py, _raised_cosine_window): ones([1]) for a window of one
+  sample; else a - b cos(2 pi count / n') with n' = window_length + periodic * even - 1, even = 1 - window_length % 2 - `periodic`
+  changes EVEN lengths only, an odd length is the symmetric window either way (round 6; before, this stand-in divided by n)."""
+  n = int(n)
+  if n == 1:
+    return _t(np.ones(1, dtype))
+  i = np.arange(n, dtype=np.float64)
+  d = n + (1 if periodic else 0) * (1 - n % 2) - 1
   return _t((0.5 - 0.5 * np.cos(2.0 * np.pi * i / d)).astype(dtype))
 
 

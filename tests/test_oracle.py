@@ -570,3 +570,21 @@ def test_loudness_matches_the_reference_source_and_its_gradient_finite_differenc
     d = np.zeros_like(a64); d[idx] = eps
     fd = ((O.compute_loudness(a64 + d, dtype=np.float64) - O.compute_loudness(a64 - d, dtype=np.float64)) * gl).sum() / (2 * eps)
     np.testing.assert_allclose(gb[idx], fd, rtol=1e-4, atol=1e-9)
+
+
+def test_hann_window_is_tensorflows_not_the_textbook_periodic_one():
+  """tf.signal.hann_window(n) (tensorflow/python/ops/signal/window_ops.py, _raised_cosine_window; periodic=True is what
+  core.py:698, 1505 and tf.signal.stft pass): n' = window_length + periodic * even - 1 with even = 1 - window_length % 2 -
+  periodic for EVEN lengths, the SYMMETRIC window for odd ones (the constructor's window_size=257 on a response longer than
+  that: core_test.py:775), ones([1]) for a single sample.  Known answers worked out from that definition; rounds 1-5
+  divided by n whatever its parity, in the oracle AND in the TF stand-in the fixtures are made with."""
+  np.testing.assert_allclose(O.hann_window_periodic(4, np.float64), [0.0, 0.5, 1.0, 0.5], atol=1e-15)        # periodic: d = 4
+  np.testing.assert_allclose(O.hann_window_periodic(5, np.float64), [0.0, 0.5, 1.0, 0.5, 0.0], atol=1e-15)   # symmetric: d = 4
+  np.testing.assert_array_equal(O.hann_window_periodic(1), [1.0])
+  w = O.hann_window_periodic(257, np.float64)
+  assert w[0] == 0.0 and abs(w[256]) < 1e-30 and w[128] == 1.0 and np.allclose(w, w[::-1], atol=1e-15)
+  w = O.hann_window_periodic(128, np.float64)
+  assert w[0] == 0.0 and w[64] == 1.0 and np.allclose(w[1:], w[:0:-1], atol=1e-15) and w[127] > 0.0
+  # an impulse response of one sample comes back as it is (a window of [1.0]; core.py:1477-1531)
+  ir = np.array([[[0.75]]], np.float32)
+  np.testing.assert_array_equal(O.apply_window_to_impulse_response(ir, 0), ir)
