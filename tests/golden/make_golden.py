@@ -19,9 +19,17 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import tf_numpy_shim  # noqa: E402
 
-tf_numpy_shim.install('/root/reference')
+# DDSP_GOLDEN_BACKEND=tf (set by make_golden_tf.py): the same cases on REAL TensorFlow, written beside the fixtures as NAME.tf.npz
+BACKEND = os.environ.get('DDSP_GOLDEN_BACKEND', 'shim')
+REFERENCE = os.environ.get('DDSP_REFERENCE_ROOT', '/root/reference')
+SUFFIX = '.npz' if BACKEND == 'shim' else '.tf.npz'
+if BACKEND == 'shim':
+  import tf_numpy_shim  # noqa: E402
+  tf_numpy_shim.install(REFERENCE)
+else:
+  import make_golden_tf  # noqa: E402
+  make_golden_tf.install(REFERENCE)
 from ddsp import core, effects, losses, processors, spectral_ops, synths  # noqa: E402  (the reference's files)
 
 
@@ -282,7 +290,7 @@ def main():
   cases['add'] = dict(signal_one=s1, signal_two=s2, signal=a(processors.Add()(s1, s2)))
 
   for name, d in cases.items():
-    path = os.path.join(HERE, name + '.npz')
+    path = os.path.join(HERE, name + SUFFIX)
     d = {k: np.asarray(v) for k, v in d.items()}
     if os.path.exists(path):                       # leave identical fixtures alone (zip timestamps differ)
       with np.load(path) as z:
