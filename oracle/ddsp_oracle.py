@@ -157,8 +157,15 @@ def hann_window_periodic(n, dtype=np.float32):
   n = int(n)
   if n == 1:
     return np.ones(1, dtype)
-  i = np.arange(n, dtype=np.float64)
   d = n - 1 + (1 - n % 2)
+  if np.dtype(dtype) == np.float32:
+    # the faithful mode: TensorFlow's own op order in fp32 - cos_arg = constant(2 pi) * count / n, then a - b * cos(cos_arg) -,
+    # which is where the first samples of a long window lose their relative accuracy (0.5 - 0.5 cos(x), x -> 0: 2e-4 at
+    # sample 17 of 4096 points; the yardstick tools/fuzz_parity.py holds loss values on very short clips to)
+    count = np.arange(n, dtype=np.float32)
+    cos_arg = (np.float32(TWO_PI) * count) / np.float32(d)
+    return (np.float32(0.5) - np.float32(0.5) * np.cos(cos_arg, dtype=np.float32)).astype(np.float32)
+  i = np.arange(n, dtype=np.float64)
   return (0.5 - 0.5 * np.cos(TWO_PI * i / d)).astype(dtype)
 
 
@@ -934,16 +941,24 @@ def spectral_loss(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64)
 
 
 def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64),
-                           mag_weight=1.0, logmag_weight=0.0):
+                           mag_weight=1.0, logmag_weight=0.0, fp32_envelope=None):
   """dL/d audio [B,N] of spectral_loss(target_audio, audio, loss_type='L1') (fp64 truth).
 
   |z| has gradient z/|z| (0 at z = 0, as tf.abs), safe_log passes a gradient only where its
   argument is positive, sign(0) = 0; the zero-padded tail of the last frames gets no gradient.
+
+  fp32_envelope = r (tools/fuzz_parity.py: 2e-5): returns (gradient, envelope) instead.  The L1 loss is not differentiable where
+  two magnitudes are equal, and the logmag term's 1 / |X| is unbounded at a spectral null: a bin whose |X_t| - |X_a| is below r
+  of their sum, or whose |X_a| is below r of its frame's spectrum (fp32 transforms - TensorFlow's included - know |X| to about
+  1e-6 of the frame's rms), has no gradient that fp32 arithmetic can tell from its neighbours in the SUBDIFFERENTIAL.  Such bins are
+  left out of `gradient`, and `envelope[b, n]` is the largest magnitude their terms can add at sample n (every admissible
+  coefficient, every phase): a correct fp32 gradient g satisfies |g - gradient| <= envelope + rounding, sample by sample.
   """
   t = as_float(target_audio, np.float64)
   a = as_float(audio, np.float64)
   b, n = a.shape
   grad = np.zeros_like(a)
+  envelope = np.zeros_like(a)
   for size in fft_sizes:
     hop = int(size * 0.25)
     zt = stft(t, size, dtype=np.float64)
@@ -954,6 +969,25 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
     if logmag_weight > 0:
       coef = coef - logmag_weight * np.sign(safe_log(mt) - safe_log(ma)) * np.where(
           ma > 0.0, 1.0 / np.where(ma > 0.0, ma, 1.0), 0.0)
+    if fp32_envelope is not None:
+      r = float(fp32_envelope)
+      frame_rms = np.sqrt(np.mean(ma * ma, axis=-1, keepdims=True)) + np.sqrt(np.mean(mt * mt, axis=-1, keepdims=True))
+      floor = r * frame_rms                                        # what fp32 knows a magnitude of this frame to
+      unsure = np.abs(mt - ma) <= r * (mt + ma) + floor            # the sign of the difference is rounding's to decide
+      bound = np.full(ma.shape, float(mag_weight))
+      if logmag_weight > 0:
+        # (safe_log, core.py:213-216: log(max(x, 1e-5)) - no gradient below 1e-5; above it 1 / |X|, as small as fp32 may think |X| is)
+        unsure |= ma <= 30.0 * floor
+        bound = bound + logmag_weight / np.maximum(ma - floor, 1e-5)
+      # a bin's term at sample i of its frame: (coef / count) w[i] Re(unit phasor) (x 2 for the bins the rfft holds once)
+      weight = np.where(unsure, 2.0 * bound / count, 0.0).sum(axis=-1)                       # [B, frames]
+      coef = np.where(unsure, 0.0, coef)
+      env_frames = weight[..., None] * hann_window_periodic(size, np.float64)[None, None, :]
+      n_fr = env_frames.shape[1]
+      env_padded = np.zeros((b, (n_fr - 1) * hop + size))
+      for f in range(n_fr):
+        env_padded[:, f * hop:f * hop + size] += env_frames[:, f]
+      envelope += env_padded[:, :n]
     g_bins = (coef / count) * np.where(ma > 0.0, za / np.where(ma > 0.0, ma, 1.0), 0.0)
     # (the transform has the enclosing power of two as its length - stft() above -: the frame's gradient is the first `size`
     #  samples of the adjoint, the zero padding has none)
@@ -966,7 +1000,7 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
     for f in range(n_frames):
       padded[:, f * hop:f * hop + size] += g_frames[:, f]
     grad += padded[:, :n]
-  return grad
+  return grad if fp32_envelope is None else (grad, envelope)
 
 
 def add(signal_one, signal_two):

@@ -110,8 +110,12 @@ def hann_window(n, periodic=True, dtype=np.float32):
   n = int(n)
   if n == 1:
     return _t(np.ones(1, dtype))
-  i = np.arange(n, dtype=np.float64)
   d = n + (1 if periodic else 0) * (1 - n % 2) - 1
+  if np.dtype(dtype) == np.float32:         # TF's op order, every step in `dtype`: constant(2 pi) * count / n, a - b * cos(.)
+    count = np.arange(n, dtype=np.float32)
+    cos_arg = (np.float32(2.0 * np.pi) * count) / np.float32(d)
+    return _t((np.float32(0.5) - np.float32(0.5) * np.cos(cos_arg, dtype=np.float32)).astype(np.float32))
+  i = np.arange(n, dtype=np.float64)
   return _t((0.5 - 0.5 * np.cos(2.0 * np.pi * i / d)).astype(dtype))
 
 

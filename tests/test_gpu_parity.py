@@ -1549,6 +1549,69 @@ def test_synth_plus_trainable_reverb_trains(ddsp):                   # solo_inst
 
 
 # ---- SpectralLoss backward: |ours - fp64 analytic gradient| <= 2e-4 * max|grad| + 1e-9 ------------------
+
+# ---- SpectralLoss on random short clips: the draw and the checks of tools/fuzz_parity.py's `loss` family, and the seeds its round-5
+# campaigns ended on as regression cases -----------------------------------------------------------------------
+LOSS_FUZZ_SIZES = [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 6144, 3072, 1536, 768, 384, 192, 96, 48]   # (3 * 2**k: vst_48k.gin's kind)
+
+
+def draw_loss_case(rng):
+  """One random (batch, clip length, subset of frame sizes, weights) with its two signals - the draw order is part of the
+  replay contract of tools/fuzz_parity.py (--replay loss:<seed>)."""
+  b = int(rng.integers(1, 10))
+  n = int(rng.choice([17, 64, 100, 1023, 1024, 1025, 3000, 12345, 20000, int(rng.integers(16, 30000))]))
+  sizes = tuple(int(s) for s in rng.permutation(LOSS_FUZZ_SIZES)[:int(rng.integers(1, 7))])
+  mw, lw = float(rng.choice([1.0, 0.0, 0.5])), float(rng.choice([1.0, 0.0, 0.5]))
+  if mw == 0.0 and lw == 0.0:
+    mw = 1.0
+  t = (0.3 * rng.standard_normal((b, n))).astype(np.float32)
+  a = (0.8 * t + 0.05 * rng.standard_normal((b, n))).astype(np.float32)
+  if n >= 64:
+    a[0, n // 2: n // 2 + n // 8] = 0.0
+  return dict(batch=b, n=n, sizes=sizes, mag_weight=mw, logmag_weight=lw, target=t, audio=a)
+
+
+def check_loss_case(ddsp, case):
+  """Value and gradient of SpectralLoss against exact arithmetic; returns the worst error over its tolerance.
+
+  Value: 5e-5 relative on clips of >= 4096 samples; on shorter ones - a few samples under the first points of a long
+  window - 1e-4, or THREE TIMES the error of the reference's own fp32 arithmetic if that is larger (the faithful oracle runs
+  tf.signal.hann_window's fp32 op order: 0.5 - 0.5 cos(x) is good to 2e-4 at sample 17 of 4096 points, in TensorFlow as anywhere).
+  Gradient: EVERY sample within 2e-4 of the largest gradient of the SUBDIFFERENTIAL (oracle.spectral_loss_backward,
+  fp32_envelope: bins whose |X_t| - |X_a| or |X_a| is below what fp32 knows a magnitude to are left out of the reference and their
+  largest possible contribution is allowed for, sample by sample).  Rounds 4-5 checked the median and the 80th percentile and
+  ended their campaigns on "known" failures where one flipped bin covered a fifth of a short clip."""
+  t, a, sizes, mw, lw, n = case['target'], case['audio'], case['sizes'], case['mag_weight'], case['logmag_weight'], case['n']
+  loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=mw, logmag_weight=lw)
+  ta = ddsp.core.tf_float32(a).requires_grad_(True)
+  val = loss(t, ta)
+  val.backward()
+  ref_v = float(O.spectral_loss(t, a, sizes, mag_weight=mw, logmag_weight=lw, dtype=np.float64))
+  vtol = 5e-5
+  if n < 4096:
+    ref_v32 = float(O.spectral_loss(t, a, sizes, mag_weight=mw, logmag_weight=lw, dtype=np.float32))
+    vtol = max(1e-4, 3.0 * abs(ref_v32 - ref_v) / max(abs(ref_v), 1e-12))
+  ev = abs(float(val.detach()) - ref_v) / max(abs(ref_v), 1e-12)
+  assert ev <= vtol, ('loss value', float(val.detach()), ref_v, vtol)
+  assert abs(float(loss(t, a)) - ref_v) <= vtol * abs(ref_v), ('loss value, forward kernel', float(loss(t, a)), ref_v, vtol)
+  if n < 256:
+    return ev / vtol
+  ref, env = O.spectral_loss_backward(t, a, sizes, mw, lw, fp32_envelope=2e-5)
+  atol = 1e-9 + 2e-4 * np.abs(ref).max()
+  err = np.maximum(np.abs(npy(ta.grad) - ref) - 1.05 * env, 0.0)
+  worst = float(err.max())
+  assert worst <= atol, ('loss gradient', worst, atol, float(np.median(err)), float(env.max()), float(np.abs(ref).max()))
+  assert float(np.median(env)) <= 0.05 * np.abs(ref).max(), ('the envelope must stay an exception', float(np.median(env)))
+  return max(ev / vtol, worst / atol)
+
+
+@pytest.mark.parametrize('seed', [37014845,                                  # round 5's last campaign: a gradient bulk at n = 1025
+                                  31000384, 31003046, 31012330,             # seed 31: values of 17-sample clips under 4096 / 6144 points
+                                  4007713, 4032057, 4014585, 4029689])       # seed 4: two gradient bulks, two more 17-sample clips
+def test_spectral_loss_seeds_the_round_5_campaigns_ended_on(ddsp, seed):
+  case = draw_loss_case(np.random.default_rng(seed))
+  assert check_loss_case(ddsp, case) <= 1.0
+
 @pytest.mark.parametrize('batch,n,sizes', [(2, 3000, (2048, 1024, 512, 256, 128, 64)), (1, 777, (64, 16)),
                                            (3, 20000, (4096, 512)),
                                            (2, 1500, (32, 1024))])      # 32: the one transform plan without a radix-8 stage

@@ -92,7 +92,10 @@ def case_harmonic(rng):
   scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
   exact, knife, exact32 = P._harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges='fp32 mask')
   atol = (P.HARM_TABLE_ATOL if k <= 200 else P.HARM_TRUTH_ATOL) * scale
-  assert knife.mean() <= 2e-2, ('knife share', float(knife.mean()))
+  # (knife-edge samples ARE checked - against the sum with the reference's fp32 mask, below -; this only keeps the exact-arithmetic
+  #  comparison from becoming vacuous: a handful per row, or two per cent of a longer clip.  Round 5's campaigns ended on clips of
+  #  80 samples where three knife-edge samples are 3.75 %.)
+  assert knife.mean() <= 2e-2 or int(knife.sum()) <= 4 * b, ('knife share', float(knife.mean()), int(knife.sum()))
   err = float(np.abs(got - exact)[~knife].max()) if (~knife).any() else 0.0
   assert err <= atol, ('harmonic forward', err, atol)
   P.assert_knife_edges_take_the_fp32_side(got, exact32, knife, atol, what)
@@ -235,44 +238,11 @@ def case_reverb(rng):
 
 
 def case_loss(rng):
-  b = int(rng.integers(1, 10))
-  n = int(rng.choice([17, 64, 100, 1023, 1024, 1025, 3000, 12345, 20000, int(rng.integers(16, 30000))]))
-  all_sizes = [4096, 2048, 1024, 512, 256, 128, 64, 32, 16, 6144, 3072, 1536, 768, 384, 192, 96, 48]   # (3 * 2**k: vst_48k.gin's kind)
-  sizes = tuple(int(s) for s in rng.permutation(all_sizes)[:int(rng.integers(1, 7))])
-  mw, lw = float(rng.choice([1.0, 0.0, 0.5])), float(rng.choice([1.0, 0.0, 0.5]))
-  if mw == 0.0 and lw == 0.0:
-    mw = 1.0
-  what = note(dict(batch=b, n=n, sizes=sizes, mag_weight=mw, logmag_weight=lw))
-  t = (0.3 * rng.standard_normal((b, n))).astype(np.float32)
-  a = (0.8 * t + 0.05 * rng.standard_normal((b, n))).astype(np.float32)
-  if n >= 64:
-    a[0, n // 2: n // 2 + n // 8] = 0.0
-  loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=mw, logmag_weight=lw)
-  ta = ddsp.core.tf_float32(a).requires_grad_(True)
-  val = loss(t, ta)
-  val.backward()
-  ref_v = float(O.spectral_loss(t, a, sizes, mag_weight=mw, logmag_weight=lw, dtype=np.float64))
-  # (5e-5: the contract of DESIGN.md; clips shorter than a frame of the largest size are a few samples in thousands of zeros -
-  #  the log of bins at the fp32 noise floor of the transform: 1e-4)
-  vtol = 5e-5 if n >= 4096 else (1e-4 if n >= 256 else 3e-4)      # (17 samples under the first 17 points of a 4096-point Hann
-                                                                    #  window, 0.5 - 0.5 cos(x) at x -> 0: cancellation, in any fp32)
-  ev = abs(float(val.detach()) - ref_v) / max(abs(ref_v), 1e-12)
-  assert ev <= vtol, ('loss value', float(val.detach()), ref_v)
-  assert abs(float(loss(t, a)) - ref_v) <= vtol * abs(ref_v), ('loss value, forward kernel', float(loss(t, a)), ref_v)
-  if n < 256:
-    return what, ev / vtol
-  ref = O.spectral_loss_backward(t, a, sizes, mw, lw)
-  atol = 1e-9 + 2e-4 * np.abs(ref).max()
-  err = np.abs(npy(ta.grad) - ref)
-  # d|x|/dx is a sign (flips where two magnitudes agree to rounding move one frame's samples), and the gradient of log |X| is
-  # 1 / |X|: a bin near a spectral null dominates its frame's gradient and is only as accurate as fp32 knows |X| there
-  # (2e-6 against frame energies of 0.3 in one replayed case: +- 10 % in fp32, in TensorFlow's fp32 as here).  Held to: the bulk
-  # of the samples at the tolerance, nothing structural (a wrong frame, a missing overlap-add would move whole stretches).
-  # A flip moves a whole frame (a third of a 12 345-sample clip at size 4096) by up to ~15 x the tolerance; so the check is on
-  # the distribution: the median far below the tolerance, four samples in five within it.
-  med, q80 = float(np.median(err)), float(np.quantile(err, 0.8))
-  assert med <= 0.2 * atol and q80 <= atol, ('loss gradient (bulk)', med, q80, atol)
-  return what, max(ev / vtol, q80 / atol)
+  # (the draw and the checks live beside the GPU tests, which replay the seeds earlier campaigns ended on:
+  #  tests/test_gpu_parity.py, draw_loss_case / check_loss_case)
+  case = P.draw_loss_case(rng)
+  what = note({k: case[k] for k in ('batch', 'n', 'sizes', 'mag_weight', 'logmag_weight')})
+  return what, P.check_loss_case(ddsp, case)
 
 
 def case_fft_convolve(rng):
