@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(256) void noise_bwd_mags_generic_kernel(const float
     for (int kappa = threadIdx.x; kappa < g.L; kappa += 256) {
       int n, widx;
       ir_tap_map(g, kappa, &n, &widx);
-      const float w = (widx < 0) ? 0.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)g.ws);
+      // (tf.signal.hann_window's denominator: noise_ir_geom.h - the forward kernel's window, above)
+      const float w = (widx < 0) ? 0.0f : (g.ws == 1 ? 1.0f : 0.5f - 0.5f * cospif(2.0f * (float)widx / (float)hann_denominator(g.ws)));
       s_dw[kappa] = w * dh[(size_t)row * g.L + kappa];
     }
     __syncthreads();

@@ -245,6 +245,16 @@ __device__ __forceinline__ void sl_inverse(float2* s, int tid, int n_fr, int g_l
   }
 }
 
+// tf.signal.hann_window (periodic, an even number of points) at i / S turns, as sin^2(pi i / S): the textbook 0.5 - 0.5 cos(2 pi i / S)
+// cancels at the window's first samples (v_cos_f32 is good to 1.2e-7 ABSOLUTE: 6e-4 of the window at sample 17 of 4096 points;
+// TensorFlow's own fp32 op order 8e-5), which is all a clip much shorter than its frame ever sees of the window - round 5's fuzz
+// campaigns ended on loss values of 17-sample clips 3e-4 ... 5e-4 off exact arithmetic (profiles/r05_fuzz_seed31_failures.jsonl).
+// The square has no cancellation: 2e-5 there, one transcendental and one multiply like the other form.
+__device__ __forceinline__ float sl_hann(float turns) {
+  const float h = __builtin_amdgcn_sinf(0.5f * turns);
+  return h * h;
+}
+
 // frames -> LDS, windowed: w[i] = 0.5 - 0.5 cos(2 pi i / S) (tf.signal.hann_window, periodic); element e
 // of the array is the sample pair (2n, 2n+1) of frame e / H (first G frames: target, then audio).
 // For H <= 512 a thread meets the same pair index n in every pass: its two window values are computed once.
@@ -279,16 +289,16 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
   float w0 = 0.f, w1 = 0.f;
   if (kFixed) {
     const int n2 = (tid & (H - 1)) * 2;
-    w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-    w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+    w0 = sl_hann((float)n2 * (1.0f / (float)S));
+    w1 = sl_hann((float)(n2 + 1) * (1.0f / (float)S));
   }
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int e = tid + kSlThreads * u;
     if (!kFixed) {
       const int n2 = (e & (H - 1)) * 2;
-      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)n2 * (1.0f / (float)S));
-      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(n2 + 1) * (1.0f / (float)S));
+      w0 = sl_hann((float)n2 * (1.0f / (float)S));
+      w1 = sl_hann((float)(n2 + 1) * (1.0f / (float)S));
     }
     s[SP(e)] = make_float2(v[u].x * w0, v[u].y * w1);
   }
@@ -334,8 +344,10 @@ __device__ __forceinline__ void sl_load_stage1(float2* s, const float* __restric
   const float d0 = (c0 - s0) * kR, e0 = (c0 + s0) * kR, d1 = (c1 - s1) * kR, e1 = (c1 + s1) * kR;
   const float hc0[8] = {c0, d0, -s0, -e0, -c0, -d0, s0, e0};            // 0.5 cos(a0 + j pi / 4)
   const float hc1[8] = {c1, d1, -s1, -e1, -c1, -d1, s1, e1};
+  // (j = 0 - the window's first eighth, where 0.5 - 0.5 cos cancels - as the square: sl_hann)
+  v[0] = make_float2(v[0].x * sl_hann(a0), v[0].y * sl_hann(a1));
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = make_float2(v[j].x * (0.5f - hc0[j]), v[j].y * (0.5f - hc1[j]));
+  for (int j = 1; j < 8; ++j) v[j] = make_float2(v[j].x * (0.5f - hc0[j]), v[j].y * (0.5f - hc1[j]));
   fft_dft8(v);
   float2 w[8];
   const float rev = (float)r * (0.125f / (float)Q);
@@ -661,7 +673,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     // the window at i = ir + jj S/4: cos(x + jj pi/2) = cos x, -sin x, -cos x, sin x - one sine and one cosine for the four frames
     const float wrev = (float)ir * (1.0f / (float)S);
     const float hc = 0.5f * __builtin_amdgcn_cosf(wrev), hs = 0.5f * __builtin_amdgcn_sinf(wrev);
-    const float wj[4] = {0.5f - hc, 0.5f + hs, 0.5f + hc, 0.5f - hs};
+    const float wj[4] = {sl_hann(wrev), 0.5f + hs, 0.5f + hc, 0.5f - hs};      // (the first quarter as the square: sl_hann)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int g = gp - jj, i = ir + jj * HOP;               // frame g covers the sample at its index i
@@ -749,8 +761,8 @@ __device__ __forceinline__ void tq_load_frames(float2* s, const float* __restric
       if (i >= 0 && i < N) x0 = row[i];
       if (i + 1 >= 0 && i + 1 < N) x1 = row[i + 1];
       // tf.signal.hann_window(F), periodic: 0.5 - 0.5 cos(2 pi i / F)
-      w0 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e) * fg.inv_F);
-      w1 = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)(2 * e + 1) * fg.inv_F);
+      w0 = sl_hann((float)(2 * e) * fg.inv_F);
+      w1 = sl_hann((float)(2 * e + 1) * fg.inv_F);
     }
     s[SP(it)] = make_float2(x0 * w0, x1 * w1);
   }
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(kSlThreads) void stft_tq_cot_bwd_kernel(const float
       if (f0 + g >= n_frames) break;
       const int i = p - g * fg.hop;                              // < F
       const float2 u = s[SP(g * H + (i >> 1))];
-      const float w = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)i * fg.inv_F);
+      const float w = sl_hann((float)i * fg.inv_F);
       acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), w, acc);
     }
     unsafeAtomicAdd(&grow[n], acc);

