@@ -45,7 +45,7 @@ rm -rf $OUT/prof5
 python - <<PY
 import json
 d = json.load(open('$OUT/bench_1000.json'))
-for k in ('configs_2', 'configs_3', 'fnoise_full_resolution'):
+for k in ('configs_2', 'configs_3', 'fnoise_11_bit_levels', 'fnoise_full_resolution'):
   b = d.get(k, {})
   print(k, {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in b.items() if kk in ('ms_per_step', 'value', 'error', 'cost_of_the_twelve_bits_us', 'with_gradient_wrt_audio', 'kernel_breakdown_us')}, 'frac', b.get('whole_step', {}).get('frac'))
 PY
