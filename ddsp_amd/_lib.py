@@ -96,6 +96,8 @@ SIGNATURES = {
     'ddsp_exp_decay_ir_backward_f32': (c_int, [c_f32p] * 6 + [c_voidp, c_size_t] + [c_int] * 2 + [c_uint, c_voidp]),
     'ddsp_sigmoid_f32': (c_int, [c_f32p] * 2 + [c_size_t, c_voidp]),
     'ddsp_mix_f32': (c_int, [c_f32p] * 4 + [c_size_t, c_int, c_voidp]),
+    'ddsp_sigmoid_backward_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_voidp]),
+    'ddsp_mix_backward_f32': (c_int, [c_f32p] * 7 + [c_size_t, c_int, c_voidp]),
     'ddsp_safe_divide_f32': (c_int, [c_f32p] * 3 + [c_size_t, c_int, c_int, ctypes.c_float, c_voidp]),
     'ddsp_safe_log_f32': (c_int, [c_f32p] * 2 + [c_size_t, ctypes.c_float, c_voidp]),
     'ddsp_harmonic_frequencies_f32': (c_int, [c_f32p] * 2 + [c_size_t, c_int, c_voidp]),

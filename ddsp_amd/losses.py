@@ -218,7 +218,7 @@ class SpectralLoss(Loss):
           tuple(target_audio.shape), tuple(audio.shape)))
     general = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
                self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or self.loudness_weight > 0 or
-               any(int(v) & (int(v) - 1) for v in self.fft_sizes))         # frames of 3 * 2**k samples (vst_48k.gin): the plain kernels
+               any(int(v) & (int(v) - 1) for v in self.fft_sizes))         # frames that are not powers of two (vst_48k.gin: 3 * 2**k): the plain kernels
     if general:
       weights = self._weights_tensor(weights, audio.device)
       if torch.is_grad_enabled() and audio.requires_grad:
@@ -256,12 +256,13 @@ class SpectralLoss(Loss):
     for z, size in enumerate(self.fft_sizes):
       size = int(size)
       pow2 = 16 <= size <= 4096 and not size & (size - 1)
-      tri = 48 <= size <= 6144 and size % 3 == 0 and not (size // 3) & (size // 3 - 1)
-      if not (pow2 or tri):
-        raise ValueError('fft_sizes must be powers of two in [16, 4096] or 3 * 2**k in [48, 6144] (vst_48k.gin) on the MI355X '
-                         'path, got {}'.format(tuple(self.fft_sizes)))
+      other = 34 <= size <= 8190 and size % 2 == 0 and size & (size - 1)       # (vst_48k.gin: 6144, 3072 .. 192; any since round 6)
+      if not (pow2 or other):
+        raise ValueError('fft_sizes must be powers of two in [16, 4096] or even sizes in [34, 8190] on the MI355X path (odd frames, '
+                         'and frames of fewer than 34 samples that are not powers of two, are not built), got {}'.format(
+                             tuple(self.fft_sizes)))
       # spectral_ops.stft (spectral_ops.py:40-45): tf.signal.stft with fft_length=None transforms the ENCLOSING power of two
-      frames, bins = -(-n // (size // 4)), (size if pow2 else 4 * size // 3) // 2 + 1
+      frames, bins = -(-n // (size // 4)), (1 << (size - 1).bit_length()) // 2 + 1
       wb = wf = wk = 0
       if weights is not None:
         wb, wf, wk = (int(v) for v in weights.shape)

@@ -114,8 +114,10 @@ class Harmonic(processors.Processor):
     core._check_amp_method(self.amp_resample_method, f, int(self.n_samples))
     needs_grad = torch.is_grad_enabled() and (amplitudes.requires_grad or harmonic_distribution.requires_grad or
                                               f0_hz.requires_grad)
-    if k > 512:
-      raise NotImplementedError('the MI355X path holds at most 512 harmonics per frame, got {}'.format(k))
+    if k > 2048:
+      # (harm_controls_kernel holds a row as ceil(K / 64) values per lane, 32 at most; the reference has no cap - 2048 harmonics
+      #  are all below Nyquist only under f0 = 11.7 Hz at 48 kHz)
+      raise NotImplementedError('the MI355X path holds at most 2048 harmonics per frame, got {}'.format(k))
     closed_form = core._on_closed_form_kernels(self.amp_resample_method, f, int(self.n_samples))
     if needs_grad and closed_form and (k > 256 or int(self.n_samples) // f > 2048):
       # the closed-form BACKWARD kernels take up to 256 harmonics and frames of up to 2048 samples (csrc/harmonic.hip); beyond

@@ -371,9 +371,9 @@ int ddsp_spectral_terms_f32(const float* target_mag, const float* value_mag, con
                             float cumsum_freq_weight, float logmag_weight, int first, void* stream);
 int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                void* stream);
-/* fft_size of the two calls above: a power of two in [16, 4096], or a frame of 3 * 2^k samples in [48, 6144]
- * (gin/models/vst/vst_48k.gin:56) - tf.signal.stft then transforms the enclosing power of two, the frame zero-padded:
- * bins = (4 fft_size / 3) / 2 + 1.
+/* fft_size of the two calls above: a power of two in [16, 4096], or any other EVEN frame size in [34, 8190] (gin/models/vst/
+ * vst_48k.gin:56 asks for 6144, 3072 .. 192; any since round 6) - tf.signal.stft then transforms the enclosing power of two S,
+ * the frame zero-padded, every int(fft_size / 4) samples: bins = S / 2 + 1.
  *
  * The loudness term of SpectralLoss (ddsp/losses.py:238-242 -> spectral_ops.compute_loudness, spectral_ops.py:253-324), in the
  * same materialised form.  ddsp_stft_frames_mag_f32: |STFT| of ONE signal under the caller's frame geometry - frames of
@@ -535,10 +535,17 @@ int ddsp_exp_decay_ir_backward_f32(const float* gain, const float* decay, const 
 /* processors.Mix (ddsp/processors.py:180-233), the constant-power crossfade next to processors.Add:
  *   ddsp_sigmoid_f32: tf.nn.sigmoid on n values (get_controls, :207; in may equal out);
  *   ddsp_mix_f32:     out[r][c] = sqrt(|m[r]|) * signal_one[r][c] + (1 - sqrt(|m[r] - 1|)) * signal_two[r][c]
- *                     for rows = batch * n_time time steps of C channels (get_signal, :231-233). */
+ *                     for rows = batch * n_time time steps of C channels (get_signal, :231-233);
+ *   ddsp_sigmoid_backward_f32, ddsp_mix_backward_f32: their adjoints, what tf.GradientTape takes through the two
+ *                     (grad_in = grad_out s (1 - s); grad_one = sqrt|m| g, grad_two = (1 - sqrt|m - 1|) g, grad_level [rows] =
+ *                     sum_c g (one sign(m) / (2 sqrt|m|) - two sign(m - 1) / (2 sqrt|m - 1|)); any of the three outputs may be
+ *                     NULL; no atomics: bit-reproducible). */
 int ddsp_sigmoid_f32(const float* in, float* out, size_t n, void* stream);
 int ddsp_mix_f32(const float* signal_one, const float* signal_two, const float* mix_level, float* out,
                  size_t rows, int C, void* stream);
+int ddsp_sigmoid_backward_f32(const float* in, const float* grad_out, float* grad_in, size_t n, void* stream);
+int ddsp_mix_backward_f32(const float* signal_one, const float* signal_two, const float* mix_level, const float* grad_out,
+                          float* grad_one, float* grad_two, float* grad_level, size_t rows, int C, void* stream);
 
 /* Small pieces of ddsp/core.py that the synths only use fused inside their kernels, callable on their own (the reference
  * exports them; nothing on the hot path calls these):

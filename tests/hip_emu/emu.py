@@ -20,7 +20,7 @@ ENTRY_POINTS = ['ddsp_resample_ex_f32', 'ddsp_fft_convolve_f32', 'ddsp_harmonic_
                 'ddsp_scale_f32', 'ddsp_harmonic_oscillator_bank_workspace_bytes', 'ddsp_harmonic_oscillator_bank_f32',
                 'ddsp_harmonic_f0_grad_workspace_bytes', 'ddsp_harmonic_f0_grad_f32', 'ddsp_exp_decay_ir_f32',
                 'ddsp_exp_decay_ir_backward_workspace_bytes', 'ddsp_exp_decay_ir_backward_f32', 'ddsp_sigmoid_f32',
-                'ddsp_mix_f32']
+                'ddsp_mix_f32', 'ddsp_sigmoid_backward_f32', 'ddsp_mix_backward_f32', 'ddsp_resample_ex_backward_f32']
 
 _emu = None
 

