@@ -13,10 +13,11 @@
 constexpr int ITERS = 4096;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-enum Kind { B128_ALIGNED, READ2_B32_X2, B128_AT4, B64_X2_AT4, B64_X2_ALIGNED, N_KIND };
+enum Kind { B128_ALIGNED, READ2_B32_X2, B128_AT4, B64_X2_AT4, B64_X2_ALIGNED, READ2_B64_ALIGNED, N_KIND };
 static const char* kNames[N_KIND] = {"ds_read_b128, 16-byte aligned (lane * 16)", "2 x ds_read2_b32, Toeplitz at 4 bytes (today)",
                                      "1 x ds_read_b128 at a 4-byte aligned address", "2 x ds_read_b64 at 4-byte aligned addresses",
-                                     "2 x ds_read_b64, 8-byte aligned (Toeplitz at 8 bytes)"};
+                                     "2 x ds_read_b64, 8-byte aligned (Toeplitz at 8 bytes)",
+                                     "1 x ds_read2_b64 offset1:1, 8-byte aligned (Toeplitz at 8 bytes)"};
 
 template <int K>
 __global__ __launch_bounds__(512) void bench(long long* clocks, unsigned* wrong) {
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(512) void bench(long long* clocks, unsigned* wrong)
   // the kernel's pattern: row i reads a 16-byte fragment one dword further down per row; g picks one of four 32-byte groups
   unsigned addr;
   if (K == B128_ALIGNED) addr = 16u * (unsigned)lane + 4096u * (unsigned)wave;
-  else if (K == B64_X2_ALIGNED) addr = 8u * (unsigned)(15 - i) + 160u * (unsigned)g + 4096u * (unsigned)wave;
+  else if (K == B64_X2_ALIGNED || K == READ2_B64_ALIGNED) addr = 8u * (unsigned)(15 - i) + 160u * (unsigned)g + 4096u * (unsigned)wave;
   else addr = 4u * (unsigned)(15 - i) + 160u * (unsigned)g + 4096u * (unsigned)wave;
   unsigned bad = 0, sum = 0;
   const long long t0 = clock64();
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(512) void bench(long long* clocks, unsigned* wrong)
         __asm__ volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(lo) : "v"(a));
         __asm__ volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(hi) : "v"(a));
         v[r] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      } else if (K == READ2_B64_ALIGNED) {
+        __asm__ volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(v[r]) : "v"(a));
       } else {
         u32x2 lo, hi;
         __asm__ volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(a));
@@ -101,5 +104,6 @@ int main() {
   run<B128_AT4>(d_clk, d_wrong, blocks);
   run<B64_X2_AT4>(d_clk, d_wrong, blocks);
   run<B64_X2_ALIGNED>(d_clk, d_wrong, blocks);
+  run<READ2_B64_ALIGNED>(d_clk, d_wrong, blocks);
   return 0;
 }
