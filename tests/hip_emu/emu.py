@@ -41,13 +41,18 @@ def load():
     return _emu
   stamp = OUT + '.stamp'
   digest = _digest()
-  if not (os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest):
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run(['g++', '-x', 'c++', '-std=c++17', '-O2', '-ffp-contract=off', '-shared', '-fPIC',
-                    '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include'), SOURCE,
-                    '-o', OUT], check=True)
-    with open(stamp, 'w') as f:
-      f.write(digest + '\n')
+  os.makedirs(os.path.dirname(OUT), exist_ok=True)
+  import fcntl
+  with open(OUT + '.lock', 'w') as lock:                # (pytest-xdist workers that find the library stale at the same moment)
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if not (os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest):
+      tmp = OUT + '.tmp.%d' % os.getpid()
+      subprocess.run(['g++', '-x', 'c++', '-std=c++17', '-O2', '-ffp-contract=off', '-shared', '-fPIC',
+                      '-I' + os.path.join(HERE, 'include'), '-I' + os.path.join(ROOT, 'include'), SOURCE,
+                      '-o', tmp], check=True)
+      os.replace(tmp, OUT)
+      with open(stamp, 'w') as f:
+        f.write(digest + '\n')
   lib = ctypes.CDLL(OUT)
   for name in ENTRY_POINTS:
     fn = getattr(lib, name)
