@@ -304,6 +304,37 @@ __device__ __forceinline__ void sl_load_frames(float2* s, const float* __restric
   }
 }
 
+// The same for frames of F < S samples every `hop` under a window of F points, zero-padded to the transform's S (round 6: frames of
+// 3 * 2^k samples - gin/models/vst/vst_48k.gin:56 - on the fused loss kernels; tf.signal.stft with fft_length=None transforms the
+// enclosing power of two).  F is even: a sample pair is inside the frame or outside.
+template <int S>
+__device__ __forceinline__ void sl_load_frames_geom(float2* s, const float* __restrict__ trow, const float* __restrict__ arow, int tid,
+                                                    int f0, int n_frames, int N, int F, int hop) {
+  constexpr int H = S / 2, G = kSlPoints / 2 / H, LOG2H = __builtin_ctz(H);
+  constexpr int kPer = kSlPoints / kSlThreads;
+  const float inv_F = 1.0f / (float)F;
+  float2 v[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kSlThreads * u;
+    const int g2 = e >> LOG2H, n2 = (e & (H - 1)) * 2;
+    const int g = g2 >= G ? g2 - G : g2;
+    const long n = (long)(f0 + g) * hop + n2;
+    v[u] = make_float2(0.f, 0.f);
+    if (f0 + g < n_frames && n2 < F && n < N) {
+      const float* __restrict__ row = g2 >= G ? arow : trow;
+      v[u].x = row[n];
+      if (n + 1 < N) v[u].y = row[n + 1];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + kSlThreads * u;
+    const int n2 = (e & (H - 1)) * 2;
+    s[SP(e)] = make_float2(v[u].x * sl_hann((float)n2 * inv_F), v[u].y * sl_hann((float)(n2 + 1) * inv_F));
+  }
+}
+
 // Frames -> first radix-8 stage -> LDS (late round 5).  The first stage of the forward transform (q = H / 8) takes the
 // elements r + j H / 8 (j = 0 .. 7) of a frame - with 2 G frames of H points and 512 threads exactly one butterfly per thread -
 // so a thread can fetch those eight sample pairs itself, window them and write the stage's OUTPUT: the array is neither
@@ -362,8 +393,15 @@ __device__ __forceinline__ void sl_load_stage1(float2* s, const float* __restric
 // frames of both signals, windowed and transformed (bin k at sl_pos<H>(k))
 template <int S>
 __device__ __forceinline__ void sl_frames_to_spectra(float2* s, const float* __restrict__ trow, const float* __restrict__ arow,
-                                                     int tid, int f0, int n_frames, int N) {
+                                                     int tid, int f0, int n_frames, int N, int F = S, int hop = S / 4) {
   constexpr int H = S / 2, G = kSlPoints / 2 / H;
+  if (F != S) {                          // (block-uniform) frames shorter than their transform: the plain load, then every stage
+    sl_load_frames_geom<S>(s, trow, arow, tid, f0, n_frames, N, F, hop);
+    __syncthreads();
+    sl_forward<H>(s, tid, 2 * G, 0);
+    if (SlPlan<H>::kWaveLocal) __syncthreads();
+    return;
+  }
   // (DDSP_SL_NO_*: parts of the kernels compiled out for the time accounting of tools/exp_loss_ablation.sh - wrong results)
 #if defined(DDSP_SL_NO_LOAD) || defined(DDSP_SL_NO_FFT) || defined(DDSP_SL_UNFUSED)
 #ifndef DDSP_SL_NO_LOAD
@@ -390,7 +428,7 @@ __device__ __forceinline__ void sl_frames_to_spectra(float2* s, const float* __r
 template <int S>
 __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThreads / 64], const float* __restrict__ target,
                                               const float* __restrict__ audio, double* __restrict__ partial, int N,
-                                              int n_frames, float safe_eps, int bx, int b, int nbx) {
+                                              int n_frames, float safe_eps, int bx, int b, int nbx, int F = S, int hop = S / 4) {
   // A real frame x[0..S) is transformed as the complex sequence z[n] = x[2n] + i x[2n+1] of H = S/2
   // points; X[k] = E[k] + exp(-2 pi i k / S) O[k] with E, O untangled from Z[k] and Z[H-k].  An
   // all-zero frame still gives exact zeros (nothing of another frame or signal is mixed in).
@@ -401,7 +439,7 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N);
+  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N, F, hop);
   // ---- untangle, magnitudes of bins 0 .. S/2, L1 terms ---------------------------------------------
   // per PAIR of bins (k, S/2 - k), k = 0 .. S/4: the two share the packed bins Z[k] and Z[H-k], their positions and the
   // twiddle (X[k] = E + W^k O, X[H-k] = conj(E - W^k O)) - half the LDS reads, bit reversals and sin / cos of a loop over
@@ -462,6 +500,8 @@ __device__ __forceinline__ void stft_l1_block(float2* s, double (*red)[kSlThread
 struct SlMulti {
   int n;
   int size[16], first[17], nbx[16], frames[16], offset[16];      // per size: S, first linear block, blocks per row, frames, partial offset
+  int frame[16];                                                 // ... and the frame's length F <= S (F < S: 3 * 2^k samples under 2^(k+2) points)
+  FastDiv hop_div[16];                                           // F / 4
   float mag_scale[16], log_scale[16];                            // (the gradient kernel: weight / count of the size)
   int units;                                                     // > 0: the XCD-aware block order below (B * nbx units of n blocks)
   FastDiv n_div, nbx_div;                                        // n; nbx (the same for every size)
@@ -503,7 +543,7 @@ __global__ __launch_bounds__(kSlThreads, 8) void stft_l1_kernel(const float* __r
   if (!sl_where(m, (int)blockIdx.x, z, b, bx)) return;
   const int nbx = m.nbx[z];
   double* dst = partial + 2 * (size_t)m.offset[z];
-#define DDSP_SL_BLOCK(SZ) case SZ: stft_l1_block<SZ>(s, red, target, audio, dst, N, m.frames[z], safe_eps, bx, b, nbx); break
+#define DDSP_SL_BLOCK(SZ) case SZ: stft_l1_block<SZ>(s, red, target, audio, dst, N, m.frames[z], safe_eps, bx, b, nbx, m.frame[z], m.frame[z] / 4); break
   switch (m.size[z]) {
     DDSP_SL_BLOCK(16); DDSP_SL_BLOCK(32); DDSP_SL_BLOCK(64); DDSP_SL_BLOCK(128); DDSP_SL_BLOCK(256);
     DDSP_SL_BLOCK(512); DDSP_SL_BLOCK(1024); DDSP_SL_BLOCK(2048); DDSP_SL_BLOCK(4096);
@@ -565,7 +605,8 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
                                                   const float* __restrict__ audio, const float* __restrict__ grad_loss,
                                                   float* __restrict__ grad_audio, int N, int n_frames, float safe_eps,
                                                   float mag_scale, float log_scale, double* __restrict__ partial,
-                                                  const float* __restrict__ cot, int bx, int b, int nbx) {
+                                                  const float* __restrict__ cot, int bx, int b, int nbx, int F = S,
+                                                  FastDiv hop_div = FastDiv{(uint32_t)(S / 4), 0u}) {
   constexpr int H = S / 2;
   constexpr int G = kSlPoints / 2 / H;
   constexpr int LOG2H = __builtin_ctz(H);
@@ -574,7 +615,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   const int f0 = bx * G;
   const float* __restrict__ trow = target + (size_t)b * N;
   const float* __restrict__ arow = audio + (size_t)b * N;
-  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N);
+  sl_frames_to_spectra<S>(s, trow, arow, tid, f0, n_frames, N, F, (int)hop_div.d);
   // ---- bins -> gradient spectrum, in place in the audio half of the array --------------------------
   // grad_loss == nullptr: the fused loss + gradient call - dL/dloss = 1 and the block's L1 sums go to
   // `partial` exactly as stft_l1_kernel writes them (the frame spectra are computed once for both)
@@ -661,6 +702,28 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
   // blocks and go through fp32 atomics.  (One atomic per frame and sample, 49 M per call at batch 32,
   // was the bound of this kernel.)
   float* __restrict__ grow = grad_audio + (size_t)b * N;
+  if (F != S) {
+    // frames of F = 4 hop samples under a transform of S points (round 6): the same gather with the hop a run-time number - a
+    // division by it (fastdiv) and the window by its own sine per frame
+    const int hop = (int)hop_div.d;
+    const float inv_F = 1.0f / (float)F;
+    for (int pidx = tid; pidx < (G + 3) * hop; pidx += kSlThreads) {
+      const long n = (long)f0 * hop + pidx;
+      if (n >= N) continue;
+      uint32_t ir_;
+      const int gp = (int)fastdiv((uint32_t)pidx, hop_div, ir_), ir = (int)ir_;
+      float acc = 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int g = gp - jj, i = ir + jj * hop;             // frame g covers the sample at its index i < F
+        if (g >= 0 && g < G && f0 + g < n_frames) {
+          const float2 u = s[SP(((g + G) << LOG2H) + (i >> 1))];
+          acc = fmaf(2.0f * ((i & 1) ? u.y : u.x), sl_hann((float)i * inv_F), acc);
+        }
+      }
+      unsafeAtomicAdd(&grow[n], acc);
+    }
+  } else {
   constexpr int LOG2HOP = __builtin_ctz(HOP);
 #ifdef DDSP_SL_NO_OLA
   if (N == 12345)
@@ -691,6 +754,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     unsafeAtomicAdd(&grow[n], acc);
 #endif
   }
+  }
   if (partial) {                                               // block-uniform
     const double sm = (double)wave_sum(dm_sum), sl = (double)wave_sum(dl_sum);
     if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = sl; }
@@ -716,7 +780,8 @@ __global__ __launch_bounds__(kSlThreads, 8) void stft_l1_bwd_kernel(const float*
   const int nbx = m.nbx[z];
   double* dst = partial ? partial + 2 * (size_t)m.offset[z] : nullptr;
 #define DDSP_SLB_BLOCK(SZ) case SZ: stft_l1_bwd_block<SZ, false>(s, red, target, audio, grad_loss, grad_audio, N, m.frames[z], \
-                                                                 safe_eps, m.mag_scale[z], m.log_scale[z], dst, nullptr, bx, b, nbx); break
+                                                                 safe_eps, m.mag_scale[z], m.log_scale[z], dst, nullptr, bx, b, nbx, \
+                                                                 m.frame[z], m.hop_div[z]); break
   switch (m.size[z]) {
     DDSP_SLB_BLOCK(16); DDSP_SLB_BLOCK(32); DDSP_SLB_BLOCK(64); DDSP_SLB_BLOCK(128); DDSP_SLB_BLOCK(256);
     DDSP_SLB_BLOCK(512); DDSP_SLB_BLOCK(1024); DDSP_SLB_BLOCK(2048); DDSP_SLB_BLOCK(4096);
@@ -968,9 +1033,18 @@ __global__ __launch_bounds__(kSlFinishThreads) void spectral_loss_finish_kernel(
   }
 }
 
-static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }
+static inline int sl_frames(int N, int S) { const int hop = S / 4; return (N + hop - 1) / hop; }       // (S: the FRAME size)
 static inline int sl_blocks(int N, int S) { const int g = kSlPoints / S; return (sl_frames(N, S) + g - 1) / g; }
 static inline bool sl_size_ok(int S) { return S >= 16 && S <= kSlPoints && (S & (S - 1)) == 0; }
+// The fused 'L1' kernels' frame sizes (round 6): a power of two in [16, 4096] - or 3 * 2^k in [48, 3072] (gin/models/vst/vst_48k.gin:
+// 3072 .. 192), a frame of F = 4 hop samples zero-padded to the 4 F / 3 points tf.signal.stft transforms.  -> that transform's
+// size, or 0 (6144 samples need 8192 points: two signals of one frame do not fit a block's 4096 complex points - the plain kernels).
+static inline int sl_fused_fft_size(int F) {
+  if (sl_size_ok(F)) return F;
+  if (F >= 48 && F <= 3072 && F % 3 == 0 && ((F / 3) & (F / 3 - 1)) == 0) return 4 * (F / 3);
+  return 0;
+}
+static inline int sl_fused_blocks(int N, int F) { const int g = kSlPoints / sl_fused_fft_size(F); return (sl_frames(N, F) + g - 1) / g; }
 // the one grid of all sizes: in descending order of size - the long blocks first -, whatever order the caller lists them
 // in (the partial sums stay in the caller's order: fin.offset)
 struct SlFinishArgs;
@@ -983,8 +1057,9 @@ static inline bool sl_plan_grid(SlMulti& m, const Fin& fin, int B, int N, const 
   long long total = 0;
   m.n = n_sizes;
   for (int i = 0; i < n_sizes; ++i) {
-    const int z = order[i], S = fft_sizes[z];
-    m.size[i] = S; m.first[i] = (int)total; m.nbx[i] = sl_blocks(N, S); m.frames[i] = sl_frames(N, S); m.offset[i] = fin.offset[z];
+    const int z = order[i], F = fft_sizes[z], S = sl_fused_fft_size(F);
+    m.size[i] = S; m.frame[i] = F; m.hop_div[i] = make_fastdiv((uint32_t)(F / 4));
+    m.first[i] = (int)total; m.nbx[i] = sl_fused_blocks(N, F); m.frames[i] = sl_frames(N, F); m.offset[i] = fin.offset[z];
     m.mag_scale[i] = 0.0f; m.log_scale[i] = 0.0f;
     total += (long long)B * m.nbx[i];
   }
@@ -1015,8 +1090,8 @@ extern "C" size_t ddsp_spectral_loss_workspace_bytes(int B, int N, const int* ff
   if (B <= 0 || N <= 0 || !fft_sizes || n_sizes <= 0 || n_sizes > 16) return 0;
   size_t pairs = 0;
   for (int z = 0; z < n_sizes; ++z) {
-    if (!sl_size_ok(fft_sizes[z])) return 0;
-    pairs += (size_t)B * sl_blocks(N, fft_sizes[z]);
+    if (!sl_fused_fft_size(fft_sizes[z])) return 0;
+    pairs += (size_t)B * sl_fused_blocks(N, fft_sizes[z]);
   }
   return pairs * 2 * sizeof(double);
 }
@@ -1028,7 +1103,7 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
   if (!target_audio || !audio || !loss || !workspace || !fft_sizes) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
   if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
-  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
+  for (int z = 0; z < n_sizes; ++z) if (!sl_fused_fft_size(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
   if (workspace_bytes < ddsp_spectral_loss_workspace_bytes(B, N, fft_sizes, n_sizes) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15))
     return DDSP_ERR_WORKSPACE;
@@ -1038,9 +1113,9 @@ extern "C" int ddsp_spectral_loss_f32(const float* target_audio, const float* au
   fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
   int offset = 0;
   for (int z = 0; z < n_sizes; ++z) {
-    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+    const int F = fft_sizes[z], frames = sl_frames(N, F), blocks = sl_fused_blocks(N, F);
     fin.offset[z] = offset; fin.count[z] = B * blocks;
-    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(sl_fused_fft_size(F) / 2 + 1));
     offset += B * blocks;
   }
   SlMulti m;
@@ -1060,7 +1135,7 @@ static int sl_backward_impl(const float* target_audio, const float* audio, const
   if (!target_audio || !audio || !grad_audio || !fft_sizes) return DDSP_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || n_sizes <= 0) return DDSP_ERR_BAD_SHAPE;
   if (n_sizes > 16 || B > 65535) return DDSP_ERR_UNSUPPORTED;
-  for (int z = 0; z < n_sizes; ++z) if (!sl_size_ok(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
+  for (int z = 0; z < n_sizes; ++z) if (!sl_fused_fft_size(fft_sizes[z])) return DDSP_ERR_UNSUPPORTED;
   double* partial = nullptr;
   if (loss) {
     if (!workspace) return DDSP_ERR_NULL_POINTER;
@@ -1074,9 +1149,9 @@ static int sl_backward_impl(const float* target_audio, const float* audio, const
   fin.n_sizes = n_sizes; fin.mag_weight = mag_weight; fin.logmag_weight = logmag_weight;
   int offset = 0;
   for (int z = 0; z < n_sizes; ++z) {
-    const int S = fft_sizes[z], frames = sl_frames(N, S), blocks = sl_blocks(N, S);
+    const int F = fft_sizes[z], frames = sl_frames(N, F), blocks = sl_fused_blocks(N, F);
     fin.offset[z] = offset; fin.count[z] = B * blocks;
-    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(S / 2 + 1));
+    fin.inv_elems[z] = 1.0 / ((double)B * (double)frames * (double)(sl_fused_fft_size(F) / 2 + 1));
     offset += B * blocks;
   }
   SlMulti m;

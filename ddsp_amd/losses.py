@@ -216,9 +216,16 @@ class SpectralLoss(Loss):
     if target_audio.dim() != 2 or target_audio.shape != audio.shape:
       raise ValueError('target_audio and audio must both be [batch, n_samples], got {} and {}'.format(
           tuple(target_audio.shape), tuple(audio.shape)))
-    general = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
-               self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or self.loudness_weight > 0 or
-               any(int(v) & (int(v) - 1) for v in self.fft_sizes))         # frames that are not powers of two (vst_48k.gin: 3 * 2**k): the plain kernels
+    plain_terms = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
+                   self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or self.loudness_weight > 0)
+    # frame sizes the fused 'L1' kernels take: 2^k in [16, 4096] and, since round 6, 3 * 2^k in [48, 3072] (vst_48k.gin:56 asks for
+    # 6144, 3072 .. 192: five of its six scales); the others (6144: an 8192-point transform; any other even size) on the plain kernels
+    others = [v for v in self.fft_sizes if not self._fused_size(v)]
+    if not plain_terms and others and len(others) < len(self.fft_sizes):
+      # the loss is a sum over its scales (losses.py:199-236): the fused kernels for the scales they take, the plain ones for the rest
+      fused_part, plain_part = self._split_by_kernel(others)
+      return fused_part.call(target_audio, audio) + plain_part.call(target_audio, audio)
+    general = plain_terms or bool(others)
     if general:
       weights = self._weights_tensor(weights, audio.device)
       if torch.is_grad_enabled() and audio.requires_grad:
@@ -227,6 +234,22 @@ class SpectralLoss(Loss):
     if torch.is_grad_enabled() and audio.requires_grad:
       return _SpectralLossFunction.apply(target_audio.detach(), audio, self)
     return self._forward(target_audio, audio)
+
+  @staticmethod
+  def _fused_size(v):
+    v = int(v)
+    return (16 <= v <= 4096 and not v & (v - 1)) or (48 <= v <= 3072 and v % 3 == 0 and not (v // 3) & (v // 3 - 1))
+
+  def _split_by_kernel(self, others):
+    key = tuple(int(v) for v in self.fft_sizes)
+    if getattr(self, '_split_key', None) != key:
+      kw = dict(loss_type=self.loss_type, mag_weight=self.mag_weight, logmag_weight=self.logmag_weight)
+      self._split_parts = (SpectralLoss(fft_sizes=tuple(v for v in self.fft_sizes if v not in others), **kw),
+                           SpectralLoss(fft_sizes=tuple(others), **kw))
+      self._split_key = key
+    for part in self._split_parts:           # (the weights are plain attributes a caller may change between calls)
+      part.mag_weight, part.logmag_weight = self.mag_weight, self.logmag_weight
+    return self._split_parts
 
   @staticmethod
   def _weights_tensor(weights, device):
@@ -369,7 +392,7 @@ class SpectralLoss(Loss):
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
-      raise ValueError('fft_sizes must be at most 16 powers of two in [16, 4096], got {}'.format(
+      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 4096], 3 * 2**k in [48, 3072]), got {}'.format(
           tuple(self.fft_sizes)))
     ws = self._ws.get(nbytes, audio.device)
     loss = torch.empty((), dtype=torch.float32, device=audio.device)
@@ -385,7 +408,7 @@ class SpectralLoss(Loss):
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
-      raise ValueError('fft_sizes must be at most 16 powers of two in [16, 4096], got {}'.format(
+      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 4096], 3 * 2**k in [48, 3072]), got {}'.format(
           tuple(self.fft_sizes)))
     ws = self._ws.get(nbytes, audio.device)
     loss = torch.empty((), dtype=torch.float32, device=audio.device)
