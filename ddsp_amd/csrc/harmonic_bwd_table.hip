@@ -231,11 +231,20 @@ __global__ __launch_bounds__(W == 10 ? 1024 : 64 * kBtFrames, DDSP_BT_MIN_WAVES)
         const int i_abs = (int)flu;
         const int i0 = i_abs & (kBtT - 1);
         const int rev_abs = i_abs >> 9;
-        const int rev = rev_abs - __builtin_amdgcn_readfirstlane(rev_abs);
         // the revolutions the tile's LIVE samples span: positions grow along the frame, so the last live lane holds the last
         // (lane 63 of a frame's last tile is past the frame when hop % 64 != 0: taken from there, live lanes' turns were
         // skipped and their share of G dropped - ADVICE r4)
-        const int rev_last = __builtin_amdgcn_readlane(rev, min(63, p.hop - 1 - t0));
+        const int last_live = min(63, p.hop - 1 - t0);
+        int rev = rev_abs - __builtin_amdgcn_readfirstlane(rev_abs);
+        int rev_last = __builtin_amdgcn_readlane(rev, last_live);
+        // A tile whose live samples span fewer than T entries takes ONE turn even when it crosses the end of the table: the
+        // entries (i_abs + tap offset) mod T of a fixed tap number are distinct as long as i_abs grows by >= 1 per lane and by
+        // less than T over the tile, whatever revolution they fall in.  At 70 Hz a tile spans 143 entries, 28 % of the tiles wrap,
+        // and with eight frames per group nearly every group waited for a wavefront that ran the W read-modify-writes twice
+        // (round 6).
+#ifndef DDSP_EXP_BT_TWO_TURNS         // (the A/B switch of tools/exp_bwd.py)
+        if (__builtin_amdgcn_readlane(i_abs, last_live) - __builtin_amdgcn_readfirstlane(i_abs) < kBtT) { rev = 0; rev_last = 0; }
+#endif
         const float zz = z * z;
         float w_lo[W / 2], w_hi[W / 2];
 #pragma unroll

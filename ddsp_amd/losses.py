@@ -218,8 +218,9 @@ class SpectralLoss(Loss):
           tuple(target_audio.shape), tuple(audio.shape)))
     plain_terms = (self.loss_type.upper() != 'L1' or weights is not None or self.delta_time_weight > 0 or
                    self.delta_freq_weight > 0 or self.cumsum_freq_weight > 0 or self.loudness_weight > 0)
-    # frame sizes the fused 'L1' kernels take: 2^k in [16, 4096] and, since round 6, 3 * 2^k in [48, 3072] (vst_48k.gin:56 asks for
-    # 6144, 3072 .. 192: five of its six scales); the others (6144: an 8192-point transform; any other even size) on the plain kernels
+    # frame sizes the fused 'L1' kernels take: 2^k in [16, 8192] and, since round 6, 3 * 2^k in [48, 6144] (vst_48k.gin:56 asks for
+    # 6144, 3072 .. 192; 8192-point transforms one frame and one signal at a time: stft_l1_big_kernel); any other even size on the
+    # plain kernels
     others = [v for v in self.fft_sizes if not self._fused_size(v)]
     if not plain_terms and others and len(others) < len(self.fft_sizes):
       # the loss is a sum over its scales (losses.py:199-236): the fused kernels for the scales they take, the plain ones for the rest
@@ -238,7 +239,7 @@ class SpectralLoss(Loss):
   @staticmethod
   def _fused_size(v):
     v = int(v)
-    return (16 <= v <= 4096 and not v & (v - 1)) or (48 <= v <= 3072 and v % 3 == 0 and not (v // 3) & (v // 3 - 1))
+    return (16 <= v <= 8192 and not v & (v - 1)) or (48 <= v <= 6144 and v % 3 == 0 and not (v // 3) & (v // 3 - 1))
 
   def _split_by_kernel(self, others):
     key = tuple(int(v) for v in self.fft_sizes)
@@ -279,9 +280,9 @@ class SpectralLoss(Loss):
     for z, size in enumerate(self.fft_sizes):
       size = int(size)
       pow2 = 16 <= size <= 4096 and not size & (size - 1)
-      other = 34 <= size <= 8190 and size % 2 == 0 and size & (size - 1)       # (vst_48k.gin: 6144, 3072 .. 192; any since round 6)
+      other = (34 <= size <= 8190 and size % 2 == 0 and size & (size - 1)) or size == 8192       # (vst_48k.gin: 6144, 3072 .. 192; any since round 6)
       if not (pow2 or other):
-        raise ValueError('fft_sizes must be powers of two in [16, 4096] or even sizes in [34, 8190] on the MI355X path (odd frames, '
+        raise ValueError('fft_sizes must be powers of two in [16, 8192] or even sizes in [34, 8190] on the MI355X path (odd frames, '
                          'and frames of fewer than 34 samples that are not powers of two, are not built), got {}'.format(
                              tuple(self.fft_sizes)))
       # spectral_ops.stft (spectral_ops.py:40-45): tf.signal.stft with fft_length=None transforms the ENCLOSING power of two
@@ -392,7 +393,7 @@ class SpectralLoss(Loss):
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
-      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 4096], 3 * 2**k in [48, 3072]), got {}'.format(
+      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 8192], 3 * 2**k in [48, 6144]), got {}'.format(
           tuple(self.fft_sizes)))
     ws = self._ws.get(nbytes, audio.device)
     loss = torch.empty((), dtype=torch.float32, device=audio.device)
@@ -408,7 +409,7 @@ class SpectralLoss(Loss):
     lib = _lib.load()
     nbytes = lib.ddsp_spectral_loss_workspace_bytes(b, n, sizes, len(self.fft_sizes))
     if nbytes == 0:
-      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 4096], 3 * 2**k in [48, 3072]), got {}'.format(
+      raise ValueError('fft_sizes must be at most 16 sizes the fused kernels take (2**k in [16, 8192], 3 * 2**k in [48, 6144]), got {}'.format(
           tuple(self.fft_sizes)))
     ws = self._ws.get(nbytes, audio.device)
     loss = torch.empty((), dtype=torch.float32, device=audio.device)

@@ -314,7 +314,7 @@ int ddsp_sum_rows_f32(const float* x, float* out, int B, int L, int zero_first, 
  *     *loss = sum over fft_sizes of  mag_weight * mean|mag_t - mag_a| + logmag_weight * mean|safe_log mag_t - safe_log mag_a|
  * with mag = |tf.signal.stft(frame_length=S, frame_step=S/4, pad_end=True)| (spectral_ops.py:34-47,
  * 67-70), safe_log per core.py:213-216.  target_audio, audio [B,N] and loss (one float) are device
- * pointers; fft_sizes is a HOST array of n_sizes (<= 16) frame sizes: powers of two in [16, 4096] or (round 6) 3 * 2^k in [48, 3072] -
+ * pointers; fft_sizes is a HOST array of n_sizes (<= 16) frame sizes: powers of two in [16, 8192] or (round 6) 3 * 2^k in [48, 6144] -
  * gin/models/vst/vst_48k.gin:56 -, frames of 4 hops zero-padded to the 4 F / 3 points tf.signal.stft transforms (S / 2 + 1 bins).
  * workspace: ddsp_spectral_loss_workspace_bytes(...) bytes (per-block fp64 partial sums; the
  * result does not depend on scheduling).
@@ -372,7 +372,7 @@ int ddsp_spectral_terms_f32(const float* target_mag, const float* value_mag, con
                             float cumsum_freq_weight, float logmag_weight, int first, void* stream);
 int ddsp_stft_mag_backward_f32(const float* audio, const float* grad_mag, float* grad_audio, int B, int N, int fft_size,
                                void* stream);
-/* fft_size of the two calls above: a power of two in [16, 4096], or any other EVEN frame size in [34, 8190] (gin/models/vst/
+/* fft_size of the two calls above: a power of two in [16, 8192], or any other EVEN frame size in [34, 8190] (gin/models/vst/
  * vst_48k.gin:56 asks for 6144, 3072 .. 192; any since round 6) - tf.signal.stft then transforms the enclosing power of two S,
  * the frame zero-padded, every int(fft_size / 4) samples: bins = S / 2 + 1.
  *
