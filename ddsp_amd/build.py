@@ -13,6 +13,15 @@ OUT = os.path.join(HERE, 'lib', 'libddsp_amd.so')
 
 STAMP = OUT + '.stamp'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fno-slp-vectorize']
+# Per-source compiler switches.  The FIR kernels of FilteredNoise sit AT their register budget (128 VGPRs, two blocks of eight
+# wavefronts per CU); with LLVM's AMDGPU-specific register-pressure trackers the pre-RA scheduler orders their software pipelines
+# so that the 2^23-level instance of noise_mfma65_kernel runs 36.6 -> 34.5 us per launch at batch 128 and tv_fir_mfma_kernel
+# 35.0 -> 33.5 (same-session A/B, profiles/r06_compiler_scheduling_switches.txt).  Every other source measured the same with it
+# or 0.3 us slower (harmonic_table.hip), so it stays per file.
+EXTRA_FLAGS = {
+    'filtered_noise_mfma.hip': ['-mllvm', '-amdgpu-use-amdgpu-trackers=1'],
+    'filtered_noise_general.hip': ['-mllvm', '-amdgpu-use-amdgpu-trackers=1'],
+}
 
 
 def _deps():
@@ -24,7 +33,7 @@ def _deps():
 def source_digest():
   """sha256 over the sources, the header and the compiler flags: a snapshot copied to another
   box need not preserve mtimes, and a needless rebuild there costs minutes of GPU-box time."""
-  h = hashlib.sha256(' '.join(FLAGS + SOURCES).encode())
+  h = hashlib.sha256(' '.join(FLAGS + SOURCES + [k + ' '.join(v) for k, v in sorted(EXTRA_FLAGS.items())]).encode())
   for d in _deps():
     with open(d, 'rb') as f:
       h.update(os.path.basename(d).encode() + b'\0' + f.read())
@@ -52,7 +61,7 @@ def build(force=False, verbose=True):
 
   def compile_one(src):
     obj = os.path.join(objdir, src.replace('.hip', '.o'))
-    cmd = [hipcc] + compile_flags + ['-c', os.path.join(HERE, 'csrc', src), '-o', obj]
+    cmd = [hipcc] + compile_flags + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(HERE, 'csrc', src), '-o', obj]
     if verbose:
       print('[ddsp_amd.build]', ' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)

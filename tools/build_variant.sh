@@ -12,7 +12,8 @@ objs=""
 for o in ddsp_amd/lib/obj/*.o; do
   b=$(basename $o .o)
   if echo " $FILES " | grep -q " $b.hip "; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude "$@" -c ddsp_amd/csrc/$b.hip -o tools/bin/${b}_$NAME.o &
+    extra=$(python -c "from ddsp_amd import build; print(' '.join(build.EXTRA_FLAGS.get('$b.hip', [])))")      # the product's per-source switches
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Iinclude $extra "$@" -c ddsp_amd/csrc/$b.hip -o tools/bin/${b}_$NAME.o &
     objs="$objs tools/bin/${b}_$NAME.o"
   else
     objs="$objs $o"
