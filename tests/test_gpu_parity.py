@@ -1363,6 +1363,41 @@ def test_harmonic_backward_ragged_frames_and_steep_f0_drops(ddsp, hop):
   np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=slack * grad_tol(gh))
 
 
+def test_harmonic_sloping_ramp_exactly_on_nyquist_is_a_knife_edge(ddsp):
+  """tools/fuzz_parity.py harmonic_bwd:41016811 (round 6, the one failure of seeds 31 / 37 / 41 / 43): frames of 192 samples,
+  harmonic 8 of f0 falling from fl32(1000.07117) to fl32(999.85767) Hz - 8 f0 falls by 1.7080078125 Hz, a third of which is
+  representable, so at r = 64 the ramp is EXACTLY 8000 Hz in fp64 and in the kernels' (and the reference's) fp32 op order: masked.
+  The oracle's backward keeps TF's fp32 resize POSITION (fl32(4096 fl32(1 / 192)) = 21.333334) in fp64 arithmetic and finds the
+  harmonic 1e-6 Hz below Nyquist: one sample's worth of that harmonic, 1 % of dL/d amplitude of the frame.  The exact-arithmetic
+  checker now calls such a sample a knife edge like any near miss (only a flat ramp on Nyquist is unambiguous); the forward
+  output there is held to the reference's fp32 side, the backward to the oracle with no cotangent on knife-edge samples."""
+  f32 = np.float32
+  hop, sr, k = 192, 16000, 20
+  f0 = np.array([1000.3, 1000.07117, 999.85767, 1000.0506, 999.9], dtype=f32).reshape(1, -1, 1)
+  n_frames = f0.shape[1]
+  n = n_frames * hop
+  rng = np.random.default_rng(41016811)
+  amps = rng.standard_normal((1, n_frames, 1)).astype(f32)
+  hd = rng.standard_normal((1, n_frames, k)).astype(f32)
+  exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='fp32 mask')
+  t = 1 * hop + 64
+  top, bot = f32(f0[0, 1, 0] * f32(8)), f32(f0[0, 2, 0] * f32(8))
+  assert float(top) + (float(bot) - float(top)) * (64 / 192) == 8000.0          # the premise: exactly on Nyquist in fp64
+  assert knife[0, t] and int(knife.sum()) <= 8
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
+  got = npy(synth(amps, hd, f0))
+  assert np.abs(got - exact)[~knife].max() <= HARM_TABLE_ATOL
+  assert_knife_edges_take_the_fp32_side(got, exact32, knife, HARM_TABLE_ATOL, 'sloping ramp on Nyquist')
+  g = rng.standard_normal((1, n)).astype(f32)
+  g[knife] = 0.0
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  synth(ta, th, f0).backward(ddsp.core.tf_float32(g))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, 'window')
+  np.testing.assert_allclose(npy(ta.grad), ga, rtol=0, atol=grad_tol(ga))
+  np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=grad_tol(gh))
+
+
 @pytest.mark.parametrize('scale', [1e-10, 1e-6, 1.0, 3e4, 1e5])
 def test_synth_backward_is_invariant_to_the_scale_of_grad_audio(ddsp, scale):
   """the matrix-core backward kernels split dL/d audio (Harmonic: its spread image G) into fp16 hi / lo
@@ -1845,7 +1880,10 @@ def _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=False):
     # samples where a harmonic sits within fp32 rounding of Nyquist: the reference's fp32 comparison (which the kernels
     # reproduce) and the fp64 one may fall on different sides
     d = ft * q - sr / 2                      # (exactly on Nyquist - f0 = 200 Hz, harmonic 40 - is not ambiguous: both say >=)
-    knife |= (d != 0) & (np.abs(d) <= 4e-7 * sr)
+    # ... on a FLAT ramp.  A sloping one that lands exactly on Nyquist in fp64 is as ambiguous as any near miss: frames of 192
+    # samples, r = 64, top - bot divisible by three - d == 0.0 here and fl32 agrees, but the oracle's backward keeps TF's fp32
+    # resize position (21.333334 for 21 1/3) and finds the harmonic 1e-6 Hz below (fuzz seed harmonic_bwd:41016811, round 6)
+    knife |= (np.abs(d) <= 4e-7 * sr) & ((d != 0) | (top != bot))
   if with_knife_edges == 'fp32 mask':
     return out, knife, out32
   return (out, knife) if with_knife_edges else out
