@@ -708,6 +708,30 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     // division by it (fastdiv) and the window by its own sine per frame
     const int hop = (int)hop_div.d;
     const float inv_F = 1.0f / (float)F;
+#if !defined(DDSP_EXP_SL_OLA_SINGLES)
+    if ((hop & 1) == 0) {                                      // (every 3 * 2^k frame the fused path takes: hop = 3 * 2^(k - 2), k >= 4)
+      // sample pairs, as below: four LDS reads per pair
+      for (int pp = tid; pp < (G + 3) * (hop >> 1); pp += kSlThreads) {
+        const int pidx = 2 * pp;
+        const long n = (long)f0 * hop + pidx;
+        if (n >= N) continue;
+        uint32_t ir_;
+        const int gp = (int)fastdiv((uint32_t)pidx, hop_div, ir_), ir = (int)ir_;       // (ir even)
+        float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int g = gp - jj, i = ir + jj * hop;
+          if (g >= 0 && g < G && f0 + g < n_frames) {
+            const float2 u = s[SP(((g + G) << LOG2H) + (i >> 1))];
+            acc0 = fmaf(2.0f * u.x, sl_hann((float)i * inv_F), acc0);
+            acc1 = fmaf(2.0f * u.y, sl_hann((float)(i + 1) * inv_F), acc1);
+          }
+        }
+        unsafeAtomicAdd(&grow[n], acc0);
+        if (n + 1 < N) unsafeAtomicAdd(&grow[n + 1], acc1);
+      }
+    } else
+#endif
     for (int pidx = tid; pidx < (G + 3) * hop; pidx += kSlThreads) {
       const long n = (long)f0 * hop + pidx;
       if (n >= N) continue;
@@ -726,6 +750,45 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     }
   } else {
   constexpr int LOG2HOP = __builtin_ctz(HOP);
+#if !defined(DDSP_EXP_SL_OLA_SINGLES)
+  // (round 6) a lane takes the sample PAIR (2 m, 2 m + 1): both sit in one element of the transform (Re, Im), so the four frames
+  // that cover them cost four LDS reads per pair instead of eight - the same fused multiply-adds per sample in the same order
+  static_assert((HOP & 1) == 0, "sample pairs do not straddle a hop");
+#ifdef DDSP_SL_NO_OLA
+  if (N == 12345)
+#endif
+  for (int pp = tid; pp < (G + 3) * (HOP / 2); pp += kSlThreads) {
+    const int pidx = 2 * pp;
+    const int n = f0 * HOP + pidx;
+    if (n >= N) continue;
+    const int gp = pidx >> LOG2HOP, ir = pidx & (HOP - 1);   // (ir even)
+    float acc0 = 0.0f, acc1 = 0.0f;
+    // the window at i = ir + jj S/4: cos(x + jj pi/2) = cos x, -sin x, -cos x, sin x - one sine and one cosine for the four frames
+    const float wrev0 = (float)ir * (1.0f / (float)S), wrev1 = (float)(ir + 1) * (1.0f / (float)S);
+    const float hc0 = 0.5f * __builtin_amdgcn_cosf(wrev0), hs0 = 0.5f * __builtin_amdgcn_sinf(wrev0);
+    const float hc1 = 0.5f * __builtin_amdgcn_cosf(wrev1), hs1 = 0.5f * __builtin_amdgcn_sinf(wrev1);
+    const float wj0[4] = {sl_hann(wrev0), 0.5f + hs0, 0.5f + hc0, 0.5f - hs0};      // (the first quarter as the square: sl_hann)
+    const float wj1[4] = {sl_hann(wrev1), 0.5f + hs1, 0.5f + hc1, 0.5f - hs1};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int g = gp - jj, i = ir + jj * HOP;               // frame g covers the pair at its indices i, i + 1
+      if (g >= 0 && g < G && f0 + g < n_frames) {
+        const float2 u = s[SP(((g + G) << LOG2H) + (i >> 1))];
+        acc0 = fmaf(2.0f * u.x, wj0[jj], acc0);
+        acc1 = fmaf(2.0f * u.y, wj1[jj], acc1);
+      }
+    }
+    // (one fp32 atomic per sample and block, every one of them: blocks of every FFT size run side by side since the end of
+    // round 3.  Rounds 2-3 kept plain read-modify-writes for the samples a block owns among the blocks of ITS size - and
+    // were no faster for it: 190 us against 182 with atomics throughout, profiles/r03v_*)
+#ifdef DDSP_SL_NO_ATOMIC
+    if (acc0 == 1234.5f) { grow[n] = acc0; grow[n + 1] = acc1; }
+#else
+    unsafeAtomicAdd(&grow[n], acc0);
+    if (n + 1 < N) unsafeAtomicAdd(&grow[n + 1], acc1);
+#endif
+  }
+#else
 #ifdef DDSP_SL_NO_OLA
   if (N == 12345)
 #endif
@@ -755,6 +818,7 @@ __device__ __forceinline__ void stft_l1_bwd_block(float2* s, double (*red)[kSlTh
     unsafeAtomicAdd(&grow[n], acc);
 #endif
   }
+#endif
   }
   if (partial) {                                               // block-uniform
     const double sm = (double)wave_sum(dm_sum), sl = (double)wave_sum(dl_sum);
