@@ -64,7 +64,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-DTYPE = 'f32 (Harmonic wavetables and the FilteredNoise FIR/IR products: fp16 hi/lo-split MFMA operands, fp32 accumulate)'
+DTYPE = ('f32 (Harmonic wavetables and the FilteredNoise FIR/IR products: 22-bit operands - fp16 hi/lo pairs on the MFMA matrix cores - '
+         'with fp32 accumulation; everything else plain fp32, the frame phase prefix fp64)')
 
 
 def parse_args(argv=None):
