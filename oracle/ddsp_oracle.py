@@ -949,11 +949,11 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
 
   fp32_envelope = r (tests/test_gpu_parity.py::check_loss_case: 5e-6): returns (gradient, envelope) instead.  The L1 loss is not differentiable where
   two magnitudes are equal, and the logmag term's 1 / |X| (core.safe_log replaces only NON-POSITIVE arguments, core.py:213-216) is
-  unbounded at a spectral null.  fp32 arithmetic - TensorFlow's included - knows a magnitude to `floor` = r of its frame's
+  unbounded at a spectral null (and the mag term's z / |z| has no direction there).  fp32 arithmetic - TensorFlow's included - knows a magnitude to `floor` = r of its frame's
   spectrum + 1e-6 of the norm of the frame's UNWINDOWED samples (the window's own absolute accuracy: what is left of a frame that
   only touches the signal with the last points of its window).  A bin whose |X_t| - |X_a| is within r of their sum + floor has no
   sign fp32 can tell from its neighbours in the SUBDIFFERENTIAL; a bin whose |X_a| is within 30 floor of zero has a 1 / |X_a| that is
-  anything.  Such bins are left out of `gradient`, and `envelope[b, n]` is the largest magnitude their terms can add at sample n
+  anything, one within 3 floor a phasor X_a / |X_a| that is any.  Such bins are left out of `gradient`, and `envelope[b, n]` is the largest magnitude their terms can add at sample n
   (every admissible coefficient, every phase; inf under a frame with a bin at the noise floor): a correct fp32 gradient g satisfies
   |g - gradient| <= envelope + rounding, sample by sample.
   """
@@ -979,6 +979,10 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
                   np.sqrt((frame_pad_end(t, size, hop) ** 2).sum(axis=-1, keepdims=True)))
       floor = r * frame_rms + 1e-6 * frame_l2                      # what fp32 knows a magnitude of this frame to
       unsure = np.abs(mt - ma) <= r * (mt + ma) + floor            # the sign of the difference is rounding's to decide
+      # |z| has gradient z / |z|: the unit phasor of a magnitude INSIDE the noise floor is rounding's to choose too (a DC bin
+      # whose windowed samples cancel to 2.5e-8: fuzz seed loss:47050735, round 6 - mag term alone, one frame of 16 samples off by
+      # its whole coefficient); the coefficient itself stays bounded by mag_weight
+      unsure |= ma <= 3.0 * floor
       bound = np.full(ma.shape, float(mag_weight))
       if logmag_weight > 0:
         null = (ma > 0.0) & (ma <= 30.0 * floor)                   # 1 / |X_a| of a magnitude inside the noise floor: anything

@@ -1209,6 +1209,27 @@ def test_streaming_chunks_are_phase_continuous(ddsp):               # inference.
   assert np.abs(got).max() > 0.2
 
 
+@pytest.mark.parametrize('method', ['linear', 'cubic'])
+def test_streaming_frame_rate_nyquist_mask_takes_the_reference_fp32_side(ddsp, method):
+  """tools/fuzz_parity.py streaming:53047898 (round 6): f0 = fl32(296.2963) Hz, harmonic 27 at 7999.99997 Hz in exact arithmetic
+  and at fl32(27 f0) = 8000.0 in the reference's fp32 product (core.get_harmonic_frequencies, then remove_above_nyquist's
+  f >= sr / 2: core.py:869-903): the reference drops it from the frame's distribution, and so must streaming_harmonic_synthesis -
+  the fp64 oracle keeps it and is 1e-2 away, the fp32-faithful oracle (the reference's op order) agrees to 3e-4."""
+  f32 = np.float32
+  f0 = np.array([296.2963, 305.857], dtype=f32).reshape(1, 2, 1)
+  assert f32(27) * f0[0, 0, 0] == f32(8000.0) and 27 * float(f0[0, 0, 0]) < 8000.0          # the premise
+  rng = np.random.default_rng(53047898)
+  amps = rng.uniform(0.1, 1.0, (1, 2, 1)).astype(f32)
+  hd = rng.uniform(0.0, 1.0, (1, 2, 100)).astype(f32)
+  got, _ = ddsp.core.streaming_harmonic_synthesis(f0, amps, hd, n_samples=64, sample_rate=16000, amp_resample_method=method)
+  ref32, _ = O.streaming_harmonic_synthesis(f0, amps, hd, n_samples=64, sample_rate=16000, amp_resample_method=method,
+                                            dtype=np.float32)
+  ref64, _ = O.streaming_harmonic_synthesis(f0, amps, hd, n_samples=64, sample_rate=16000, amp_resample_method=method,
+                                            dtype=np.float64)
+  assert np.abs(npy(got) - ref32).max() <= 3e-4
+  assert np.abs(ref64 - ref32).max() >= 6e-4             # ... which is not what exact arithmetic gives: the case is what it claims
+
+
 @pytest.mark.parametrize('method,n', [('linear', 320), ('window', 320), ('nearest', 333), ('cubic', 250)])
 def test_streaming_synthesis_with_per_harmonic_amplitudes_and_no_distribution(ddsp, method, n):
   """core.streaming_harmonic_synthesis(frequencies, amplitudes [batch, n_frames, n_harmonics]) without a distribution: the
@@ -1363,14 +1384,14 @@ def test_harmonic_backward_ragged_frames_and_steep_f0_drops(ddsp, hop):
   np.testing.assert_allclose(npy(th.grad), gh, rtol=0, atol=slack * grad_tol(gh))
 
 
-def test_harmonic_sloping_ramp_exactly_on_nyquist_is_a_knife_edge(ddsp):
+def test_harmonic_sloping_ramp_exactly_on_nyquist(ddsp):
   """tools/fuzz_parity.py harmonic_bwd:41016811 (round 6, the one failure of seeds 31 / 37 / 41 / 43): frames of 192 samples,
   harmonic 8 of f0 falling from fl32(1000.07117) to fl32(999.85767) Hz - 8 f0 falls by 1.7080078125 Hz, a third of which is
   representable, so at r = 64 the ramp is EXACTLY 8000 Hz in fp64 and in the kernels' (and the reference's) fp32 op order: masked.
   The oracle's backward keeps TF's fp32 resize POSITION (fl32(4096 fl32(1 / 192)) = 21.333334) in fp64 arithmetic and finds the
   harmonic 1e-6 Hz below Nyquist: one sample's worth of that harmonic, 1 % of dL/d amplitude of the frame.  The exact-arithmetic
-  checker now calls such a sample a knife edge like any near miss (only a flat ramp on Nyquist is unambiguous); the forward
-  output there is held to the reference's fp32 side, the backward to the oracle with no cotangent on knife-edge samples."""
+  checker reports such samples (`hits`: exactly on Nyquist on a sloping ramp) beside the knife edges: the forward output agrees
+  with exact arithmetic there (both mask the harmonic); comparisons against oracle.harmonic_backward carry no cotangent on them."""
   f32 = np.float32
   hop, sr, k = 192, 16000, 20
   f0 = np.array([1000.3, 1000.07117, 999.85767, 1000.0506, 999.9], dtype=f32).reshape(1, -1, 1)
@@ -1380,16 +1401,17 @@ def test_harmonic_sloping_ramp_exactly_on_nyquist_is_a_knife_edge(ddsp):
   amps = rng.standard_normal((1, n_frames, 1)).astype(f32)
   hd = rng.standard_normal((1, n_frames, k)).astype(f32)
   exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='fp32 mask')
+  _, _, hits = _harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='and exact hits')
   t = 1 * hop + 64
   top, bot = f32(f0[0, 1, 0] * f32(8)), f32(f0[0, 2, 0] * f32(8))
   assert float(top) + (float(bot) - float(top)) * (64 / 192) == 8000.0          # the premise: exactly on Nyquist in fp64
-  assert knife[0, t] and int(knife.sum()) <= 8
+  assert hits[0, t] and not knife[0, t] and int(hits.sum()) == 1 and int(knife.sum()) <= 8
   synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   got = npy(synth(amps, hd, f0))
   assert np.abs(got - exact)[~knife].max() <= HARM_TABLE_ATOL
   assert_knife_edges_take_the_fp32_side(got, exact32, knife, HARM_TABLE_ATOL, 'sloping ramp on Nyquist')
   g = rng.standard_normal((1, n)).astype(f32)
-  g[knife] = 0.0
+  g[knife | hits] = 0.0
   ta = ddsp.core.tf_float32(amps).requires_grad_(True)
   th = ddsp.core.tf_float32(hd).requires_grad_(True)
   synth(ta, th, f0).backward(ddsp.core.tf_float32(g))
@@ -1674,7 +1696,8 @@ def check_loss_case(ddsp, case):
 
 @pytest.mark.parametrize('seed', [37014845,                                  # round 5's last campaign: a gradient bulk at n = 1025
                                   31000384, 31003046, 31012330,             # seed 31: values of 17-sample clips under 4096 / 6144 points
-                                  4007713, 4032057, 4014585, 4029689])       # seed 4: two gradient bulks, two more 17-sample clips
+                                  4007713, 4032057, 4014585, 4029689,        # seed 4: two gradient bulks, two more 17-sample clips
+                                  47050735])                                 # round 6, seed 47: the mag term's phasor at a DC bin that cancels to 2.5e-8
 def test_spectral_loss_seeds_the_round_5_campaigns_ended_on(ddsp, seed):
   case = draw_loss_case(np.random.default_rng(seed))
   assert check_loss_case(ddsp, case) <= 1.0
@@ -1863,6 +1886,7 @@ def _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=False):
   out = np.zeros((b, n))
   out32 = np.zeros((b, n))                   # the same sum with the audio-rate mask decided as the reference decides it
   knife = np.zeros((b, n), dtype=bool)
+  hits = np.zeros((b, n), dtype=bool)        # exactly on Nyquist on a sloping ramp (with_knife_edges='and exact hits')
   # the reference's decision (core.py:942-944 on what core.resample made of get_harmonic_frequencies' fp32 products): legacy
   # bilinear resize, top + (bottom - top) * lerp with every step rounded to fp32, compared with fl32(sr / 2).
   # lerp = r / hop is exact in fp32 for frame sizes that are powers of two; for others (192) TF's position t * fl32(F / N) is up
@@ -1880,12 +1904,16 @@ def _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges=False):
     # samples where a harmonic sits within fp32 rounding of Nyquist: the reference's fp32 comparison (which the kernels
     # reproduce) and the fp64 one may fall on different sides
     d = ft * q - sr / 2                      # (exactly on Nyquist - f0 = 200 Hz, harmonic 40 - is not ambiguous: both say >=)
-    # ... on a FLAT ramp.  A sloping one that lands exactly on Nyquist in fp64 is as ambiguous as any near miss: frames of 192
-    # samples, r = 64, top - bot divisible by three - d == 0.0 here and fl32 agrees, but the oracle's backward keeps TF's fp32
-    # resize position (21.333334 for 21 1/3) and finds the harmonic 1e-6 Hz below (fuzz seed harmonic_bwd:41016811, round 6)
-    knife |= (np.abs(d) <= 4e-7 * sr) & ((d != 0) | (top != bot))
+    knife |= (d != 0) & (np.abs(d) <= 4e-7 * sr)
+    # A SLOPING ramp that lands exactly on Nyquist: this function and the kernels' fp32 op order agree on it (masked), but an
+    # evaluation at TF's fp32 resize POSITION - oracle.harmonic_backward's: fl32(4096 fl32(1 / 192)) = 21.333334 for 21 1/3 - finds
+    # the harmonic 1e-6 Hz to one side or the other.  Not knife edges for the forward comparisons; comparisons against that oracle
+    # leave them out as well (fuzz seed harmonic_bwd:41016811, round 6: frames of 192 samples, r = 64, top - bot divisible by three)
+    hits |= (d == 0) & (top != bot)
   if with_knife_edges == 'fp32 mask':
     return out, knife, out32
+  if with_knife_edges == 'and exact hits':
+    return out, knife, hits
   return (out, knife) if with_knife_edges else out
 
 

@@ -60,10 +60,15 @@ def f0_regime(rng, b, f, k, sr):
     f0 = sr / 2.0 / max(k, 1) * (1.0 + 0.01 * rng.standard_normal((b, f, 1)))
   else:
     f0 = np.linspace(60.0, 900.0, f)[None, :, None] * np.ones((b, 1, 1))
-  f0 = np.abs(f0).astype(np.float32)
-  # a harmonic within fp32 rounding of Nyquist AT A FRAME (106.666664 Hz x 75 at 16 kHz: 7999.9998 in exact arithmetic, 8000.0 in
-  # fp32): the reference's fp32 frame-rate mask (core.py:869-891) and an fp64 checker fall on different sides for two whole
-  # frames.  The kernels take the fp32 side (tests/test_gpu_parity.py asserts it per sample); here such values are nudged away.
+  return nudge_off_nyquist(np.abs(f0).astype(np.float32), k, sr), kind, base
+
+
+def nudge_off_nyquist(f0, k, sr):
+  """A harmonic within fp32 rounding of Nyquist AT A FRAME (106.666664 Hz x 75 at 16 kHz: 7999.9998 in exact arithmetic, 8000.0 in
+  fp32): the reference's fp32 frame-rate mask (core.py:869-891) and an fp64 checker fall on different sides for two whole
+  frames.  The kernels take the fp32 side (tests/test_gpu_parity.py asserts it per sample); here such values are nudged away.
+  (Every family whose checker is the fp64 oracle draws its f0 through this: the streaming family did not until seed 53047898 drew
+  fl32(296.2963) Hz - 27 f0 = 7999.99997 exactly, 8000.0 in fp32 - in round 6.)"""
   ks = np.arange(1, max(k, 1) + 1, dtype=np.float64)
   for _ in range(4):
     d = np.abs(f0.astype(np.float64) * ks[None, None, :] - sr / 2.0).min(axis=-1, keepdims=True)
@@ -71,7 +76,7 @@ def f0_regime(rng, b, f, k, sr):
     if not near.any():
       break
     f0 = np.where(near, f0 * np.float32(1.0003), f0).astype(np.float32)
-  return f0, kind, base
+  return f0
 
 
 def case_harmonic(rng):
@@ -123,8 +128,10 @@ def case_harmonic_bwd(rng):
   g = (scale * rng.standard_normal((b, n))).astype(np.float32)
   # samples where a harmonic sits within fp32 rounding of Nyquist (the fp32 mask of the kernels / the reference and the fp64
   # oracle's may differ there): no cotangent, for the kernels and the oracle alike - the gradient is linear in g
-  _, knife = P._harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges=True)
-  g[knife] = 0.0
+  # (... and samples where a SLOPING ramp lands exactly on Nyquist: the oracle's backward evaluates the ramp at TF's fp32 resize
+  #  position and may find the harmonic on the other side - test_harmonic_sloping_ramp_exactly_on_nyquist.., seed 41016811)
+  _, knife, hits = P._harmonic_exact(amps, hd, f0, n, sr, 'window', with_knife_edges='and exact hits')
+  g[knife | hits] = 0.0
   what = note(dict(hop=hop, frames=f, k=k, batch=b, sr=sr, f0=kind, base=base, grad_scale=scale))
   synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr)
   ta = ddsp.core.tf_float32(amps).requires_grad_(True)
@@ -306,7 +313,7 @@ def case_harmonic_chain(rng):
   if b * n * k > 1.5e6:
     n = max(f, int(1.5e6 / (b * k)))
   base = float(rng.choice([70.0, 110.0, 220.0, 440.0]))
-  f0 = np.abs(base * (1.0 + 0.01 * rng.standard_normal((b, f, 1)))).astype(np.float32)
+  f0 = nudge_off_nyquist(np.abs(base * (1.0 + 0.01 * rng.standard_normal((b, f, 1)))).astype(np.float32), k, sr)
   amps = rng.standard_normal((b, f, 1)).astype(np.float32)
   hd = rng.standard_normal((b, f, k)).astype(np.float32)
   what = note(dict(frames=f, n=n, k=k, batch=b, sr=sr, method=method, base=base))
@@ -371,7 +378,7 @@ def case_streaming(rng):
   phase = np.zeros((b, 1, 1), np.float32); phase64 = np.zeros((b, 1, 1))
   worst = 0.0
   for _ in range(calls):
-    f0 = rng.uniform(60.0, 600.0, (b, f, 1)).astype(np.float32)
+    f0 = nudge_off_nyquist(rng.uniform(60.0, 600.0, (b, f, 1)).astype(np.float32), k, sr)
     amps = rng.uniform(0.1, 1.0, (b, f, 1 if with_hd else k)).astype(np.float32)
     hd = rng.uniform(0.0, 1.0, (b, f, k)).astype(np.float32) if with_hd else None
     got, phase = ddsp.core.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase, n_samples=n, sample_rate=sr,
