@@ -1961,6 +1961,30 @@ def test_harmonic_random_shapes_vs_exact_arithmetic(ddsp, seed):
       assert np.abs(got - truth)[~knife].max() <= HARM_TABLE_ATOL * scale, what
 
 
+@pytest.mark.parametrize('k,method', [(99, 'window'), (160, 'linear')])
+def test_harmonic_sweep_through_nyquist_on_frames_of_eight(ddsp, k, method):
+  """tools/fuzz_parity.py harmonic:67005602 / 67051142 (round 6, seed 67's two stops): a 60 -> 900 Hz sweep over 64 frames of EIGHT
+  samples at 44.1 kHz takes harmonics 25 .. k through Nyquist inside 512 samples - one crossing sample per harmonic, a dozen of them
+  within fp32 rounding of Nyquist (2-3 % of the clip: the tool's non-vacuity guard stopped there, the kernels were never compared).
+  Every other sample against exact arithmetic, the knife edges on the reference's fp32 side; the guard's new form - one knife-edge
+  sample per (row, harmonic) that crosses - holds with room."""
+  hop, f, sr, b = 8, 64, 44100, 1
+  n = f * hop
+  rng = np.random.default_rng(67000000 + k)
+  f0 = (np.linspace(60.0, 900.0, f)[None, :, None] * np.ones((b, 1, 1))).astype(np.float32)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  got = npy(ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)(amps, hd, f0))
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  exact, knife, exact32 = _harmonic_exact(amps, hd, f0, n, sr, method, with_knife_edges='fp32 mask')
+  fk = f0.astype(np.float64) * np.arange(1, k + 1, dtype=np.float64)[None, None, :]
+  crossing = int(((fk.min(axis=1) < 0.5 * sr) & (fk.max(axis=1) >= 0.5 * sr)).sum())
+  assert crossing >= 70 and int(knife.sum()) <= crossing and knife.mean() <= 0.1
+  atol = (HARM_TABLE_ATOL if k <= 200 else HARM_TRUTH_ATOL) * scale
+  assert np.abs(got - exact)[~knife].max() <= atol
+  assert_knife_edges_take_the_fp32_side(got, exact32, knife, atol, dict(k=k, method=method))
+
+
 @pytest.mark.parametrize('k', [99, 61, 5, 1])
 def test_harmonic_counts_that_are_not_multiples_of_four(ddsp, k):
   """The reference's own test shape has 99 harmonics (ddsp/processors_test.py:28-73): rows of the distribution that are
