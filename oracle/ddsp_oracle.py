@@ -32,6 +32,8 @@ Two arithmetic modes share one code path (`dtype` argument):
 All tensors are row-major [batch, time, channel], as in the reference.
 """
 
+import contextlib
+
 import numpy as np
 
 TWO_PI = 2.0 * np.pi
@@ -69,6 +71,23 @@ def exp_sigmoid(x, exponent=10.0, max_value=2.0, threshold=1e-7, dtype=np.float3
 # ----------------------------------------------------------------------------
 # Resampling   (ddsp/core.py:573-714)
 # ----------------------------------------------------------------------------
+_EXACT_POSITIONS = [False]
+
+
+@contextlib.contextmanager
+def exact_resize_positions():
+  """Inside this context the BILINEAR legacy resize (what core.resample(..., 'linear') and therefore every frequency envelope
+  goes through) takes its source coordinate t n_in / n_out in exact arithmetic instead of TF's fp32 product with an fp32 scale
+  (up to pos 2^-23 frames off when n_out / n_in is not a power of two).  For checkers that want to know how far the reference's
+  own position rounding moves a result - tools/fuzz_parity.py's streaming family allows the kernels, which take r / hop on clips
+  that are whole frames, that much (known limits).  Never the default: the fixtures pin TF's arithmetic."""
+  _EXACT_POSITIONS[0] = True
+  try:
+    yield
+  finally:
+    _EXACT_POSITIONS[0] = False
+
+
 def resize_bilinear_legacy(x, n_out, align_corners=False):
   """tf.compat.v1.image.resize(BILINEAR) on the time axis of x[B, F, C].
 
@@ -79,6 +98,15 @@ def resize_bilinear_legacy(x, n_out, align_corners=False):
   """
   dt = x.dtype.type
   n_in = x.shape[1]
+  if _EXACT_POSITIONS[0]:
+    # (checkers only, see exact_resize_positions below: t n_in / n_out in fp64 instead of TF's fl32(t fl32(n_in / n_out)))
+    num, den = (n_in - 1, n_out - 1) if (align_corners and n_out > 1) else (n_in, n_out)
+    pos = np.arange(n_out, dtype=np.float64) * num / den
+    lo = np.floor(pos)
+    hi = np.minimum(np.ceil(pos), float(n_in - 1))
+    lo_i, hi_i = lo.astype(np.int64), hi.astype(np.int64)
+    top, bottom = x[:, lo_i, :], x[:, hi_i, :]
+    return top + (bottom - top) * (pos - lo).astype(x.dtype)[None, :, None]
   if align_corners and n_out > 1:
     scale = np.float32(n_in - 1) / np.float32(n_out - 1)
   else:

@@ -1985,6 +1985,86 @@ def test_harmonic_sweep_through_nyquist_on_frames_of_eight(ddsp, k, method):
   assert_knife_edges_take_the_fp32_side(got, exact32, knife, atol, dict(k=k, method=method))
 
 
+def test_streaming_wild_f0_on_frames_of_252_samples(ddsp):
+  """tools/fuzz_parity.py streaming:89027392 (round 6): four calls of core.streaming_harmonic_synthesis, 5 frames of 252 samples,
+  60 harmonics, f0 drawn U(60, 600) Hz PER FRAME.  The reference's frequency envelope takes TF's fp32 resize position
+  fl32(t fl32(5 / 1260)) (up to pos 2^-23 frames off); with steps of hundreds of Hz that alone moves the result by more than this
+  family's tolerance - the fp64 oracle with exact positions against itself with TF's: 3.2e-4 on the second call.  The kernels
+  take r / hop on clips that are whole frames (known limits): held to the tolerance against the exact-position oracle,
+  phase carried call to call, and the distance to the TF-position oracle explained by that oracle pair's own distance."""
+  rng = np.random.default_rng(89027392)
+  b, f = int(rng.integers(1, 3)), int(rng.integers(2, 6))
+  k = int(rng.choice([1, 20, 60, 100]))
+  n = int(rng.choice([64, 320, 512, 1000, int(rng.integers(f, 1500))]))
+  sr = int(rng.choice([16000, 48000]))
+  method = str(rng.choice(['linear', 'linear', 'window', 'nearest', 'cubic']))
+  n = f * int(rng.integers(2, 300))
+  calls = int(rng.integers(1, 5)); with_hd = bool(rng.integers(0, 4))
+  assert (b, f, k, n, sr, method, calls, with_hd) == (1, 5, 60, 1260, 16000, 'window', 4, True)
+  phase = np.zeros((b, 1, 1), np.float32); phase_tf = np.zeros((b, 1, 1)); phase_x = np.zeros((b, 1, 1))
+  moved_most = 0.0
+  for _ in range(calls):
+    f0 = rng.uniform(60.0, 600.0, (b, f, 1)).astype(np.float32)
+    amps = rng.uniform(0.1, 1.0, (b, f, 1)).astype(np.float32)
+    hd = rng.uniform(0.0, 1.0, (b, f, k)).astype(np.float32)
+    got, phase = ddsp.core.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase, n_samples=n, sample_rate=sr,
+                                                        amp_resample_method=method)
+    ref_tf, phase_tf = O.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase_tf, n_samples=n, sample_rate=sr,
+                                                      amp_resample_method=method, dtype=np.float64)
+    with O.exact_resize_positions():
+      ref_x, phase_x = O.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase_x, n_samples=n, sample_rate=sr,
+                                                      amp_resample_method=method, dtype=np.float64)
+    got, phase = npy(got), npy(phase)
+    tol = 3e-4 * max(1.0, float(np.abs(ref_x).max()))
+    moved = float(np.abs(ref_tf - ref_x).max())
+    moved_most = max(moved_most, moved)
+    assert np.abs(got - ref_x).max() <= 0.2 * tol                     # (measured 4e-6)
+    assert np.abs(got - ref_tf).max() <= 0.2 * tol + moved            # ... and no further from TF's positions than they are from exact
+    dphi = np.abs(((phase.astype(np.float64) - phase_x + np.pi) % (2 * np.pi)) - np.pi).max()
+    assert dphi <= 2e-5
+  assert 2.5e-4 < moved_most < 4e-4                                   # the premise: the position rounding alone is worth the tolerance
+
+
+def test_materialised_chain_backward_with_a_quiet_knife_edge(ddsp):
+  """tools/fuzz_parity.py harmonic_chain:83029253 (round 6): 6 frames -> 670 samples at 48 kHz, cubic envelopes, f0 = 440 Hz +- 1 %.
+  Harmonic 54 of row 0 is 4.4e-4 Hz below Nyquist (1.8e-8 sr) at sample 144 in exact arithmetic and at or above it in the fp32
+  comparison of the kernels and of the reference (core.py:942-944) - a knife edge, but a QUIET one: the harmonic is 2.0e-4 of the
+  audio there, under the forward tolerance, so the tool's `e > atol` never set its cotangent aside, and dL/d harmonic_distribution
+  [0, 2, 53] came out 6.2e-4 from the oracle's (tolerance 3.5e-4): one sample's worth of one harmonic.  With the knife edges found
+  from the frequencies themselves the case sits at a twentieth of the tolerance; every other harmonic was there all along."""
+  rng = np.random.default_rng(83029253)
+  f = int(rng.integers(2, 40)); k = int(rng.choice([1, 7, 20, 60, 100])); b = int(rng.integers(1, 3)); sr = int(rng.choice([16000, 48000]))
+  method = str(rng.choice(['nearest', 'cubic', 'linear'])); n = int(rng.integers(f, f * 120))
+  base = float(rng.choice([70.0, 110.0, 220.0, 440.0]))
+  assert (f, k, b, sr, method, n, base) == (6, 60, 2, 48000, 'cubic', 670, 440.0)
+  f0 = np.abs(base * (1.0 + 0.01 * rng.standard_normal((b, f, 1)))).astype(np.float32)
+  amps = rng.standard_normal((b, f, 1)).astype(np.float32)
+  hd = rng.standard_normal((b, f, k)).astype(np.float32)
+  synth = ddsp.synths.Harmonic(n_samples=n, sample_rate=sr, amp_resample_method=method)
+  ta = ddsp.core.tf_float32(amps).requires_grad_(True)
+  th = ddsp.core.tf_float32(hd).requires_grad_(True)
+  audio = synth(ta, th, f0)
+  g = rng.standard_normal((b, n)).astype(np.float32)
+  truth = O.harmonic(amps, hd, f0, n_samples=n, sample_rate=sr, amp_resample_method=method, dtype=np.float64)
+  f_env = O.resample(f0.astype(np.float64), n, method='linear', dtype=np.float64)[:, :, 0]
+  ks = np.arange(1, k + 1, dtype=np.float64)
+  step = np.abs(np.diff(f0.astype(np.float64)[:, :, 0], axis=1)).max()
+  d = np.abs(f_env[:, :, None] * ks[None, None, :] - 0.5 * sr)
+  near = (d <= (4e-7 * sr + f * 2.0 ** -22 * step * ks)[None, None, :])
+  assert near.sum() == 1 and near[0, 144, 53]                                   # the one knife edge, where the docstring says
+  knife = near.any(axis=-1)
+  scale = max(1.0, float(O.exp_sigmoid(amps.astype(np.float64), dtype=np.float64).max()))
+  e = np.abs(npy(audio.detach()) - truth)
+  assert e[~knife].max() <= 8 * HARM_TRUTH_ATOL * scale                         # (cubic envelopes: fuzz_parity's allowance)
+  # at the knife edge the kernel took the fp32 side: harmonic 54 masked - the audio differs from the fp64 oracle's by that harmonic
+  assert 1e-4 < e[0, 144] < 3e-4
+  g[knife] = 0.0
+  audio.backward(ddsp.core.tf_float32(g))
+  ga, gh = O.harmonic_backward(amps, hd, f0, g, n, sr, O.exp_sigmoid, True, method)
+  assert np.abs(npy(ta.grad) - ga).max() <= 1e-5 + 2e-4 * np.abs(ga).max()
+  assert np.abs(npy(th.grad) - gh).max() <= 1e-5 + 2e-4 * np.abs(gh).max()
+
+
 @pytest.mark.parametrize('k', [99, 61, 5, 1])
 def test_harmonic_counts_that_are_not_multiples_of_four(ddsp, k):
   """The reference's own test shape has 99 harmonics (ddsp/processors_test.py:28-73): rows of the distribution that are

@@ -339,6 +339,18 @@ def case_harmonic_chain(rng):
   # (replayed: exactly one sample, off by that harmonic's amplitude); those carry no cotangent below
   knife = e > atol
   assert knife.sum(axis=1).max() <= 3, ('materialised chain forward', float(e.max()), atol, int(knife.sum()))
+  # ... and a QUIET harmonic's knife edge stays under that threshold while its own gradient hears the sample (seed 83029253:
+  # harmonic 54 of a 48 kHz clip 4.4e-4 Hz under Nyquist at one sample, 2.0e-4 in the audio, 6.2e-4 of a 3.5e-4 tolerance in
+  # dL/d harmonic_distribution[.., 53]): the samples at which any harmonic's interpolated frequency is within fp32 rounding of
+  # Nyquist (4e-7 sr, as tests/test_gpu_parity.py::_harmonic_exact) or within what TF's fp32 resize position can move it
+  # (pos 2^-23 frames of the frame-to-frame step) are found here from the frequencies themselves
+  f_env = O.resample(f0.astype(np.float64), n, method='linear', dtype=np.float64)[:, :, 0]                      # [b, n]
+  step = np.abs(np.diff(f0.astype(np.float64)[:, :, 0], axis=1)).max() if f > 1 else 0.0
+  ks = np.arange(1, k + 1, dtype=np.float64)
+  d = np.abs(f_env[:, :, None] * ks[None, None, :] - 0.5 * sr)
+  near = (d <= (4e-7 * sr + f * 2.0 ** -22 * step * ks)[None, None, :]).any(axis=-1)
+  assert near.sum(axis=1).max() <= 3, ('materialised chain: knife-edge samples', int(near.sum()))
+  knife |= near
   err = float(e[~knife].max())
   g[knife] = 0.0
   audio.backward(ddsp.core.tf_float32(g))
@@ -382,7 +394,7 @@ def case_streaming(rng):
   calls = int(rng.integers(1, 5))
   with_hd = bool(rng.integers(0, 4))
   what = note(dict(batch=b, frames=f, k=k, n=n, sr=sr, method=method, calls=calls, with_distribution=with_hd))
-  phase = np.zeros((b, 1, 1), np.float32); phase64 = np.zeros((b, 1, 1))
+  phase = np.zeros((b, 1, 1), np.float32); phase64 = np.zeros((b, 1, 1)); phase64x = np.zeros((b, 1, 1))
   worst = 0.0
   for _ in range(calls):
     f0 = nudge_off_nyquist(rng.uniform(60.0, 600.0, (b, f, 1)).astype(np.float32), k, sr)
@@ -392,14 +404,26 @@ def case_streaming(rng):
                                                         amp_resample_method=method)
     ref, phase64 = O.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase64, n_samples=n, sample_rate=sr,
                                                   amp_resample_method=method, dtype=np.float64)
+    # The reference's frequency envelope takes TF's fp32 resize position, fl32(t fl32(F / N)): up to pos 2^-23 frames off t F / N
+    # when the frame size is not a power of two.  With f0 jumping by hundreds of Hz from frame to frame (this family draws
+    # U(60, 600) per frame) that alone moves the phase by ~1e-5 rad per call, and sixty harmonics hear it: seed 89027392, frames
+    # of 252 samples - the SAME oracle with exact positions is 3.16e-4 away from itself on the second call, the tolerance is
+    # 3.0e-4, and the kernels, which take r / hop on clips that are whole frames (known limits), were 3.13e-4 from the
+    # one and 2e-5 from the other.  Held to the tolerance against ONE of the two position conventions, each chain of calls
+    # carrying its own phase (paths that restate TF's fp32 positions - lengths that are not whole frames - sit on the first).
+    with O.exact_resize_positions():
+      ref_x, phase64x = O.streaming_harmonic_synthesis(f0, amps, hd, initial_phase=phase64x, n_samples=n, sample_rate=sr,
+                                                       amp_resample_method=method, dtype=np.float64)
     # (the carried phase goes through fp32 between calls: tests/test_gpu_parity.py allows 2e-3 over 40 calls)
     tol = 3e-4 * max(1.0, float(np.abs(ref).max()))
-    err = float(np.abs(npy(got) - ref).max())
-    assert err <= tol, ('streaming synthesis', err, tol)
-    dphi = np.abs(((npy(phase).astype(np.float64) - phase64 + np.pi) % (2 * np.pi)) - np.pi).max()
+    err_tf, err_x = float(np.abs(npy(got) - ref).max()), float(np.abs(npy(got) - ref_x).max())
+    err = min(err_tf, err_x)
+    assert err <= tol, ('streaming synthesis', err_tf, err_x, tol)
+    wrap = lambda d: np.abs(((d + np.pi) % (2 * np.pi)) - np.pi).max()
+    dphi = min(wrap(npy(phase).astype(np.float64) - phase64), wrap(npy(phase).astype(np.float64) - phase64x))
     assert dphi <= 2e-4, ('carried phase', float(dphi))
     worst = max(worst, err / tol)
-    phase = npy(phase); 
+    phase = npy(phase)
   return what, worst
 
 
