@@ -620,3 +620,30 @@ def test_the_subdifferential_check_of_the_loss_gradient_is_not_vacuous():
     assert not verdict(halved)
     assert not verdict(O.spectral_loss_backward(t, a, sizes[:-1], mw, lw))    # a scale forgotten
     assert float((env[1:] <= 0.05 * np.abs(ref).max()).mean()) >= 0.5 or n < 4 * size
+
+
+def test_exact_resize_positions_is_a_checker_switch_and_never_the_default():
+  """oracle.exact_resize_positions (round 6; tools/fuzz_parity.py's streaming family): inside the context the bilinear legacy resize
+  takes t n_in / n_out in exact arithmetic; outside - before, after, and after an exception inside - TF's fl32(t fl32(n_in / n_out)).
+  Frame sizes that are powers of two: the two agree to the last bit.  Frames of 252 samples: they differ, by no more than the
+  frame-to-frame step times pos 2^-23."""
+  rng = np.random.default_rng(5)
+  x = rng.uniform(60.0, 600.0, (2, 5, 1))
+  tf_256 = O.resample(x, 5 * 256, method='linear', dtype=np.float64)
+  tf_252 = O.resample(x, 5 * 252, method='linear', dtype=np.float64)
+  with O.exact_resize_positions():
+    ex_256 = O.resample(x, 5 * 256, method='linear', dtype=np.float64)
+    ex_252 = O.resample(x, 5 * 252, method='linear', dtype=np.float64)
+  np.testing.assert_array_equal(ex_256, tf_256)
+  d = np.abs(ex_252 - tf_252).max()
+  step = np.abs(np.diff(x, axis=1)).max()
+  assert 0.0 < d <= step * 5 * 2.0 ** -22
+  # exact positions against the definition: frame j + r / 252 of a linear ramp between frames
+  t = np.arange(5 * 252) / 252.0
+  j = np.minimum(np.floor(t).astype(int), 4); j1 = np.minimum(j + 1, 4)
+  want = x[:, j, 0] + (x[:, j1, 0] - x[:, j, 0]) * (t - j)[None]
+  np.testing.assert_allclose(ex_252[:, :, 0], want, rtol=0, atol=1e-10)
+  with pytest.raises(RuntimeError):
+    with O.exact_resize_positions():
+      raise RuntimeError('inside')
+  np.testing.assert_array_equal(O.resample(x, 5 * 252, method='linear', dtype=np.float64), tf_252)       # the default is back
