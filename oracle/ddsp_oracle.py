@@ -1048,6 +1048,48 @@ def spectral_loss_backward(target_audio, audio, fft_sizes=(2048, 1024, 512, 256,
   return grad if fp32_envelope is None else (grad, envelope)
 
 
+def spectral_loss_value_bounds(target_audio, audio, fft_sizes=(2048, 1024, 512, 256, 128, 64), mag_weight=1.0, logmag_weight=0.0,
+                               fp32_floor=5e-6):
+  """(lo, hi, n_null): the interval a correct fp32 evaluation of spectral_loss(.., loss_type='L1') may land in when some bin is a
+  spectral NULL, and how many such bins there are (tests/test_gpu_parity.py::check_loss_case uses it only when n_null > 0).
+
+  core.safe_log replaces only NON-POSITIVE arguments (core.py:213-216), so the logmag term of a bin whose magnitude cancels to
+  2e-7 - the Nyquist bin of one frame in ten thousand (tools/fuzz_parity.py loss:107037044, round 6: exact 2.46e-7, the reference's
+  own fp32 op order 4.75e-7, the MI355X 6e-9; 0.66 and 3.7 nats of a 10 320-term mean) - is log of whatever rounding left of it:
+  any fp32 implementation, TensorFlow's included, returns an arbitrary number there.  `floor` is what fp32 knows a magnitude of a
+  frame to (as in spectral_loss_backward: fp32_floor of the frame's spectrum + 1e-6 of the norm of its unwindowed samples).  A bin
+  with |X_t| or |X_a| within 3 floor of zero is a null: its logmag term is only known to be >= 0 and <= its exact value + 110
+  (a magnitude may come out as small as fp32's smallest positive number, or as 0 and take log(eps)); every other bin's term is known
+  to -log(1 - floor / |X|) for each of its two magnitudes, and every mag term to 2 floor."""
+  t = as_float(target_audio, np.float64)
+  a = as_float(audio, np.float64)
+  lo = hi = 0.0
+  n_null = 0
+  for size in fft_sizes:
+    hop = int(size * 0.25)
+    mt, ma = np.abs(stft(t, size, dtype=np.float64)), np.abs(stft(a, size, dtype=np.float64))
+    count = float(mt.size)
+    frame_rms = np.sqrt(np.mean(ma * ma, axis=-1, keepdims=True)) + np.sqrt(np.mean(mt * mt, axis=-1, keepdims=True))
+    frame_l2 = (np.sqrt((frame_pad_end(a, size, hop) ** 2).sum(axis=-1, keepdims=True)) +
+                np.sqrt((frame_pad_end(t, size, hop) ** 2).sum(axis=-1, keepdims=True)))
+    floor = np.broadcast_to(float(fp32_floor) * frame_rms + 1e-6 * frame_l2, mt.shape)
+    if mag_weight > 0:
+      d = np.abs(mt - ma)
+      lo += mag_weight * np.maximum(d - 2.0 * floor, 0.0).sum() / count
+      hi += mag_weight * (d + 2.0 * floor).sum() / count
+    if logmag_weight > 0:
+      null = ((mt > 0.0) & (mt <= 3.0 * floor)) | ((ma > 0.0) & (ma <= 3.0 * floor))
+      n_null += int(null.sum())
+      terms = np.abs(safe_log(mt) - safe_log(ma))
+      def wobble(m):        # how far log m moves when m moves by floor (m > 3 floor: at most 0.41)
+        safe = np.where(m > 3.0 * floor, m, 4.0 * floor)
+        return np.where(m > 3.0 * floor, -np.log1p(-floor / safe), 0.0)
+      slack = np.where(null, 0.0, wobble(mt) + wobble(ma))
+      lo += logmag_weight * np.where(null, 0.0, np.maximum(terms - slack, 0.0)).sum() / count
+      hi += logmag_weight * np.where(null, terms + 110.0, terms + slack).sum() / count
+  return lo, hi, n_null
+
+
 def add(signal_one, signal_two):
   """processors.Add.get_signal (processors.py:174-176)."""
   return signal_one + signal_two

@@ -1673,8 +1673,19 @@ def check_loss_case(ddsp, case):
     ref_v32 = float(O.spectral_loss(t, a, sizes, mag_weight=mw, logmag_weight=lw, dtype=np.float32))
     vtol = max(1e-4, 3.0 * abs(ref_v32 - ref_v) / max(abs(ref_v), 1e-12))
   ev = abs(float(val.detach()) - ref_v) / max(abs(ref_v), 1e-12)
-  assert ev <= vtol, ('loss value', float(val.detach()), ref_v, vtol)
-  assert abs(float(loss(t, a)) - ref_v) <= vtol * abs(ref_v), ('loss value, forward kernel', float(loss(t, a)), ref_v, vtol)
+  fwd = float(loss(t, a))                                           # (the forward-only kernel)
+  if ev > vtol or abs(fwd - ref_v) > vtol * abs(ref_v):
+    # A spectral NULL: core.safe_log passes any positive magnitude, and the log of a bin that cancels to 2e-7 is the log of what
+    # rounding left of it - in TensorFlow's fp32 as in any (fuzz seed loss:107037044, round 6: the Nyquist bin of one frame of 256
+    # samples, exact 2.46e-7, the reference's own op order 4.75e-7, the MI355X 6e-9: 1.56e-4 of the loss).  Only then: the value is
+    # held to the interval oracle.spectral_loss_value_bounds derives - every other bin to what fp32 knows its magnitudes to, the
+    # null bins' terms to "not negative, and not 110 nats above exact".  tests/test_oracle.py: without a null the interval is the
+    # value +- 2.5e-4 of it, and a null opens it upwards only.
+    lo, hi, n_null = O.spectral_loss_value_bounds(t, a, sizes, mw, lw)
+    assert n_null > 0, ('loss value', float(val.detach()), fwd, ref_v, vtol)
+    for v in (float(val.detach()), fwd):
+      assert lo - vtol * abs(ref_v) <= v <= hi + vtol * abs(ref_v), ('loss value with %d null bin(s)' % n_null, v, lo, hi, ref_v)
+    ev = min(ev, vtol)
   if n < 256:
     return ev / vtol
   ref, env = O.spectral_loss_backward(t, a, sizes, mw, lw, fp32_envelope=5e-6)
@@ -1697,7 +1708,8 @@ def check_loss_case(ddsp, case):
 @pytest.mark.parametrize('seed', [37014845,                                  # round 5's last campaign: a gradient bulk at n = 1025
                                   31000384, 31003046, 31012330,             # seed 31: values of 17-sample clips under 4096 / 6144 points
                                   4007713, 4032057, 4014585, 4029689,        # seed 4: two gradient bulks, two more 17-sample clips
-                                  47050735])                                 # round 6, seed 47: the mag term's phasor at a DC bin that cancels to 2.5e-8
+                                  47050735,                                  # round 6, seed 47: the mag term's phasor at a DC bin that cancels to 2.5e-8
+                                  107037044])                                # round 6, seed 107: the logmag VALUE with a Nyquist bin that cancels to 2.5e-7
 def test_spectral_loss_seeds_the_round_5_campaigns_ended_on(ddsp, seed):
   case = draw_loss_case(np.random.default_rng(seed))
   assert check_loss_case(ddsp, case) <= 1.0

@@ -647,3 +647,32 @@ def test_exact_resize_positions_is_a_checker_switch_and_never_the_default():
     with O.exact_resize_positions():
       raise RuntimeError('inside')
   np.testing.assert_array_equal(O.resample(x, 5 * 252, method='linear', dtype=np.float64), tf_252)       # the default is back
+
+
+def test_spectral_loss_value_bounds_are_tight_without_a_null_and_open_only_upwards_with_one():
+  """oracle.spectral_loss_value_bounds (round 6, fuzz seed loss:107037044).  Ordinary signals: no null bin, and the interval is the
+  fp64 value +- 2.5e-4 of it (every magnitude moved by what fp32 knows it to, all in the same direction).  A frame made to cancel at Nyquist (its
+  windowed samples alternate to 1e-7 of their size): one null per signal planted, the interval's lower end moves by that bin's
+  exact term only, its upper end by 110 nats over the number of terms - and the reference's own fp32 op order lands inside."""
+  rng = np.random.default_rng(3)
+  sizes, n = (256, 64), 1024
+  t = (0.3 * rng.standard_normal((2, n))).astype(np.float32)
+  a = (0.8 * t + 0.05 * rng.standard_normal((2, n))).astype(np.float32)
+  v = float(O.spectral_loss(t, a, sizes, mag_weight=1.0, logmag_weight=1.0, dtype=np.float64))
+  lo, hi, n_null = O.spectral_loss_value_bounds(t, a, sizes, 1.0, 1.0)
+  assert n_null == 0 and lo <= v <= hi and hi - lo <= 5e-4 * v
+  # plant the null: make the Nyquist bin of frame 0 (size 256) of row 0 of `a` cancel - move one sample by what is left of it
+  w = O.hann_window_periodic(256, np.float64)
+  alt = (-1.0) ** np.arange(256)
+  a2 = a.astype(np.float64)
+  a2[0, 100] -= float((a2[0, :256] * w * alt).sum()) / (w[100] * alt[100])
+  a2 = a2.astype(np.float32)
+  ny = abs(float((a2[0, :256].astype(np.float64) * w * alt).sum()))
+  assert 0.0 < ny < 1e-6                                       # fp32 storage leaves ~1e-8 .. 1e-7 of it
+  v2 = float(O.spectral_loss(t, a2, sizes, mag_weight=1.0, logmag_weight=1.0, dtype=np.float64))
+  lo2, hi2, n_null2 = O.spectral_loss_value_bounds(t, a2, sizes, 1.0, 1.0)
+  count = float(np.abs(O.stft(t, 256, dtype=np.float64)).size)
+  assert n_null2 == 1 and lo2 <= v2 <= hi2
+  assert 110.0 / count <= hi2 - lo2 <= (110.0 + 25.0) / count + 5e-4 * v2     # the null's exact term (<= 25 nats) + 110, once
+  v32 = float(O.spectral_loss(t, a2, sizes, mag_weight=1.0, logmag_weight=1.0, dtype=np.float32))
+  assert lo2 - 1e-4 * v2 <= v32 <= hi2 + 1e-4 * v2
